@@ -1,0 +1,186 @@
+"""Pin the CPU oracle (oracle/dic_oracle.py) to golden vectors captured from the
+imported reference (oracle/make_golden.py).  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dic_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def T(a, dtype=torch.float32, grad=False):
+    return torch.tensor(a, dtype=dtype, requires_grad=grad)
+
+
+INTERP = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'interp_*.npz')))
+RBF = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'rbf_*.npz')))
+DEC = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'dec_K*.npz')))
+
+
+def test_fixture_inventory():
+    assert len(INTERP) == 5 and len(RBF) == 4 and len(DEC) == 5
+
+
+@pytest.mark.parametrize('name', INTERP)
+def test_sci_cci_forward_matches_reference(name):
+    g = load(name)
+    R, H = int(g['R']), float(g['H'])
+    s = O.sci_forward(T(g['x']), T(g['sci_kernel']), R, H)
+    o = O.cci_forward(s, T(g['cci_kernel']))
+    np.testing.assert_allclose(s.numpy(), g['sci_out'], rtol=2e-5, atol=2e-5, equal_nan=True)
+    np.testing.assert_allclose(o.numpy(), g['cci_out'], rtol=2e-5, atol=2e-5, equal_nan=True)
+    if 'edge' in name:   # the n=0 channel poisons its whole encounter after cci, exactly as upstream
+        C = g['cci_kernel'].shape[0]
+        for arr in (g['cci_out'], o.numpy()):
+            assert np.isnan(arr[3][:, :C]).all() and np.isnan(arr[3][:, 2 * C:]).all()
+            assert np.isfinite(arr[3][:, C:2 * C]).all() and (arr[3][:, C] == 0).all()   # intensity exp(-inf) = 0
+            assert not np.isnan(arr[[0, 1, 2, 4]]).any()
+
+
+@pytest.mark.parametrize('name', [n for n in INTERP if 'edge' not in n])
+def test_sci_cci_grads_match_reference(name):
+    g = load(name)
+    R, H = int(g['R']), float(g['H'])
+    ks, kc = T(g['sci_kernel'], grad=True), T(g['cci_kernel'], grad=True)
+    (O.sci_cci_forward(T(g['x']), ks, kc, R, H) * T(g['cot'])).sum().backward()
+    scale = np.abs(g['g_sci']).max()
+    np.testing.assert_allclose(ks.grad.numpy(), g['g_sci'], rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(kc.grad.numpy(), g['g_cci'], rtol=1e-4, atol=1e-4 * np.abs(g['g_cci']).max())
+    # closed form (what the HIP backward implements) in fp64 against fp64 autograd
+    ks64, kc64 = T(g['sci_kernel'], torch.float64, True), T(g['cci_kernel'], torch.float64, True)
+    x64, cot64 = T(g['x'], torch.float64), T(g['cot'], torch.float64)
+    (O.sci_cci_forward(x64, ks64, kc64, R, H) * cot64).sum().backward()
+    cs, cc = O.sci_cci_backward(x64, ks64.detach(), kc64.detach(), R, H, cot64)
+    np.testing.assert_allclose(cs.numpy(), ks64.grad.numpy(), rtol=1e-9, atol=1e-9 * scale)
+    np.testing.assert_allclose(cc.numpy(), kc64.grad.numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(cs.numpy(), g['g_sci'], rtol=2e-4, atol=2e-4 * scale)
+
+
+@pytest.mark.parametrize('name', RBF)
+def test_rbf_matches_reference(name):
+    g = load(name)
+    R, H = int(g['R']), float(g['H'])
+    C = g['kernel'].shape[0]
+    x = T(g['x'])
+    v, k = T(g['v'], grad=True), T(g['kernel'], grad=True)
+    y = O.rbf_deinterp(v, x, k, R, H)
+    np.testing.assert_allclose(y.detach().numpy(), g['y'], rtol=2e-5, atol=2e-6)
+    mask = x[:, C:2 * C]
+    loss = O.rec_loss(T(g['ob']), y, mask)
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(v.grad.numpy(), g['g_v'], rtol=1e-4, atol=1e-6 * np.abs(g['g_v']).max() + 1e-9)
+    np.testing.assert_allclose(k.grad.numpy(), g['g_kernel'], rtol=2e-4, atol=2e-5 * np.abs(g['g_kernel']).max())
+    # closed form in fp64
+    v64, k64, x64 = T(g['v'], torch.float64, True), T(g['kernel'], torch.float64, True), T(g['x'], torch.float64)
+    y64 = O.rbf_deinterp(v64, x64, k64, R, H)
+    cot = torch.randn(y64.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    (y64 * cot).sum().backward()
+    gv, gk = O.rbf_backward(v64.detach(), x64, k64.detach(), R, H, cot)
+    np.testing.assert_allclose(gv.numpy(), v64.grad.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gk.numpy(), k64.grad.numpy(), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', DEC)
+def test_dec_matches_reference(name):
+    g = load(name)
+    z, mu = T(g['z'], grad=True), T(g['mu'], grad=True)
+    q = O.dec_soft_assign(z, mu, 1.0)
+    p = O.dec_target(q).detach()
+    np.testing.assert_allclose(q.detach().numpy(), g['q'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(p.numpy(), g['p'], rtol=1e-5, atol=1e-7)
+    kl = O.kl_loss(p, q)
+    np.testing.assert_allclose(float(kl), float(g['kl']), rtol=1e-5)
+    kl.backward()
+    np.testing.assert_allclose(z.grad.numpy(), g['g_z'], rtol=1e-4, atol=1e-6 * np.abs(g['g_z']).max())
+    np.testing.assert_allclose(mu.grad.numpy(), g['g_mu'], rtol=1e-4, atol=1e-5 * np.abs(g['g_mu']).max())
+    # closed form, general alpha, fp64
+    for alpha in (1.0, 2.5):
+        z64, m64 = T(g['z'], torch.float64, True), T(g['mu'], torch.float64, True)
+        q64 = O.dec_soft_assign(z64, m64, alpha)
+        cot = torch.randn(q64.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+        (q64 * cot).sum().backward()
+        gz, gc = O.dec_backward(z64.detach(), m64.detach(), cot, alpha)
+        np.testing.assert_allclose(gz.numpy(), z64.grad.numpy(), rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(gc.numpy(), m64.grad.numpy(), rtol=1e-9, atol=1e-13)
+
+
+def _load_sd0(name):
+    plain = load('netstep_plain.npz')
+    sd = {k[4:]: v for k, v in plain.items() if k.startswith('sd0/')}
+    g = plain
+    if name == 'fake':
+        g = load('netstep_fake.npz')
+        sd.update({k[4:]: v for k, v in g.items() if k.startswith('sd0/')})
+        sd = {k: v for k, v in sd.items()}
+    return g, sd
+
+
+@pytest.mark.parametrize('name', ['plain', 'fake'])
+def test_net_step_matches_reference(name):
+    g, sd0 = _load_sd0(name)
+    fake = name == 'fake'
+    net = O.OracleNet(6, int(g['R']), float(g['H']), int(g['K']), 0.0, fake_detection=fake)
+    missing = net.load_state_dict({k: torch.tensor(v) for k, v in sd0.items()}, strict=True)
+    net.train()
+    opt = O.make_optimizer(net)
+    x = T(g['x'])
+    C = 6
+    kw = {}
+    if fake:
+        kw = dict(fake_x=T(g['fake_x']), fake_perm_idx=torch.tensor(g['fake_perm_idx']),
+                  fake_label=torch.tensor(g['fake_label']))
+    opt.zero_grad()
+    terms, z, y, aux = O.joint_loss(net, x, T(g['ob']), x[:, C:2 * C], 10.0, **kw)
+    for k in ('loss', 'ae_mse', 'kl'):
+        # kl is ~1e-4 here (Xavier centroids => p ~= q): a sum of cancelling p*log(p/q) terms of size
+        # ~1e-2, so its fp32 conditioning allows ~1e-8 absolute; the 1e-5 relative bar applies to the losses
+        np.testing.assert_allclose(float(terms[k]), float(g['loss_' + k]), rtol=1e-5,
+                                   atol=5e-8 if k == 'kl' else 0, err_msg=k)
+    if fake:
+        np.testing.assert_allclose(float(terms['fake_detection']), float(g['loss_fake_detection']), rtol=1e-5)
+    np.testing.assert_allclose(z.detach().numpy(), g['z'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(y.detach().numpy(), g['y'], rtol=1e-4, atol=1e-5)
+    terms['loss'].backward()
+    gnorm = torch.nn.utils.clip_grad_norm_(net.parameters(), 15.0)
+    np.testing.assert_allclose(float(gnorm), float(g['gnorm']), rtol=1e-4)
+    for k, p in net.named_parameters():
+        if 'g/' + k in g:
+            ref = g['g/' + k]
+            np.testing.assert_allclose(p.grad.numpy() * 1.0, ref * min(1.0, 15.0 / (float(g['gnorm']) + 1e-6)),
+                                       rtol=2e-3, atol=2e-5 * np.abs(ref).max() + 2e-6 * float(g['gnorm']), err_msg=k)
+            # (a bias feeding BatchNorm has an exactly-zero true gradient: only rounding noise is left,
+            #  hence the absolute floor relative to the global gradient norm)
+    opt.step()
+    for k, v in net.state_dict().items():
+        if 'sd1/' + k in g:
+            got, ref = v.numpy(), g['sd1/' + k]
+            if 'g/' + k in g:
+                # Adam's first update is lr*g/(|g|+1e-8): chaotic where the true gradient is ~0 (see above)
+                live = np.abs(g['g/' + k]) >= 1e-4 * float(g['gnorm'])
+                got, ref = got[live], ref[live]
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5, err_msg=k)
+        elif 'sd1n/' + k in g:
+            np.testing.assert_allclose(np.linalg.norm(v.numpy().astype(np.float64)), float(g['sd1n/' + k]), rtol=1e-5)
+            np.testing.assert_allclose(v.numpy().reshape(-1)[:64], g['sd1h/' + k], rtol=1e-3, atol=1e-5)
+
+
+def test_kmeans_fixture_matches_installed_sklearn():
+    """k4's oracle is scikit-learn itself (third-party; version recorded in the fixture)."""
+    from sklearn.cluster import KMeans
+    from oracle.synth import latent_blobs
+    for K in (4, 16):
+        g = load(f'kmeans_K{K}.npz')
+        X, _ = latent_blobs(int(g['seed']), int(g['N']), int(g['D']), K)
+        km = KMeans(n_clusters=K, init=X[g['init_idx']].copy(), n_init=1).fit(X)
+        assert (km.labels_ == g['labels']).all()
+        np.testing.assert_allclose(km.cluster_centers_, g['centers'], rtol=1e-5, atol=1e-6)
+        assert km.n_iter_ == int(g['n_iter'])
