@@ -1,0 +1,126 @@
+"""ctypes binding of the C ABI in ``include/dic_hip.h`` (``libdic_hip.so``).
+
+This is the *only* compute back end of the package: there is no eager/PyTorch fallback for the
+hot-path operators.  If the shared object is missing, or a call returns a non-zero status, a
+``RuntimeError`` is raised (C status codes -> Python exceptions).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdic_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dic_hip.h')
+CSRC_DIR = os.path.join(_HERE, 'csrc')
+
+KM_STATUS_WORDS = 8
+MAX_CHANNELS, MAX_REFPOINTS, MAX_CLUSTERS, LATENT_MAX_DIM = 16, 64, 32, 256
+
+_lib = None
+_lock = threading.Lock()
+
+_p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+# name -> (restype, argtypes); must list every symbol declared in include/dic_hip.h
+SIGNATURES = {
+    'dic_version': (_i, []),
+    'dic_status_string': (C.c_char_p, [_i]),
+    'dic_last_error_string': (C.c_char_p, []),
+    'dic_sci_cci_fwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'dic_sci_cci_fwd_ragged': (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'dic_sci_cci_bwd_workspace': (_sz, [_i, _i, _i]),
+    'dic_sci_cci_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    'dic_cci_fwd': (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    'dic_cci_bwd_workspace': (_sz, [_i, _i, _i]),
+    'dic_cci_bwd': (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    'dic_rbf_fwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'dic_rbf_bwd_workspace': (_sz, [_i, _i, _i, _i]),
+    'dic_rbf_bwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'dic_masked_sse_workspace': (_sz, [_i, _i, _i]),
+    'dic_masked_sse_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p]),
+    'dic_masked_sse_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    'dic_dec_fwd_workspace': (_sz, [_i, _i, _i]),
+    'dic_dec_fwd': (_i, [_p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),
+    'dic_dec_target': (_i, [_p, _p, _i, _i, _p, _p]),
+    'dic_dec_bwd_workspace': (_sz, [_i, _i, _i]),
+    'dic_dec_bwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _sz, _p]),
+    'dic_dec_kl_workspace': (_sz, [_i, _i]),
+    'dic_dec_kl': (_i, [_p, _p, _i, _i, _f, _f, _p, _p, _p, _sz, _p]),
+    'dic_kmeans_workspace': (_sz, [_i, _i, _i, _i]),
+    'dic_kmeans_lloyd_iter': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    'dic_kmeans_predict': (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    'dic_kmeans_pp_workspace': (_sz, [_i, _i]),
+    'dic_kmeans_pp_candidates': (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _sz, _p]),
+}
+
+
+def header_symbols():
+    """Every ``dic_*`` function declared in include/dic_hip.h (used by the ABI test)."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(dic_[a-z0-9_]+)\s*\(', text)))
+
+
+def build(verbose=False):
+    """Compile libdic_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    res = subprocess.run(['make', '-C', CSRC_DIR, '-j4'], capture_output=True, text=True)
+    if verbose or res.returncode:
+        print(res.stdout[-4000:], res.stderr[-4000:])
+    if res.returncode:
+        raise RuntimeError('building libdic_hip.so failed')
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Fails loudly if the extension is missing."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f'{LIB_PATH} is missing: the HIP extension is the only implementation of the hot path. '
+                        'Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                        'or `make -C deep_interpolation_clustering_amd/csrc`.')
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        L = lib()
+        raise RuntimeError(f'{what} failed: {L.dic_status_string(status).decode()} '
+                           f'({L.dic_last_error_string().decode()})')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    """hipStream_t of torch's current stream on the tensor's device."""
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('deep_interpolation_clustering_amd: hot-path operators run only on an MI355X '
+                               f'(got a {t.device} tensor); there is no CPU fallback by design')
+
+
+def f32c(t):
+    """float32 + contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,64 @@
+// Shared host/device helpers for the gfx950 kernels of the DIC hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dic_hip.h"
+
+namespace dic {
+
+constexpr int kWave = 64;            // CDNA4 wavefront
+constexpr int kBlock = 256;          // default workgroup: 4 waves, one per SIMD
+constexpr int kNumCU = 256;          // MI355X
+constexpr float kLog2e = 1.4426950408889634f;
+
+// host side ---------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define DIC_REQUIRE(cond, code, ...)                \
+    do {                                            \
+        if (!(cond)) {                              \
+            ::dic::set_error(__VA_ARGS__);          \
+            return (code);                          \
+        }                                           \
+    } while (0)
+
+// device side -------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// 2^x on the transcendental unit (v_exp_f32).  Callers pass x <= 0 (max-subtracted logits),
+// so the missing denormal handling only flushes weights below 2^-126 to zero.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// log(1 + e^k): the positive bandwidth upstream derives from its raw `kernel` parameter
+// (interpolation_layer.py:51, rbf.py:78).
+__device__ __forceinline__ float softplus_raw(float k) { return logf(1.0f + expf(k)); }
+__device__ __forceinline__ float sigmoidf(float k) { return 1.0f / (1.0f + expf(-k)); }
+
+// XCD-aware block remap (8 XCDs, round-robin dispatch): consecutive logical tiles land on the
+// same XCD so neighbouring rows share that XCD's L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+}  // namespace dic

@@ -1,0 +1,594 @@
+// k1 / k1': single-channel RBF interpolation onto the reference grid with the cross-channel
+// mixing fused as its epilogue, forward and parameter backward.
+//
+// Replaces SingleChannelInterp.forward (interpolation_layer.py:31-86) and
+// CrossChannelInterp.forward (interpolation_layer.py:99-127); math per SURVEY.md Appendix A.
+//
+// Work decomposition (MI355X): one 256-thread workgroup owns E whole encounters.
+//   1. the (time,value) pairs of its E*C rows are staged ONCE from HBM into LDS with
+//      coalesced, mutually independent loads (prefix rows: only the valid slots are read);
+//   2. work items (encounter, channel, grid point[, split]) are spread over the threads; each
+//      item streams its row from LDS (same-row lanes hit the same address = LDS broadcast) in two
+//      passes: min_t u (the soft-max shift, shared by the alpha and 10*alpha smoothers) and one
+//      fused accumulation of both smoothers plus the E[u], E[xu] moments the backward needs;
+//   3. results stay in LDS for the cross-channel epilogue (channel soft-max, per-encounter
+//      mean over the grid, CxC mix), so the (B,R,3C) SCI tensor never round-trips through HBM.
+// Per (c,t,r) triple the inner loop issues 2 v_exp_f32 + ~15 VALU ops: at ~50 observations per
+// channel the kernel sits on the fp32-VALU/HBM ridge.
+#include "dic_common.h"
+
+namespace dic {
+
+struct InterpLayout {   // LDS carve-up, identical on host and device
+    int cnt, alpha, refg, kmat, res, mean, lse, amat, obs;   // offsets in 4-byte words
+    int total_words;
+};
+
+__host__ __device__ inline InterpLayout interp_layout(int E, int C, int R, int Tcap) {
+    InterpLayout L;
+    int o = 0;
+    L.cnt = o;   o += E * C;
+    L.alpha = o; o += C;
+    L.refg = o;  o += R;
+    L.kmat = o;  o += C * C;
+    L.res = o;   o += E * 3 * C * R;
+    L.mean = o;  o += E * C;
+    L.lse = o;   o += E * R;
+    L.amat = o;  o += E * R * C;
+    o = (o + 1) & ~1;            // float2 alignment
+    L.obs = o;   o += 2 * E * C * Tcap;
+    L.total_words = o;
+    return L;
+}
+
+struct InterpArgs {
+    const float* x; const int32_t* lengths; int T;                   // dense stacked input
+    const float* t_pk; const float* v_pk; const int64_t* row_off;     // packed ragged input
+    int B, C, R, Tcap, E, S, logS;
+    const float* ref_grid; const float* sci_kernel; const float* cci_kernel;
+    float* out; float* saved;
+};
+
+constexpr float kMaskedTime = 1e18f;   // u = 1e36 stays finite in f32; its soft-max weight is exactly 0
+constexpr float kEmptyU = 1e35f;
+
+// Cross-channel epilogue on LDS-resident y,w,y_trans (res[e][3][C][R]) -> out (B,R,3C).
+__device__ void cci_epilogue(const float* res, const float* kmat, float* mean, float* lse, float* amat,
+                             int Ev, int C, int R, int e0, float* out) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < Ev * C; i += kBlock) {          // mean over the grid, per (e,c)
+        const float* y = res + ((i / C) * 3 * C + (i % C)) * R;
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += y[r];
+        mean[i] = s / (float)R;
+    }
+    for (int i = tid; i < Ev * R; i += kBlock) {          // log-sum-exp over channels, per (e,r)
+        const int e = i / R, r = i % R;
+        const float* w = res + (e * 3 * C + C) * R + r;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, w[c * R]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(w[c * R] - mx);
+        lse[i] = (mx == -INFINITY) ? -INFINITY : mx + logf(s);
+    }
+    __syncthreads();
+    for (int i = tid; i < Ev * R * C; i += kBlock) {      // a = softmax_c(w) * (y - mean)
+        const int e = i / (R * C), rc = i % (R * C), r = rc / C, c = rc % C;
+        const float* base = res + e * 3 * C * R;
+        const float y = base[c * R + r], w = base[(C + c) * R + r];
+        amat[i] = expf(w - lse[e * R + r]) * (y - mean[e * C + c]);
+    }
+    __syncthreads();
+    for (int i = tid; i < Ev * R * C; i += kBlock) {      // smooth = a @ K + mean
+        const int e = i / (R * C), rc = i % (R * C), r = rc / C, j = rc % C;
+        const float* base = res + e * 3 * C * R;
+        const float* arow = amat + (e * R + r) * C;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(arow[c], kmat[c * C + j], s);
+        s += mean[e * C + j];
+        float* o = out + ((size_t)(e0 + e) * R + r) * 3 * C;
+        o[j] = s;
+        o[C + j] = expf(base[(C + j) * R + r]);
+        o[2 * C + j] = base[(2 * C + j) * R + r] - s;
+    }
+}
+
+template <bool RAGGED>
+__global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    const int C = a.C, R = a.R, E = a.E, Tcap = a.Tcap;
+    const InterpLayout L = interp_layout(E, C, R, Tcap);
+    int* cnt = reinterpret_cast<int*>(smem + L.cnt);
+    float* alpha = smem + L.alpha;
+    float* refg = smem + L.refg;
+    float* kmat = smem + L.kmat;
+    float* res = smem + L.res;
+    float2* obs = reinterpret_cast<float2*>(smem + L.obs);
+
+    const int tid = threadIdx.x;
+    const int e0 = blockIdx.x * E;
+    const int Ev = min(E, a.B - e0);
+    const int nrows = Ev * C;
+
+    // ---- 1. row lengths + parameters
+    for (int i = tid; i < nrows; i += kBlock) {
+        const size_t g = (size_t)e0 * C + i;
+        int n;
+        if (RAGGED) n = (int)(a.row_off[g + 1] - a.row_off[g]);
+        else n = a.lengths ? a.lengths[g] : a.T;
+        cnt[i] = max(0, min(n, Tcap));
+    }
+    for (int i = tid; i < C; i += kBlock) alpha[i] = softplus_raw(a.sci_kernel[i]);
+    for (int i = tid; i < R; i += kBlock) refg[i] = a.ref_grid[i];
+    if (a.cci_kernel)
+        for (int i = tid; i < C * C; i += kBlock) kmat[i] = a.cci_kernel[i];
+    __syncthreads();
+
+    // ---- 2. stage (time,value) rows into LDS: one wave per 64-slot chunk of a row
+    {
+        const int nchunk = (Tcap + kWave - 1) / kWave;
+        const int units = nrows * nchunk;
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll 2
+        for (int u = wave; u < units; u += kBlock / kWave) {
+            const int row = u / nchunk;
+            const int i = (u - row * nchunk) * kWave + lane;
+            if (i < cnt[row]) {
+                float t, v;
+                if (RAGGED) {
+                    const int64_t off = a.row_off[(size_t)e0 * C + row] + i;
+                    t = a.t_pk[off];
+                    v = a.v_pk[off];
+                } else {
+                    const int e = row / C, c = row - e * C;
+                    const float* base = a.x + (size_t)(e0 + e) * 4 * C * a.T;
+                    t = base[(size_t)(2 * C + c) * a.T + i];
+                    v = base[(size_t)c * a.T + i];
+                    if (!a.lengths && base[(size_t)(C + c) * a.T + i] == 0.f) { t = kMaskedTime; v = 0.f; }
+                }
+                obs[row * Tcap + i] = make_float2(t, v);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. items (row, grid point, split): two passes over the LDS row
+    const int S = a.S, logS = a.logS;
+    const int nitems = nrows * R * S;
+    for (int item = tid; item < nitems; item += kBlock) {
+        const int s = item & (S - 1);
+        const int q = item >> logS;
+        const int row = q / R, r = q - row * R;
+        const int e = row / C, c = row - e * C;
+        const int n = cnt[row];
+        const float2* p = obs + row * Tcap;
+        const float ref = refg[r];
+        const float al = alpha[c];
+
+        float umin = INFINITY;
+        for (int i = s; i < n; i += S) {
+            const float d = p[i].x - ref;
+            umin = fminf(umin, d * d);
+        }
+        for (int m = 1; m < S; m <<= 1) umin = fminf(umin, __shfl_xor(umin, m));
+
+        const float na1 = -al * kLog2e, na10 = -10.0f * al * kLog2e;
+        float s1 = 0.f, sx1 = 0.f, su1 = 0.f, sxu1 = 0.f;
+        float s10 = 0.f, sx10 = 0.f, su10 = 0.f, sxu10 = 0.f;
+        for (int i = s; i < n; i += S) {
+            const float2 tv = p[i];
+            const float d = tv.x - ref;
+            const float u = d * d;
+            const float du = u - umin;
+            const float e1 = fast_exp2(na1 * du);
+            const float e10 = fast_exp2(na10 * du);
+            const float eu1 = e1 * u, eu10 = e10 * u;
+            s1 += e1;    sx1 = fmaf(e1, tv.y, sx1);    su1 += eu1;    sxu1 = fmaf(eu1, tv.y, sxu1);
+            s10 += e10;  sx10 = fmaf(e10, tv.y, sx10); su10 += eu10;  sxu10 = fmaf(eu10, tv.y, sxu10);
+        }
+        for (int m = 1; m < S; m <<= 1) {
+            s1 += __shfl_xor(s1, m);     sx1 += __shfl_xor(sx1, m);
+            su1 += __shfl_xor(su1, m);   sxu1 += __shfl_xor(sxu1, m);
+            s10 += __shfl_xor(s10, m);   sx10 += __shfl_xor(sx10, m);
+            su10 += __shfl_xor(su10, m); sxu10 += __shfl_xor(sxu10, m);
+        }
+        if (s == 0) {
+            float y, w, yt, eu1, exu1, eu10, exu10;
+            if (umin < kEmptyU) {
+                const float i1 = 1.0f / s1, i10 = 1.0f / s10;
+                y = sx1 * i1;  yt = sx10 * i10;
+                w = logf(s1) - al * umin;
+                eu1 = su1 * i1;  exu1 = sxu1 * i1;  eu10 = su10 * i10;  exu10 = sxu10 * i10;
+            } else {   // no observation on this channel: upstream yields exp(-inf+inf)=NaN and LSE=-inf
+                y = yt = eu1 = exu1 = eu10 = exu10 = NAN;
+                w = -INFINITY;
+            }
+            float* rr = res + e * 3 * C * R + c * R + r;
+            rr[0] = y;  rr[C * R] = w;  rr[2 * C * R] = yt;
+            if (a.saved) {
+                float* sv = a.saved + ((size_t)(e0 + e) * 7 * C + c) * R + r;
+                const size_t st = (size_t)C * R;
+                sv[0] = y; sv[st] = w; sv[2 * st] = yt;
+                sv[3 * st] = eu1; sv[4 * st] = exu1; sv[5 * st] = eu10; sv[6 * st] = exu10;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. epilogue
+    if (a.cci_kernel) {
+        cci_epilogue(res, kmat, smem + L.mean, smem + L.lse, smem + L.amat, Ev, C, R, e0, a.out);
+    } else {
+        for (int i = tid; i < Ev * R * C; i += kBlock) {
+            const int e = i / (R * C), rc = i % (R * C), r = rc / C, c = rc % C;
+            const float* base = res + e * 3 * C * R + c * R + r;
+            float* o = a.out + ((size_t)(e0 + e) * R + r) * 3 * C + c;
+            o[0] = base[0];  o[C] = base[C * R];  o[2 * C] = base[2 * C * R];
+        }
+    }
+}
+
+// Stand-alone CCI forward: load s (B,R,3C) into the LDS result layout, run the epilogue.
+__global__ __launch_bounds__(kBlock) void cci_fwd_kernel(const float* s, const float* cci_kernel, int B, int C,
+                                                        int R, int E, float* out) {
+    extern __shared__ __align__(16) float smem[];
+    const InterpLayout L = interp_layout(E, C, R, 0);
+    float* res = smem + L.res;
+    float* kmat = smem + L.kmat;
+    const int tid = threadIdx.x, e0 = blockIdx.x * E, Ev = min(E, B - e0);
+    for (int i = tid; i < C * C; i += kBlock) kmat[i] = cci_kernel[i];
+    for (int i = tid; i < Ev * R * 3 * C; i += kBlock) {
+        const int e = i / (R * 3 * C), rem = i % (R * 3 * C), r = rem / (3 * C), qc = rem % (3 * C);
+        res[(e * 3 * C + qc) * R + r] = s[(size_t)e0 * R * 3 * C + i];
+    }
+    __syncthreads();
+    cci_epilogue(res, kmat, smem + L.mean, smem + L.lse, smem + L.amat, Ev, C, R, e0, out);
+}
+
+// ------------------------------------------------------------------------------- backward
+struct BwdLayout {
+    int kmat, val, grad, mean, lse, what, amat, gs, ga, sgs, sgaw, gww, gout, part;
+    int total_words;
+};
+__host__ __device__ inline BwdLayout bwd_layout(int E, int C, int R) {
+    BwdLayout L;
+    int o = 0;
+    const int ecr = E * C * R;
+    L.kmat = o; o += C * C;
+    L.val = o;  o += 3 * ecr;      // y,w,yt   [e][3][C][R]
+    L.grad = o; o += 3 * ecr;      // g1,g2,g3 [e][3][C][R]
+    L.mean = o; o += E * C;
+    L.lse = o;  o += E * R;
+    L.what = o; o += ecr;          // [e][C][R]
+    L.amat = o; o += ecr;
+    L.gs = o;   o += ecr;
+    L.ga = o;   o += ecr;
+    L.sgs = o;  o += E * C;
+    L.sgaw = o; o += E * C;
+    L.gww = o;  o += E * R;        // sum_c g_what*w_hat
+    L.gout = o; o += 3 * ecr;      // gy,gw,gyt [e][3][C][R]
+    L.part = o; o += ecr;          // per-(e,c,r) alpha-gradient terms
+    L.total_words = o;
+    return L;
+}
+
+// Given LDS-resident val (y,w,yt) and grad (g1,g2,g3 of the CCI output), compute the CCI
+// backward: gout = (g_y, g_w, g_yt) and this block's contribution to dL/dK (returned per
+// thread for (i,j) = tid<C*C; accumulate across calls).
+__device__ float cci_backward_lds(float* sm, const BwdLayout& L, int Ev, int C, int R) {
+    const int tid = threadIdx.x;
+    const int CR = C * R;
+    float* val = sm + L.val; float* grd = sm + L.grad; float* kmat = sm + L.kmat;
+    float* mean = sm + L.mean; float* lse = sm + L.lse; float* what = sm + L.what; float* amat = sm + L.amat;
+    float* gs = sm + L.gs; float* ga = sm + L.ga; float* sgs = sm + L.sgs; float* sgaw = sm + L.sgaw;
+    float* gww = sm + L.gww; float* gout = sm + L.gout;
+
+    for (int i = tid; i < Ev * C; i += kBlock) {
+        const float* y = val + (i / C) * 3 * CR + (i % C) * R;
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += y[r];
+        mean[i] = s / (float)R;
+    }
+    for (int i = tid; i < Ev * R; i += kBlock) {
+        const int e = i / R, r = i % R;
+        const float* w = val + e * 3 * CR + CR + r;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, w[c * R]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(w[c * R] - mx);
+        lse[i] = (mx == -INFINITY) ? -INFINITY : mx + logf(s);
+    }
+    __syncthreads();
+    for (int i = tid; i < Ev * CR; i += kBlock) {
+        const int e = i / CR, cr = i % CR, c = cr / R, r = cr % R;
+        const float* v = val + e * 3 * CR;
+        const float* g = grd + e * 3 * CR;
+        const float wh = expf(v[CR + cr] - lse[e * R + r]);
+        what[i] = wh;
+        amat[i] = wh * (v[cr] - mean[e * C + c]);
+        gs[i] = g[cr] - g[2 * CR + cr];
+    }
+    __syncthreads();
+    // dL/dK[i][j] = sum_{e,r} a[e][i][r] * gs[e][j][r]
+    float gk = 0.f;
+    if (tid < C * C) {
+        const int i = tid / C, j = tid % C;
+        for (int e = 0; e < Ev; ++e) {
+            const float* ar = amat + e * CR + i * R;
+            const float* gr = gs + e * CR + j * R;
+            for (int r = 0; r < R; ++r) gk = fmaf(ar[r], gr[r], gk);
+        }
+    }
+    // ga[e][c][r] = sum_j gs[e][j][r] * K[c][j]
+    for (int i = tid; i < Ev * CR; i += kBlock) {
+        const int e = i / CR, cr = i % CR, c = cr / R, r = cr % R;
+        const float* g = gs + e * CR + r;
+        float s = 0.f;
+        for (int j = 0; j < C; ++j) s = fmaf(g[j * R], kmat[c * C + j], s);
+        ga[i] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < Ev * C; i += kBlock) {           // per (e,c): sums over r
+        const int e = i / C, c = i % C;
+        float a1 = 0.f, a2 = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const int k = e * CR + c * R + r;
+            a1 += gs[k];
+            a2 = fmaf(ga[k], what[k], a2);
+        }
+        sgs[i] = a1; sgaw[i] = a2;
+    }
+    for (int i = tid; i < Ev * R; i += kBlock) {           // per (e,r): sum_c g_what*w_hat
+        const int e = i / R, r = i % R;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const int k = e * CR + c * R + r;
+            const float gwh = ga[k] * (val[e * 3 * CR + c * R + r] - mean[e * C + c]);
+            s = fmaf(gwh, what[k], s);
+        }
+        gww[i] = s;
+    }
+    __syncthreads();
+    const float invR = 1.0f / (float)R;
+    for (int i = tid; i < Ev * CR; i += kBlock) {
+        const int e = i / CR, cr = i % CR, c = cr / R, r = cr % R;
+        const float* v = val + e * 3 * CR;
+        const float* g = grd + e * 3 * CR;
+        const float wh = what[i];
+        const float gwh = ga[i] * (v[cr] - mean[e * C + c]);
+        float* go = gout + e * 3 * CR;
+        go[cr] = ga[i] * wh + (sgs[e * C + c] - sgaw[e * C + c]) * invR;
+        go[CR + cr] = g[CR + cr] * expf(v[CR + cr]) + wh * (gwh - gww[e * R + r]);
+        go[2 * CR + cr] = g[2 * CR + cr];
+    }
+    __syncthreads();
+    return gk;
+}
+
+// Fused backward: grad_out (B,R,3C) + saved (B,7,C,R) -> per-block partials [C | C*C].
+__global__ __launch_bounds__(kBlock) void sci_cci_bwd_kernel(const float* grad_out, const float* saved,
+                                                            const float* cci_kernel, int B, int C, int R, int E,
+                                                            int nblk, float* partials) {
+    extern __shared__ __align__(16) float smem[];
+    const BwdLayout L = bwd_layout(E, C, R);
+    const int tid = threadIdx.x, CR = C * R;
+    float* val = smem + L.val; float* grd = smem + L.grad; float* gout = smem + L.gout; float* part = smem + L.part;
+    if (cci_kernel)
+        for (int i = tid; i < C * C; i += kBlock) smem[L.kmat + i] = cci_kernel[i];
+
+    float gk_acc = 0.f;        // thread (i,j) < C*C
+    float ga_acc = 0.f;        // thread c < C
+    for (int e0 = blockIdx.x * E; e0 < B; e0 += nblk * E) {     // grid-stride over encounter tiles
+        const int Ev = min(E, B - e0);
+        __syncthreads();
+        for (int i = tid; i < Ev * 3 * CR; i += kBlock) {       // saved planes 0..2 = y,w,yt
+            const int e = i / (3 * CR), rem = i % (3 * CR);
+            val[i] = saved[((size_t)(e0 + e) * 7) * CR + rem];
+        }
+        for (int i = tid; i < Ev * R * 3 * C; i += kBlock) {    // (B,R,3C) -> [e][3][C][R]
+            const int e = i / (R * 3 * C), rem = i % (R * 3 * C), r = rem / (3 * C), qc = rem % (3 * C);
+            grd[(e * 3 * C + qc) * R + r] = grad_out[(size_t)e0 * R * 3 * C + i];
+        }
+        __syncthreads();
+        const float* g3;   // (g_y, g_w, g_yt) source
+        if (cci_kernel) {
+            gk_acc += cci_backward_lds(smem, L, Ev, C, R);
+            g3 = gout;
+        } else {
+            g3 = grd;
+        }
+        // dL/dalpha terms per (e,c,r): -gw*Eu1 - gy*(Exu1 - y*Eu1) - 10*gyt*(Exu10 - yt*Eu10)
+        for (int i = tid; i < Ev * CR; i += kBlock) {
+            const int e = i / CR, cr = i % CR;
+            const float* sv = saved + ((size_t)(e0 + e) * 7) * CR + cr;
+            const float y = val[e * 3 * CR + cr], yt = val[e * 3 * CR + 2 * CR + cr];
+            const float eu1 = sv[3 * CR], exu1 = sv[4 * CR], eu10 = sv[5 * CR], exu10 = sv[6 * CR];
+            const float gy = g3[e * 3 * CR + cr], gw = g3[e * 3 * CR + CR + cr], gyt = g3[e * 3 * CR + 2 * CR + cr];
+            part[i] = -gw * eu1 - gy * (exu1 - y * eu1) - 10.0f * gyt * (exu10 - yt * eu10);
+        }
+        __syncthreads();
+        if (tid < C) {
+            float s = 0.f;
+            for (int e = 0; e < Ev; ++e)
+                for (int r = 0; r < R; ++r) s += part[e * CR + tid * R + r];
+            ga_acc += s;
+        }
+    }
+    float* o = partials + (size_t)blockIdx.x * (C + C * C);
+    if (tid < C) o[tid] = ga_acc;
+    if (tid < C * C) o[C + tid] = gk_acc;
+}
+
+// Stand-alone CCI backward: grad wrt s (B,R,3C) and per-block dL/dK partials.
+__global__ __launch_bounds__(kBlock) void cci_bwd_kernel(const float* grad_out, const float* s, const float* cci_kernel,
+                                                        int B, int C, int R, int E, int nblk, float* grad_s,
+                                                        float* partials) {
+    extern __shared__ __align__(16) float smem[];
+    const BwdLayout L = bwd_layout(E, C, R);
+    const int tid = threadIdx.x, CR = C * R;
+    float* val = smem + L.val; float* grd = smem + L.grad; float* gout = smem + L.gout;
+    for (int i = tid; i < C * C; i += kBlock) smem[L.kmat + i] = cci_kernel[i];
+    float gk_acc = 0.f;
+    for (int e0 = blockIdx.x * E; e0 < B; e0 += nblk * E) {
+        const int Ev = min(E, B - e0);
+        __syncthreads();
+        for (int i = tid; i < Ev * R * 3 * C; i += kBlock) {
+            const int e = i / (R * 3 * C), rem = i % (R * 3 * C), r = rem / (3 * C), qc = rem % (3 * C);
+            const size_t g = (size_t)e0 * R * 3 * C + i;
+            val[(e * 3 * C + qc) * R + r] = s[g];
+            grd[(e * 3 * C + qc) * R + r] = grad_out[g];
+        }
+        __syncthreads();
+        gk_acc += cci_backward_lds(smem, L, Ev, C, R);
+        for (int i = tid; i < Ev * R * 3 * C; i += kBlock) {
+            const int e = i / (R * 3 * C), rem = i % (R * 3 * C), r = rem / (3 * C), qc = rem % (3 * C);
+            grad_s[(size_t)e0 * R * 3 * C + i] = gout[(e * 3 * C + qc) * R + r];
+        }
+    }
+    if (tid < C * C) partials[(size_t)blockIdx.x * (C + C * C) + C + tid] = gk_acc;
+    if (tid < C) partials[(size_t)blockIdx.x * (C + C * C) + tid] = 0.f;
+}
+
+// Fixed-order reduction of the per-block partials (f64), sigmoid chain rule for the raw kernel.
+__global__ void interp_bwd_finalize(const float* partials, int nblk, int C, const float* sci_kernel,
+                                    float* grad_sci, float* grad_cci) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = C + C * C;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partials[(size_t)b * n + i];
+    if (i < C) {
+        if (grad_sci) grad_sci[i] = (float)(s * (double)sigmoidf(sci_kernel[i]));
+    } else if (grad_cci) {
+        grad_cci[i - C] = (float)s;
+    }
+}
+
+// ------------------------------------------------------------------------------- host side
+static int pick_tile(int B, int per_enc_words, int fixed_words, int budget_bytes, int cap) {
+    int E = (budget_bytes / 4 - fixed_words) / per_enc_words;
+    E = max(1, min(E, cap));
+    const int want = max(1, B / (8 * kNumCU));     // keep >= ~2048 workgroups in flight when B allows
+    return max(1, min(E, want));
+}
+
+static int interp_fwd_launch(InterpArgs a, bool ragged, hipStream_t st) {
+    DIC_REQUIRE(a.B > 0 && a.C > 0 && a.R > 0 && a.Tcap > 0, DIC_ERR_INVALID_ARG, "sci_cci_fwd: non-positive size");
+    DIC_REQUIRE(a.C <= DIC_MAX_CHANNELS && a.R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED,
+                "sci_cci_fwd: C=%d R=%d exceed limits (%d,%d)", a.C, a.R, DIC_MAX_CHANNELS, DIC_MAX_REFPOINTS);
+    DIC_REQUIRE(a.ref_grid && a.sci_kernel && a.out, DIC_ERR_INVALID_ARG, "sci_cci_fwd: NULL pointer");
+    const InterpLayout one = interp_layout(1, a.C, a.R, a.Tcap), two = interp_layout(2, a.C, a.R, a.Tcap);
+    const int per_enc = two.total_words - one.total_words;
+    const int fixed = one.total_words - per_enc;
+    DIC_REQUIRE((size_t)one.total_words * 4 <= 64 * 1024, DIC_ERR_UNSUPPORTED,
+                "sci_cci_fwd: one encounter needs %d B of LDS (C=%d T=%d R=%d)", one.total_words * 4, a.C, a.Tcap, a.R);
+    a.E = pick_tile(a.B, per_enc, fixed, 40 * 1024, 16);
+    int S = 1, logS = 0;
+    while (a.E * a.C * a.R * S < kBlock && S < 16) { S <<= 1; ++logS; }
+    a.S = S; a.logS = logS;
+    const InterpLayout L = interp_layout(a.E, a.C, a.R, a.Tcap);
+    const int grid = (a.B + a.E - 1) / a.E;
+    if (ragged) hipLaunchKernelGGL(sci_cci_fwd_kernel<true>, dim3(grid), dim3(kBlock), (size_t)L.total_words * 4, st, a);
+    else hipLaunchKernelGGL(sci_cci_fwd_kernel<false>, dim3(grid), dim3(kBlock), (size_t)L.total_words * 4, st, a);
+    return check_launch("sci_cci_fwd");
+}
+
+static void bwd_geometry(int B, int C, int R, int* E, int* nblk, size_t* lds) {
+    const BwdLayout one = bwd_layout(1, C, R), two = bwd_layout(2, C, R);
+    const int per_enc = two.total_words - one.total_words, fixed = one.total_words - per_enc;
+    *E = pick_tile(B, per_enc, fixed, 48 * 1024, 16);
+    *nblk = min((B + *E - 1) / *E, 4 * kNumCU);
+    *lds = (size_t)bwd_layout(*E, C, R).total_words * 4;
+}
+
+}  // namespace dic
+
+using namespace dic;
+
+extern "C" {
+
+int dic_sci_cci_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                    const float* sci_kernel, const float* cci_kernel, float* out, float* saved,
+                    dic_stream_t stream) {
+    DIC_REQUIRE(x, DIC_ERR_INVALID_ARG, "sci_cci_fwd: x is NULL");
+    InterpArgs a{};
+    a.x = x; a.lengths = lengths; a.T = T; a.B = B; a.C = C; a.R = R; a.Tcap = T;
+    a.ref_grid = ref_grid; a.sci_kernel = sci_kernel; a.cci_kernel = cci_kernel; a.out = out; a.saved = saved;
+    return interp_fwd_launch(a, false, (hipStream_t)stream);
+}
+
+int dic_sci_cci_fwd_ragged(const float* t_pk, const float* v_pk, const int64_t* row_off, int max_len, int B, int C,
+                           int R, const float* ref_grid, const float* sci_kernel, const float* cci_kernel,
+                           float* out, float* saved, dic_stream_t stream) {
+    DIC_REQUIRE(t_pk && v_pk && row_off, DIC_ERR_INVALID_ARG, "sci_cci_fwd_ragged: NULL input");
+    InterpArgs a{};
+    a.t_pk = t_pk; a.v_pk = v_pk; a.row_off = row_off; a.B = B; a.C = C; a.R = R; a.Tcap = max_len;
+    a.ref_grid = ref_grid; a.sci_kernel = sci_kernel; a.cci_kernel = cci_kernel; a.out = out; a.saved = saved;
+    return interp_fwd_launch(a, true, (hipStream_t)stream);
+}
+
+size_t dic_sci_cci_bwd_workspace(int B, int C, int R) {
+    if (B <= 0 || C <= 0 || R <= 0 || C > DIC_MAX_CHANNELS || R > DIC_MAX_REFPOINTS) return 0;
+    int E, nblk; size_t lds;
+    bwd_geometry(B, C, R, &E, &nblk, &lds);
+    return (size_t)nblk * (C + C * C) * sizeof(float);
+}
+
+int dic_sci_cci_bwd(const float* grad_out, const float* saved, const float* sci_kernel, const float* cci_kernel,
+                    int B, int C, int R, float* grad_sci_kernel, float* grad_cci_kernel, void* workspace,
+                    size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(B > 0 && C > 0 && R > 0, DIC_ERR_INVALID_ARG, "sci_cci_bwd: non-positive size");
+    DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "sci_cci_bwd: C=%d R=%d", C, R);
+    DIC_REQUIRE(grad_out && saved && sci_kernel && grad_sci_kernel && workspace, DIC_ERR_INVALID_ARG,
+                "sci_cci_bwd: NULL pointer");
+    DIC_REQUIRE(!cci_kernel || grad_cci_kernel, DIC_ERR_INVALID_ARG, "sci_cci_bwd: grad_cci_kernel is NULL");
+    int E, nblk; size_t lds;
+    bwd_geometry(B, C, R, &E, &nblk, &lds);
+    DIC_REQUIRE(lds <= 64 * 1024, DIC_ERR_UNSUPPORTED, "sci_cci_bwd: LDS %zu B", lds);
+    DIC_REQUIRE(workspace_bytes >= (size_t)nblk * (C + C * C) * sizeof(float), DIC_ERR_WORKSPACE,
+                "sci_cci_bwd: workspace %zu B too small", workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sci_cci_bwd_kernel, dim3(nblk), dim3(kBlock), lds, st, grad_out, saved, cci_kernel, B, C, R, E,
+                       nblk, (float*)workspace);
+    const int n = C + C * C;
+    hipLaunchKernelGGL(interp_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)workspace, nblk, C,
+                       sci_kernel, grad_sci_kernel, cci_kernel ? grad_cci_kernel : nullptr);
+    return check_launch("sci_cci_bwd");
+}
+
+int dic_cci_fwd(const float* s, const float* cci_kernel, int B, int C, int R, float* out, dic_stream_t stream) {
+    DIC_REQUIRE(B > 0 && C > 0 && R > 0, DIC_ERR_INVALID_ARG, "cci_fwd: non-positive size");
+    DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "cci_fwd: C=%d R=%d", C, R);
+    DIC_REQUIRE(s && cci_kernel && out, DIC_ERR_INVALID_ARG, "cci_fwd: NULL pointer");
+    const InterpLayout one = interp_layout(1, C, R, 0), two = interp_layout(2, C, R, 0);
+    const int per_enc = two.total_words - one.total_words;
+    const int E = pick_tile(B, per_enc, one.total_words - per_enc, 40 * 1024, 16);
+    const size_t lds = (size_t)interp_layout(E, C, R, 0).total_words * 4;
+    hipLaunchKernelGGL(cci_fwd_kernel, dim3((B + E - 1) / E), dim3(kBlock), lds, (hipStream_t)stream, s, cci_kernel, B,
+                       C, R, E, out);
+    return check_launch("cci_fwd");
+}
+
+size_t dic_cci_bwd_workspace(int B, int C, int R) { return dic_sci_cci_bwd_workspace(B, C, R); }
+
+int dic_cci_bwd(const float* grad_out, const float* s, const float* cci_kernel, int B, int C, int R, float* grad_s,
+                float* grad_cci_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(B > 0 && C > 0 && R > 0, DIC_ERR_INVALID_ARG, "cci_bwd: non-positive size");
+    DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "cci_bwd: C=%d R=%d", C, R);
+    DIC_REQUIRE(grad_out && s && cci_kernel && grad_s && grad_cci_kernel && workspace, DIC_ERR_INVALID_ARG,
+                "cci_bwd: NULL pointer");
+    int E, nblk; size_t lds;
+    bwd_geometry(B, C, R, &E, &nblk, &lds);
+    DIC_REQUIRE(lds <= 64 * 1024, DIC_ERR_UNSUPPORTED, "cci_bwd: LDS %zu B", lds);
+    DIC_REQUIRE(workspace_bytes >= (size_t)nblk * (C + C * C) * sizeof(float), DIC_ERR_WORKSPACE,
+                "cci_bwd: workspace %zu B too small", workspace_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cci_bwd_kernel, dim3(nblk), dim3(kBlock), lds, st, grad_out, s, cci_kernel, B, C, R, E, nblk,
+                       grad_s, (float*)workspace);
+    const int n = C + C * C;
+    hipLaunchKernelGGL(interp_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)workspace, nblk, C,
+                       (const float*)nullptr, (float*)nullptr, grad_cci_kernel);
+    return check_launch("cci_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,335 @@
+// k2: Gaussian RBF de-interpolation from the reference grid back to the observed time stamps,
+// its backward, and the masked reconstruction loss.
+//
+// Replaces RBF.forward minus compress_fc (rbf.py:57-108, gaussian rbf.py:129-131) and
+// Net.rec_loss (clustering_interp.py:197-203); math per SURVEY.md Appendix A (k2).
+//
+// Forward: one lane per observation slot; the encounter tile's v (C x R grid values), the grid
+// and the bandwidths sit in LDS (every lane of a row reads the same word = broadcast).
+// Backward: same tiling as k1 -- per-slot (t, g*m/(N+eps), S/(N+eps)) triples are staged in LDS
+// once, work items (row, grid point[, split]) stream them, so dL/dv needs no cross-lane
+// reduction and dL/dbeta needs one per workgroup.
+#include "dic_common.h"
+
+namespace dic {
+
+constexpr float kRbfEps = 1e-10f;   // rbf.py:107
+
+struct RbfArgs {
+    const float* x; const int32_t* lengths; int B, C, T, R, E;
+    const float* ref_grid; const float* rbf_kernel; const float* v;
+    float* y; float* norm;                       // forward outputs (norm optional)
+};
+
+__host__ __device__ inline int rbf_fwd_words(int E, int C, int R) { return E * C * R + R + C + E * C; }
+
+__global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    const int C = a.C, R = a.R, T = a.T, E = a.E;
+    float* vs = smem;                  // [E][C][R]
+    float* refg = vs + E * C * R;      // [R]
+    float* nbeta = refg + R;           // [C]  -beta*log2(e)
+    int* cnt = reinterpret_cast<int*>(nbeta + C);   // [E*C]
+    const int tid = threadIdx.x, e0 = blockIdx.x * E, Ev = min(E, a.B - e0), nrows = Ev * C;
+
+    for (int i = tid; i < nrows * R; i += kBlock) vs[i] = a.v[(size_t)e0 * C * R + i];
+    for (int i = tid; i < R; i += kBlock) refg[i] = a.ref_grid[i];
+    for (int i = tid; i < C; i += kBlock) nbeta[i] = -softplus_raw(a.rbf_kernel[i]) * kLog2e;
+    for (int i = tid; i < nrows; i += kBlock)
+        cnt[i] = a.lengths ? max(0, min(a.lengths[(size_t)e0 * C + i], T)) : T;
+    __syncthreads();
+
+    const int nchunk = (T + kWave - 1) / kWave, units = nrows * nchunk;
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll 2
+    for (int u = wave; u < units; u += kBlock / kWave) {
+        const int row = u / nchunk;
+        const int i = (u - row * nchunk) * kWave + lane;
+        if (i >= T) continue;
+        const int e = row / C, c = row - e * C;
+        const float* base = a.x + (size_t)(e0 + e) * 4 * C * T;
+        bool valid = i < cnt[row];
+        float t = 0.f;
+        if (valid) {
+            t = base[(size_t)(2 * C + c) * T + i];
+            if (!a.lengths) valid = base[(size_t)(C + c) * T + i] != 0.f;
+        }
+        float N = 0.f, S = 0.f;
+        if (valid) {
+            const float nb = nbeta[c];
+            const float* vr = vs + row * R;
+            for (int r = 0; r < R; ++r) {
+                const float d = t - refg[r];
+                const float phi = fast_exp2(nb * (d * d));
+                N += phi;
+                S = fmaf(phi, vr[r], S);
+            }
+        }
+        const size_t o = ((size_t)(e0 + e) * C + c) * T + i;
+        a.y[o] = valid ? S / (N + kRbfEps) : 0.f;
+        if (a.norm) a.norm[o] = valid ? N : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------- backward
+struct RbfBwdArgs {
+    const float* x; const int32_t* lengths; int B, C, T, R, E, S, logS, nblk;
+    const float* ref_grid; const float* rbf_kernel; const float* v;
+    const float* y; const float* norm; const float* grad_y;
+    float* grad_v; float* partials;
+};
+
+struct RbfBwdLayout { int cnt, refg, nbeta, vs, gbeta, obs, total_words; };
+__host__ __device__ inline RbfBwdLayout rbf_bwd_layout(int E, int C, int R, int T) {
+    RbfBwdLayout L;
+    int o = 0;
+    L.cnt = o;   o += E * C;
+    L.refg = o;  o += R;
+    L.nbeta = o; o += C;
+    L.vs = o;    o += E * C * R;
+    L.gbeta = o; o += E * C * R;      // per-item dL/dbeta terms
+    o = (o + 3) & ~3;                 // float4 alignment
+    L.obs = o;   o += 4 * E * C * T;
+    L.total_words = o;
+    return L;
+}
+
+__global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    const int C = a.C, R = a.R, T = a.T, E = a.E;
+    const RbfBwdLayout L = rbf_bwd_layout(E, C, R, T);
+    int* cnt = reinterpret_cast<int*>(smem + L.cnt);
+    float* refg = smem + L.refg; float* nbeta = smem + L.nbeta; float* vs = smem + L.vs; float* gb = smem + L.gbeta;
+    float4* obs = reinterpret_cast<float4*>(smem + L.obs);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    for (int i = tid; i < R; i += kBlock) refg[i] = a.ref_grid[i];
+    for (int i = tid; i < C; i += kBlock) nbeta[i] = -softplus_raw(a.rbf_kernel[i]) * kLog2e;
+    float gbeta_acc = 0.f;          // thread c < C
+
+    for (int e0 = blockIdx.x * E; e0 < a.B; e0 += a.nblk * E) {
+        const int Ev = min(E, a.B - e0), nrows = Ev * C;
+        __syncthreads();
+        for (int i = tid; i < nrows * R; i += kBlock) vs[i] = a.v[(size_t)e0 * C * R + i];
+        for (int i = tid; i < nrows; i += kBlock)
+            cnt[i] = a.lengths ? max(0, min(a.lengths[(size_t)e0 * C + i], T)) : T;
+        __syncthreads();
+        // stage (t, g*m/(N+eps), S/(N+eps), -) per slot; masked slots get weight 0
+        const int nchunk = (T + kWave - 1) / kWave, units = nrows * nchunk;
+#pragma unroll 2
+        for (int u = wave; u < units; u += kBlock / kWave) {
+            const int row = u / nchunk;
+            const int i = (u - row * nchunk) * kWave + lane;
+            if (i < cnt[row]) {
+                const int e = row / C, c = row - e * C;
+                const float* base = a.x + (size_t)(e0 + e) * 4 * C * T;
+                const size_t o = ((size_t)(e0 + e) * C + c) * T + i;
+                const float t = base[(size_t)(2 * C + c) * T + i];
+                float m = 1.f;
+                if (!a.lengths) m = base[(size_t)(C + c) * T + i];
+                const float den = a.norm[o] + kRbfEps;
+                // y = m*S/den upstream, so dL/dS = g*m/den; S/den = y for a valid slot
+                const float wgt = (m != 0.f) ? a.grad_y[o] * m / den : 0.f;
+                obs[row * T + i] = make_float4(t, wgt, (m != 0.f) ? a.y[o] / m : 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        const int S = a.S, logS = a.logS, nitems = nrows * R * S;
+        for (int item = tid; item < nitems; item += kBlock) {
+            const int s = item & (S - 1), q = item >> logS;
+            const int row = q / R, r = q - row * R, c = row % C;
+            const int n = cnt[row];
+            const float4* p = obs + row * T;
+            const float ref = refg[r], nb = nbeta[c], vr = vs[row * R + r];
+            float gv = 0.f, gbt = 0.f;
+            for (int i = s; i < n; i += S) {
+                const float4 o = p[i];
+                const float d = o.x - ref;
+                const float u = d * d;
+                const float wphi = o.y * fast_exp2(nb * u);
+                gv += wphi;
+                gbt = fmaf(wphi * u, o.z - vr, gbt);
+            }
+            for (int m = 1; m < S; m <<= 1) { gv += __shfl_xor(gv, m); gbt += __shfl_xor(gbt, m); }
+            if (s == 0) {
+                a.grad_v[((size_t)e0 * C + row) * R + r] = gv;
+                gb[row * R + r] = gbt;
+            }
+        }
+        __syncthreads();
+        if (tid < C) {
+            float s = 0.f;
+            for (int e = 0; e < Ev; ++e)
+                for (int r = 0; r < R; ++r) s += gb[(e * C + tid) * R + r];
+            gbeta_acc += s;
+        }
+    }
+    if (tid < C) a.partials[(size_t)blockIdx.x * C + tid] = gbeta_acc;
+}
+
+__global__ void rbf_bwd_finalize(const float* partials, int nblk, int C, const float* rbf_kernel, float* grad_kernel) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partials[(size_t)b * C + c];
+    grad_kernel[c] = (float)(s * (double)sigmoidf(rbf_kernel[c]));
+}
+
+// ------------------------------------------------------------------------------- rec loss
+__global__ __launch_bounds__(kBlock) void masked_sse_kernel(const float* ob, const float* rec, const float* mask,
+                                                           const int32_t* lengths, int rows, int T, int nblk,
+                                                           double* partials) {
+    __shared__ double red[2][kBlock / kWave];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nchunk = (T + kWave - 1) / kWave;
+    const long units = (long)rows * nchunk;
+    float sse = 0.f, cntv = 0.f;
+    for (long u = (long)blockIdx.x * (kBlock / kWave) + wave; u < units; u += (long)nblk * (kBlock / kWave)) {
+        const long row = u / nchunk;
+        const int i = (int)(u - row * nchunk) * kWave + lane;
+        const int n = lengths ? max(0, min(lengths[row], T)) : T;
+        if (i < n) {
+            const size_t o = (size_t)row * T + i;
+            const float m = mask ? mask[o] : 1.f;
+            const float d = rec[o] * m - ob[o] * m;
+            sse = fmaf(d, d, sse);
+            cntv += (m == 1.f) ? 1.f : 0.f;
+        }
+    }
+    const double ws = wave_sum((double)sse), wc = wave_sum((double)cntv);
+    if (lane == 0) { red[0][wave] = ws; red[1][wave] = wc; }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0, c = 0;
+        for (int w = 0; w < kBlock / kWave; ++w) { s += red[0][w]; c += red[1][w]; }
+        partials[2 * blockIdx.x] = s;
+        partials[2 * blockIdx.x + 1] = c;
+    }
+}
+
+__global__ void masked_sse_finalize(const double* partials, int nblk, float* out2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0, c = 0;
+        for (int b = 0; b < nblk; ++b) { s += partials[2 * b]; c += partials[2 * b + 1]; }
+        out2[0] = (float)s;
+        out2[1] = (float)c;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void masked_sse_bwd_kernel(const float* ob, const float* rec, const float* mask,
+                                                               const int32_t* lengths, long total, int T,
+                                                               const float* sse_count, const float* grad_loss,
+                                                               float* grad_rec) {
+    const float scale = 2.0f * grad_loss[0] / sse_count[1];
+    for (long o = (long)blockIdx.x * kBlock + threadIdx.x; o < total; o += (long)gridDim.x * kBlock) {
+        float m;
+        if (lengths) {
+            const long row = o / T;
+            m = ((int)(o - row * T) < lengths[row]) ? 1.f : 0.f;
+            if (mask && m != 0.f) m = mask[o];
+        } else {
+            m = mask[o];
+        }
+        grad_rec[o] = (m != 0.f) ? scale * m * (rec[o] * m - ob[o] * m) : 0.f;
+    }
+}
+
+static int rbf_tile(int B, int per_enc_words, int fixed_words, int budget_bytes) {
+    int E = (budget_bytes / 4 - fixed_words) / per_enc_words;
+    E = max(1, min(E, 16));
+    return max(1, min(E, max(1, B / (8 * kNumCU))));
+}
+
+static int sse_blocks(int rows, int T) {
+    const long units = (long)rows * ((T + kWave - 1) / kWave);
+    return (int)max(1L, min((units + 3) / 4, (long)8 * kNumCU));
+}
+
+}  // namespace dic
+
+using namespace dic;
+
+extern "C" {
+
+int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                const float* rbf_kernel, const float* v, float* y, float* norm, dic_stream_t stream) {
+    DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_fwd: non-positive size");
+    DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_fwd: C=%d R=%d", C, R);
+    DIC_REQUIRE(x && ref_grid && rbf_kernel && v && y, DIC_ERR_INVALID_ARG, "rbf_fwd: NULL pointer");
+    RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm};
+    const int per_enc = rbf_fwd_words(2, C, R) - rbf_fwd_words(1, C, R);
+    a.E = rbf_tile(B, per_enc, rbf_fwd_words(1, C, R) - per_enc, 32 * 1024);
+    hipLaunchKernelGGL(rbf_fwd_kernel, dim3((B + a.E - 1) / a.E), dim3(kBlock), (size_t)rbf_fwd_words(a.E, C, R) * 4,
+                       (hipStream_t)stream, a);
+    return check_launch("rbf_fwd");
+}
+
+static void rbf_bwd_geometry(int B, int C, int T, int R, int* E, int* nblk, size_t* lds) {
+    const int one = rbf_bwd_layout(1, C, R, T).total_words, two = rbf_bwd_layout(2, C, R, T).total_words;
+    *E = rbf_tile(B, two - one, one - (two - one), 48 * 1024);
+    *nblk = min((B + *E - 1) / *E, 8 * kNumCU);
+    *lds = (size_t)rbf_bwd_layout(*E, C, R, T).total_words * 4;
+}
+
+size_t dic_rbf_bwd_workspace(int B, int C, int T, int R) {
+    if (B <= 0 || C <= 0 || T <= 0 || R <= 0) return 0;
+    int E, nblk; size_t lds;
+    rbf_bwd_geometry(B, C, T, R, &E, &nblk, &lds);
+    return (size_t)nblk * C * sizeof(float);
+}
+
+int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                const float* rbf_kernel, const float* v, const float* y, const float* norm, const float* grad_y,
+                float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_bwd: non-positive size");
+    DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_bwd: C=%d R=%d", C, R);
+    DIC_REQUIRE(x && ref_grid && rbf_kernel && v && y && norm && grad_y && grad_v && grad_rbf_kernel && workspace,
+                DIC_ERR_INVALID_ARG, "rbf_bwd: NULL pointer");
+    RbfBwdArgs a{};
+    a.x = x; a.lengths = lengths; a.B = B; a.C = C; a.T = T; a.R = R;
+    a.ref_grid = ref_grid; a.rbf_kernel = rbf_kernel; a.v = v; a.y = y; a.norm = norm; a.grad_y = grad_y;
+    a.grad_v = grad_v; a.partials = (float*)workspace;
+    size_t lds;
+    rbf_bwd_geometry(B, C, T, R, &a.E, &a.nblk, &lds);
+    DIC_REQUIRE(lds <= 64 * 1024, DIC_ERR_UNSUPPORTED, "rbf_bwd: one encounter needs %zu B of LDS", lds);
+    DIC_REQUIRE(workspace_bytes >= (size_t)a.nblk * C * sizeof(float), DIC_ERR_WORKSPACE, "rbf_bwd: workspace too small");
+    a.S = 1; a.logS = 0;
+    while (a.E * C * R * a.S < kBlock && a.S < 16) { a.S <<= 1; ++a.logS; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rbf_bwd_kernel, dim3(a.nblk), dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL(rbf_bwd_finalize, dim3(1), dim3(64), 0, st, (const float*)workspace, a.nblk, C, rbf_kernel,
+                       grad_rbf_kernel);
+    return check_launch("rbf_bwd");
+}
+
+size_t dic_masked_sse_workspace(int B, int C, int T) {
+    if (B <= 0 || C <= 0 || T <= 0) return 0;
+    return (size_t)sse_blocks(B * C, T) * 2 * sizeof(double);
+}
+
+int dic_masked_sse_fwd(const float* ob, const float* rec, const float* mask, const int32_t* lengths, int B, int C, int T,
+                       float* out2, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(B > 0 && C > 0 && T > 0, DIC_ERR_INVALID_ARG, "masked_sse: non-positive size");
+    DIC_REQUIRE(ob && rec && out2 && workspace && (mask || lengths), DIC_ERR_INVALID_ARG, "masked_sse: NULL pointer");
+    const int nblk = sse_blocks(B * C, T);
+    DIC_REQUIRE(workspace_bytes >= (size_t)nblk * 2 * sizeof(double), DIC_ERR_WORKSPACE, "masked_sse: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(masked_sse_kernel, dim3(nblk), dim3(kBlock), 0, st, ob, rec, mask, lengths, B * C, T, nblk,
+                       (double*)workspace);
+    hipLaunchKernelGGL(masked_sse_finalize, dim3(1), dim3(64), 0, st, (const double*)workspace, nblk, out2);
+    return check_launch("masked_sse_fwd");
+}
+
+int dic_masked_sse_bwd(const float* ob, const float* rec, const float* mask, const int32_t* lengths, int B, int C, int T,
+                       const float* sse_count, const float* grad_loss, float* grad_rec, dic_stream_t stream) {
+    DIC_REQUIRE(B > 0 && C > 0 && T > 0, DIC_ERR_INVALID_ARG, "masked_sse_bwd: non-positive size");
+    DIC_REQUIRE(ob && rec && sse_count && grad_loss && grad_rec && (mask || lengths), DIC_ERR_INVALID_ARG,
+                "masked_sse_bwd: NULL pointer");
+    const long total = (long)B * C * T;
+    const int grid = (int)min((total + kBlock - 1) / kBlock, (long)16 * kNumCU);
+    hipLaunchKernelGGL(masked_sse_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, ob, rec, mask, lengths,
+                       total, T, sse_count, grad_loss, grad_rec);
+    return check_launch("masked_sse_bwd");
+}
+
+}  // extern "C"

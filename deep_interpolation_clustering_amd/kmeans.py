@@ -1,0 +1,235 @@
+"""``KMeans`` with scikit-learn's estimator surface, running on the HIP k-means kernels.
+
+Drop-in for the ``sklearn.cluster.KMeans`` calls of the reference (clustering_trainer.py:75-82,
+p2_clustering_optK.py:260-389, p4_clustering_final.py:159-174).  Control flow follows scikit-learn
+1.7.2 (``_kmeans.py`` fit :1453-1551, ``_kmeans_single_lloyd`` :624-753, ``_kmeans_plusplus``
+:176-262): centre the data, k-means++ seeding driven by NumPy's global ``RandomState`` in the same
+draw order, Lloyd iterations with strict-convergence / ``tol`` stops, final E-step, lowest inertia
+of ``n_init`` restarts wins.  The MI355X-specific part: all ``n_init`` restarts advance TOGETHER --
+one launch per Lloyd iteration covers every restart (grid.y = restart), converged restarts drop out
+on a device-side flag, and the host only polls that flag every few iterations.
+
+Outputs (``cluster_centers_``, ``labels_``, ``inertia_``, ``n_iter_``) are NumPy, like sklearn's.
+There is no CPU fallback: without a GPU ``fit``/``predict`` raise.
+"""
+from __future__ import annotations
+
+import numbers
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import dist
+
+_POLL_EVERY = 4      # Lloyd iterations enqueued between two host reads of the done flags
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('deep_interpolation_clustering_amd.KMeans needs an MI355X (no CPU fallback by design)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _as_device_matrix(X, device):
+    if isinstance(X, torch.Tensor):
+        t = X.detach().to(device=device, dtype=torch.float32)
+    else:
+        t = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32), device=device)
+    if t.dim() != 2:
+        raise ValueError(f'expected a 2-D array, got shape {tuple(t.shape)}')
+    return t.contiguous()
+
+
+def _pad_features(t):
+    """Kernels take D % 4 == 0 (one float4 per lane); zero columns leave every distance unchanged."""
+    D = t.shape[1]
+    if D > N.LATENT_MAX_DIM:
+        raise ValueError(f'n_features={D} > {N.LATENT_MAX_DIM}: outside the compiled latent width')
+    pad = (-D) % 4
+    return torch.nn.functional.pad(t, (0, pad)) if pad else t
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def lloyd(X, xnorm, centers, tol, max_iter):
+    """Batched Lloyd on centred device data.  centers (n_runs,K,D) is updated in place.
+    Returns (labels (n_runs,N) int32, inertia (n_runs,) f32, n_iter (n_runs,) int list)."""
+    L = N.lib()
+    n_runs, K, D = centers.shape
+    Nn = X.shape[0]
+    dev = X.device
+    labels = torch.full((n_runs, Nn), -1, dtype=torch.int32, device=dev)
+    status = torch.zeros((n_runs, N.KM_STATUS_WORDS), dtype=torch.float32, device=dev)
+    status[:, 6] = float(tol)
+    status[:, 7] = float(max_iter)
+    ws = _ws(L.dic_kmeans_workspace(Nn, D, K, n_runs), dev)
+    st = N.stream_of(X)
+    it = 0
+    while it < max_iter:
+        for _ in range(min(_POLL_EVERY, max_iter - it)):
+            N.check(L.dic_kmeans_lloyd_iter(N.ptr(X), N.ptr(xnorm), Nn, D, K, n_runs, N.ptr(centers), N.ptr(labels),
+                                            N.ptr(status), N.ptr(ws), ws.numel(), st), 'dic_kmeans_lloyd_iter')
+            it += 1
+        if bool((status[:, 0] != 0).all()):       # the only host sync of the loop
+            break
+    # final E-step: labels consistent with the final centres (a no-op change for strictly converged runs),
+    # exact inertia (_kmeans.py:736-750)
+    inertia = torch.empty(n_runs, dtype=torch.float32, device=dev)
+    N.check(L.dic_kmeans_predict(N.ptr(X), Nn, D, K, n_runs, N.ptr(centers), N.ptr(labels), None, N.ptr(inertia),
+                                 N.ptr(ws), ws.numel(), st), 'dic_kmeans_predict')
+    return labels, inertia, status
+
+
+def _pp_init(X, K, n_runs, rs):
+    """k-means++ (greedy, 2+log K local trials) for n_runs restarts at once.  Every random number is
+    drawn from ``rs`` up front in scikit-learn's order (per restart: one ``choice`` then K-1
+    ``uniform(size=trials)``), which is possible because the Lloyd runs consume no randomness."""
+    L = N.lib()
+    Nn, D = X.shape
+    dev = X.device
+    trials = 2 + int(np.log(K))
+    p_uniform = np.full(Nn, 1.0 / Nn)
+    first = np.empty(n_runs, dtype=np.int64)
+    u = np.empty((n_runs, max(K - 1, 0), trials), dtype=np.float64)
+    for r in range(n_runs):
+        first[r] = rs.choice(Nn, p=p_uniform)
+        for c in range(K - 1):
+            u[r, c] = rs.uniform(size=trials)
+    u = torch.as_tensor(u, device=dev)
+    st = N.stream_of(X)
+    centers_idx = torch.empty((n_runs, K), dtype=torch.int64, device=dev)
+    centers_idx[:, 0] = torch.as_tensor(first, device=dev)
+    inf = torch.full((n_runs, Nn), float('inf'), dtype=torch.float32, device=dev)
+    closest = torch.empty((n_runs, Nn), dtype=torch.float32, device=dev)
+    pot = torch.empty(n_runs, dtype=torch.float64, device=dev)
+    ws = _ws(L.dic_kmeans_pp_workspace(Nn, n_runs * trials), dev)
+    N.check(L.dic_kmeans_pp_candidates(N.ptr(X), Nn, D, N.ptr(centers_idx[:, 0].contiguous()), n_runs, 1, N.ptr(inf),
+                                       N.ptr(closest), N.ptr(pot), N.ptr(ws), ws.numel(), st), 'dic_kmeans_pp_candidates')
+    dist_c = torch.empty((n_runs * trials, Nn), dtype=torch.float32, device=dev)
+    pot_c = torch.empty(n_runs * trials, dtype=torch.float64, device=dev)
+    ar = torch.arange(n_runs, device=dev)
+    for c in range(1, K):
+        cur = pot.float().double()                                   # current_pot is an f32 scalar upstream
+        cum = torch.cumsum(closest, dim=1, dtype=torch.float64)      # stable_cumsum(sample_weight * closest)
+        cand = torch.searchsorted(cum, u[:, c - 1] * cur[:, None]).clamp_(max=Nn - 1)      # (n_runs, trials)
+        N.check(L.dic_kmeans_pp_candidates(N.ptr(X), Nn, D, N.ptr(cand.contiguous()), n_runs * trials, trials,
+                                           N.ptr(closest), N.ptr(dist_c), N.ptr(pot_c), N.ptr(ws), ws.numel(), st),
+                'dic_kmeans_pp_candidates')
+        best = torch.argmin(pot_c.view(n_runs, trials), dim=1)
+        centers_idx[:, c] = cand[ar, best]
+        closest = dist_c.view(n_runs, trials, Nn)[ar, best].contiguous()
+        pot = pot_c.view(n_runs, trials)[ar, best]
+    return X[centers_idx]                                            # (n_runs, K, D)
+
+
+def _same_clustering(a, b, K):
+    """sklearn _is_same_clustering: equal up to a permutation of the label ids."""
+    pair = torch.unique(a.long() * K + b.long()).numel()
+    return pair == torch.unique(a).numel() == torch.unique(b).numel()
+
+
+class KMeans:
+    def __init__(self, n_clusters=8, *, init='k-means++', n_init='auto', max_iter=300, tol=1e-4, verbose=0,
+                 random_state=None, copy_x=True, algorithm='lloyd'):
+        self.n_clusters = n_clusters
+        self.init = init
+        self.n_init = n_init
+        self.max_iter = max_iter
+        self.tol = tol
+        self.verbose = verbose
+        self.random_state = random_state
+        self.copy_x = copy_x
+        self.algorithm = algorithm
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _random_state(self):
+        rs = self.random_state
+        if rs is None or rs is np.random:
+            return np.random.mtrand._rand            # sklearn check_random_state(None): NumPy's global state
+        if isinstance(rs, numbers.Integral):
+            return np.random.RandomState(rs)
+        return rs
+
+    def _resolve_n_init(self, init_is_array):
+        n_init = self.n_init
+        if n_init == 'auto':                          # sklearn >= 1.4 (_kmeans.py:_check_params_vs_input)
+            n_init = 1 if (init_is_array or self.init == 'k-means++') else 10
+        if init_is_array and n_init != 1:
+            n_init = 1
+        return int(n_init)
+
+    # -- estimator API ------------------------------------------------------------------------
+    def fit(self, X, y=None, sample_weight=None):
+        if sample_weight is not None:
+            raise NotImplementedError('sample_weight is not used by the reference call sites')
+        if self.algorithm not in ('lloyd', 'auto', 'full'):
+            raise NotImplementedError("only algorithm='lloyd' is implemented")
+        dev = _device()
+        K = int(self.n_clusters)
+        if K > N.MAX_CLUSTERS:
+            raise ValueError(f'n_clusters={K} > {N.MAX_CLUSTERS}: outside the compiled limit')
+        Xd = _as_device_matrix(X, dev)
+        Nn, D0 = Xd.shape
+        if Nn < K:
+            raise ValueError(f'n_samples={Nn} should be >= n_clusters={K}.')
+        rs = self._random_state()
+        init_is_array = not isinstance(self.init, str)
+        n_init = self._resolve_n_init(init_is_array)
+
+        tol_abs = float(Xd.var(dim=0, unbiased=False).mean()) * self.tol      # _tolerance (:279-288)
+        mean = Xd.mean(dim=0)                                                 # :1479-1484
+        Xc = _pad_features(Xd - mean)
+        D = Xc.shape[1]
+        xnorm = (Xc * Xc).sum(dim=1)
+
+        if init_is_array:
+            c0 = _as_device_matrix(self.init, dev)
+            if tuple(c0.shape) != (K, D0):
+                raise ValueError(f'The shape of the initial centers {tuple(c0.shape)} does not match (n_clusters, n_features)')
+            centers = _pad_features(c0 - mean)[None].contiguous()
+        elif self.init == 'k-means++':
+            centers = _pp_init(Xc, K, n_init, rs).contiguous()
+        elif self.init == 'random':
+            p = np.full(Nn, 1.0 / Nn)
+            seeds = np.stack([rs.choice(Nn, size=K, replace=False, p=p) for _ in range(n_init)])
+            centers = Xc[torch.as_tensor(seeds, device=dev)].contiguous()
+        else:
+            raise ValueError(f"init must be 'k-means++', 'random' or an array, got {self.init!r}")
+
+        labels, inertia, status = lloyd(Xc, xnorm, centers, tol_abs, int(self.max_iter))
+        inertia_h = inertia.cpu().numpy()
+        best = 0
+        for i in range(1, centers.shape[0]):                                  # :1517-1532
+            if inertia_h[i] < inertia_h[best] and not _same_clustering(labels[i], labels[best], K):
+                best = i
+        self.cluster_centers_ = (centers[best, :, :D0] + mean).cpu().numpy()
+        self.labels_ = labels[best].cpu().numpy()
+        self.inertia_ = float(inertia_h[best])
+        self.n_iter_ = int(status[best, 1].item())
+        self.n_features_in_ = D0
+        self._status = status.cpu().numpy()
+        return self
+
+    def fit_predict(self, X, y=None, sample_weight=None):
+        return self.fit(X, sample_weight=sample_weight).labels_
+
+    def predict(self, X):
+        """One E-step against the stored centres, no centring (_kmeans.py:1066-1090)."""
+        dev = _device()
+        Xd = _pad_features(_as_device_matrix(X, dev))
+        c = _pad_features(_as_device_matrix(self.cluster_centers_, dev))[None].contiguous()
+        Nn, D = Xd.shape
+        labels = torch.empty((1, Nn), dtype=torch.int32, device=dev)
+        N.check(N.lib().dic_kmeans_predict(N.ptr(Xd), Nn, D, c.shape[1], 1, N.ptr(c), N.ptr(labels), None, None, None, 0,
+                                           N.stream_of(Xd)), 'dic_kmeans_predict')
+        return labels[0].cpu().numpy()
+
+    def transform(self, X):
+        raise NotImplementedError('transform is not on the reference path')
+
+    def get_params(self, deep=True):
+        return dict(n_clusters=self.n_clusters, init=self.init, n_init=self.n_init, max_iter=self.max_iter, tol=self.tol,
+                    random_state=self.random_state)

@@ -1,0 +1,291 @@
+"""Differentiable operators of the hot path, each a thin ``torch.autograd.Function`` over one or
+two launches of the HIP library (``_native``).  PyTorch supplies device memory, the current HIP
+stream and autograd plumbing only; every value is produced by the gfx950 kernels.
+
+Operator <-> reference map (upstream file:line):
+  sci_cci / sci_only    SingleChannelInterp.forward  interpolation_layer.py:31-86
+                        + CrossChannelInterp.forward interpolation_layer.py:99-127 (fused epilogue)
+  cci                   CrossChannelInterp.forward on an arbitrary (B,R,3C) tensor
+  rbf_deinterp          RBF.forward minus compress_fc rbf.py:57-108
+  masked_mse            Net.rec_loss                  clustering_interp.py:197-203
+  dec_soft_assign       ClusterAssignment.forward     dec.py:49-63
+  dec_target            target_distribution           dec.py:66-76
+  kl_batchmean          Net.kl_loss                   clustering_interp.py:205-207
+
+Sharded (one process per GPU) execution: the batch-level statistics -- mask count and SSE of the
+reconstruction loss, the DEC column sums f_j, the KL batch divisor -- are all-reduced over RCCL
+(``dist.all_reduce_sum_``) so a sharded step equals the single-device step on the global batch.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as N
+from . import dist
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _lengths_arg(lengths, B, C, device):
+    if lengths is None:
+        return None
+    if lengths.dtype != torch.int32 or not lengths.is_contiguous() or lengths.device != device:
+        lengths = lengths.to(device=device, dtype=torch.int32).contiguous()
+    if lengths.numel() != B * C:
+        raise ValueError(f'lengths must have B*C={B * C} entries, got {tuple(lengths.shape)}')
+    return lengths
+
+
+def ref_grid(hours, ref_points, device):
+    """interpolation_layer.py:41 / rbf.py:44 -- the grid is data for the kernels."""
+    return torch.linspace(0, hours, ref_points, device=device, dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------------------- k1
+class _SciCci(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sci_kernel, cci_kernel, grid, lengths):
+        N.require_gpu(x, sci_kernel, grid)
+        x = N.f32c(x)
+        B, C4, T = x.shape
+        C = sci_kernel.numel()
+        if C4 != 4 * C:
+            raise ValueError(f'stacked input must be (B, 4*{C}, T), got {tuple(x.shape)}')
+        R = grid.numel()
+        lengths = _lengths_arg(lengths, B, C, x.device)
+        sk = N.f32c(sci_kernel.detach())
+        ck = None if cci_kernel is None else N.f32c(cci_kernel.detach())
+        need_grad = any(ctx.needs_input_grad)
+        out = torch.empty((B, R, 3 * C), device=x.device, dtype=torch.float32)
+        saved = torch.empty((B, 7, C, R), device=x.device, dtype=torch.float32) if need_grad else None
+        N.check(N.lib().dic_sci_cci_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck),
+                                        N.ptr(out), N.ptr(saved), N.stream_of(x)), 'dic_sci_cci_fwd')
+        ctx.dims = (B, C, R)
+        ctx.has_cci = ck is not None
+        ctx.save_for_backward(saved, sk, ck)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        saved, sk, ck = ctx.saved_tensors
+        B, C, R = ctx.dims
+        g = N.f32c(grad_out)
+        gs = torch.empty(C, device=g.device, dtype=torch.float32)
+        gc = torch.empty((C, C), device=g.device, dtype=torch.float32) if ctx.has_cci else None
+        L = N.lib()
+        ws = _ws(L.dic_sci_cci_bwd_workspace(B, C, R), g.device)
+        N.check(L.dic_sci_cci_bwd(N.ptr(g), N.ptr(saved), N.ptr(sk), N.ptr(ck), B, C, R, N.ptr(gs), N.ptr(gc), N.ptr(ws),
+                                  ws.numel(), N.stream_of(g)), 'dic_sci_cci_bwd')
+        return None, gs, gc, None, None
+
+
+def sci_cci(x, sci_kernel, cci_kernel, grid, lengths=None):
+    """Fused SCI + CCI: x (B,4C,T) -> (B,R,3C) = [smooth | intensity | transient]."""
+    return _SciCci.apply(x, sci_kernel, cci_kernel, grid, lengths)
+
+
+def sci_only(x, sci_kernel, grid, lengths=None):
+    """SCI alone: x (B,4C,T) -> (B,R,3C) = [y | w | y_trans]."""
+    return _SciCci.apply(x, sci_kernel, None, grid, lengths)
+
+
+class _Cci(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, cci_kernel):
+        N.require_gpu(s, cci_kernel)
+        s = N.f32c(s)
+        B, R, C3 = s.shape
+        C = cci_kernel.shape[0]
+        if C3 != 3 * C:
+            raise ValueError(f'input must be (B,R,3*{C}), got {tuple(s.shape)}')
+        ck = N.f32c(cci_kernel.detach())
+        out = torch.empty_like(s)
+        N.check(N.lib().dic_cci_fwd(N.ptr(s), N.ptr(ck), B, C, R, N.ptr(out), N.stream_of(s)), 'dic_cci_fwd')
+        ctx.dims = (B, C, R)
+        ctx.save_for_backward(s, ck)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        s, ck = ctx.saved_tensors
+        B, C, R = ctx.dims
+        g = N.f32c(grad_out)
+        gs = torch.empty_like(s)
+        gk = torch.empty((C, C), device=g.device, dtype=torch.float32)
+        L = N.lib()
+        ws = _ws(L.dic_cci_bwd_workspace(B, C, R), g.device)
+        N.check(L.dic_cci_bwd(N.ptr(g), N.ptr(s), N.ptr(ck), B, C, R, N.ptr(gs), N.ptr(gk), N.ptr(ws), ws.numel(),
+                              N.stream_of(g)), 'dic_cci_bwd')
+        return gs, gk
+
+
+def cci(s, cci_kernel):
+    return _Cci.apply(s, cci_kernel)
+
+
+# ----------------------------------------------------------------------------------------- k2
+class _Rbf(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, raw_input, rbf_kernel, grid, lengths):
+        N.require_gpu(v, raw_input, rbf_kernel, grid)
+        x = N.f32c(raw_input)
+        v = N.f32c(v)
+        B, C4, T = x.shape
+        C = rbf_kernel.numel()
+        R = grid.numel()
+        if C4 != 4 * C or tuple(v.shape) != (B, C, R):
+            raise ValueError(f'rbf: raw_input {tuple(x.shape)} / v {tuple(v.shape)} do not match C={C}, R={R}')
+        lengths = _lengths_arg(lengths, B, C, x.device)
+        rk = N.f32c(rbf_kernel.detach())
+        need_grad = any(ctx.needs_input_grad)
+        y = torch.empty((B, C, T), device=x.device, dtype=torch.float32)
+        norm = torch.empty_like(y) if need_grad else None
+        N.check(N.lib().dic_rbf_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(v), N.ptr(y),
+                                    N.ptr(norm), N.stream_of(x)), 'dic_rbf_fwd')
+        ctx.dims = (B, C, T, R)
+        ctx.save_for_backward(x, lengths, grid, rk, v, y, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, lengths, grid, rk, v, y, norm = ctx.saved_tensors
+        B, C, T, R = ctx.dims
+        g = N.f32c(grad_y)
+        gv = torch.empty((B, C, R), device=g.device, dtype=torch.float32)
+        gk = torch.empty(C, device=g.device, dtype=torch.float32)
+        L = N.lib()
+        ws = _ws(L.dic_rbf_bwd_workspace(B, C, T, R), g.device)
+        N.check(L.dic_rbf_bwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(v), N.ptr(y), N.ptr(norm),
+                              N.ptr(g), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_rbf_bwd')
+        return gv, None, gk, None, None
+
+
+def rbf_deinterp(v, raw_input, rbf_kernel, grid, lengths=None):
+    """v (B,C,R) grid values -> (B,C,T) values at the observed time stamps of ``raw_input``."""
+    return _Rbf.apply(v, raw_input, rbf_kernel, grid, lengths)
+
+
+class _MaskedMse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, org_ob, rec_ob, mask, lengths):
+        N.require_gpu(org_ob, rec_ob)
+        ob, rec = N.f32c(org_ob), N.f32c(rec_ob)
+        B, C, T = rec.shape
+        mask = None if mask is None else N.f32c(mask)
+        lengths = _lengths_arg(lengths, B, C, rec.device)
+        out2 = torch.empty(2, device=rec.device, dtype=torch.float32)
+        L = N.lib()
+        ws = _ws(L.dic_masked_sse_workspace(B, C, T), rec.device)
+        N.check(L.dic_masked_sse_fwd(N.ptr(ob), N.ptr(rec), N.ptr(mask), N.ptr(lengths), B, C, T, N.ptr(out2), N.ptr(ws),
+                                     ws.numel(), N.stream_of(rec)), 'dic_masked_sse_fwd')
+        dist.all_reduce_sum_(out2)          # global SSE and global #{mask == 1}
+        ctx.dims = (B, C, T)
+        ctx.save_for_backward(ob, rec, mask, lengths, out2)
+        return out2[0] / out2[1]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        ob, rec, mask, lengths, out2 = ctx.saved_tensors
+        B, C, T = ctx.dims
+        gl = N.f32c(grad_loss.reshape(1))
+        grad_rec = torch.empty_like(rec)
+        N.check(N.lib().dic_masked_sse_bwd(N.ptr(ob), N.ptr(rec), N.ptr(mask), N.ptr(lengths), B, C, T, N.ptr(out2),
+                                           N.ptr(gl), N.ptr(grad_rec), N.stream_of(rec)), 'dic_masked_sse_bwd')
+        return None, grad_rec, None, None
+
+
+def masked_mse(org_ob, rec_ob, padding_mask=None, lengths=None):
+    """sum((rec*m - ob*m)^2) / #{m == 1} over the (global) batch."""
+    if padding_mask is None and lengths is None:
+        raise ValueError('masked_mse needs a mask or prefix lengths')
+    return _MaskedMse.apply(org_ob, rec_ob, padding_mask, lengths)
+
+
+# ----------------------------------------------------------------------------------------- k3
+class _DecAssign(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, centers, alpha, want_colsum):
+        N.require_gpu(z, centers)
+        z, mu = N.f32c(z), N.f32c(centers.detach())
+        B, D = z.shape
+        K = mu.shape[0]
+        if mu.shape[1] != D:
+            raise ValueError(f'embedding dim mismatch: z {tuple(z.shape)} vs centers {tuple(mu.shape)}')
+        q = torch.empty((B, K), device=z.device, dtype=torch.float32)
+        need_grad = any(ctx.needs_input_grad)
+        ts = torch.empty_like(q) if need_grad else None
+        colsum = torch.empty(K, device=z.device, dtype=torch.float32) if want_colsum else None
+        L = N.lib()
+        ws = _ws(L.dic_dec_fwd_workspace(B, D, K), z.device)
+        N.check(L.dic_dec_fwd(N.ptr(z), N.ptr(mu), B, D, K, float(alpha), N.ptr(q), N.ptr(ts), N.ptr(colsum), N.ptr(ws),
+                              ws.numel(), N.stream_of(z)), 'dic_dec_fwd')
+        ctx.dims = (B, D, K, float(alpha))
+        ctx.save_for_backward(z, mu, q, ts)
+        if want_colsum:
+            ctx.mark_non_differentiable(colsum)
+            return q, colsum
+        return q, None
+
+    @staticmethod
+    def backward(ctx, grad_q, _unused=None):
+        z, mu, q, ts = ctx.saved_tensors
+        B, D, K, alpha = ctx.dims
+        g = N.f32c(grad_q)
+        gz = torch.empty_like(z)
+        gc = torch.empty_like(mu)
+        L = N.lib()
+        ws = _ws(L.dic_dec_bwd_workspace(B, D, K), g.device)
+        N.check(L.dic_dec_bwd(N.ptr(z), N.ptr(mu), N.ptr(q), N.ptr(ts), N.ptr(g), B, D, K, alpha, N.ptr(gz), N.ptr(gc),
+                              N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_dec_bwd')
+        return gz, gc, None, None
+
+
+def dec_soft_assign(z, centers, alpha=1.0, return_colsum=False):
+    """Student-t soft assignment q (B,K); optionally also the local column sums f_j = sum_i q_ij."""
+    q, colsum = _DecAssign.apply(z, centers, alpha, return_colsum)
+    return (q, colsum) if return_colsum else q
+
+
+def dec_target(q, colsum=None):
+    """p = (q^2/f)/sum_j(q^2/f).  ``colsum`` = local column sums from ``dec_soft_assign`` (recomputed
+    through a forward-only pass of the same kernel family when absent); all-reduced when sharded."""
+    N.require_gpu(q)
+    qd = N.f32c(q.detach())
+    B, K = qd.shape
+    if colsum is None:
+        colsum = qd.sum(dim=0)      # K floats of host-side plumbing; hot callers pass the kernel's colsum
+    colsum = colsum.clone() if dist.is_sharded() else colsum
+    dist.all_reduce_sum_(colsum)
+    p = torch.empty_like(qd)
+    N.check(N.lib().dic_dec_target(N.ptr(qd), N.ptr(N.f32c(colsum)), B, K, N.ptr(p), N.stream_of(qd)), 'dic_dec_target')
+    return p
+
+
+class _KlBatchMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, q):
+        N.require_gpu(p, q)
+        pd, qd = N.f32c(p.detach()), N.f32c(q)
+        B, K = qd.shape
+        bdiv = float(B * dist.world_size())          # 'batchmean' over the GLOBAL batch
+        kl = torch.empty(1, device=qd.device, dtype=torch.float32)
+        gq = torch.empty_like(qd) if ctx.needs_input_grad[1] else None
+        L = N.lib()
+        ws = _ws(L.dic_dec_kl_workspace(B, K), qd.device)
+        N.check(L.dic_dec_kl(N.ptr(qd), N.ptr(pd), B, K, bdiv, 1.0, N.ptr(kl), N.ptr(gq), N.ptr(ws), ws.numel(),
+                             N.stream_of(qd)), 'dic_dec_kl')
+        dist.all_reduce_sum_(kl)
+        ctx.save_for_backward(gq)
+        return kl[0]
+
+    @staticmethod
+    def backward(ctx, grad_kl):
+        (gq,) = ctx.saved_tensors
+        return None, gq * grad_kl
+
+
+def kl_batchmean(p, q):
+    """F.kl_div(q.log(), p, reduction='batchmean') with the closed-form d/dq fused into the forward."""
+    return _KlBatchMean.apply(p, q)

@@ -1,0 +1,188 @@
+/*
+ * dic_hip.h -- C ABI of the MI355X (gfx950) hot path of deep-interpolation-clustering.
+ *
+ * One shared object (libdic_hip.so), extern "C", plain pointers and sizes only.
+ * Conventions shared by every compute entry point:
+ *   - returns DIC_OK (0) or a negative dic_status code; never throws, never allocates;
+ *   - every pointer is a DEVICE pointer owned by the caller and borrowed for the call;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
+ *   - `workspace` buffers are caller-allocated scratch; query their size first;
+ *   - kernels hold no global mutable state and are re-entrant across streams.
+ *
+ * The reference has no FFI: its boundary is the Python module surface.  Each entry
+ * point below names the reference lines (relative to the upstream repository) whose
+ * arithmetic it replaces; INTEGRATION.md shows the ctypes stub that binds them
+ * behind the upstream module names.
+ *
+ * Stacked input layout (reference: interpolation_layer.py:25-30, dataloader.py:54-69):
+ *   x is (B, 4C, T) contiguous f32; planes [value*mask | mask | time(h) | hold-out].
+ *   `lengths` (B,C) int32 is optional: when given, row (b,c) is a PREFIX of
+ *   lengths[b,c] valid slots (what p0/the trainers always produce) and the mask
+ *   plane is not read; when NULL the mask plane is honoured slot by slot.
+ * Packed ragged layout (dataset-resident fast path):
+ *   row_off (B*C+1) int64 offsets into packed `t_pk`/`v_pk` f32 arrays, rows stored
+ *   back to back in (b,c) order; max_len = longest row.
+ */
+#ifndef DIC_HIP_H
+#define DIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIC_ABI_VERSION 1
+
+typedef enum dic_status {
+    DIC_OK = 0,
+    DIC_ERR_INVALID_ARG = -1,   /* NULL pointer, non-positive size                      */
+    DIC_ERR_UNSUPPORTED = -2,   /* shape outside the compiled limits (see each entry)   */
+    DIC_ERR_WORKSPACE = -3,     /* workspace too small                                  */
+    DIC_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after the launch     */
+} dic_status;
+
+typedef void* dic_stream_t;    /* hipStream_t */
+
+/* Limits compiled into the kernels. */
+#define DIC_MAX_CHANNELS 16    /* C  (C*C <= one 256-thread workgroup) */
+#define DIC_MAX_REFPOINTS 64   /* R  */
+#define DIC_MAX_CLUSTERS 32    /* K  */
+#define DIC_LATENT_MAX_DIM 256 /* D: latent rows are handled 4 columns per lane by one wave */
+
+int dic_version(void);
+const char* dic_status_string(int status);
+const char* dic_last_error_string(void);   /* detail of the last failure on this thread */
+
+/* ------------------------------------------------------------------ k1: SCI (+CCI) ------
+ * Replaces SingleChannelInterp.forward (interpolation_layer.py:31-86) and, when
+ * cci_kernel != NULL, CrossChannelInterp.forward fused as its epilogue
+ * (interpolation_layer.py:99-127).
+ *   out   (B,R,3C): cci_kernel==NULL -> [y | w | y_trans]; else [smooth | exp(w) | y_trans-smooth]
+ *   saved (B,7,C,R) or NULL: y,w,y_trans,Eu1,Exu1,Eu10,Exu10 -- what the backward needs
+ *          (Eu = E_s[u], Exu = E_s[x u] under the softmax weights, u=(t-ref)^2).
+ * A channel with no valid observation yields NaN y/y_trans and w=-inf, as upstream.
+ * ref_grid (R) f32 = the reference time grid, i.e. torch.linspace(0, hours, R) (interpolation_layer.py:41),
+ * passed as data so the kernel sees bit-identical grid values.
+ * Limits: C<=16, R<=64, one encounter (2*C*T f32 + results) must fit 64 KB of LDS. */
+int dic_sci_cci_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                    const float* sci_kernel, const float* cci_kernel,
+                    float* out, float* saved, dic_stream_t stream);
+
+int dic_sci_cci_fwd_ragged(const float* t_pk, const float* v_pk, const int64_t* row_off, int max_len,
+                           int B, int C, int R, const float* ref_grid,
+                           const float* sci_kernel, const float* cci_kernel,
+                           float* out, float* saved, dic_stream_t stream);
+
+/* Backward of the above wrt the two parameters only (the inputs carry no gradient upstream).
+ *   grad_out (B,R,3C) cotangent of `out`; saved from the forward;
+ *   grad_sci_kernel (C), grad_cci_kernel (C,C; ignored when cci_kernel==NULL): OVERWRITTEN.
+ * Deterministic two-stage reduction through `workspace`. */
+size_t dic_sci_cci_bwd_workspace(int B, int C, int R);
+int dic_sci_cci_bwd(const float* grad_out, const float* saved, const float* sci_kernel,
+                    const float* cci_kernel, int B, int C, int R,
+                    float* grad_sci_kernel, float* grad_cci_kernel,
+                    void* workspace, size_t workspace_bytes, dic_stream_t stream);
+
+/* Stand-alone CrossChannelInterp on an arbitrary (B,R,3C) tensor s=[y|w|y_trans]
+ * (interpolation_layer.py:99-127) and its backward wrt both s and the kernel. */
+int dic_cci_fwd(const float* s, const float* cci_kernel, int B, int C, int R, float* out,
+                dic_stream_t stream);
+size_t dic_cci_bwd_workspace(int B, int C, int R);
+int dic_cci_bwd(const float* grad_out, const float* s, const float* cci_kernel, int B, int C, int R,
+                float* grad_s, float* grad_cci_kernel,
+                void* workspace, size_t workspace_bytes, dic_stream_t stream);
+
+/* ------------------------------------------------------------------ k2: RBF de-interpolation
+ * Replaces RBF.forward minus compress_fc (rbf.py:57-108, gaussian rbf.py:129-131).
+ *   v (B,C,R) = compress_fc output;  y (B,C,T) OVERWRITTEN (0 in masked slots).
+ * Limits: C<=16, R<=64. */
+int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                const float* rbf_kernel, const float* v, float* y, float* norm /* (B,C,T) or NULL: sum_r phi,
+                saved for the backward */, dic_stream_t stream);
+
+/* grad_y (B,C,T) -> grad_v (B,C,R), grad_rbf_kernel (C); both OVERWRITTEN.  y, norm: forward outputs.
+ * Masks are binary upstream; a non-zero mask value is treated as 1. */
+size_t dic_rbf_bwd_workspace(int B, int C, int T, int R);
+int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                const float* rbf_kernel, const float* v, const float* y, const float* norm,
+                const float* grad_y, float* grad_v, float* grad_rbf_kernel,
+                void* workspace, size_t workspace_bytes, dic_stream_t stream);
+
+/* Net.rec_loss (clustering_interp.py:197-203): out2[0]=sum((rec*m-ob*m)^2), out2[1]=#{m==1}.
+ * mask (B,C,T) may be NULL when lengths is given.  The loss is out2[0]/out2[1]. */
+size_t dic_masked_sse_workspace(int B, int C, int T);
+int dic_masked_sse_fwd(const float* ob, const float* rec, const float* mask, const int32_t* lengths,
+                       int B, int C, int T, float* out2,
+                       void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* grad_rec = grad_loss[0] * 2*m*(rec*m-ob*m)/sse_count[1]   (all device pointers). */
+int dic_masked_sse_bwd(const float* ob, const float* rec, const float* mask, const int32_t* lengths,
+                       int B, int C, int T, const float* sse_count, const float* grad_loss,
+                       float* grad_rec, dic_stream_t stream);
+
+/* ------------------------------------------------------------------ k3: DEC ---------------
+ * Replaces ClusterAssignment.forward (dec.py:49-63).
+ *   z (B,D), centers (K,D) -> q (B,K); tsaved (B,K) or NULL = 1/(1+d2/alpha) for the backward;
+ *   colsum (K) or NULL = sum_i q_ij (the batch-level f_j of dec.py:73; all-reduce it when sharded).
+ * Limits: D%4==0, D<=256, K<=32. */
+size_t dic_dec_fwd_workspace(int B, int D, int K);
+int dic_dec_fwd(const float* z, const float* centers, int B, int D, int K, float alpha,
+                float* q, float* tsaved, float* colsum,
+                void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* target_distribution (dec.py:66-76) given the (global) column sums. */
+int dic_dec_target(const float* q, const float* colsum, int B, int K, float* p, dic_stream_t stream);
+/* Backward of dic_dec_fwd: grad_q (B,K) -> grad_z (B,D), grad_centers (K,D); OVERWRITTEN. */
+size_t dic_dec_bwd_workspace(int B, int D, int K);
+int dic_dec_bwd(const float* z, const float* centers, const float* q, const float* tsaved,
+                const float* grad_q, int B, int D, int K, float alpha,
+                float* grad_z, float* grad_centers,
+                void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* Fused Net.kl_loss (clustering_interp.py:205-207) forward + d/dq:
+ *   kl_out[0] = sum_ij p (log p - log q) / batch_div ; grad_q (B,K) or NULL = -gscale*p/(batch_div*q). */
+size_t dic_dec_kl_workspace(int B, int K);
+int dic_dec_kl(const float* q, const float* p, int B, int K, float batch_div, float gscale,
+               float* kl_out, float* grad_q,
+               void* workspace, size_t workspace_bytes, dic_stream_t stream);
+
+/* ------------------------------------------------------------------ k4: k-means -----------
+ * Replaces the Lloyd E+M step scikit-learn runs for KMeans.fit/predict at
+ * clustering_trainer.py:75-82, p2_clustering_optK.py:260-389, p4_clustering_final.py:159-174
+ * (sklearn 1.7.2 _k_means_lloyd.pyx:23-218, _k_means_common.pyx:167-311).
+ * `n_runs` independent problems on the SAME data share one launch (restarts / n_init).
+ *   X (N,D) f32 (already mean-centred by the caller, as sklearn does), xnorm (N) = ||x||^2,
+ *   centers (n_runs,K,D) IN/OUT: replaced by the updated centres,
+ *   labels  (n_runs,N) int32 IN/OUT: previous labels in (use -1 before the first call),
+ *   status  (n_runs,DIC_KM_STATUS_WORDS) f32 IN/OUT, zero it before the first iteration:
+ *     [0] done flag (1 = converged: this and later calls are no-ops for the run)
+ *     [1] iterations executed   [2] last center_shift_tot   [3] last #labels changed
+ *     [4] strict-convergence flag [5] relocations performed [6] tol (IN) [7] max_iter (IN)
+ * One call = one Lloyd iteration for every run that is not done: assign by
+ * argmin_j(||c_j||^2 - 2 x.c_j) (first minimum wins), accumulate sums/counts, relocate empty
+ * clusters, average, centre shift, convergence test (labels unchanged -> strict; else
+ * shift_tot <= tol).  Limits: D%4==0, D<=256, K<=32. */
+#define DIC_KM_STATUS_WORDS 8
+size_t dic_kmeans_workspace(int N, int D, int K, int n_runs);
+int dic_kmeans_lloyd_iter(const float* X, const float* xnorm, int N, int D, int K, int n_runs,
+                          float* centers, int32_t* labels, float* status,
+                          void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* E-step only (KMeans.predict; also the final E-step after a tol stop):
+ *   labels (n_runs,N) OVERWRITTEN; mindist (n_runs,N) or NULL = exact ||x-c_label||^2;
+ *   inertia (n_runs) or NULL = sum of mindist (deterministic, f64 accumulation, f32 result). */
+int dic_kmeans_predict(const float* X, int N, int D, int K, int n_runs, const float* centers,
+                       int32_t* labels, float* mindist, float* inertia,
+                       void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* k-means++ helper (sklearn _kmeans.py:218-243 inner step), batched over restarts: L candidate rows
+ * `cand` (int64 indices into X) in groups of `group` consecutive candidates per restart;
+ * closest (L/group, N) = current closest squared distances of each restart (+inf for the first centre);
+ * dist_out (L,N) = min(closest[l/group], ||x_i - X[cand_l]||^2), distances evaluated in f64 like
+ * sklearn's float32 up-cast path; pot_out (L) f64 = sum_i dist_out[l,i]. */
+size_t dic_kmeans_pp_workspace(int N, int L);
+int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, int L, int group,
+                             const float* closest, float* dist_out, double* pot_out,
+                             void* workspace, size_t workspace_bytes, dic_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIC_HIP_H */

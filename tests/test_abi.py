@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the shared object builds/loads and exports exactly the
+symbols include/dic_hip.h declares; argument validation works without a GPU (no compute calls)."""
+import ctypes
+import os
+
+import pytest
+
+from deep_interpolation_clustering_amd import _native as N
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(N.LIB_PATH):
+        N.build()
+    return N.lib()
+
+
+def test_header_and_binding_agree():
+    assert N.header_symbols() == sorted(N.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    raw = ctypes.CDLL(N.LIB_PATH)
+    for name in N.header_symbols():
+        assert hasattr(raw, name), f'{name} declared in dic_hip.h but not exported'
+    assert lib.dic_version() == 1
+
+
+def test_status_strings(lib):
+    assert lib.dic_status_string(0) == b'DIC_OK'
+    assert lib.dic_status_string(-2) == b'DIC_ERR_UNSUPPORTED'
+
+
+def test_argument_validation_without_gpu(lib):
+    # NULL pointers / bad shapes are rejected before any launch
+    assert lib.dic_dec_fwd(None, None, 8, 256, 4, 1.0, None, None, None, None, 0, None) == -1
+    assert b'NULL' in lib.dic_last_error_string()
+    assert lib.dic_dec_fwd(None, None, 8, 258, 4, 1.0, None, None, None, None, 0, None) == -2     # D % 4
+    assert lib.dic_dec_fwd(None, None, 8, 256, 64, 1.0, None, None, None, None, 0, None) == -2    # K > 32
+    assert lib.dic_sci_cci_fwd(None, None, 8, 6, 96, 24, None, None, None, None, None, None) == -1
+    assert lib.dic_kmeans_lloyd_iter(None, None, 0, 256, 4, 1, None, None, None, None, 0, None) == -1
+    assert lib.dic_rbf_fwd(None, None, 8, 40, 96, 24, None, None, None, None, None, None) == -2    # C > 16
+
+
+def test_workspace_queries(lib):
+    assert lib.dic_sci_cci_bwd_workspace(256, 6, 24) > 0
+    assert lib.dic_rbf_bwd_workspace(256, 6, 96, 24) > 0
+    assert lib.dic_dec_fwd_workspace(75000, 256, 4) > 0
+    assert lib.dic_kmeans_workspace(75000, 256, 4, 20) >= 75000 * 20 * 4
+    assert lib.dic_masked_sse_workspace(256, 6, 96) > 0
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from deep_interpolation_clustering_amd import ops
+    z = torch.zeros(4, 256)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.dec_soft_assign(z, torch.zeros(2, 256))

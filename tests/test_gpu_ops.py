@@ -1,0 +1,299 @@
+"""GPU parity tests: HIP kernels (through the C ABI via ops.py) vs the golden vectors captured from
+the reference and vs the CPU oracle on seeded inputs.  Run with ``-m gpu`` on an MI355X."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dic_oracle as O
+from oracle.synth import latent_blobs, vitals_stack
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+INTERP = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'interp_*.npz')))
+RBF = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'rbf_*.npz')))
+DEC = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'dec_K*.npz')))
+
+# fp32 tolerances (north_star: losses within 1e-5 relative; element-wise tensors get a small absolute floor
+# because the kernels use v_exp_f32 / a different summation order than ATen)
+RT, AT = 3e-5, 3e-5
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from deep_interpolation_clustering_amd import ops as _ops
+    return _ops
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def G(a, grad=False, dtype=torch.float32):
+    return torch.tensor(a, dtype=dtype, device='cuda', requires_grad=grad)
+
+
+def prefix_lengths(x, C):
+    """(B,C) int32 lengths if every mask row is a prefix of ones, else None."""
+    m = x[:, C:2 * C]
+    n = m.sum(-1).astype(np.int32)
+    ok = (m == (np.arange(m.shape[-1])[None, None] < n[..., None])).all()
+    return n if ok else None
+
+
+# ------------------------------------------------------------------------------------ k1 golden
+@pytest.mark.parametrize('name', INTERP)
+def test_sci_cci_golden(ops, name):
+    g = load(name)
+    R, H = int(g['R']), float(g['H'])
+    C = g['sci_kernel'].shape[0]
+    grid = ops.ref_grid(H, R, 'cuda')
+    x = G(g['x'])
+    ks, kc = G(g['sci_kernel'], True), G(g['cci_kernel'], True)
+    s = ops.sci_only(x, ks, grid)
+    o = ops.sci_cci(x, ks, kc, grid)
+    o2 = ops.cci(s, kc)
+    np.testing.assert_allclose(s.detach().cpu().numpy(), g['sci_out'], rtol=RT, atol=AT, equal_nan=True)
+    np.testing.assert_allclose(o.detach().cpu().numpy(), g['cci_out'], rtol=RT, atol=AT, equal_nan=True)
+    np.testing.assert_allclose(o2.detach().cpu().numpy(), g['cci_out'], rtol=RT, atol=AT, equal_nan=True)
+    lens = prefix_lengths(g['x'], C)
+    if lens is not None:       # prefix-length fast path == mask path, bit for bit
+        o3 = ops.sci_cci(x, ks, kc, grid, lengths=G(lens, dtype=torch.int32))
+        assert torch.equal(torch.nan_to_num(o3, nan=7.0), torch.nan_to_num(o, nan=7.0))
+    if 'edge' in name:
+        return
+    (o * G(g['cot'])).sum().backward()
+    sc = np.abs(g['g_sci']).max()
+    np.testing.assert_allclose(ks.grad.cpu().numpy(), g['g_sci'], rtol=2e-4, atol=2e-4 * sc)
+    np.testing.assert_allclose(kc.grad.cpu().numpy(), g['g_cci'], rtol=2e-4, atol=2e-4 * np.abs(g['g_cci']).max())
+    # unfused composition cci(sci(x)) gives the same parameter gradients
+    ks2, kc2 = G(g['sci_kernel'], True), G(g['cci_kernel'], True)
+    (ops.cci(ops.sci_only(x, ks2, grid), kc2) * G(g['cot'])).sum().backward()
+    np.testing.assert_allclose(ks2.grad.cpu().numpy(), ks.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * sc)
+    np.testing.assert_allclose(kc2.grad.cpu().numpy(), kc.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * np.abs(g['g_cci']).max())
+
+
+def test_sci_cci_ragged_packed_matches_dense(ops):
+    from deep_interpolation_clustering_amd import _native as N
+    B, C, T, R, H = 37, 6, 96, 24, 24
+    x, n = vitals_stack(11, B, C, T, H, 50)
+    grid = ops.ref_grid(H, R, 'cuda')
+    ks = G(np.linspace(-0.3, 1.1, C).astype(np.float32))
+    kc = G((np.eye(C) + 0.1 * np.random.default_rng(3).normal(size=(C, C))).astype(np.float32))
+    dense = ops.sci_cci(G(x), ks, kc, grid, lengths=G(n, dtype=torch.int32))
+    off = np.zeros(B * C + 1, np.int64)
+    off[1:] = np.cumsum(n.reshape(-1))
+    tp = np.concatenate([x[b, 2 * C + c, :n[b, c]] for b in range(B) for c in range(C)])
+    vp = np.concatenate([x[b, c, :n[b, c]] for b in range(B) for c in range(C)])
+    out = torch.empty_like(dense)
+    tpk, vpk, offd = G(tp), G(vp), torch.tensor(off, device='cuda')
+    N.check(N.lib().dic_sci_cci_fwd_ragged(N.ptr(tpk), N.ptr(vpk), N.ptr(offd), int(n.max()), B, C, R, N.ptr(grid),
+                                           N.ptr(ks), N.ptr(kc), N.ptr(out), None, N.stream_of(out)), 'ragged')
+    assert torch.equal(out, dense)
+
+
+@pytest.mark.parametrize('shape', [(64, 6, 96, 24, 24, 50), (300, 6, 354, 6, 6, 60), (33, 12, 288, 24, 24, 200),
+                                   (1, 6, 96, 24, 24, 50), (517, 3, 40, 9, 12, 20), (5, 16, 64, 64, 24, 30)])
+def test_sci_cci_vs_oracle(ops, shape):
+    B, C, T, R, H, lam = shape
+    x, n = vitals_stack(5 + B, B, C, T, H, lam)
+    rng = np.random.default_rng(B)
+    ks_np = rng.uniform(-0.5, 1.5, C).astype(np.float32)
+    kc_np = (np.eye(C) + rng.normal(0, 0.2, (C, C))).astype(np.float32)
+    cot_np = rng.normal(0, 1, (B, R, 3 * C)).astype(np.float32)
+    grid = ops.ref_grid(H, R, 'cuda')
+    ks, kc = G(ks_np, True), G(kc_np, True)
+    out = ops.sci_cci(G(x), ks, kc, grid, lengths=G(n, dtype=torch.int32))
+    (out * G(cot_np)).sum().backward()
+    # oracle in fp64: the kernel must be at least as close to it as fp32 rounding allows
+    x64 = torch.tensor(x, dtype=torch.float64)
+    k1, k2 = torch.tensor(ks_np, dtype=torch.float64, requires_grad=True), torch.tensor(kc_np, dtype=torch.float64, requires_grad=True)
+    ref = O.sci_cci_forward(x64, k1, k2, R, H)
+    (ref * torch.tensor(cot_np, dtype=torch.float64)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=AT)
+    sc = float(k1.grad.abs().max())
+    np.testing.assert_allclose(ks.grad.cpu().numpy(), k1.grad.numpy(), rtol=2e-4, atol=2e-4 * sc)
+    np.testing.assert_allclose(kc.grad.cpu().numpy(), k2.grad.numpy(), rtol=2e-4, atol=2e-4 * float(k2.grad.abs().max()))
+
+
+# ------------------------------------------------------------------------------------ k2 golden
+@pytest.mark.parametrize('name', RBF)
+def test_rbf_golden(ops, name):
+    g = load(name)
+    R, H = int(g['R']), float(g['H'])
+    C = g['kernel'].shape[0]
+    grid = ops.ref_grid(H, R, 'cuda')
+    x = G(g['x'])
+    v, k = G(g['v'], True), G(g['kernel'], True)
+    y = ops.rbf_deinterp(v, x, k, grid)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g['y'], rtol=RT, atol=3e-6)
+    mask = x[:, C:2 * C]
+    loss = ops.masked_mse(G(g['ob']), y, mask)
+    np.testing.assert_allclose(float(loss), float(g['loss']), rtol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(v.grad.cpu().numpy(), g['g_v'], rtol=2e-4, atol=2e-6 * np.abs(g['g_v']).max() + 1e-9)
+    np.testing.assert_allclose(k.grad.cpu().numpy(), g['g_kernel'], rtol=3e-4, atol=3e-5 * np.abs(g['g_kernel']).max())
+    lens = prefix_lengths(g['x'], C)
+    if lens is not None:
+        ld = G(lens, dtype=torch.int32)
+        v2, k2 = G(g['v'], True), G(g['kernel'], True)
+        y2 = ops.rbf_deinterp(v2, x, k2, grid, lengths=ld)
+        assert torch.equal(y2, y)
+        l2 = ops.masked_mse(G(g['ob']), y2, None, lengths=ld)
+        np.testing.assert_allclose(float(l2), float(loss), rtol=1e-6)
+        l2.backward()
+        np.testing.assert_allclose(v2.grad.cpu().numpy(), v.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(k2.grad.cpu().numpy(), k.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('shape', [(64, 6, 96, 24, 24, 50), (130, 6, 354, 6, 6, 60), (9, 12, 288, 24, 24, 200), (1, 6, 30, 11, 6, 9)])
+def test_rbf_vs_oracle(ops, shape):
+    B, C, T, R, H, lam = shape
+    x, n = vitals_stack(77 + B, B, C, T, H, lam)
+    rng = np.random.default_rng(B)
+    v_np = rng.normal(0, 1, (B, C, R)).astype(np.float32)
+    k_np = rng.uniform(-0.5, 1.5, C).astype(np.float32)
+    cot = rng.normal(0, 1, (B, C, T)).astype(np.float32)
+    grid = ops.ref_grid(H, R, 'cuda')
+    v, k = G(v_np, True), G(k_np, True)
+    y = ops.rbf_deinterp(v, G(x), k, grid, lengths=G(n, dtype=torch.int32))
+    (y * G(cot)).sum().backward()
+    v64 = torch.tensor(v_np, dtype=torch.float64, requires_grad=True)
+    k64 = torch.tensor(k_np, dtype=torch.float64, requires_grad=True)
+    ref = O.rbf_deinterp(v64, torch.tensor(x, dtype=torch.float64), k64, R, H)
+    (ref * torch.tensor(cot, dtype=torch.float64)).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=3e-6)
+    np.testing.assert_allclose(v.grad.cpu().numpy(), v64.grad.numpy(), rtol=2e-4, atol=2e-5 * float(v64.grad.abs().max()))
+    np.testing.assert_allclose(k.grad.cpu().numpy(), k64.grad.numpy(), rtol=3e-4, atol=3e-5 * float(k64.grad.abs().max()))
+
+
+# ------------------------------------------------------------------------------------ k3 golden
+@pytest.mark.parametrize('name', DEC)
+def test_dec_golden(ops, name):
+    g = load(name)
+    z, mu = G(g['z'], True), G(g['mu'], True)
+    q, colsum = ops.dec_soft_assign(z, mu, 1.0, return_colsum=True)
+    p = ops.dec_target(q, colsum)
+    np.testing.assert_allclose(q.detach().cpu().numpy(), g['q'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(colsum.cpu().numpy(), g['q'].sum(0), rtol=1e-5)
+    np.testing.assert_allclose(p.cpu().numpy(), g['p'], rtol=2e-5, atol=1e-7)
+    kl = ops.kl_batchmean(p, q)
+    np.testing.assert_allclose(float(kl), float(g['kl']), rtol=1e-5, atol=1e-8)
+    kl.backward()
+    np.testing.assert_allclose(z.grad.cpu().numpy(), g['g_z'], rtol=2e-4, atol=2e-6 * np.abs(g['g_z']).max())
+    np.testing.assert_allclose(mu.grad.cpu().numpy(), g['g_mu'], rtol=2e-4, atol=2e-5 * np.abs(g['g_mu']).max())
+    # predicted label = argmax q = argmin distance (clustering_trainer.py:477): exact
+    assert (q.argmax(1).cpu().numpy() == g['q'].argmax(1)).all()
+
+
+@pytest.mark.parametrize('B,D,K,alpha', [(1000, 256, 4, 1.0), (777, 256, 20, 1.0), (64, 128, 3, 2.5), (5, 256, 32, 1.0), (4099, 64, 7, 0.5)])
+def test_dec_vs_oracle(ops, B, D, K, alpha):
+    X, _ = latent_blobs(B + K, B, D, K, spread=0.3, noise=0.2)
+    rng = np.random.default_rng(K)
+    mu_np = (X[rng.choice(B, K, replace=False)] + rng.normal(0, 0.05, (K, D))).astype(np.float32)
+    cot = rng.normal(0, 1, (B, K)).astype(np.float32)
+    z, mu = G(X, True), G(mu_np, True)
+    q = ops.dec_soft_assign(z, mu, alpha)
+    (q * G(cot)).sum().backward()
+    z64 = torch.tensor(X, dtype=torch.float64, requires_grad=True)
+    m64 = torch.tensor(mu_np, dtype=torch.float64, requires_grad=True)
+    ref = O.dec_soft_assign(z64, m64, alpha)
+    (ref * torch.tensor(cot, dtype=torch.float64)).sum().backward()
+    np.testing.assert_allclose(q.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(z.grad.cpu().numpy(), z64.grad.numpy(), rtol=2e-4, atol=2e-6 * float(z64.grad.abs().max()))
+    np.testing.assert_allclose(mu.grad.cpu().numpy(), m64.grad.numpy(), rtol=2e-4, atol=2e-5 * float(m64.grad.abs().max()))
+    p = ops.dec_target(q.detach())
+    np.testing.assert_allclose(p.cpu().numpy(), O.dec_target(ref.detach()).numpy(), rtol=5e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------ k4
+def _label_audit(X, centers, got, want):
+    """Labels must agree except where the fp64 margin between the two best centres is below fp32 resolution."""
+    bad = np.nonzero(got != want)[0]
+    if bad.size == 0:
+        return 0
+    d = ((X[bad, None, :].astype(np.float64) - centers[None].astype(np.float64)) ** 2).sum(-1)
+    d.sort(axis=1)
+    margin = (d[:, 1] - d[:, 0]) / np.maximum(d[:, 1], 1e-30)
+    assert (margin < 1e-5).all(), f'{bad.size} label mismatches with a decisive fp64 margin (max {margin.max():.3e})'
+    return bad.size
+
+
+@pytest.mark.parametrize('K', [4, 16])
+def test_kmeans_golden_fixed_init(K):
+    from deep_interpolation_clustering_amd.kmeans import KMeans
+    g = load(f'kmeans_K{K}.npz')
+    X, _ = latent_blobs(int(g['seed']), int(g['N']), int(g['D']), K)
+    km = KMeans(n_clusters=K, init=X[g['init_idx']].copy(), n_init=1).fit(X)
+    assert (km.labels_ == g['labels']).all()          # bit-exact assignments for a fixed init
+    np.testing.assert_allclose(km.cluster_centers_, g['centers'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(km.inertia_, float(g['inertia']), rtol=1e-5)
+    assert km.n_iter_ == int(g['n_iter'])
+    Xv, _ = latent_blobs(int(g['seed']) + 1, 500, int(g['D']), K, centers_seed=int(g['seed']))
+    assert (km.predict(Xv) == g['pred']).all()
+
+
+@pytest.mark.parametrize('N,D,K', [(20000, 256, 8), (5000, 256, 2), (3001, 64, 20), (1500, 6, 3), (900, 256, 32)])
+def test_kmeans_vs_sklearn_fixed_init(N, D, K):
+    from sklearn.cluster import KMeans as SK
+    from deep_interpolation_clustering_amd.kmeans import KMeans
+    X, _ = latent_blobs(N + K, N, D, max(2, K // 2), spread=0.3, noise=0.3)     # fewer blobs than K: slow, tie-prone Lloyd
+    init = X[np.random.default_rng(K).choice(N, K, replace=False)].copy()
+    ref = SK(n_clusters=K, init=init, n_init=1).fit(X)
+    km = KMeans(n_clusters=K, init=init, n_init=1).fit(X)
+    _label_audit(X, ref.cluster_centers_, km.labels_, ref.labels_)
+    np.testing.assert_allclose(km.inertia_, ref.inertia_, rtol=2e-5)
+    np.testing.assert_allclose(km.cluster_centers_, ref.cluster_centers_, rtol=1e-4, atol=1e-5)
+    assert abs(km.n_iter_ - ref.n_iter_) <= 1
+    Xv, _ = latent_blobs(N + K + 1, 777, D, max(2, K // 2), centers_seed=N + K, spread=0.3, noise=0.3)
+    _label_audit(Xv, ref.cluster_centers_, km.predict(Xv), ref.predict(Xv))
+
+
+def test_kmeans_plusplus_restarts_quality():
+    """n_init=20 k-means++ (NumPy global RandomState, as set_seed does upstream): the seeding consumes the same
+    random stream as scikit-learn; the result must be an equally good optimum (same inertia to 1e-4, same partition
+    up to label permutation on well-separated data)."""
+    from sklearn.cluster import KMeans as SK
+    from sklearn.metrics import adjusted_rand_score
+    from deep_interpolation_clustering_amd.kmeans import KMeans
+    X, comp = latent_blobs(99, 30000, 256, 4, spread=0.5, noise=0.25)
+    np.random.seed(7529)
+    ref = SK(n_clusters=4, n_init=20).fit(X)
+    np.random.seed(7529)
+    km = KMeans(n_clusters=4, n_init=20).fit(X)
+    np.testing.assert_allclose(km.inertia_, ref.inertia_, rtol=1e-4)
+    assert adjusted_rand_score(ref.labels_, km.labels_) > 0.9999
+    assert adjusted_rand_score(comp, km.labels_) > 0.99
+
+
+def test_kmeans_empty_cluster_relocation():
+    """An initial centre far from all data gets no points: it must be relocated to the farthest point (sklearn
+    _relocate_empty_clusters_dense), and the fit must still match sklearn."""
+    from sklearn.cluster import KMeans as SK
+    from deep_interpolation_clustering_amd.kmeans import KMeans
+    X, _ = latent_blobs(5, 4000, 256, 3, spread=0.4, noise=0.2)
+    init = X[[0, 1, 2, 3]].copy()
+    init[3] += 50.0
+    ref = SK(n_clusters=4, init=init, n_init=1).fit(X)
+    km = KMeans(n_clusters=4, init=init, n_init=1).fit(X)
+    assert km._status[0, 5] >= 1                      # a relocation happened
+    _label_audit(X, ref.cluster_centers_, km.labels_, ref.labels_)
+    np.testing.assert_allclose(km.inertia_, ref.inertia_, rtol=2e-5)
+
+
+def test_kmeans_full_size_properties():
+    """75k x 256 (BASELINE size): idempotence of the E-step and optimality conditions of the fixed point."""
+    from deep_interpolation_clustering_amd.kmeans import KMeans
+    X, _ = latent_blobs(2024, 75000, 256, 4, spread=0.35, noise=0.3)
+    np.random.seed(1)
+    km = KMeans(n_clusters=4, n_init=3).fit(X)
+    lab = km.predict(X)
+    assert (lab == km.labels_).all()                                   # predict(fit data) == labels_
+    cent = np.stack([X[lab == k].mean(0) for k in range(4)])
+    np.testing.assert_allclose(cent, km.cluster_centers_, rtol=0, atol=5e-5)   # centres are the cluster means
+    d = ((X[:2000, None] - km.cluster_centers_[None]) ** 2).sum(-1)
+    assert (d.argmin(1) == lab[:2000]).all()
+    np.testing.assert_allclose(km.inertia_, ((X - km.cluster_centers_[lab]) ** 2).sum(dtype=np.float64), rtol=1e-5)
