@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encounters/sec through one joint interp+DEC training step (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 30 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 75 000 synthetic encounters, 6 vitals, ~50 irregular samples per
+channel over 24 h (T=96 padded slots), R=24 reference points, K=4 clusters.  The cohort is resident in
+HBM before the timed region; one step = zero_grad -> Net.forward (HIP interp, bi-LSTM enc/dec, HIP
+de-interp, HIP DEC) -> ae_mse + 10*kl -> backward -> RCCL gradient all-reduce -> clip 15 -> Adam(amsgrad)
+on a per-GPU batch of --batch encounters (weak scaling: the per-GPU batch is fixed as N grows).
+
+Besides the contract line it reports, for the dominant hand-written kernel, achieved algorithmic HBM GB/s
+(HIP-event timed on the launch stream) against the 8 TB/s peak, a per-kernel table, and the CPU oracle
+("port" of the reference path, oracle/dic_oracle.py) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+C, T, H, LAM, R, D = 6, 96, 24.0, 50.0, 24, 256
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=30)
+    p.add_argument('--warmup', type=int, default=10)
+    p.add_argument('--batch', type=int, default=int(os.environ.get('DIC_BENCH_BATCH', 8192)), help='encounters per GPU per step')
+    p.add_argument('--encounters', type=int, default=75000, help='cohort size resident per GPU')
+    p.add_argument('--clusters', type=int, default=None, help='K (default 4; 8 for the 8-GPU config)')
+    p.add_argument('--dtype', choices=['bf16', 'f32'], default=os.environ.get('DIC_BENCH_DTYPE', 'bf16'),
+                   help='bf16: autocast for the bi-LSTMs / FC heads (HIP kernels stay f32)')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=15.0)
+    p.add_argument('--kernel-iters', type=int, default=20)
+    return p.parse_args()
+
+
+def make_args(K):
+    return SimpleNamespace(num_variables=C, num_timestamps=T, ref_points=R, hours_from_admission=H, dropout=0.0,
+                           aux_tasks={}, fake_detection=False, triple_margin=0.0, cluster_number=K, loss='ae_mse_kl',
+                           grad_clip=15.0, unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.},
+                           aux_pos_weights={})
+
+
+def time_kernel(fn, iters):
+    """Average duration (ms) of fn() -- one or more launches on torch's current HIP stream -- by HIP events."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_table(net, x, ob, lengths, K, iters):
+    """Per hand-written kernel: algorithmic bytes (SURVEY.md 8d formulas, ragged accounting) / HIP-event time."""
+    from deep_interpolation_clustering_amd import _native as N
+    from deep_interpolation_clustering_amd import ops
+    L = N.lib()
+    B = x.shape[0]
+    dev = x.device
+    nsum = float(lengths.sum())                  # sum over (b,c) of observed samples
+    grid = net.sci.grid()
+    sk, ck, rk = net.sci.kernel.detach(), net.cci.kernel.detach(), net.rbf.kernel.detach()
+    st = N.stream_of(x)
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = torch.empty((B, R, 3 * C), **f32)
+    saved = torch.empty((B, 7, C, R), **f32)
+    gout = torch.randn((B, R, 3 * C), **f32)
+    gs, gc = torch.empty(C, **f32), torch.empty((C, C), **f32)
+    ws1 = torch.empty(max(16, L.dic_sci_cci_bwd_workspace(B, C, R)), dtype=torch.uint8, device=dev)
+    v = torch.randn((B, C, R), **f32)
+    y, norm, gy = torch.empty((B, C, T), **f32), torch.empty((B, C, T), **f32), torch.randn((B, C, T), **f32)
+    gv, gk = torch.empty((B, C, R), **f32), torch.empty(C, **f32)
+    ws2 = torch.empty(max(16, L.dic_rbf_bwd_workspace(B, C, T, R)), dtype=torch.uint8, device=dev)
+    out2, gl = torch.empty(2, **f32), torch.ones(1, **f32)
+    ws3 = torch.empty(max(16, L.dic_masked_sse_workspace(B, C, T)), dtype=torch.uint8, device=dev)
+    z, mu = torch.randn((B, D), **f32) * 0.3, torch.randn((K, D), **f32) * 0.3
+    q, ts, colsum, p = torch.empty((B, K), **f32), torch.empty((B, K), **f32), torch.empty(K, **f32), torch.empty((B, K), **f32)
+    gq, gz, gmu = torch.randn((B, K), **f32), torch.empty((B, D), **f32), torch.empty((K, D), **f32)
+    ws4 = torch.empty(max(16, L.dic_dec_fwd_workspace(B, D, K)), dtype=torch.uint8, device=dev)
+    ws5 = torch.empty(max(16, L.dic_dec_bwd_workspace(B, D, K)), dtype=torch.uint8, device=dev)
+    P = N.ptr
+    calls = {
+        'sci_cci_fwd': (lambda: L.dic_sci_cci_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(sk), P(ck), P(out), P(saved), st),
+                        8 * nsum + 4 * B * C + 12 * B * C * R),
+        'sci_cci_bwd': (lambda: L.dic_sci_cci_bwd(P(gout), P(saved), P(sk), P(ck), B, C, R, P(gs), P(gc), P(ws1), ws1.numel(), st),
+                        8 * nsum + 24 * B * C * R),
+        'rbf_fwd': (lambda: L.dic_rbf_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(rk), P(v), P(y), P(norm), st),
+                    12 * nsum + 4 * B * C * R),
+        'rbf_bwd': (lambda: L.dic_rbf_bwd(P(x), P(lengths), B, C, T, R, P(grid), P(rk), P(v), P(y), P(norm), P(gy), P(gv), P(gk),
+                                          P(ws2), ws2.numel(), st), 8 * nsum + 8 * B * C * R),
+        'masked_sse_fwd': (lambda: L.dic_masked_sse_fwd(P(ob), P(y), None, P(lengths), B, C, T, P(out2), P(ws3), ws3.numel(), st),
+                           8 * nsum),
+        'masked_sse_bwd': (lambda: L.dic_masked_sse_bwd(P(ob), P(y), None, P(lengths), B, C, T, P(out2), P(gl), P(gy), st),
+                           12 * nsum),
+        'dec_fwd': (lambda: L.dic_dec_fwd(P(z), P(mu), B, D, K, 1.0, P(q), P(ts), P(colsum), P(ws4), ws4.numel(), st),
+                    4.0 * B * (D + 2 * K)),
+        'dec_bwd': (lambda: L.dic_dec_bwd(P(z), P(mu), P(q), P(ts), P(gq), B, D, K, 1.0, P(gz), P(gmu), P(ws5), ws5.numel(), st),
+                    4.0 * B * (2 * D + 2 * K)),
+    }
+    # run the forwards once so the backward inputs (saved, y, norm, out2, ts) hold real values
+    for name in ('sci_cci_fwd', 'rbf_fwd', 'masked_sse_fwd', 'dec_fwd'):
+        assert calls[name][0]() == 0, name
+    table = {}
+    for name, (fn, nbytes) in calls.items():
+        ms = time_kernel(fn, iters)
+        table[name] = {'ms': round(ms, 5), 'algorithmic_bytes': int(nbytes), 'GBps': round(nbytes / ms / 1e6, 1),
+                       'frac_hbm_peak': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return table
+
+
+def cpu_baseline(K, seconds):
+    """The CPU oracle (a port of the reference's PyTorch path: oracle/dic_oracle.py) timed on this host."""
+    from deep_interpolation_clustering_amd import synthetic
+    from oracle import dic_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get('DIC_CPU_THREADS', 16))))    # the GPU box grants ~16 cores per GPU
+    torch.set_num_threads(cores)
+    B = 256                                          # the reference's own batch size (p1_pretrain_main.py:43)
+    coh = synthetic.make_cohort(B, C=C, T=T, H=H, lam=LAM, G=K, seed=99)
+    x_np, ob_np, _ = synthetic.stacked_batch(coh)
+    x, ob = torch.tensor(x_np), torch.tensor(ob_np)
+    torch.manual_seed(0)
+    net = O.OracleNet(C, R, H, K, 0.0)
+    net.train()
+    opt = O.make_optimizer(net)
+    for _ in range(2):
+        O.train_step(net, opt, x, ob, x[:, C:2 * C], 10.0, 15.0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.train_step(net, opt, x, ob, x[:, C:2 * C], 10.0, 15.0)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {'value': round(B * n / el, 1), 'unit': 'encounters/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} joint steps of B={B} (C={C}, T={T}, R={R}, K={K}, f32) on torch-CPU, {el:.1f} s',
+            'ms_per_step': round(1e3 * el / n, 2)}
+
+
+def log(*msg):
+    print('[bench]', *msg, file=sys.stderr, flush=True)
+
+
+def main():
+    a = parse()
+    t_start = time.perf_counter()
+    from deep_interpolation_clustering_amd import dist, synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    import torch.distributed as td
+
+    rank, world, local = dist.init_from_env()
+    if a.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU implementation')
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    K = a.clusters or (8 if world == 8 else 4)
+    args = make_args(K)
+
+    # ---- cohort shard, resident in HBM before anything is timed
+    n_enc = max(a.encounters, a.batch)
+    coh = synthetic.make_cohort(n_enc, C=C, T=T, H=H, lam=LAM, G=K, seed=synthetic.SEED + rank)
+    x_np, ob_np, len_np = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(len_np, device=dev)
+    del coh, x_np, ob_np
+    nb = n_enc // a.batch
+    log(f'rank {rank}: cohort of {n_enc} encounters resident after {time.perf_counter() - t_start:.1f}s')
+
+    torch.manual_seed(1234)
+    net = Net(args, dev).to(dev)
+    net.train()
+    stepper = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args,
+                      autocast_dtype=torch.bfloat16 if a.dtype == 'bf16' else None)
+
+    def one_step(i):
+        lo = (i % nb) * a.batch
+        return stepper.step(X[lo:lo + a.batch], OB[lo:lo + a.batch], None, LEN[lo:lo + a.batch])
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        losses, gnorm, _ = one_step(a.warmup + i)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        el = float(tt)
+    final_loss = float(losses['loss'].detach())
+    log(f'{a.steps} steps in {el:.3f}s ({1e3 * el / a.steps:.2f} ms/step), loss {final_loss:.5f}')
+
+    if rank == 0:
+        ms = 1e3 * el / a.steps
+        value = world * a.batch * a.steps / el
+        lo = 0
+        table = kernel_table(net, X[lo:lo + a.batch], OB[lo:lo + a.batch], LEN[lo:lo + a.batch], K, a.kernel_iters)
+        dom = max(table, key=lambda k: table[k]['ms'])
+        log('kernel table done:', {k: v['ms'] for k, v in table.items()})
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'traffic.json')      # PMC-derived HBM bytes per launch, when collected
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(dom)
+        custom_ms = sum(v['ms'] for v in table.values())
+        out = {
+            'metric': 'encounters/sec per joint interp+DEC step', 'value': round(value, 1), 'unit': 'encounters/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': a.dtype, 'dtype_note': 'HIP kernels compute in f32; bf16 = torch.autocast for the bi-LSTMs / FC heads only',
+            'data': 'synthetic',
+            'config': {'workload': f'{n_enc} synthetic encounters/GPU, 6 vitals, ~50 irregular samples per channel per 24h '
+                                   f'(T={T}), R={R}, K={K}, loss ae_mse+10*kl', 'per_gpu_batch': a.batch,
+                       'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single'},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': table[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': table[dom]['frac_hbm_peak'], 'traffic': traffic},
+            'kernels': table,
+            'step_breakdown': {'hip_kernels_ms': round(custom_ms, 3), 'rest_ms(lstm,fc,optimizer,launch)': round(ms - custom_ms, 3)},
+            'final_loss': final_loss,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(K, a.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,185 @@
+"""Shared body of the two ``Net`` variants (clustering_interp.py:14-247, pretrain_interp.py:14-215).
+
+Layer inventory and ``state_dict`` keys are upstream's: ``sci.kernel``, ``cci.kernel``,
+``encoder.lstm.*``, ``decoder.lstm.*``, ``rbf.kernel``, ``rbf.compress_fc.module.model.{0,1,4}.*``,
+optional ``predict_future / aux_head / fake_det_head`` ``.model.*`` and (clustering only)
+``cluster_assignment.cluster_centers`` -- checkpoints are interchangeable with the reference's.
+
+What runs where: interpolation (k1), de-interpolation (k2), reconstruction loss, DEC soft assignment,
+target and KL (k3) are HIP kernels; the two bi-LSTMs and the small FC heads are PyTorch-ROCm
+(MIOpen / hipBLASLt).  Differences from upstream that do not change results: the fake / positive
+branches share ONE encoder call with the real batch (rows are independent in sci, cci and the LSTM),
+and BatchNorm uses global-batch moments when the batch is sharded over ranks.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import dist, ops
+from .dec import ClusterAssignment, target_distribution
+from .interpolation_layer import CrossChannelInterp, SingleChannelInterp, fused_forward
+from .rbf import RBF, basis_func_dict
+from .utils import logger
+
+
+class EncoderRNN(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers, dropout, bidirectional, device):
+        super().__init__()
+        self.device, self.hidden_size, self.num_layers = device, hidden_size, num_layers
+        self.num_directions = 2 if bidirectional else 1
+        self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
+
+    def forward(self, x):
+        output, (hidden, cell_state) = self.lstm(x)
+        return output, hidden, cell_state
+
+
+class DecoderRNN(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers, dropout, bidirectional, device):
+        super().__init__()
+        self.device, self.hidden_size = device, hidden_size
+        self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
+
+    def forward(self, x, hidden, context):
+        x, (hidden, cell_state) = self.lstm(F.relu(x), (hidden, context))      # clustering_interp.py:38-41
+        return x, (hidden, cell_state)
+
+
+class _Head(nn.Module):
+    """Linear(256,128) -> BN -> Dropout -> Linear(128,odim) [-> tail]; clustering_interp.py:43-87."""
+
+    def __init__(self, idim, odim, dropout, tail=None):
+        super().__init__()
+        layers = [nn.Linear(idim, 128), nn.BatchNorm1d(128), nn.Dropout(dropout), nn.Linear(128, odim)]
+        if tail is not None:
+            layers.append(tail)
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class AuxFc(_Head):
+    def __init__(self, idim, odim, dropout):
+        super().__init__(idim, odim, dropout)
+
+
+class FuturePredFc(_Head):
+    def __init__(self, idim, odim, dropout):
+        super().__init__(idim, odim, dropout, nn.Sigmoid())
+
+
+class FakeDetFc(_Head):
+    def __init__(self, idim, odim, dropout):
+        super().__init__(idim, odim, dropout, nn.LogSoftmax(dim=1))
+
+
+class NetBase(nn.Module):
+    clustering = False
+
+    def __init__(self, args, device):
+        super().__init__()
+        self.device, self.args = device, args
+        self.num_variables, self.num_timestamps = args.num_variables, args.num_timestamps
+        self.nhidden, self.nlstm, self.bidirectional = 128, 1, True
+        self.dim_enc_hidden = self.nlstm * self.nhidden * (2 if self.bidirectional else 1)
+        self.dim_dec_out = self.nhidden * (2 if self.bidirectional else 1)
+        C = self.num_variables
+        self.sci = SingleChannelInterp(args.ref_points, args.hours_from_admission, C, self.num_timestamps, device)
+        self.cci = CrossChannelInterp(C, self.num_timestamps, device)
+        self.encoder = EncoderRNN(3 * C, self.nhidden, self.nlstm, 0, self.bidirectional, device)
+        self.decoder = DecoderRNN(self.nhidden * 2, self.nhidden, self.nlstm, 0, self.bidirectional, device)
+        self.rbf = RBF(hours_look_ahead=args.hours_from_admission, ref_points=args.ref_points, in_dim=self.dim_dec_out,
+                       out_dim=C, dropout=args.dropout, basis_func=basis_func_dict()['gaussian'], device=device)
+        n_aux = len(args.aux_tasks)
+        if 'future_vital' in args.aux_tasks:
+            self.predict_future = FuturePredFc(self.dim_enc_hidden, C, args.dropout)
+            n_aux -= 1
+        if n_aux > 0:
+            self.aux_head = AuxFc(self.dim_enc_hidden, n_aux, args.dropout)
+        if args.fake_detection:
+            self.fake_det_head = FakeDetFc(self.dim_enc_hidden, 2, args.dropout)
+        if self.clustering:
+            self.cluster_assignment = ClusterAssignment(args.cluster_number, self.dim_enc_hidden, 1.0)
+        dist.convert_batchnorm_(self)
+
+    # ------------------------------------------------------------------------------ forward
+    def _interp(self, x, lengths=None):
+        return fused_forward(self.sci, self.cci, x, lengths)             # (B,R,3C), one launch
+
+    def forward(self, x, fake_x=None, fake_perm_idx=None, positive_x=None, lengths=None):
+        """x (B,4C,T) -> (cat_hidden (B,256), rec (B,C,T), aux_pred_dict); clustering_interp.py:134-189.
+        ``lengths`` (B,C) int32 is an optional side channel: prefix lengths of the padding mask."""
+        args = self.args
+        B = x.size(0)
+        feats = [self._interp(x, lengths)]
+        want_fake = bool(args.fake_detection)
+        want_pos = self.clustering and args.triple_margin != 0. and want_fake
+        if want_fake:
+            feats.append(self._interp(fake_x, lengths))
+        if want_pos:
+            feats.append(self._interp(positive_x, lengths))
+        seq = (feats[0] if len(feats) == 1 else torch.cat(feats, dim=0)).permute(1, 0, 2)     # (R, nB, 3C)
+        context, hidden, cell = self.encoder(seq)
+        z_all = torch.cat([h for h in hidden], dim=-1)                    # (nB, 256)
+        cat_hidden = z_all[:B]
+        if len(feats) > 1:
+            context, hidden, cell = context[:, :B], hidden[:, :B].contiguous(), cell[:, :B].contiguous()
+        y, _ = self.decoder(context, hidden, cell)
+        y = self.rbf(y.permute(1, 2, 0), x, lengths)                      # (B,C,T)
+
+        aux = dict()
+        n_aux = len(args.aux_tasks)
+        if 'future_vital' in args.aux_tasks:
+            aux['future_vital'] = self.predict_future(cat_hidden)
+            n_aux -= 1
+        if n_aux > 0:
+            pred = self.aux_head(cat_hidden)
+            for i, task in enumerate(t for t in args.aux_tasks.keys() if t != 'future_vital'):
+                aux[task] = pred[:, i]
+        if want_fake:
+            fake_hidden = z_all[B:2 * B]
+            aux['fake_det'] = self.fake_det_head(torch.cat([cat_hidden, fake_hidden], dim=0)[fake_perm_idx])
+        if want_pos:
+            aux['positive'] = z_all[2 * B:3 * B]
+            aux['negative'] = z_all[B:2 * B]
+        if self.clustering:
+            q = self.cluster_assignment(cat_hidden)
+            _, colsum = self.cluster_assignment.last_colsum
+            aux['cluster_pred'] = q
+            aux['cluster_label'] = target_distribution(q, colsum).detach()
+        return cat_hidden, y, aux
+
+    # ------------------------------------------------------------------------------ losses
+    def rec_loss(self, org_ob, rec_ob, padding_mask, lengths=None):
+        """Masked SSE / #observed over the global batch (clustering_interp.py:197-203), one HIP reduction."""
+        mse = ops.masked_mse(org_ob, rec_ob, padding_mask, lengths)
+        return {'loss': mse, 'ae_mse': mse}
+
+    def sup_aux_loss(self, aux_tasks, aux_label_dict, aux_pred_dict, future_vital_mask=None):
+        out = dict()
+        if 'future_vital' in aux_tasks:
+            m = future_vital_mask
+            sse = F.mse_loss(aux_pred_dict['future_vital'] * m, aux_label_dict['future_vital'] * m, reduction='sum')
+            cnt = (m == 1.0).sum().to(sse.dtype)
+            out['future_vital'] = sse / dist.all_reduce_sum_(cnt.clone())
+        for task in aux_tasks:
+            if task == 'future_vital':
+                continue
+            pw = torch.tensor(self.args.aux_pos_weights[task]).to(self.device)
+            out[task] = F.binary_cross_entropy_with_logits(aux_pred_dict[task], aux_label_dict[task], pos_weight=pw) \
+                / dist.world_size()
+        return out
+
+    def fake_det_loss(self, label, pred):
+        return {'fake_detection': F.nll_loss(pred, label, reduction='mean') / dist.world_size()}
+
+    def multi_task_loss(self, aux_tasks, rec_loss_dict, aux_loss_dict):
+        """ae_mse + sum_k w_k * loss_k (clustering_interp.py:239-247)."""
+        loss = rec_loss_dict['ae_mse']
+        for name, value in aux_loss_dict.items():
+            loss = loss + aux_tasks[name] * value
+            logger.debug('Aux loss {}:{}, w:{}'.format(name, value, aux_tasks[name]))
+        rec_loss_dict['loss'] = loss
+        rec_loss_dict.update(aux_loss_dict)
+        return rec_loss_dict

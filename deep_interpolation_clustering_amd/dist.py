@@ -104,3 +104,66 @@ class FlatParams:
     def broadcast_(self, src: int = 0):
         if is_sharded():
             td.broadcast(self.flat, src=src)
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm over the GLOBAL batch.  The reference's heads (rbf.py:118, clustering_interp.py:50,65,80)
+# normalise with whole-batch moments on one device; when the batch is sharded each rank must use the
+# same moments or the sharded step stops being the single-device step.
+class _SyncBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        F_ = x.shape[1]
+        stats = torch.empty(2 * F_ + 1, device=x.device, dtype=torch.float32)
+        xf = x.float()
+        stats[:F_] = xf.sum(0)
+        stats[F_:2 * F_] = (xf * xf).sum(0)
+        stats[2 * F_] = x.shape[0]
+        all_reduce_sum_(stats)
+        n = stats[2 * F_]
+        mean = stats[:F_] / n
+        var = (stats[F_:2 * F_] / n - mean * mean).clamp_min_(0)
+        rstd = torch.rsqrt(var + eps)
+        xhat = (xf - mean) * rstd
+        ctx.save_for_backward(xhat, rstd, weight, n)
+        y = xhat * weight.float() + bias.float()
+        ctx.mark_non_differentiable(mean, var, n)
+        return y.to(x.dtype), mean, var, n
+
+    @staticmethod
+    def backward(ctx, dy, _m, _v, _n):
+        xhat, rstd, weight, n = ctx.saved_tensors
+        dyf = dy.float()
+        F_ = dyf.shape[1]
+        red = torch.empty(2 * F_, device=dy.device, dtype=torch.float32)
+        red[:F_] = dyf.sum(0)
+        red[F_:] = (dyf * xhat).sum(0)
+        local = red.clone()
+        all_reduce_sum_(red)
+        dx = (weight.float() * rstd / n) * (n * dyf - red[:F_] - xhat * red[F_:])
+        return dx.to(dy.dtype), local[F_:].to(weight.dtype), local[:F_].to(weight.dtype), None
+
+
+class GlobalBatchNorm1d(torch.nn.BatchNorm1d):
+    """nn.BatchNorm1d whose training-mode moments span all ranks; identical module state / keys."""
+
+    def forward(self, x):
+        if not (self.training and is_sharded()):
+            return super().forward(x)
+        y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                self.running_mean.mul_(1 - mom).add_(mean.to(self.running_mean.dtype), alpha=mom)
+                unbiased = var * (n / (n - 1).clamp_min(1))
+                self.running_var.mul_(1 - mom).add_(unbiased.to(self.running_var.dtype), alpha=mom)
+        return y
+
+
+def convert_batchnorm_(module: torch.nn.Module) -> torch.nn.Module:
+    """Re-class every nn.BatchNorm1d in ``module`` as GlobalBatchNorm1d (in place; same parameters)."""
+    for m in module.modules():
+        if type(m) is torch.nn.BatchNorm1d:
+            m.__class__ = GlobalBatchNorm1d
+    return module

@@ -164,7 +164,7 @@ class _Rbf(torch.autograd.Function):
 
 def rbf_deinterp(v, raw_input, rbf_kernel, grid, lengths=None):
     """v (B,C,R) grid values -> (B,C,T) values at the observed time stamps of ``raw_input``."""
-    return _Rbf.apply(v, raw_input, rbf_kernel, grid, lengths)
+    return _Rbf.apply(v.float(), raw_input, rbf_kernel, grid, lengths)   # .float(): bf16 autocast producers
 
 
 class _MaskedMse(torch.autograd.Function):
@@ -200,7 +200,7 @@ def masked_mse(org_ob, rec_ob, padding_mask=None, lengths=None):
     """sum((rec*m - ob*m)^2) / #{m == 1} over the (global) batch."""
     if padding_mask is None and lengths is None:
         raise ValueError('masked_mse needs a mask or prefix lengths')
-    return _MaskedMse.apply(org_ob, rec_ob, padding_mask, lengths)
+    return _MaskedMse.apply(org_ob, rec_ob.float(), padding_mask, lengths)
 
 
 # ----------------------------------------------------------------------------------------- k3
@@ -244,7 +244,7 @@ class _DecAssign(torch.autograd.Function):
 
 def dec_soft_assign(z, centers, alpha=1.0, return_colsum=False):
     """Student-t soft assignment q (B,K); optionally also the local column sums f_j = sum_i q_ij."""
-    q, colsum = _DecAssign.apply(z, centers, alpha, return_colsum)
+    q, colsum = _DecAssign.apply(z.float(), centers, alpha, return_colsum)
     return (q, colsum) if return_colsum else q
 
 
@@ -288,4 +288,4 @@ class _KlBatchMean(torch.autograd.Function):
 
 def kl_batchmean(p, q):
     """F.kl_div(q.log(), p, reduction='batchmean') with the closed-form d/dq fused into the forward."""
-    return _KlBatchMean.apply(p, q)
+    return _KlBatchMean.apply(p, q.float())

@@ -1,0 +1,54 @@
+"""Drop-in for the reference's ``rbf`` module (rbf.py:15-202): Gaussian RBF de-interpolation head.
+
+``CompressFC`` (two small GEMMs + BatchNorm, rbf.py:111-125) stays on PyTorch-ROCm; the
+(B,C,T,R)-shaped basis evaluation, normalisation and contraction run in ``csrc/dic_rbf.hip`` (k2).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .utils import TimeDistributed
+
+
+class CompressFC(nn.Module):
+    """Applied per (b, r) row through TimeDistributed: 256 -> 128 -> BN -> ReLU -> Dropout -> C."""
+
+    def __init__(self, idim, odim, dropout):
+        super().__init__()
+        self.model = nn.Sequential(nn.Linear(idim, 128), nn.BatchNorm1d(128), nn.ReLU(), nn.Dropout(dropout),
+                                   nn.Linear(128, odim))
+
+    def forward(self, rec_input):
+        return self.model(rec_input)
+
+
+def gaussian(beta, alpha):
+    """phi = exp(-beta * alpha^2) (rbf.py:129-131).  Kept for API parity (torch, tiny inputs); the
+    model path evaluates this basis inside the HIP kernel."""
+    return torch.exp(-beta * alpha.pow(2))
+
+
+def basis_func_dict():
+    """Only 'gaussian' is ever selected upstream (clustering_interp.py:116); the other upstream
+    entries have a signature their caller cannot use and are not provided."""
+    return {'gaussian': gaussian}
+
+
+class RBF(nn.Module):
+    def __init__(self, hours_look_ahead, ref_points, in_dim, out_dim, dropout, basis_func, device):
+        super().__init__()
+        if basis_func is not gaussian:
+            raise NotImplementedError("only the 'gaussian' basis is on the reference path")
+        self.ref_points, self.hours_look_ahead, self.device = ref_points, hours_look_ahead, device
+        self.interp_t = torch.linspace(0, hours_look_ahead, ref_points, device=device)
+        self.out_dim = self.num_variables = out_dim
+        self.basis_func = basis_func
+        self.compress_fc = TimeDistributed(CompressFC(in_dim, out_dim, dropout))
+        self.kernel = nn.Parameter(torch.rand(out_dim, device=device), requires_grad=True)
+
+    def forward(self, interp_data, raw_input, lengths=None):
+        """interp_data (B,256,R), raw_input (B,4C,T) -> (B,C,T) (rbf.py:57-108)."""
+        v = self.compress_fc(interp_data.permute(0, 2, 1)).permute(0, 2, 1)       # (B,C,R)
+        if self.interp_t.device != v.device:
+            self.interp_t = self.interp_t.to(v.device)
+        return ops.rbf_deinterp(v, raw_input, self.kernel, self.interp_t, lengths)

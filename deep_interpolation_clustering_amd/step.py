@@ -1,0 +1,75 @@
+"""The joint training step shared by both trainers and ``bench.py``.
+
+One step = what pretrain_trainer.py:189-229 / clustering_trainer.py:222-279 do per batch:
+zero_grad -> Net.forward -> loss switch on ``args.loss`` -> backward -> [gradient all-reduce over
+RCCL when sharded] -> clip_grad_norm_(grad_clip) -> optimizer.step.  Loss terms stay on the device
+(the reference's per-term ``.item()`` is a host sync per batch); callers read them when they log.
+"""
+import contextlib
+
+import torch
+
+from . import dist
+
+LOSS_NAMES = ('ae_mse', 'ae_mse_sup', 'ae_mse_fake_detect', 'ae_mse_fake_detect_triplet', 'ae_mse_sup_fake_detect',
+              'ae_mse_kl', 'ae_mse_fake_detect_kl', 'ae_mse_sup_kl', 'ae_mse_sup_fake_detect_kl')
+
+
+def compute_losses(model, args, hidden, rec_ob, aux_pred, ob, padding_mask, lengths=None, aux_label_dict=None,
+                   future_vital_mask=None, fake_det_label=None):
+    """The loss switch of the trainers (pretrain_trainer.py:196-221, clustering_trainer.py:227-272)."""
+    rec = model.rec_loss(ob, rec_ob, padding_mask, lengths)
+    name = args.loss
+    if name not in LOSS_NAMES:
+        raise NotImplementedError(name)
+    if name == 'ae_mse':
+        return rec
+    tasks, terms = {}, {}
+    if '_sup' in name:
+        tasks.update(args.aux_tasks)
+        terms.update(model.sup_aux_loss(args.aux_tasks, aux_label_dict or {}, aux_pred, future_vital_mask))
+    if 'fake_detect' in name:
+        tasks.update(args.unsup_aux_tasks)
+        terms.update(model.fake_det_loss(fake_det_label, aux_pred['fake_det']))
+    if name.endswith('triplet'):
+        terms.update(model.triplet_loss(hidden, aux_pred['positive'], aux_pred['negative'], args.triple_margin))
+    if name.endswith('_kl'):
+        tasks.update(args.unsup_aux_tasks)
+        terms.update(model.kl_loss(aux_pred['cluster_label'], aux_pred['cluster_pred']))
+    return model.multi_task_loss(tasks, rec, terms)
+
+
+class Stepper:
+    """Owns the flat parameter/gradient buckets and runs one optimisation step.
+
+    ``autocast_dtype`` (e.g. torch.bfloat16) wraps the forward in torch.autocast so the bi-LSTMs and the
+    FC heads run on bf16 MFMA; the HIP kernels always compute in f32."""
+
+    def __init__(self, model, optimizer_factory, args, autocast_dtype=None):
+        self.model, self.args = model, args
+        self.flat = dist.FlatParams(model)          # must precede the optimizer: it re-homes parameter storage
+        self.flat.broadcast_(0)
+        self.optimizer = optimizer_factory(model)
+        self.autocast_dtype = autocast_dtype
+
+    def _ctx(self):
+        if self.autocast_dtype is None:
+            return contextlib.nullcontext()
+        return torch.autocast('cuda', dtype=self.autocast_dtype)
+
+    def forward_loss(self, x, ob, padding_mask, lengths=None, fake_x=None, fake_perm_idx=None, positive_x=None,
+                     aux_label_dict=None, future_vital_mask=None, fake_det_label=None):
+        with self._ctx():
+            hidden, rec_ob, aux_pred = self.model(x, fake_x, fake_perm_idx, positive_x, lengths=lengths)
+        losses = compute_losses(self.model, self.args, hidden, rec_ob, aux_pred, ob, padding_mask, lengths,
+                                aux_label_dict, future_vital_mask, fake_det_label)
+        return losses, hidden, rec_ob, aux_pred
+
+    def step(self, x, ob, padding_mask, lengths=None, **kw):
+        self.flat.zero_grad()
+        losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
+        losses['loss'].backward()
+        self.flat.all_reduce_grads()
+        gnorm = self.flat.clip_grad_norm_(self.args.grad_clip)
+        self.optimizer.step()
+        return losses, gnorm, hidden

@@ -340,4 +340,4 @@ def train_step(net, opt, x, ob, padding_mask, kl_weight=10.0, grad_clip=15.0, **
     terms['loss'].backward()
     gnorm = torch.nn.utils.clip_grad_norm_(net.parameters(), grad_clip)
     opt.step()
-    return {k: float(v) for k, v in terms.items()}, float(gnorm), z.detach()
+    return {k: float(v.detach()) for k, v in terms.items()}, float(gnorm), z.detach()

@@ -1,0 +1,109 @@
+"""GPU parity of the assembled network and of one full optimisation step against the golden
+step captured from the reference (tests/golden/netstep_*.npz) and against the CPU oracle."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dic_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def make_args(g, fake, loss):
+    return SimpleNamespace(num_variables=6, num_timestamps=g['x'].shape[-1], ref_points=int(g['R']),
+                           hours_from_admission=float(g['H']), dropout=0.0, aux_tasks={}, fake_detection=fake,
+                           triple_margin=0.0, cluster_number=int(g['K']), loss=loss, grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.}, aux_pos_weights={})
+
+
+def initial_state(name):
+    plain = load('netstep_plain.npz')
+    sd = {k[4:]: v for k, v in plain.items() if k.startswith('sd0/')}
+    g = plain
+    if name == 'fake':
+        g = load('netstep_fake.npz')
+        sd.update({k[4:]: v for k, v in g.items() if k.startswith('sd0/')})
+    return g, {k: torch.tensor(v) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize('name', ['plain', 'fake'])
+@pytest.mark.parametrize('use_lengths', [False, True])
+def test_joint_step_matches_reference(name, use_lengths):
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    g, sd0 = initial_state(name)
+    fake = name == 'fake'
+    args = make_args(g, fake, 'ae_mse_fake_detect_kl' if fake else 'ae_mse_kl')
+    dev = torch.device('cuda')
+    net = Net(args, dev).to(dev)
+    net.load_state_dict(sd0, strict=True)            # reference checkpoint keys load as they are
+    net.train()
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args)
+    x = torch.tensor(g['x'], device=dev)
+    ob = torch.tensor(g['ob'], device=dev)
+    mask = x[:, 6:12].contiguous()
+    lengths = mask.sum(-1).to(torch.int32) if use_lengths else None
+    kw = {}
+    if fake:
+        kw = dict(fake_x=torch.tensor(g['fake_x'], device=dev), fake_perm_idx=torch.tensor(g['fake_perm_idx'], device=dev),
+                  fake_det_label=torch.tensor(g['fake_label'], device=dev))
+    losses, gnorm, z = st.step(x, ob, mask, lengths, **kw)
+    # --- the north-star bar: losses within 1e-5 relative (kl is ~1e-4 here and ill-conditioned in fp32: abs floor)
+    for k in ('loss', 'ae_mse'):
+        np.testing.assert_allclose(float(losses[k]), float(g['loss_' + k]), rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(float(losses['kl']), float(g['loss_kl']), rtol=1e-5, atol=5e-8)
+    if fake:
+        np.testing.assert_allclose(float(losses['fake_detection']), float(g['loss_fake_detection']), rtol=1e-5)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g['z'], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(float(gnorm), float(g['gnorm']), rtol=1e-4)
+    # parameters after clip + Adam(amsgrad, wd): compare where the gradient is decisively non-zero
+    for k, v in net.state_dict().items():
+        got = v.detach().cpu().numpy()
+        if 'sd1/' + k in g:
+            ref = g['sd1/' + k]
+            if 'g/' + k in g:
+                live = np.abs(g['g/' + k]) >= 1e-4 * float(g['gnorm'])
+                got, ref = got[live], ref[live]
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5, err_msg=k)
+        elif 'sd1n/' + k in g:
+            np.testing.assert_allclose(np.linalg.norm(got.astype(np.float64)), float(g['sd1n/' + k]), rtol=2e-5, err_msg=k)
+
+
+def test_forward_matches_oracle_bigger_batch():
+    """B=300 ragged batch at the BASELINE shape (C=6,T=96,R=24,H=24): whole forward + losses vs the CPU oracle
+    carrying the same weights."""
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    coh = synthetic.make_cohort(300, seed=5)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0,
+                           aux_tasks={}, fake_detection=False, triple_margin=0.0, cluster_number=4)
+    torch.manual_seed(3)
+    ref = O.OracleNet(6, 24, 24, 4, 0.0)
+    ref.train()
+    dev = torch.device('cuda')
+    net = Net(args, dev).to(dev)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net.train()
+    x, ob = torch.tensor(x_np), torch.tensor(ob_np)
+    terms, z_ref, y_ref, aux_ref = O.joint_loss(ref, x, ob, x[:, 6:12], 10.0)
+    xd, obd = x.to(dev), ob.to(dev)
+    lengths = torch.tensor(n, device=dev)
+    z, y, aux = net(xd, lengths=lengths)
+    rec = net.rec_loss(obd, y, None, lengths)['ae_mse']
+    kl = net.kl_loss(aux['cluster_label'], aux['cluster_pred'])['kl']
+    np.testing.assert_allclose(float(rec), float(terms['ae_mse']), rtol=1e-5)
+    np.testing.assert_allclose(float(kl), float(terms['kl']), rtol=1e-5, atol=5e-8)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), z_ref.detach().numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(aux['cluster_pred'].detach().cpu().numpy(), aux_ref['cluster_pred'].detach().numpy(), rtol=1e-4)
+    assert (aux['cluster_pred'].argmax(1).cpu() == aux_ref['cluster_pred'].argmax(1)).all()
