@@ -53,6 +53,23 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float softplus_raw(float k) { return logf(1.0f + expf(k)); }
 __device__ __forceinline__ float sigmoidf(float k) { return 1.0f / (1.0f + expf(-k)); }
 
+// Fixed-order (deterministic) second-stage reduction: out_i = sum_b partials[b*n + i].
+// Call from a 256-thread workgroup; it covers outputs i0 .. i0+31 as 32 outputs x 8 slices of b
+// (coalesced 128-B reads per slice row).  The result is valid in threads 0..31 (for i = i0 + tid).
+template <typename T>
+__device__ __forceinline__ double reduce_partials_32x8(const T* partials, int nblk, int n, int i0, double* lds256) {
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5, i = i0 + o;
+    double acc = 0.0;
+    if (i < n)
+        for (int b = sl; b < nblk; b += 8) acc += (double)partials[(size_t)b * n + i];
+    lds256[threadIdx.x] = acc;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x < 32)
+        for (int k = 0; k < 8; ++k) r += lds256[k * 32 + threadIdx.x];
+    return r;
+}
+
 // XCD-aware block remap (8 XCDs, round-robin dispatch): consecutive logical tiles land on the
 // same XCD so neighbouring rows share that XCD's L2.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

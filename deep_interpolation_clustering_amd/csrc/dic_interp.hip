@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kBlock) void cci_bwd_kernel(const float* grad_out, 
                                                         float* partials) {
     extern __shared__ __align__(16) float smem[];
     const BwdLayout L = bwd_layout(E, C, R);
-    const int tid = threadIdx.x, CR = C * R;
+    const int tid = threadIdx.x;
     float* val = smem + L.val; float* grd = smem + L.grad; float* gout = smem + L.gout;
     for (int i = tid; i < C * C; i += kBlock) smem[L.kmat + i] = cci_kernel[i];
     float gk_acc = 0.f;
@@ -450,13 +450,13 @@ __global__ __launch_bounds__(kBlock) void cci_bwd_kernel(const float* grad_out, 
 }
 
 // Fixed-order reduction of the per-block partials (f64), sigmoid chain rule for the raw kernel.
-__global__ void interp_bwd_finalize(const float* partials, int nblk, int C, const float* sci_kernel,
-                                    float* grad_sci, float* grad_cci) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void interp_bwd_finalize(const float* partials, int nblk, int C, const float* sci_kernel,
+                                                          float* grad_sci, float* grad_cci) {
+    __shared__ double red[256];
     const int n = C + C * C;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partials[(size_t)b * n + i];
+    const double s = reduce_partials_32x8(partials, nblk, n, blockIdx.x * 32, red);
+    const int i = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x >= 32 || i >= n) return;
     if (i < C) {
         if (grad_sci) grad_sci[i] = (float)(s * (double)sigmoidf(sci_kernel[i]));
     } else if (grad_cci) {
@@ -551,7 +551,7 @@ int dic_sci_cci_bwd(const float* grad_out, const float* saved, const float* sci_
     hipLaunchKernelGGL(sci_cci_bwd_kernel, dim3(nblk), dim3(kBlock), lds, st, grad_out, saved, cci_kernel, B, C, R, E,
                        nblk, (float*)workspace);
     const int n = C + C * C;
-    hipLaunchKernelGGL(interp_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)workspace, nblk, C,
+    hipLaunchKernelGGL(interp_bwd_finalize, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)workspace, nblk, C,
                        sci_kernel, grad_sci_kernel, cci_kernel ? grad_cci_kernel : nullptr);
     return check_launch("sci_cci_bwd");
 }
@@ -586,7 +586,7 @@ int dic_cci_bwd(const float* grad_out, const float* s, const float* cci_kernel, 
     hipLaunchKernelGGL(cci_bwd_kernel, dim3(nblk), dim3(kBlock), lds, st, grad_out, s, cci_kernel, B, C, R, E, nblk,
                        grad_s, (float*)workspace);
     const int n = C + C * C;
-    hipLaunchKernelGGL(interp_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)workspace, nblk, C,
+    hipLaunchKernelGGL(interp_bwd_finalize, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)workspace, nblk, C,
                        (const float*)nullptr, (float*)nullptr, grad_cci_kernel);
     return check_launch("cci_bwd");
 }

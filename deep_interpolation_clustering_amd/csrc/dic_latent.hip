@@ -110,12 +110,10 @@ __global__ __launch_bounds__(kLatBlock) void dec_fwd_kernel(const float* z, cons
     }
 }
 
-__global__ void colsum_finalize(const float* partials, int nblk, int K, float* colsum) {
-    const int k = threadIdx.x;
-    if (k >= K) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partials[(size_t)b * K + k];
-    colsum[k] = (float)s;
+__global__ __launch_bounds__(256) void colsum_finalize(const float* partials, int nblk, int K, float* colsum) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(partials, nblk, K, 0, red);
+    if (threadIdx.x < K) colsum[threadIdx.x] = (float)s;
 }
 
 // target_distribution (dec.py:73-74): p = (q^2/f) / sum_j (q^2/f)
@@ -189,12 +187,11 @@ __global__ __launch_bounds__(kLatBlock) void dec_bwd_kernel(const float* z, cons
     }
 }
 
-__global__ void dec_bwd_finalize(const float* partials, int nblk, int n, float sign, float* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partials[(size_t)b * n + i];
-    out[i] = (float)(sign * s);
+__global__ __launch_bounds__(256) void dec_bwd_finalize(const float* partials, int nblk, int n, float sign, float* out) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(partials, nblk, n, blockIdx.x * 32, red);
+    const int i = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x < 32 && i < n) out[i] = (float)(sign * s);
 }
 
 // fused KL(p||q)/batch_div and d/dq
@@ -216,12 +213,10 @@ __global__ __launch_bounds__(kLatBlock) void dec_kl_kernel(const float* q, const
         partials[blockIdx.x] = s;
     }
 }
-__global__ void dec_kl_finalize(const double* partials, int nblk, float batch_div, float* out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0;
-        for (int b = 0; b < nblk; ++b) s += partials[b];
-        out[0] = (float)(s / (double)batch_div);
-    }
+__global__ __launch_bounds__(256) void dec_kl_finalize(const double* partials, int nblk, float batch_div, float* out) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(partials, nblk, 1, 0, red);
+    if (threadIdx.x == 0) out[0] = (float)(s / (double)batch_div);
 }
 
 // =============================================================================== k-means
@@ -232,8 +227,8 @@ __host__ __device__ inline KmWs km_ws(int N, int D, int K, int n_runs, int nblk)
     KmWs w;
     size_t o = 0;
     w.psum = o; o += (size_t)n_runs * nblk * K * D * sizeof(float);
-    w.pcnt = o; o += (size_t)n_runs * nblk * K * sizeof(int);
-    w.pchg = o; o += (size_t)n_runs * nblk * sizeof(int);
+    w.pcnt = o; o += (size_t)n_runs * nblk * (K + 1) * sizeof(int);     // K counts + #changed per workgroup
+    w.pchg = o;
     o = (o + 15) & ~(size_t)15;
     w.sums = o; o += (size_t)n_runs * K * D * sizeof(double);
     w.mind = o; o += (size_t)n_runs * N * sizeof(float);
@@ -347,24 +342,25 @@ __global__ __launch_bounds__(kLatBlock) void kmeans_assign_kernel(const float* X
     if (threadIdx.x < K) {
         int s = 0;
         for (int w = 0; w < kLatWaves; ++w) s += cntred[w][threadIdx.x];
-        pcnt_all[pb * K + threadIdx.x] = s;
+        pcnt_all[pb * (K + 1) + threadIdx.x] = s;
     }
     if (threadIdx.x == 0) {
         int s = 0;
         for (int w = 0; w < kLatWaves; ++w) s += chgred[w];
-        pchg_all[pb] = s;
+        pcnt_all[pb * (K + 1) + K] = s;
     }
+    (void)pchg_all;
 }
 
-// stage A of the update: fixed-order f64 reduction of the workgroup partial sums, one block per (k, run)
+// stage A of the update: fixed-order f64 reduction of the workgroup partial sums; grid (K*D/32, n_runs)
 __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const float* psum_all, int nblk, int K, int D,
                                                            const float* status_all, double* sums_all) {
-    const int k = blockIdx.x, run = blockIdx.y, d = threadIdx.x;
-    if (status_all[run * DIC_KM_STATUS_WORDS] != 0.f || d >= D) return;
-    const float* p = psum_all + ((size_t)run * nblk * K + k) * D + d;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)p[(size_t)b * K * D];
-    sums_all[((size_t)run * K + k) * D + d] = s;
+    __shared__ double red[256];
+    const int run = blockIdx.y, n = K * D;
+    if (status_all[run * DIC_KM_STATUS_WORDS] != 0.f) return;
+    const double s = reduce_partials_32x8(psum_all + (size_t)run * nblk * n, nblk, n, blockIdx.x * 32, red);
+    const int i = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x < 32 && i < n) sums_all[(size_t)run * n + i] = s;
 }
 
 // stage B: counts, empty-cluster relocation, averaging, centre shift, convergence; one block per run
@@ -386,16 +382,19 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* X, int 
     float* mind = mind_all + (size_t)run * N;
     const int32_t* labels = labels_all + (size_t)run * N;
 
-    if (tid < K) {
-        int s = 0;
-        for (int b = 0; b < nblk; ++b) s += pcnt_all[((size_t)run * nblk + b) * K + tid];
-        cntf[tid] = (float)s;
-    }
-    if (tid == 0) {
-        int s = 0;
-        for (int b = 0; b < nblk; ++b) s += pchg_all[(size_t)run * nblk + b];
-        s_changed = s;
-        s_relocs = 0;
+    {   // counts (exact in f64) and #changed: K+1 <= 33 outputs -> two passes of the 32-wide reducer
+        __shared__ double red[256];
+        const int* pc = pcnt_all + (size_t)run * nblk * (K + 1);
+        const double c0 = reduce_partials_32x8(pc, nblk, K + 1, 0, red);
+        if (tid < 32 && tid < K) cntf[tid] = (float)c0;
+        if (tid < 32 && tid == K) s_changed = (int)c0;
+        __syncthreads();
+        if (K + 1 > 32) {
+            const double c1 = reduce_partials_32x8(pc, nblk, K + 1, 32, red);
+            if (tid == 0) s_changed = (int)c1;       // K == 32: output 32 is #changed
+        }
+        if (tid == 0) s_relocs = 0;
+        (void)pchg_all;
     }
     __syncthreads();
 
@@ -502,14 +501,13 @@ __global__ __launch_bounds__(kLatBlock) void kmeans_pp_kernel(const float* X, in
     }
     if (lane == 0) red[wave] = pot;
     __syncthreads();
-    if (threadIdx.x == 0) ppart[(size_t)l * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) ppart[(size_t)blockIdx.x * L + l] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void kmeans_pp_finalize(const double* ppart, int nblk, int L, double* pot) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= L) return;
-    double s = 0;
-    for (int b = 0; b < nblk; ++b) s += ppart[(size_t)l * nblk + b];
-    pot[l] = s;
+__global__ __launch_bounds__(256) void kmeans_pp_finalize(const double* ppart, int nblk, int L, double* pot) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(ppart, nblk, L, blockIdx.x * 32, red);
+    const int l = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x < 32 && l < L) pot[l] = s;
 }
 
 static int pad_k(int K) { int kp = 2; while (kp < K) kp <<= 1; return kp; }
@@ -556,7 +554,7 @@ int dic_dec_fwd(const float* z, const float* centers, int B, int D, int K, float
     float* part = colsum ? (float*)workspace : nullptr;
     DIC_DISPATCH_KP(pad_k(K), hipLaunchKernelGGL(dec_fwd_kernel<KP>, dim3(nblk), dim3(kLatBlock), 0, st, z, centers, B, D, K,
                                                  alpha, q, tsaved, part));
-    if (colsum) hipLaunchKernelGGL(colsum_finalize, dim3(1), dim3(64), 0, st, (const float*)part, nblk, K, colsum);
+    if (colsum) hipLaunchKernelGGL(colsum_finalize, dim3(1), dim3(256), 0, st, (const float*)part, nblk, K, colsum);
     return check_launch("dec_fwd");
 }
 
@@ -588,7 +586,7 @@ int dic_dec_bwd(const float* z, const float* centers, const float* q, const floa
     DIC_DISPATCH_KP(pad_k(K), hipLaunchKernelGGL(dec_bwd_kernel<KP>, dim3(nblk), dim3(kLatBlock), 0, st, z, centers, tsaved,
                                                  grad_q, B, D, K, alpha, grad_z, (float*)workspace));
     const int n = K * D;
-    hipLaunchKernelGGL(dec_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)workspace, nblk, n, -1.0f,
+    hipLaunchKernelGGL(dec_bwd_finalize, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)workspace, nblk, n, -1.0f,
                        grad_centers);
     return check_launch("dec_bwd");
 }
@@ -610,7 +608,7 @@ int dic_dec_kl(const float* q, const float* p, int B, int K, float batch_div, fl
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dec_kl_kernel, dim3(nblk), dim3(kLatBlock), 0, st, q, p, n, batch_div, gscale, (double*)workspace,
                        grad_q);
-    hipLaunchKernelGGL(dec_kl_finalize, dim3(1), dim3(64), 0, st, (const double*)workspace, nblk, batch_div, kl_out);
+    hipLaunchKernelGGL(dec_kl_finalize, dim3(1), dim3(256), 0, st, (const double*)workspace, nblk, batch_div, kl_out);
     return check_launch("dec_kl");
 }
 
@@ -641,7 +639,7 @@ int dic_kmeans_lloyd_iter(const float* X, const float* xnorm, int N, int D, int 
     DIC_DISPATCH_KP(pad_k(K), hipLaunchKernelGGL((kmeans_assign_kernel<KP, true>), dim3(nblk, n_runs), dim3(kLatBlock), 0, st, X,
                                                  xnorm, N, D, K, (const float*)centers, labels, (const float*)status, mind, psum,
                                                  pcnt, pchg));
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(K, n_runs), dim3(256), 0, st, (const float*)psum, nblk, K, D,
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((K * D + 31) / 32, n_runs), dim3(256), 0, st, (const float*)psum, nblk, K, D,
                        (const float*)status, sums);
     hipLaunchKernelGGL(kmeans_update_kernel, dim3(n_runs), dim3(256), 0, st, X, N, D, K, nblk, (const int*)pcnt,
                        (const int*)pchg, sums, mind, (const int32_t*)labels, centers, status);
@@ -681,7 +679,7 @@ int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(kmeans_pp_kernel, dim3(nblk, L), dim3(kLatBlock), 0, st, X, N, D, cand, L, group, closest, dist_out,
                        (double*)workspace);
-    hipLaunchKernelGGL(kmeans_pp_finalize, dim3((L + 63) / 64), dim3(64), 0, st, (const double*)workspace, nblk, L, pot_out);
+    hipLaunchKernelGGL(kmeans_pp_finalize, dim3((L + 31) / 32), dim3(256), 0, st, (const double*)workspace, nblk, L, pot_out);
     return check_launch("kmeans_pp_candidates");
 }
 

@@ -167,12 +167,12 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
     if (tid < C) a.partials[(size_t)blockIdx.x * C + tid] = gbeta_acc;
 }
 
-__global__ void rbf_bwd_finalize(const float* partials, int nblk, int C, const float* rbf_kernel, float* grad_kernel) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partials[(size_t)b * C + c];
-    grad_kernel[c] = (float)(s * (double)sigmoidf(rbf_kernel[c]));
+__global__ __launch_bounds__(256) void rbf_bwd_finalize(const float* partials, int nblk, int C, const float* rbf_kernel,
+                                                       float* grad_kernel) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(partials, nblk, C, blockIdx.x * 32, red);
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x < 32 && c < C) grad_kernel[c] = (float)(s * (double)sigmoidf(rbf_kernel[c]));
 }
 
 // ------------------------------------------------------------------------------- rec loss
@@ -207,13 +207,10 @@ __global__ __launch_bounds__(kBlock) void masked_sse_kernel(const float* ob, con
     }
 }
 
-__global__ void masked_sse_finalize(const double* partials, int nblk, float* out2) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0, c = 0;
-        for (int b = 0; b < nblk; ++b) { s += partials[2 * b]; c += partials[2 * b + 1]; }
-        out2[0] = (float)s;
-        out2[1] = (float)c;
-    }
+__global__ __launch_bounds__(256) void masked_sse_finalize(const double* partials, int nblk, float* out2) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(partials, nblk, 2, 0, red);
+    if (threadIdx.x < 2) out2[threadIdx.x] = (float)s;
 }
 
 __global__ __launch_bounds__(kBlock) void masked_sse_bwd_kernel(const float* ob, const float* rec, const float* mask,
@@ -242,7 +239,7 @@ static int rbf_tile(int B, int per_enc_words, int fixed_words, int budget_bytes)
 
 static int sse_blocks(int rows, int T) {
     const long units = (long)rows * ((T + kWave - 1) / kWave);
-    return (int)max(1L, min((units + 3) / 4, (long)8 * kNumCU));
+    return (int)max(1L, min((units + 3) / 4, (long)4 * kNumCU));
 }
 
 }  // namespace dic
@@ -297,7 +294,7 @@ int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int
     while (a.E * C * R * a.S < kBlock && a.S < 16) { a.S <<= 1; ++a.logS; }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(rbf_bwd_kernel, dim3(a.nblk), dim3(kBlock), lds, st, a);
-    hipLaunchKernelGGL(rbf_bwd_finalize, dim3(1), dim3(64), 0, st, (const float*)workspace, a.nblk, C, rbf_kernel,
+    hipLaunchKernelGGL(rbf_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)workspace, a.nblk, C, rbf_kernel,
                        grad_rbf_kernel);
     return check_launch("rbf_bwd");
 }
@@ -316,7 +313,7 @@ int dic_masked_sse_fwd(const float* ob, const float* rec, const float* mask, con
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(masked_sse_kernel, dim3(nblk), dim3(kBlock), 0, st, ob, rec, mask, lengths, B * C, T, nblk,
                        (double*)workspace);
-    hipLaunchKernelGGL(masked_sse_finalize, dim3(1), dim3(64), 0, st, (const double*)workspace, nblk, out2);
+    hipLaunchKernelGGL(masked_sse_finalize, dim3(1), dim3(256), 0, st, (const double*)workspace, nblk, out2);
     return check_launch("masked_sse_fwd");
 }
 

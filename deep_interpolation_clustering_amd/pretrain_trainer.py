@@ -1,0 +1,28 @@
+"""Drop-in for the reference's ``pretrain_trainer`` module: ``Trainer`` for the interpolation auto-encoder
+(pretrain_trainer.py:17-438).  The epoch machinery lives in ``_trainer_common.TrainerBase``."""
+from ._trainer_common import TrainerBase
+from .utils import format_metric_dict, logger, timer
+
+
+class Trainer(TrainerBase):
+    restore_attr = 'restore_metric'
+
+    def __init__(self, args, model, dl_dict, exp_path, device, **kwags):
+        super().__init__(args, model, dl_dict, exp_path, device, **kwags)
+
+    def train(self):
+        """pretrain_trainer.py:64-88: epochs of train -> validate -> checkpoint-on-improvement -> early stop."""
+        logger.info('*******Building the model*******')
+        if self.args.restore:
+            self.load_weight()
+        with timer('Duration of training'):
+            for epoch in range(1, self.args.max_epochs):
+                train_metrics = self.train_one_epoch(self.train_dl, denoise=self.args.denoise)
+                logger.info('==> Epoch: {}, Train, {}'.format(epoch, format_metric_dict(train_metrics)))
+                valid_metrics, _ = self.eval_one_epoch('valid', self.valid_dl, denoise=self.args.denoise)
+                verdict = self.aly_pred('valid', valid_metrics)
+                self.epoch += 1
+                if verdict['early_stop']:
+                    logger.info('========Best model=========')
+                    logger.info('{}'.format(self.flag_dict))
+                    break

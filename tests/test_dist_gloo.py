@@ -1,0 +1,93 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing in ``dist``: the flat gradient bucket,
+global-batch BatchNorm and the sharding helpers make a sharded step equal the single-process step."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as td
+    from deep_interpolation_clustering_amd import dist
+    dist.init_from_env('gloo')
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 128), torch.nn.BatchNorm1d(128), torch.nn.ReLU(), torch.nn.Linear(128, 3))
+        dist.convert_batchnorm_(net)
+        flat = dist.FlatParams(net)
+        flat.broadcast_(0)
+        g = torch.Generator().manual_seed(5)
+        X, Y = torch.randn(64, 16, generator=g), torch.randn(64, 3, generator=g)
+        lo, hi = dist.shard_bounds(64)
+        opt = torch.optim.Adam(net.parameters(), lr=3e-3, weight_decay=4e-4, amsgrad=True)
+        for _ in range(3):
+            flat.zero_grad()
+            # loss normalised by the GLOBAL count -> SUM of rank gradients is the global gradient
+            loss = ((net(X[lo:hi]) - Y[lo:hi]) ** 2).sum() / 64
+            loss.backward()
+            flat.all_reduce_grads()
+            gn = flat.clip_grad_norm_(15.0)
+            opt.step()
+        stat = torch.tensor([float(loss.detach())])
+        dist.all_reduce_sum_(stat)
+        torch.save({'flat': flat.flat.clone(), 'gn': float(gn), 'loss': float(stat), 'rm': net[1].running_mean.clone(),
+                    'rv': net[1].running_var.clone(), 'bounds': (lo, hi)}, os.path.join(out, f'r{rank}.pt'))
+    finally:
+        td.destroy_process_group()
+
+
+def _single():
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 128), torch.nn.BatchNorm1d(128), torch.nn.ReLU(), torch.nn.Linear(128, 3))
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(64, 16, generator=g), torch.randn(64, 3, generator=g)
+    opt = torch.optim.Adam(net.parameters(), lr=3e-3, weight_decay=4e-4, amsgrad=True)
+    for _ in range(3):
+        opt.zero_grad()
+        loss = ((net(X) - Y) ** 2).sum() / 64
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(net.parameters(), 15.0)
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    return flat, float(gn), float(loss.detach()), net[1].running_mean, net[1].running_var
+
+
+def test_sharded_step_equals_single_process(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'r0.pt'), torch.load(tmp_path / 'r1.pt')
+    assert r0['bounds'] == (0, 32) and r1['bounds'] == (32, 64)
+    assert torch.equal(r0['flat'], r1['flat'])                        # replicas stay bit-identical
+    flat, gn, loss, rm, rv = _single()
+    live = np.ones(flat.numel(), bool)
+    live[16 * 128:16 * 128 + 128] = False      # Linear bias feeding BatchNorm: true gradient 0, Adam amplifies rounding noise
+    np.testing.assert_allclose(r0['flat'].numpy()[live], flat.numpy()[live], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(r0['gn'], gn, rtol=1e-5)
+    np.testing.assert_allclose(r0['loss'], loss, rtol=1e-5)           # sum of the two shard losses
+    np.testing.assert_allclose(r0['rm'].numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r0['rv'].numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_shard_bounds_cover_everything():
+    from deep_interpolation_clustering_amd import dist
+    for n in (1, 7, 64, 75000):
+        for ws in (1, 2, 3, 8):
+            b = [dist.shard_bounds(n, r, ws) for r in range(ws)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(ws - 1))
+
+
+def test_flat_params_views_survive_state_dict_load():
+    from deep_interpolation_clustering_amd import dist
+    net = torch.nn.Linear(4, 3)
+    flat = dist.FlatParams(net)
+    net.load_state_dict({'weight': torch.ones(3, 4), 'bias': torch.zeros(3)})
+    assert float(flat.flat.sum()) == 12.0 and net.weight.data_ptr() == flat.flat.data_ptr()
+    net(torch.ones(2, 4)).sum().backward()
+    assert float(flat.grad.abs().sum()) > 0 and net.weight.grad.data_ptr() == flat.grad.data_ptr()
