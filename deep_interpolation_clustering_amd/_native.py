@@ -54,6 +54,8 @@ SIGNATURES = {
     'dic_kmeans_workspace': (_sz, [_i, _i, _i, _i]),
     'dic_kmeans_lloyd_iter': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     'dic_kmeans_predict': (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    'dic_lstm_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'dic_lstm_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     'dic_kmeans_pp_workspace': (_sz, [_i, _i]),
     'dic_kmeans_pp_candidates': (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _sz, _p]),
 }

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import dist, ops
+from . import lstm as fused_lstm
 from .dec import ClusterAssignment, target_distribution
 from .interpolation_layer import CrossChannelInterp, SingleChannelInterp, fused_forward
 from .rbf import RBF, basis_func_dict
@@ -30,7 +31,10 @@ class EncoderRNN(nn.Module):
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
 
     def forward(self, x):
-        output, (hidden, cell_state) = self.lstm(x)
+        if fused_lstm.fused_available(x, self.lstm):        # bf16 autocast on the GPU: persistent HIP recurrence
+            output, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm)
+        else:
+            output, (hidden, cell_state) = self.lstm(x)
         return output, hidden, cell_state
 
 
@@ -41,7 +45,11 @@ class DecoderRNN(nn.Module):
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
 
     def forward(self, x, hidden, context):
-        x, (hidden, cell_state) = self.lstm(F.relu(x), (hidden, context))      # clustering_interp.py:38-41
+        x = F.relu(x)                                                           # clustering_interp.py:38-41
+        if fused_lstm.fused_available(x, self.lstm):
+            x, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, hidden, context)
+        else:
+            x, (hidden, cell_state) = self.lstm(x, (hidden, context))
         return x, (hidden, cell_state)
 
 

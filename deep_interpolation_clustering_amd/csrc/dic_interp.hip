@@ -21,13 +21,20 @@ namespace dic {
 
 struct InterpLayout {   // LDS carve-up, identical on host and device
     int cnt, alpha, refg, kmat, res, mean, lse, amat, obs;   // offsets in 4-byte words
+    int stride;                                              // float2 elements per staged row
     int total_words;
 };
+
+constexpr int kMaxSplit = 16;
+
+// Row stride of the staged (t,v) rows: room for the tail padding of the unrolled loops, and ODD so that
+// the 2-4 rows one wave touches per ds_read_b64 fall on different LDS banks (768-B rows all hit bank 0).
+__host__ __device__ inline int interp_row_stride(int Tcap) { return (Tcap + kMaxSplit) | 1; }
 
 __host__ __device__ inline InterpLayout interp_layout(int E, int C, int R, int Tcap) {
     InterpLayout L;
     int o = 0;
-    L.cnt = o;   o += E * C;
+    L.cnt = o;   o += E * C + 1;   // +1: tile maximum
     L.alpha = o; o += C;
     L.refg = o;  o += R;
     L.kmat = o;  o += C * C;
@@ -36,7 +43,8 @@ __host__ __device__ inline InterpLayout interp_layout(int E, int C, int R, int T
     L.lse = o;   o += E * R;
     L.amat = o;  o += E * R * C;
     o = (o + 1) & ~1;            // float2 alignment
-    L.obs = o;   o += 2 * E * C * Tcap;
+    L.stride = Tcap > 0 ? interp_row_stride(Tcap) : 0;
+    L.obs = o;   o += 2 * E * C * L.stride;
     L.total_words = o;
     return L;
 }
@@ -93,11 +101,15 @@ __device__ void cci_epilogue(const float* res, const float* kmat, float* mean, f
     }
 }
 
-template <bool RAGGED>
+// S = lanes that split one (row, grid point) item; U = unroll of the streaming loops.
+template <bool RAGGED, int S>
 __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
+    constexpr int U = S >= 4 ? 1 : 4 / S;
+    constexpr int LOGS = S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : S == 8 ? 3 : 4;
     extern __shared__ __align__(16) float smem[];
     const int C = a.C, R = a.R, E = a.E, Tcap = a.Tcap;
     const InterpLayout L = interp_layout(E, C, R, Tcap);
+    const int stride = L.stride;
     int* cnt = reinterpret_cast<int*>(smem + L.cnt);
     float* alpha = smem + L.alpha;
     float* refg = smem + L.refg;
@@ -109,14 +121,19 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
     const int e0 = blockIdx.x * E;
     const int Ev = min(E, a.B - e0);
     const int nrows = Ev * C;
+    int* tile_max = cnt + E * C;
 
     // ---- 1. row lengths + parameters
+    if (tid == 0) *tile_max = 0;
+    __syncthreads();
     for (int i = tid; i < nrows; i += kBlock) {
         const size_t g = (size_t)e0 * C + i;
         int n;
         if (RAGGED) n = (int)(a.row_off[g + 1] - a.row_off[g]);
         else n = a.lengths ? a.lengths[g] : a.T;
-        cnt[i] = max(0, min(n, Tcap));
+        n = max(0, min(n, Tcap));
+        cnt[i] = n;
+        atomicMax(tile_max, n);
     }
     for (int i = tid; i < C; i += kBlock) alpha[i] = softplus_raw(a.sci_kernel[i]);
     for (int i = tid; i < R; i += kBlock) refg[i] = a.ref_grid[i];
@@ -124,75 +141,110 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
         for (int i = tid; i < C * C; i += kBlock) kmat[i] = a.cci_kernel[i];
     __syncthreads();
 
-    // ---- 2. stage (time,value) rows into LDS: one wave per 64-slot chunk of a row
+    // ---- 2. stage (time,value) rows into LDS: one wave per 64-slot chunk of a row, 4 chunks in flight per
+    //         wave.  Every row is padded with zero-weight sentinels up to the tile maximum (+ loop tail), so
+    //         the streaming loops below run wave-uniform trip counts with no per-lane bounds checks.
+    const int npad = min(*tile_max + kMaxSplit, stride);
     {
-        const int nchunk = (Tcap + kWave - 1) / kWave;
+        const int nchunk = (npad + kWave - 1) / kWave;
         const int units = nrows * nchunk;
         const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll 2
-        for (int u = wave; u < units; u += kBlock / kWave) {
-            const int row = u / nchunk;
-            const int i = (u - row * nchunk) * kWave + lane;
-            if (i < cnt[row]) {
-                float t, v;
-                if (RAGGED) {
-                    const int64_t off = a.row_off[(size_t)e0 * C + row] + i;
-                    t = a.t_pk[off];
-                    v = a.v_pk[off];
-                } else {
-                    const int e = row / C, c = row - e * C;
-                    const float* base = a.x + (size_t)(e0 + e) * 4 * C * a.T;
-                    t = base[(size_t)(2 * C + c) * a.T + i];
-                    v = base[(size_t)c * a.T + i];
-                    if (!a.lengths && base[(size_t)(C + c) * a.T + i] == 0.f) { t = kMaskedTime; v = 0.f; }
+        constexpr int NW = kBlock / kWave, G = 4;
+        for (int u0 = wave * G; u0 < units; u0 += NW * G) {
+            float2 val[G];
+            int dst[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int u = u0 + k;
+                dst[k] = -1;
+                val[k] = make_float2(kMaskedTime, 0.f);
+                if (u < units) {
+                    const int row = u / nchunk;
+                    const int i = (u - row * nchunk) * kWave + lane;
+                    if (i < npad) {
+                        dst[k] = row * stride + i;
+                        if (i < cnt[row]) {
+                            if (RAGGED) {
+                                const int64_t off = a.row_off[(size_t)e0 * C + row] + i;
+                                val[k] = make_float2(a.t_pk[off], a.v_pk[off]);
+                            } else {
+                                const int e = row / C, c = row - e * C;
+                                const float* base = a.x + (size_t)(e0 + e) * 4 * C * a.T;
+                                const float t = base[(size_t)(2 * C + c) * a.T + i];
+                                const float v = base[(size_t)c * a.T + i];
+                                const bool keep = a.lengths || base[(size_t)(C + c) * a.T + i] != 0.f;
+                                if (keep) val[k] = make_float2(t, v);
+                            }
+                        }
+                    }
                 }
-                obs[row * Tcap + i] = make_float2(t, v);
             }
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+                if (dst[k] >= 0) obs[dst[k]] = val[k];
         }
     }
     __syncthreads();
 
     // ---- 3. items (row, grid point, split): two passes over the LDS row
-    const int S = a.S, logS = a.logS;
     const int nitems = nrows * R * S;
-    for (int item = tid; item < nitems; item += kBlock) {
-        const int s = item & (S - 1);
-        const int q = item >> logS;
+    for (int base = 0; base < nitems; base += kBlock) {
+        const int item = base + tid;
+        const bool live = item < nitems;
+        const int it = live ? item : 0;
+        const int s = it & (S - 1);
+        const int q = it >> LOGS;
         const int row = q / R, r = q - row * R;
         const int e = row / C, c = row - e * C;
-        const int n = cnt[row];
-        const float2* p = obs + row * Tcap;
+        const float2* p = obs + row * stride + s;
         const float ref = refg[r];
         const float al = alpha[c];
+        // wave-uniform trip count: the longest row any lane of this wave works on
+        int nw = live ? cnt[row] : 0;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nw = max(nw, __shfl_xor(nw, m));
+        nw = __builtin_amdgcn_readfirstlane(nw);
+        const int nj = ((nw + S - 1) / S + U - 1) / U * U;      // per-lane elements, padded to the unroll
 
-        float umin = INFINITY;
-        for (int i = s; i < n; i += S) {
-            const float d = p[i].x - ref;
-            umin = fminf(umin, d * d);
+        // min_t u: u >= 0, so its IEEE bit pattern orders like an unsigned integer (v_min_u32: no NaN
+        // canonicalisation, and the compiler keeps the loop branch-free)
+        unsigned umin_bits = 0x7f800000u;
+        for (int j = 0; j < nj; j += U) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const float d = p[(j + k) * S].x - ref;
+                umin_bits = min(umin_bits, __float_as_uint(d * d));
+            }
         }
-        for (int m = 1; m < S; m <<= 1) umin = fminf(umin, __shfl_xor(umin, m));
+#pragma unroll
+        for (int m = 1; m < S; m <<= 1) umin_bits = min(umin_bits, (unsigned)__shfl_xor((int)umin_bits, m));
+        const float umin = __uint_as_float(umin_bits);
 
         const float na1 = -al * kLog2e, na10 = -10.0f * al * kLog2e;
         float s1 = 0.f, sx1 = 0.f, su1 = 0.f, sxu1 = 0.f;
         float s10 = 0.f, sx10 = 0.f, su10 = 0.f, sxu10 = 0.f;
-        for (int i = s; i < n; i += S) {
-            const float2 tv = p[i];
-            const float d = tv.x - ref;
-            const float u = d * d;
-            const float du = u - umin;
-            const float e1 = fast_exp2(na1 * du);
-            const float e10 = fast_exp2(na10 * du);
-            const float eu1 = e1 * u, eu10 = e10 * u;
-            s1 += e1;    sx1 = fmaf(e1, tv.y, sx1);    su1 += eu1;    sxu1 = fmaf(eu1, tv.y, sxu1);
-            s10 += e10;  sx10 = fmaf(e10, tv.y, sx10); su10 += eu10;  sxu10 = fmaf(eu10, tv.y, sxu10);
+        for (int j = 0; j < nj; j += U) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const float2 tv = p[(j + k) * S];
+                const float d = tv.x - ref;
+                const float u = d * d;
+                const float du = u - umin;
+                const float e1 = fast_exp2(na1 * du);
+                const float e10 = fast_exp2(na10 * du);
+                const float eu1 = e1 * u, eu10 = e10 * u;
+                s1 += e1;    sx1 = fmaf(e1, tv.y, sx1);    su1 += eu1;    sxu1 = fmaf(eu1, tv.y, sxu1);
+                s10 += e10;  sx10 = fmaf(e10, tv.y, sx10); su10 += eu10;  sxu10 = fmaf(eu10, tv.y, sxu10);
+            }
         }
+#pragma unroll
         for (int m = 1; m < S; m <<= 1) {
             s1 += __shfl_xor(s1, m);     sx1 += __shfl_xor(sx1, m);
             su1 += __shfl_xor(su1, m);   sxu1 += __shfl_xor(sxu1, m);
             s10 += __shfl_xor(s10, m);   sx10 += __shfl_xor(sx10, m);
             su10 += __shfl_xor(su10, m); sxu10 += __shfl_xor(sxu10, m);
         }
-        if (s == 0) {
+        if (live && s == 0) {
             float y, w, yt, eu1, exu1, eu10, exu10;
             if (umin < kEmptyU) {
                 const float i1 = 1.0f / s1, i10 = 1.0f / s10;
@@ -482,21 +534,43 @@ static int interp_fwd_launch(InterpArgs a, bool ragged, hipStream_t st) {
     const int fixed = one.total_words - per_enc;
     DIC_REQUIRE((size_t)one.total_words * 4 <= 64 * 1024, DIC_ERR_UNSUPPORTED,
                 "sci_cci_fwd: one encounter needs %d B of LDS (C=%d T=%d R=%d)", one.total_words * 4, a.C, a.Tcap, a.R);
-    a.E = pick_tile(a.B, per_enc, fixed, 40 * 1024, 16);
+    a.E = pick_tile(a.B, per_enc, fixed, 24 * 1024, 16);     // <= 24 KB of LDS: 6+ workgroups per CU hide the staging latency
+    // lanes per item: fill the 256 threads evenly (rounds of 256 items) without shrinking the per-lane
+    // stream below ~8 elements (the split costs 9 x log2(S) shuffles per item)
     int S = 1, logS = 0;
-    while (a.E * a.C * a.R * S < kBlock && S < 16) { S <<= 1; ++logS; }
+    {
+        const int base_items = a.E * a.C * a.R;
+        const int nest = max(8, a.Tcap / 2);
+        double best = 1e30;
+        for (int cand = 1, lg = 0; cand <= kMaxSplit; cand <<= 1, ++lg) {
+            const int rounds = (base_items * cand + kBlock - 1) / kBlock;
+            const double cost = rounds * ((double)nest / cand * 24.0 + 20.0 * lg + 30.0);
+            if (cost < best * 0.97) { best = cost; S = cand; logS = lg; }
+        }
+    }
     a.S = S; a.logS = logS;
     const InterpLayout L = interp_layout(a.E, a.C, a.R, a.Tcap);
     const int grid = (a.B + a.E - 1) / a.E;
-    if (ragged) hipLaunchKernelGGL(sci_cci_fwd_kernel<true>, dim3(grid), dim3(kBlock), (size_t)L.total_words * 4, st, a);
-    else hipLaunchKernelGGL(sci_cci_fwd_kernel<false>, dim3(grid), dim3(kBlock), (size_t)L.total_words * 4, st, a);
+    const size_t lds = (size_t)L.total_words * 4;
+#define DIC_LAUNCH_FWD(RG, SS) hipLaunchKernelGGL((sci_cci_fwd_kernel<RG, SS>), dim3(grid), dim3(kBlock), lds, st, a)
+#define DIC_LAUNCH_FWD_S(RG)                     \
+    switch (S) {                                 \
+        case 1: DIC_LAUNCH_FWD(RG, 1); break;    \
+        case 2: DIC_LAUNCH_FWD(RG, 2); break;    \
+        case 4: DIC_LAUNCH_FWD(RG, 4); break;    \
+        case 8: DIC_LAUNCH_FWD(RG, 8); break;    \
+        default: DIC_LAUNCH_FWD(RG, 16); break;  \
+    }
+    if (ragged) { DIC_LAUNCH_FWD_S(true) } else { DIC_LAUNCH_FWD_S(false) }
+#undef DIC_LAUNCH_FWD_S
+#undef DIC_LAUNCH_FWD
     return check_launch("sci_cci_fwd");
 }
 
 static void bwd_geometry(int B, int C, int R, int* E, int* nblk, size_t* lds) {
     const BwdLayout one = bwd_layout(1, C, R), two = bwd_layout(2, C, R);
     const int per_enc = two.total_words - one.total_words, fixed = one.total_words - per_enc;
-    *E = pick_tile(B, per_enc, fixed, 48 * 1024, 16);
+    *E = pick_tile(B, per_enc, fixed, 24 * 1024, 16);
     *nblk = min((B + *E - 1) / *E, 4 * kNumCU);
     *lds = (size_t)bwd_layout(*E, C, R).total_words * 4;
 }

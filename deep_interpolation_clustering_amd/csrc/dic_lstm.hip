@@ -1,0 +1,315 @@
+// Persistent recurrence kernels of the bidirectional LSTM (hidden size 128) that sits between the
+// interpolation and de-interpolation kernels (clustering_interp.py:14-41: EncoderRNN / DecoderRNN,
+// torch.nn.LSTM semantics, gate order i,f,g,o).
+//
+// Why: rocprofv3 of the joint step (profiles/r1_step_*_kernel_stats.csv) shows MIOpen's LSTM -- ~100 small
+// GEMM + point-wise launches per direction-step, a 2.5 ms generic bias-gradient reduce, sub-tensor copies --
+// taking ~90 % of the step; the north-star's "MFMA only if the dense layers prove the bottleneck" clause.
+//
+// Split of the work: the time-parallel GEMMs (input projection X.W_ih^T for all steps, dX, dW_ih, dW_hh,
+// bias gradient) stay large hipBLASLt GEMMs issued from Python; these kernels do the SEQUENTIAL part only:
+//   forward :  G_t = gx_t + h_{t-1}.W_hh^T ; i,f,o = sigmoid, g = tanh ; c_t = f c_{t-1} + i g ; h_t = o tanh(c_t)
+//   backward:  gate gradients from (dh_t, dc_t), dh_{t-1} = dG_t.W_hh, dc_{t-1} = dc_t f_t
+// One 256-thread workgroup owns 64 batch rows of one direction for the whole sequence (h, c, dh, dc never
+// leave the chip).  The MFMA is issued TRANSPOSED -- D[gate col][batch] = W_hh[gate col][k] . h^T[k][batch]
+// (v_mfma_f32_32x32x16_bf16) -- so that wave w's A operand is the slice of W_hh for hidden units
+// [32w,32w+32): 32 fragments = 128 VGPRs loaded ONCE and kept for all R steps (weights never re-read), the
+// B operand is the 64x128 bf16 h tile in LDS (272-B padded rows: conflict-free ds_read_b128), and the four
+// gate accumulators of a hidden unit land in the same lane/register, so the gate math is register-local.
+// bf16 operands, f32 accumulation, f32 cell state.
+#include "dic_common.h"
+
+namespace dic {
+
+constexpr int LH = 128;            // hidden size (compiled in)
+constexpr int LBM = 64;            // batch rows per workgroup
+constexpr int LNB = LBM / 32;      // 32-wide batch tiles per workgroup
+constexpr int HSTR = LH + 8;       // bf16 elements per LDS row of the h tile (272 B)
+constexpr int GSTR = 4 * LH + 8;   // bf16 elements per LDS row of the dG tile (1040 B)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp2(-kLog2e * x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp2(2.0f * kLog2e * x)); }
+
+struct LstmFwdArgs {
+    const __bf16* gx;      // (R,B,2,4,H) input projection + both biases
+    const __bf16* whh;     // (2,4H,H)
+    const float* h0; const float* c0;     // (2,B,H) or NULL (zeros)
+    __bf16* out;           // (R,B,2H): forward direction in [:H], reverse in [H:]
+    float* hn; float* cn;  // (2,B,H)
+    __bf16* gates;         // (R,B,2,4,H) post-activation i,f,g,o, or NULL (inference)
+    float* cs;             // (R,B,2,H) cell states, or NULL
+    int R, B;
+};
+
+__global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(LstmFwdArgs a) {
+    __shared__ __align__(16) __bf16 hbuf[2][LBM * HSTR];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
+
+    // A operand: this wave's W_hh rows (4 gates x 32 hidden units) for all 8 k-steps, resident in VGPRs
+    bf16x8 wf[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            wf[g][ks] = *reinterpret_cast<const bf16x8*>(a.whh + ((size_t)(dir * 4 + g) * LH + 32 * w + r) * LH + ks * 16 + 8 * hh);
+
+    // cell state and h_0: lane owns batch row (nb*32 + r) and hidden units 32w + 8q + 4hh + {0..3}, q = 0..3
+    float c[LNB][16];
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) {
+        const int b = b0 + nb * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = 32 * w + 8 * q + 4 * hh;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+                if (a.h0) hv = *reinterpret_cast<const f32x4*>(a.h0 + ((size_t)dir * B + b) * LH + u);
+                if (a.c0) cv = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + b) * LH + u);
+            }
+            bf16x4 hb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hb[j] = (__bf16)hv[j]; c[nb][4 * q + j] = cv[j]; }
+            *reinterpret_cast<bf16x4*>(&hbuf[0][(nb * 32 + r) * HSTR + u]) = hb;
+        }
+    }
+    __syncthreads();
+
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? R - 1 - step : step;
+        const int cur = step & 1;
+        // accumulators start from the input projection of this step
+        f32x16 acc[4][LNB];
+#pragma unroll
+        for (int nb = 0; nb < LNB; ++nb) {
+            const int b = b0 + nb * 32 + r;
+            const __bf16* gp = a.gx + (((size_t)t * B + min(b, B - 1)) * 2 + dir) * 4 * LH + 32 * w + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(gp + g * LH + 8 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[g][nb][4 * q + j] = (float)v[j];
+                }
+        }
+        // G += W_hh . h_{t-1}^T
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < LNB; ++nb) {
+                const bf16x8 hb = *reinterpret_cast<const bf16x8*>(&hbuf[cur][(nb * 32 + r) * HSTR + ks * 16 + 8 * hh]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g][ks], hb, acc[g][nb], 0, 0, 0);
+            }
+        // gate math, register-local
+        const bool last = step == R - 1;
+#pragma unroll
+        for (int nb = 0; nb < LNB; ++nb) {
+            const int b = b0 + nb * 32 + r;
+            const bool ok = b < B;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u = 32 * w + 8 * q + 4 * hh;
+                bf16x4 hb, ib, fb, gb, ob;
+                f32x4 cv, hv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * q + j;
+                    const float ig = sigmoid_fast(acc[0][nb][k]);
+                    const float fg = sigmoid_fast(acc[1][nb][k]);
+                    const float gg = tanh_fast(acc[2][nb][k]);
+                    const float og = sigmoid_fast(acc[3][nb][k]);
+                    const float cn = fmaf(fg, c[nb][k], ig * gg);
+                    const float hn = og * tanh_fast(cn);
+                    c[nb][k] = cn;
+                    cv[j] = cn; hv[j] = hn;
+                    hb[j] = (__bf16)hn; ib[j] = (__bf16)ig; fb[j] = (__bf16)fg; gb[j] = (__bf16)gg; ob[j] = (__bf16)og;
+                }
+                *reinterpret_cast<bf16x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + u]) = hb;
+                if (ok) {
+                    const size_t row = (size_t)t * B + b;
+                    *reinterpret_cast<bf16x4*>(a.out + row * 2 * LH + dir * LH + u) = hb;
+                    if (a.gates) {
+                        __bf16* gp = a.gates + (row * 2 + dir) * 4 * LH + u;
+                        *reinterpret_cast<bf16x4*>(gp) = ib;
+                        *reinterpret_cast<bf16x4*>(gp + LH) = fb;
+                        *reinterpret_cast<bf16x4*>(gp + 2 * LH) = gb;
+                        *reinterpret_cast<bf16x4*>(gp + 3 * LH) = ob;
+                    }
+                    if (a.cs) *reinterpret_cast<f32x4*>(a.cs + (row * 2 + dir) * LH + u) = cv;
+                    if (last) {
+                        *reinterpret_cast<f32x4*>(a.hn + ((size_t)dir * B + b) * LH + u) = hv;
+                        *reinterpret_cast<f32x4*>(a.cn + ((size_t)dir * B + b) * LH + u) = cv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct LstmBwdArgs {
+    const __bf16* whh_t;   // (2,H,4H): whh_t[d][u][n] = whh[d][n][u]
+    const __bf16* gates;   // (R,B,2,4,H)
+    const float* cs;       // (R,B,2,H)
+    const float* c0;       // (2,B,H) or NULL
+    const __bf16* dout;    // (R,B,2H) or NULL
+    const float* dhn; const float* dcn;   // (2,B,H) or NULL
+    __bf16* dgx;           // (R,B,2,4,H) pre-activation gate gradients
+    float* dh0; float* dc0;               // (2,B,H)
+    int R, B;
+};
+
+__global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(LstmBwdArgs a) {
+    extern __shared__ __align__(16) __bf16 dgt[];      // [LBM][GSTR]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
+
+    // A operand: W_hh^T rows for this wave's 32 hidden units, all 32 k-steps over the 4H gate columns
+    bf16x8 wt[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks)
+        wt[ks] = *reinterpret_cast<const bf16x8*>(a.whh_t + ((size_t)dir * LH + 32 * w + r) * 4 * LH + ks * 16 + 8 * hh);
+
+    f32x16 dh[LNB];        // recurrent dL/dh arriving at the current step
+    float dc[LNB][16];
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) {
+        const int b = b0 + nb * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = 32 * w + 8 * q + 4 * hh;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+                if (a.dhn) hv = *reinterpret_cast<const f32x4*>(a.dhn + ((size_t)dir * B + b) * LH + u);
+                if (a.dcn) cv = *reinterpret_cast<const f32x4*>(a.dcn + ((size_t)dir * B + b) * LH + u);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dh[nb][4 * q + j] = hv[j]; dc[nb][4 * q + j] = cv[j]; }
+        }
+    }
+
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? step : R - 1 - step;           // reverse of the forward visiting order
+        const bool first_fwd = step == R - 1;               // this t was the forward pass' first step
+        const int tp = dir ? t + 1 : t - 1;                 // forward predecessor
+#pragma unroll
+        for (int nb = 0; nb < LNB; ++nb) {
+            const int b = b0 + nb * 32 + r;
+            const bool ok = b < B;
+            const size_t row = (size_t)t * B + min(b, B - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u = 32 * w + 8 * q + 4 * hh;
+                const __bf16* gp = a.gates + (row * 2 + dir) * 4 * LH + u;
+                const bf16x4 ib = *reinterpret_cast<const bf16x4*>(gp);
+                const bf16x4 fb = *reinterpret_cast<const bf16x4*>(gp + LH);
+                const bf16x4 gb = *reinterpret_cast<const bf16x4*>(gp + 2 * LH);
+                const bf16x4 ob = *reinterpret_cast<const bf16x4*>(gp + 3 * LH);
+                const f32x4 ct = *reinterpret_cast<const f32x4*>(a.cs + (row * 2 + dir) * LH + u);
+                f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+                if (!first_fwd) cp = *reinterpret_cast<const f32x4*>(a.cs + ((((size_t)tp * B + min(b, B - 1)) * 2 + dir)) * LH + u);
+                else if (a.c0) cp = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + min(b, B - 1)) * LH + u);
+                bf16x4 go = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + row * 2 * LH + dir * LH + u);
+                bf16x4 di, df, dg, dO;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * q + j;
+                    const float ig = (float)ib[j], fg = (float)fb[j], gg = (float)gb[j], og = (float)ob[j];
+                    const float dht = dh[nb][k] + (float)go[j];
+                    const float tc = tanh_fast(ct[j]);
+                    const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
+                    di[j] = (__bf16)(dct * gg * ig * (1.0f - ig));
+                    df[j] = (__bf16)(dct * cp[j] * fg * (1.0f - fg));
+                    dg[j] = (__bf16)(dct * ig * (1.0f - gg * gg));
+                    dO[j] = (__bf16)(dht * tc * og * (1.0f - og));
+                    dc[nb][k] = dct * fg;
+                }
+                __bf16* lp = dgt + (nb * 32 + r) * GSTR + u;
+                *reinterpret_cast<bf16x4*>(lp) = di;
+                *reinterpret_cast<bf16x4*>(lp + LH) = df;
+                *reinterpret_cast<bf16x4*>(lp + 2 * LH) = dg;
+                *reinterpret_cast<bf16x4*>(lp + 3 * LH) = dO;
+                if (ok) {
+                    __bf16* op = a.dgx + (row * 2 + dir) * 4 * LH + u;
+                    *reinterpret_cast<bf16x4*>(op) = di;
+                    *reinterpret_cast<bf16x4*>(op + LH) = df;
+                    *reinterpret_cast<bf16x4*>(op + 2 * LH) = dg;
+                    *reinterpret_cast<bf16x4*>(op + 3 * LH) = dO;
+                }
+            }
+        }
+        __syncthreads();
+        // dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n]
+#pragma unroll
+        for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dh[nb][k] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < LNB; ++nb) {
+                const bf16x8 gbv = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + r) * GSTR + ks * 16 + 8 * hh);
+                dh[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, dh[nb], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) {
+        const int b = b0 + nb * 32 + r;
+        if (b >= B) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = 32 * w + 8 * q + 4 * hh;
+            f32x4 hv, cv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hv[j] = dh[nb][4 * q + j]; cv[j] = dc[nb][4 * q + j]; }
+            *reinterpret_cast<f32x4*>(a.dh0 + ((size_t)dir * B + b) * LH + u) = hv;
+            *reinterpret_cast<f32x4*>(a.dc0 + ((size_t)dir * B + b) * LH + u) = cv;
+        }
+    }
+}
+
+}  // namespace dic
+
+using namespace dic;
+
+extern "C" {
+
+int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
+                 void* out, float* hn, float* cn, void* gates, float* cs, dic_stream_t stream) {
+    DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd: non-positive size");
+    DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d (compiled for %d)", H, LH);
+    DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd: NULL pointer");
+    DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd: gates and cs go together");
+    LstmFwdArgs a{(const __bf16*)gx, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, cs, R, B};
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + LBM - 1) / LBM, 2), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("lstm_fwd");
+}
+
+int dic_lstm_bwd(const void* whh_t, const void* gates, const float* cs, const float* c0, const void* dout,
+                 const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
+                 dic_stream_t stream) {
+    DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_bwd: non-positive size");
+    DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_bwd: hidden size %d (compiled for %d)", H, LH);
+    DIC_REQUIRE(whh_t && gates && cs && dgx && dh0 && dc0, DIC_ERR_INVALID_ARG, "lstm_bwd: NULL pointer");
+    static const size_t lds = (size_t)LBM * GSTR * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    LstmBwdArgs a{(const __bf16*)whh_t, (const __bf16*)gates, cs, c0, (const __bf16*)dout, dhn, dcn, (__bf16*)dgx, dh0, dc0, R, B};
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + LBM - 1) / LBM, 2), dim3(256), lds, (hipStream_t)stream, a);
+    return check_launch("lstm_bwd");
+}
+
+}  // extern "C"

@@ -79,26 +79,35 @@ struct RbfBwdArgs {
     float* grad_v; float* partials;
 };
 
-struct RbfBwdLayout { int cnt, refg, nbeta, vs, gbeta, obs, total_words; };
+struct RbfBwdLayout { int cnt, refg, nbeta, vs, gbeta, obs, stride, total_words; };
+constexpr int kRbfMaxSplit = 16;
+// odd stride (in float4 elements) + room for the loop-tail padding: see interp_row_stride
+__host__ __device__ inline int rbf_row_stride(int T) { return (T + kRbfMaxSplit) | 1; }
 __host__ __device__ inline RbfBwdLayout rbf_bwd_layout(int E, int C, int R, int T) {
     RbfBwdLayout L;
     int o = 0;
-    L.cnt = o;   o += E * C;
+    L.cnt = o;   o += E * C + 1;      // +1: tile maximum
     L.refg = o;  o += R;
     L.nbeta = o; o += C;
     L.vs = o;    o += E * C * R;
     L.gbeta = o; o += E * C * R;      // per-item dL/dbeta terms
     o = (o + 3) & ~3;                 // float4 alignment
-    L.obs = o;   o += 4 * E * C * T;
+    L.stride = rbf_row_stride(T);
+    L.obs = o;   o += 4 * E * C * L.stride;
     L.total_words = o;
     return L;
 }
 
+template <int S>
 __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
+    constexpr int U = S >= 4 ? 1 : 4 / S;
+    constexpr int LOGS = S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : S == 8 ? 3 : 4;
     extern __shared__ __align__(16) float smem[];
     const int C = a.C, R = a.R, T = a.T, E = a.E;
     const RbfBwdLayout L = rbf_bwd_layout(E, C, R, T);
+    const int stride = L.stride;
     int* cnt = reinterpret_cast<int*>(smem + L.cnt);
+    int* tile_max = cnt + E * C;
     float* refg = smem + L.refg; float* nbeta = smem + L.nbeta; float* vs = smem + L.vs; float* gb = smem + L.gbeta;
     float4* obs = reinterpret_cast<float4*>(smem + L.obs);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -110,48 +119,80 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
     for (int e0 = blockIdx.x * E; e0 < a.B; e0 += a.nblk * E) {
         const int Ev = min(E, a.B - e0), nrows = Ev * C;
         __syncthreads();
-        for (int i = tid; i < nrows * R; i += kBlock) vs[i] = a.v[(size_t)e0 * C * R + i];
-        for (int i = tid; i < nrows; i += kBlock)
-            cnt[i] = a.lengths ? max(0, min(a.lengths[(size_t)e0 * C + i], T)) : T;
+        if (tid == 0) *tile_max = 0;
         __syncthreads();
-        // stage (t, g*m/(N+eps), S/(N+eps), -) per slot; masked slots get weight 0
-        const int nchunk = (T + kWave - 1) / kWave, units = nrows * nchunk;
-#pragma unroll 2
-        for (int u = wave; u < units; u += kBlock / kWave) {
-            const int row = u / nchunk;
-            const int i = (u - row * nchunk) * kWave + lane;
-            if (i < cnt[row]) {
-                const int e = row / C, c = row - e * C;
-                const float* base = a.x + (size_t)(e0 + e) * 4 * C * T;
-                const size_t o = ((size_t)(e0 + e) * C + c) * T + i;
-                const float t = base[(size_t)(2 * C + c) * T + i];
-                float m = 1.f;
-                if (!a.lengths) m = base[(size_t)(C + c) * T + i];
-                const float den = a.norm[o] + kRbfEps;
-                // y = m*S/den upstream, so dL/dS = g*m/den; S/den = y for a valid slot
-                const float wgt = (m != 0.f) ? a.grad_y[o] * m / den : 0.f;
-                obs[row * T + i] = make_float4(t, wgt, (m != 0.f) ? a.y[o] / m : 0.f, 0.f);
-            }
+        for (int i = tid; i < nrows * R; i += kBlock) vs[i] = a.v[(size_t)e0 * C * R + i];
+        for (int i = tid; i < nrows; i += kBlock) {
+            const int n = a.lengths ? max(0, min(a.lengths[(size_t)e0 * C + i], T)) : T;
+            cnt[i] = n;
+            atomicMax(tile_max, n);
         }
         __syncthreads();
-        const int S = a.S, logS = a.logS, nitems = nrows * R * S;
-        for (int item = tid; item < nitems; item += kBlock) {
-            const int s = item & (S - 1), q = item >> logS;
-            const int row = q / R, r = q - row * R, c = row % C;
-            const int n = cnt[row];
-            const float4* p = obs + row * T;
-            const float ref = refg[r], nb = nbeta[c], vr = vs[row * R + r];
-            float gv = 0.f, gbt = 0.f;
-            for (int i = s; i < n; i += S) {
-                const float4 o = p[i];
-                const float d = o.x - ref;
-                const float u = d * d;
-                const float wphi = o.y * fast_exp2(nb * u);
-                gv += wphi;
-                gbt = fmaf(wphi * u, o.z - vr, gbt);
+        // stage (t, g*m/(N+eps), S/(N+eps), -) per slot, 4 chunks in flight per wave; masked slots and the
+        // padding up to the tile maximum get weight 0 (so the streaming loop needs no bounds checks)
+        const int npad = min(*tile_max + kRbfMaxSplit, stride);
+        const int nchunk = (npad + kWave - 1) / kWave, units = nrows * nchunk;
+        constexpr int NW = kBlock / kWave, G = 4;
+        for (int u0 = wave * G; u0 < units; u0 += NW * G) {
+            float4 val[G];
+            int dst[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int u = u0 + k;
+                dst[k] = -1;
+                val[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u < units) {
+                    const int row = u / nchunk;
+                    const int i = (u - row * nchunk) * kWave + lane;
+                    if (i < npad) {
+                        dst[k] = row * stride + i;
+                        if (i < cnt[row]) {
+                            const int e = row / C, c = row - e * C;
+                            const float* base = a.x + (size_t)(e0 + e) * 4 * C * T;
+                            const size_t o = ((size_t)(e0 + e) * C + c) * T + i;
+                            const float t = base[(size_t)(2 * C + c) * T + i];
+                            const float m = a.lengths ? 1.f : base[(size_t)(C + c) * T + i];
+                            const float den = a.norm[o] + kRbfEps;
+                            // y = m*S/den upstream, so dL/dS = g*m/den; S/den = y for a valid slot
+                            if (m != 0.f) val[k] = make_float4(t, a.grad_y[o] / den, a.y[o], 0.f);
+                        }
+                    }
+                }
             }
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+                if (dst[k] >= 0) obs[dst[k]] = val[k];
+        }
+        __syncthreads();
+        const int nitems = nrows * R * S;
+        for (int base = 0; base < nitems; base += kBlock) {
+            const int item = base + tid;
+            const bool live = item < nitems;
+            const int it = live ? item : 0;
+            const int s = it & (S - 1), q = it >> LOGS;
+            const int row = q / R, r = q - row * R, c = row % C;
+            const float4* p = obs + row * stride + s;
+            const float ref = refg[r], nb = nbeta[c], vr = vs[row * R + r];
+            int nw = live ? cnt[row] : 0;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) nw = max(nw, __shfl_xor(nw, m));
+            nw = __builtin_amdgcn_readfirstlane(nw);
+            const int nj = ((nw + S - 1) / S + U - 1) / U * U;
+            float gv = 0.f, gbt = 0.f;
+            for (int j = 0; j < nj; j += U) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const float4 o = p[(j + k) * S];
+                    const float d = o.x - ref;
+                    const float u = d * d;
+                    const float wphi = o.y * fast_exp2(nb * u);
+                    gv += wphi;
+                    gbt = fmaf(wphi * u, o.z - vr, gbt);
+                }
+            }
+#pragma unroll
             for (int m = 1; m < S; m <<= 1) { gv += __shfl_xor(gv, m); gbt += __shfl_xor(gbt, m); }
-            if (s == 0) {
+            if (live && s == 0) {
                 a.grad_v[((size_t)e0 * C + row) * R + r] = gv;
                 gb[row * R + r] = gbt;
             }
@@ -263,7 +304,7 @@ int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int
 
 static void rbf_bwd_geometry(int B, int C, int T, int R, int* E, int* nblk, size_t* lds) {
     const int one = rbf_bwd_layout(1, C, R, T).total_words, two = rbf_bwd_layout(2, C, R, T).total_words;
-    *E = rbf_tile(B, two - one, one - (two - one), 48 * 1024);
+    *E = rbf_tile(B, two - one, one - (two - one), 24 * 1024);
     *nblk = min((B + *E - 1) / *E, 8 * kNumCU);
     *lds = (size_t)rbf_bwd_layout(*E, C, R, T).total_words * 4;
 }
@@ -290,10 +331,25 @@ int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int
     rbf_bwd_geometry(B, C, T, R, &a.E, &a.nblk, &lds);
     DIC_REQUIRE(lds <= 64 * 1024, DIC_ERR_UNSUPPORTED, "rbf_bwd: one encounter needs %zu B of LDS", lds);
     DIC_REQUIRE(workspace_bytes >= (size_t)a.nblk * C * sizeof(float), DIC_ERR_WORKSPACE, "rbf_bwd: workspace too small");
-    a.S = 1; a.logS = 0;
-    while (a.E * C * R * a.S < kBlock && a.S < 16) { a.S <<= 1; ++a.logS; }
+    {   // lanes per (row, grid point) item: see sci_cci_fwd
+        const int base_items = a.E * C * R;
+        const int nest = max(8, T / 2);
+        double best = 1e30;
+        a.S = 1; a.logS = 0;
+        for (int cand = 1, lg = 0; cand <= kRbfMaxSplit; cand <<= 1, ++lg) {
+            const int rounds = (base_items * cand + kBlock - 1) / kBlock;
+            const double cost = rounds * ((double)nest / cand * 12.0 + 6.0 * lg + 25.0);
+            if (cost < best * 0.97) { best = cost; a.S = cand; a.logS = lg; }
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(rbf_bwd_kernel, dim3(a.nblk), dim3(kBlock), lds, st, a);
+    switch (a.S) {
+        case 1: hipLaunchKernelGGL(rbf_bwd_kernel<1>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
+        case 2: hipLaunchKernelGGL(rbf_bwd_kernel<2>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
+        case 4: hipLaunchKernelGGL(rbf_bwd_kernel<4>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
+        case 8: hipLaunchKernelGGL(rbf_bwd_kernel<8>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
+        default: hipLaunchKernelGGL(rbf_bwd_kernel<16>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
+    }
     hipLaunchKernelGGL(rbf_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)workspace, a.nblk, C, rbf_kernel,
                        grad_rbf_kernel);
     return check_launch("rbf_bwd");

@@ -1,0 +1,109 @@
+"""Fused bidirectional LSTM (hidden 128, one layer) for the encoder / decoder of ``Net``
+(clustering_interp.py:14-41) on the persistent HIP recurrence kernels of ``csrc/dic_lstm.hip``.
+
+``torch.nn.LSTM`` semantics and parameters (``weight_ih_l0[_reverse]``, ``weight_hh_l0[_reverse]``,
+``bias_ih_l0[_reverse]``, ``bias_hh_l0[_reverse]``; gate order i,f,g,o) are kept -- the module still owns an
+``nn.LSTM`` so ``state_dict`` keys do not change.  What changes is who executes it when the step runs
+under bf16 autocast on the GPU:
+
+  time-parallel GEMMs (hipBLASLt, bf16 in / f32 accumulate), issued here:
+      gx = X.W_ih^T + b_ih + b_hh            (R*B x I) . (I x 8H)
+      dX = dG.W_ih,  dW_ih = dG^T.X,  dW_hh = dG^T.H_prev,  db = sum dG
+  sequential recurrence (dic_lstm_fwd / dic_lstm_bwd): one workgroup per 64 batch rows and direction keeps
+  h, c (dh, dc) on chip for all R steps with W_hh resident in registers.
+
+In f32 (no autocast) the stock ``nn.LSTM`` (MIOpen) is used: that is the configuration the 1e-5 parity
+tests run in.  The bf16 path is checked against an f32 emulation with the same rounding points.
+"""
+import torch
+
+from . import _native as N
+
+H = 128
+
+
+def fused_available(x, lstm):
+    return (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and lstm.hidden_size == H and lstm.num_layers == 1 and lstm.bidirectional and lstm.bias
+            and not lstm.batch_first and lstm.proj_size == 0)
+
+
+class _BiLstm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, bias, h0, c0):
+        R, B, I = x.shape
+        bf = torch.bfloat16
+        Ip = (I + 15) // 16 * 16                                  # K of the projection GEMM padded to the MFMA step
+        xb = x.to(bf)
+        wihb = w_ih.reshape(8 * H, I).to(bf)
+        if Ip != I:
+            xb = torch.nn.functional.pad(xb, (0, Ip - I))
+            wihb = torch.nn.functional.pad(wihb, (0, Ip - I))
+        xb = xb.contiguous()
+        gx = torch.addmm(bias.reshape(8 * H).to(bf), xb.view(R * B, Ip), wihb.t())      # (R*B, 2*4*H)
+        whhb = w_hh.to(bf).contiguous()                            # (2,4H,H)
+        need = any(ctx.needs_input_grad)
+        dev = x.device
+        out = torch.empty((R, B, 2 * H), device=dev, dtype=bf)
+        hn = torch.empty((2, B, H), device=dev, dtype=torch.float32)
+        cn = torch.empty_like(hn)
+        gates = torch.empty((R, B, 2, 4, H), device=dev, dtype=bf) if need else None
+        cs = torch.empty((R, B, 2, H), device=dev, dtype=torch.float32) if need else None
+        h0c = None if h0 is None else h0.float().contiguous()
+        c0c = None if c0 is None else c0.float().contiguous()
+        N.check(N.lib().dic_lstm_fwd(N.ptr(gx), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
+                                     N.ptr(cn), N.ptr(gates), N.ptr(cs), N.stream_of(x)), 'dic_lstm_fwd')
+        ctx.dims = (R, B, I, Ip)
+        ctx.x_dtype = x.dtype
+        ctx.has_init = h0 is not None
+        ctx.save_for_backward(xb, wihb, whhb, gates, cs, out, h0c, c0c)
+        return out, hn, cn
+
+    @staticmethod
+    def backward(ctx, dout, dhn, dcn):
+        xb, wihb, whhb, gates, cs, out, h0c, c0c = ctx.saved_tensors
+        R, B, I, Ip = ctx.dims
+        bf = torch.bfloat16
+        dev = out.device
+        dgx = torch.empty((R, B, 2, 4, H), device=dev, dtype=bf)
+        dh0 = torch.empty((2, B, H), device=dev, dtype=torch.float32)
+        dc0 = torch.empty_like(dh0)
+        whh_t = whhb.transpose(1, 2).contiguous()                  # (2,H,4H)
+        doutb = None if dout is None else dout.to(bf).contiguous()
+        dhnc = None if dhn is None else dhn.float().contiguous()
+        dcnc = None if dcn is None else dcn.float().contiguous()
+        N.check(N.lib().dic_lstm_bwd(N.ptr(whh_t), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
+                                     R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.stream_of(out)), 'dic_lstm_bwd')
+        dg2 = dgx.view(R * B, 8 * H)
+        dx = dw_ih = dw_hh = dbias = None
+        if ctx.needs_input_grad[0]:
+            dx = (dg2 @ wihb)[:, :I].reshape(R, B, I).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            dw_ih = (dg2.t() @ xb.view(R * B, Ip))[:, :I].float().reshape(2, 4 * H, I)
+        if ctx.needs_input_grad[2]:
+            # H_prev: the hidden state each step consumed (forward: h_{t-1}; reverse: h_{t+1}; h_0 at the ends)
+            hprev = torch.empty((R, B, 2, H), device=dev, dtype=bf)
+            o4 = out.view(R, B, 2, H)
+            hprev[1:, :, 0] = o4[:-1, :, 0]
+            hprev[:-1, :, 1] = o4[1:, :, 1]
+            if h0c is None:
+                hprev[0, :, 0].zero_()
+                hprev[R - 1, :, 1].zero_()
+            else:
+                hprev[0, :, 0] = h0c[0].to(bf)
+                hprev[R - 1, :, 1] = h0c[1].to(bf)
+            full = dg2.t() @ hprev.view(R * B, 2 * H)             # (8H, 2H): the two diagonal blocks are wanted
+            dw_hh = torch.stack([full[:4 * H, :H], full[4 * H:, H:]]).float()
+        if ctx.needs_input_grad[3]:
+            dbias = torch.sum(dg2, dim=0, dtype=torch.float32).reshape(2, 4 * H)
+        return dx, dw_ih, dw_hh, dbias, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None)
+
+
+def bilstm(x, lstm, h0=None, c0=None):
+    """(out (R,B,2H) bf16, (h_n, c_n) (2,B,H) f32) = bidirectional LSTM of x (R,B,I) with ``lstm``'s parameters."""
+    w_ih = torch.stack([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse])
+    w_hh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse])
+    bias = torch.stack([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse])
+    with torch.autocast('cuda', enabled=False):
+        out, hn, cn = _BiLstm.apply(x, w_ih.float(), w_hh.float(), bias.float(), h0, c0)
+    return out, (hn, cn)

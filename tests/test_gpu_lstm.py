@@ -1,0 +1,125 @@
+"""Fused bi-LSTM recurrence (csrc/dic_lstm.hip + lstm.py, the bf16 fast path) against
+(1) an f32 emulation that rounds to bf16 at exactly the kernel's rounding points, and
+(2) torch.nn.LSTM in f32 (loose: bf16 operands)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+H = 128
+
+
+def rb(x):
+    return x.to(torch.bfloat16).float()
+
+
+def emulate(x, lstm, h0=None, c0=None):
+    """Differentiable f32 torch loop with the kernel's bf16 rounding points: X, W_ih, W_hh, gx, the h fed back."""
+    R, B, I = x.shape
+    outs, hn, cn = [None, None], [], []
+    for d, sfx in enumerate(('', '_reverse')):
+        w_ih, w_hh = getattr(lstm, 'weight_ih_l0' + sfx), getattr(lstm, 'weight_hh_l0' + sfx)
+        bias = getattr(lstm, 'bias_ih_l0' + sfx) + getattr(lstm, 'bias_hh_l0' + sfx)
+        gx = rb(rb(x).reshape(R * B, I) @ rb(w_ih).t() + rb(bias)).reshape(R, B, 4 * H)
+        h = torch.zeros(B, H, device=x.device) if h0 is None else h0[d]
+        c = torch.zeros(B, H, device=x.device) if c0 is None else c0[d]
+        seq = [None] * R
+        for t in (range(R) if d == 0 else range(R - 1, -1, -1)):
+            g = gx[t] + rb(h) @ rb(w_hh).t()
+            i, f, gg, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H]), torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:])
+            c = f * c + i * gg
+            h = o * torch.tanh(c)
+            seq[t] = h
+        outs[d] = torch.stack(seq)
+        hn.append(h)
+        cn.append(c)
+    return torch.cat(outs, dim=-1), torch.stack(hn), torch.stack(cn)
+
+
+@pytest.mark.parametrize('R,B,I,init', [(24, 200, 18, False), (24, 96, 256, True), (6, 64, 18, False), (5, 1, 256, True), (3, 130, 40, True)])
+def test_fused_bilstm_matches_emulation(R, B, I, init):
+    from deep_interpolation_clustering_amd import lstm as L
+    torch.manual_seed(R * 1000 + B)
+    dev = torch.device('cuda')
+    net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, I, device=dev) * (1.0 if I < 100 else 0.5)
+    h0 = (torch.randn(2, B, H, device=dev) * 0.5).requires_grad_() if init else None
+    c0 = (torch.randn(2, B, H, device=dev) * 0.5).requires_grad_() if init else None
+    x1 = x.clone().requires_grad_()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert L.fused_available(x1, net)
+        out, (hn, cn) = L.bilstm(x1, net, h0, c0)
+    assert out.dtype == torch.bfloat16 and hn.dtype == torch.float32
+    go = torch.randn(R, B, 2 * H, device=dev)
+    ghn, gcn = torch.randn(2, B, H, device=dev), torch.randn(2, B, H, device=dev)
+    ((out.float() * rb(go)).sum() + (hn * ghn).sum() + (cn * gcn).sum()).backward()
+    got = {k: p.grad.clone() for k, p in net.named_parameters()}
+    gx1 = x1.grad.clone()
+    gh0 = None if not init else (h0.grad.clone(), c0.grad.clone())
+    net.zero_grad()
+    if init:
+        h0.grad = c0.grad = None
+
+    x2 = x.clone().requires_grad_()
+    eo, ehn, ecn = emulate(x2, net, h0, c0)
+    ((eo * rb(go)).sum() + (ehn * ghn).sum() + (ecn * gcn).sum()).backward()
+    # forward: same rounding points -> differences only from accumulation order / fast sigmoid
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), eo.detach().cpu().numpy(), rtol=2e-2, atol=6e-3)
+    np.testing.assert_allclose(hn.detach().cpu().numpy(), ehn.detach().cpu().numpy(), rtol=1e-2, atol=4e-3)
+    np.testing.assert_allclose(cn.detach().cpu().numpy(), ecn.detach().cpu().numpy(), rtol=1e-2, atol=6e-3)
+
+    def close(a, b, name, tol=3e-2):
+        a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
+        err = np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+        assert err < tol, f'{name}: max err {err:.3e} of the max magnitude'
+    close(gx1, x2.grad, 'dx')
+    for k, p in net.named_parameters():
+        close(got[k], p.grad, k)
+    if init:
+        close(gh0[0], h0.grad, 'dh0')
+        close(gh0[1], c0.grad, 'dc0')
+
+
+def test_fused_bilstm_close_to_f32_lstm():
+    from deep_interpolation_clustering_amd import lstm as L
+    torch.manual_seed(7)
+    dev = torch.device('cuda')
+    R, B, I = 24, 300, 18
+    net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, I, device=dev)
+    ref, (rh, rc) = net(x)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out, (hn, cn) = L.bilstm(x, net)
+    assert float((out.float() - ref).abs().max()) < 3e-2
+    assert float((hn - rh).abs().max()) < 3e-2 and float((cn - rc).abs().max()) < 5e-2
+
+
+def test_joint_step_bf16_fused_tracks_f32():
+    """Whole joint step under bf16 autocast with the fused LSTM vs the f32 step: losses agree to bf16 accuracy."""
+    from types import SimpleNamespace
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=4, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    coh = synthetic.make_cohort(512, seed=3)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    x, ob, lens = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    res = {}
+    for mode in ('f32', 'bf16'):
+        torch.manual_seed(11)
+        net = Net(args, dev).to(dev)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args,
+                     autocast_dtype=torch.bfloat16 if mode == 'bf16' else None)
+        traj = []
+        for _ in range(5):
+            losses, gnorm, _ = st.step(x, ob, None, lens)
+            traj.append([float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(gnorm)])
+        res[mode] = np.array(traj)
+    assert np.isfinite(res['bf16']).all()
+    np.testing.assert_allclose(res['bf16'][:, 0], res['f32'][:, 0], rtol=3e-2)
+    assert res['bf16'][-1, 0] < res['bf16'][0, 0]           # it trains
