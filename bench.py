@@ -37,7 +37,7 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=30)
     p.add_argument('--warmup', type=int, default=10)
-    p.add_argument('--batch', type=int, default=int(os.environ.get('DIC_BENCH_BATCH', 8192)), help='encounters per GPU per step')
+    p.add_argument('--batch', type=int, default=int(os.environ.get('DIC_BENCH_BATCH', 16384)), help='encounters per GPU per step')
     p.add_argument('--encounters', type=int, default=75000, help='cohort size resident per GPU')
     p.add_argument('--clusters', type=int, default=None, help='K (default 4; 8 for the 8-GPU config)')
     p.add_argument('--dtype', choices=['bf16', 'f32'], default=os.environ.get('DIC_BENCH_DTYPE', 'bf16'),
@@ -116,8 +116,24 @@ def kernel_table(net, x, ob, lengths, K, iters):
         'dec_bwd': (lambda: L.dic_dec_bwd(P(z), P(mu), P(q), P(ts), P(gq), B, D, K, 1.0, P(gz), P(gmu), P(ws5), ws5.numel(), st),
                     4.0 * B * (2 * D + 2 * K)),
     }
-    # run the forwards once so the backward inputs (saved, y, norm, out2, ts) hold real values
-    for name in ('sci_cci_fwd', 'rbf_fwd', 'masked_sse_fwd', 'dec_fwd'):
+    # persistent bi-LSTM recurrence kernels (decoder shape; the encoder differs only in the GEMM feeding gx)
+    Hh, bf = 128, torch.bfloat16
+    Bp = (B + 63) // 64 * 64
+    gxl = (torch.randn((R, B, 2, 4, Hh), **f32) * 0.5).to(bf)
+    whh = (torch.randn((2, 4 * Hh, Hh), **f32) * 0.08).to(bf)
+    whh_t = whh.transpose(1, 2).contiguous()
+    lout, lgates = torch.empty((R, B, 2 * Hh), device=dev, dtype=bf), torch.empty((R, Bp, 2, 4, Hh), device=dev, dtype=bf)
+    lcs, lhn, lcn = torch.empty((R, Bp, 2, Hh), **f32), torch.empty((2, B, Hh), **f32), torch.empty((2, B, Hh), **f32)
+    ldout = (torch.randn((R, B, 2 * Hh), **f32) * 0.1).to(bf)
+    ldgx, ldh0, ldc0 = torch.empty((R, B, 2, 4, Hh), device=dev, dtype=bf), torch.empty((2, B, Hh), **f32), torch.empty((2, B, Hh), **f32)
+    rows = 2.0 * R * B                     # (step, batch row, direction) units
+    calls['lstm_fwd'] = (lambda: L.dic_lstm_fwd(P(gxl), P(whh), None, None, R, B, Hh, P(lout), P(lhn), P(lcn), P(lgates), P(lcs), st),
+                         rows * (4 * Hh * 2 + Hh * 2 + 4 * Hh * 2 + Hh * 4))      # gx in; h, gates, c out
+    calls['lstm_bwd'] = (lambda: L.dic_lstm_bwd(P(whh_t), P(lgates), P(lcs), None, P(ldout), None, None, R, B, Hh, P(ldgx), P(ldh0),
+                                                P(ldc0), st),
+                         rows * (4 * Hh * 2 + 2 * Hh * 4 + Hh * 2 + 4 * Hh * 2))  # gates, c_t, c_prev, dout in; dG out
+    # run the forwards once so the backward inputs (saved, y, norm, out2, ts, LSTM state) hold real values
+    for name in ('sci_cci_fwd', 'rbf_fwd', 'masked_sse_fwd', 'dec_fwd', 'lstm_fwd'):
         assert calls[name][0]() == 0, name
     table = {}
     for name, (fn, nbytes) in calls.items():
@@ -229,9 +245,11 @@ def main():
         dom = max(table, key=lambda k: table[k]['ms'])
         log('kernel table done:', {k: v['ms'] for k, v in table.items()})
         traffic = None
-        tf = os.path.join(ROOT, 'profiles', 'traffic.json')      # PMC-derived HBM bytes per launch, when collected
+        tf = os.path.join(ROOT, 'profiles', 'traffic.json')      # PMC-derived HBM bytes per launch (see its _note)
         if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(dom)
+            tj = json.load(open(tf))
+            if dom in tj:
+                traffic = int(tj[dom]['hbm_bytes'] * a.batch / tj.get('_batch', a.batch))
         custom_ms = sum(v['ms'] for v in table.values())
         out = {
             'metric': 'encounters/sec per joint interp+DEC step', 'value': round(value, 1), 'unit': 'encounters/s',

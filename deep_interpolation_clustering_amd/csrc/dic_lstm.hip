@@ -10,7 +10,7 @@
 // bias gradient) stay large hipBLASLt GEMMs issued from Python; these kernels do the SEQUENTIAL part only:
 //   forward :  G_t = gx_t + h_{t-1}.W_hh^T ; i,f,o = sigmoid, g = tanh ; c_t = f c_{t-1} + i g ; h_t = o tanh(c_t)
 //   backward:  gate gradients from (dh_t, dc_t), dh_{t-1} = dG_t.W_hh, dc_{t-1} = dc_t f_t
-// One 256-thread workgroup owns 64 batch rows of one direction for the whole sequence (h, c, dh, dc never
+// One 256-thread workgroup owns 32*DIC_LSTM_NB batch rows of one direction for the whole sequence (h, c, dh, dc never
 // leave the chip).  The MFMA is issued TRANSPOSED -- D[gate col][batch] = W_hh[gate col][k] . h^T[k][batch]
 // (v_mfma_f32_32x32x16_bf16) -- so that wave w's A operand is the slice of W_hh for hidden units
 // [32w,32w+32): 32 fragments = 128 VGPRs loaded ONCE and kept for all R steps (weights never re-read), the
@@ -22,8 +22,11 @@
 namespace dic {
 
 constexpr int LH = 128;            // hidden size (compiled in)
-constexpr int LBM = 64;            // batch rows per workgroup
-constexpr int LNB = LBM / 32;      // 32-wide batch tiles per workgroup
+#ifndef DIC_LSTM_NB
+#define DIC_LSTM_NB 2              // 32-wide batch tiles per workgroup (1 -> 2 workgroups/CU measured slower: 0.77/1.33 ms vs
+#endif                             // 0.74/1.06 ms fwd/bwd at B=16384)
+constexpr int LNB = DIC_LSTM_NB;
+constexpr int LBM = 32 * LNB;      // batch rows per workgroup
 constexpr int HSTR = LH + 8;       // bf16 elements per LDS row of the h tile (272 B)
 constexpr int GSTR = 4 * LH + 8;   // bf16 elements per LDS row of the dG tile (1040 B)
 
@@ -35,21 +38,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp2(-kLog2e * x)); }
 __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp2(2.0f * kLog2e * x)); }
 
+// "Lane-native" layout of the tensors only these two kernels exchange (saved gates, cell states): element
+// (t, batch b, dir, gate g, unit u) lives at
+//     ((((((t*NBT + b/32)*2 + dir)*4 + u/32)*G + g)*4 + (u%32)/8)*2 + (u%8)/4)*32 + b%32)*4 + u%4
+// so the 8-byte (bf16x4) / 16-byte (f32x4) access of every lane of a wave instruction is contiguous with its
+// neighbours': one 512-B / 1-KiB transaction instead of 32 scattered 16-B pieces (the MFMA accumulator
+// layout puts batch rows on lanes, hidden units on registers).  B is padded to a multiple of 32.
+__device__ __forceinline__ size_t native_off(int t, int nbt, int bt, int dir, int w, int G, int g, int q, int hh, int r) {
+    size_t o = (size_t)t * nbt + bt;
+    o = (o * 2 + dir) * 4 + w;
+    o = (o * G + g) * 4 + q;
+    o = (o * 2 + hh) * 32 + r;
+    return o * 4;
+}
+
 struct LstmFwdArgs {
     const __bf16* gx;      // (R,B,2,4,H) input projection + both biases
     const __bf16* whh;     // (2,4H,H)
     const float* h0; const float* c0;     // (2,B,H) or NULL (zeros)
     __bf16* out;           // (R,B,2H): forward direction in [:H], reverse in [H:]
     float* hn; float* cn;  // (2,B,H)
-    __bf16* gates;         // (R,B,2,4,H) post-activation i,f,g,o, or NULL (inference)
-    float* cs;             // (R,B,2,H) cell states, or NULL
+    __bf16* gates;         // lane-native (R,Bpad,2,4,H) post-activation i,f,g,o, or NULL (inference)
+    float* cs;             // lane-native (R,Bpad,2,H) cell states, or NULL
     int R, B;
 };
 
-__global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(LstmFwdArgs a) {
-    __shared__ __align__(16) __bf16 hbuf[2][LBM * HSTR];
+__global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwdArgs a) {
+    extern __shared__ __align__(16) __bf16 fsm[];
+    __bf16 (*hbuf)[LBM * HSTR] = reinterpret_cast<__bf16 (*)[LBM * HSTR]>(fsm);      // [2][LBM*HSTR]
+    __bf16* gst = fsm + 2 * LBM * HSTR;                    // [LBM][GSTR] staged gx tile of the current step
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
+    const int nbt = gridDim.x * LNB;                       // 32-row batch tiles in the padded batch
 
     // A operand: this wave's W_hh rows (4 gates x 32 hidden units) for all 8 k-steps, resident in VGPRs
     bf16x8 wf[4][8];
@@ -83,12 +103,21 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(LstmFwdArgs a) {
     for (int step = 0; step < R; ++step) {
         const int t = dir ? R - 1 - step : step;
         const int cur = step & 1;
+        // stage this step's gx tile: every wave instruction loads one whole 1-KiB row (row-major, as the GEMM
+        // wrote it); the accumulator layout (batch rows on lanes) is then read back from LDS
+#pragma unroll
+        for (int k = 0; k < LBM / 4; ++k) {
+            const int rowl = k * 4 + w;
+            const int b = min(b0 + rowl, B - 1);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.gx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8);
+            *reinterpret_cast<bf16x8*>(gst + rowl * GSTR + lane * 8) = v;
+        }
+        __syncthreads();
         // accumulators start from the input projection of this step
         f32x16 acc[4][LNB];
 #pragma unroll
         for (int nb = 0; nb < LNB; ++nb) {
-            const int b = b0 + nb * 32 + r;
-            const __bf16* gp = a.gx + (((size_t)t * B + min(b, B - 1)) * 2 + dir) * 4 * LH + 32 * w + 4 * hh;
+            const __bf16* gp = gst + (nb * 32 + r) * GSTR + 32 * w + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -132,17 +161,17 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(LstmFwdArgs a) {
                     hb[j] = (__bf16)hn; ib[j] = (__bf16)ig; fb[j] = (__bf16)fg; gb[j] = (__bf16)gg; ob[j] = (__bf16)og;
                 }
                 *reinterpret_cast<bf16x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + u]) = hb;
+                if (a.gates) {
+                    const int bt = blockIdx.x * LNB + nb;
+                    *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, hh, r)) = ib;
+                    *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r)) = fb;
+                    *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r)) = gb;
+                    *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r)) = ob;
+                    *reinterpret_cast<f32x4*>(a.cs + native_off(t, nbt, bt, dir, w, 1, 0, q, hh, r)) = cv;
+                }
                 if (ok) {
                     const size_t row = (size_t)t * B + b;
                     *reinterpret_cast<bf16x4*>(a.out + row * 2 * LH + dir * LH + u) = hb;
-                    if (a.gates) {
-                        __bf16* gp = a.gates + (row * 2 + dir) * 4 * LH + u;
-                        *reinterpret_cast<bf16x4*>(gp) = ib;
-                        *reinterpret_cast<bf16x4*>(gp + LH) = fb;
-                        *reinterpret_cast<bf16x4*>(gp + 2 * LH) = gb;
-                        *reinterpret_cast<bf16x4*>(gp + 3 * LH) = ob;
-                    }
-                    if (a.cs) *reinterpret_cast<f32x4*>(a.cs + (row * 2 + dir) * LH + u) = cv;
                     if (last) {
                         *reinterpret_cast<f32x4*>(a.hn + ((size_t)dir * B + b) * LH + u) = hv;
                         *reinterpret_cast<f32x4*>(a.cn + ((size_t)dir * B + b) * LH + u) = cv;
@@ -156,8 +185,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(LstmFwdArgs a) {
 
 struct LstmBwdArgs {
     const __bf16* whh_t;   // (2,H,4H): whh_t[d][u][n] = whh[d][n][u]
-    const __bf16* gates;   // (R,B,2,4,H)
-    const float* cs;       // (R,B,2,H)
+    const __bf16* gates;   // lane-native, as written by lstm_fwd_kernel
+    const float* cs;       // lane-native
     const float* c0;       // (2,B,H) or NULL
     const __bf16* dout;    // (R,B,2H) or NULL
     const float* dhn; const float* dcn;   // (2,B,H) or NULL
@@ -166,10 +195,11 @@ struct LstmBwdArgs {
     int R, B;
 };
 
-__global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(LstmBwdArgs a) {
+__global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwdArgs a) {
     extern __shared__ __align__(16) __bf16 dgt[];      // [LBM][GSTR]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
+    const int nbt = gridDim.x * LNB;
 
     // A operand: W_hh^T rows for this wave's 32 hidden units, all 32 k-steps over the 4H gate columns
     bf16x8 wt[32];
@@ -207,14 +237,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(LstmBwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int u = 32 * w + 8 * q + 4 * hh;
-                const __bf16* gp = a.gates + (row * 2 + dir) * 4 * LH + u;
-                const bf16x4 ib = *reinterpret_cast<const bf16x4*>(gp);
-                const bf16x4 fb = *reinterpret_cast<const bf16x4*>(gp + LH);
-                const bf16x4 gb = *reinterpret_cast<const bf16x4*>(gp + 2 * LH);
-                const bf16x4 ob = *reinterpret_cast<const bf16x4*>(gp + 3 * LH);
-                const f32x4 ct = *reinterpret_cast<const f32x4*>(a.cs + (row * 2 + dir) * LH + u);
+                const int bt = blockIdx.x * LNB + nb;
+                const bf16x4 ib = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
+                const bf16x4 fb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
+                const bf16x4 gb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
+                const bf16x4 ob = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
+                const f32x4 ct = *reinterpret_cast<const f32x4*>(a.cs + native_off(t, nbt, bt, dir, w, 1, 0, q, hh, r));
                 f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-                if (!first_fwd) cp = *reinterpret_cast<const f32x4*>(a.cs + ((((size_t)tp * B + min(b, B - 1)) * 2 + dir)) * LH + u);
+                if (!first_fwd) cp = *reinterpret_cast<const f32x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
                 else if (a.c0) cp = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + min(b, B - 1)) * LH + u);
                 bf16x4 go = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
                 if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + row * 2 * LH + dir * LH + u);
@@ -237,16 +267,21 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(LstmBwdArgs a) {
                 *reinterpret_cast<bf16x4*>(lp + LH) = df;
                 *reinterpret_cast<bf16x4*>(lp + 2 * LH) = dg;
                 *reinterpret_cast<bf16x4*>(lp + 3 * LH) = dO;
-                if (ok) {
-                    __bf16* op = a.dgx + (row * 2 + dir) * 4 * LH + u;
-                    *reinterpret_cast<bf16x4*>(op) = di;
-                    *reinterpret_cast<bf16x4*>(op + LH) = df;
-                    *reinterpret_cast<bf16x4*>(op + 2 * LH) = dg;
-                    *reinterpret_cast<bf16x4*>(op + 3 * LH) = dO;
-                }
+                (void)ok;
             }
         }
         __syncthreads();
+        // dG_t -> global, row-major for the weight-gradient GEMMs: re-read the LDS tile so that every wave
+        // instruction stores one whole 1-KiB row (the accumulator layout would scatter 32 x 16-B pieces)
+#pragma unroll
+        for (int k = 0; k < LBM / 4; ++k) {
+            const int rowl = k * 4 + w;
+            const int b = b0 + rowl;
+            if (b < B) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dgt + rowl * GSTR + lane * 8);
+                *reinterpret_cast<bf16x8*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8) = v;
+            }
+        }
         // dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n]
 #pragma unroll
         for (int nb = 0; nb < LNB; ++nb)
@@ -290,7 +325,14 @@ int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* 
     DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd: gates and cs go together");
     LstmFwdArgs a{(const __bf16*)gx, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, cs, R, B};
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + LBM - 1) / LBM, 2), dim3(256), 0, (hipStream_t)stream, a);
+    static const size_t lds = (size_t)(2 * LBM * HSTR + LBM * GSTR) * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + LBM - 1) / LBM, 2), dim3(256), lds, (hipStream_t)stream, a);
     return check_launch("lstm_fwd");
 }
 

@@ -47,8 +47,9 @@ class _BiLstm(torch.autograd.Function):
         out = torch.empty((R, B, 2 * H), device=dev, dtype=bf)
         hn = torch.empty((2, B, H), device=dev, dtype=torch.float32)
         cn = torch.empty_like(hn)
-        gates = torch.empty((R, B, 2, 4, H), device=dev, dtype=bf) if need else None
-        cs = torch.empty((R, B, 2, H), device=dev, dtype=torch.float32) if need else None
+        Bp = (B + 63) // 64 * 64                                   # kernel-native saved state is tiled by 64 rows
+        gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=bf) if need else None
+        cs = torch.empty((R, Bp, 2, H), device=dev, dtype=torch.float32) if need else None
         h0c = None if h0 is None else h0.float().contiguous()
         c0c = None if c0 is None else c0.float().contiguous()
         N.check(N.lib().dic_lstm_fwd(N.ptr(gx), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
@@ -78,8 +79,11 @@ class _BiLstm(torch.autograd.Function):
         dx = dw_ih = dw_hh = dbias = None
         if ctx.needs_input_grad[0]:
             dx = (dg2 @ wihb)[:, :I].reshape(R, B, I).to(ctx.x_dtype)
+        dg3 = dgx.view(R, B, 8 * H).transpose(1, 2)               # (R, 8H, B): one K-slice per time step
         if ctx.needs_input_grad[1]:
-            dw_ih = (dg2.t() @ xb.view(R * B, Ip))[:, :I].float().reshape(2, 4 * H, I)
+            # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split K by time step so the
+            # GEMM fills the chip (R x 16+ output tiles), then add the R partial products in f32
+            dw_ih = torch.bmm(dg3, xb).float().sum(0)[:, :I].reshape(2, 4 * H, I)
         if ctx.needs_input_grad[2]:
             # H_prev: the hidden state each step consumed (forward: h_{t-1}; reverse: h_{t+1}; h_0 at the ends)
             hprev = torch.empty((R, B, 2, H), device=dev, dtype=bf)
@@ -92,8 +96,8 @@ class _BiLstm(torch.autograd.Function):
             else:
                 hprev[0, :, 0] = h0c[0].to(bf)
                 hprev[R - 1, :, 1] = h0c[1].to(bf)
-            full = dg2.t() @ hprev.view(R * B, 2 * H)             # (8H, 2H): the two diagonal blocks are wanted
-            dw_hh = torch.stack([full[:4 * H, :H], full[4 * H:, H:]]).float()
+            full = torch.bmm(dg3, hprev.view(R, B, 2 * H)).float().sum(0)     # (8H, 2H): the diagonal blocks are wanted
+            dw_hh = torch.stack([full[:4 * H, :H], full[4 * H:, H:]])
         if ctx.needs_input_grad[3]:
             dbias = torch.sum(dg2, dim=0, dtype=torch.float32).reshape(2, 4 * H)
         return dx, dw_ih, dw_hh, dbias, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None)

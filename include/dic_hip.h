@@ -189,8 +189,8 @@ int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, 
  *   gx    (R,B,2,4,H) bf16  X.W_ih^T + b_ih + b_hh per direction (0 = forward, 1 = reverse)
  *   whh   (2,4H,H)    bf16  recurrent weights;   whh_t (2,H,4H) bf16 their per-direction transposes
  *   h0,c0 (2,B,H) f32 or NULL;   out (R,B,2H) bf16;   hn,cn (2,B,H) f32
- *   gates (R,B,2,4,H) bf16 post-activation gates and cs (R,B,2,H) f32 cell states: saved for the
- *   backward (both NULL for inference).
+ *   gates (R,Bp,2,4,H) bf16 post-activation gates and cs (R,Bp,2,H) f32 cell states, Bp = B rounded up to
+ *   64: opaque, lane-native layout exchanged only between these two calls (both NULL for inference).
  * Backward: dout (R,B,2H) bf16 / dhn, dcn (2,B,H) f32 (each may be NULL) -> dgx (R,B,2,4,H) bf16
  * pre-activation gate gradients (the caller turns them into dX, dW_ih, dW_hh, db by GEMMs), dh0, dc0. */
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
