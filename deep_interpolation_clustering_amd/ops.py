@@ -289,3 +289,41 @@ class _KlBatchMean(torch.autograd.Function):
 def kl_batchmean(p, q):
     """F.kl_div(q.log(), p, reduction='batchmean') with the closed-form d/dq fused into the forward."""
     return _KlBatchMean.apply(p, q.float())
+
+
+# ----------------------------------------------------------------------------------------- a4 tail
+class _HeadLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, weight, bias):
+        N.require_gpu(h, weight, bias)
+        hb = h.to(torch.bfloat16).contiguous()
+        n, k = hb.shape
+        c = weight.shape[0]
+        w, b = N.f32c(weight.detach()), N.f32c(bias.detach())
+        v = torch.empty((n, c), device=hb.device, dtype=torch.float32)
+        N.check(N.lib().dic_head_fwd(N.ptr(hb), N.ptr(w), N.ptr(b), n, k, c, N.ptr(v), N.stream_of(hb)), 'dic_head_fwd')
+        ctx.save_for_backward(hb, w)
+        ctx.h_dtype = h.dtype
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        hb, w = ctx.saved_tensors
+        n, k = hb.shape
+        c = w.shape[0]
+        g = N.f32c(dv)
+        dh = torch.empty_like(hb)
+        dw, db = torch.empty_like(w), torch.empty(c, device=hb.device, dtype=torch.float32)
+        L = N.lib()
+        ws = _ws(L.dic_head_bwd_workspace(n, k, c), hb.device)
+        N.check(L.dic_head_bwd(N.ptr(hb), N.ptr(w), N.ptr(g), n, k, c, N.ptr(dh), N.ptr(dw), N.ptr(db), N.ptr(ws), ws.numel(),
+                               N.stream_of(hb)), 'dic_head_bwd')
+        return dh.to(ctx.h_dtype), dw, db
+
+
+HEAD_IN, HEAD_OUT = 128, (1, 2, 3, 4, 5, 6, 7, 8, 12, 16)
+
+
+def head_linear(h, weight, bias):
+    """Linear(128, C) for small C on (N,128) bf16 activations -> (N,C) f32 (CompressFC's output layer)."""
+    return _HeadLinear.apply(h, weight, bias)

@@ -199,6 +199,15 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const float* cs, const fl
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
                  dic_stream_t stream);
 
+/* ------------------------------------------------------------------ CompressFC output layer ---
+ * Linear(128, C) over all N = B*R decoder rows (rbf.py:111-125, last layer; TimeDistributed utils.py:202-224)
+ * for small C (1..8, 12, 16): h (N,128) bf16, W (C,128) f32, b (C) f32 -> v (N,C) f32; backward:
+ * dv (N,C) f32 -> dh (N,128) bf16, dW (C,128), db (C). */
+int dic_head_fwd(const void* h, const float* W, const float* b, int64_t N, int K, int C, float* v, dic_stream_t stream);
+size_t dic_head_bwd_workspace(int64_t N, int K, int C);
+int dic_head_bwd(const void* h, const float* W, const float* dv, int64_t N, int K, int C, void* dh, float* dW, float* db,
+                 void* workspace, size_t workspace_bytes, dic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,3 +123,26 @@ def test_joint_step_bf16_fused_tracks_f32():
     assert np.isfinite(res['bf16']).all()
     np.testing.assert_allclose(res['bf16'][:, 0], res['f32'][:, 0], rtol=3e-2)
     assert res['bf16'][-1, 0] < res['bf16'][0, 0]           # it trains
+
+
+@pytest.mark.parametrize('N,C', [(5000, 6), (257, 12), (3, 1), (70000, 16)])
+def test_head_linear_matches_torch(N, C):
+    """CompressFC's small-output Linear as a streaming kernel (csrc/dic_head.hip) vs torch on the same bf16 input."""
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(N)
+    dev = torch.device('cuda')
+    lin = torch.nn.Linear(128, C).to(dev)
+    h = (torch.randn(N, 128, device=dev)).to(torch.bfloat16)
+    h1 = h.clone().requires_grad_()
+    v = ops.head_linear(h1, lin.weight, lin.bias)
+    cot = torch.randn(N, C, device=dev)
+    (v * cot).sum().backward()
+    got = (h1.grad.float().clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    lin.zero_grad()
+    h2 = h.float().clone().requires_grad_()
+    ref = torch.nn.functional.linear(h2, lin.weight, lin.bias)
+    (ref * cot).sum().backward()
+    np.testing.assert_allclose(v.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got[0].cpu().numpy(), h2.grad.cpu().numpy(), rtol=1e-2, atol=1e-2 * float(h2.grad.abs().max()))   # dh is bf16
+    np.testing.assert_allclose(got[1].cpu().numpy(), lin.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(lin.weight.grad.abs().max()))
+    np.testing.assert_allclose(got[2].cpu().numpy(), lin.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(lin.bias.grad.abs().max()))
