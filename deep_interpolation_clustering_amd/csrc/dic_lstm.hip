@@ -192,6 +192,7 @@ struct LstmBwdArgs {
     const float* dhn; const float* dcn;   // (2,B,H) or NULL
     __bf16* dgx;           // (R,B,2,4,H) pre-activation gate gradients
     float* dh0; float* dc0;               // (2,B,H)
+    float* dbias_part;     // (gridDim.x, 2, 4H) per-workgroup sums of dG over its rows and all steps, or NULL
     int R, B;
 };
 
@@ -209,6 +210,11 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 
     f32x16 dh[LNB];        // recurrent dL/dh arriving at the current step
     float dc[LNB][16];
+    float bsum[4][16];     // running sum of dG over this lane's batch rows and steps (bias gradient)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bsum[g][k] = 0.f;
 #pragma unroll
     for (int nb = 0; nb < LNB; ++nb) {
         const int b = b0 + nb * 32 + r;
@@ -256,10 +262,10 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                     const float dht = dh[nb][k] + (float)go[j];
                     const float tc = tanh_fast(ct[j]);
                     const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
-                    di[j] = (__bf16)(dct * gg * ig * (1.0f - ig));
-                    df[j] = (__bf16)(dct * cp[j] * fg * (1.0f - fg));
-                    dg[j] = (__bf16)(dct * ig * (1.0f - gg * gg));
-                    dO[j] = (__bf16)(dht * tc * og * (1.0f - og));
+                    const float vi = dct * gg * ig * (1.0f - ig), vf = dct * cp[j] * fg * (1.0f - fg);
+                    const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
+                    di[j] = (__bf16)vi; df[j] = (__bf16)vf; dg[j] = (__bf16)vg; dO[j] = (__bf16)vo;
+                    if (ok) { bsum[0][k] += vi; bsum[1][k] += vf; bsum[2][k] += vg; bsum[3][k] += vo; }
                     dc[nb][k] = dct * fg;
                 }
                 __bf16* lp = dgt + (nb * 32 + r) * GSTR + u;
@@ -267,7 +273,6 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                 *reinterpret_cast<bf16x4*>(lp + LH) = df;
                 *reinterpret_cast<bf16x4*>(lp + 2 * LH) = dg;
                 *reinterpret_cast<bf16x4*>(lp + 3 * LH) = dO;
-                (void)ok;
             }
         }
         __syncthreads();
@@ -296,6 +301,17 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             }
         __syncthreads();
     }
+    if (a.dbias_part) {     // fold the 32 batch-row lanes of each half-wave, one partial per workgroup
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float v = bsum[g][k];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+                if (r == 0) a.dbias_part[((size_t)blockIdx.x * 2 + dir) * 4 * LH + g * LH + 32 * w + 8 * (k >> 2) + 4 * hh + (k & 3)] = v;
+            }
+    }
 #pragma unroll
     for (int nb = 0; nb < LNB; ++nb) {
         const int b = b0 + nb * 32 + r;
@@ -310,6 +326,14 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             *reinterpret_cast<f32x4*>(a.dc0 + ((size_t)dir * B + b) * LH + u) = cv;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void lstm_dbias_finalize(const float* partials, int nblk, float* dbias) {
+    __shared__ double red[256];
+    const int n = 2 * 4 * LH;
+    const double s = reduce_partials_32x8(partials, nblk, n, blockIdx.x * 32, red);
+    const int i = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x < 32 && i < n) dbias[i] = (float)s;
 }
 
 }  // namespace dic
@@ -336,9 +360,11 @@ int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* 
     return check_launch("lstm_fwd");
 }
 
+size_t dic_lstm_bwd_workspace(int B) { return B > 0 ? (size_t)((B + LBM - 1) / LBM) * 2 * 4 * LH * sizeof(float) : 0; }
+
 int dic_lstm_bwd(const void* whh_t, const void* gates, const float* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
-                 dic_stream_t stream) {
+                 float* dbias, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_bwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_bwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(whh_t && gates && cs && dgx && dh0 && dc0, DIC_ERR_INVALID_ARG, "lstm_bwd: NULL pointer");
@@ -349,8 +375,15 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const float* cs, const fl
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
-    LstmBwdArgs a{(const __bf16*)whh_t, (const __bf16*)gates, cs, c0, (const __bf16*)dout, dhn, dcn, (__bf16*)dgx, dh0, dc0, R, B};
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((B + LBM - 1) / LBM, 2), dim3(256), lds, (hipStream_t)stream, a);
+    const int nwg = (B + LBM - 1) / LBM;
+    DIC_REQUIRE(!dbias || (workspace && workspace_bytes >= dic_lstm_bwd_workspace(B)), DIC_ERR_WORKSPACE,
+                "lstm_bwd: dbias needs %zu B of workspace", dic_lstm_bwd_workspace(B));
+    LstmBwdArgs a{(const __bf16*)whh_t, (const __bf16*)gates, cs, c0, (const __bf16*)dout, dhn, dcn, (__bf16*)dgx, dh0, dc0,
+                  dbias ? (float*)workspace : nullptr, R, B};
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nwg, 2), dim3(256), lds, (hipStream_t)stream, a);
+    if (dbias)
+        hipLaunchKernelGGL(lstm_dbias_finalize, dim3(2 * 4 * LH / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nwg,
+                           dbias);
     return check_launch("lstm_bwd");
 }
 

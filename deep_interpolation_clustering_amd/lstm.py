@@ -73,10 +73,14 @@ class _BiLstm(torch.autograd.Function):
         doutb = None if dout is None else dout.to(bf).contiguous()
         dhnc = None if dhn is None else dhn.float().contiguous()
         dcnc = None if dcn is None else dcn.float().contiguous()
-        N.check(N.lib().dic_lstm_bwd(N.ptr(whh_t), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
-                                     R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.stream_of(out)), 'dic_lstm_bwd')
+        Lb = N.lib()
+        dbias = torch.empty((2, 4 * H), device=dev, dtype=torch.float32)         # summed inside the kernel, f32
+        ws = torch.empty(max(16, Lb.dic_lstm_bwd_workspace(B)), device=dev, dtype=torch.uint8)
+        N.check(Lb.dic_lstm_bwd(N.ptr(whh_t), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
+                                R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(),
+                                N.stream_of(out)), 'dic_lstm_bwd')
         dg2 = dgx.view(R * B, 8 * H)
-        dx = dw_ih = dw_hh = dbias = None
+        dx = dw_ih = dw_hh = None
         if ctx.needs_input_grad[0]:
             dx = (dg2 @ wihb)[:, :I].reshape(R, B, I).to(ctx.x_dtype)
         dg3 = dgx.view(R, B, 8 * H).transpose(1, 2)               # (R, 8H, B): one K-slice per time step
@@ -96,11 +100,9 @@ class _BiLstm(torch.autograd.Function):
             else:
                 hprev[0, :, 0] = h0c[0].to(bf)
                 hprev[R - 1, :, 1] = h0c[1].to(bf)
-            full = torch.bmm(dg3, hprev.view(R, B, 2 * H)).float().sum(0)     # (8H, 2H): the diagonal blocks are wanted
-            dw_hh = torch.stack([full[:4 * H, :H], full[4 * H:, H:]])
-        if ctx.needs_input_grad[3]:
-            dbias = torch.sum(dg2, dim=0, dtype=torch.float32).reshape(2, 4 * H)
-        return dx, dw_ih, dw_hh, dbias, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None)
+            dg5 = dgx.view(R, B, 2, 4 * H)
+            dw_hh = torch.stack([torch.bmm(dg5[:, :, d].transpose(1, 2), hprev[:, :, d]).float().sum(0) for d in (0, 1)])
+        return dx, dw_ih, dw_hh, (dbias if ctx.needs_input_grad[3] else None), (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None)
 
 
 def bilstm(x, lstm, h0=None, c0=None):

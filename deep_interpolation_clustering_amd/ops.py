@@ -327,3 +327,35 @@ HEAD_IN, HEAD_OUT = 128, (1, 2, 3, 4, 5, 6, 7, 8, 12, 16)
 def head_linear(h, weight, bias):
     """Linear(128, C) for small C on (N,128) bf16 activations -> (N,C) f32 (CompressFC's output layer)."""
     return _HeadLinear.apply(h, weight, bias)
+
+
+class _RowsLinear(torch.autograd.Function):
+    """y = x W^T + b on (N, I) bf16 rows with N in the hundreds of thousands (library GEMMs).  Only the weight
+    gradient is special: dW = dy^T x has K = N and a tiny output, so it is issued as a bmm over row chunks
+    (fills the chip) and the chunk products are added in f32 -- hipBLASLt otherwise runs it on 4 tiles."""
+
+    CHUNK = 16384
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xb, wb = x.to(torch.bfloat16), weight.to(torch.bfloat16)
+        ctx.save_for_backward(xb, wb)
+        ctx.x_dtype = x.dtype
+        return torch.addmm(bias.to(torch.bfloat16), xb, wb.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        dyb = dy.to(torch.bfloat16).contiguous()
+        n = xb.shape[0]
+        dx = (dyb @ wb).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        c = _RowsLinear.CHUNK
+        if n >= 4 * c and n % c == 0:
+            dw = torch.bmm(dyb.view(n // c, c, -1).transpose(1, 2), xb.view(n // c, c, -1)).float().sum(0)
+        else:
+            dw = (dyb.t() @ xb).float()
+        return dx, dw, torch.sum(dyb, dim=0, dtype=torch.float32)
+
+
+def rows_linear(x, weight, bias):
+    return _RowsLinear.apply(x, weight, bias)

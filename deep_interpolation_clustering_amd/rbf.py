@@ -25,7 +25,10 @@ class CompressFC(nn.Module):
         if not fast:
             return self.model(rec_input)
         # bf16 step: the C-wide output layer over all B*R rows is a 100 MB stream, not a GEMM (csrc/dic_head.hip)
-        hidden = self.model[3](self.model[2](self.model[1](self.model[0](rec_input))))
+        first = self.model[0]
+        with torch.autocast('cuda', enabled=False):
+            z = ops.rows_linear(rec_input, first.weight, first.bias)           # split-K weight gradient
+        hidden = self.model[3](self.model[2](self.model[1](z)))
         with torch.autocast('cuda', enabled=False):
             return ops.head_linear(hidden, last.weight, last.bias)
 

@@ -192,12 +192,14 @@ int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, 
  *   gates (R,Bp,2,4,H) bf16 post-activation gates and cs (R,Bp,2,H) f32 cell states, Bp = B rounded up to
  *   64: opaque, lane-native layout exchanged only between these two calls (both NULL for inference).
  * Backward: dout (R,B,2H) bf16 / dhn, dcn (2,B,H) f32 (each may be NULL) -> dgx (R,B,2,4,H) bf16
- * pre-activation gate gradients (the caller turns them into dX, dW_ih, dW_hh, db by GEMMs), dh0, dc0. */
+ * pre-activation gate gradients (the caller turns them into dX, dW_ih, dW_hh by GEMMs), dh0, dc0, and
+ * dbias (2,4H) f32 or NULL = sum of dG over steps and batch rows (needs dic_lstm_bwd_workspace(B) bytes). */
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
                  void* out, float* hn, float* cn, void* gates, float* cs, dic_stream_t stream);
+size_t dic_lstm_bwd_workspace(int B);
 int dic_lstm_bwd(const void* whh_t, const void* gates, const float* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
-                 dic_stream_t stream);
+                 float* dbias, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
 /* ------------------------------------------------------------------ CompressFC output layer ---
  * Linear(128, C) over all N = B*R decoder rows (rbf.py:111-125, last layer; TimeDistributed utils.py:202-224)
