@@ -210,11 +210,9 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 
     f32x16 dh[LNB];        // recurrent dL/dh arriving at the current step
     float dc[LNB][16];
-    float bsum[4][16];     // running sum of dG over this lane's batch rows and steps (bias gradient)
+    float bsum[8];         // bias gradient: running column sums of dG (columns lane*8 .. +7 of this wave's rows)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) bsum[g][k] = 0.f;
+    for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
 #pragma unroll
     for (int nb = 0; nb < LNB; ++nb) {
         const int b = b0 + nb * 32 + r;
@@ -238,7 +236,6 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 #pragma unroll
         for (int nb = 0; nb < LNB; ++nb) {
             const int b = b0 + nb * 32 + r;
-            const bool ok = b < B;
             const size_t row = (size_t)t * B + min(b, B - 1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -265,7 +262,6 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                     const float vi = dct * gg * ig * (1.0f - ig), vf = dct * cp[j] * fg * (1.0f - fg);
                     const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
                     di[j] = (__bf16)vi; df[j] = (__bf16)vf; dg[j] = (__bf16)vg; dO[j] = (__bf16)vo;
-                    if (ok) { bsum[0][k] += vi; bsum[1][k] += vf; bsum[2][k] += vg; bsum[3][k] += vo; }
                     dc[nb][k] = dct * fg;
                 }
                 __bf16* lp = dgt + (nb * 32 + r) * GSTR + u;
@@ -285,6 +281,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             if (b < B) {
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(dgt + rowl * GSTR + lane * 8);
                 *reinterpret_cast<bf16x8*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8) = v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
             }
         }
         // dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n]
@@ -301,16 +299,13 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             }
         __syncthreads();
     }
-    if (a.dbias_part) {     // fold the 32 batch-row lanes of each half-wave, one partial per workgroup
+    if (a.dbias_part) {     // add the 4 waves' column sums through LDS (the dG tile is free now): one partial per workgroup
+        float* red = reinterpret_cast<float*>(dgt);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                float v = bsum[g][k];
-#pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-                if (r == 0) a.dbias_part[((size_t)blockIdx.x * 2 + dir) * 4 * LH + g * LH + 32 * w + 8 * (k >> 2) + 4 * hh + (k & 3)] = v;
-            }
+        for (int e = 0; e < 8; ++e) red[w * 4 * LH + lane * 8 + e] = bsum[e];
+        __syncthreads();
+        for (int i = tid; i < 4 * LH; i += 256)
+            a.dbias_part[((size_t)blockIdx.x * 2 + dir) * 4 * LH + i] = red[i] + red[4 * LH + i] + red[8 * LH + i] + red[12 * LH + i];
     }
 #pragma unroll
     for (int nb = 0; nb < LNB; ++nb) {
