@@ -133,7 +133,7 @@ def kernel_table(net, x, ob, lengths, K, iters):
     ws6 = torch.empty(max(16, L.dic_lstm_bwd_workspace(B)), dtype=torch.uint8, device=dev)
     calls['lstm_bwd'] = (lambda: L.dic_lstm_bwd(P(whh_t), P(lgates), P(lcs), None, P(ldout), None, None, R, B, Hh, P(ldgx), P(ldh0),
                                                 P(ldc0), P(ldb), P(ws6), ws6.numel(), st),
-                         rows * (4 * Hh * 2 + 2 * Hh * 4 + Hh * 2 + 4 * Hh * 2))  # gates, c_t, c_prev, dout in; dG out
+                         rows * (4 * Hh * 2 + Hh * 4 + Hh * 2 + 4 * Hh * 2))      # gates, c, dout in; dG out
     # run the forwards once so the backward inputs (saved, y, norm, out2, ts, LSTM state) hold real values
     for name in ('sci_cci_fwd', 'rbf_fwd', 'masked_sse_fwd', 'dec_fwd', 'lstm_fwd'):
         assert calls[name][0]() == 0, name

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 
     f32x16 dh[LNB];        // recurrent dL/dh arriving at the current step
     float dc[LNB][16];
+    float ccar[LNB][16];   // c of the step processed next (= this step's c_prev): each cell state is read once
     float bsum[8];         // bias gradient: running column sums of dG (columns lane*8 .. +7 of this wave's rows)
 #pragma unroll
     for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
@@ -245,10 +246,14 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                 const bf16x4 fb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
                 const bf16x4 gb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
                 const bf16x4 ob = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
-                const f32x4 ct = *reinterpret_cast<const f32x4*>(a.cs + native_off(t, nbt, bt, dir, w, 1, 0, q, hh, r));
+                f32x4 ct;
+                if (step == 0) ct = *reinterpret_cast<const f32x4*>(a.cs + native_off(t, nbt, bt, dir, w, 1, 0, q, hh, r));
+                else { ct[0] = ccar[nb][4 * q]; ct[1] = ccar[nb][4 * q + 1]; ct[2] = ccar[nb][4 * q + 2]; ct[3] = ccar[nb][4 * q + 3]; }
                 f32x4 cp = {0.f, 0.f, 0.f, 0.f};
                 if (!first_fwd) cp = *reinterpret_cast<const f32x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
                 else if (a.c0) cp = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + min(b, B - 1)) * LH + u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ccar[nb][4 * q + j] = cp[j];
                 bf16x4 go = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
                 if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + row * 2 * LH + dir * LH + u);
                 bf16x4 di, df, dg, dO;

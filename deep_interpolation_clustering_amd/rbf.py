@@ -59,7 +59,13 @@ class RBF(nn.Module):
 
     def forward(self, interp_data, raw_input, lengths=None):
         """interp_data (B,256,R), raw_input (B,4C,T) -> (B,C,T) (rbf.py:57-108)."""
-        v = self.compress_fc(interp_data.permute(0, 2, 1)).permute(0, 2, 1)       # (B,C,R)
+        native = interp_data.permute(2, 0, 1)                                     # (R,B,256)
+        if native.is_contiguous():
+            # the decoder emits (R,B,256); CompressFC is row-wise and its BatchNorm moments are order-invariant, so run
+            # it on the rows as they lie in memory and permute the small (R,B,C) result instead of copying 256-wide rows
+            v = self.compress_fc(native).permute(1, 2, 0)                         # (B,C,R)
+        else:
+            v = self.compress_fc(interp_data.permute(0, 2, 1)).permute(0, 2, 1)   # (B,C,R)
         if self.interp_t.device != v.device:
             self.interp_t = self.interp_t.to(v.device)
         return ops.rbf_deinterp(v, raw_input, self.kernel, self.interp_t, lengths)
