@@ -195,7 +195,7 @@ def main():
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU implementation')
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local % torch.cuda.device_count())       # (ranks may share a GPU under DIC_DIST_BACKEND=gloo)
     torch.cuda.set_device(dev)
     K = a.clusters or (8 if world == 8 else 4)
     args = make_args(K)

@@ -42,8 +42,8 @@ def init_from_env(backend=None):
     if ws > 1 and not td.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:     # DIC_DIST_BACKEND=gloo lets several ranks share ONE GPU (rehearsal of the N>1 path on a 1-GPU box)
+            backend = os.environ.get('DIC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(lr)
             td.init_process_group(backend, rank=rk, world_size=ws, device_id=torch.device('cuda', lr))
