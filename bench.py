@@ -37,7 +37,7 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=30)
     p.add_argument('--warmup', type=int, default=10)
-    p.add_argument('--batch', type=int, default=int(os.environ.get('DIC_BENCH_BATCH', 16384)), help='encounters per GPU per step')
+    p.add_argument('--batch', type=int, default=int(os.environ.get('DIC_BENCH_BATCH', 32768)), help='encounters per GPU per step')
     p.add_argument('--encounters', type=int, default=75000, help='cohort size resident per GPU')
     p.add_argument('--clusters', type=int, default=None, help='K (default 4; 8 for the 8-GPU config)')
     p.add_argument('--dtype', choices=['bf16', 'f32'], default=os.environ.get('DIC_BENCH_DTYPE', 'bf16'),

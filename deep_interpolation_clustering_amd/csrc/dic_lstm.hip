@@ -230,44 +230,70 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         }
     }
 
-    for (int step = 0; step < R; ++step) {
+    // Software pipeline: the saved gates / c_prev / dout of step s+1 are requested while step s runs its LDS,
+    // store and MFMA phases (one workgroup per CU: nothing else would hide the HBM latency).
+    struct StepIn { bf16x4 ib, fb, gb, ob, go; f32x4 cp; };
+    StepIn cur[LNB][4], nxt[LNB][4];
+    auto load_step = [&](int step, StepIn (&dst)[LNB][4]) {
         const int t = dir ? step : R - 1 - step;           // reverse of the forward visiting order
         const bool first_fwd = step == R - 1;               // this t was the forward pass' first step
         const int tp = dir ? t + 1 : t - 1;                 // forward predecessor
 #pragma unroll
         for (int nb = 0; nb < LNB; ++nb) {
-            const int b = b0 + nb * 32 + r;
-            const size_t row = (size_t)t * B + min(b, B - 1);
+            const int b = min(b0 + nb * 32 + r, B - 1);
+            const int bt = blockIdx.x * LNB + nb;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int u = 32 * w + 8 * q + 4 * hh;
-                const int bt = blockIdx.x * LNB + nb;
-                const bf16x4 ib = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
-                const bf16x4 fb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
-                const bf16x4 gb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
-                const bf16x4 ob = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
-                f32x4 ct;
-                if (step == 0) ct = *reinterpret_cast<const f32x4*>(a.cs + native_off(t, nbt, bt, dir, w, 1, 0, q, hh, r));
-                else { ct[0] = ccar[nb][4 * q]; ct[1] = ccar[nb][4 * q + 1]; ct[2] = ccar[nb][4 * q + 2]; ct[3] = ccar[nb][4 * q + 3]; }
+                StepIn& d = dst[nb][q];
+                d.ib = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
+                d.fb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
+                d.gb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
+                d.ob = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
                 f32x4 cp = {0.f, 0.f, 0.f, 0.f};
                 if (!first_fwd) cp = *reinterpret_cast<const f32x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
-                else if (a.c0) cp = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + min(b, B - 1)) * LH + u);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ccar[nb][4 * q + j] = cp[j];
+                else if (a.c0) cp = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + b) * LH + u);
+                d.cp = cp;
                 bf16x4 go = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + row * 2 * LH + dir * LH + u);
+                if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + u);
+                d.go = go;
+            }
+        }
+    };
+    {   // prologue: c of the first visited step, then its inputs
+        const int t0 = dir ? 0 : R - 1;
+#pragma unroll
+        for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 ct = *reinterpret_cast<const f32x4*>(a.cs + native_off(t0, nbt, blockIdx.x * LNB + nb, dir, w, 1, 0, q, hh, r));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ccar[nb][4 * q + j] = ct[j];
+            }
+        load_step(0, cur);
+    }
+
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? step : R - 1 - step;
+#pragma unroll
+        for (int nb = 0; nb < LNB; ++nb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u = 32 * w + 8 * q + 4 * hh;
+                const StepIn& in = cur[nb][q];
                 bf16x4 di, df, dg, dO;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * q + j;
-                    const float ig = (float)ib[j], fg = (float)fb[j], gg = (float)gb[j], og = (float)ob[j];
-                    const float dht = dh[nb][k] + (float)go[j];
-                    const float tc = tanh_fast(ct[j]);
+                    const float ig = (float)in.ib[j], fg = (float)in.fb[j], gg = (float)in.gb[j], og = (float)in.ob[j];
+                    const float dht = dh[nb][k] + (float)in.go[j];
+                    const float tc = tanh_fast(ccar[nb][k]);
                     const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
-                    const float vi = dct * gg * ig * (1.0f - ig), vf = dct * cp[j] * fg * (1.0f - fg);
+                    const float vi = dct * gg * ig * (1.0f - ig), vf = dct * in.cp[j] * fg * (1.0f - fg);
                     const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
                     di[j] = (__bf16)vi; df[j] = (__bf16)vf; dg[j] = (__bf16)vg; dO[j] = (__bf16)vo;
                     dc[nb][k] = dct * fg;
+                    ccar[nb][k] = in.cp[j];                 // this step's c_prev is the next visited step's c
                 }
                 __bf16* lp = dgt + (nb * 32 + r) * GSTR + u;
                 *reinterpret_cast<bf16x4*>(lp) = di;
@@ -276,6 +302,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                 *reinterpret_cast<bf16x4*>(lp + 3 * LH) = dO;
             }
         }
+        if (step + 1 < R) load_step(step + 1, nxt);        // in flight across the store / MFMA phases below
         __syncthreads();
         // dG_t -> global, row-major for the weight-gradient GEMMs: re-read the LDS tile so that every wave
         // instruction stores one whole 1-KiB row (the accumulator layout would scatter 32 x 16-B pieces)
@@ -303,6 +330,10 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                 dh[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, dh[nb], 0, 0, 0);
             }
         __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[nb][q] = nxt[nb][q];
     }
     if (a.dbias_part) {     // add the 4 waves' column sums through LDS (the dG tile is free now): one partial per workgroup
         float* red = reinterpret_cast<float*>(dgt);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Launch each hand-written kernel a few times at the bench shape (no LSTM): the target of
-`rocprofv3 --kernel-trace --stats` / `--pmc` runs.  Usage: python3 scripts/kbench.py [batch] [iters] [K]"""
+"""Launch each hand-written kernel a few times at the bench shape: the target of
+`rocprofv3 --kernel-trace --stats` / `--pmc` runs.
+Usage: python3 scripts/kbench.py [batch] [iters] [K] [C T lam]     (cfg4 stress: 8192 10 16 12 288 200)"""
 import os
 import sys
 
@@ -14,6 +15,8 @@ from deep_interpolation_clustering_amd.clustering_interp import Net  # noqa: E40
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+if len(sys.argv) > 6:
+    bench.C, bench.T, bench.LAM = int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
 dev = torch.device('cuda', 0)
 coh = synthetic.make_cohort(B, C=bench.C, T=bench.T, H=bench.H, lam=bench.LAM, G=K, seed=7)
 x_np, ob_np, n = synthetic.stacked_batch(coh)
