@@ -98,21 +98,27 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
             *reinterpret_cast<bf16x4*>(&hbuf[0][(nb * 32 + r) * HSTR + u]) = hb;
         }
     }
+    // gx tile of a step -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous): one instruction moves
+    // one whole 1-KiB row (row-major, as the GEMM wrote it) to a padded LDS row; the accumulator layout (batch
+    // rows on lanes) is read back from LDS.  The tile of step s+1 is requested right after step s has consumed
+    // its own, so it lands during the MFMA / gate-math / store phases (__syncthreads waits for it).
+    auto request_gx = [&](int step) {
+        const int t = dir ? R - 1 - step : step;
+#pragma unroll
+        for (int k = 0; k < LBM / 4; ++k) {
+            const int rowl = k * 4 + w;
+            const int b = min(b0 + rowl, B - 1);
+            const __bf16* src = a.gx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(gst + rowl * GSTR), 16, 0, 0);
+        }
+    };
+    request_gx(0);
     __syncthreads();
 
     for (int step = 0; step < R; ++step) {
         const int t = dir ? R - 1 - step : step;
         const int cur = step & 1;
-        // stage this step's gx tile: every wave instruction loads one whole 1-KiB row (row-major, as the GEMM
-        // wrote it); the accumulator layout (batch rows on lanes) is then read back from LDS
-#pragma unroll
-        for (int k = 0; k < LBM / 4; ++k) {
-            const int rowl = k * 4 + w;
-            const int b = min(b0 + rowl, B - 1);
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.gx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8);
-            *reinterpret_cast<bf16x8*>(gst + rowl * GSTR + lane * 8) = v;
-        }
-        __syncthreads();
         // accumulators start from the input projection of this step
         f32x16 acc[4][LNB];
 #pragma unroll
@@ -127,6 +133,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                     for (int j = 0; j < 4; ++j) acc[g][nb][4 * q + j] = (float)v[j];
                 }
         }
+        __syncthreads();                                   // every wave has read its part of the staged tile
+        if (step + 1 < R) request_gx(step + 1);
         // G += W_hh . h_{t-1}^T
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
