@@ -42,6 +42,7 @@ def parse():
     p.add_argument('--clusters', type=int, default=None, help='K (default 4; 8 for the 8-GPU config)')
     p.add_argument('--dtype', choices=['bf16', 'f32'], default=os.environ.get('DIC_BENCH_DTYPE', 'bf16'),
                    help='bf16: autocast for the bi-LSTMs / FC heads (HIP kernels stay f32)')
+    p.add_argument('--graph', action='store_true', help='capture the step in a hipGraph (pays off for small --batch)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=15.0)
     p.add_argument('--kernel-iters', type=int, default=20)
@@ -213,7 +214,7 @@ def main():
     net = Net(args, dev).to(dev)
     net.train()
     stepper = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args,
-                      autocast_dtype=torch.bfloat16 if a.dtype == 'bf16' else None)
+                      autocast_dtype=torch.bfloat16 if a.dtype == 'bf16' else None, use_graphs=a.graph)
 
     def one_step(i):
         lo = (i % nb) * a.batch

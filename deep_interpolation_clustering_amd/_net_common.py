@@ -187,7 +187,7 @@ class NetBase(nn.Module):
         loss = rec_loss_dict['ae_mse']
         for name, value in aux_loss_dict.items():
             loss = loss + aux_tasks[name] * value
-            logger.debug('Aux loss {}:{}, w:{}'.format(name, value, aux_tasks[name]))
+            # (upstream logs the value here, clustering_interp.py:243: formatting a device tensor is a host sync per term)
         rec_loss_dict['loss'] = loss
         rec_loss_dict.update(aux_loss_dict)
         return rec_loss_dict

@@ -35,7 +35,7 @@ class TrainerBase(object):
         self.model = model.to(device)
         autocast = torch.bfloat16 if (getattr(args, 'amp_bf16', False) and device.type == 'cuda') else None
         self.stepper = Stepper(self.model, lambda m: pytorch_optimizer(m, args.optimizer, args.init_lr, args.weight_decay_rate),
-                               args, autocast_dtype=autocast)
+                               args, autocast_dtype=autocast, use_graphs=getattr(args, 'hip_graph', False))
         self.optimizer = self.stepper.optimizer
         self.lr_scheduler = pytorch_lr_scheduler(self.optimizer, args.lr_decay_mode, args.lr_decay_step_or_patience,
                                                  args.lr_decay_rate)

@@ -45,12 +45,16 @@ class Stepper:
     ``autocast_dtype`` (e.g. torch.bfloat16) wraps the forward in torch.autocast so the bi-LSTMs and the
     FC heads run on bf16 MFMA; the HIP kernels always compute in f32."""
 
-    def __init__(self, model, optimizer_factory, args, autocast_dtype=None):
+    def __init__(self, model, optimizer_factory, args, autocast_dtype=None, use_graphs=False):
         self.model, self.args = model, args
         self.flat = dist.FlatParams(model)          # must precede the optimizer: it re-homes parameter storage
         self.flat.broadcast_(0)
         self.optimizer = optimizer_factory(model)
         self.autocast_dtype = autocast_dtype
+        # hipGraph capture of the whole step (single-GPU): at the reference's batch size (256) the ~250 launches of a
+        # step are launch-bound (2.5 ms); one graph replay runs them back to back.
+        self.use_graphs = bool(use_graphs) and not dist.is_sharded()
+        self._graphs = {}
 
     def _ctx(self):
         if self.autocast_dtype is None:
@@ -65,7 +69,51 @@ class Stepper:
                                 aux_label_dict, future_vital_mask, fake_det_label)
         return losses, hidden, rec_ob, aux_pred
 
+    # ------------------------------------------------------------------------------ hipGraph path
+    def _graph_key(self, tensors):
+        lrs = tuple(float(g['lr']) for g in self.optimizer.param_groups)
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in tensors.items()) + (lrs, self.model.training)
+
+    def _step_graphed(self, tensors):
+        key = self._graph_key(tensors)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static = {k: v.clone() for k, v in tensors.items()}
+
+            def run():
+                return self._step_eager(static.get('x'), static.get('ob'), static.get('padding_mask'), static.get('lengths'),
+                                        **{k: static[k] for k in static if k not in ('x', 'ob', 'padding_mask', 'lengths')})
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up outside capture (lazy init, hipFuncSetAttribute, ...)
+                for _ in range(2):
+                    run()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = run()
+            entry = self._graphs[key] = (graph, static, out)
+            return out                                         # the two warm-up runs + capture already stepped
+        graph, static, out = entry
+        for k, v in tensors.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return out
+
     def step(self, x, ob, padding_mask, lengths=None, **kw):
+        if self.use_graphs and x.is_cuda:
+            tensors = {'x': x, 'ob': ob}
+            if padding_mask is not None:
+                tensors['padding_mask'] = padding_mask
+            if lengths is not None:
+                tensors['lengths'] = lengths
+            extra = {k: v for k, v in kw.items() if v is not None and not (isinstance(v, dict) and not v)}
+            if all(torch.is_tensor(v) for v in extra.values()):
+                tensors.update(extra)
+                return self._step_graphed(tensors)
+        return self._step_eager(x, ob, padding_mask, lengths, **kw)
+
+    def _step_eager(self, x, ob, padding_mask, lengths=None, **kw):
         self.flat.zero_grad()
         losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
         losses['loss'].backward()

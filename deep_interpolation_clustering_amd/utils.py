@@ -86,7 +86,9 @@ def pytorch_optimizer(model, optimizer, init_lr, weight_decay=0):
         return optim.RMSprop(params, lr=init_lr, momentum=0.9, weight_decay=weight_decay)
     if optimizer == 'Adam':
         fused = bool(params) and all(p.is_cuda for p in params)
-        return optim.Adam(params, lr=init_lr, weight_decay=weight_decay, amsgrad=True, fused=fused or None)
+        # capturable: the optimizer state lives on the device, so a whole step can be captured in a hipGraph
+        return optim.Adam(params, lr=init_lr, weight_decay=weight_decay, amsgrad=True, fused=fused or None,
+                          capturable=fused)
     raise ValueError('unknown optimizer {}'.format(optimizer))
 
 

@@ -107,3 +107,33 @@ def test_forward_matches_oracle_bigger_batch():
     np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(aux['cluster_pred'].detach().cpu().numpy(), aux_ref['cluster_pred'].detach().numpy(), rtol=1e-4)
     assert (aux['cluster_pred'].argmax(1).cpu() == aux_ref['cluster_pred'].argmax(1)).all()
+
+
+def test_hip_graph_step_matches_eager():
+    """Stepper(use_graphs=True) captures the whole step in a hipGraph; the trajectory must equal the eager one."""
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=4, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    coh = synthetic.make_cohort(512, seed=8)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    traj = {}
+    for mode in (False, True):
+        torch.manual_seed(4)
+        net = Net(args, dev).to(dev)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16, use_graphs=mode)
+        out = []
+        for i in range(8):
+            lo = (i % 2) * 256
+            losses, gnorm, _ = st.step(X[lo:lo + 256], OB[lo:lo + 256], None, LEN[lo:lo + 256])
+            out.append([float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(gnorm)])
+        traj[mode] = np.array(out)
+        if mode:
+            assert len(st._graphs) == 1
+    np.testing.assert_allclose(traj[True], traj[False], rtol=2e-3)
