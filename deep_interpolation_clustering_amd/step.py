@@ -83,17 +83,30 @@ class Stepper:
             def run():
                 return self._step_eager(static.get('x'), static.get('ob'), static.get('padding_mask'), static.get('lengths'),
                                         **{k: static[k] for k in static if k not in ('x', 'ob', 'padding_mask', 'lengths')})
+            # warm-up outside capture (lazy initialisation, hipFuncSetAttribute, allocator), with the training state
+            # snapshotted and put back so that the warm-up leaves no trace: capturing executes nothing, the first
+            # replay below IS this call's step
+            snap_flat = self.flat.flat.clone()
+            snap_buf = [b.clone() for b in self.model.buffers()]
+            snap_opt = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.optimizer.state.items()}
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                      # warm-up outside capture (lazy init, hipFuncSetAttribute, ...)
+            with torch.cuda.stream(side):
                 for _ in range(2):
                     run()
             torch.cuda.current_stream().wait_stream(side)
+            with torch.no_grad():
+                self.flat.flat.copy_(snap_flat)
+                for b, sb in zip(self.model.buffers(), snap_buf):
+                    b.copy_(sb)
+                for p_, st in self.optimizer.state.items():
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(snap_opt[p_][k]) if p_ in snap_opt and k in snap_opt[p_] else v.zero_()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = run()
             entry = self._graphs[key] = (graph, static, out)
-            return out                                         # the two warm-up runs + capture already stepped
         graph, static, out = entry
         for k, v in tensors.items():
             static[k].copy_(v, non_blocking=True)
