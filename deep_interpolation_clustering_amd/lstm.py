@@ -18,6 +18,7 @@ tests run in.  The bf16 path is checked against an f32 emulation with the same r
 import torch
 
 from . import _native as N
+from .ops import splitk_tn
 
 H = 128
 
@@ -83,11 +84,9 @@ class _BiLstm(torch.autograd.Function):
         dx = dw_ih = dw_hh = None
         if ctx.needs_input_grad[0]:
             dx = (dg2 @ wihb)[:, :I].reshape(R, B, I).to(ctx.x_dtype)
-        dg3 = dgx.view(R, B, 8 * H).transpose(1, 2)               # (R, 8H, B): one K-slice per time step
         if ctx.needs_input_grad[1]:
-            # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split K by time step so the
-            # GEMM fills the chip (R x 16+ output tiles), then add the R partial products in f32
-            dw_ih = torch.bmm(dg3, xb).float().sum(0)[:, :I].reshape(2, 4 * H, I)
+            # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split-K bmm (ops.splitk_tn)
+            dw_ih = splitk_tn(dg2, xb.view(R * B, Ip))[:, :I].reshape(2, 4 * H, I)
         if ctx.needs_input_grad[2]:
             # H_prev: the hidden state each step consumed (forward: h_{t-1}; reverse: h_{t+1}; h_0 at the ends)
             hprev = torch.empty((R, B, 2, H), device=dev, dtype=bf)
@@ -100,8 +99,8 @@ class _BiLstm(torch.autograd.Function):
             else:
                 hprev[0, :, 0] = h0c[0].to(bf)
                 hprev[R - 1, :, 1] = h0c[1].to(bf)
-            dg5 = dgx.view(R, B, 2, 4 * H)
-            dw_hh = torch.stack([torch.bmm(dg5[:, :, d].transpose(1, 2), hprev[:, :, d]).float().sum(0) for d in (0, 1)])
+            full = splitk_tn(dg2, hprev.view(R * B, 2 * H))       # (8H, 2H) in one pass over dG: the diagonal blocks are wanted
+            dw_hh = torch.stack([full[:4 * H, :H], full[4 * H:, H:]])
         return dx, dw_ih, dw_hh, (dbias if ctx.needs_input_grad[3] else None), (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None)
 
 

@@ -329,12 +329,21 @@ def head_linear(h, weight, bias):
     return _HeadLinear.apply(h, weight, bias)
 
 
+def splitk_tn(a, b):
+    """a^T b in f32 for a (N,M), b (N,K) bf16 row-major with N in the hundreds of thousands and a small (M,K) output:
+    the weight-gradient shape of everything applied per (time step, encounter) row.  Issued as a bmm over 8192-row
+    chunks + an f32 sum of the chunk products: measured 800 TFLOP/s, against 230 for the single GEMM (4 output
+    tiles) and 330 for one chunk per time step (scripts/gemm_probe.py)."""
+    n = a.shape[0]
+    for c in (8192, 4096, 2048):
+        if n % c == 0 and n >= 2 * c:
+            return torch.bmm(a.view(n // c, c, -1).transpose(1, 2), b.view(n // c, c, -1)).float().sum(0)
+    return (a.t() @ b).float()
+
+
 class _RowsLinear(torch.autograd.Function):
     """y = x W^T + b on (N, I) bf16 rows with N in the hundreds of thousands (library GEMMs).  Only the weight
-    gradient is special: dW = dy^T x has K = N and a tiny output, so it is issued as a bmm over row chunks
-    (fills the chip) and the chunk products are added in f32 -- hipBLASLt otherwise runs it on 4 tiles."""
-
-    CHUNK = 16384
+    gradient is special: dW = dy^T x has K = N and a tiny output (see splitk_tn)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -349,12 +358,7 @@ class _RowsLinear(torch.autograd.Function):
         dyb = dy.to(torch.bfloat16).contiguous()
         n = xb.shape[0]
         dx = (dyb @ wb).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
-        c = _RowsLinear.CHUNK
-        if n >= 4 * c and n % c == 0:
-            dw = torch.bmm(dyb.view(n // c, c, -1).transpose(1, 2), xb.view(n // c, c, -1)).float().sum(0)
-        else:
-            dw = (dyb.t() @ xb).float()
-        return dx, dw, torch.sum(dyb, dim=0, dtype=torch.float32)
+        return dx, splitk_tn(dyb, xb), torch.sum(dyb, dim=0, dtype=torch.float32)
 
 
 def rows_linear(x, weight, bias):
