@@ -60,8 +60,19 @@ template <typename T>
 __device__ __forceinline__ double reduce_partials_32x8(const T* partials, int nblk, int n, int i0, double* lds256) {
     const int o = threadIdx.x & 31, sl = threadIdx.x >> 5, i = i0 + o;
     double acc = 0.0;
-    if (i < n)
-        for (int b = sl; b < nblk; b += 8) acc += (double)partials[(size_t)b * n + i];
+    if (i < n) {
+        // four independent chains so that four loads are in flight per thread (the loop is latency-bound otherwise)
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = sl;
+        for (; b + 24 < nblk; b += 32) {
+            acc += (double)partials[(size_t)b * n + i];
+            a1 += (double)partials[(size_t)(b + 8) * n + i];
+            a2 += (double)partials[(size_t)(b + 16) * n + i];
+            a3 += (double)partials[(size_t)(b + 24) * n + i];
+        }
+        for (; b < nblk; b += 8) acc += (double)partials[(size_t)b * n + i];
+        acc = (acc + a1) + (a2 + a3);
+    }
     lds256[threadIdx.x] = acc;
     __syncthreads();
     double r = 0.0;

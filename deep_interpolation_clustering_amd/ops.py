@@ -329,15 +329,98 @@ def head_linear(h, weight, bias):
     return _HeadLinear.apply(h, weight, bias)
 
 
-def splitk_tn(a, b):
-    """a^T b in f32 for a (N,M), b (N,K) bf16 row-major with N in the hundreds of thousands and a small (M,K) output:
-    the weight-gradient shape of everything applied per (time step, encounter) row.  Issued as a bmm over 8192-row
-    chunks + an f32 sum of the chunk products: measured 800 TFLOP/s, against 230 for the single GEMM (4 output
-    tiles) and 330 for one chunk per time step (scripts/gemm_probe.py)."""
+class _BnReluHead(torch.autograd.Function):
+    """BatchNorm1d(128) -> ReLU -> Linear(128, C) over (N,128) bf16 rows (csrc/dic_bnhead.hip).  Returns
+    (v, mean, biased var, global row count); the moments are for the caller's running statistics."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, training):
+        N.require_gpu(z, gamma, beta, weight, bias)
+        zb = z.to(torch.bfloat16).contiguous()
+        n, k = zb.shape
+        c = weight.shape[0]
+        L, dev, st = N.lib(), zb.device, N.stream_of(zb)
+        if training:
+            sums = torch.empty(2 * k + 1, device=dev, dtype=torch.float64)
+            ws = _ws(L.dic_bn_colstats_workspace(n, k), dev)
+            N.check(L.dic_bn_colstats(N.ptr(zb), n, k, N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bn_colstats')
+            sums[2 * k:].fill_(n)                 # (a fill kernel: item assignment is a host-to-device copy, not capturable)
+            dist.all_reduce_sum_(sums)            # the moments of the GLOBAL batch (SURVEY.md 8e)
+            cnt = sums[2 * k]
+            mean64 = sums[:k] / cnt
+            var = (sums[k:2 * k] / cnt - mean64 * mean64).clamp_min_(0).float()
+            mean, cnt = mean64.float(), cnt.float()
+        else:
+            mean, var = N.f32c(running_mean), N.f32c(running_var)
+            cnt = torch.ones((), device=dev, dtype=torch.float32)
+        rstd = torch.rsqrt(var + eps)
+        g, bt, w, b = N.f32c(gamma.detach()), N.f32c(beta.detach()), N.f32c(weight.detach()), N.f32c(bias.detach())
+        v = torch.empty((n, c), device=dev, dtype=torch.float32)
+        N.check(L.dic_bnhead_fwd(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(b), n, k, c, N.ptr(v), st),
+                'dic_bnhead_fwd')
+        ctx.save_for_backward(zb, mean, rstd, g, bt, w, cnt)
+        ctx.z_dtype, ctx.training = z.dtype, bool(training)
+        ctx.mark_non_differentiable(mean, var, cnt)
+        return v, mean, var, cnt
+
+    @staticmethod
+    def backward(ctx, dv, _m, _v, _c):
+        zb, mean, rstd, g, bt, w, cnt = ctx.saved_tensors
+        n, k = zb.shape
+        c = w.shape[0]
+        L, dev, st = N.lib(), zb.device, N.stream_of(zb)
+        gv = N.f32c(dv)
+        sums = torch.empty((2 + c) * k + c, device=dev, dtype=torch.float32)
+        ws = _ws(L.dic_bnhead_bwd_workspace(n, k, c), dev)
+        N.check(L.dic_bnhead_bwd_reduce(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), n, k, c, N.ptr(sums),
+                                        N.ptr(ws), ws.numel(), st), 'dic_bnhead_bwd_reduce')
+        dbeta, dgamma = sums[:k], sums[k:2 * k]                 # this rank's share; the gradient all-reduce sums them
+        dw, db = sums[2 * k:(2 + c) * k].view(c, k), sums[(2 + c) * k:]
+        dz = None
+        if ctx.needs_input_grad[0]:
+            if ctx.training:
+                red = sums[:2 * k].clone()
+                dist.all_reduce_sum_(red)
+                red /= cnt                          # global row count, on the device (shards may differ by a row)
+            else:
+                red = torch.zeros(2 * k, device=dev, dtype=torch.float32)
+            dz = torch.empty_like(zb)
+            N.check(L.dic_bnhead_bwd_input(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), N.ptr(red),
+                                           N.ptr(red[k:]), 1.0, n, k, c, N.ptr(dz), st), 'dic_bnhead_bwd_input')
+            dz = dz.to(ctx.z_dtype)
+        return dz, dgamma, dbeta, dw, db, None, None, None, None
+
+
+BNHEAD_OUT = (1, 2, 3, 4, 5, 6, 7, 8)
+
+
+def bn_relu_head(z, bn, linear):
+    """``linear(relu(bn(z)))`` for an nn.BatchNorm1d(128) and an nn.Linear(128, C <= 8) on (N,128) bf16 rows, with the
+    module semantics of BatchNorm1d (batch moments + running statistics in training mode, running statistics in
+    eval mode) and moments over the GLOBAL batch when the batch is sharded over ranks (dist.GlobalBatchNorm1d)."""
+    training = bn.training or bn.running_mean is None
+    v, mean, var, cnt = _BnReluHead.apply(z, bn.weight, bn.bias, linear.weight, linear.bias, bn.eps, bn.running_mean,
+                                          bn.running_var, training)
+    if bn.training and bn.track_running_stats:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            # momentum=None (cumulative average) needs the step count on the host: not used on the reference path
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            unbiased = var * (cnt / (cnt - 1).clamp_min(1))
+            bn.running_var.mul_(1 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
+    return v
+
+
+def splitk_tn(a, b, chunks=(8192, 4096, 2048)):
+    """a^T b in f32 for a (N,M), b (N,K) bf16 (rows may be strided views) with N in the hundreds of thousands and a small
+    (M,K) output: the weight-gradient shape of everything applied per (time step, encounter) row.  Issued as a bmm over
+    row chunks + an f32 sum of the chunk products: measured 800 TFLOP/s with 8192-row chunks, against 230 for the single
+    GEMM (4 output tiles) and 330 for one chunk per time step (scripts/gemm_probe.py)."""
     n = a.shape[0]
-    for c in (8192, 4096, 2048):
+    for c in chunks:
         if n % c == 0 and n >= 2 * c:
-            return torch.bmm(a.view(n // c, c, -1).transpose(1, 2), b.view(n // c, c, -1)).float().sum(0)
+            return torch.bmm(a.unflatten(0, (n // c, c)).transpose(1, 2), b.unflatten(0, (n // c, c))).float().sum(0)
     return (a.t() @ b).float()
 
 

@@ -28,7 +28,12 @@ class CompressFC(nn.Module):
         first = self.model[0]
         with torch.autocast('cuda', enabled=False):
             z = ops.rows_linear(rec_input, first.weight, first.bias)           # split-K weight gradient
-        hidden = self.model[3](self.model[2](self.model[1](z)))
+        bn, drop = self.model[1], self.model[3]
+        if last.out_features in ops.BNHEAD_OUT and not (drop.training and drop.p > 0):
+            # BatchNorm -> ReLU -> Linear in four streaming passes over z, the hidden activation never materialised
+            with torch.autocast('cuda', enabled=False):
+                return ops.bn_relu_head(z, bn, last)
+        hidden = drop(self.model[2](bn(z)))
         with torch.autocast('cuda', enabled=False):
             return ops.head_linear(hidden, last.weight, last.bias)
 

@@ -210,6 +210,29 @@ size_t dic_head_bwd_workspace(int64_t N, int K, int C);
 int dic_head_bwd(const void* h, const float* W, const float* dv, int64_t N, int K, int C, void* dh, float* dW, float* db,
                  void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
+/* ------------------------------------------------------------- CompressFC tail, fused ---------
+ * BatchNorm1d(128) -> ReLU -> Linear(128, C) (rbf.py:116-123 with dropout p = 0 or eval mode) over N rows
+ * without materialising the hidden activation.  z (N,128) bf16 = output of the first Linear; mean, rstd,
+ * gamma, beta (128) f32; W (C,128), b (C) f32; C in 1..8.
+ *   dic_bn_colstats:       sums[0:128] = sum_rows z, sums[128:256] = sum_rows z^2 (f64; the caller forms the
+ *                          batch moments, all-reducing the sums first when the batch is sharded over ranks)
+ *   dic_bnhead_fwd:        v (N,C) f32 = b + W relu(gamma (z - mean) rstd + beta)
+ *   dic_bnhead_bwd_reduce: sums[(2+C)*128 + C] f32 = sum da | sum da*xhat | dW (C,128) | db (C), where
+ *                          da = (dv W) 1[h > 0]; the first two rows are d beta and d gamma
+ *   dic_bnhead_bwd_input:  dz (N,128) bf16 = gamma rstd (da - sum_da*inv_n - xhat sum_dax*inv_n); inv_n = 1 /
+ *                          global row count in training mode; pass zero sums for eval-mode BatchNorm. */
+size_t dic_bn_colstats_workspace(int64_t N, int K);
+int dic_bn_colstats(const void* z, int64_t N, int K, double* sums, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+int dic_bnhead_fwd(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                   const float* b, int64_t N, int K, int C, float* v, dic_stream_t stream);
+size_t dic_bnhead_bwd_workspace(int64_t N, int K, int C);
+int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                          const float* dv, int64_t N, int K, int C, float* sums, void* workspace, size_t workspace_bytes,
+                          dic_stream_t stream);
+int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, void* dz,
+                         dic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

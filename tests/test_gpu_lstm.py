@@ -146,3 +146,57 @@ def test_head_linear_matches_torch(N, C):
     np.testing.assert_allclose(got[0].cpu().numpy(), h2.grad.cpu().numpy(), rtol=1e-2, atol=1e-2 * float(h2.grad.abs().max()))   # dh is bf16
     np.testing.assert_allclose(got[1].cpu().numpy(), lin.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(lin.weight.grad.abs().max()))
     np.testing.assert_allclose(got[2].cpu().numpy(), lin.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(lin.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize('N,C,training', [(1, 6, False), (77, 6, True), (4099, 1, True), (20000, 8, True), (20000, 6, False)])
+def test_bn_relu_head_matches_torch(N, C, training):
+    """Fused BatchNorm1d -> ReLU -> Linear tail of CompressFC (csrc/dic_bnhead.hip, rbf.py:116-123) vs the torch modules in
+    f32 on the same bf16 input: output, running statistics, and all five gradients."""
+    import copy
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(N + C)
+    dev = torch.device('cuda')
+    bn = torch.nn.BatchNorm1d(128).to(dev)
+    lin = torch.nn.Linear(128, C).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+    bn.train(training)
+    bn_ref, lin_ref = copy.deepcopy(bn), copy.deepcopy(lin)
+    z = (torch.randn(N, 128, device=dev) * 1.5 + 0.3).to(torch.bfloat16)
+    cot = torch.randn(N, C, device=dev)
+    z1 = z.clone().requires_grad_()
+    v = ops.bn_relu_head(z1, bn, lin)
+    (v * cot).sum().backward()
+    z2 = z.float().clone().requires_grad_()
+    ref = lin_ref(torch.relu(bn_ref(z2)))
+    (ref * cot).sum().backward()
+
+    def close(a, b, tol):
+        a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=tol, atol=tol * max(float(np.abs(b).max()), 1e-6))
+    close(v, ref, 2e-5)
+    close(bn.running_mean, bn_ref.running_mean, 1e-5)
+    close(bn.running_var, bn_ref.running_var, 1e-5)
+    assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+    close(z1.grad, z2.grad, 1e-2)                       # dz is rounded to bf16
+    close(lin.weight.grad, lin_ref.weight.grad, 2e-4)
+    close(lin.bias.grad, lin_ref.bias.grad, 2e-4)
+    close(bn.weight.grad, bn_ref.weight.grad, 2e-4)
+    close(bn.bias.grad, bn_ref.bias.grad, 2e-4)
+
+
+def test_compress_fc_fused_tail_matches_module_path():
+    """CompressFC under bf16 autocast takes the fused tail; with dropout active it must not (rbf.py:111-125)."""
+    from deep_interpolation_clustering_amd.rbf import CompressFC
+    torch.manual_seed(5)
+    dev = torch.device('cuda')
+    fc = CompressFC(256, 6, 0.0).to(dev).train()
+    x = torch.randn(3000, 256, device=dev)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        got = fc(x)
+    ref = fc.model(x)                                    # f32 module path (updates running stats a second time: irrelevant here)
+    np.testing.assert_allclose(got.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=0, atol=3e-2)
+    assert got.dtype == torch.float32
