@@ -1,0 +1,162 @@
+"""Cluster statistics of the K sweep on the device.
+
+Upstream p2 evaluates, for every K and every gap-statistic reference set, ``pairwise_distances`` of each cluster
+(p2_clustering_optK.py:334-351: an n_c x n_c float64 matrix per cluster) and scikit-learn's silhouette /
+Calinski-Harabasz / Davies-Bouldin scores plus an O(N^2) Python-loop Dunn index (internal_eval.py:37-147).  Here
+all distance work is ONE pass of ``dic_cluster_pairdist`` (csrc/dic_pairdist.hip) over the N^2 point pairs:
+
+    S[i][k]    = sum_{j in cluster k} ||x_i - x_j||        Dmin[i][k] = min_{j in cluster k} ||x_i - x_j||
+    own_max[i] = max_{j in cluster(i)} ||x_i - x_j||
+
+from which every index above follows by O(N K) reductions (done here in f64 with torch on the device).  The centroid
+based indices (CH, DB) need no pair pass at all.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+def _device_points(x):
+    x = torch.as_tensor(x)
+    if not x.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError('deep_interpolation_clustering_amd.cluster_stats runs only on an MI355X; there is no CPU path by design')
+        x = x.to('cuda')
+    return x.to(torch.float32).contiguous()
+
+
+def _encode(labels, device):
+    """sklearn LabelEncoder semantics: sorted unique values -> 0..K-1."""
+    lab = torch.as_tensor(np.asarray(labels) if not torch.is_tensor(labels) else labels).to(device).reshape(-1)
+    uniq, inv = torch.unique(lab, sorted=True, return_inverse=True)
+    return inv.to(torch.int64), int(uniq.numel())
+
+
+class PairStats:
+    """Result of one pair pass: ``labels`` (N) encoded 0..K-1, ``counts`` (K), ``S`` / ``Dmin`` (N,K) f32 and ``own_max`` (N),
+    all in the caller's row order."""
+
+    def __init__(self, labels, counts, S, Dmin, own_max):
+        self.labels, self.counts, self.S, self.Dmin, self.own_max = labels, counts, S, Dmin, own_max
+        self.K = int(counts.numel())
+
+    def intra_sums(self):
+        """(K,) f64: sum over ordered pairs (i, j) of one cluster of ||x_i - x_j||  (= np.sum(pairwise_distances(X_c)))."""
+        own = self.S.gather(1, self.labels[:, None])[:, 0].double()
+        return torch.zeros(self.K, dtype=torch.float64, device=own.device).index_add_(0, self.labels, own)
+
+
+def pair_stats(x, labels, need_min=True, need_max=True):
+    x = _device_points(x)
+    n, d = x.shape
+    lab, K = _encode(labels, x.device)
+    if lab.numel() != n:
+        raise ValueError('labels: %d entries for %d points' % (lab.numel(), n))
+    if d % 4:
+        x = torch.nn.functional.pad(x, (0, 4 - d % 4))          # zero columns do not change distances
+        d = x.shape[1]
+    order = torch.argsort(lab, stable=True)
+    xs = x[order].contiguous()
+    counts = torch.bincount(lab, minlength=K)
+    seg = torch.zeros(K + 1, dtype=torch.int32, device=x.device)
+    seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    S = torch.empty((n, K), device=x.device, dtype=torch.float32)
+    Dmin = torch.empty_like(S) if need_min else None
+    omax = torch.empty(n, device=x.device, dtype=torch.float32) if need_max else None
+    N.check(N.lib().dic_cluster_pairdist(N.ptr(xs), N.ptr(seg), n, d, K, N.ptr(S), N.ptr(Dmin), N.ptr(omax), N.stream_of(xs)),
+            'dic_cluster_pairdist')
+
+    def unsort(t):
+        if t is None:
+            return None
+        out = torch.empty_like(t)
+        out[order] = t
+        return out
+    return PairStats(lab, counts, unsort(S), unsort(Dmin), unsort(omax))
+
+
+# ---------------------------------------------------------------------------- gap-statistic inertia (p2:334-351)
+def inertia_v1(x, labels, stats=None):
+    """np.mean([np.mean(pairwise_distances(X[a == c])) for c in unique(a)])  (p2:334-342)."""
+    st = stats or pair_stats(x, labels, need_min=False, need_max=False)
+    n = st.counts.double()
+    return float((st.intra_sums() / (n * n)).mean())
+
+
+def inertia_v2(x, labels, stats=None):
+    """sum_c sum(pairwise_distances(X[a == c])) / (2 n_c)  (p2:344-351)."""
+    st = stats or pair_stats(x, labels, need_min=False, need_max=False)
+    return float((st.intra_sums() / (2.0 * st.counts.double())).sum())
+
+
+# ---------------------------------------------------------------------------- validity indices (internal_eval.py)
+def silhouette_samples(x, labels, stats=None):
+    st = stats or pair_stats(x, labels, need_min=False, need_max=False)
+    n_pts = st.labels.numel()
+    if not 1 < st.K < n_pts:
+        raise ValueError('Number of labels is %d. Valid values are 2 to n_samples - 1 (inclusive)' % st.K)
+    S = st.S.double()
+    cnt = st.counts.double()
+    own_mask = torch.nn.functional.one_hot(st.labels, st.K).bool()
+    intra = S.gather(1, st.labels[:, None])[:, 0] / (cnt[st.labels] - 1)             # 0/0 = nan for singletons, as sklearn
+    inter = (S / cnt).masked_fill(own_mask, float('inf')).min(1).values
+    sil = (inter - intra) / torch.maximum(intra, inter)
+    return torch.nan_to_num(sil, nan=0.0)
+
+
+def silhouette_score(x, labels, stats=None):
+    """sklearn.metrics.silhouette_score(x, labels, metric='euclidean') (internal_eval.py:112-123)."""
+    return float(silhouette_samples(x, labels, stats).mean())
+
+
+def dunn_index(x, labels, stats=None):
+    """min non-zero nearest-point distance between two clusters / largest farthest-point diameter
+    (internal_eval.py:84-110 with the 'nearest' / 'farthest' definitions of :21-82)."""
+    st = stats or pair_stats(x, labels)
+    K = st.K
+    idx = st.labels[:, None].expand(-1, K)
+    between = torch.full((K, K), float('inf'), device=st.Dmin.device, dtype=torch.float32)
+    between = between.scatter_reduce(0, idx, st.Dmin, reduce='amin', include_self=True)   # [a][b] = min_{i in a} Dmin[i][b]
+    off = between[~torch.eye(K, dtype=torch.bool, device=between.device)]
+    off = off[off != 0]
+    return float(off.min() / st.own_max.max())
+
+
+def _centroids(x, lab, K):
+    x64 = x.double()
+    cnt = torch.bincount(lab, minlength=K).double()
+    cen = torch.zeros((K, x.shape[1]), dtype=torch.float64, device=x.device).index_add_(0, lab, x64) / cnt[:, None]
+    return x64, cnt, cen
+
+
+def calinski_harabasz_score(x, labels):
+    """sklearn.metrics.calinski_harabasz_score (internal_eval.py:126-136)."""
+    x = _device_points(x)
+    lab, K = _encode(labels, x.device)
+    n = x.shape[0]
+    if not 1 < K < n:
+        raise ValueError('Number of labels is %d. Valid values are 2 to n_samples - 1 (inclusive)' % K)
+    x64, cnt, cen = _centroids(x, lab, K)
+    extra = float((cnt * ((cen - x64.mean(0)) ** 2).sum(1)).sum())
+    intra = float(((x64 - cen[lab]) ** 2).sum())
+    return 1.0 if intra == 0.0 else extra * (n - K) / (intra * (K - 1.0))
+
+
+def davies_bouldin_score(x, labels):
+    """sklearn.metrics.davies_bouldin_score (internal_eval.py:139-147)."""
+    x = _device_points(x)
+    lab, K = _encode(labels, x.device)
+    n = x.shape[0]
+    if not 1 < K < n:
+        raise ValueError('Number of labels is %d. Valid values are 2 to n_samples - 1 (inclusive)' % K)
+    x64, cnt, cen = _centroids(x, lab, K)
+    dist = ((x64 - cen[lab]) ** 2).sum(1).sqrt()
+    intra = torch.zeros(K, dtype=torch.float64, device=x.device).index_add_(0, lab, dist) / cnt
+    cd = torch.cdist(cen, cen)
+    if bool(torch.allclose(intra, torch.zeros_like(intra))) or bool(torch.allclose(cd, torch.zeros_like(cd))):
+        return 0.0
+    cd = cd.masked_fill(cd == 0, float('inf'))
+    return float(((intra[:, None] + intra[None, :]) / cd).max(1).values.mean())

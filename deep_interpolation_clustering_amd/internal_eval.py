@@ -1,37 +1,31 @@
-"""Cluster validity indices used by p2 (internal_eval.py:112-147 upstream): thin callables over scikit-learn.
-Post-hoc analysis, not on the accelerated path; ``DunnIndex`` (an O(N^2) Python loop
-upstream, internal_eval.py:37-110) is evaluated from a chunked distance pass instead."""
-import numpy as np
-from sklearn import metrics
+"""Drop-in for the reference's ``internal_eval`` module (internal_eval.py:15-147): the four cluster validity
+callables p2 looks up by name.  Same call convention (``metric(x, labels) -> float``) and error behaviour (scikit-learn's
+ValueError for fewer than 2 / as many as N clusters); the arithmetic runs on the device (cluster_stats.py): all distance
+work is one tiled pass of ``dic_cluster_pairdist`` instead of an (N,N) float64 matrix (silhouette) or an O(N^2) Python
+loop (Dunn).  ``stats=`` lets a caller that evaluates several indices on one labelling share the pair pass."""
+from . import cluster_stats as _cs
 
 
 class Sihouette(object):
     def __call__(self, x, labels, *args, **kwargs):
-        return metrics.silhouette_score(x, labels, metric=kwargs.get('metrics', 'euclidean'))
+        metric = kwargs.get('metrics', 'euclidean')
+        if metric != 'euclidean':
+            raise NotImplementedError("only the 'euclidean' silhouette of the reference path is provided")
+        return _cs.silhouette_score(x, labels, kwargs.get('stats'))
 
 
 class CHIndex(object):
     def __call__(self, x, labels, *args, **kwargs):
-        return metrics.calinski_harabasz_score(x, labels)
+        return _cs.calinski_harabasz_score(x, labels)
 
 
 class DBIndex(object):
     def __call__(self, x, label, *args, **kwargs):
-        return metrics.davies_bouldin_score(x, label)
+        return _cs.davies_bouldin_score(x, label)
 
 
 class DunnIndex(object):
-    """min nearest inter-cluster distance / max farthest intra-cluster diameter."""
+    """min nearest inter-cluster distance / max farthest intra-cluster diameter (internal_eval.py:84-110)."""
 
     def __call__(self, x, labels, *args, **kwargs):
-        x, labels = np.asarray(x), np.asarray(labels)
-        ids = np.unique(labels)
-        min_inter, max_diam = np.inf, 0.0
-        for a, i in enumerate(ids):
-            xi = x[labels == i]
-            for d in metrics.pairwise_distances_chunked(xi):
-                max_diam = max(max_diam, float(d.max()))
-            for j in ids[a + 1:]:
-                for d in metrics.pairwise_distances_chunked(xi, x[labels == j]):
-                    min_inter = min(min_inter, float(d.min()))
-        return min_inter / max_diam
+        return _cs.dunn_index(x, labels, kwargs.get('stats'))

@@ -5,8 +5,8 @@
 
 Reads Results/Pretrain/out_feat/<metric>/<cohort>.npy (written by p1), writes
 Results/Pretrain/out_feat/<metric>_kmeans_aligned/plot/{elbow.csv, gap_sts_v1.csv}.  The gap statistic's
-"mean intra-cluster pairwise distance" is evaluated on the GPU in tiles instead of materialising the
-n_c x n_c matrix per cluster (multi-GB at 75 k points).  DBSCAN / OPTICS and the seaborn plots of the
+"mean intra-cluster pairwise distance" and the validity indices come from one tiled all-pairs pass on the GPU
+(cluster_stats.py / csrc/dic_pairdist.hip) instead of an n_c x n_c float64 matrix per cluster (multi-GB at 75 k points).  DBSCAN / OPTICS and the seaborn plots of the
 upstream script are alternative algorithms / presentation and are not provided.
 """
 import argparse
@@ -17,6 +17,7 @@ import numpy as np
 import pandas as pd
 import torch
 
+from . import cluster_stats
 from .info import COHORTS
 from .internal_eval import CHIndex, DBIndex, DunnIndex, Sihouette
 from .kmeans import KMeans
@@ -40,21 +41,6 @@ def get_arguments(argv=None):
     return p.parse_args(argv)
 
 
-def mean_pairwise_distance(X, tile=8192):
-    """mean_{i,j} ||x_i - x_j|| over ALL ordered pairs incl. i == j (np.mean(pairwise_distances(X)), p2:334-342),
-    accumulated tile by tile on the device in f64."""
-    n = X.shape[0]
-    total = torch.zeros((), dtype=torch.float64, device=X.device)
-    for i in range(0, n, tile):
-        total += torch.cdist(X[i:i + tile], X, compute_mode='donot_use_mm_for_euclid_dist').sum(dtype=torch.float64)
-    return float(total) / (float(n) * float(n))
-
-
-def sum_pairwise_distance(X, tile=8192):
-    n = X.shape[0]
-    return mean_pairwise_distance(X, tile) * float(n) * float(n)
-
-
 class KM(object):
     def __init__(self, k_max, out_path, internal_metrics, n_init, gap_b, metric_sample=0):
         self.k_max, self.n_init, self.gap_b, self.metric_sample = k_max, n_init, gap_b, metric_sample
@@ -64,14 +50,12 @@ class KM(object):
         table = {'Dunn_Index': DunnIndex, 'Sihouette': Sihouette, 'Davies-Bouldin_Index': DBIndex, 'Calinski-Harabasz': CHIndex}
         self.internal_metrics = [table[n]() for n in internal_metrics]
 
-    # -- inertia definitions of the gap statistic (p2:334-351)
-    def compute_inertia_v1(self, a, X):
-        a = torch.as_tensor(a, device=X.device)
-        return float(np.mean([mean_pairwise_distance(X[a == c]) for c in torch.unique(a).tolist()]))
+    # -- inertia definitions of the gap statistic (p2:334-351): one tiled pair pass on the device, nothing n x n
+    def compute_inertia_v1(self, a, X, stats=None):
+        return cluster_stats.inertia_v1(X, a, stats)
 
-    def computer_intertia_v2(self, a, X):
-        a = torch.as_tensor(a, device=X.device)
-        return float(sum(sum_pairwise_distance(X[a == c]) / (2.0 * int((a == c).sum())) for c in torch.unique(a).tolist()))
+    def computer_intertia_v2(self, a, X, stats=None):
+        return cluster_stats.inertia_v2(X, a, stats)
 
     def elbow(self, train_feat, valid_feat):
         rows = []
@@ -105,13 +89,15 @@ class KM(object):
             ref_mean, ref_std = np.mean(np.log(local)), np.std(np.log(local))
             ref_s = np.sqrt(1 + 1 / n_references) * ref_std
             assignments = KMeans(n_clusters=k, n_init=self.n_init).fit_predict(Xd)
-            act = np.log(inertia(assignments, Xd))
+            need_minmax = any(isinstance(m, DunnIndex) for m in self.internal_metrics)
+            stats = cluster_stats.pair_stats(Xd, assignments, need_min=need_minmax, need_max=need_minmax)
+            act = np.log(inertia(assignments, Xd, stats))      # the same pair pass feeds the gap term and every index
             gap = ref_mean - act
-            xs, ls = data, assignments
             if self.metric_sample and self.metric_sample < len(data):
                 pick = np.random.RandomState(0).choice(len(data), self.metric_sample, replace=False)
-                xs, ls = data[pick], assignments[pick]
-            vals = [m(xs, ls) for m in self.internal_metrics]
+                vals = [m(Xd[torch.as_tensor(pick, device=dev)], assignments[pick]) for m in self.internal_metrics]
+            else:
+                vals = [m(Xd, assignments, stats=stats) for m in self.internal_metrics]
             logger.info('k: {}, gap: {:.4f}, ref: {:.4f}, act: {:.4f}, ref_s: {:.4f} '.format(k, gap, ref_mean, act, ref_s)
                         + ' '.join('{}: {:.4f}'.format(n, v) for n, v in zip(self.internal_metrics_names, vals)))
             rows.append([k, gap, ref_mean, act, ref_s] + vals)

@@ -233,6 +233,18 @@ int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, co
                          const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, void* dz,
                          dic_stream_t stream);
 
+/* ------------------------------------------------- K-sweep statistics (p2, internal_eval) ------
+ * One pass over all N^2 point pairs, nothing n x n materialised.  Replaces sklearn pairwise_distances per
+ * cluster (p2_clustering_optK.py:334-351, gap-statistic inertia) and the distance work inside
+ * silhouette_score / DunnIndex (internal_eval.py:37-126).
+ * X (N,D) f32 with rows SORTED by cluster: cluster k = rows seg[k] .. seg[k+1]-1, seg (K+1) int32 on the
+ * device, seg[0] = 0, seg[K] = N; D % 4 == 0; K <= 64.
+ *   S (N,K) f32:     S[i][k] = sum over j in cluster k of ||x_i - x_j||   (f32 direct-difference distances)
+ *   Dmin (N,K) f32:  Dmin[i][k] = min over j in cluster k of ||x_i - x_j|| (+inf for an empty cluster) [may be NULL]
+ *   own_max (N):     farthest point of i's own cluster (0 for singletons)                              [may be NULL] */
+int dic_cluster_pairdist(const float* X, const int32_t* seg, int N, int D, int K, float* S, float* Dmin, float* own_max,
+                         dic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

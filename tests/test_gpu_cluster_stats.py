@@ -1,0 +1,87 @@
+"""GPU parity of the K-sweep statistics (csrc/dic_pairdist.hip through cluster_stats.py / internal_eval.py) against the
+reference's own scores (tests/golden/cluster_stats_*.npz), the CPU oracle, and scikit-learn.  ``-m gpu``."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cluster_stats_oracle as CO
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 'cluster_stats_*.npz')))
+
+
+@pytest.fixture(scope='module')
+def cs():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from deep_interpolation_clustering_amd import cluster_stats
+    return cluster_stats
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_scores_match_reference(cs, name):
+    g = dict(np.load(os.path.join(GOLDEN, name)))
+    x, lab = g['x'], g['labels']
+    st = cs.pair_stats(x, lab)
+    np.testing.assert_allclose(cs.inertia_v1(x, lab, st), g['inertia_v1'], rtol=1e-5)
+    np.testing.assert_allclose(cs.inertia_v2(x, lab, st), g['inertia_v2'], rtol=1e-5)
+    np.testing.assert_allclose(cs.dunn_index(x, lab, st), g['dunn'], rtol=1e-5)
+    np.testing.assert_allclose(cs.silhouette_score(x, lab, st), g['silhouette'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cs.calinski_harabasz_score(x, lab), g['calinski_harabasz'], rtol=1e-5)
+    np.testing.assert_allclose(cs.davies_bouldin_score(x, lab), g['davies_bouldin'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('n,d,k', [(1, 4, 1), (63, 4, 2), (64, 8, 1), (65, 36, 3), (1000, 256, 7), (1537, 20, 64), (300, 6, 5)])
+def test_pair_stats_match_oracle(cs, n, d, k):
+    """Every S / Dmin / own_max entry against the float64 oracle: ragged tile edges, D not a multiple of the 32-wide
+    staging chunk (and not of 4: zero padded), the K limit, empty label values skipped by the encoder."""
+    rng = np.random.default_rng(n * 1000 + d)
+    x = rng.normal(0, 1, (n, d)).astype(np.float32)
+    lab = rng.integers(0, k, n) * 3 - 4              # arbitrary label values; some may be unused
+    st = cs.pair_stats(x, lab)
+    olab, K, S, Dmin, own_max = CO.pair_stats(x, lab)
+    assert st.K == K and np.array_equal(st.labels.cpu().numpy(), olab)
+    np.testing.assert_allclose(st.S.cpu().numpy(), S, rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(st.Dmin.cpu().numpy(), Dmin, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(st.own_max.cpu().numpy(), own_max, rtol=2e-6, atol=1e-6)
+
+
+def test_validity_indices_match_sklearn(cs):
+    """The drop-in callables of internal_eval.py against scikit-learn on k-means-like data (2 000 x 256)."""
+    from sklearn import metrics
+    from deep_interpolation_clustering_amd.internal_eval import CHIndex, DBIndex, DunnIndex, Sihouette
+    rng = np.random.default_rng(5)
+    cen = rng.normal(0, 1.0, (4, 256))
+    lab = rng.integers(0, 4, 2000)
+    x = (cen[lab] + rng.normal(0, 1.0, (2000, 256))).astype(np.float32)
+    lab[rng.integers(0, 2000, 100)] = rng.integers(0, 4, 100)        # some misassigned points
+    np.testing.assert_allclose(Sihouette()(x, lab), metrics.silhouette_score(x, lab), rtol=1e-5)
+    np.testing.assert_allclose(CHIndex()(x, lab), metrics.calinski_harabasz_score(x, lab), rtol=1e-5)
+    np.testing.assert_allclose(DBIndex()(x, lab), metrics.davies_bouldin_score(x, lab), rtol=1e-5)
+    np.testing.assert_allclose(DunnIndex()(x, lab), CO.dunn(x, lab), rtol=1e-5)
+    with pytest.raises(ValueError):
+        Sihouette()(x, np.zeros(2000, dtype=np.int64))
+
+
+def test_full_size_properties(cs):
+    """75 000 x 256 latents (BASELINE cfg2), K = 4: properties that need no O(N^2) oracle -- row sums of S against
+    torch.cdist for sampled rows, symmetry of the cluster-to-cluster sums, the Dmin / own_max invariants."""
+    from oracle.synth import latent_blobs
+    x, lab = latent_blobs(11, 75000, 256, 4)
+    xd = torch.tensor(x, device='cuda')
+    st = cs.pair_stats(xd, lab)
+    pick = torch.arange(0, 75000, 293, device='cuda')
+    ref = torch.cdist(xd[pick].double(), xd.double())
+    np.testing.assert_allclose(st.S[pick].double().sum(1).cpu().numpy(), ref.sum(1).cpu().numpy(), rtol=2e-6)
+    onehot = torch.nn.functional.one_hot(st.labels, st.K).double()
+    between = onehot.t() @ st.S.double()                       # [a][b] = sum_{i in a, j in b} d_ij
+    np.testing.assert_allclose(between.cpu().numpy(), between.t().cpu().numpy(), rtol=1e-6)
+    assert float(st.Dmin.gather(1, st.labels[:, None]).abs().max()) == 0.0          # every point is its own nearest
+    lab_t = st.labels[pick]
+    own = torch.where(st.labels[None, :] == lab_t[:, None], ref, torch.zeros_like(ref)).max(1).values
+    np.testing.assert_allclose(st.own_max[pick].cpu().numpy(), own.cpu().numpy(), rtol=2e-6)
+    s = cs.silhouette_score(xd, lab, st)
+    assert -1.0 <= s <= 1.0
