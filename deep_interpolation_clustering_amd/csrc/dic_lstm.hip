@@ -52,8 +52,13 @@ __device__ __forceinline__ size_t native_off(int t, int nbt, int bt, int dir, in
     return o * 4;
 }
 
+constexpr int LXK = 32;            // input width of the fused-projection variant (two MFMA k-steps)
+constexpr int XSTR = LXK + 8;      // bf16 elements per LDS row of the x tile (80 B: conflict-free ds_read_b128)
+
 struct LstmFwdArgs {
-    const __bf16* gx;      // (R,B,2,4,H) input projection + both biases
+    const __bf16* gx;      // (R,B,2,4,H) input projection + both biases      [lstm_fwd_kernel<false>]
+    const __bf16* x;       // (R,B,32) inputs and  wih (2,4H,32) input weights [lstm_fwd_kernel<true>: projection in-kernel]
+    const __bf16* wih;
     const __bf16* whh;     // (2,4H,H)
     const float* h0; const float* c0;     // (2,B,H) or NULL (zeros)
     __bf16* out;           // (R,B,2H): forward direction in [:H], reverse in [H:]
@@ -63,10 +68,16 @@ struct LstmFwdArgs {
     int R, B;
 };
 
+// PROJ = false: G_t starts from a precomputed gx_t (the projection was a library GEMM: decoder, input width 256).
+// PROJ = true:  G_t = x_t.W_ih^T + h_{t-1}.W_hh^T with W_ih (4H x 32) resident in registers next to W_hh, for narrow
+//               inputs (encoder: 3C = 18 channels): the (R,B,8H) gx tensor -- a 1.6 GB write and a 1.6 GB read at
+//               B = 32768 for 50 MB of actual input -- never exists.  The caller folds the bias in as a constant-one
+//               input column.
+template <bool PROJ>
 __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwdArgs a) {
     extern __shared__ __align__(16) __bf16 fsm[];
     __bf16 (*hbuf)[LBM * HSTR] = reinterpret_cast<__bf16 (*)[LBM * HSTR]>(fsm);      // [2][LBM*HSTR]
-    __bf16* gst = fsm + 2 * LBM * HSTR;                    // [LBM][GSTR] staged gx tile of the current step
+    __bf16* gst = fsm + 2 * LBM * HSTR;                    // PROJ ? [2][LBM][XSTR] x tiles : [LBM][GSTR] staged gx tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
     const int nbt = gridDim.x * LNB;                       // 32-row batch tiles in the padded batch
@@ -78,6 +89,14 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             wf[g][ks] = *reinterpret_cast<const bf16x8*>(a.whh + ((size_t)(dir * 4 + g) * LH + 32 * w + r) * LH + ks * 16 + 8 * hh);
+    bf16x8 wx[4][LXK / 16];
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ks = 0; ks < LXK / 16; ++ks)
+                wx[g][ks] = *reinterpret_cast<const bf16x8*>(a.wih + ((size_t)(dir * 4 + g) * LH + 32 * w + r) * LXK + ks * 16 + 8 * hh);
+    }
 
     // cell state and h_0: lane owns batch row (nb*32 + r) and hidden units 32w + 8q + 4hh + {0..3}, q = 0..3
     float c[LNB][16];
@@ -113,28 +132,59 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                                              (__attribute__((address_space(3))) void*)(gst + rowl * GSTR), 16, 0, 0);
         }
     };
-    request_gx(0);
+    // PROJ: the 64 x 32 x tile of a step is 4 KB -- one 16-B piece per thread, prefetched one step ahead through a
+    // register and written to the other LDS buffer before the step's closing barrier
+    const int xrow = tid >> 2, xpc = tid & 3;
+    auto load_x = [&](int step) {
+        const int t = dir ? R - 1 - step : step;
+        return *reinterpret_cast<const bf16x8*>(a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * LXK + xpc * 8);
+    };
+    bf16x8 xnext = {};
+    if constexpr (PROJ) {
+        *reinterpret_cast<bf16x8*>(gst + xrow * XSTR + xpc * 8) = load_x(0);
+    } else {
+        request_gx(0);
+    }
     __syncthreads();
 
     for (int step = 0; step < R; ++step) {
         const int t = dir ? R - 1 - step : step;
         const int cur = step & 1;
-        // accumulators start from the input projection of this step
         f32x16 acc[4][LNB];
+        if constexpr (PROJ) {
+            if (step + 1 < R) xnext = load_x(step + 1);        // in flight across the MFMA and gate-math phases
 #pragma unroll
-        for (int nb = 0; nb < LNB; ++nb) {
-            const __bf16* gp = gst + (nb * 32 + r) * GSTR + 32 * w + 4 * hh;
+            for (int nb = 0; nb < LNB; ++nb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(gp + g * LH + 8 * q);
+                    for (int k = 0; k < 16; ++k) acc[g][nb][k] = 0.f;
+            // G = W_ih . x_t^T (bias included: constant-one input column)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[g][nb][4 * q + j] = (float)v[j];
+            for (int ks = 0; ks < LXK / 16; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < LNB; ++nb) {
+                    const bf16x8 xb = *reinterpret_cast<const bf16x8*>(gst + cur * LBM * XSTR + (nb * 32 + r) * XSTR + ks * 16 + 8 * hh);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[g][ks], xb, acc[g][nb], 0, 0, 0);
                 }
+        } else {
+            // accumulators start from the input projection of this step
+#pragma unroll
+            for (int nb = 0; nb < LNB; ++nb) {
+                const __bf16* gp = gst + (nb * 32 + r) * GSTR + 32 * w + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bf16x4 v = *reinterpret_cast<const bf16x4*>(gp + g * LH + 8 * q);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[g][nb][4 * q + j] = (float)v[j];
+                    }
+            }
+            __syncthreads();                                   // every wave has read its part of the staged tile
+            if (step + 1 < R) request_gx(step + 1);
         }
-        __syncthreads();                                   // every wave has read its part of the staged tile
-        if (step + 1 < R) request_gx(step + 1);
         // G += W_hh . h_{t-1}^T
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
@@ -186,6 +236,9 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                     }
                 }
             }
+        }
+        if constexpr (PROJ) {
+            if (step + 1 < R) *reinterpret_cast<bf16x8*>(gst + (cur ^ 1) * LBM * XSTR + xrow * XSTR + xpc * 8) = xnext;
         }
         __syncthreads();
     }
@@ -381,22 +434,40 @@ using namespace dic;
 
 extern "C" {
 
+static int lstm_fwd_launch(bool proj, const LstmFwdArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(2 * LBM * HSTR + (proj ? 2 * LBM * XSTR : LBM * GSTR)) * sizeof(__bf16);
+    static bool attr_set[2] = {false, false};
+    const void* fn = proj ? (const void*)lstm_fwd_kernel<true> : (const void*)lstm_fwd_kernel<false>;
+    if (!attr_set[proj]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set[proj] = true;
+    }
+    const dim3 grid((a.B + LBM - 1) / LBM, 2);
+    if (proj) hipLaunchKernelGGL(lstm_fwd_kernel<true>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(lstm_fwd_kernel<false>, grid, dim3(256), lds, st, a);
+    return check_launch("lstm_fwd");
+}
+
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
                  void* out, float* hn, float* cn, void* gates, float* cs, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd: gates and cs go together");
-    LstmFwdArgs a{(const __bf16*)gx, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, cs, R, B};
-    static const size_t lds = (size_t)(2 * LBM * HSTR + LBM * GSTR) * sizeof(__bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((B + LBM - 1) / LBM, 2), dim3(256), lds, (hipStream_t)stream, a);
-    return check_launch("lstm_fwd");
+    LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, cs, R, B};
+    return lstm_fwd_launch(false, a, (hipStream_t)stream);
+}
+
+int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
+                      int I, void* out, float* hn, float* cn, void* gates, float* cs, dic_stream_t stream) {
+    DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: non-positive size");
+    DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: hidden size %d (compiled for %d)", H, LH);
+    DIC_REQUIRE(I == LXK, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: input width %d (compiled for %d: zero-pad narrower inputs)", I, LXK);
+    DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: NULL pointer");
+    DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd_proj: gates and cs go together");
+    LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, cs, R, B};
+    return lstm_fwd_launch(true, a, (hipStream_t)stream);
 }
 
 size_t dic_lstm_bwd_workspace(int B) { return B > 0 ? (size_t)((B + LBM - 1) / LBM) * 2 * 4 * LH * sizeof(float) : 0; }

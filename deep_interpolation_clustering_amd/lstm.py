@@ -7,7 +7,8 @@
 under bf16 autocast on the GPU:
 
   time-parallel GEMMs (hipBLASLt, bf16 in / f32 accumulate), issued here:
-      gx = X.W_ih^T + b_ih + b_hh            (R*B x I) . (I x 8H)
+      gx = X.W_ih^T + b_ih + b_hh            (R*B x I) . (I x 8H)     [I >= 32: decoder; the encoder's 18-wide
+                                                                       projection runs inside the recurrence kernel]
       dX = dG.W_ih,  dW_ih = dG^T.X,  dW_hh = dG^T.H_prev,  db = sum dG
   sequential recurrence (dic_lstm_fwd / dic_lstm_bwd): one workgroup per 64 batch rows and direction keeps
   h, c (dh, dc) on chip for all R steps with W_hh resident in registers.
@@ -21,6 +22,7 @@ from . import _native as N
 from .ops import splitk_tn
 
 H = 128
+PROJ_WIDTH = 32      # dic_lstm_fwd_proj's compiled input width
 
 
 def fused_available(x, lstm):
@@ -34,14 +36,21 @@ class _BiLstm(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, bias, h0, c0):
         R, B, I = x.shape
         bf = torch.bfloat16
-        Ip = (I + 15) // 16 * 16                                  # K of the projection GEMM padded to the MFMA step
+        proj = I < PROJ_WIDTH                                      # narrow input (encoder): projection inside the recurrence
+        Ip = PROJ_WIDTH if proj else (I + 15) // 16 * 16           # K of the projection padded to the MFMA step
         xb = x.to(bf)
         wihb = w_ih.reshape(8 * H, I).to(bf)
         if Ip != I:
             xb = torch.nn.functional.pad(xb, (0, Ip - I))
             wihb = torch.nn.functional.pad(wihb, (0, Ip - I))
         xb = xb.contiguous()
-        gx = torch.addmm(bias.reshape(8 * H).to(bf), xb.view(R * B, Ip), wihb.t())      # (R*B, 2*4*H)
+        if proj:
+            # the bias rides along as a constant-one input column (a spare one exists because I < 32); gx is never formed
+            xb[..., I].fill_(1.0)
+            wihb[:, I] = bias.reshape(8 * H).to(bf)
+            gx = None
+        else:
+            gx = torch.addmm(bias.reshape(8 * H).to(bf), xb.view(R * B, Ip), wihb.t())      # (R*B, 2*4*H)
         whhb = w_hh.to(bf).contiguous()                            # (2,4H,H)
         need = any(ctx.needs_input_grad)
         dev = x.device
@@ -53,8 +62,12 @@ class _BiLstm(torch.autograd.Function):
         cs = torch.empty((R, Bp, 2, H), device=dev, dtype=torch.float32) if need else None
         h0c = None if h0 is None else h0.float().contiguous()
         c0c = None if c0 is None else c0.float().contiguous()
-        N.check(N.lib().dic_lstm_fwd(N.ptr(gx), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
-                                     N.ptr(cn), N.ptr(gates), N.ptr(cs), N.stream_of(x)), 'dic_lstm_fwd')
+        if proj:
+            N.check(N.lib().dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wihb), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out),
+                                              N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), N.stream_of(x)), 'dic_lstm_fwd_proj')
+        else:
+            N.check(N.lib().dic_lstm_fwd(N.ptr(gx), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
+                                         N.ptr(cn), N.ptr(gates), N.ptr(cs), N.stream_of(x)), 'dic_lstm_fwd')
         ctx.dims = (R, B, I, Ip)
         ctx.x_dtype = x.dtype
         ctx.has_init = h0 is not None

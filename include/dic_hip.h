@@ -196,6 +196,12 @@ int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, 
  * dbias (2,4H) f32 or NULL = sum of dG over steps and batch rows (needs dic_lstm_bwd_workspace(B) bytes). */
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
                  void* out, float* hn, float* cn, void* gates, float* cs, dic_stream_t stream);
+/* Same recurrence with the input projection computed in-kernel, for narrow inputs (the encoder's 3C channels):
+ * G_t = x_t.wih^T + h_{t-1}.whh^T with x (R,B,I) bf16 and wih (2,4H,I) bf16, I == 32 (zero-pad narrower inputs; fold
+ * the bias in as a constant-one input column whose weights are b_ih + b_hh).  Everything else as dic_lstm_fwd; the
+ * backward is dic_lstm_bwd unchanged. */
+int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
+                      int I, void* out, float* hn, float* cn, void* gates, float* cs, dic_stream_t stream);
 size_t dic_lstm_bwd_workspace(int B);
 int dic_lstm_bwd(const void* whh_t, const void* gates, const float* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
