@@ -44,6 +44,7 @@ def parse():
                    help='bf16: autocast for the bi-LSTMs / FC heads (HIP kernels stay f32)')
     p.add_argument('--graph', action='store_true', help='capture the step in a hipGraph (pays off for small --batch)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-tuned-gemm', action='store_true', help='library GEMMs with the default heuristics instead of the shipped table')
     p.add_argument('--cpu-seconds', type=float, default=15.0)
     p.add_argument('--kernel-iters', type=int, default=20)
     return p.parse_args()
@@ -200,6 +201,8 @@ def main():
     torch.cuda.set_device(dev)
     K = a.clusters or (8 if world == 8 else 4)
     args = make_args(K)
+    from deep_interpolation_clustering_amd import tuned
+    gemm_table = (not a.no_tuned_gemm) and a.dtype == 'bf16' and tuned.enable()      # read-only: pre-tuned hipBLASLt / rocBLAS picks
 
     # ---- cohort shard, resident in HBM before anything is timed
     n_enc = max(a.encounters, a.batch)
@@ -262,7 +265,8 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'{n_enc} synthetic encounters/GPU, 6 vitals, ~50 irregular samples per channel per 24h '
                                    f'(T={T}), R={R}, K={K}, loss ae_mse+10*kl', 'per_gpu_batch': a.batch,
-                       'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single'},
+                       'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'tuned_gemm_table': bool(gemm_table)},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': table[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': table[dom]['frac_hbm_peak'], 'traffic': traffic},
             'kernels': table,

@@ -34,6 +34,9 @@ class TrainerBase(object):
         self.args, self.device = args, device
         self.model = model.to(device)
         autocast = torch.bfloat16 if (getattr(args, 'amp_bf16', False) and device.type == 'cuda') else None
+        if autocast is not None:
+            from . import tuned
+            tuned.enable()                       # pre-tuned library GEMM picks for the step's shapes (read-only; tuned.py)
         self.stepper = Stepper(self.model, lambda m: pytorch_optimizer(m, args.optimizer, args.init_lr, args.weight_decay_rate),
                                args, autocast_dtype=autocast, use_graphs=getattr(args, 'hip_graph', False))
         self.optimizer = self.stepper.optimizer
