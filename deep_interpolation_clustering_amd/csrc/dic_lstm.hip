@@ -64,7 +64,7 @@ struct LstmFwdArgs {
     __bf16* out;           // (R,B,2H): forward direction in [:H], reverse in [H:]
     float* hn; float* cn;  // (2,B,H)
     __bf16* gates;         // lane-native (R,Bpad,2,4,H) post-activation i,f,g,o, or NULL (inference)
-    float* cs;             // lane-native (R,Bpad,2,H) cell states, or NULL
+    __bf16* cs;            // lane-native (R,Bpad,2,H) cell states rounded to bf16 (the recurrence itself carries c in f32), or NULL
     int R, B;
 };
 
@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                     *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r)) = fb;
                     *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r)) = gb;
                     *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r)) = ob;
-                    *reinterpret_cast<f32x4*>(a.cs + native_off(t, nbt, bt, dir, w, 1, 0, q, hh, r)) = cv;
+                    bf16x4 cb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cb[j] = (__bf16)cv[j];
+                    *reinterpret_cast<bf16x4*>(a.cs + native_off(t, nbt, bt, dir, w, 1, 0, q, hh, r)) = cb;
                 }
                 if (ok) {
                     const size_t row = (size_t)t * B + b;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
 struct LstmBwdArgs {
     const __bf16* whh_t;   // (2,H,4H): whh_t[d][u][n] = whh[d][n][u]
     const __bf16* gates;   // lane-native, as written by lstm_fwd_kernel
-    const float* cs;       // lane-native
+    const __bf16* cs;      // lane-native, bf16
     const float* c0;       // (2,B,H) or NULL
     const __bf16* dout;    // (R,B,2H) or NULL
     const float* dhn; const float* dcn;   // (2,B,H) or NULL
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 
     // Software pipeline: the saved gates / c_prev / dout of step s+1 are requested while step s runs its LDS,
     // store and MFMA phases (one workgroup per CU: nothing else would hide the HBM latency).
-    struct StepIn { bf16x4 ib, fb, gb, ob, go; f32x4 cp; };
+    struct StepIn { bf16x4 ib, fb, gb, ob, go, cp; };
     StepIn cur[LNB][4], nxt[LNB][4];
     auto load_step = [&](int step, StepIn (&dst)[LNB][4]) {
         const int t = dir ? step : R - 1 - step;           // reverse of the forward visiting order
@@ -311,9 +314,13 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                 d.fb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
                 d.gb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
                 d.ob = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
-                f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-                if (!first_fwd) cp = *reinterpret_cast<const f32x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
-                else if (a.c0) cp = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + b) * LH + u);
+                bf16x4 cp = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
+                else if (a.c0) {
+                    const f32x4 c0v = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + b) * LH + u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cp[j] = (__bf16)c0v[j];
+                }
                 d.cp = cp;
                 bf16x4 go = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
                 if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + u);
@@ -327,9 +334,9 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         for (int nb = 0; nb < LNB; ++nb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 ct = *reinterpret_cast<const f32x4*>(a.cs + native_off(t0, nbt, blockIdx.x * LNB + nb, dir, w, 1, 0, q, hh, r));
+                const bf16x4 ct = *reinterpret_cast<const bf16x4*>(a.cs + native_off(t0, nbt, blockIdx.x * LNB + nb, dir, w, 1, 0, q, hh, r));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ccar[nb][4 * q + j] = ct[j];
+                for (int j = 0; j < 4; ++j) ccar[nb][4 * q + j] = (float)ct[j];
             }
         load_step(0, cur);
     }
@@ -350,11 +357,11 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                     const float dht = dh[nb][k] + (float)in.go[j];
                     const float tc = tanh_fast(ccar[nb][k]);
                     const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
-                    const float vi = dct * gg * ig * (1.0f - ig), vf = dct * in.cp[j] * fg * (1.0f - fg);
+                    const float vi = dct * gg * ig * (1.0f - ig), vf = dct * (float)in.cp[j] * fg * (1.0f - fg);
                     const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
                     di[j] = (__bf16)vi; df[j] = (__bf16)vf; dg[j] = (__bf16)vg; dO[j] = (__bf16)vo;
                     dc[nb][k] = dct * fg;
-                    ccar[nb][k] = in.cp[j];                 // this step's c_prev is the next visited step's c
+                    ccar[nb][k] = (float)in.cp[j];                 // this step's c_prev is the next visited step's c
                 }
                 __bf16* lp = dgt + (nb * 32 + r) * GSTR + u;
                 *reinterpret_cast<bf16x4*>(lp) = di;
@@ -450,29 +457,29 @@ static int lstm_fwd_launch(bool proj, const LstmFwdArgs& a, hipStream_t st) {
 }
 
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                 void* out, float* hn, float* cn, void* gates, float* cs, dic_stream_t stream) {
+                 void* out, float* hn, float* cn, void* gates, void* cs, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd: gates and cs go together");
-    LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, cs, R, B};
+    LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B};
     return lstm_fwd_launch(false, a, (hipStream_t)stream);
 }
 
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                      int I, void* out, float* hn, float* cn, void* gates, float* cs, dic_stream_t stream) {
+                      int I, void* out, float* hn, float* cn, void* gates, void* cs, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(I == LXK, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: input width %d (compiled for %d: zero-pad narrower inputs)", I, LXK);
     DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd_proj: gates and cs go together");
-    LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, cs, R, B};
+    LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B};
     return lstm_fwd_launch(true, a, (hipStream_t)stream);
 }
 
 size_t dic_lstm_bwd_workspace(int B) { return B > 0 ? (size_t)((B + LBM - 1) / LBM) * 2 * 4 * LH * sizeof(float) : 0; }
 
-int dic_lstm_bwd(const void* whh_t, const void* gates, const float* cs, const float* c0, const void* dout,
+int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
                  float* dbias, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_bwd: non-positive size");
@@ -488,7 +495,7 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const float* cs, const fl
     const int nwg = (B + LBM - 1) / LBM;
     DIC_REQUIRE(!dbias || (workspace && workspace_bytes >= dic_lstm_bwd_workspace(B)), DIC_ERR_WORKSPACE,
                 "lstm_bwd: dbias needs %zu B of workspace", dic_lstm_bwd_workspace(B));
-    LstmBwdArgs a{(const __bf16*)whh_t, (const __bf16*)gates, cs, c0, (const __bf16*)dout, dhn, dcn, (__bf16*)dgx, dh0, dc0,
+    LstmBwdArgs a{(const __bf16*)whh_t, (const __bf16*)gates, (const __bf16*)cs, c0, (const __bf16*)dout, dhn, dcn, (__bf16*)dgx, dh0, dc0,
                   dbias ? (float*)workspace : nullptr, R, B};
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nwg, 2), dim3(256), lds, (hipStream_t)stream, a);
     if (dbias)

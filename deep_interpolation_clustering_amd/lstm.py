@@ -59,7 +59,7 @@ class _BiLstm(torch.autograd.Function):
         cn = torch.empty_like(hn)
         Bp = (B + 63) // 64 * 64                                   # kernel-native saved state is tiled by 64 rows
         gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=bf) if need else None
-        cs = torch.empty((R, Bp, 2, H), device=dev, dtype=torch.float32) if need else None
+        cs = torch.empty((R, Bp, 2, H), device=dev, dtype=bf) if need else None    # bf16 copy for the backward; c itself stays f32 on chip
         h0c = None if h0 is None else h0.float().contiguous()
         c0c = None if c0 is None else c0.float().contiguous()
         if proj:
