@@ -103,11 +103,11 @@ class _BiLstm(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             # dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d], h_prev = h_{t-1} (forward) / h_{t+1} (reverse): shifted strided views
             # of dG and out, one direction at a time -- no H_prev copy and none of the cross-direction blocks a single
-            # (8H, 2H) product would compute (0.54 ms against 0.82 at R*B = 786k, scripts/gemm_probe2.py)
+            # (8H, 2H) product would compute (0.42 ms against 0.82 at R*B = 786k, scripts/gemm_probe2.py / gemm_probe3.py)
             o2 = out.view(R * B, 2 * H)
             if R > 1:
-                fwd = splitk_tn(dg2[B:, :4 * H], o2[:-B, :H], chunks=(4096, 8192, 2048))
-                rev = splitk_tn(dg2[:-B, 4 * H:], o2[B:, H:], chunks=(4096, 8192, 2048))
+                fwd = splitk_tn(dg2[B:, :4 * H], o2[:-B, :H], chunks=(8192, 4096, 2048))
+                rev = splitk_tn(dg2[:-B, 4 * H:], o2[B:, H:], chunks=(8192, 4096, 2048))
             else:
                 fwd = rev = torch.zeros((4 * H, H), device=dev, dtype=torch.float32)
             if h0c is not None:
