@@ -44,15 +44,19 @@ def parse():
                    help='bf16: autocast for the bi-LSTMs / FC heads (HIP kernels stay f32)')
     p.add_argument('--graph', action='store_true', help='capture the step in a hipGraph (pays off for small --batch)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--fake-detection', action='store_true',
+                   help="upstream's default unsupervised loss ae_mse_fake_detect_kl (p3:78 minus the private supervised labels): "
+                        "sci/cci/encoder run a second time on corrupted samples; NOT the headline configuration")
     p.add_argument('--no-tuned-gemm', action='store_true', help='library GEMMs with the default heuristics instead of the shipped table')
     p.add_argument('--cpu-seconds', type=float, default=15.0)
     p.add_argument('--kernel-iters', type=int, default=20)
     return p.parse_args()
 
 
-def make_args(K):
+def make_args(K, fake_detection=False):
     return SimpleNamespace(num_variables=C, num_timestamps=T, ref_points=R, hours_from_admission=H, dropout=0.0,
-                           aux_tasks={}, fake_detection=False, triple_margin=0.0, cluster_number=K, loss='ae_mse_kl',
+                           aux_tasks={}, fake_detection=fake_detection, triple_margin=0.0, cluster_number=K,
+                           loss='ae_mse_fake_detect_kl' if fake_detection else 'ae_mse_kl',
                            grad_clip=15.0, unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.},
                            aux_pos_weights={})
 
@@ -205,7 +209,7 @@ def main():
     dev = torch.device('cuda', local % torch.cuda.device_count())       # (ranks may share a GPU under DIC_DIST_BACKEND=gloo)
     torch.cuda.set_device(dev)
     K = a.clusters or (8 if world == 8 else 4)
-    args = make_args(K)
+    args = make_args(K, a.fake_detection)
     from deep_interpolation_clustering_amd import tuned
     gemm_table = (not a.no_tuned_gemm) and a.dtype == 'bf16' and tuned.enable()      # read-only: pre-tuned hipBLASLt / rocBLAS picks
 
@@ -224,9 +228,22 @@ def main():
     stepper = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args,
                       autocast_dtype=torch.bfloat16 if a.dtype == 'bf16' else None, use_graphs=a.graph)
 
+    XF = label2 = None
+    if a.fake_detection:          # corrupted copies as dataloader.py:182-193 makes them (half of each channel's samples -> noise)
+        g = torch.Generator(device=dev).manual_seed(5 + rank)
+        XF = X.clone()
+        m = X[:, C:2 * C] > 0
+        hit = m & (torch.rand(m.shape, device=dev, generator=g) < 0.5)
+        XF[:, :C] = torch.where(hit, torch.rand(m.shape, device=dev, generator=g) * 5.0 - 2.5, X[:, :C])
+        label2 = torch.cat([torch.ones(a.batch, device=dev), torch.zeros(a.batch, device=dev)])
+
     def one_step(i):
         lo = (i % nb) * a.batch
-        return stepper.step(X[lo:lo + a.batch], OB[lo:lo + a.batch], None, LEN[lo:lo + a.batch])
+        if XF is None:
+            return stepper.step(X[lo:lo + a.batch], OB[lo:lo + a.batch], None, LEN[lo:lo + a.batch])
+        perm = torch.randperm(2 * a.batch, device=dev)                       # as the trainers draw it (pretrain_trainer.py:156-160)
+        return stepper.step(X[lo:lo + a.batch], OB[lo:lo + a.batch], None, LEN[lo:lo + a.batch], fake_x=XF[lo:lo + a.batch],
+                            fake_perm_idx=perm, fake_det_label=label2[perm].to(torch.int64))
 
     def barrier():
         if world > 1:
@@ -269,7 +286,7 @@ def main():
             'dtype': a.dtype, 'dtype_note': 'HIP kernels compute in f32; bf16 = torch.autocast for the bi-LSTMs / FC heads only',
             'data': 'synthetic',
             'config': {'workload': f'{n_enc} synthetic encounters/GPU, 6 vitals, ~50 irregular samples per channel per 24h '
-                                   f'(T={T}), R={R}, K={K}, loss ae_mse+10*kl', 'per_gpu_batch': a.batch,
+                                   f'(T={T}), R={R}, K={K}, loss ' + ('ae_mse+fake_detect+10*kl' if a.fake_detection else 'ae_mse+10*kl'), 'per_gpu_batch': a.batch,
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single',
                        'tuned_gemm_table': bool(gemm_table)},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': table[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
