@@ -94,10 +94,14 @@ class FlatParams:
         the sum (not the mean) of rank gradients is the gradient of the global-batch loss."""
         all_reduce_sum_(self.grad)
 
-    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
-        """torch.nn.utils.clip_grad_norm_ semantics (pretrain_trainer.py:228) on the flat bucket."""
+    def clip_coef(self, max_norm: float):
+        """(total norm, clip coefficient) of torch.nn.utils.clip_grad_norm_ (pretrain_trainer.py:228), both on the device."""
         total = torch.linalg.vector_norm(self.grad)
-        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        return total, torch.clamp(max_norm / (total + 1e-6), max=1.0)
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_ semantics on the flat bucket."""
+        total, coef = self.clip_coef(max_norm)
         self.grad.mul_(coef)
         return total
 

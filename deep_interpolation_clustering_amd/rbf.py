@@ -26,9 +26,10 @@ class CompressFC(nn.Module):
             return self.model(rec_input)
         # bf16 step: the C-wide output layer over all B*R rows is a 100 MB stream, not a GEMM (csrc/dic_head.hip)
         first = self.model[0]
-        with torch.autocast('cuda', enabled=False):
-            z = ops.rows_linear(rec_input, first.weight, first.bias)           # split-K weight gradient
         bn, drop = self.model[1], self.model[3]
+        with torch.autocast('cuda', enabled=False):
+            # split-K weight gradient; the bias sits in front of BatchNorm: its gradient is identically 0 in training mode
+            z = ops.rows_linear(rec_input, first.weight, first.bias, bias_grad_is_zero=bn.training)
         if last.out_features in ops.BNHEAD_OUT and not (drop.training and drop.p > 0):
             # BatchNorm -> ReLU -> Linear in four streaming passes over z, the hidden activation never materialised
             with torch.autocast('cuda', enabled=False):

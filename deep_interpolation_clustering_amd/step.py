@@ -50,6 +50,9 @@ class Stepper:
         self.flat = dist.FlatParams(model)          # must precede the optimizer: it re-homes parameter storage
         self.flat.broadcast_(0)
         self.optimizer = optimizer_factory(model)
+        self._fused_tail = hasattr(self.optimizer, 'bind')       # flat_adam.FlatAdam: clip scale + Adam in one kernel
+        if self._fused_tail:
+            self.optimizer.bind(self.flat)
         self.autocast_dtype = autocast_dtype
         # hipGraph capture of the whole step (single-GPU): at the reference's batch size (256) the ~250 launches of a
         # step are launch-bound (2.5 ms); one graph replay runs them back to back.
@@ -131,6 +134,10 @@ class Stepper:
         losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
         losses['loss'].backward()
         self.flat.all_reduce_grads()
-        gnorm = self.flat.clip_grad_norm_(self.args.grad_clip)
-        self.optimizer.step()
+        if self._fused_tail:
+            gnorm, coef = self.flat.clip_coef(self.args.grad_clip)
+            self.optimizer.step(grad_scale=coef)
+        else:
+            gnorm = self.flat.clip_grad_norm_(self.args.grad_clip)
+            self.optimizer.step()
         return losses, gnorm, hidden

@@ -77,18 +77,19 @@ def count_parameters(model):
 
 
 def pytorch_optimizer(model, optimizer, init_lr, weight_decay=0):
-    """utils.py:76-83.  Adam is amsgrad with L2 weight decay; on a GPU the fused single-launch
-    implementation is used (same update rule, same state_dict layout)."""
+    """utils.py:76-83.  Adam is amsgrad with L2 weight decay; on a GPU it is flat_adam.FlatAdam (same update rule,
+    same state_dict layout, one kernel)."""
     params = list(model.parameters())
     if optimizer == 'SGD':
         return optim.SGD(params, lr=init_lr, momentum=0.9, weight_decay=weight_decay, nesterov=True)
     if optimizer == 'RMSprop':
         return optim.RMSprop(params, lr=init_lr, momentum=0.9, weight_decay=weight_decay)
     if optimizer == 'Adam':
-        fused = bool(params) and all(p.is_cuda for p in params)
-        # capturable: the optimizer state lives on the device, so a whole step can be captured in a hipGraph
-        return optim.Adam(params, lr=init_lr, weight_decay=weight_decay, amsgrad=True, fused=fused or None,
-                          capturable=fused)
+        if bool(params) and all(p.is_cuda for p in params):
+            # one HIP kernel over the flat parameter bucket (clip scale + amsgrad update); state_dict-compatible with optim.Adam
+            from .flat_adam import FlatAdam
+            return FlatAdam(params, lr=init_lr, weight_decay=weight_decay)
+        return optim.Adam(params, lr=init_lr, weight_decay=weight_decay, amsgrad=True)
     raise ValueError('unknown optimizer {}'.format(optimizer))
 
 
