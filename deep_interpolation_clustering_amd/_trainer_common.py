@@ -127,7 +127,7 @@ class TrainerBase(object):
                 sums[k] = sums[k] + v.detach()
             n_batches += 1
             if i_batch % int(self.args.log_train_freq) == 1:
-                now = {k: float(v) for k, v in losses.items()}          # the only host sync, at the logging cadence
+                now = {k: float(v.detach()) for k, v in losses.items()}  # the only host sync, at the logging cadence
                 logger.info('{}-[{}/{} ({:.0f}%)]: train-{}'.format(self.epoch, i_batch, total, 100. * i_batch / total, now))
                 self.summary.add_summary(self.epoch * total + i_batch, scope='train_batch', **now)
         out = {'scope': 'train'}
