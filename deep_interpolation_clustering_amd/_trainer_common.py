@@ -65,6 +65,20 @@ class TrainerBase(object):
     def _get_dl(self, cohort):
         return {'training': self.train_dl, 'validation': self.valid_dl, 'testing': self.test_dl}.get(cohort)
 
+    def _eval_dl(self, cohort):
+        """Loader for evaluation / feature passes.  When the training loader is sharded over ranks (one process per GPU),
+        feature dumps, the k-means initialisation and label-change statistics still need EVERY encounter on every rank: an
+        unsharded, unshuffled loader over the same device-resident cohort is used instead (identical work and results on all
+        ranks, so the collectives inside the loss operators stay matched)."""
+        dl = self._get_dl(cohort)
+        if getattr(dl, 'world', 1) > 1:
+            cache = self.__dict__.setdefault('_full_loaders', {})
+            if cohort not in cache:
+                from .dataloader import DeviceLoader
+                cache[cohort] = DeviceLoader(dl.ds, dl.batch_size, False, dl.device, seed=0, shard=False)
+            return cache[cohort]
+        return dl
+
     def _to_device(self, sample):
         return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in sample.items()}
 
@@ -211,6 +225,7 @@ class TrainerBase(object):
 
     def load_weight(self):
         metric = getattr(self.args, self.restore_attr)
+        dist.barrier()                              # rank 0 has finished writing the checkpoint every rank is about to read
         logger.info('*******Restoring the model weight based on {}*******'.format(metric))
         checkpoint = torch.load(self._restore_file(), map_location=self.device)     # upstream hard-codes cuda:0
         self.epoch = checkpoint['epoch']
@@ -222,7 +237,7 @@ class TrainerBase(object):
         logger.info('*******Evaluating the model*******')
         self.load_weight()
         scope = COHORT2SCOPE[cohort]
-        metrics, ob_pred_lst = self.eval_one_epoch(scope, self._get_dl(cohort), denoise)
+        metrics, ob_pred_lst = self.eval_one_epoch(scope, self._eval_dl(cohort), denoise)
         logger.info('{}, {}'.format(scope, format_metric_dict(metrics)))
         ob_pred_dict = self.re_norm_data(self.merge_ob_pred(ob_pred_lst))
         if generate_feat and dist.rank() == 0:

@@ -11,6 +11,7 @@ import os
 import numpy as np
 import torch
 
+from . import dist
 from ._trainer_common import TrainerBase
 from .info import COHORT2SCOPE
 from .kmeans import KMeans
@@ -33,6 +34,7 @@ class TrainerCluster(TrainerBase):
         """Warm start from the p1 checkpoint; only keys this model has are taken (clustering_trainer.py:431-447)."""
         logger.info('*******Restoring the pretrain model weight based on {}*******'.format(self.args.restore_metric))
         f = os.path.join(self.pretrain_exp_path, 'weight', '{}'.format(self.args.restore_metric), 'model.pth.tar')
+        dist.barrier()
         pretrained = torch.load(f, map_location=self.device)['state_dict']
         own = self.model.state_dict()
         # a checkpoint written through nn.DataParallel upstream carries a 'module.' prefix: accept both
@@ -45,7 +47,7 @@ class TrainerCluster(TrainerBase):
 
     def _latents(self, cohort, denoise=False):
         """Feature pass that keeps the latents on the device: (hidden (N,256) cuda tensor, metrics)."""
-        metrics, recs = self.eval_one_epoch(COHORT2SCOPE[cohort], self._get_dl(cohort), denoise)
+        metrics, recs = self.eval_one_epoch(COHORT2SCOPE[cohort], self._eval_dl(cohort), denoise)    # all encounters on every rank
         logger.info('{}, {}'.format(COHORT2SCOPE[cohort], format_metric_dict(metrics)))
         return torch.cat([r['hidden'].float() for r in recs], dim=0), recs
 

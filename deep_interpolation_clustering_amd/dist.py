@@ -33,6 +33,12 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def barrier():
+    """Rank barrier (no-op when not sharded): rank 0 writes checkpoints / feature files that the other ranks read."""
+    if is_sharded():
+        td.barrier()
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun-style env vars (RANK, WORLD_SIZE,
     LOCAL_RANK, MASTER_ADDR, MASTER_PORT).  Returns (rank, world_size, local_rank)."""

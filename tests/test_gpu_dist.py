@@ -66,3 +66,51 @@ def test_two_rank_step_equals_single_device(tmp_path):
     np.testing.assert_allclose(r0['bn_mean'].numpy(), one['bn_mean'].numpy(), rtol=1e-3, atol=1e-4)   # global-batch BatchNorm moments
     d = (r0['flat'] - one['flat']).abs()
     assert float(d.max()) < 2e-2 and float((d > 1e-4).float().mean()) < 0.01        # Adam amplifies noise only where grad ~ 0
+
+
+COMMON = ['--hours_from_admission', '24', '--ref_points', '24', '--num_timestamps', '96', '--batch_size', '128',
+          '--dropout', '0', '--no_aux', '--no_fake', '--amp_bf16', '--log-level', 'WARNING', '--seed', '11']
+
+
+def _run_drivers(rank, world, port, base):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      DIC_DIST_BACKEND='gloo')
+    from deep_interpolation_clustering_amd import dataloader
+    from deep_interpolation_clustering_amd import p1_pretrain_main as p1, p3_clustering_main as p3
+    run = os.path.join(base, 'run')
+    os.makedirs(run, exist_ok=True)
+    os.chdir(run)
+    dataloader.BASE_PATH = base
+    p1.main(p1.get_arguments(COMMON + ['--mode', 'train', '--max_epochs', '3', '--loss', 'ae_mse']))
+    a3 = p3.get_arguments(COMMON + ['--mode', 'train', '--max_epochs', '3', '--loss', 'ae_mse_kl', '--cluster_number', '4'])
+    # capture this rank's final replica before the evaluation passes reload checkpoints
+    from deep_interpolation_clustering_amd import clustering_trainer as ct
+    orig = ct.TrainerCluster.train
+
+    def train_and_dump(self):
+        orig(self)
+        torch.save({'flat': self.stepper.flat.flat.detach().cpu(), 'centers': self.model.get_cluster_center().detach().cpu()},
+                   os.path.join(base, f'replica_r{rank}.pt'))
+    ct.TrainerCluster.train = train_and_dump
+    p3.main(a3)
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+def test_two_rank_drivers_keep_replicas_identical_and_dump_every_encounter(tmp_path):
+    """p1 -> p3 under two ranks (sharded training batches): k-means initialisation, label-change early stopping and the
+    feature dumps must see ALL encounters on every rank, or the replicas diverge / the dumps lose rows."""
+    sys.path.insert(0, ROOT)
+    from deep_interpolation_clustering_amd import synthetic
+    base = str(tmp_path)
+    synthetic.write_split(base, 500, C=6, T=96, H=24.0, lam=50.0, G=4)
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_run_drivers, args=(2, port, base), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(base, f'replica_r{r}.pt'), weights_only=False) for r in (0, 1))
+    assert torch.equal(r0['flat'], r1['flat']) and torch.equal(r0['centers'], r1['centers'])
+    assert float(r0['centers'].abs().sum()) > 0
+    feat = np.load(os.path.join(base, 'run/Results/Clustering/out_feat/ae_mse/training.npy'), allow_pickle=True).item()
+    assert feat['hidden'].shape == (400, 256) and len(set(feat['encounter_id'].tolist())) == 400
+    pre = np.load(os.path.join(base, 'run/Results/Pretrain/out_feat/ae_mse/training.npy'), allow_pickle=True).item()
+    assert pre['hidden'].shape == (400, 256)
