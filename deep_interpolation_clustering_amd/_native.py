@@ -53,6 +53,9 @@ SIGNATURES = {
     'dic_dec_kl': (_i, [_p, _p, _i, _i, _f, _f, _p, _p, _p, _sz, _p]),
     'dic_kmeans_workspace': (_sz, [_i, _i, _i, _i]),
     'dic_kmeans_lloyd_iter': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    'dic_kmeans_stats_words': (_sz, [_i, _i]),
+    'dic_kmeans_lloyd_partial': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    'dic_kmeans_lloyd_finish': (_i, [_i, _i, _i, _p, _p, _p, _p]),
     'dic_kmeans_predict': (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     'dic_lstm_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     'dic_lstm_fwd_proj': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),

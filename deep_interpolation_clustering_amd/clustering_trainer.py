@@ -75,7 +75,7 @@ class TrainerCluster(TrainerBase):
         if args.init_cluster_center == 'kmeans':
             self.load_pretrain_weight()
             train_hidden, _ = self._latents('training')
-            kmeans = KMeans(n_clusters=args.cluster_number, n_init=20)
+            kmeans = KMeans(n_clusters=args.cluster_number, n_init=20, shard_points=True)   # rows sharded over ranks when there are several
             kmeans.fit(train_hidden)                                            # clustering_trainer.py:75-76
             self.init_cluster_center(torch.tensor(kmeans.cluster_centers_, dtype=torch.float, device=self.device))
             valid_hidden, _ = self._latents('validation')

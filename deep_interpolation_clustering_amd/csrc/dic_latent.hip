@@ -470,6 +470,81 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* X, int 
     }
 }
 
+// ---- Lloyd with the points sharded over ranks (one process per GPU): stage A stops at per-rank partial statistics,
+// the caller sums them over ranks (RCCL all-reduce of one f64 buffer), stage B finishes the iteration identically on every
+// rank.  stats[run] = [ sums (K*D) | counts (K) | #labels changed (1) ] in f64.
+__global__ __launch_bounds__(256) void kmeans_pack_counts_kernel(const int* pcnt_all, int nblk, int K, int D, const float* status_all,
+                                                                double* stats_all) {
+    __shared__ double red[256];
+    const int run = blockIdx.x, tid = threadIdx.x;
+    if (status_all[run * DIC_KM_STATUS_WORDS] != 0.f) return;
+    const int* pc = pcnt_all + (size_t)run * nblk * (K + 1);
+    double* out = stats_all + (size_t)run * ((size_t)K * D + K + 1) + (size_t)K * D;
+    for (int i0 = 0; i0 < K + 1; i0 += 32) {                     // K + 1 <= 33 outputs: at most two passes
+        const double c = reduce_partials_32x8(pc, nblk, K + 1, i0, red);
+        if (tid < 32 && i0 + tid < K + 1) out[i0 + tid] = c;
+        __syncthreads();
+    }
+}
+
+// stage B on globally summed statistics: averaging (with scikit-learn's in-place quirk for a still-empty cluster), centre
+// shift, convergence -- the tail of kmeans_update_kernel.  An EMPTY cluster cannot be relocated here (the farthest point
+// may live on another rank): the run is halted with status[0] = 2 and the caller re-runs it unsharded.
+__global__ __launch_bounds__(256) void kmeans_finish_kernel(int D, int K, const double* stats_all, float* centers_all, float* status_all) {
+    __shared__ float cntf[DIC_MAX_CLUSTERS];
+    __shared__ float redv[256];
+    __shared__ float shift2[DIC_MAX_CLUSTERS];
+    __shared__ int s_empty;
+    const int run = blockIdx.x, tid = threadIdx.x;
+    float* status = status_all + run * DIC_KM_STATUS_WORDS;
+    if (status[0] != 0.f) return;
+    const double* stats = stats_all + (size_t)run * ((size_t)K * D + K + 1);
+    const double* sums = stats;
+    float* centers = centers_all + (size_t)run * K * D;
+    if (tid == 0) s_empty = 0;
+    __syncthreads();
+    if (tid < K) {
+        cntf[tid] = (float)stats[(size_t)K * D + tid];
+        if (cntf[tid] == 0.f) s_empty = 1;
+    }
+    __syncthreads();
+    if (s_empty) {
+        if (tid == 0) status[0] = 2.f;
+        return;
+    }
+    const int changed = (int)stats[(size_t)K * D + K];
+    float ss_local[DIC_MAX_CLUSTERS];
+    if (tid < D) {
+        for (int k = 0; k < K; ++k) {
+            const float nc = (float)sums[(size_t)k * D + tid] * (1.0f / cntf[k]);
+            const float dlt = nc - centers[(size_t)k * D + tid];
+            ss_local[k] = dlt * dlt;
+            centers[(size_t)k * D + tid] = nc;
+        }
+    } else {
+        for (int k = 0; k < K; ++k) ss_local[k] = 0.f;
+    }
+    for (int k = 0; k < K; ++k) {
+        redv[tid] = ss_local[k];
+        __syncthreads();
+        for (int st = 128; st >= 1; st >>= 1) {
+            if (tid < st) redv[tid] += redv[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) shift2[k] = redv[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < K; ++k) { const float sh = sqrtf(shift2[k]); tot += sh * sh; }
+        const float iters = status[1] + 1.f;
+        status[1] = iters; status[2] = tot; status[3] = (float)changed;
+        if (changed == 0) { status[4] = 1.f; status[0] = 1.f; }
+        else if (tot <= status[6]) status[0] = 1.f;
+        if (iters >= status[7]) status[0] = 1.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void inertia_kernel(const float* mind_all, int N, float* inertia) {
     __shared__ double red[4];
     const int run = blockIdx.x;
@@ -644,6 +719,44 @@ int dic_kmeans_lloyd_iter(const float* X, const float* xnorm, int N, int D, int 
     hipLaunchKernelGGL(kmeans_update_kernel, dim3(n_runs), dim3(256), 0, st, X, N, D, K, nblk, (const int*)pcnt,
                        (const int*)pchg, sums, mind, (const int32_t*)labels, centers, status);
     return check_launch("kmeans_lloyd_iter");
+}
+
+size_t dic_kmeans_stats_words(int D, int K) { return (D > 0 && K > 0) ? (size_t)K * D + K + 1 : 0; }
+
+int dic_kmeans_lloyd_partial(const float* X, const float* xnorm, int N, int D, int K, int n_runs, const float* centers,
+                             int32_t* labels, const float* status, double* stats, void* workspace, size_t workspace_bytes,
+                             dic_stream_t stream) {
+    int rc = latent_check("kmeans_lloyd_partial", N, D, K);
+    if (rc) return rc;
+    DIC_REQUIRE(n_runs > 0 && n_runs <= 65535, DIC_ERR_INVALID_ARG, "kmeans_lloyd_partial: n_runs=%d", n_runs);
+    DIC_REQUIRE(X && xnorm && centers && labels && status && stats && workspace, DIC_ERR_INVALID_ARG, "kmeans_lloyd_partial: NULL pointer");
+    const int nblk = km_blocks(N);
+    const KmWs w = km_ws(N, D, K, n_runs, nblk);
+    DIC_REQUIRE(workspace_bytes >= w.total, DIC_ERR_WORKSPACE, "kmeans_lloyd_partial: workspace %zu < %zu", workspace_bytes, w.total);
+    char* ws = (char*)workspace;
+    float* psum = (float*)(ws + w.psum); int* pcnt = (int*)(ws + w.pcnt); int* pchg = (int*)(ws + w.pchg);
+    double* sums = (double*)(ws + w.sums); float* mind = (float*)(ws + w.mind);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t words = dic_kmeans_stats_words(D, K);
+    DIC_DISPATCH_KP(pad_k(K), hipLaunchKernelGGL((kmeans_assign_kernel<KP, true>), dim3(nblk, n_runs), dim3(kLatBlock), 0, st, X,
+                                                 xnorm, N, D, K, centers, labels, status, mind, psum, pcnt, pchg));
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((K * D + 31) / 32, n_runs), dim3(256), 0, st, (const float*)psum, nblk, K, D,
+                       status, sums);
+    // sums -> the head of each run's stats record (strided device copy), counts / #changed behind them
+    hipError_t e = hipMemcpy2DAsync(stats, words * sizeof(double), sums, (size_t)K * D * sizeof(double), (size_t)K * D * sizeof(double),
+                                    (size_t)n_runs, hipMemcpyDeviceToDevice, st);
+    DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "kmeans_lloyd_partial: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kmeans_pack_counts_kernel, dim3(n_runs), dim3(256), 0, st, (const int*)pcnt, nblk, K, D, status, stats);
+    return check_launch("kmeans_lloyd_partial");
+}
+
+int dic_kmeans_lloyd_finish(int D, int K, int n_runs, const double* stats, float* centers, float* status, dic_stream_t stream) {
+    DIC_REQUIRE(D > 0 && D <= DIC_LATENT_MAX_DIM && D % 4 == 0 && K > 0 && K <= DIC_MAX_CLUSTERS, DIC_ERR_UNSUPPORTED,
+                "kmeans_lloyd_finish: D=%d K=%d", D, K);
+    DIC_REQUIRE(n_runs > 0 && n_runs <= 65535, DIC_ERR_INVALID_ARG, "kmeans_lloyd_finish: n_runs=%d", n_runs);
+    DIC_REQUIRE(stats && centers && status, DIC_ERR_INVALID_ARG, "kmeans_lloyd_finish: NULL pointer");
+    hipLaunchKernelGGL(kmeans_finish_kernel, dim3(n_runs), dim3(256), 0, (hipStream_t)stream, D, K, stats, centers, status);
+    return check_launch("kmeans_lloyd_finish");
 }
 
 int dic_kmeans_predict(const float* X, int N, int D, int K, int n_runs, const float* centers, int32_t* labels,

@@ -83,6 +83,59 @@ def lloyd(X, xnorm, centers, tol, max_iter):
     return labels, inertia, status
 
 
+def lloyd_sharded(X, xnorm, centers, tol, max_iter):
+    """``lloyd`` with the points sharded over ranks ("centroid partial sums over RCCL").
+
+    Every rank holds the same X (the trainers compute the latents unsharded) and the same initial centres; rank r iterates
+    over rows [r N/P, (r+1) N/P) only.  Per iteration: dic_kmeans_lloyd_partial on the shard, ONE all-reduce of the f64
+    statistics (K*D sums + K counts + #changed per restart), dic_kmeans_lloyd_finish on every rank -- so centres, the
+    convergence decisions and the iteration counts are identical everywhere.  A restart that meets an empty cluster (its
+    relocation needs the globally farthest point) is re-run on the full X by the unsharded kernels, on every rank alike.
+    Returns what ``lloyd`` returns, with full-length labels on every rank."""
+    L = N.lib()
+    n_runs, K, D = centers.shape
+    Nn, dev, st = X.shape[0], X.device, N.stream_of(X)
+    lo, hi = dist.shard_bounds(Nn)
+    if hi <= lo:
+        raise ValueError(f'k-means shard of rank {dist.rank()} is empty ({Nn} points over {dist.world_size()} ranks)')
+    Xl, xnl = X[lo:hi], xnorm[lo:hi]                       # contiguous row ranges: views
+    n_loc = hi - lo
+    init = centers.clone()
+    labels_l = torch.full((n_runs, n_loc), -1, dtype=torch.int32, device=dev)
+    status = torch.zeros((n_runs, N.KM_STATUS_WORDS), dtype=torch.float32, device=dev)
+    status[:, 6] = float(tol)
+    status[:, 7] = float(max_iter)
+    ws = _ws(L.dic_kmeans_workspace(n_loc, D, K, n_runs), dev)
+    stats = torch.zeros((n_runs, L.dic_kmeans_stats_words(D, K)), dtype=torch.float64, device=dev)
+    it = 0
+    while it < max_iter:
+        for _ in range(min(_POLL_EVERY, max_iter - it)):
+            N.check(L.dic_kmeans_lloyd_partial(N.ptr(Xl), N.ptr(xnl), n_loc, D, K, n_runs, N.ptr(centers), N.ptr(labels_l), N.ptr(status),
+                                               N.ptr(stats), N.ptr(ws), ws.numel(), st), 'dic_kmeans_lloyd_partial')
+            dist.all_reduce_sum_(stats)                  # converged restarts contribute their (stale, ignored) previous values
+            N.check(L.dic_kmeans_lloyd_finish(D, K, n_runs, N.ptr(stats), N.ptr(centers), N.ptr(status), st), 'dic_kmeans_lloyd_finish')
+            it += 1
+        if bool((status[:, 0] != 0).all()):
+            break
+    # final E-step on the shard; inertia summed and labels assembled over ranks
+    inertia = torch.empty(n_runs, dtype=torch.float32, device=dev)
+    N.check(L.dic_kmeans_predict(N.ptr(Xl), n_loc, D, K, n_runs, N.ptr(centers), N.ptr(labels_l), None, N.ptr(inertia), N.ptr(ws),
+                                 ws.numel(), st), 'dic_kmeans_predict')
+    inertia64 = inertia.double()
+    dist.all_reduce_sum_(inertia64)
+    inertia = inertia64.float()
+    labels = torch.zeros((n_runs, Nn), dtype=torch.int32, device=dev)
+    labels[:, lo:hi] = labels_l
+    dist.all_reduce_sum_(labels)                         # disjoint row ranges: the sum is the concatenation
+    halted = (status[:, 0] == 2).nonzero().flatten().tolist()     # same on every rank (status is a function of reduced data)
+    if halted:
+        idx = torch.as_tensor(halted, device=dev)
+        c_h = init[idx].contiguous()
+        lab_h, in_h, st_h = lloyd(X, xnorm, c_h, tol, max_iter)
+        centers[idx], labels[idx], inertia[idx], status[idx] = c_h, lab_h, in_h, st_h
+    return labels, inertia, status
+
+
 def _pp_init(X, K, n_runs, rs):
     """k-means++ (greedy, 2+log K local trials) for n_runs restarts at once.  Every random number is
     drawn from ``rs`` up front in scikit-learn's order (per restart: one ``choice`` then K-1
@@ -133,7 +186,7 @@ def _same_clustering(a, b, K):
 
 class KMeans:
     def __init__(self, n_clusters=8, *, init='k-means++', n_init='auto', max_iter=300, tol=1e-4, verbose=0,
-                 random_state=None, copy_x=True, algorithm='lloyd'):
+                 random_state=None, copy_x=True, algorithm='lloyd', shard_points=False):
         self.n_clusters = n_clusters
         self.init = init
         self.n_init = n_init
@@ -143,6 +196,9 @@ class KMeans:
         self.random_state = random_state
         self.copy_x = copy_x
         self.algorithm = algorithm
+        # (extra) one process per GPU: every rank passes the SAME X to fit(); the Lloyd iterations then run on this rank's row
+        # shard with one all-reduce of centroid partial sums per iteration (lloyd_sharded).  Seeding stays unsharded.
+        self.shard_points = shard_points
 
     # -- helpers ------------------------------------------------------------------------------
     def _random_state(self):
@@ -199,7 +255,8 @@ class KMeans:
         else:
             raise ValueError(f"init must be 'k-means++', 'random' or an array, got {self.init!r}")
 
-        labels, inertia, status = lloyd(Xc, xnorm, centers, tol_abs, int(self.max_iter))
+        run = lloyd_sharded if (self.shard_points and dist.is_sharded()) else lloyd
+        labels, inertia, status = run(Xc, xnorm, centers, tol_abs, int(self.max_iter))
         inertia_h = inertia.cpu().numpy()
         best = 0
         for i in range(1, centers.shape[0]):                                  # :1517-1532

@@ -166,6 +166,17 @@ size_t dic_kmeans_workspace(int N, int D, int K, int n_runs);
 int dic_kmeans_lloyd_iter(const float* X, const float* xnorm, int N, int D, int K, int n_runs,
                           float* centers, int32_t* labels, float* status,
                           void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* The same iteration with the POINTS SHARDED over ranks (one process per GPU): each rank runs
+ * dic_kmeans_lloyd_partial on its rows, the caller sums `stats` over ranks (one RCCL all-reduce of
+ * n_runs * dic_kmeans_stats_words(D, K) doubles), and dic_kmeans_lloyd_finish completes the iteration identically on
+ * every rank.  stats[run] = [ sums (K*D) | counts (K) | #labels changed (1) ], f64.  An empty cluster cannot be
+ * relocated from partial data (the farthest point may live on another rank): finish then sets status[0] = 2 and leaves
+ * the centres untouched; the caller re-runs that restart on unsharded data with dic_kmeans_lloyd_iter. */
+size_t dic_kmeans_stats_words(int D, int K);
+int dic_kmeans_lloyd_partial(const float* X, const float* xnorm, int N, int D, int K, int n_runs, const float* centers,
+                             int32_t* labels, const float* status, double* stats, void* workspace, size_t workspace_bytes,
+                             dic_stream_t stream);
+int dic_kmeans_lloyd_finish(int D, int K, int n_runs, const double* stats, float* centers, float* status, dic_stream_t stream);
 /* E-step only (KMeans.predict; also the final E-step after a tol stop):
  *   labels (n_runs,N) OVERWRITTEN; mindist (n_runs,N) or NULL = exact ||x-c_label||^2;
  *   inertia (n_runs) or NULL = sum of mindist (deterministic, f64 accumulation, f32 result). */

@@ -114,3 +114,45 @@ def test_two_rank_drivers_keep_replicas_identical_and_dump_every_encounter(tmp_p
     assert feat['hidden'].shape == (400, 256) and len(set(feat['encounter_id'].tolist())) == 400
     pre = np.load(os.path.join(base, 'run/Results/Pretrain/out_feat/ae_mse/training.npy'), allow_pickle=True).item()
     assert pre['hidden'].shape == (400, 256)
+
+
+def _run_kmeans(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      DIC_DIST_BACKEND='gloo')
+    from deep_interpolation_clustering_amd import dist
+    from deep_interpolation_clustering_amd.kmeans import KMeans
+    from oracle.synth import latent_blobs
+    if world > 1:
+        dist.init_from_env()
+    X, _ = latent_blobs(3, 20011, 256, 5)                       # odd size: uneven shards
+    res = {}
+    km = KMeans(n_clusters=5, n_init=4, random_state=7, shard_points=True).fit(X)
+    res['pp'] = (km.labels_, km.cluster_centers_, km.inertia_, km.n_iter_)
+    # an init that leaves a cluster empty (one centre far from all points): sharded runs fall back to the unsharded kernels
+    init = np.concatenate([X[:3], X[:1] + 100.0], axis=0).astype(np.float32)
+    km = KMeans(n_clusters=4, init=init, n_init=1, shard_points=True).fit(X)
+    res['empty'] = (km.labels_, km.cluster_centers_, km.inertia_, km.n_iter_)
+    torch.save(res, os.path.join(out, f'km_w{world}_r{rank}.pt'))
+    if world > 1:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+def test_sharded_kmeans_equals_single_device(tmp_path):
+    """Points sharded over two ranks, centroid partial sums all-reduced every Lloyd iteration (dic_kmeans_lloyd_partial /
+    _finish) == the single-device fit: same labels, same iteration count, centres to f32 rounding -- on every rank."""
+    port = 29800 + (os.getpid() % 1000)
+    mp.spawn(_run_kmeans, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_run_kmeans, args=(2, port + 1, str(tmp_path)), nprocs=2, join=True)
+    one = torch.load(tmp_path / 'km_w1_r0.pt', weights_only=False)
+    r0, r1 = torch.load(tmp_path / 'km_w2_r0.pt', weights_only=False), torch.load(tmp_path / 'km_w2_r1.pt', weights_only=False)
+    for case in ('pp', 'empty'):
+        for a, b in ((r0, r1), (r0, one)):
+            la, ca, ia, na = a[case]
+            lb, cb, ib, nb = b[case]
+            assert np.array_equal(la, lb), case
+            assert na == nb, case
+            np.testing.assert_allclose(ca, cb, rtol=1e-5, atol=1e-6, err_msg=case)
+            np.testing.assert_allclose(ia, ib, rtol=1e-5, err_msg=case)
+    assert len(np.unique(one['empty'][0])) == 4               # the empty cluster was relocated, as scikit-learn does
