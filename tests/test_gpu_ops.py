@@ -319,3 +319,71 @@ def test_kmeans_full_size_properties():
     d = ((X[:2000, None] - km.cluster_centers_[None]) ** 2).sum(-1)
     assert (d.argmin(1) == lab[:2000]).all()
     np.testing.assert_allclose(km.inertia_, ((X - km.cluster_centers_[lab]) ** 2).sum(dtype=np.float64), rtol=1e-5)
+
+
+# ------------------------------------------------------------------ full BASELINE sizes: size-independent properties
+def _device_vitals(B, C, T, H, lam, seed):
+    """Stacked (B,4C,T) ragged input generated on the device (prefix masks, sorted times), plus lengths."""
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    n = torch.poisson(torch.full((B, C), float(lam), device='cuda'), generator=g).clamp_(1, T).to(torch.int32)
+    mask = (torch.arange(T, device='cuda')[None, None, :] < n[..., None]).float()
+    # sorted observation times in the first n slots: sort uniform draws with the padded slots pushed to the end
+    t = torch.rand((B, C, T), device='cuda', generator=g) * H
+    t = torch.where(mask > 0, t, torch.full_like(t, 2 * H)).sort(dim=-1).values * mask
+    val = torch.randn((B, C, T), device='cuda', generator=g) * 1.2 * mask
+    hold = (torch.rand((B, C, T), device='cuda', generator=g) < 0.2).float()
+    x = torch.cat([val, mask, t, hold], dim=1)
+    del val, mask, t, hold
+    return x, n
+
+
+@pytest.mark.parametrize('B,C,T,R,H,lam', [(75000, 6, 96, 24, 24, 50), (300000, 12, 288, 24, 24, 200)], ids=['cfg2_75k', 'cfg4_300k'])
+def test_interp_full_size_properties(ops, B, C, T, R, H, lam):
+    """BASELINE configs[1] and [3] at full size (cfg4: 16.6 GB of input), k1 and k2 forward:
+    (a) encounters are independent -- any slice computed alone reproduces its rows of the full launch (to f32 rounding), and
+        a small slice is checked against the fp64 oracle; (b) the smoothers are weighted means: a channel whose observed values
+        all equal v interpolates to v at every grid point; (c) both operators are linear in the values they average."""
+    x, n = _device_vitals(B, C, T, H, lam, seed=B)
+    rng = np.random.default_rng(C)
+    ks = G(rng.uniform(-0.5, 1.5, C).astype(np.float32))
+    kc = G((np.eye(C) + rng.normal(0, 0.2, (C, C))).astype(np.float32))
+    kr = G(rng.uniform(-0.5, 1.5, C).astype(np.float32))
+    grid = ops.ref_grid(H, R, 'cuda')
+    with torch.no_grad():
+        full = ops.sci_cci(x, ks, kc, grid, lengths=n)
+        assert bool(torch.isfinite(full).all())
+        pick = torch.arange(17, B, max(1, B // 300), device='cuda')[:256]
+        part = ops.sci_cci(x[pick].contiguous(), ks, kc, grid, lengths=n[pick].contiguous())
+        # (a) (not bit-equal: the launch shape -- encounters per workgroup, time-axis split -- follows the batch size)
+        np.testing.assert_allclose(part.cpu().numpy(), full[pick].cpu().numpy(), rtol=2e-5, atol=2e-6)
+        ref = O.sci_cci_forward(x[pick[:16]].double().cpu(), ks.double().cpu(), kc.double().cpu(), R, H)
+        np.testing.assert_allclose(part[:16].cpu().numpy(), ref.numpy(), rtol=RT, atol=AT)
+        # (b) constant channels, SCI alone: y == y_trans == the constant
+        const = torch.randn((B, C, 1), device='cuda')
+        xc = x.clone()
+        xc[:, :C] = const * x[:, C:2 * C]
+        s = ops.sci_only(xc, ks, grid, lengths=n)                                                # (B,R,3C) = [y | w | y_trans]
+        np.testing.assert_allclose(s[:, :, :C].amax(1).cpu().numpy(), const[:, :, 0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(s[:, :, 2 * C:].amin(1).cpu().numpy(), const[:, :, 0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+        del xc
+        # (c) linearity of SCI in the values (weights depend on times only): sci(2.5 x) = 2.5 sci(x) for y and y_trans, same w
+        s1 = ops.sci_only(x, ks, grid, lengths=n)
+        x2 = x.clone()
+        x2[:, :C] *= 2.5
+        s2 = ops.sci_only(x2, ks, grid, lengths=n)
+        del x2
+        assert torch.equal(s1[:, :, C:2 * C], s2[:, :, C:2 * C])
+        lin = torch.cat([s1[:, :, :C], s1[:, :, 2 * C:]], dim=-1) * 2.5
+        got = torch.cat([s2[:, :, :C], s2[:, :, 2 * C:]], dim=-1)
+        assert float((got - lin).abs().max()) <= 2e-6 * float(lin.abs().max())
+        del s1, s2, lin, got, full
+        # k2: slice consistency, oracle on a small slice, linearity in v
+        v = torch.randn((B, C, R), device='cuda')
+        y = ops.rbf_deinterp(v, x, kr, grid, lengths=n)
+        assert bool(torch.isfinite(y).all())
+        yp = ops.rbf_deinterp(v[pick].contiguous(), x[pick].contiguous(), kr, grid, lengths=n[pick].contiguous())
+        np.testing.assert_allclose(yp.cpu().numpy(), y[pick].cpu().numpy(), rtol=2e-5, atol=2e-6)
+        ref = O.rbf_deinterp(v[pick[:16]].double().cpu(), x[pick[:16]].double().cpu(), kr.double().cpu(), R, H)
+        np.testing.assert_allclose(yp[:16].cpu().numpy(), ref.numpy(), rtol=RT, atol=3e-6)
+        y2 = ops.rbf_deinterp(v * -3.0, x, kr, grid, lengths=n)
+        assert float((y2 + 3.0 * y).abs().max()) <= 2e-6 * float(y.abs().max()) * 3.0
