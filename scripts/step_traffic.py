@@ -1,0 +1,29 @@
+"""Whole-step HBM traffic from two rocprofv3 PMC passes of bench.py (FETCH_SIZE, WRITE_SIZE; see profiles/traffic.json's note
+for the gfx950 correction): sums the counters over the kernels of the last 4 optimisation steps.
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/step_fetch -o p -- python3 bench.py --no-cpu-baseline --steps 6 --warmup 2 --kernel-iters 1
+    rocprofv3 --pmc WRITE_SIZE ... -d gpurun_out/step_write ...
+    python scripts/step_traffic.py gpurun_out/step_fetch/p_counter_collection.csv gpurun_out/step_write/p_counter_collection.csv"""
+import csv, json, os, sys
+
+
+def per_step(path, counter, n=4):
+    rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    marks = [i for i, r in enumerate(rows) if 'adam_amsgrad_kernel' in r['Kernel_Name']]
+    lo, hi = marks[-n - 1] + 1, marks[-1] + 1
+    by = {}
+    for r in rows[lo:hi]:
+        k = r['Kernel_Name']
+        c = 'lstm_recurrence' if 'lstm_' in k else 'library_gemm' if 'Cijk' in k else 'other_hip_kernels' if 'dic' in k else 'torch_elementwise'
+        by[c] = by.get(c, 0.0) + float(r['Counter_Value']) * 1024 / n
+    return by
+
+
+f, w = per_step(sys.argv[1], 'FETCH_SIZE'), per_step(sys.argv[2], 'WRITE_SIZE')
+out = {'_note': 'HBM bytes per joint step at B=32768 (bench.py defaults): read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024; '
+                'separate rocprofv3 --pmc passes, mean of 4 steps (scripts/step_traffic.py)'}
+for c in sorted(set(f) | set(w)):
+    out[c] = {'read_bytes': int(2 * f.get(c, 0)), 'write_bytes': int(w.get(c, 0))}
+out['total_bytes'] = int(sum(v['read_bytes'] + v['write_bytes'] for k, v in out.items() if isinstance(v, dict)))
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r1_step_hbm_traffic.json'), 'w'), indent=1)
+print(json.dumps(out, indent=1))
