@@ -83,8 +83,9 @@ class KM(object):
         for k in range(2, k_max + 1):
             local = []
             for _ in range(n_references):
-                ref = np.random.random_sample(data.shape) * rng_ + lo           # host draw keeps upstream's random stream
-                refd = torch.as_tensor(ref, dtype=torch.float32, device=dev)
+                u = np.random.random_sample(data.shape)                       # host draw keeps upstream's random stream;
+                refd = torch.as_tensor(u, device=dev).mul_(rng_).add_(lo).float()     # scale / shift / f32 cast on the device (f64 math as upstream)
+                del u
                 local.append(inertia(KMeans(n_clusters=k, n_init=self.n_init).fit_predict(refd), refd))
             ref_mean, ref_std = np.mean(np.log(local)), np.std(np.log(local))
             ref_s = np.sqrt(1 + 1 / n_references) * ref_std
