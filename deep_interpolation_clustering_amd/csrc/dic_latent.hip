@@ -271,8 +271,13 @@ __global__ __launch_bounds__(kLatBlock) void kmeans_assign_kernel(const float* X
     for (int k = 0; k < KP; ++k) { acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); cnt[k] = 0; }
     int changed = 0;
     const long nw = (long)nblk * kLatWaves;
-    for (long row = (long)blockIdx.x * kLatWaves + wave; row < N; row += nw) {
-        const float4 x = load_row4(X, row, D, lane);
+    // the row of the NEXT trip is requested before this trip's shuffle chain: at K >= 8 the accumulators leave two waves
+    // per SIMD, too few to hide the load latency by occupancy alone
+    long row = (long)blockIdx.x * kLatWaves + wave;
+    float4 xn = row < N ? load_row4(X, row, D, lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; row < N; row += nw) {
+        const float4 x = xn;
+        if (row + nw < N) xn = load_row4(X, row + nw, D, lane);
         float v[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
