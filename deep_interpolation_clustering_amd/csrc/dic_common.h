@@ -81,6 +81,26 @@ __device__ __forceinline__ double reduce_partials_32x8(const T* partials, int nb
     return r;
 }
 
+// Per-channel sums over a tile: returns sum over (e, r) of buf[(e*C + c)*R + r] for channel c = tid / LPC in EVERY lane of
+// that channel's group (LPC = 32 lanes per channel for C <= 8, 16 for C <= 16; lanes beyond C*LPC return 0).  Call from all
+// 256 threads.  Replaces `if (tid < C) for e, r: s += ...` -- a serial chain of Ev*R dependent LDS reads on C threads that cost
+// as much as the tile's whole compute phase.  Fixed summation order.
+__device__ __forceinline__ int channel_group_lanes(int C) { return C <= 8 ? 32 : 16; }
+__device__ __forceinline__ float channel_sum_er(const float* buf, int Ev, int C, int R, int tid) {
+    const int lpc = channel_group_lanes(C);
+    const int c = tid / lpc, j = tid - c * lpc;
+    float s = 0.f;
+    if (c < C)
+        for (int i = j; i < Ev * R; i += lpc) {
+            const int e = i / R, r = i - e * R;
+            s += buf[(e * C + c) * R + r];
+        }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1)
+        if (m < lpc) s += __shfl_xor(s, m);
+    return s;
+}
+
 // XCD-aware block remap (8 XCDs, round-robin dispatch): consecutive logical tiles land on the
 // same XCD so neighbouring rows share that XCD's L2.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_bwd_kernel(const float* grad_o
         for (int i = tid; i < C * C; i += kBlock) smem[L.kmat + i] = cci_kernel[i];
 
     float gk_acc = 0.f;        // thread (i,j) < C*C
-    float ga_acc = 0.f;        // thread c < C
+    float ga_acc = 0.f;        // channel tid / lanes-per-channel
     for (int e0 = blockIdx.x * E; e0 < B; e0 += nblk * E) {     // grid-stride over encounter tiles
         const int Ev = min(E, B - e0);
         __syncthreads();
@@ -459,15 +459,11 @@ __global__ __launch_bounds__(kBlock) void sci_cci_bwd_kernel(const float* grad_o
             part[i] = -gw * eu1 - gy * (exu1 - y * eu1) - 10.0f * gyt * (exu10 - yt * eu10);
         }
         __syncthreads();
-        if (tid < C) {
-            float s = 0.f;
-            for (int e = 0; e < Ev; ++e)
-                for (int r = 0; r < R; ++r) s += part[e * CR + tid * R + r];
-            ga_acc += s;
-        }
+        ga_acc += channel_sum_er(part, Ev, C, R, tid);
     }
     float* o = partials + (size_t)blockIdx.x * (C + C * C);
-    if (tid < C) o[tid] = ga_acc;
+    const int lpc = channel_group_lanes(C);
+    if (tid % lpc == 0 && tid / lpc < C) o[tid / lpc] = ga_acc;
     if (tid < C * C) o[C + tid] = gk_acc;
 }
 

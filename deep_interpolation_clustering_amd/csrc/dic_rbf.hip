@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
 
     for (int i = tid; i < R; i += kBlock) refg[i] = a.ref_grid[i];
     for (int i = tid; i < C; i += kBlock) nbeta[i] = -softplus_raw(a.rbf_kernel[i]) * kLog2e;
-    float gbeta_acc = 0.f;          // thread c < C
+    float gbeta_acc = 0.f;          // channel tid / lanes-per-channel (every lane of the group carries it)
 
     for (int e0 = blockIdx.x * E; e0 < a.B; e0 += a.nblk * E) {
         const int Ev = min(E, a.B - e0), nrows = Ev * C;
@@ -198,14 +198,10 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
             }
         }
         __syncthreads();
-        if (tid < C) {
-            float s = 0.f;
-            for (int e = 0; e < Ev; ++e)
-                for (int r = 0; r < R; ++r) s += gb[(e * C + tid) * R + r];
-            gbeta_acc += s;
-        }
+        gbeta_acc += channel_sum_er(gb, Ev, C, R, tid);
     }
-    if (tid < C) a.partials[(size_t)blockIdx.x * C + tid] = gbeta_acc;
+    const int lpc = channel_group_lanes(C);
+    if (tid % lpc == 0 && tid / lpc < C) a.partials[(size_t)blockIdx.x * C + tid / lpc] = gbeta_acc;
 }
 
 __global__ __launch_bounds__(256) void rbf_bwd_finalize(const float* partials, int nblk, int C, const float* rbf_kernel,
