@@ -366,6 +366,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 
     for (int step = 0; step < R; ++step) {
         const int t = dir ? step : R - 1 - step;
+        DIC_STAMP(1, step, 0);
 #pragma unroll
         for (int nb = 0; nb < LNB; ++nb) {
 #pragma unroll
@@ -393,10 +394,19 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                 *reinterpret_cast<bf16x4*>(lp + 3 * LH) = dO;
             }
         }
+        DIC_STAMP(1, step, 1);
         if (step + 1 < R) load_step(step + 1, nxt);        // in flight across the store / MFMA phases below
         __syncthreads();
-        // dG_t -> global, row-major for the weight-gradient GEMMs: re-read the LDS tile so that every wave
-        // instruction stores one whole 1-KiB row (the accumulator layout would scatter 32 x 16-B pieces)
+        DIC_STAMP(1, step, 2);
+        // dG_t -> global, row-major for the weight-gradient GEMMs: re-read the LDS tile so that every wave instruction stores
+        // one whole 1-KiB row (the accumulator layout would scatter 32 x 16-B pieces) -- interleaved, one row per two
+        // k-steps, with  dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n]  so that the stores and the bias column sums issue in
+        // the shadow of the MFMAs
+#pragma unroll
+        for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dh[nb][k] = 0.f;
+        DIC_STAMP(1, step, 3);
 #pragma unroll
         for (int k = 0; k < LBM / 4; ++k) {
             const int rowl = k * 4 + w;
@@ -407,20 +417,17 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
             }
+#pragma unroll
+            for (int ks = 2 * k; ks < 2 * k + 2; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < LNB; ++nb) {
+                    const bf16x8 gbv = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + r) * GSTR + ks * 16 + 8 * hh);
+                    dh[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, dh[nb], 0, 0, 0);
+                }
         }
-        // dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n]
-#pragma unroll
-        for (int nb = 0; nb < LNB; ++nb)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) dh[nb][k] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks)
-#pragma unroll
-            for (int nb = 0; nb < LNB; ++nb) {
-                const bf16x8 gbv = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + r) * GSTR + ks * 16 + 8 * hh);
-                dh[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, dh[nb], 0, 0, 0);
-            }
+        DIC_STAMP(1, step, 4);
         __syncthreads();
+        DIC_STAMP(1, step, 5);
 #pragma unroll
         for (int nb = 0; nb < LNB; ++nb)
 #pragma unroll

@@ -29,3 +29,18 @@ for i, n in enumerate(names):
     print('  %-22s %8.0f' % (n, np.median(d[2:, i])))
 print('  %-22s %8.0f' % ('loop overhead', np.median(nxt[2:])))
 print('  step total             %8.0f' % np.median(t[3:, 0] - t[2:-1, 0]))
+if not proj:
+    # backward kernel on the state the forward just saved
+    whh_t = whh.transpose(1, 2).contiguous(); dout = (torch.randn(R, B, 2 * H, device=dev) * 0.1).to(bf)
+    dgx = torch.empty(R, B, 2, 4, H, device=dev, dtype=bf); dh0 = torch.empty(2, B, H, device=dev); dc0 = torch.empty(2, B, H, device=dev)
+    db = torch.empty(2, 4 * H, device=dev); ws = torch.empty(max(16, L.dic_lstm_bwd_workspace(B)), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        L.dic_lstm_bwd(P(whh_t), P(gates), P(cs), None, P(dout), None, None, R, B, H, P(dgx), P(dh0), P(dc0), P(db), P(ws), ws.numel(), st)
+    torch.cuda.synchronize()
+    assert fn(buf.ctypes.data) == 0
+    t = buf[1, :R, :6].astype(np.int64)
+    d = np.diff(t, axis=1)
+    print('lstm_bwd, cycles per phase:')
+    for i, n in enumerate(['gate-gradient math + LDS write', 'issue next loads + barrier', 'dG rows LDS -> global (+bias sums)', 'MFMA dh = W^T dG', 'closing barrier']):
+        print('  %-34s %8.0f' % (n, np.median(d[2:, i])))
+    print('  step total                         %8.0f' % np.median(t[3:, 0] - t[2:-1, 0]))
