@@ -7,7 +7,7 @@ optional ``predict_future / aux_head / fake_det_head`` ``.model.*`` and (cluster
 
 What runs where: interpolation (k1), de-interpolation (k2), reconstruction loss, DEC soft assignment,
 target and KL (k3) are HIP kernels; the two bi-LSTMs and the small FC heads are PyTorch-ROCm
-(MIOpen / hipBLASLt).  Differences from upstream that do not change results: the fake / positive
+(MIOpen / hipBLASLt).  Differences from upstream that do not change results: at small batch sizes the fake / positive
 branches share ONE encoder call with the real batch (rows are independent in sci, cci and the LSTM),
 and BatchNorm uses global-batch moments when the batch is sharded over ranks.
 """
@@ -21,6 +21,9 @@ from .dec import ClusterAssignment, target_distribution
 from .interpolation_layer import CrossChannelInterp, SingleChannelInterp, fused_forward
 from .rbf import RBF, basis_func_dict
 from .utils import logger
+
+
+SEPARATE_ENCODER_ROWS = 65536      # (batch x grid points) from which the fake / positive branches get their own encoder call
 
 
 class EncoderRNN(nn.Module):
@@ -127,12 +130,19 @@ class NetBase(nn.Module):
             feats.append(self._interp(fake_x, lengths))
         if want_pos:
             feats.append(self._interp(positive_x, lengths))
-        seq = (feats[0] if len(feats) == 1 else torch.cat(feats, dim=0)).permute(1, 0, 2)     # (R, nB, 3C)
-        context, hidden, cell = self.encoder(seq)
-        z_all = torch.cat([h for h in hidden], dim=-1)                    # (nB, 256)
+        if len(feats) > 1 and B * feats[0].size(1) >= SEPARATE_ENCODER_ROWS:
+            # large batches: one encoder call per branch.  Each already fills the chip, and the shared call would cost three
+            # 100-MB-class copies (stacking the inputs, slicing the real half of the context and of the final states back out)
+            outs = [self.encoder(f.permute(1, 0, 2)) for f in feats]
+            context, hidden, cell = outs[0]
+            z_all = torch.cat([torch.cat([h for h in o[1]], dim=-1) for o in outs], dim=0)          # (nB, 256)
+        else:
+            seq = (feats[0] if len(feats) == 1 else torch.cat(feats, dim=0)).permute(1, 0, 2)     # (R, nB, 3C)
+            context, hidden, cell = self.encoder(seq)
+            z_all = torch.cat([h for h in hidden], dim=-1)                # (nB, 256)
+            if len(feats) > 1:
+                context, hidden, cell = context[:, :B], hidden[:, :B].contiguous(), cell[:, :B].contiguous()
         cat_hidden = z_all[:B]
-        if len(feats) > 1:
-            context, hidden, cell = context[:, :B], hidden[:, :B].contiguous(), cell[:, :B].contiguous()
         y, _ = self.decoder(context, hidden, cell)
         y = self.rbf(y.permute(1, 2, 0), x, lengths)                      # (B,C,T)
 

@@ -18,10 +18,18 @@ from deep_interpolation_clustering_amd.clustering_interp import Net
 from deep_interpolation_clustering_amd.step import Stepper
 from deep_interpolation_clustering_amd.utils import pytorch_optimizer
 dev = torch.device('cuda')
-for B in [int(a) for a in sys.argv[1:]] or [8192, 16384, 32768]:
+for B in [int(a) for a in sys.argv[1:]] or [256, 2048, 8192, 16384, 32768]:
     coh = synthetic.make_cohort(B, seed=3)
     x_np, ob_np, n = synthetic.stacked_batch(coh)
     X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    # the fake-detection variant of the step first (its extra shapes: the detection head on 2B rows), then the headline step
+    args_f = bench.make_args(4, True)
+    net = Net(args_f, dev).to(dev); net.train()
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args_f, autocast_dtype=torch.bfloat16)
+    perm = torch.randperm(2 * B, device=dev)
+    lab = torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)])[perm].to(torch.int64)
+    st.step(X, OB, None, LEN, fake_x=X.clone(), fake_perm_idx=perm, fake_det_label=lab); torch.cuda.synchronize()
+    del st, net
     net = Net(bench.make_args(4), dev).to(dev); net.train()
     st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), bench.make_args(4), autocast_dtype=torch.bfloat16)
     t0 = time.time()
