@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void bn_colstats_finalize(const float* partial
 
 template <int C>
 __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
-                                                         const float* beta, const float* W, const float* b, long N, float* v) {
+                                                         const float* beta, const float* W, const float* b, long N, float floor_, float* v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
     const ColParams p = load_cols(mean, rstd, gamma, beta, kc);
     float w[C][8];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const 
         for (int j = 0; j < C; ++j) acc[j] = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float h = fmaxf(fmaf((float)x[e], p.scale[e], p.shift[e]), 0.f);
+            const float h = fmaxf(fmaf((float)x[e], p.scale[e], p.shift[e]), floor_);      // floor_ = 0 (ReLU) or -inf (none)
 #pragma unroll
             for (int j = 0; j < C; ++j) acc[j] = fmaf(h, w[j][e], acc[j]);
         }
@@ -124,23 +124,23 @@ __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const 
 // recompute the post-ReLU activation h, x-hat and da = (dv W) 1[h > 0] for this lane's 8 columns of one row
 template <int C>
 __device__ __forceinline__ void recompute_row(const bf16x8 x, const ColParams& p, const float (&w)[C][8], const float (&g)[C],
-                                              float (&h)[8], float (&xhat)[8], float (&da)[8]) {
+                                              float floor_, float (&h)[8], float (&xhat)[8], float (&da)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float xe = (float)x[e];
-        h[e] = fmaxf(fmaf(xe, p.scale[e], p.shift[e]), 0.f);
+        h[e] = fmaxf(fmaf(xe, p.scale[e], p.shift[e]), floor_);
         xhat[e] = (xe - p.mean[e]) * p.rstd[e];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < C; ++j) s = fmaf(g[j], w[j][e], s);
-        da[e] = h[e] > 0.f ? s : 0.f;
+        da[e] = h[e] > floor_ ? s : 0.f;
     }
 }
 
 // partials[blk][(2 + C) * BK + C]: sum da | sum da*xhat | dW[C][BK] | db[C]
 template <int C>
 __global__ __launch_bounds__(256) void bnhead_bwd_reduce_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
-                                                                const float* beta, const float* W, const float* dv, long N, float* partials) {
+                                                                const float* beta, const float* W, const float* dv, long N, float floor_, float* partials) {
     constexpr int NOUT = (2 + C) * BK + C;
     __shared__ float red[4][NOUT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void bnhead_bwd_reduce_kernel(const __bf16* z,
             for (int j = 0; j < C; ++j) gn[j] = dv[(row + stride) * C + j];
         }
         float h[8], xhat[8], da[8];
-        recompute_row<C>(x, p, w, g, h, xhat, da);
+        recompute_row<C>(x, p, w, g, floor_, h, xhat, da);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             sda[e] += da[e];
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void bnhead_bwd_finalize(const float* partials
 template <int C>
 __global__ __launch_bounds__(256) void bnhead_bwd_input_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
                                                                const float* beta, const float* W, const float* dv, const float* sum_da,
-                                                               const float* sum_dax, float inv_n, long N, __bf16* dz) {
+                                                               const float* sum_dax, float inv_n, long N, float floor_, __bf16* dz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
     const ColParams p = load_cols(mean, rstd, gamma, beta, kc);
     float w[C][8], c1[8], c2[8];
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void bnhead_bwd_input_kernel(const __bf16* z, 
 #pragma unroll
         for (int j = 0; j < C; ++j) g[j] = dv[row * C + j];
         float h[8], xhat[8], da[8];
-        recompute_row<C>(x, p, w, g, h, xhat, da);
+        recompute_row<C>(x, p, w, g, floor_, h, xhat, da);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (__bf16)(p.scale[e] * (da[e] - c1[e] - xhat[e] * c2[e]));
@@ -306,13 +306,13 @@ int dic_bn_colstats(const void* z, int64_t N, int K, double* sums, void* workspa
 }
 
 int dic_bnhead_fwd(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                   const float* b, int64_t N, int K, int C, float* v, dic_stream_t stream) {
+                   const float* b, int64_t N, int K, int C, int relu, float* v, dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_fwd: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_fwd: in_features %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && mean && rstd && gamma && beta && W && b && v, DIC_ERR_INVALID_ARG, "bnhead_fwd: NULL pointer");
     const int grid = bnhead_blocks(N);
     DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_fwd_kernel<C>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)z, mean,
-                                                rstd, gamma, beta, W, b, (long)N, v));
+                                                rstd, gamma, beta, W, b, (long)N, relu ? 0.f : -INFINITY, v));
     return check_launch("bnhead_fwd");
 }
 
@@ -322,7 +322,7 @@ size_t dic_bnhead_bwd_workspace(int64_t N, int K, int C) {
 }
 
 int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                          const float* dv, int64_t N, int K, int C, float* sums, void* workspace, size_t workspace_bytes,
+                          const float* dv, int64_t N, int K, int C, int relu, float* sums, void* workspace, size_t workspace_bytes,
                           dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_bwd_reduce: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_bwd_reduce: in_features %d (compiled for %d)", K, BK);
@@ -331,20 +331,20 @@ int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, c
     DIC_REQUIRE(workspace_bytes >= (size_t)nblk * nout * sizeof(float), DIC_ERR_WORKSPACE, "bnhead_bwd_reduce: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_bwd_reduce_kernel<C>, dim3(nblk), dim3(256), 0, st, (const __bf16*)z, mean, rstd, gamma,
-                                                beta, W, dv, (long)N, (float*)workspace));
+                                                beta, W, dv, (long)N, relu ? 0.f : -INFINITY, (float*)workspace));
     hipLaunchKernelGGL(bnhead_bwd_finalize, dim3((nout + 31) / 32), dim3(256), 0, st, (const float*)workspace, nblk, nout, sums);
     return check_launch("bnhead_bwd_reduce");
 }
 
 int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, void* dz,
-                         dic_stream_t stream) {
+                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, int relu,
+                         void* dz, dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_bwd_input: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_bwd_input: in_features %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && mean && rstd && gamma && beta && W && dv && sum_da && sum_dax && dz, DIC_ERR_INVALID_ARG, "bnhead_bwd_input: NULL pointer");
     const int grid = bnhead_blocks(N);
     DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_bwd_input_kernel<C>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)z, mean,
-                                                rstd, gamma, beta, W, dv, sum_da, sum_dax, (float)inv_n, (long)N, (__bf16*)dz));
+                                                rstd, gamma, beta, W, dv, sum_da, sum_dax, (float)inv_n, (long)N, relu ? 0.f : -INFINITY, (__bf16*)dz));
     return check_launch("bnhead_bwd_input");
 }
 

@@ -334,7 +334,7 @@ class _BnReluHead(torch.autograd.Function):
     (v, mean, biased var, global row count); the moments are for the caller's running statistics."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, training):
+    def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, training, relu):
         N.require_gpu(z, gamma, beta, weight, bias)
         zb = z.to(torch.bfloat16).contiguous()
         n, k = zb.shape
@@ -356,10 +356,10 @@ class _BnReluHead(torch.autograd.Function):
         rstd = torch.rsqrt(var + eps)
         g, bt, w, b = N.f32c(gamma.detach()), N.f32c(beta.detach()), N.f32c(weight.detach()), N.f32c(bias.detach())
         v = torch.empty((n, c), device=dev, dtype=torch.float32)
-        N.check(L.dic_bnhead_fwd(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(b), n, k, c, N.ptr(v), st),
+        N.check(L.dic_bnhead_fwd(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(b), n, k, c, int(relu), N.ptr(v), st),
                 'dic_bnhead_fwd')
         ctx.save_for_backward(zb, mean, rstd, g, bt, w, cnt)
-        ctx.z_dtype, ctx.training = z.dtype, bool(training)
+        ctx.z_dtype, ctx.training, ctx.relu = z.dtype, bool(training), int(relu)
         ctx.mark_non_differentiable(mean, var, cnt)
         return v, mean, var, cnt
 
@@ -372,7 +372,7 @@ class _BnReluHead(torch.autograd.Function):
         gv = N.f32c(dv)
         sums = torch.empty((2 + c) * k + c, device=dev, dtype=torch.float32)
         ws = _ws(L.dic_bnhead_bwd_workspace(n, k, c), dev)
-        N.check(L.dic_bnhead_bwd_reduce(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), n, k, c, N.ptr(sums),
+        N.check(L.dic_bnhead_bwd_reduce(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), n, k, c, ctx.relu, N.ptr(sums),
                                         N.ptr(ws), ws.numel(), st), 'dic_bnhead_bwd_reduce')
         dbeta, dgamma = sums[:k], sums[k:2 * k]                 # this rank's share; the gradient all-reduce sums them
         dw, db = sums[2 * k:(2 + c) * k].view(c, k), sums[(2 + c) * k:]
@@ -386,21 +386,21 @@ class _BnReluHead(torch.autograd.Function):
                 red = torch.zeros(2 * k, device=dev, dtype=torch.float32)
             dz = torch.empty_like(zb)
             N.check(L.dic_bnhead_bwd_input(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), N.ptr(red),
-                                           N.ptr(red[k:]), 1.0, n, k, c, N.ptr(dz), st), 'dic_bnhead_bwd_input')
+                                           N.ptr(red[k:]), 1.0, n, k, c, ctx.relu, N.ptr(dz), st), 'dic_bnhead_bwd_input')
             dz = dz.to(ctx.z_dtype)
-        return dz, dgamma, dbeta, dw, db, None, None, None, None
+        return dz, dgamma, dbeta, dw, db, None, None, None, None, None
 
 
 BNHEAD_OUT = (1, 2, 3, 4, 5, 6, 7, 8)
 
 
-def bn_relu_head(z, bn, linear):
-    """``linear(relu(bn(z)))`` for an nn.BatchNorm1d(128) and an nn.Linear(128, C <= 8) on (N,128) bf16 rows, with the
+def bn_relu_head(z, bn, linear, relu=True):
+    """``linear(relu(bn(z)))`` (``relu=False``: ``linear(bn(z))``) for an nn.BatchNorm1d(128) and an nn.Linear(128, C <= 8) on (N,128) bf16 rows, with the
     module semantics of BatchNorm1d (batch moments + running statistics in training mode, running statistics in
     eval mode) and moments over the GLOBAL batch when the batch is sharded over ranks (dist.GlobalBatchNorm1d)."""
     training = bn.training or bn.running_mean is None
     v, mean, var, cnt = _BnReluHead.apply(z, bn.weight, bn.bias, linear.weight, linear.bias, bn.eps, bn.running_mean,
-                                          bn.running_var, training)
+                                          bn.running_var, training, relu)
     if bn.training and bn.track_running_stats:
         with torch.no_grad():
             bn.num_batches_tracked += 1

@@ -237,18 +237,20 @@ int dic_head_bwd(const void* h, const float* W, const float* dv, int64_t N, int 
  *   dic_bnhead_bwd_reduce: sums[(2+C)*128 + C] f32 = sum da | sum da*xhat | dW (C,128) | db (C), where
  *                          da = (dv W) 1[h > 0]; the first two rows are d beta and d gamma
  *   dic_bnhead_bwd_input:  dz (N,128) bf16 = gamma rstd (da - sum_da*inv_n - xhat sum_dax*inv_n); inv_n = 1 /
- *                          global row count in training mode; pass zero sums for eval-mode BatchNorm. */
+ *                          global row count in training mode; pass zero sums for eval-mode BatchNorm.
+ * relu = 0 drops the ReLU: BatchNorm1d(128) -> Linear(128, C), the tail of the auxiliary / fake-detection heads
+ * (clustering_interp.py:43-87). */
 size_t dic_bn_colstats_workspace(int64_t N, int K);
 int dic_bn_colstats(const void* z, int64_t N, int K, double* sums, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 int dic_bnhead_fwd(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                   const float* b, int64_t N, int K, int C, float* v, dic_stream_t stream);
+                   const float* b, int64_t N, int K, int C, int relu, float* v, dic_stream_t stream);
 size_t dic_bnhead_bwd_workspace(int64_t N, int K, int C);
 int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                          const float* dv, int64_t N, int K, int C, float* sums, void* workspace, size_t workspace_bytes,
+                          const float* dv, int64_t N, int K, int C, int relu, float* sums, void* workspace, size_t workspace_bytes,
                           dic_stream_t stream);
 int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, void* dz,
-                         dic_stream_t stream);
+                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, int relu,
+                         void* dz, dic_stream_t stream);
 
 /* ------------------------------------------------- K-sweep statistics (p2, internal_eval) ------
  * One pass over all N^2 point pairs, nothing n x n materialised.  Replaces sklearn pairwise_distances per

@@ -151,8 +151,9 @@ def test_head_linear_matches_torch(N, C):
     np.testing.assert_allclose(got[2].cpu().numpy(), lin.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(lin.bias.grad.abs().max()))
 
 
+@pytest.mark.parametrize('relu', [True, False])
 @pytest.mark.parametrize('N,C,training', [(1, 6, False), (77, 6, True), (4099, 1, True), (20000, 8, True), (20000, 6, False)])
-def test_bn_relu_head_matches_torch(N, C, training):
+def test_bn_relu_head_matches_torch(N, C, training, relu):
     """Fused BatchNorm1d -> ReLU -> Linear tail of CompressFC (csrc/dic_bnhead.hip, rbf.py:116-123) vs the torch modules in
     f32 on the same bf16 input: output, running statistics, and all five gradients."""
     import copy
@@ -171,10 +172,10 @@ def test_bn_relu_head_matches_torch(N, C, training):
     z = (torch.randn(N, 128, device=dev) * 1.5 + 0.3).to(torch.bfloat16)
     cot = torch.randn(N, C, device=dev)
     z1 = z.clone().requires_grad_()
-    v = ops.bn_relu_head(z1, bn, lin)
+    v = ops.bn_relu_head(z1, bn, lin, relu=relu)
     (v * cot).sum().backward()
     z2 = z.float().clone().requires_grad_()
-    ref = lin_ref(torch.relu(bn_ref(z2)))
+    ref = lin_ref(torch.relu(bn_ref(z2)) if relu else bn_ref(z2))
     (ref * cot).sum().backward()
 
     def close(a, b, tol):
@@ -203,3 +204,32 @@ def test_compress_fc_fused_tail_matches_module_path():
     ref = fc.model(x)                                    # f32 module path (updates running stats a second time: irrelevant here)
     np.testing.assert_allclose(got.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=0, atol=3e-2)
     assert got.dtype == torch.float32
+
+
+def test_aux_head_fast_path_matches_module_path():
+    """The auxiliary / fake-detection heads (Linear -> BatchNorm -> Dropout -> Linear [-> LogSoftmax], clustering_interp.py:43-87)
+    take the streaming BatchNorm+Linear kernels under bf16 autocast: same outputs and gradients as the module path."""
+    import copy
+    from deep_interpolation_clustering_amd._net_common import FakeDetFc
+    torch.manual_seed(9)
+    dev = torch.device('cuda')
+    head = FakeDetFc(256, 2, 0.0).to(dev).train()
+    ref_head = copy.deepcopy(head)
+    x = torch.randn(5000, 256, device=dev)
+    cot = torch.randn(5000, 2, device=dev)
+    x1 = x.clone().requires_grad_()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        got = head(x1)
+    (got * cot).sum().backward()
+    x2 = x.clone().requires_grad_()
+    ref = ref_head.model(x2)                              # f32 module path
+    (ref * cot).sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=0, atol=3e-2)
+    np.testing.assert_allclose(np.exp(got.detach().cpu().numpy()).sum(1), 1.0, rtol=1e-5)          # LogSoftmax tail applied
+    g1, g2 = x1.grad.cpu().numpy(), x2.grad.cpu().numpy()
+    assert np.abs(g1 - g2).max() < 3e-2 * np.abs(g2).max()
+    for (k, p), (_, q) in zip(head.named_parameters(), ref_head.named_parameters()):
+        if k == 'model.0.bias':
+            continue                                      # identically zero in front of a training-mode BatchNorm (noise upstream)
+        a, b = p.grad.cpu().numpy(), q.grad.cpu().numpy()
+        assert np.abs(a - b).max() < 3e-2 * max(np.abs(b).max(), 1e-6), k
