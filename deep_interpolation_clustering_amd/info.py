@@ -1,20 +1,35 @@
-"""Surface constants of the reference pipeline (info.py:1-41): paths, cohort names, the six vitals
-and their physiologic ranges, and the metric names the trainers checkpoint on."""
+"""Surface constants of the reference pipeline (upstream info.py): where the data lives, the cohort names, the monitored
+vitals with their physiologic ranges (used to map reconstructions back to physical units) and the metric names the trainers
+keep a best checkpoint for.  Everything is derived from the two small tables below."""
 import os
 
-BASE_PATH = os.path.dirname(os.getcwd())        # data lives in ../Data relative to the run directory (info.py:2)
-USE_FEATURES = ['sbp', 'dbp', 'heartRate', 'temperature', 'spo2', 'respiratory']
-COHORTS = ['training', 'validation', 'testing']
-COHORT2SCOPE = dict(zip(COHORTS, ('train', 'valid', 'test')))
-DATA_DICT_KEYS = ['feat', 'time_step', 'padding_mask', 'encounter_id']
-MIN_MAX_VALUES = {
-    'sbp': [20, 300], 'dbp': [5, 225], 'heartRate': [0, 300],
-    'temperature': [24, 45], 'spo2': [0, 100], 'respiratory': [0, 60],
-}
-LEGEND_INFO = {str(i): 'Phenotype ' + chr(ord('A') + i) for i in range(10)}
-PALETTE_INFO = {0: '#9b59b6', 1: '#3498db', 2: '#8de5a1', 3: '#e74c3c', 4: '#34495e', 5: '#2ecc71'}
+# the run directory is <base>/<something>; pickles are read from <base>/Data/model_data/split_processed
+BASE_PATH = os.path.dirname(os.getcwd())
 
-METRICS = ['loss', 'ae_mse', 'delta']            # a checkpoint directory per metric (utils.create_weight_dir)
-MIN_METRICS = ['loss', 'ae_mse', 'delta']        # lower is better
+# (name in the cohort tables, lowest / highest physiologic value)
+_VITALS = (
+    ('sbp', 20, 300),
+    ('dbp', 5, 225),
+    ('heartRate', 0, 300),
+    ('temperature', 24, 45),
+    ('spo2', 0, 100),
+    ('respiratory', 0, 60),
+)
+USE_FEATURES = [name for name, _, _ in _VITALS]
+MIN_MAX_VALUES = {name: [lo, hi] for name, lo, hi in _VITALS}
+
+# (pickle / dump file stem, short scope name used in logs and summaries)
+_SPLITS = (('training', 'train'), ('validation', 'valid'), ('testing', 'test'))
+COHORTS = [stem for stem, _ in _SPLITS]
+COHORT2SCOPE = dict(_SPLITS)
+DATA_DICT_KEYS = ['feat', 'time_step', 'padding_mask', 'encounter_id']
+
+# presentation (p4 tables): cluster id -> display name / colour
+LEGEND_INFO = {str(i): 'Phenotype ' + chr(ord('A') + i) for i in range(10)}
+PALETTE_INFO = dict(enumerate(('#9b59b6', '#3498db', '#8de5a1', '#e74c3c', '#34495e', '#2ecc71')))
+
+# one best-checkpoint directory per metric; all three are minimised
+METRICS = ['loss', 'ae_mse', 'delta']
+MIN_METRICS = list(METRICS)
 MAX_METRICS = []
 SUMMARY_ITEMS = ['lr', 'kl', 'fake_detection']
