@@ -16,12 +16,13 @@ namespace dic {
 __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                            float* __restrict__ v, float* __restrict__ vmax, long n, float lr, float b1,
                                                            float b2, float eps, float wd, const float* __restrict__ step,
-                                                           const float* __restrict__ coef) {
+                                                           const float* __restrict__ coef, const unsigned char* __restrict__ active) {
     const float t = step[0];
     const float c = coef ? coef[0] : 1.0f;
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
     const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        if (active && !active[i]) continue;       // no gradient reached this parameter: torch.optim skips it (no decay, no state)
         const float pi = p[i];
         float gi = g[i] * c;
         g[i] = gi;
@@ -43,12 +44,13 @@ using namespace dic;
 extern "C" {
 
 int dic_adam_amsgrad_step(float* p, float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
-                          float eps, float weight_decay, const float* step, const float* grad_scale, dic_stream_t stream) {
+                          float eps, float weight_decay, const float* step, const float* grad_scale, const unsigned char* active,
+                          dic_stream_t stream) {
     DIC_REQUIRE(n > 0, DIC_ERR_INVALID_ARG, "adam_amsgrad_step: non-positive size");
     DIC_REQUIRE(p && g && m && v && vmax && step, DIC_ERR_INVALID_ARG, "adam_amsgrad_step: NULL pointer");
     const int grid = (int)max(1L, min(((long)n + 255) / 256, (long)8 * kNumCU));
     hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, (long)n, lr, beta1, beta2,
-                       eps, weight_decay, step, grad_scale);
+                       eps, weight_decay, step, grad_scale, active);
     return check_launch("adam_amsgrad_step");
 }
 

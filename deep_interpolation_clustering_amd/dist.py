@@ -78,6 +78,34 @@ class FlatParams:
         self.flat = torch.empty(total, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
         self._attach(copy=True)
+        # which parameters a backward pass actually reached: torch.optim skips parameters whose .grad is None (no weight decay,
+        # no state), and with pre-allocated gradient views "None" has to be observed instead -- a hook per parameter flags it
+        self._reached = [False] * len(self.params)
+        self._mask_key, self._mask = None, None
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_param):
+            self._reached[i] = True
+        return hook
+
+    def active_mask(self):
+        """Per-element byte mask of the parameters the last backward reached, or None when it reached all of them.  Cached per
+        reach pattern (it is a property of the loss configuration, constant from step to step)."""
+        key = tuple(self._reached)
+        if all(key) or not any(key):          # nothing recorded (e.g. a replayed hipGraph) counts as 'all', the common case
+            return None
+        if key != self._mask_key:
+            m = torch.zeros(self.flat.numel(), dtype=torch.uint8)
+            o = 0
+            for p, on in zip(self.params, key):
+                n = p.numel()
+                if on:
+                    m[o:o + n] = 1
+                o += n
+            self._mask_key, self._mask = key, m.to(self.flat.device)
+        return self._mask
 
     def _attach(self, copy=False):
         o = 0
@@ -94,6 +122,7 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
         self._attach()          # re-attach in case something replaced .data / .grad
+        self._reached = [False] * len(self.params)
 
     def all_reduce_grads(self):
         """Sum over ranks: each rank's loss is already normalised by GLOBAL batch statistics, so

@@ -4,7 +4,9 @@ single HIP kernel (csrc/dic_optim.hip) instead of torch's multi-tensor Adam over
 
 Drop-in for ``torch.optim.Adam``: same constructor defaults, same ``param_groups`` keys (lr schedulers work), same
 ``state_dict`` layout (per parameter ``step, exp_avg, exp_avg_sq, max_exp_avg_sq``), so checkpoints written by either
-load into the other.  The per-parameter state tensors are views into three flat buffers.
+load into the other.  The per-parameter state tensors are views into three flat buffers.  Parameters that the backward pass
+did not reach are skipped like ``torch.optim`` skips ``grad is None`` (``FlatParams.active_mask``); one difference remains:
+the step count is shared, so a parameter that starts receiving gradients later uses the global count in its bias correction.
 """
 import torch
 
@@ -73,6 +75,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._step += 1
         N.check(N.lib().dic_adam_amsgrad_step(N.ptr(f.flat), N.ptr(f.grad), N.ptr(self._m), N.ptr(self._v), N.ptr(self._vmax), f.flat.numel(),
                                               float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
-                                              float(g['weight_decay']), N.ptr(self._step), N.ptr(grad_scale), N.stream_of(f.flat)),
+                                              float(g['weight_decay']), N.ptr(self._step), N.ptr(grad_scale), N.ptr(f.active_mask()),
+                                              N.stream_of(f.flat)),
                 'dic_adam_amsgrad_step')
         return loss

@@ -268,9 +268,11 @@ int dic_cluster_pairdist(const float* X, const int32_t* seg, int N, int D, int K
  * clip_grad_norm_ scaling + torch.optim.Adam(amsgrad=True, L2 weight decay) (pretrain_trainer.py:228-229, utils.py:83)
  * over one flat f32 bucket of n elements: p, g (scaled in place by *grad_scale, NULL = 1), exp_avg m, exp_avg_sq v,
  * max_exp_avg_sq vmax.  `step` = device pointer to the already incremented step count t (f32); `grad_scale` = device
- * pointer to the clip coefficient min(1, max_norm / (||g|| + 1e-6)). */
+ * pointer to the clip coefficient min(1, max_norm / (||g|| + 1e-6)); `active` = per-element byte mask or NULL (all):
+ * elements with 0 are left untouched, as torch.optim skips parameters whose .grad is None. */
 int dic_adam_amsgrad_step(float* p, float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
-                          float eps, float weight_decay, const float* step, const float* grad_scale, dic_stream_t stream);
+                          float eps, float weight_decay, const float* step, const float* grad_scale, const unsigned char* active,
+                          dic_stream_t stream);
 
 #ifdef __cplusplus
 }

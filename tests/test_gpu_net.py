@@ -137,3 +137,82 @@ def test_hip_graph_step_matches_eager():
         if mode:
             assert len(st._graphs) == 1
     np.testing.assert_allclose(traj[True], traj[False], rtol=2e-3)
+
+
+def _overlay_state(name):
+    plain = load('netstep_plain.npz')
+    g = load('netstep_%s.npz' % name)
+    sd = {k[4:]: v for k, v in plain.items() if k.startswith('sd0/')}
+    sd.update({k[4:]: v for k, v in g.items() if k.startswith('sd0/')})
+    return g, sd
+
+
+def _check_after_step(net, g):
+    for k, v in net.state_dict().items():
+        got = v.detach().cpu().numpy()
+        if 'sd1/' + k in g:
+            ref = g['sd1/' + k]
+            if 'g/' + k in g:
+                live = np.abs(g['g/' + k]) >= 1e-4 * float(g['gnorm'])
+                got, ref = got[live], ref[live]
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5, err_msg=k)
+        elif 'sd1n/' + k in g:
+            np.testing.assert_allclose(np.linalg.norm(got.astype(np.float64)), float(g['sd1n/' + k]), rtol=2e-5, err_msg=k)
+
+
+def test_supervised_heads_step_matches_reference():
+    """clustering_interp.Net with the supervised auxiliary heads (masked future-vital MSE, two weighted-BCE tasks), fake detection
+    and the KL term -- upstream's default p3 objective ae_mse_sup_fake_detect_kl (p3:78) -- against the reference's own step
+    (oracle/make_golden_sup.py; synthetic labels stand in for the private cohort's)."""
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    g, sd0 = _overlay_state('sup')
+    tasks = {k: float(g['w_' + k]) for k in ('future_vital', 'AKI_overall', 'ICU_24h')}
+    args = SimpleNamespace(num_variables=6, num_timestamps=g['x'].shape[-1], ref_points=int(g['R']), hours_from_admission=float(g['H']),
+                           dropout=0.0, aux_tasks=tasks, fake_detection=True, triple_margin=0.0, cluster_number=int(g['K']),
+                           loss='ae_mse_sup_fake_detect_kl', grad_clip=15.0, unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.},
+                           aux_pos_weights={'AKI_overall': float(g['pos_w_AKI_overall']), 'ICU_24h': float(g['pos_w_ICU_24h'])})
+    dev = torch.device('cuda')
+    net = Net(args, dev).to(dev)
+    net.load_state_dict({k: torch.tensor(v) for k, v in sd0.items()}, strict=True)
+    net.train()
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args)
+    G = lambda a: torch.tensor(a, device=dev)                                   # noqa: E731
+    x = G(g['x'])
+    losses, gnorm, z = st.step(x, G(g['ob']), x[:, 6:12].contiguous(), None, fake_x=G(g['fake_x']), fake_perm_idx=G(g['fake_perm_idx']),
+                               fake_det_label=G(g['fake_label']), future_vital_mask=G(g['fv_mask']),
+                               aux_label_dict={k: G(g['label_' + k]) for k in tasks})
+    for k in ('loss', 'ae_mse', 'future_vital', 'AKI_overall', 'ICU_24h', 'fake_detection'):
+        np.testing.assert_allclose(float(losses[k].detach()), float(g['loss_' + k]), rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(float(losses['kl'].detach()), float(g['loss_kl']), rtol=1e-5, atol=5e-8)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g['z'], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(float(gnorm), float(g['gnorm']), rtol=1e-4)
+    _check_after_step(net, g)
+
+
+def test_triplet_step_matches_reference():
+    """Fake detection + triplet margin on clustering_interp.Net (the only net with the triplet branch, :171-180, :234-236), loss
+    ae_mse_fake_detect_triplet, hinge active on part of the batch."""
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    g, sd0 = _overlay_state('triplet')
+    args = SimpleNamespace(num_variables=6, num_timestamps=g['x'].shape[-1], ref_points=int(g['R']), hours_from_admission=float(g['H']),
+                           dropout=0.0, aux_tasks={}, fake_detection=True, triple_margin=float(g['margin']), cluster_number=int(g['K']),
+                           loss='ae_mse_fake_detect_triplet', grad_clip=15.0, unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.},
+                           aux_pos_weights={})
+    dev = torch.device('cuda')
+    net = Net(args, dev).to(dev)
+    net.load_state_dict({k: torch.tensor(v) for k, v in sd0.items()}, strict=True)
+    net.train()
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args)
+    G = lambda a: torch.tensor(a, device=dev)                                   # noqa: E731
+    x = G(g['x'])
+    losses, gnorm, z = st.step(x, G(g['ob']), x[:, 6:12].contiguous(), None, fake_x=G(g['fake_x']), fake_perm_idx=G(g['fake_perm_idx']),
+                               positive_x=G(g['positive_x']), fake_det_label=G(g['fake_label']))
+    assert float(g['loss_triplet']) > 0.05
+    for k in ('loss', 'ae_mse', 'fake_detection', 'triplet'):
+        np.testing.assert_allclose(float(losses[k].detach()), float(g['loss_' + k]), rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(float(gnorm), float(g['gnorm']), rtol=1e-4)
+    _check_after_step(net, g)
