@@ -47,14 +47,15 @@ def parse():
     p.add_argument('--fake-detection', action='store_true',
                    help="upstream's default unsupervised loss ae_mse_fake_detect_kl (p3:78 minus the private supervised labels): "
                         "sci/cci/encoder run a second time on corrupted samples; NOT the headline configuration")
+    p.add_argument('--dropout', type=float, default=0.0, help='CompressFC / head dropout (upstream default 0.2; the headline uses 0)')
     p.add_argument('--no-tuned-gemm', action='store_true', help='library GEMMs with the default heuristics instead of the shipped table')
     p.add_argument('--cpu-seconds', type=float, default=15.0)
     p.add_argument('--kernel-iters', type=int, default=20)
     return p.parse_args()
 
 
-def make_args(K, fake_detection=False):
-    return SimpleNamespace(num_variables=C, num_timestamps=T, ref_points=R, hours_from_admission=H, dropout=0.0,
+def make_args(K, fake_detection=False, dropout=0.0):
+    return SimpleNamespace(num_variables=C, num_timestamps=T, ref_points=R, hours_from_admission=H, dropout=dropout,
                            aux_tasks={}, fake_detection=fake_detection, triple_margin=0.0, cluster_number=K,
                            loss='ae_mse_fake_detect_kl' if fake_detection else 'ae_mse_kl',
                            grad_clip=15.0, unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.},
@@ -209,7 +210,7 @@ def main():
     dev = torch.device('cuda', local % torch.cuda.device_count())       # (ranks may share a GPU under DIC_DIST_BACKEND=gloo)
     torch.cuda.set_device(dev)
     K = a.clusters or (8 if world == 8 else 4)
-    args = make_args(K, a.fake_detection)
+    args = make_args(K, a.fake_detection, a.dropout)
     from deep_interpolation_clustering_amd import tuned
     gemm_table = (not a.no_tuned_gemm) and a.dtype == 'bf16' and tuned.enable()      # read-only: pre-tuned hipBLASLt / rocBLAS picks
 

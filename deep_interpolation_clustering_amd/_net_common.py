@@ -69,14 +69,14 @@ class _Head(nn.Module):
     def forward(self, x):
         first, bn, drop, last = self.model[0], self.model[1], self.model[2], self.model[3]
         fast = (x.is_cuda and x.dim() == 2 and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
-                and last.in_features == ops.HEAD_IN and last.out_features in ops.BNHEAD_OUT and not (drop.training and drop.p > 0))
+                and last.in_features == ops.HEAD_IN and last.out_features in ops.BNHEAD_OUT)
         if not fast:
             return self.model(x)
         # bf16 step: BatchNorm -> Linear(128, <= 8) as the streaming kernels of csrc/dic_bnhead.hip (no ReLU in these heads);
         # the library picks a 256 x 16 macro-tile for the 2-wide output layer otherwise (0.33 ms for 65 536 rows)
         with torch.autocast('cuda', enabled=False):
             z = ops.rows_linear(x, first.weight, first.bias, bias_grad_is_zero=bn.training)
-            out = ops.bn_relu_head(z, bn, last, relu=False)
+            out = ops.bn_relu_head(z, bn, last, relu=False, dropout=drop)
         for tail in self.model[4:]:
             out = tail(out)
         return out

@@ -19,6 +19,45 @@ constexpr int BK = 128;       // BatchNorm width / Linear in_features (compiled 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Dropout between the activation and the Linear (nn.Dropout(p) in CompressFC / the heads, rbf.py:120, clustering_interp.py:51):
+// the keep mask is a counter-based hash of (seed, call counter, element index), recomputed in the backward -- no mask tensor.
+// One 64-bit murmur3 finaliser yields the decisions of two neighbouring columns (its low and high words).
+struct Drop {
+    float scale;              // 1 / (1 - p); 1 when dropout is off
+    unsigned int thresh;      // keep iff hash >= thresh = p * 2^32; 0 = keep all
+    unsigned long long key;   // seed ^ golden-ratio * counter
+};
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+// keep-and-scale factors of the 8 columns kc*8 .. kc*8+7 of `row`
+__device__ __forceinline__ void drop_factors(const Drop& d, long row, int kc, float (&f)[8]) {
+    if (d.thresh == 0u) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 1.f;
+        return;
+    }
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+        const unsigned long long hsh = mix64(d.key + (unsigned long long)(row * 64 + kc * 4 + e2));      // one hash per column pair
+        f[2 * e2] = (unsigned int)hsh >= d.thresh ? d.scale : 0.f;
+        f[2 * e2 + 1] = (unsigned int)(hsh >> 32) >= d.thresh ? d.scale : 0.f;
+    }
+}
+__device__ __forceinline__ Drop load_drop(float p, const unsigned long long* rng) {
+    Drop d;
+    d.scale = 1.f; d.thresh = 0u; d.key = 0ull;
+    if (p > 0.f && rng) {
+        d.scale = 1.0f / (1.0f - p);
+        d.thresh = (unsigned int)fminf(p * 4294967296.0f, 4294967040.0f);
+        d.key = rng[0] ^ (rng[1] * 0x9E3779B97F4A7C15ULL);
+    }
+    return d;
+}
+
 struct ColParams {            // per-lane constants for its 8 columns
     float scale[8], shift[8], mean[8], rstd[8];
 };
@@ -80,9 +119,11 @@ __global__ __launch_bounds__(256) void bn_colstats_finalize(const float* partial
 
 template <int C>
 __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
-                                                         const float* beta, const float* W, const float* b, long N, float floor_, float* v) {
+                                                         const float* beta, const float* W, const float* b, long N, float floor_, float drop_p,
+                                                         const unsigned long long* rng, float* v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
     const ColParams p = load_cols(mean, rstd, gamma, beta, kc);
+    const Drop drop = load_drop(drop_p, rng);
     float w[C][8];
 #pragma unroll
     for (int j = 0; j < C; ++j)
@@ -98,12 +139,13 @@ __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const 
         const bool live = row < N;
         bf16x8 x = {};
         if (live) x = *reinterpret_cast<const bf16x8*>(z + row * BK + kc * 8);
-        float acc[C];
+        float acc[C], keep[8];
+        drop_factors(drop, row, kc, keep);
 #pragma unroll
         for (int j = 0; j < C; ++j) acc[j] = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float h = fmaxf(fmaf((float)x[e], p.scale[e], p.shift[e]), floor_);      // floor_ = 0 (ReLU) or -inf (none)
+            const float h = fmaxf(fmaf((float)x[e], p.scale[e], p.shift[e]), floor_) * keep[e];      // floor_ = 0 (ReLU) or -inf (none)
 #pragma unroll
             for (int j = 0; j < C; ++j) acc[j] = fmaf(h, w[j][e], acc[j]);
         }
@@ -124,27 +166,30 @@ __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const 
 // recompute the post-ReLU activation h, x-hat and da = (dv W) 1[h > 0] for this lane's 8 columns of one row
 template <int C>
 __device__ __forceinline__ void recompute_row(const bf16x8 x, const ColParams& p, const float (&w)[C][8], const float (&g)[C],
-                                              float floor_, float (&h)[8], float (&xhat)[8], float (&da)[8]) {
+                                              float floor_, const float (&keep)[8], float (&h)[8], float (&xhat)[8], float (&da)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float xe = (float)x[e];
-        h[e] = fmaxf(fmaf(xe, p.scale[e], p.shift[e]), floor_);
+        const float act = fmaxf(fmaf(xe, p.scale[e], p.shift[e]), floor_);
+        h[e] = act * keep[e];                      // what the Linear saw (dropout applied): multiplies dv in dW
         xhat[e] = (xe - p.mean[e]) * p.rstd[e];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < C; ++j) s = fmaf(g[j], w[j][e], s);
-        da[e] = h[e] > floor_ ? s : 0.f;
+        da[e] = act > floor_ ? s * keep[e] : 0.f;
     }
 }
 
 // partials[blk][(2 + C) * BK + C]: sum da | sum da*xhat | dW[C][BK] | db[C]
 template <int C>
 __global__ __launch_bounds__(256) void bnhead_bwd_reduce_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
-                                                                const float* beta, const float* W, const float* dv, long N, float floor_, float* partials) {
+                                                                const float* beta, const float* W, const float* dv, long N, float floor_, float drop_p,
+                                                                const unsigned long long* rng, float* partials) {
     constexpr int NOUT = (2 + C) * BK + C;
     __shared__ float red[4][NOUT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
     const ColParams p = load_cols(mean, rstd, gamma, beta, kc);
+    const Drop drop = load_drop(drop_p, rng);
     float w[C][8];
 #pragma unroll
     for (int j = 0; j < C; ++j)
@@ -179,7 +224,9 @@ __global__ __launch_bounds__(256) void bnhead_bwd_reduce_kernel(const __bf16* z,
             for (int j = 0; j < C; ++j) gn[j] = dv[(row + stride) * C + j];
         }
         float h[8], xhat[8], da[8];
-        recompute_row<C>(x, p, w, g, floor_, h, xhat, da);
+        float keep[8];
+        drop_factors(drop, row, kc, keep);
+        recompute_row<C>(x, p, w, g, floor_, keep, h, xhat, da);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             sda[e] += da[e];
@@ -237,9 +284,11 @@ __global__ __launch_bounds__(256) void bnhead_bwd_finalize(const float* partials
 template <int C>
 __global__ __launch_bounds__(256) void bnhead_bwd_input_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
                                                                const float* beta, const float* W, const float* dv, const float* sum_da,
-                                                               const float* sum_dax, float inv_n, long N, float floor_, __bf16* dz) {
+                                                               const float* sum_dax, float inv_n, long N, float floor_, float drop_p, const unsigned long long* rng,
+                                                               __bf16* dz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
     const ColParams p = load_cols(mean, rstd, gamma, beta, kc);
+    const Drop drop = load_drop(drop_p, rng);
     float w[C][8], c1[8], c2[8];
 #pragma unroll
     for (int j = 0; j < C; ++j)
@@ -257,7 +306,9 @@ __global__ __launch_bounds__(256) void bnhead_bwd_input_kernel(const __bf16* z, 
 #pragma unroll
         for (int j = 0; j < C; ++j) g[j] = dv[row * C + j];
         float h[8], xhat[8], da[8];
-        recompute_row<C>(x, p, w, g, floor_, h, xhat, da);
+        float keep[8];
+        drop_factors(drop, row, kc, keep);
+        recompute_row<C>(x, p, w, g, floor_, keep, h, xhat, da);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (__bf16)(p.scale[e] * (da[e] - c1[e] - xhat[e] * c2[e]));
@@ -306,13 +357,14 @@ int dic_bn_colstats(const void* z, int64_t N, int K, double* sums, void* workspa
 }
 
 int dic_bnhead_fwd(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                   const float* b, int64_t N, int K, int C, int relu, float* v, dic_stream_t stream) {
+                   const float* b, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* v, dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_fwd: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_fwd: in_features %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && mean && rstd && gamma && beta && W && b && v, DIC_ERR_INVALID_ARG, "bnhead_fwd: NULL pointer");
+    DIC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), DIC_ERR_INVALID_ARG, "bnhead_fwd: dropout p=%g needs 0 <= p < 1 and an rng state", (double)drop_p);
     const int grid = bnhead_blocks(N);
     DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_fwd_kernel<C>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)z, mean,
-                                                rstd, gamma, beta, W, b, (long)N, relu ? 0.f : -INFINITY, v));
+                                                rstd, gamma, beta, W, b, (long)N, relu ? 0.f : -INFINITY, drop_p, (const unsigned long long*)rng, v));
     return check_launch("bnhead_fwd");
 }
 
@@ -322,8 +374,8 @@ size_t dic_bnhead_bwd_workspace(int64_t N, int K, int C) {
 }
 
 int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                          const float* dv, int64_t N, int K, int C, int relu, float* sums, void* workspace, size_t workspace_bytes,
-                          dic_stream_t stream) {
+                          const float* dv, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* sums,
+                          void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_bwd_reduce: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_bwd_reduce: in_features %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && mean && rstd && gamma && beta && W && dv && sums && workspace, DIC_ERR_INVALID_ARG, "bnhead_bwd_reduce: NULL pointer");
@@ -331,20 +383,21 @@ int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, c
     DIC_REQUIRE(workspace_bytes >= (size_t)nblk * nout * sizeof(float), DIC_ERR_WORKSPACE, "bnhead_bwd_reduce: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_bwd_reduce_kernel<C>, dim3(nblk), dim3(256), 0, st, (const __bf16*)z, mean, rstd, gamma,
-                                                beta, W, dv, (long)N, relu ? 0.f : -INFINITY, (float*)workspace));
+                                                beta, W, dv, (long)N, relu ? 0.f : -INFINITY, drop_p, (const unsigned long long*)rng, (float*)workspace));
     hipLaunchKernelGGL(bnhead_bwd_finalize, dim3((nout + 31) / 32), dim3(256), 0, st, (const float*)workspace, nblk, nout, sums);
     return check_launch("bnhead_bwd_reduce");
 }
 
 int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
                          const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, int relu,
-                         void* dz, dic_stream_t stream) {
+                         float drop_p, const uint64_t* rng, void* dz, dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_bwd_input: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_bwd_input: in_features %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && mean && rstd && gamma && beta && W && dv && sum_da && sum_dax && dz, DIC_ERR_INVALID_ARG, "bnhead_bwd_input: NULL pointer");
     const int grid = bnhead_blocks(N);
     DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_bwd_input_kernel<C>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)z, mean,
-                                                rstd, gamma, beta, W, dv, sum_da, sum_dax, (float)inv_n, (long)N, relu ? 0.f : -INFINITY, (__bf16*)dz));
+                                                rstd, gamma, beta, W, dv, sum_da, sum_dax, (float)inv_n, (long)N, relu ? 0.f : -INFINITY, drop_p,
+                                                (const unsigned long long*)rng, (__bf16*)dz));
     return check_launch("bnhead_bwd_input");
 }
 

@@ -334,7 +334,7 @@ class _BnReluHead(torch.autograd.Function):
     (v, mean, biased var, global row count); the moments are for the caller's running statistics."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, training, relu):
+    def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, training, relu, drop_p=0.0):
         N.require_gpu(z, gamma, beta, weight, bias)
         zb = z.to(torch.bfloat16).contiguous()
         n, k = zb.shape
@@ -356,24 +356,25 @@ class _BnReluHead(torch.autograd.Function):
         rstd = torch.rsqrt(var + eps)
         g, bt, w, b = N.f32c(gamma.detach()), N.f32c(beta.detach()), N.f32c(weight.detach()), N.f32c(bias.detach())
         v = torch.empty((n, c), device=dev, dtype=torch.float32)
-        N.check(L.dic_bnhead_fwd(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(b), n, k, c, int(relu), N.ptr(v), st),
+        rng = _dropout_rng(dev) if drop_p > 0 else torch.zeros(2, dtype=torch.int64, device=dev)
+        N.check(L.dic_bnhead_fwd(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(b), n, k, c, int(relu), float(drop_p), N.ptr(rng), N.ptr(v), st),
                 'dic_bnhead_fwd')
-        ctx.save_for_backward(zb, mean, rstd, g, bt, w, cnt)
-        ctx.z_dtype, ctx.training, ctx.relu = z.dtype, bool(training), int(relu)
+        ctx.save_for_backward(zb, mean, rstd, g, bt, w, cnt, rng)
+        ctx.z_dtype, ctx.training, ctx.relu, ctx.drop_p = z.dtype, bool(training), int(relu), float(drop_p)
         ctx.mark_non_differentiable(mean, var, cnt)
         return v, mean, var, cnt
 
     @staticmethod
     def backward(ctx, dv, _m, _v, _c):
-        zb, mean, rstd, g, bt, w, cnt = ctx.saved_tensors
+        zb, mean, rstd, g, bt, w, cnt, rng = ctx.saved_tensors
         n, k = zb.shape
         c = w.shape[0]
         L, dev, st = N.lib(), zb.device, N.stream_of(zb)
         gv = N.f32c(dv)
         sums = torch.empty((2 + c) * k + c, device=dev, dtype=torch.float32)
         ws = _ws(L.dic_bnhead_bwd_workspace(n, k, c), dev)
-        N.check(L.dic_bnhead_bwd_reduce(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), n, k, c, ctx.relu, N.ptr(sums),
-                                        N.ptr(ws), ws.numel(), st), 'dic_bnhead_bwd_reduce')
+        N.check(L.dic_bnhead_bwd_reduce(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), n, k, c, ctx.relu, ctx.drop_p, N.ptr(rng),
+                                        N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bnhead_bwd_reduce')
         dbeta, dgamma = sums[:k], sums[k:2 * k]                 # this rank's share; the gradient all-reduce sums them
         dw, db = sums[2 * k:(2 + c) * k].view(c, k), sums[(2 + c) * k:]
         dz = None
@@ -386,21 +387,35 @@ class _BnReluHead(torch.autograd.Function):
                 red = torch.zeros(2 * k, device=dev, dtype=torch.float32)
             dz = torch.empty_like(zb)
             N.check(L.dic_bnhead_bwd_input(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), N.ptr(red),
-                                           N.ptr(red[k:]), 1.0, n, k, c, ctx.relu, N.ptr(dz), st), 'dic_bnhead_bwd_input')
+                                           N.ptr(red[k:]), 1.0, n, k, c, ctx.relu, ctx.drop_p, N.ptr(rng), N.ptr(dz), st), 'dic_bnhead_bwd_input')
             dz = dz.to(ctx.z_dtype)
-        return dz, dgamma, dbeta, dw, db, None, None, None, None, None
+        return dz, dgamma, dbeta, dw, db, None, None, None, None, None, None
 
 
 BNHEAD_OUT = (1, 2, 3, 4, 5, 6, 7, 8)
+_DROP_STATE = {}
 
 
-def bn_relu_head(z, bn, linear, relu=True):
+def _dropout_rng(device):
+    """(seed, call counter) for the in-kernel dropout mask, as a fresh 2-word device tensor for ONE forward/backward pair.  The
+    per-device counter advances with an in-place device add, so a captured hipGraph draws a new mask on every replay."""
+    key = (device.type, device.index)
+    st = _DROP_STATE.get(key)
+    if st is None:
+        st = _DROP_STATE[key] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+    st[1:] += 1
+    return st.clone()
+
+
+def bn_relu_head(z, bn, linear, relu=True, dropout=None):
     """``linear(relu(bn(z)))`` (``relu=False``: ``linear(bn(z))``) for an nn.BatchNorm1d(128) and an nn.Linear(128, C <= 8) on (N,128) bf16 rows, with the
     module semantics of BatchNorm1d (batch moments + running statistics in training mode, running statistics in
-    eval mode) and moments over the GLOBAL batch when the batch is sharded over ranks (dist.GlobalBatchNorm1d)."""
+    eval mode) and moments over the GLOBAL batch when the batch is sharded over ranks (dist.GlobalBatchNorm1d).  ``dropout``: the
+    nn.Dropout between the activation and ``linear`` (active when in training mode with p > 0; the mask is drawn in-kernel)."""
     training = bn.training or bn.running_mean is None
+    drop_p = float(dropout.p) if (dropout is not None and dropout.training) else 0.0
     v, mean, var, cnt = _BnReluHead.apply(z, bn.weight, bn.bias, linear.weight, linear.bias, bn.eps, bn.running_mean,
-                                          bn.running_var, training, relu)
+                                          bn.running_var, training, relu, drop_p)
     if bn.training and bn.track_running_stats:
         with torch.no_grad():
             bn.num_batches_tracked += 1

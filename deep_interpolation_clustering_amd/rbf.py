@@ -30,10 +30,10 @@ class CompressFC(nn.Module):
         with torch.autocast('cuda', enabled=False):
             # split-K weight gradient; the bias sits in front of BatchNorm: its gradient is identically 0 in training mode
             z = ops.rows_linear(rec_input, first.weight, first.bias, bias_grad_is_zero=bn.training)
-        if last.out_features in ops.BNHEAD_OUT and not (drop.training and drop.p > 0):
-            # BatchNorm -> ReLU -> Linear in four streaming passes over z, the hidden activation never materialised
+        if last.out_features in ops.BNHEAD_OUT:
+            # BatchNorm -> ReLU -> Dropout -> Linear in four streaming passes over z, the hidden activation never materialised
             with torch.autocast('cuda', enabled=False):
-                return ops.bn_relu_head(z, bn, last)
+                return ops.bn_relu_head(z, bn, last, dropout=drop)
         hidden = drop(self.model[2](bn(z)))
         with torch.autocast('cuda', enabled=False):
             return ops.head_linear(hidden, last.weight, last.bias)

@@ -239,18 +239,20 @@ int dic_head_bwd(const void* h, const float* W, const float* dv, int64_t N, int 
  *   dic_bnhead_bwd_input:  dz (N,128) bf16 = gamma rstd (da - sum_da*inv_n - xhat sum_dax*inv_n); inv_n = 1 /
  *                          global row count in training mode; pass zero sums for eval-mode BatchNorm.
  * relu = 0 drops the ReLU: BatchNorm1d(128) -> Linear(128, C), the tail of the auxiliary / fake-detection heads
- * (clustering_interp.py:43-87). */
+ * (clustering_interp.py:43-87).  drop_p > 0 applies nn.Dropout(p) between the activation and the Linear (rbf.py:120): the
+ * keep mask is a hash of (rng[0] = seed, rng[1] = call counter, element index) -- rng is a 2-word device buffer that the
+ * caller keeps unchanged between a forward and its backward calls -- so no mask tensor exists. */
 size_t dic_bn_colstats_workspace(int64_t N, int K);
 int dic_bn_colstats(const void* z, int64_t N, int K, double* sums, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 int dic_bnhead_fwd(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                   const float* b, int64_t N, int K, int C, int relu, float* v, dic_stream_t stream);
+                   const float* b, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* v, dic_stream_t stream);
 size_t dic_bnhead_bwd_workspace(int64_t N, int K, int C);
 int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                          const float* dv, int64_t N, int K, int C, int relu, float* sums, void* workspace, size_t workspace_bytes,
-                          dic_stream_t stream);
+                          const float* dv, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* sums,
+                          void* workspace, size_t workspace_bytes, dic_stream_t stream);
 int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
                          const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, int relu,
-                         void* dz, dic_stream_t stream);
+                         float drop_p, const uint64_t* rng, void* dz, dic_stream_t stream);
 
 /* ------------------------------------------------- K-sweep statistics (p2, internal_eval) ------
  * One pass over all N^2 point pairs, nothing n x n materialised.  Replaces sklearn pairwise_distances per

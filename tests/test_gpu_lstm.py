@@ -233,3 +233,68 @@ def test_aux_head_fast_path_matches_module_path():
             continue                                      # identically zero in front of a training-mode BatchNorm (noise upstream)
         a, b = p.grad.cpu().numpy(), q.grad.cpu().numpy()
         assert np.abs(a - b).max() < 3e-2 * max(np.abs(b).max(), 1e-6), k
+
+
+def _host_keep_mask(seed, counter, n_rows, p):
+    """NumPy restatement of the in-kernel dropout decision (csrc/dic_bnhead.hip drop_factors): murmur3's 64-bit finaliser of
+    key + (row * 64 + column pair); low word -> even column, high word -> odd column; keep iff word >= p * 2^32."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over='ignore'):
+        key = np.uint64(seed) ^ (np.uint64(counter) * np.uint64(0x9E3779B97F4A7C15))
+        idx = (np.arange(n_rows, dtype=np.uint64)[:, None] * np.uint64(64) + np.arange(64, dtype=np.uint64)[None, :])
+        x = (key + idx) & M
+        x ^= x >> np.uint64(33); x = (x * np.uint64(0xff51afd7ed558ccd)) & M
+        x ^= x >> np.uint64(33); x = (x * np.uint64(0xc4ceb9fe1a85ec53)) & M
+        x ^= x >> np.uint64(33)
+    thresh = np.uint64(min(np.float32(p) * np.float32(4294967296.0), np.float32(4294967040.0)))
+    lo, hi = x & np.uint64(0xFFFFFFFF), x >> np.uint64(32)
+    keep = np.empty((n_rows, 128), dtype=bool)
+    keep[:, 0::2], keep[:, 1::2] = lo >= thresh, hi >= thresh
+    return keep
+
+
+@pytest.mark.parametrize('relu', [True, False])
+def test_bn_head_dropout_matches_torch_with_the_same_mask(relu):
+    """nn.Dropout between the activation and the Linear, drawn inside the kernels: the mask is re-derived on the host from the
+    (seed, counter) the call used, and the fused forward / backward must equal torch with exactly that mask."""
+    import copy
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(4)
+    dev = torch.device('cuda')
+    N_, C, p = 6000, 6, 0.3
+    bn = torch.nn.BatchNorm1d(128).to(dev).train()
+    lin = torch.nn.Linear(128, C).to(dev)
+    drop = torch.nn.Dropout(p).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+    bn_ref, lin_ref = copy.deepcopy(bn), copy.deepcopy(lin)
+    z = (torch.randn(N_, 128, device=dev) * 1.5 + 0.3).to(torch.bfloat16)
+    cot = torch.randn(N_, C, device=dev)
+    z1 = z.clone().requires_grad_()
+    v = ops.bn_relu_head(z1, bn, lin, relu=relu, dropout=drop)
+    seed, counter = (int(t) for t in ops._DROP_STATE[(z.device.type, z.device.index)].tolist())      # the state this call used
+    (v * cot).sum().backward()
+    keep = torch.tensor(_host_keep_mask(seed, counter, N_, p), device=dev)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+    z2 = z.float().clone().requires_grad_()
+    a = bn_ref(z2)
+    a = torch.relu(a) if relu else a
+    ref = lin_ref(a * keep / (1 - p))
+    (ref * cot).sum().backward()
+
+    def close(x, y, tol):
+        x, y = x.detach().float().cpu().numpy(), y.detach().float().cpu().numpy()
+        np.testing.assert_allclose(x, y, rtol=tol, atol=tol * max(float(np.abs(y).max()), 1e-6))
+    close(v, ref, 2e-5)
+    close(z1.grad, z2.grad, 1e-2)
+    close(lin.weight.grad, lin_ref.weight.grad, 2e-4)
+    close(lin.bias.grad, lin_ref.bias.grad, 2e-4)
+    close(bn.weight.grad, bn_ref.weight.grad, 2e-4)
+    close(bn.bias.grad, bn_ref.bias.grad, 2e-4)
+    # a second call draws a different mask; eval mode draws none
+    v2 = ops.bn_relu_head(z.clone(), bn, lin, relu=relu, dropout=drop)
+    assert not torch.equal(v2, v.detach())
+    drop.eval(); bn.eval()
+    e1, e2 = ops.bn_relu_head(z.clone(), bn, lin, relu=relu, dropout=drop), ops.bn_relu_head(z.clone(), bn, lin, relu=relu, dropout=drop)
+    assert torch.equal(e1, e2)
