@@ -216,3 +216,31 @@ def test_triplet_step_matches_reference():
         np.testing.assert_allclose(float(losses[k].detach()), float(g['loss_' + k]), rtol=1e-5, err_msg=k)
     np.testing.assert_allclose(float(gnorm), float(g['gnorm']), rtol=1e-4)
     _check_after_step(net, g)
+
+
+def test_hip_graph_replays_draw_fresh_dropout_masks():
+    """With dropout active the captured step must not freeze its mask: the per-device call counter advances inside the graph, so
+    two replays on identical inputs and (restored) identical parameters see different masks -> different losses."""
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.5, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=4, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    coh = synthetic.make_cohort(256, seed=8)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    torch.manual_seed(4)
+    net = Net(args, dev).to(dev)
+    net.train()
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 0.0, 0.0), args, autocast_dtype=torch.bfloat16, use_graphs=True)   # lr 0: parameters stay put
+    vals = []
+    for _ in range(4):
+        losses, _, _ = st.step(X, OB, None, LEN)
+        vals.append(float(losses['ae_mse'].detach()))
+    assert len(st._graphs) == 1 and len(set(vals)) == 4, vals
+    net.eval()                                    # dropout off: the (re-captured, eval-mode) step is deterministic
+    e = [float(st.forward_loss(X, OB, None, LEN)[0]['ae_mse'].detach()) for _ in range(2)]
+    assert e[0] == e[1]
