@@ -101,6 +101,17 @@ __device__ void cci_epilogue(const float* res, const float* kmat, float* mean, f
     }
 }
 
+#ifdef DIC_K1_EXP_TIMING        // experiment: cycle stamps of thread 0 of a few workgroups (scripts/k1_experiments.sh timing)
+__device__ unsigned long long dic_k1_stamps[64][8];
+#define K1_STAMP(slot)                                                                         \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x % 127 == 5 && blockIdx.x / 127 < 64)                \
+            dic_k1_stamps[blockIdx.x / 127][slot] = __builtin_readcyclecounter();              \
+    } while (0)
+#else
+#define K1_STAMP(slot) do {} while (0)
+#endif
+
 // S = lanes that split one (row, grid point) item; U = unroll of the streaming loops.
 template <bool RAGGED, int S>
 __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
@@ -123,6 +134,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
     const int nrows = Ev * C;
     int* tile_max = cnt + E * C;
 
+    K1_STAMP(0);
     // ---- 1. row lengths + parameters
     if (tid == 0) *tile_max = 0;
     __syncthreads();
@@ -141,6 +153,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
         for (int i = tid; i < C * C; i += kBlock) kmat[i] = a.cci_kernel[i];
     __syncthreads();
 
+    K1_STAMP(1);
     // ---- 2. stage (time,value) rows into LDS: one wave per 64-slot chunk of a row, 4 chunks in flight per
     //         wave.  Every row is padded with zero-weight sentinels up to the tile maximum (+ loop tail), so
     //         the streaming loops below run wave-uniform trip counts with no per-lane bounds checks.
@@ -186,6 +199,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
     }
     __syncthreads();
 
+    K1_STAMP(2);
     // ---- 3. items (row, grid point, split): two passes over the LDS row
     const int nitems = nrows * R * S;
     for (int base = 0; base < nitems; base += kBlock) {
@@ -204,7 +218,11 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) nw = max(nw, __shfl_xor(nw, m));
         nw = __builtin_amdgcn_readfirstlane(nw);
+#ifdef DIC_K1_EXP_NOLOOP         // experiment (scripts/k1_experiments.sh): everything except the two streaming passes
+        const int nj = 0;
+#else
         const int nj = ((nw + S - 1) / S + U - 1) / U * U;      // per-lane elements, padded to the unroll
+#endif
 
         // min_t u: u >= 0, so its IEEE bit pattern orders like an unsigned integer (v_min_u32: no NaN
         // canonicalisation, and the compiler keeps the loop branch-free)
@@ -267,6 +285,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
     }
     __syncthreads();
 
+    K1_STAMP(3);
     // ---- 4. epilogue
     if (a.cci_kernel) {
         cci_epilogue(res, kmat, smem + L.mean, smem + L.lse, smem + L.amat, Ev, C, R, e0, a.out);
@@ -278,6 +297,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
             o[0] = base[0];  o[C] = base[C * R];  o[2 * C] = base[2 * C * R];
         }
     }
+    K1_STAMP(4);
 }
 
 // Stand-alone CCI forward: load s (B,R,3C) into the LDS result layout, run the epilogue.
@@ -576,6 +596,12 @@ static void bwd_geometry(int B, int C, int R, int* E, int* nblk, size_t* lds) {
 using namespace dic;
 
 extern "C" {
+
+#ifdef DIC_K1_EXP_TIMING
+int dic_k1_debug_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dic_k1_stamps), sizeof(unsigned long long) * 64 * 8);
+}
+#endif
 
 int dic_sci_cci_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
                     const float* sci_kernel, const float* cci_kernel, float* out, float* saved,

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Where does sci_cci_fwd's time go?  Rebuild with the streaming passes removed and compare (scripts/kbench.py).
+set -e
+cd "$(dirname "$0")/.."
+build() {
+  rm -f deep_interpolation_clustering_amd/csrc/dic_interp.o
+  make -s -C deep_interpolation_clustering_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$PWD/include -Wall -Wno-unused-function $1" > /dev/null 2>&1
+}
+if [ "$1" == "timing" ]; then
+  build "-DDIC_K1_EXP_TIMING"; python scripts/k1_timing.py 2>&1 | grep -v amdgpu.ids
+  build ""; exit 0
+fi
+for flags in "" "-DDIC_K1_EXP_NOLOOP"; do
+  build "$flags"; echo "== flags: [$flags]"
+  python scripts/kbench.py 32768 10 2>/dev/null | grep "sci_cci_fwd"
+done
+build ""
