@@ -17,6 +17,9 @@
 // channel the kernel sits on the fp32-VALU/HBM ridge.
 #include "dic_common.h"
 
+#ifndef DIC_K1_LDS_BUDGET
+#define DIC_K1_LDS_BUDGET (24 * 1024)
+#endif
 namespace dic {
 
 struct InterpLayout {   // LDS carve-up, identical on host and device
@@ -550,7 +553,7 @@ static int interp_fwd_launch(InterpArgs a, bool ragged, hipStream_t st) {
     const int fixed = one.total_words - per_enc;
     DIC_REQUIRE((size_t)one.total_words * 4 <= 64 * 1024, DIC_ERR_UNSUPPORTED,
                 "sci_cci_fwd: one encounter needs %d B of LDS (C=%d T=%d R=%d)", one.total_words * 4, a.C, a.Tcap, a.R);
-    a.E = pick_tile(a.B, per_enc, fixed, 24 * 1024, 16);     // <= 24 KB of LDS: 6+ workgroups per CU hide the staging latency
+    a.E = pick_tile(a.B, per_enc, fixed, DIC_K1_LDS_BUDGET, 16);     // <= 24 KB of LDS: 6+ workgroups per CU hide the staging latency
     // lanes per item: fill the 256 threads evenly (rounds of 256 items) without shrinking the per-lane
     // stream below ~8 elements (the split costs 9 x log2(S) shuffles per item)
     int S = 1, logS = 0;
