@@ -436,6 +436,11 @@ def splitk_tn(a, b, chunks=(8192, 4096, 2048)):
     for c in chunks:
         if n % c == 0 and n >= 2 * c:
             return torch.bmm(a.unflatten(0, (n // c, c)).transpose(1, 2), b.unflatten(0, (n // c, c))).float().sum(0)
+    c = chunks[0]
+    if n >= 4 * c:            # row counts that are not a multiple of a chunk (batch 10 000, 75 000, ...): chunked body + a short tail
+        m = n // c * c
+        body = torch.bmm(a[:m].unflatten(0, (m // c, c)).transpose(1, 2), b[:m].unflatten(0, (m // c, c))).float().sum(0)
+        return body + (a[m:].t() @ b[m:]).float()
     return (a.t() @ b).float()
 
 

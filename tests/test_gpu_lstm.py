@@ -298,3 +298,19 @@ def test_bn_head_dropout_matches_torch_with_the_same_mask(relu):
     drop.eval(); bn.eval()
     e1, e2 = ops.bn_relu_head(z.clone(), bn, lin, relu=relu, dropout=drop), ops.bn_relu_head(z.clone(), bn, lin, relu=relu, dropout=drop)
     assert torch.equal(e1, e2)
+
+
+@pytest.mark.parametrize('n', [8192 * 3, 8192 * 5 + 1000, 70000, 1000])
+def test_splitk_tn_matches_plain_product(n):
+    """a^T b over row chunks (+ tail) == the plain product, for row counts that are and are not multiples of the chunk."""
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(n)
+    a = (torch.randn(n, 96, device='cuda') * 0.1).to(torch.bfloat16)
+    b = torch.randn(n, 40, device='cuda').to(torch.bfloat16)
+    ref = a.double().t() @ b.double()
+    got = ops.splitk_tn(a, b)
+    assert got.dtype == torch.float32
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=6e-3 * float(ref.abs().max()))
+    s = ops.splitk_tn(a[100:, :64], b[:-100, 8:])              # strided views, as the per-direction dW_hh uses them
+    np.testing.assert_allclose(s.cpu().numpy(), (a[100:, :64].double().t() @ b[:-100, 8:].double()).cpu().numpy(), rtol=0,
+                               atol=6e-3 * float(ref.abs().max()))
