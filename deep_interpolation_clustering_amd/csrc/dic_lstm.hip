@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
             wf[g][ks] = *reinterpret_cast<const bf16x8*>(a.whh + ((size_t)(dir * 4 + g) * LH + 32 * w + r) * LH + ks * 16 + 8 * hh);
+    // A-operand slices of the 32x32 identity for the two 16-wide k-steps: lane (row r, k-group hh) holds I[r][ks*16 + 8hh + j]
+    bf16x8 eye[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) eye[ks][j] = (__bf16)((r == ks * 16 + 8 * hh + j) ? 1.0f : 0.0f);
     bf16x8 wx[4][LXK / 16];
     if constexpr (PROJ) {
 #pragma unroll
@@ -171,19 +177,20 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
         if constexpr (PROJ) {
             if (step + 1 < R) xnext = load_x(step + 1);        // in flight across the MFMA and gate-math phases
         } else {
-            // accumulators start from the input projection of this step
+            // accumulators start from the input projection of this step, brought into the accumulator layout BY the matrix core:
+            // acc = I . gx^T with two 32x16 slices of the identity as A operand and 16-B row pieces of the staged tile as B
+            // (exact: 1.0 x bf16 in f32).  16 ds_read_b128 + 16 MFMAs per wave instead of 64 ds_read_b64 + 128 conversions.
 #pragma unroll
-            for (int nb = 0; nb < LNB; ++nb) {
-                const __bf16* gp = gst + (nb * 32 + r) * GSTR + 32 * w + 4 * hh;
+            for (int nb = 0; nb < LNB; ++nb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g) {
+                    const __bf16* gp = gst + (nb * 32 + r) * GSTR + g * LH + 32 * w + 8 * hh;
+                    f32x16 z;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bf16x4 v = *reinterpret_cast<const bf16x4*>(gp + g * LH + 8 * q);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[g][nb][4 * q + j] = (float)v[j];
-                    }
-            }
+                    for (int k = 0; k < 16; ++k) z[k] = 0.f;
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eye[0], *reinterpret_cast<const bf16x8*>(gp), z, 0, 0, 0);
+                    acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eye[1], *reinterpret_cast<const bf16x8*>(gp + 16), z, 0, 0, 0);
+                }
             __syncthreads();                                   // every wave has read its part of the staged tile
             if (step + 1 < R) request_gx(step + 1);
         }
