@@ -196,10 +196,11 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
         }
         DIC_STAMP(0, step, 1);
         const bool last = step == R - 1;
-        // One 32-row half at a time: MFMAs, then gate math + stores.  The stores of a half (48 KB per workgroup) drain while
-        // the next half's MFMAs (or the next step's LDS phase) run, instead of all 96 KB queueing behind one long MFMA phase.
-#pragma unroll
-        for (int nb = 0; nb < LNB; ++nb) {
+        // Software pipeline over the two 32-row halves: the MFMAs of half 1 are issued between the four gate-math groups of
+        // half 0 (an MFMA occupies the vector issue port for 8 of its 32 cycles: the transcendental-heavy gate math runs in its
+        // shadow), and the stores of half 0 drain while half 1 computes.
+        static_assert(LNB == 2, "the half-step software pipeline is written for two 32-row halves");
+        auto x_part = [&](int nb) {
             if constexpr (PROJ) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -213,18 +214,16 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                     for (int g = 0; g < 4; ++g) acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[g][ks], xb, acc[g][nb], 0, 0, 0);
                 }
             }
-            // G += W_hh . h_{t-1}^T
+        };
+        auto h_part = [&](int nb, int ks) {        // G += W_hh . h_{t-1}^T, one k-step
+            const bf16x8 hb = *reinterpret_cast<const bf16x8*>(&hbuf[cur][(nb * 32 + r) * HSTR + ks * 16 + 8 * hh]);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 hb = *reinterpret_cast<const bf16x8*>(&hbuf[cur][(nb * 32 + r) * HSTR + ks * 16 + 8 * hh]);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g][ks], hb, acc[g][nb], 0, 0, 0);
-            }
-            // gate math, register-local
+            for (int g = 0; g < 4; ++g) acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g][ks], hb, acc[g][nb], 0, 0, 0);
+        };
+        auto gate_math = [&](int nb, int q) {      // register-local: the four gates of a unit sit in the same lane / register
             const int b = b0 + nb * 32 + r;
             const bool ok = b < B;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+
                 const int u = 32 * w + 8 * q + 4 * hh;
                 bf16x4 hb, ib, fb, gb, ob;
                 f32x4 cv, hv;
@@ -265,9 +264,20 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                         *reinterpret_cast<f32x4*>(a.cn + ((size_t)dir * B + b) * LH + u) = cv;
                     }
                 }
-            }
-            if (nb == 0) DIC_STAMP(0, step, 2);
+                    };
+        x_part(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) h_part(0, ks);
+        x_part(1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            gate_math(0, q);
+            h_part(1, 2 * q);
+            h_part(1, 2 * q + 1);
         }
+        DIC_STAMP(0, step, 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gate_math(1, q);
         if constexpr (PROJ) {
             if (step + 1 < R) *reinterpret_cast<bf16x8*>(gst + (cur ^ 1) * LBM * XSTR + xrow * XSTR + xpc * 8) = xnext;
         }
