@@ -334,41 +334,85 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         }
     }
 
-    // Software pipeline: the saved gates / c_prev / dout of step s+1 are requested while step s runs its LDS,
-    // store and MFMA phases (one workgroup per CU: nothing else would hide the HBM latency).
+    // Software pipeline over the two 32-row halves, each an independent recurrence chain, half a step apart:
+    //     phase X(s):  MFMA + row stores of half 0, step s   ||   gate-gradient math of half 1, step s
+    //     phase Y(s):  MFMA + row stores of half 1, step s   ||   gate-gradient math of half 0, step s+1
+    // The VALU-heavy math of one half issues in the shadow of the other half's MFMAs, and the inputs of (half, step+1) are
+    // requested right after (half, step) has consumed its registers -- a full step before they are needed, with the same
+    // 96 VGPRs the one-deep pipeline used.  One barrier per phase: it publishes the half just written to LDS and retires the
+    // reads of the half about to be overwritten.
+    static_assert(LNB == 2, "the half-step software pipeline is written for two 32-row halves");
     struct StepIn { bf16x4 ib, fb, gb, ob, go, cp; };
-    StepIn cur[LNB][4], nxt[LNB][4];
-    auto load_step = [&](int step, StepIn (&dst)[LNB][4]) {
+    StepIn in[LNB][4];
+    auto load_half = [&](int nb, int step) {
         const int t = dir ? step : R - 1 - step;           // reverse of the forward visiting order
         const bool first_fwd = step == R - 1;               // this t was the forward pass' first step
         const int tp = dir ? t + 1 : t - 1;                 // forward predecessor
+        const int b = min(b0 + nb * 32 + r, B - 1);
+        const int bt = blockIdx.x * LNB + nb;
 #pragma unroll
-        for (int nb = 0; nb < LNB; ++nb) {
-            const int b = min(b0 + nb * 32 + r, B - 1);
-            const int bt = blockIdx.x * LNB + nb;
+        for (int q = 0; q < 4; ++q) {
+            const int u = 32 * w + 8 * q + 4 * hh;
+            StepIn& d = in[nb][q];
+            d.ib = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
+            d.fb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
+            d.gb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
+            d.ob = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
+            bf16x4 cp = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
+            else if (a.c0) {
+                const f32x4 c0v = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + b) * LH + u);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int u = 32 * w + 8 * q + 4 * hh;
-                StepIn& d = dst[nb][q];
-                d.ib = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
-                d.fb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
-                d.gb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
-                d.ob = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
-                bf16x4 cp = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
-                else if (a.c0) {
-                    const f32x4 c0v = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + b) * LH + u);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) cp[j] = (__bf16)c0v[j];
-                }
-                d.cp = cp;
-                bf16x4 go = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + u);
-                d.go = go;
+                for (int j = 0; j < 4; ++j) cp[j] = (__bf16)c0v[j];
             }
+            d.cp = cp;
+            bf16x4 go = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + u);
+            d.go = go;
         }
     };
-    {   // prologue: c of the first visited step, then its inputs
+    // gate gradients of hidden units 32w + 8q + 4hh .. +3 of half nb -> its rows of the LDS dG tile; dc and the c carry advance
+    auto math_q = [&](int nb, int q) {
+        const int u = 32 * w + 8 * q + 4 * hh;
+        const StepIn& x = in[nb][q];
+        bf16x4 di, df, dg, dO;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * q + j;
+            const float ig = (float)x.ib[j], fg = (float)x.fb[j], gg = (float)x.gb[j], og = (float)x.ob[j];
+            const float dht = dh[nb][k] + (float)x.go[j];
+            const float tc = tanh_fast(ccar[nb][k]);
+            const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
+            const float vi = dct * gg * ig * (1.0f - ig), vf = dct * (float)x.cp[j] * fg * (1.0f - fg);
+            const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
+            di[j] = (__bf16)vi; df[j] = (__bf16)vf; dg[j] = (__bf16)vg; dO[j] = (__bf16)vo;
+            dc[nb][k] = dct * fg;
+            ccar[nb][k] = (float)x.cp[j];                 // this step's c_prev is the next visited step's c
+        }
+        __bf16* lp = dgt + (nb * 32 + r) * GSTR + u;
+        *reinterpret_cast<bf16x4*>(lp) = di;
+        *reinterpret_cast<bf16x4*>(lp + LH) = df;
+        *reinterpret_cast<bf16x4*>(lp + 2 * LH) = dg;
+        *reinterpret_cast<bf16x4*>(lp + 3 * LH) = dO;
+    };
+    // one of this wave's 8 rows of half nb: dG row LDS -> global (whole 1-KiB row per wave instruction, row-major for the
+    // weight-gradient GEMMs) + bias column sums, then four k-steps of dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n]
+    auto row_and_mfma = [&](int nb, int k, int t) {
+        const int rowl = nb * 32 + k * 4 + w;
+        const int b = b0 + rowl;
+        if (b < B) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(dgt + rowl * GSTR + lane * 8);
+            *reinterpret_cast<bf16x8*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
+        }
+#pragma unroll
+        for (int ks = 4 * k; ks < 4 * k + 4; ++ks) {
+            const bf16x8 gbv = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + r) * GSTR + ks * 16 + 8 * hh);
+            dh[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, dh[nb], 0, 0, 0);
+        }
+    };
+    {   // prologue: c of the first visited step, the inputs of both halves, and half 0's first gate gradients
         const int t0 = dir ? 0 : R - 1;
 #pragma unroll
         for (int nb = 0; nb < LNB; ++nb)
@@ -378,78 +422,50 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ccar[nb][4 * q + j] = (float)ct[j];
             }
-        load_step(0, cur);
+        load_half(0, 0);
+        load_half(1, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) math_q(0, q);
+        if (R > 1) load_half(0, 1);
     }
 
     for (int step = 0; step < R; ++step) {
         const int t = dir ? step : R - 1 - step;
         DIC_STAMP(1, step, 0);
+        __syncthreads();                                   // half 0 of dG_t is complete; nobody reads half 1 of the previous step any more
+        DIC_STAMP(1, step, 1);
+        // ---- phase X: MFMA + stores of half 0  ||  math of half 1
 #pragma unroll
-        for (int nb = 0; nb < LNB; ++nb) {
+        for (int k = 0; k < 16; ++k) dh[0][k] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            math_q(1, q);
+            row_and_mfma(0, 2 * q, t);
+            row_and_mfma(0, 2 * q + 1, t);
+        }
+        if (step + 1 < R) load_half(1, step + 1);          // half 1's registers are free: a full step of lead time
+        DIC_STAMP(1, step, 2);
+        __syncthreads();                                   // half 1 of dG_t is complete; the reads of half 0 have retired
+        DIC_STAMP(1, step, 3);
+        // ---- phase Y: MFMA + stores of half 1  ||  math of half 0 for the next step
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dh[1][k] = 0.f;
+        if (step + 1 < R) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int u = 32 * w + 8 * q + 4 * hh;
-                const StepIn& in = cur[nb][q];
-                bf16x4 di, df, dg, dO;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = 4 * q + j;
-                    const float ig = (float)in.ib[j], fg = (float)in.fb[j], gg = (float)in.gb[j], og = (float)in.ob[j];
-                    const float dht = dh[nb][k] + (float)in.go[j];
-                    const float tc = tanh_fast(ccar[nb][k]);
-                    const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
-                    const float vi = dct * gg * ig * (1.0f - ig), vf = dct * (float)in.cp[j] * fg * (1.0f - fg);
-                    const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
-                    di[j] = (__bf16)vi; df[j] = (__bf16)vf; dg[j] = (__bf16)vg; dO[j] = (__bf16)vo;
-                    dc[nb][k] = dct * fg;
-                    ccar[nb][k] = (float)in.cp[j];                 // this step's c_prev is the next visited step's c
-                }
-                __bf16* lp = dgt + (nb * 32 + r) * GSTR + u;
-                *reinterpret_cast<bf16x4*>(lp) = di;
-                *reinterpret_cast<bf16x4*>(lp + LH) = df;
-                *reinterpret_cast<bf16x4*>(lp + 2 * LH) = dg;
-                *reinterpret_cast<bf16x4*>(lp + 3 * LH) = dO;
+                math_q(0, q);
+                row_and_mfma(1, 2 * q, t);
+                row_and_mfma(1, 2 * q + 1, t);
             }
-        }
-        DIC_STAMP(1, step, 1);
-        if (step + 1 < R) load_step(step + 1, nxt);        // in flight across the store / MFMA phases below
-        __syncthreads();
-        DIC_STAMP(1, step, 2);
-        // dG_t -> global, row-major for the weight-gradient GEMMs: re-read the LDS tile so that every wave instruction stores
-        // one whole 1-KiB row (the accumulator layout would scatter 32 x 16-B pieces) -- interleaved, one row per two
-        // k-steps, with  dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n]  so that the stores and the bias column sums issue in
-        // the shadow of the MFMAs
+            if (step + 2 < R) load_half(0, step + 2);
+        } else {
 #pragma unroll
-        for (int nb = 0; nb < LNB; ++nb)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) dh[nb][k] = 0.f;
-        DIC_STAMP(1, step, 3);
-#pragma unroll
-        for (int k = 0; k < LBM / 4; ++k) {
-            const int rowl = k * 4 + w;
-            const int b = b0 + rowl;
-            if (b < B) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dgt + rowl * GSTR + lane * 8);
-                *reinterpret_cast<bf16x8*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8) = v;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
-            }
-#pragma unroll
-            for (int ks = 2 * k; ks < 2 * k + 2; ++ks)
-#pragma unroll
-                for (int nb = 0; nb < LNB; ++nb) {
-                    const bf16x8 gbv = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + r) * GSTR + ks * 16 + 8 * hh);
-                    dh[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, dh[nb], 0, 0, 0);
-                }
+            for (int k = 0; k < 8; ++k) row_and_mfma(1, k, t);
         }
         DIC_STAMP(1, step, 4);
-        __syncthreads();
         DIC_STAMP(1, step, 5);
-#pragma unroll
-        for (int nb = 0; nb < LNB; ++nb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cur[nb][q] = nxt[nb][q];
     }
+    __syncthreads();                                       // the dG tile is free for the bias reduction below
     if (a.dbias_part) {     // add the 4 waves' column sums through LDS (the dG tile is free now): one partial per workgroup
         float* red = reinterpret_cast<float*>(dgt);
 #pragma unroll

@@ -41,6 +41,6 @@ if not proj:
     t = buf[1, :R, :6].astype(np.int64)
     d = np.diff(t, axis=1)
     print('lstm_bwd, cycles per phase:')
-    for i, n in enumerate(['gate-gradient math + LDS write', 'issue next loads + barrier', 'dG rows LDS -> global (+bias sums)', 'MFMA dh = W^T dG', 'closing barrier']):
+    for i, n in enumerate(['barrier (half 0 published)', 'phase X: MFMA+stores half 0 || math half 1', 'barrier (half 1 published)', 'phase Y: MFMA+stores half 1 || math half 0 (next step)', '-']):
         print('  %-34s %8.0f' % (n, np.median(d[2:, i])))
     print('  step total                         %8.0f' % np.median(t[3:, 0] - t[2:-1, 0]))
