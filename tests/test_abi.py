@@ -56,3 +56,25 @@ def test_ops_refuse_cpu_tensors():
     z = torch.zeros(4, 256)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.dec_soft_assign(z, torch.zeros(2, 256))
+
+
+def test_register_heavy_kernels_do_not_spill_to_scratch():
+    """The recurrence kernels live at ~480 of 512 registers; a restructure that makes the compiler index their register arrays
+    dynamically moves them to scratch memory and costs 8x (measured).  Compile with the resource-usage remarks and require
+    ScratchSize == 0 and no spills for every kernel of the two register-heavy files."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'deep_interpolation_clustering_amd', 'csrc')
+    for name in ('dic_lstm.hip', 'dic_bnhead.hip'):
+        res = subprocess.run([hipcc, '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-I' + os.path.join(root, 'include'), '-c',
+                              os.path.join(src, name), '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'],
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', res.stderr)]
+        spills = [int(v) for v in re.findall(r'VGPRs Spill: (\d+)', res.stderr)]
+        assert scratch and max(scratch) == 0 and max(spills) == 0, (name, scratch, spills)
