@@ -34,6 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int V> struct IC { static constexpr int value = V; };      // compile-time index passed through a generic lambda
 
 #ifdef DIC_LSTM_EXP_NOMATH      // experiment: gate non-linearities replaced by one FMA each (timing only, wrong results)
 __device__ __forceinline__ float sigmoid_fast(float x) { return fmaf(x, 0.01f, 0.5f); }
@@ -344,14 +345,15 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
     static_assert(LNB == 2, "the half-step software pipeline is written for two 32-row halves");
     struct StepIn { bf16x4 ib, fb, gb, ob, go, cp; };
     StepIn in[LNB][4];
-    auto load_half = [&](int nb, int step) {
+    // (half and unit group are compile-time constants: a run-time index into the register arrays sends them to scratch memory)
+    auto load_q = [&](auto nbc, auto qc, int step) {
+        constexpr int nb = decltype(nbc)::value, q = decltype(qc)::value;
         const int t = dir ? step : R - 1 - step;           // reverse of the forward visiting order
         const bool first_fwd = step == R - 1;               // this t was the forward pass' first step
         const int tp = dir ? t + 1 : t - 1;                 // forward predecessor
         const int b = min(b0 + nb * 32 + r, B - 1);
         const int bt = blockIdx.x * LNB + nb;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        {
             const int u = 32 * w + 8 * q + 4 * hh;
             StepIn& d = in[nb][q];
             d.ib = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
@@ -370,6 +372,9 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + u);
             d.go = go;
         }
+    };
+    auto load_half = [&](auto nbc, int step) {
+        load_q(nbc, IC<0>{}, step); load_q(nbc, IC<1>{}, step); load_q(nbc, IC<2>{}, step); load_q(nbc, IC<3>{}, step);
     };
     // gate gradients of hidden units 32w + 8q + 4hh .. +3 of half nb -> its rows of the LDS dG tile; dc and the c carry advance
     auto math_q = [&](int nb, int q) {
@@ -422,11 +427,11 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ccar[nb][4 * q + j] = (float)ct[j];
             }
-        load_half(0, 0);
-        load_half(1, 0);
+        load_half(IC<0>{}, 0);
+        load_half(IC<1>{}, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) math_q(0, q);
-        if (R > 1) load_half(0, 1);
+        if (R > 1) load_half(IC<0>{}, 1);
     }
 
     for (int step = 0; step < R; ++step) {
@@ -437,13 +442,15 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         // ---- phase X: MFMA + stores of half 0  ||  math of half 1
 #pragma unroll
         for (int k = 0; k < 16; ++k) dh[0][k] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            math_q(1, q);
-            row_and_mfma(0, 2 * q, t);
-            row_and_mfma(0, 2 * q + 1, t);
-        }
-        if (step + 1 < R) load_half(1, step + 1);          // half 1's registers are free: a full step of lead time
+        // (each unit group's registers are refilled as soon as its math has consumed them: a full step of lead time, and the
+        // requests spread over the step instead of one burst per phase)
+#define DIC_BWD_X(Q)                                                   \
+        math_q(1, Q);                                                  \
+        if (step + 1 < R) load_q(IC<1>{}, IC<Q>{}, step + 1);          \
+        row_and_mfma(0, 2 * Q, t);                                     \
+        row_and_mfma(0, 2 * Q + 1, t);
+        DIC_BWD_X(0) DIC_BWD_X(1) DIC_BWD_X(2) DIC_BWD_X(3)
+#undef DIC_BWD_X
         DIC_STAMP(1, step, 2);
         __syncthreads();                                   // half 1 of dG_t is complete; the reads of half 0 have retired
         DIC_STAMP(1, step, 3);
@@ -451,13 +458,13 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 #pragma unroll
         for (int k = 0; k < 16; ++k) dh[1][k] = 0.f;
         if (step + 1 < R) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                math_q(0, q);
-                row_and_mfma(1, 2 * q, t);
-                row_and_mfma(1, 2 * q + 1, t);
-            }
-            if (step + 2 < R) load_half(0, step + 2);
+#define DIC_BWD_Y(Q)                                                   \
+            math_q(0, Q);                                              \
+            if (step + 2 < R) load_q(IC<0>{}, IC<Q>{}, step + 2);      \
+            row_and_mfma(1, 2 * Q, t);                                 \
+            row_and_mfma(1, 2 * Q + 1, t);
+            DIC_BWD_Y(0) DIC_BWD_Y(1) DIC_BWD_Y(2) DIC_BWD_Y(3)
+#undef DIC_BWD_Y
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) row_and_mfma(1, k, t);
