@@ -35,6 +35,8 @@ SIGNATURES = {
     'dic_sci_cci_fwd_ragged': (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     'dic_sci_cci_bwd_workspace': (_sz, [_i, _i, _i]),
     'dic_sci_cci_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    'dic_sci_cci_fwd_packed': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p]),
+    'dic_sci_cci_bwd_packed': (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
     'dic_cci_fwd': (_i, [_p, _p, _i, _i, _i, _p, _p]),
     'dic_cci_bwd_workspace': (_sz, [_i, _i, _i]),
     'dic_cci_bwd': (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
@@ -61,6 +63,10 @@ SIGNATURES = {
     'dic_lstm_fwd_proj': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     'dic_lstm_bwd_workspace': (_sz, [_i]),
     'dic_lstm_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    'dic_lstm_pack': (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'dic_lstm_dw_workspace': (_sz, [_i, _i]),
+    'dic_lstm_dw': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
+    'dic_lstm_unpack_grads': (_i, [_p, _i, _p, _p, _i, _i, _p, _i, _p]),
     'dic_head_fwd': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _p]),
     'dic_head_bwd_workspace': (_sz, [C.c_int64, _i, _i]),
     'dic_head_bwd': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _p, _p, _p, _sz, _p]),
@@ -123,6 +129,14 @@ def check(status, what):
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (``const float* const*``); keep the returned object alive for the duration of the call."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
 
 
 def stream_of(t):

@@ -33,8 +33,10 @@ class EncoderRNN(nn.Module):
         self.num_directions = 2 if bidirectional else 1
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
 
-    def forward(self, x):
-        if fused_lstm.fused_available(x, self.lstm):        # bf16 autocast on the GPU: persistent HIP recurrence
+    def forward(self, x, packed=False):
+        if packed:                                           # (R,B,32) bf16 rows straight from ops.sci_cci_packed
+            output, (hidden, cell_state) = fused_lstm.bilstm_packed(x, self.lstm)
+        elif fused_lstm.fused_available(x, self.lstm):      # bf16 autocast on the GPU: persistent HIP recurrence
             output, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm)
         else:
             output, (hidden, cell_state) = self.lstm(x)
@@ -127,30 +129,38 @@ class NetBase(nn.Module):
         dist.convert_batchnorm_(self)
 
     # ------------------------------------------------------------------------------ forward
-    def _interp(self, x, lengths=None):
-        return fused_forward(self.sci, self.cci, x, lengths)             # (B,R,3C), one launch
+    def _packed_path(self, x):
+        """bf16 step on the GPU with 3C < 32 features: the interpolation kernel writes the encoder LSTM's input rows itself."""
+        return 3 * self.num_variables < ops.PACKED_WIDTH and fused_lstm.fused_available(x, self.encoder.lstm)
+
+    def _interp(self, x, lengths=None, packed=False):
+        """Time-major interpolated features: (R,B,3C) f32 (a permuted view of upstream's (B,R,3C)), or the packed (R,B,32) bf16 rows."""
+        if packed:
+            return ops.sci_cci_packed(x, self.sci.kernel, self.cci.kernel, self.sci.grid(), lengths)
+        return fused_forward(self.sci, self.cci, x, lengths).permute(1, 0, 2)     # one launch
 
     def forward(self, x, fake_x=None, fake_perm_idx=None, positive_x=None, lengths=None):
         """x (B,4C,T) -> (cat_hidden (B,256), rec (B,C,T), aux_pred_dict); clustering_interp.py:134-189.
         ``lengths`` (B,C) int32 is an optional side channel: prefix lengths of the padding mask."""
         args = self.args
         B = x.size(0)
-        feats = [self._interp(x, lengths)]
+        packed = self._packed_path(x)
+        feats = [self._interp(x, lengths, packed)]
         want_fake = bool(args.fake_detection)
         want_pos = self.clustering and args.triple_margin != 0. and want_fake
         if want_fake:
-            feats.append(self._interp(fake_x, lengths))
+            feats.append(self._interp(fake_x, lengths, packed))
         if want_pos:
-            feats.append(self._interp(positive_x, lengths))
-        if len(feats) > 1 and B * feats[0].size(1) >= SEPARATE_ENCODER_ROWS:
+            feats.append(self._interp(positive_x, lengths, packed))
+        if len(feats) > 1 and B * feats[0].size(0) >= SEPARATE_ENCODER_ROWS:
             # large batches: one encoder call per branch.  Each already fills the chip, and the shared call would cost three
             # 100-MB-class copies (stacking the inputs, slicing the real half of the context and of the final states back out)
-            outs = [self.encoder(f.permute(1, 0, 2)) for f in feats]
+            outs = [self.encoder(f, packed) for f in feats]
             context, hidden, cell = outs[0]
             z_all = torch.cat([torch.cat([h for h in o[1]], dim=-1) for o in outs], dim=0)          # (nB, 256)
         else:
-            seq = (feats[0] if len(feats) == 1 else torch.cat(feats, dim=0)).permute(1, 0, 2)     # (R, nB, 3C)
-            context, hidden, cell = self.encoder(seq)
+            seq = feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)                        # (R, nB, .)
+            context, hidden, cell = self.encoder(seq, packed)
             z_all = torch.cat([h for h in hidden], dim=-1)                # (nB, 256)
             if len(feats) > 1:
                 context, hidden, cell = context[:, :B], hidden[:, :B].contiguous(), cell[:, :B].contiguous()

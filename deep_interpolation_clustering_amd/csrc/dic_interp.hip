@@ -45,7 +45,7 @@ __host__ __device__ inline InterpLayout interp_layout(int E, int C, int R, int T
     L.mean = o;  o += E * C;
     L.lse = o;   o += E * R;
     L.amat = o;  o += E * R * C;
-    o = (o + 1) & ~1;            // float2 alignment
+    o = (o + 3) & ~3;            // 16-byte alignment (float2 rows; uint4 reads of the packed output rows staged here)
     L.stride = Tcap > 0 ? interp_row_stride(Tcap) : 0;
     L.obs = o;   o += 2 * E * C * L.stride;
     L.total_words = o;
@@ -58,6 +58,7 @@ struct InterpArgs {
     int B, C, R, Tcap, E, S, logS;
     const float* ref_grid; const float* sci_kernel; const float* cci_kernel;
     float* out; float* saved;
+    __bf16* xenc; int xw;      // optional second output: (R,B,xw) bf16 rows [cci(sci(x)) | 1 | 0...], the encoder LSTM's packed input
 };
 
 constexpr float kMaskedTime = 1e18f;   // u = 1e36 stays finite in f32; its soft-max weight is exactly 0
@@ -65,7 +66,7 @@ constexpr float kEmptyU = 1e35f;
 
 // Cross-channel epilogue on LDS-resident y,w,y_trans (res[e][3][C][R]) -> out (B,R,3C).
 __device__ void cci_epilogue(const float* res, const float* kmat, float* mean, float* lse, float* amat,
-                             int Ev, int C, int R, int e0, float* out) {
+                             int Ev, int C, int R, int e0, float* out, __bf16* stage = nullptr, int xw = 0) {
     const int tid = threadIdx.x;
     for (int i = tid; i < Ev * C; i += kBlock) {          // mean over the grid, per (e,c)
         const float* y = res + ((i / C) * 3 * C + (i % C)) * R;
@@ -97,10 +98,19 @@ __device__ void cci_epilogue(const float* res, const float* kmat, float* mean, f
         float s = 0.f;
         for (int c = 0; c < C; ++c) s = fmaf(arow[c], kmat[c * C + j], s);
         s += mean[e * C + j];
-        float* o = out + ((size_t)(e0 + e) * R + r) * 3 * C;
-        o[j] = s;
-        o[C + j] = expf(base[(C + j) * R + r]);
-        o[2 * C + j] = base[(2 * C + j) * R + r] - s;
+        const float inten = expf(base[(C + j) * R + r]), trans = base[(2 * C + j) * R + r] - s;
+        if (out) {
+            float* o = out + ((size_t)(e0 + e) * R + r) * 3 * C;
+            o[j] = s;
+            o[C + j] = inten;
+            o[2 * C + j] = trans;
+        }
+        if (stage) {
+            __bf16* o = stage + (e * R + r) * xw;
+            o[j] = (__bf16)s;
+            o[C + j] = (__bf16)inten;
+            o[2 * C + j] = (__bf16)trans;
+        }
     }
 }
 
@@ -291,7 +301,22 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
     K1_STAMP(3);
     // ---- 4. epilogue
     if (a.cci_kernel) {
-        cci_epilogue(res, kmat, smem + L.mean, smem + L.lse, smem + L.amat, Ev, C, R, e0, a.out);
+        // (the staged observation rows are dead by now: their LDS holds the packed bf16 rows until the 16-B stores below)
+        __bf16* stage = a.xenc ? reinterpret_cast<__bf16*>(obs) : nullptr;
+        cci_epilogue(res, kmat, smem + L.mean, smem + L.lse, smem + L.amat, Ev, C, R, e0, a.out, stage, a.xw);
+        if (stage) {
+            const int xw = a.xw, npadc = xw - 3 * C;
+            for (int i = tid; i < Ev * R * npadc; i += kBlock) {      // constant-one column (the LSTM bias rides on it), zero padding
+                const int er = i / npadc, c = i - er * npadc;
+                stage[er * xw + 3 * C + c] = (__bf16)(c == 0 ? 1.0f : 0.0f);
+            }
+            __syncthreads();
+            const int cpr = xw / 8;                                   // 16-B pieces per packed row
+            for (int i = tid; i < Ev * R * cpr; i += kBlock) {
+                const int er = i / cpr, ch = i - er * cpr, e = er / R, r = er - e * R;
+                *reinterpret_cast<uint4*>(a.xenc + ((size_t)r * a.B + e0 + e) * xw + ch * 8) = *reinterpret_cast<const uint4*>(stage + er * xw + ch * 8);
+            }
+        }
     } else {
         for (int i = tid; i < Ev * R * C; i += kBlock) {
             const int e = i / (R * C), rc = i % (R * C), r = rc / C, c = rc % C;
@@ -441,8 +466,8 @@ __device__ float cci_backward_lds(float* sm, const BwdLayout& L, int Ev, int C, 
 }
 
 // Fused backward: grad_out (B,R,3C) + saved (B,7,C,R) -> per-block partials [C | C*C].
-__global__ __launch_bounds__(kBlock) void sci_cci_bwd_kernel(const float* grad_out, const float* saved,
-                                                            const float* cci_kernel, int B, int C, int R, int E,
+__global__ __launch_bounds__(kBlock) void sci_cci_bwd_kernel(const float* grad_out, const __bf16* grad_packed, int xw,
+                                                            const float* saved, const float* cci_kernel, int B, int C, int R, int E,
                                                             int nblk, float* partials) {
     extern __shared__ __align__(16) float smem[];
     const BwdLayout L = bwd_layout(E, C, R);
@@ -460,9 +485,16 @@ __global__ __launch_bounds__(kBlock) void sci_cci_bwd_kernel(const float* grad_o
             const int e = i / (3 * CR), rem = i % (3 * CR);
             val[i] = saved[((size_t)(e0 + e) * 7) * CR + rem];
         }
-        for (int i = tid; i < Ev * R * 3 * C; i += kBlock) {    // (B,R,3C) -> [e][3][C][R]
-            const int e = i / (R * 3 * C), rem = i % (R * 3 * C), r = rem / (3 * C), qc = rem % (3 * C);
-            grd[(e * 3 * C + qc) * R + r] = grad_out[(size_t)e0 * R * 3 * C + i];
+        if (grad_packed) {                                      // (R,B,xw) bf16 rows as the encoder's dX GEMM wrote them -> [e][3][C][R]
+            for (int i = tid; i < Ev * R * 3 * C; i += kBlock) {
+                const int e = i / (R * 3 * C), rem = i % (R * 3 * C), r = rem / (3 * C), qc = rem % (3 * C);
+                grd[(e * 3 * C + qc) * R + r] = (float)grad_packed[((size_t)r * B + e0 + e) * xw + qc];
+            }
+        } else {
+            for (int i = tid; i < Ev * R * 3 * C; i += kBlock) {    // (B,R,3C) -> [e][3][C][R]
+                const int e = i / (R * 3 * C), rem = i % (R * 3 * C), r = rem / (3 * C), qc = rem % (3 * C);
+                grd[(e * 3 * C + qc) * R + r] = grad_out[(size_t)e0 * R * 3 * C + i];
+            }
         }
         __syncthreads();
         const float* g3;   // (g_y, g_w, g_yt) source
@@ -547,7 +579,9 @@ static int interp_fwd_launch(InterpArgs a, bool ragged, hipStream_t st) {
     DIC_REQUIRE(a.B > 0 && a.C > 0 && a.R > 0 && a.Tcap > 0, DIC_ERR_INVALID_ARG, "sci_cci_fwd: non-positive size");
     DIC_REQUIRE(a.C <= DIC_MAX_CHANNELS && a.R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED,
                 "sci_cci_fwd: C=%d R=%d exceed limits (%d,%d)", a.C, a.R, DIC_MAX_CHANNELS, DIC_MAX_REFPOINTS);
-    DIC_REQUIRE(a.ref_grid && a.sci_kernel && a.out, DIC_ERR_INVALID_ARG, "sci_cci_fwd: NULL pointer");
+    DIC_REQUIRE(a.ref_grid && a.sci_kernel && (a.out || a.xenc), DIC_ERR_INVALID_ARG, "sci_cci_fwd: NULL pointer");
+    DIC_REQUIRE(!a.xenc || 2 * a.C * interp_row_stride(a.Tcap) * 4 >= a.R * a.xw * 2, DIC_ERR_UNSUPPORTED,
+                "sci_cci_fwd_packed: the packed rows (R=%d x %d) do not fit the staging area of C=%d, T=%d", a.R, a.xw, a.C, a.Tcap);
     const InterpLayout one = interp_layout(1, a.C, a.R, a.Tcap), two = interp_layout(2, a.C, a.R, a.Tcap);
     const int per_enc = two.total_words - one.total_words;
     const int fixed = one.total_words - per_enc;
@@ -616,6 +650,18 @@ int dic_sci_cci_fwd(const float* x, const int32_t* lengths, int B, int C, int T,
     return interp_fwd_launch(a, false, (hipStream_t)stream);
 }
 
+int dic_sci_cci_fwd_packed(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                           const float* sci_kernel, const float* cci_kernel, float* out, float* saved, void* xenc, int xw,
+                           dic_stream_t stream) {
+    DIC_REQUIRE(x && xenc && cci_kernel, DIC_ERR_INVALID_ARG, "sci_cci_fwd_packed: NULL pointer (x, xenc and cci_kernel are required)");
+    DIC_REQUIRE(xw % 8 == 0 && xw > 3 * C && xw <= 64, DIC_ERR_INVALID_ARG, "sci_cci_fwd_packed: row width %d (needs a multiple of 8 above 3C = %d)", xw, 3 * C);
+    InterpArgs a{};
+    a.x = x; a.lengths = lengths; a.T = T; a.B = B; a.C = C; a.R = R; a.Tcap = T;
+    a.ref_grid = ref_grid; a.sci_kernel = sci_kernel; a.cci_kernel = cci_kernel; a.out = out; a.saved = saved;
+    a.xenc = (__bf16*)xenc; a.xw = xw;
+    return interp_fwd_launch(a, false, (hipStream_t)stream);
+}
+
 int dic_sci_cci_fwd_ragged(const float* t_pk, const float* v_pk, const int64_t* row_off, int max_len, int B, int C,
                            int R, const float* ref_grid, const float* sci_kernel, const float* cci_kernel,
                            float* out, float* saved, dic_stream_t stream) {
@@ -633,13 +679,14 @@ size_t dic_sci_cci_bwd_workspace(int B, int C, int R) {
     return (size_t)nblk * (C + C * C) * sizeof(float);
 }
 
-int dic_sci_cci_bwd(const float* grad_out, const float* saved, const float* sci_kernel, const float* cci_kernel,
-                    int B, int C, int R, float* grad_sci_kernel, float* grad_cci_kernel, void* workspace,
-                    size_t workspace_bytes, dic_stream_t stream) {
+static int sci_cci_bwd_launch(const float* grad_out, const void* grad_packed, int xw, const float* saved, const float* sci_kernel,
+                              const float* cci_kernel, int B, int C, int R, float* grad_sci_kernel, float* grad_cci_kernel,
+                              void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(B > 0 && C > 0 && R > 0, DIC_ERR_INVALID_ARG, "sci_cci_bwd: non-positive size");
     DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "sci_cci_bwd: C=%d R=%d", C, R);
-    DIC_REQUIRE(grad_out && saved && sci_kernel && grad_sci_kernel && workspace, DIC_ERR_INVALID_ARG,
+    DIC_REQUIRE((grad_out || grad_packed) && saved && sci_kernel && grad_sci_kernel && workspace, DIC_ERR_INVALID_ARG,
                 "sci_cci_bwd: NULL pointer");
+    DIC_REQUIRE(!grad_packed || xw >= 3 * C, DIC_ERR_INVALID_ARG, "sci_cci_bwd: packed row width %d < 3C = %d", xw, 3 * C);
     DIC_REQUIRE(!cci_kernel || grad_cci_kernel, DIC_ERR_INVALID_ARG, "sci_cci_bwd: grad_cci_kernel is NULL");
     int E, nblk; size_t lds;
     bwd_geometry(B, C, R, &E, &nblk, &lds);
@@ -647,12 +694,28 @@ int dic_sci_cci_bwd(const float* grad_out, const float* saved, const float* sci_
     DIC_REQUIRE(workspace_bytes >= (size_t)nblk * (C + C * C) * sizeof(float), DIC_ERR_WORKSPACE,
                 "sci_cci_bwd: workspace %zu B too small", workspace_bytes);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sci_cci_bwd_kernel, dim3(nblk), dim3(kBlock), lds, st, grad_out, saved, cci_kernel, B, C, R, E,
-                       nblk, (float*)workspace);
+    hipLaunchKernelGGL(sci_cci_bwd_kernel, dim3(nblk), dim3(kBlock), lds, st, grad_out, (const __bf16*)grad_packed, xw, saved, cci_kernel,
+                       B, C, R, E, nblk, (float*)workspace);
     const int n = C + C * C;
     hipLaunchKernelGGL(interp_bwd_finalize, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)workspace, nblk, C,
                        sci_kernel, grad_sci_kernel, cci_kernel ? grad_cci_kernel : nullptr);
     return check_launch("sci_cci_bwd");
+}
+
+int dic_sci_cci_bwd(const float* grad_out, const float* saved, const float* sci_kernel, const float* cci_kernel,
+                    int B, int C, int R, float* grad_sci_kernel, float* grad_cci_kernel, void* workspace,
+                    size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(grad_out, DIC_ERR_INVALID_ARG, "sci_cci_bwd: grad_out is NULL");
+    return sci_cci_bwd_launch(grad_out, nullptr, 0, saved, sci_kernel, cci_kernel, B, C, R, grad_sci_kernel, grad_cci_kernel, workspace,
+                              workspace_bytes, stream);
+}
+
+int dic_sci_cci_bwd_packed(const void* grad_packed, int xw, const float* saved, const float* sci_kernel, const float* cci_kernel,
+                           int B, int C, int R, float* grad_sci_kernel, float* grad_cci_kernel, void* workspace,
+                           size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(grad_packed, DIC_ERR_INVALID_ARG, "sci_cci_bwd_packed: grad is NULL");
+    return sci_cci_bwd_launch(nullptr, grad_packed, xw, saved, sci_kernel, cci_kernel, B, C, R, grad_sci_kernel, grad_cci_kernel, workspace,
+                              workspace_bytes, stream);
 }
 
 int dic_cci_fwd(const float* s, const float* cci_kernel, int B, int C, int R, float* out, dic_stream_t stream) {

@@ -6,12 +6,16 @@
 ``nn.LSTM`` so ``state_dict`` keys do not change.  What changes is who executes it when the step runs
 under bf16 autocast on the GPU:
 
+  dic_lstm_pack (one launch): the eight f32 parameters -> bf16 operands (W_ih padded, bias column / bias vector, W_hh, W_hh^T)
   time-parallel GEMMs (hipBLASLt, bf16 in / f32 accumulate), issued here:
       gx = X.W_ih^T + b_ih + b_hh            (R*B x I) . (I x 8H)     [I >= 32: decoder; the encoder's 18-wide
                                                                        projection runs inside the recurrence kernel]
-      dX = dG.W_ih,  dW_ih = dG^T.X,  dW_hh = dG^T.H_prev,  db = sum dG
+      dX = dG.W_ih;  decoder: dW_ih = dG^T.X, dW_hh = dG^T.H_prev as split-K products
+  encoder: dW_ih and dW_hh from ONE pass over dG (dic_lstm_dw, MFMA with transposed LDS reads)
   sequential recurrence (dic_lstm_fwd / dic_lstm_bwd): one workgroup per 64 batch rows and direction keeps
   h, c (dh, dc) on chip for all R steps with W_hh resident in registers.
+  Parameter gradients are written by the kernels straight into ``param.grad`` when those exist (the flat gradient bucket of
+  ``dist.FlatParams``): no (2,4H,.) staging copies, no per-parameter AccumulateGrad add launches.
 
 In f32 (no autocast) the stock ``nn.LSTM`` (MIOpen) is used: that is the configuration the 1e-5 parity
 tests run in.  The bf16 path is checked against an f32 emulation with the same rounding points.
@@ -19,10 +23,12 @@ tests run in.  The bf16 path is checked against an f32 emulation with the same r
 import torch
 
 from . import _native as N
-from .ops import splitk_tn
+from .ops import PACKED_WIDTH, splitk_tn
 
 H = 128
-PROJ_WIDTH = 32      # dic_lstm_fwd_proj's compiled input width
+PROJ_WIDTH = PACKED_WIDTH      # dic_lstm_fwd_proj's compiled input width
+PARAM_NAMES = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
+               'weight_ih_l0_reverse', 'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
 
 def fused_available(x, lstm):
@@ -31,97 +37,143 @@ def fused_available(x, lstm):
             and not lstm.batch_first and lstm.proj_size == 0)
 
 
+def _grad_sinks(params, needs):
+    """The tensors the kernels write the parameter gradients into, and whether they ACCUMULATE there.
+    When every parameter already owns a dense f32 ``.grad`` (the views of the flat bucket, zeroed at the start of the step) the
+    kernels add into it and autograd is handed ``None``; otherwise fresh tensors are returned through autograd."""
+    if all(needs) and all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params):
+        return [p.grad for p in params], True
+    return [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in params], False
+
+
 class _BiLstm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, bias, h0, c0):
-        R, B, I = x.shape
+    def forward(ctx, x, h0, c0, packed, *params):
+        R, B, I_in = x.shape
         bf = torch.bfloat16
+        dev = x.device
+        I = params[0].shape[1]
         proj = I < PROJ_WIDTH                                      # narrow input (encoder): projection inside the recurrence
         Ip = PROJ_WIDTH if proj else (I + 15) // 16 * 16           # K of the projection padded to the MFMA step
-        xb = x.to(bf)
-        wihb = w_ih.reshape(8 * H, I).to(bf)
-        if Ip != I:
-            xb = torch.nn.functional.pad(xb, (0, Ip - I))
-            wihb = torch.nn.functional.pad(wihb, (0, Ip - I))
-        xb = xb.contiguous()
-        if proj:
-            # the bias rides along as a constant-one input column (a spare one exists because I < 32); gx is never formed
-            xb[..., I].fill_(1.0)
-            wihb[:, I] = bias.reshape(8 * H).to(bf)
-            gx = None
-        else:
-            gx = torch.addmm(bias.reshape(8 * H).to(bf), xb.view(R * B, Ip), wihb.t())      # (R*B, 2*4*H)
-        whhb = w_hh.to(bf).contiguous()                            # (2,4H,H)
         need = any(ctx.needs_input_grad)
-        dev = x.device
-        out = torch.empty((R, B, 2 * H), device=dev, dtype=bf)
+        pf = [N.f32c(p.detach()) for p in params]
+        wihb = torch.empty((8 * H, Ip), device=dev, dtype=bf)
+        whhb = torch.empty((2, 4 * H, H), device=dev, dtype=bf)
+        whh_t = torch.empty((2, H, 4 * H), device=dev, dtype=bf) if need else None
+        bias = None if proj else torch.empty(8 * H, device=dev, dtype=bf)
+        L, st = N.lib(), N.stream_of(x)
+        N.check(L.dic_lstm_pack(N.ptr_array(pf), H, I, Ip, int(proj), N.ptr(wihb), N.ptr(whhb), N.ptr(whh_t), N.ptr(bias), st), 'dic_lstm_pack')
+        if packed:                                                 # (R,B,32) bf16 rows [features | 1 | 0...] from ops.sci_cci_packed
+            if not proj or I_in != Ip or x.dtype != bf:
+                raise ValueError(f'packed input must be (R,B,{PROJ_WIDTH}) bf16 for an LSTM of input size < {PROJ_WIDTH}')
+            xb = x if x.is_contiguous() else x.contiguous()
+        else:
+            if I_in != I:
+                raise ValueError(f'input width {I_in} does not match the LSTM input size {I}')
+            xb = x.to(bf)
+            if Ip != I:
+                xb = torch.nn.functional.pad(xb, (0, Ip - I))
+            xb = xb.contiguous()
+            if proj:
+                xb[..., I].fill_(1.0)                              # the bias rides along as a constant-one input column
+        out_ext = torch.empty((R + 2, B, 2 * H), device=dev, dtype=bf)      # [h0 | h_1..h_R | h0]: every step's h_prev is a row above / below
+        out = out_ext[1:R + 1]
+        if need and not proj:                                      # boundary rows of the dW_hh products (backward); the other halves are never read
+            if h0 is None:
+                out_ext[0, :, :H].zero_()
+                out_ext[R + 1, :, H:].zero_()
+            else:
+                out_ext[0, :, :H].copy_(h0[0])
+                out_ext[R + 1, :, H:].copy_(h0[1])
         hn = torch.empty((2, B, H), device=dev, dtype=torch.float32)
         cn = torch.empty_like(hn)
         Bp = (B + 63) // 64 * 64                                   # kernel-native saved state is tiled by 64 rows
         gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=bf) if need else None
         cs = torch.empty((R, Bp, 2, H), device=dev, dtype=bf) if need else None    # bf16 copy for the backward; c itself stays f32 on chip
-        h0c = None if h0 is None else h0.float().contiguous()
-        c0c = None if c0 is None else c0.float().contiguous()
+        h0c = None if h0 is None else N.f32c(h0)
+        c0c = None if c0 is None else N.f32c(c0)
         if proj:
-            N.check(N.lib().dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wihb), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out),
-                                              N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), N.stream_of(x)), 'dic_lstm_fwd_proj')
+            N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wihb), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out),
+                                        N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), st), 'dic_lstm_fwd_proj')
         else:
-            N.check(N.lib().dic_lstm_fwd(N.ptr(gx), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
-                                         N.ptr(cn), N.ptr(gates), N.ptr(cs), N.stream_of(x)), 'dic_lstm_fwd')
-        ctx.dims = (R, B, I, Ip)
+            gx = torch.addmm(bias, xb.view(R * B, Ip), wihb.t())    # (R*B, 2*4*H)
+            N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
+                                   N.ptr(cn), N.ptr(gates), N.ptr(cs), st), 'dic_lstm_fwd')
+        ctx.dims = (R, B, I, Ip, proj, bool(packed))
         ctx.x_dtype = x.dtype
         ctx.has_init = h0 is not None
-        ctx.save_for_backward(xb, wihb, whhb, gates, cs, out, h0c, c0c)
+        ctx.params = params
+        ctx.save_for_backward(xb, wihb, whh_t, gates, cs, out_ext, h0c, c0c)
         return out, hn, cn
 
     @staticmethod
     def backward(ctx, dout, dhn, dcn):
-        xb, wihb, whhb, gates, cs, out, h0c, c0c = ctx.saved_tensors
-        R, B, I, Ip = ctx.dims
+        xb, wihb, whh_t, gates, cs, out_ext, h0c, c0c = ctx.saved_tensors
+        R, B, I, Ip, proj, packed = ctx.dims
+        params = ctx.params
         bf = torch.bfloat16
-        dev = out.device
+        dev = out_ext.device
+        out = out_ext[1:R + 1]
         dgx = torch.empty((R, B, 2, 4, H), device=dev, dtype=bf)
         dh0 = torch.empty((2, B, H), device=dev, dtype=torch.float32)
         dc0 = torch.empty_like(dh0)
-        whh_t = whhb.transpose(1, 2).contiguous()                  # (2,H,4H)
-        doutb = None if dout is None else dout.to(bf).contiguous()
-        dhnc = None if dhn is None else dhn.float().contiguous()
-        dcnc = None if dcn is None else dcn.float().contiguous()
-        Lb = N.lib()
+        doutb = None if dout is None else (dout if dout.dtype == bf else dout.to(bf)).contiguous()
+        dhnc = None if dhn is None else N.f32c(dhn)
+        dcnc = None if dcn is None else N.f32c(dcn)
+        Lb, st = N.lib(), N.stream_of(out_ext)
         dbias = torch.empty((2, 4 * H), device=dev, dtype=torch.float32)         # summed inside the kernel, f32
         ws = torch.empty(max(16, Lb.dic_lstm_bwd_workspace(B)), device=dev, dtype=torch.uint8)
         N.check(Lb.dic_lstm_bwd(N.ptr(whh_t), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
-                                R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(),
-                                N.stream_of(out)), 'dic_lstm_bwd')
+                                R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), st), 'dic_lstm_bwd')
         dg2 = dgx.view(R * B, 8 * H)
-        dx = dw_ih = dw_hh = None
+        dx = None
         if ctx.needs_input_grad[0]:
-            dx = (dg2 @ wihb)[:, :I].reshape(R, B, I).to(ctx.x_dtype)
-        if ctx.needs_input_grad[1]:
-            # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split-K bmm (ops.splitk_tn)
-            dw_ih = splitk_tn(dg2, xb.view(R * B, Ip))[:, :I].reshape(2, 4 * H, I)
-        if ctx.needs_input_grad[2]:
-            # dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d], h_prev = h_{t-1} (forward) / h_{t+1} (reverse): shifted strided views
-            # of dG and out, one direction at a time -- no H_prev copy and none of the cross-direction blocks a single
-            # (8H, 2H) product would compute (0.42 ms against 0.82 at R*B = 786k, scripts/gemm_probe2.py / gemm_probe3.py)
-            o2 = out.view(R * B, 2 * H)
-            if R > 1:
-                fwd = splitk_tn(dg2[B:, :4 * H], o2[:-B, :H], chunks=(8192, 4096, 2048))
-                rev = splitk_tn(dg2[:-B, 4 * H:], o2[B:, H:], chunks=(8192, 4096, 2048))
+            dx = dg2 @ wihb                                          # (R*B, Ip) bf16
+            if packed:
+                dx = dx.view(R, B, Ip)                               # consumed in this layout by ops._SciCciPacked.backward
             else:
-                fwd = rev = torch.zeros((4 * H, H), device=dev, dtype=torch.float32)
-            if h0c is not None:
-                fwd = fwd + (dg2[:B, :4 * H].t() @ h0c[0].to(bf)).float()
-                rev = rev + (dg2[-B:, 4 * H:].t() @ h0c[1].to(bf)).float()
-            dw_hh = torch.stack([fwd, rev])
-        return dx, dw_ih, dw_hh, (dbias if ctx.needs_input_grad[3] else None), (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None)
+                dx = (dx[:, :I] if Ip != I else dx).reshape(R, B, I).to(ctx.x_dtype)
+        needs = ctx.needs_input_grad[4:]
+        grads = [None] * 8
+        if any(needs):
+            sinks, accumulate = _grad_sinks(params, needs)
+            gp = N.ptr_array(sinks)
+            if proj:
+                # dW_ih and dW_hh of both directions from one pass over dG (csrc/dic_lstmgrad.hip)
+                ws2 = torch.empty(max(16, Lb.dic_lstm_dw_workspace(R, B)), device=dev, dtype=torch.uint8)
+                N.check(Lb.dic_lstm_dw(N.ptr(dgx), N.ptr(out), N.ptr(xb), N.ptr(h0c), R, B, H, I, Ip, gp, int(accumulate), N.ptr(ws2),
+                                       ws2.numel(), st), 'dic_lstm_dw')
+                N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
+            else:
+                # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split-K bmm (ops.splitk_tn).
+                # dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d], h_prev = h_{t-1} (forward) / h_{t+1} (reverse): row-shifted views of the
+                # extended output buffer whose first / last time slot holds h0 (zeros without one; filled by the forward) -- no H_prev copy, no separate
+                # products for the boundary step, none of the cross-direction blocks a single (8H, 2H) product would compute
+                oe = out_ext.view((R + 2) * B, 2 * H)
+                dw_ih = splitk_tn(dg2, xb.view(R * B, Ip))           # (8H, Ip) f32
+                dw_hh = torch.empty((2, 4 * H, H), device=dev, dtype=torch.float32)
+                dw_hh[0] = splitk_tn(dg2[:, :4 * H], oe[:R * B, :H])
+                dw_hh[1] = splitk_tn(dg2[:, 4 * H:], oe[2 * B:, H:])
+                N.check(Lb.dic_lstm_unpack_grads(N.ptr(dw_ih), Ip, N.ptr(dw_hh), N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
+            if not accumulate:
+                grads = [g if n else None for g, n in zip(sinks, needs)]
+        return (dx, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None), None, *grads)
+
+
+def _params(lstm):
+    return [getattr(lstm, n) for n in PARAM_NAMES]
 
 
 def bilstm(x, lstm, h0=None, c0=None):
     """(out (R,B,2H) bf16, (h_n, c_n) (2,B,H) f32) = bidirectional LSTM of x (R,B,I) with ``lstm``'s parameters."""
-    w_ih = torch.stack([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse])
-    w_hh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse])
-    bias = torch.stack([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse])
     with torch.autocast('cuda', enabled=False):
-        out, hn, cn = _BiLstm.apply(x, w_ih.float(), w_hh.float(), bias.float(), h0, c0)
+        out, hn, cn = _BiLstm.apply(x, h0, c0, False, *_params(lstm))
+    return out, (hn, cn)
+
+
+def bilstm_packed(xenc, lstm, h0=None, c0=None):
+    """The same for an input already in the recurrence kernel's layout: xenc (R,B,32) bf16 rows [features | 1 | 0...]
+    (``ops.sci_cci_packed``); its gradient comes back in that layout too."""
+    with torch.autocast('cuda', enabled=False):
+        out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, *_params(lstm))
     return out, (hn, cn)

@@ -91,6 +91,56 @@ def sci_only(x, sci_kernel, grid, lengths=None):
     return _SciCci.apply(x, sci_kernel, None, grid, lengths)
 
 
+PACKED_WIDTH = 32      # width of the encoder LSTM's packed input rows (dic_lstm_fwd_proj / dic_lstm_dw: one MFMA k-step pair)
+
+
+class _SciCciPacked(torch.autograd.Function):
+    """cci(sci(x)) written straight in the encoder LSTM's input layout: (R,B,32) bf16 rows [3C features | 1 | 0...] (the constant
+    one carries the LSTM bias).  Forward and backward exchange that layout with lstm.bilstm_packed -- no permute / cast / pad
+    passes between the interpolation kernel and the recurrence kernel."""
+
+    @staticmethod
+    def forward(ctx, x, sci_kernel, cci_kernel, grid, lengths):
+        N.require_gpu(x, sci_kernel, cci_kernel, grid)
+        x = N.f32c(x)
+        B, C4, T = x.shape
+        C = sci_kernel.numel()
+        if C4 != 4 * C:
+            raise ValueError(f'stacked input must be (B, 4*{C}, T), got {tuple(x.shape)}')
+        if 3 * C >= PACKED_WIDTH:
+            raise ValueError(f'packed rows hold at most {PACKED_WIDTH - 1} features, got 3C = {3 * C}')
+        R = grid.numel()
+        lengths = _lengths_arg(lengths, B, C, x.device)
+        sk, ck = N.f32c(sci_kernel.detach()), N.f32c(cci_kernel.detach())
+        need_grad = any(ctx.needs_input_grad)
+        xenc = torch.empty((R, B, PACKED_WIDTH), device=x.device, dtype=torch.bfloat16)
+        saved = torch.empty((B, 7, C, R), device=x.device, dtype=torch.float32) if need_grad else None
+        N.check(N.lib().dic_sci_cci_fwd_packed(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), None,
+                                               N.ptr(saved), N.ptr(xenc), PACKED_WIDTH, N.stream_of(x)), 'dic_sci_cci_fwd_packed')
+        ctx.dims = (B, C, R)
+        ctx.save_for_backward(saved, sk, ck)
+        return xenc
+
+    @staticmethod
+    def backward(ctx, grad):
+        saved, sk, ck = ctx.saved_tensors
+        B, C, R = ctx.dims
+        g = grad if grad.dtype == torch.bfloat16 else grad.to(torch.bfloat16)
+        g = g if g.is_contiguous() else g.contiguous()
+        gs = torch.empty(C, device=g.device, dtype=torch.float32)
+        gc = torch.empty((C, C), device=g.device, dtype=torch.float32)
+        L = N.lib()
+        ws = _ws(L.dic_sci_cci_bwd_workspace(B, C, R), g.device)
+        N.check(L.dic_sci_cci_bwd_packed(N.ptr(g), PACKED_WIDTH, N.ptr(saved), N.ptr(sk), N.ptr(ck), B, C, R, N.ptr(gs), N.ptr(gc),
+                                         N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_sci_cci_bwd_packed')
+        return None, gs, gc, None, None
+
+
+def sci_cci_packed(x, sci_kernel, cci_kernel, grid, lengths=None):
+    """Fused SCI + CCI: x (B,4C,T) -> (R,B,32) bf16 = [smooth | intensity | transient | 1 | 0...], time-major (3C < 32)."""
+    return _SciCciPacked.apply(x, sci_kernel, cci_kernel, grid, lengths)
+
+
 class _Cci(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, cci_kernel):
@@ -435,11 +485,11 @@ def splitk_tn(a, b, chunks=(8192, 4096, 2048)):
     n = a.shape[0]
     for c in chunks:
         if n % c == 0 and n >= 2 * c:
-            return torch.bmm(a.unflatten(0, (n // c, c)).transpose(1, 2), b.unflatten(0, (n // c, c))).float().sum(0)
+            return torch.sum(torch.bmm(a.unflatten(0, (n // c, c)).transpose(1, 2), b.unflatten(0, (n // c, c))), dim=0, dtype=torch.float32)
     c = chunks[0]
     if n >= 4 * c:            # row counts that are not a multiple of a chunk (batch 10 000, 75 000, ...): chunked body + a short tail
         m = n // c * c
-        body = torch.bmm(a[:m].unflatten(0, (m // c, c)).transpose(1, 2), b[:m].unflatten(0, (m // c, c))).float().sum(0)
+        body = torch.sum(torch.bmm(a[:m].unflatten(0, (m // c, c)).transpose(1, 2), b[:m].unflatten(0, (m // c, c))), dim=0, dtype=torch.float32)
         return body + (a[m:].t() @ b[m:]).float()
     return (a.t() @ b).float()
 

@@ -94,6 +94,16 @@ int dic_cci_bwd(const float* grad_out, const float* s, const float* cci_kernel, 
                 float* grad_s, float* grad_cci_kernel,
                 void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
+/* The fused pair feeding the encoder LSTM without a layout pass: the forward additionally (out may then be NULL) writes
+ * xenc (R,B,xw) bf16 = rows [cci(sci(x)) (3C) | 1 | 0 ...] -- time-major, padded to the MFMA k-step, the constant one carrying
+ * the LSTM bias (dic_lstm_fwd_proj) -- and the backward takes the encoder's input gradient in that same layout. */
+int dic_sci_cci_fwd_packed(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                           const float* sci_kernel, const float* cci_kernel, float* out, float* saved, void* xenc, int xw,
+                           dic_stream_t stream);
+int dic_sci_cci_bwd_packed(const void* grad_packed, int xw, const float* saved, const float* sci_kernel, const float* cci_kernel,
+                           int B, int C, int R, float* grad_sci_kernel, float* grad_cci_kernel, void* workspace,
+                           size_t workspace_bytes, dic_stream_t stream);
+
 /* ------------------------------------------------------------------ k2: RBF de-interpolation
  * Replaces RBF.forward minus compress_fc (rbf.py:57-108, gaussian rbf.py:129-131).
  *   v (B,C,R) = compress_fc output;  y (B,C,T) OVERWRITTEN (0 in masked slots).
@@ -217,6 +227,28 @@ size_t dic_lstm_bwd_workspace(int B);
 int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
                  float* dbias, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+
+/* ------------------------------------------------------------------ bi-LSTM parameters --------
+ * The eight f32 parameters of one bidirectional nn.LSTM layer (clustering_interp.py:22,35: weight_ih_l0, weight_hh_l0,
+ * bias_ih_l0, bias_hh_l0, then the same four with the _reverse suffix) are passed as a HOST array of 8 device pointers in
+ * that order.
+ *   dic_lstm_pack: -> wih (2*4H, Ip) bf16 [columns [0,I) = W_ih; column I = b_ih + b_hh when bias_col (dic_lstm_fwd_proj's
+ *     constant-one input column); rest 0], whh (2,4H,H) bf16, whh_t (2,H,4H) bf16 or NULL, bias (2*4H) bf16 = b_ih + b_hh
+ *     or NULL.  One launch replaces the stack / add / cast / pad / transpose sequence of torch ops.
+ *   dic_lstm_dw (encoder, packed input width Ip == 32): weight gradients from ONE pass over the gate gradients,
+ *     dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d] (h_{t-1} for d = 0, h_{t+1} for d = 1, h0 or zeros at the ends; `out` is the
+ *     layer's own output (R,B,2H) bf16) and dW_ih[d] = sum_t dG_t[d]^T x_t[:, :I] (x (R,B,Ip) bf16), MFMA with transposed LDS
+ *     reads, deterministic two-stage reduction, written (accumulate = 0) or added (accumulate = 1) straight into the
+ *     parameter gradients `grads` (host array of 8 device pointers, same order; the bias entries are not touched).
+ *   dic_lstm_unpack_grads: staging tensors dw_ih (2*4H, ldw) / dw_hh (2,4H,H) / dbias (2*4H) f32 (each may be NULL) ->
+ *     the parameter gradients (dbias goes to bias_ih AND bias_hh). */
+int dic_lstm_pack(const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
+                  dic_stream_t stream);
+size_t dic_lstm_dw_workspace(int R, int B);
+int dic_lstm_dw(const void* dgx, const void* out, const void* x, const float* h0, int R, int B, int H, int I, int Ip,
+                float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,
+                          int accumulate, dic_stream_t stream);
 
 /* ------------------------------------------------------------------ CompressFC output layer ---
  * Linear(128, C) over all N = B*R decoder rows (rbf.py:111-125, last layer; TimeDistributed utils.py:202-224)

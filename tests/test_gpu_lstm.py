@@ -314,3 +314,148 @@ def test_splitk_tn_matches_plain_product(n):
     s = ops.splitk_tn(a[100:, :64], b[:-100, 8:])              # strided views, as the per-direction dW_hh uses them
     np.testing.assert_allclose(s.cpu().numpy(), (a[100:, :64].double().t() @ b[:-100, 8:].double()).cpu().numpy(), rtol=0,
                                atol=6e-3 * float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------ parameter-side kernels (csrc/dic_lstmgrad.hip)
+def _lstm_params(net):
+    from deep_interpolation_clustering_amd import lstm as L
+    return [getattr(net, n) for n in L.PARAM_NAMES]
+
+
+@pytest.mark.parametrize('I', [18, 256, 40, 1])
+def test_lstm_pack_matches_torch(I):
+    """dic_lstm_pack: the eight nn.LSTM parameters -> the bf16 operands, against the torch stack / add / cast / pad sequence."""
+    from deep_interpolation_clustering_amd import _native as N
+    from deep_interpolation_clustering_amd import lstm as L
+    torch.manual_seed(I)
+    dev = torch.device('cuda')
+    net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
+    proj = I < L.PROJ_WIDTH
+    Ip = L.PROJ_WIDTH if proj else (I + 15) // 16 * 16
+    bf = torch.bfloat16
+    wih = torch.full((8 * H, Ip), 7.0, device=dev, dtype=bf)
+    whh, whh_t = torch.empty((2, 4 * H, H), device=dev, dtype=bf), torch.empty((2, H, 4 * H), device=dev, dtype=bf)
+    bias = torch.empty(8 * H, device=dev, dtype=bf)
+    ps = [p.detach() for p in _lstm_params(net)]
+    N.check(N.lib().dic_lstm_pack(N.ptr_array(ps), H, I, Ip, int(proj), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), N.stream_of(wih)),
+            'dic_lstm_pack')
+    w_ih = torch.stack([net.weight_ih_l0, net.weight_ih_l0_reverse]).detach()
+    w_hh = torch.stack([net.weight_hh_l0, net.weight_hh_l0_reverse]).detach()
+    b = torch.stack([net.bias_ih_l0 + net.bias_hh_l0, net.bias_ih_l0_reverse + net.bias_hh_l0_reverse]).detach()
+    want = torch.zeros((8 * H, Ip), device=dev)
+    want[:, :I] = w_ih.reshape(8 * H, I)
+    if proj:
+        want[:, I] = b.reshape(8 * H)
+    assert torch.equal(wih, want.to(bf))
+    assert torch.equal(whh, w_hh.to(bf))
+    assert torch.equal(whh_t, w_hh.transpose(1, 2).contiguous().to(bf))
+    assert torch.equal(bias, b.reshape(8 * H).to(bf))
+
+
+@pytest.mark.parametrize('R,B,I,init,accumulate', [(24, 200, 18, False, False), (3, 64, 18, True, True), (5, 130, 31, True, False),
+                                                     (1, 7, 6, False, True), (2, 4099, 18, True, False)])
+def test_lstm_dw_matches_matmul(R, B, I, init, accumulate):
+    """dic_lstm_dw (one pass over dG, MFMA with transposed LDS reads) against f64 products of the same bf16 operands:
+    dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d], dW_ih[d] = sum_t dG_t[d]^T x_t; written or accumulated into the eight gradients."""
+    from deep_interpolation_clustering_amd import _native as N
+    torch.manual_seed(R * 100 + B)
+    dev = torch.device('cuda')
+    bf = torch.bfloat16
+    dg = (torch.randn(R, B, 2, 4 * H, device=dev) * 0.3).to(bf)
+    out = (torch.randn(R, B, 2 * H, device=dev) * 0.5).to(bf)
+    x = torch.zeros(R, B, 32, device=dev)
+    x[..., :I] = torch.randn(R, B, I, device=dev)
+    x[..., I] = 1.0
+    x = x.to(bf)
+    h0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    grads = [torch.randn(4 * H, I, device=dev), torch.randn(4 * H, H, device=dev), torch.randn(4 * H, device=dev), torch.randn(4 * H, device=dev)] * 2
+    grads = [g.clone() for g in grads]
+    before = [g.clone() for g in grads]
+    L = N.lib()
+    ws = torch.empty(L.dic_lstm_dw_workspace(R, B), dtype=torch.uint8, device=dev)
+    N.check(L.dic_lstm_dw(N.ptr(dg), N.ptr(out), N.ptr(x), N.ptr(h0), R, B, H, I, 32, N.ptr_array(grads), int(accumulate), N.ptr(ws), ws.numel(),
+                          N.stream_of(dg)), 'dic_lstm_dw')
+    torch.cuda.synchronize()
+    d64, o64, x64 = dg.double(), out.double(), x.double()
+    for d in range(2):
+        hp = torch.zeros(R, B, H, device=dev, dtype=torch.float64)
+        h0d = h0[d].to(bf).double() if init else torch.zeros(B, H, device=dev, dtype=torch.float64)
+        if d == 0:
+            hp[0], hp[1:] = h0d, o64[:-1, :, :H]
+        else:
+            hp[-1], hp[:-1] = h0d, o64[1:, :, H:]
+        w_hh = torch.einsum('tbg,tbh->gh', d64[:, :, d], hp)
+        w_ih = torch.einsum('tbg,tbi->gi', d64[:, :, d], x64[..., :I])
+        base_ih = before[4 * d].double() if accumulate else 0.0
+        base_hh = before[4 * d + 1].double() if accumulate else 0.0
+        scale = float(w_hh.abs().max())
+        assert float((grads[4 * d + 1].double() - (w_hh + base_hh)).abs().max()) <= 2e-5 * scale + 1e-5
+        assert float((grads[4 * d].double() - (w_ih + base_ih)).abs().max()) <= 2e-5 * float(w_ih.abs().max()) + 1e-5
+        assert torch.equal(grads[4 * d + 2], before[4 * d + 2]) and torch.equal(grads[4 * d + 3], before[4 * d + 3])     # biases untouched
+
+
+@pytest.mark.parametrize('I,init', [(18, False), (256, True)])
+def test_lstm_param_grads_written_in_place(I, init):
+    """With ``.grad`` tensors present (the flat bucket's views) the kernels ADD the parameter gradients into them and hand autograd
+    None: same values as the autograd-returned path, on top of what the buffers held."""
+    from deep_interpolation_clustering_amd import lstm as L
+    torch.manual_seed(5)
+    dev = torch.device('cuda')
+    R, B = 6, 96
+    net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, I, device=dev)
+    h0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    go = torch.randn(R, B, 2 * H, device=dev)
+
+    def run():
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out, (hn, cn) = L.bilstm(x, net, h0, h0)
+        ((out.float() * go).sum() + hn.sum()).backward()
+    run()                                                   # .grad is None: gradients come back through autograd
+    ref = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = torch.full_like(p, 0.25)                   # now the sinks exist: the kernels accumulate
+    ptrs = {k: p.grad.data_ptr() for k, p in net.named_parameters()}
+    run()
+    for k, p in net.named_parameters():
+        assert p.grad.data_ptr() == ptrs[k]
+        np.testing.assert_allclose((p.grad - 0.25).cpu().numpy(), ref[k].cpu().numpy(), rtol=1e-4, atol=1e-4 * float(ref[k].abs().max()))
+
+
+def test_packed_interp_encoder_path_matches_unpacked():
+    """ops.sci_cci_packed -> lstm.bilstm_packed (the interpolation kernel writes the recurrence kernel's input rows, the input
+    gradient returns in that layout) against the module path sci_cci -> permute -> bilstm on the same parameters."""
+    from deep_interpolation_clustering_amd import lstm as L
+    from deep_interpolation_clustering_amd import ops
+    from oracle.synth import vitals_stack
+    torch.manual_seed(3)
+    dev = torch.device('cuda')
+    B, C, T, R, Hh = 150, 6, 96, 24, 24.0
+    x_np, n = vitals_stack(5, B, C, T, Hh, 50)
+    x, lens = torch.tensor(x_np, device=dev), torch.tensor(n, device=dev)
+    net = torch.nn.LSTM(3 * C, H, num_layers=1, bidirectional=True).to(dev)
+    grid = ops.ref_grid(Hh, R, dev)
+    go = torch.randn(R, B, 2 * H, device=dev)
+    res = {}
+    for mode in ('module', 'packed'):
+        ks = torch.rand(C, device=dev).requires_grad_()
+        kc = (torch.eye(C, device=dev) + 0.1 * torch.randn(C, C, device=dev)).requires_grad_()
+        torch.manual_seed(9)
+        ks.data.copy_(torch.rand(C))
+        kc.data.copy_(torch.eye(C) + 0.1 * torch.randn(C, C))
+        net.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            if mode == 'packed':
+                out, (hn, cn) = L.bilstm_packed(ops.sci_cci_packed(x, ks, kc, grid, lens), net)
+            else:
+                out, (hn, cn) = L.bilstm(ops.sci_cci(x, ks, kc, grid, lens).permute(1, 0, 2), net)
+        ((out.float() * go).sum() + (hn * 0.5).sum() + cn.sum()).backward()
+        res[mode] = dict(out=out.detach().float(), hn=hn.detach(), ks=ks.grad.clone(), kc=kc.grad.clone(),
+                         **{k: p.grad.clone() for k, p in net.named_parameters()})
+    assert torch.equal(res['module']['out'], res['packed']['out'])          # same bf16 input rows -> the same recurrence, bit for bit
+    assert torch.equal(res['module']['hn'], res['packed']['hn'])
+    for k in res['module']:
+        if k in ('out', 'hn'):
+            continue
+        a, b = res['packed'][k].cpu().numpy(), res['module'][k].cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=2e-2, atol=4e-3 * np.abs(b).max(), err_msg=k)     # dX stays bf16 on the packed path
