@@ -20,14 +20,19 @@ constexpr int GH = 128;            // hidden size
 constexpr int G4 = 4 * GH;         // gate rows per direction
 constexpr int XW = 32;             // packed encoder input width (MFMA k-step multiple; column I carries the constant one)
 constexpr int NW = GH + XW;        // B-operand columns of the fused product: [h_prev | x]
-constexpr int TR = 64;             // (t, b) rows per tile = 4 MFMA k-steps
-// LDS row pitches (bytes).  A transposed read takes 4 rows x 64 contiguous bytes per 32-lane half: a pitch of 64 (mod 256)
-// puts the 4 rows on disjoint 16-bank groups.
+constexpr int TR = 32;             // (t, b) rows per tile = 2 MFMA k-steps
+constexpr int NBUF = 3;            // LDS ring: one tile being read, two in flight
+// LDS image of a tile.  A transposed read (ds_read_b64_tr_b16) takes 4 rows x 64 contiguous bytes per 32-lane half:
+//   dG rows (1 KiB, one LDS-DMA instruction each) sit at a pitch of 1024 + 64 B -> the 4 rows fall on disjoint 16-bank groups;
+//   h rows (256 B) arrive four to a DMA instruction, contiguous, so the spreading is an XOR on the 16-B piece index instead
+//   (piece c of row r is stored at position c ^ ((r & 3) << 2): applied to the SOURCE address of the DMA and to the reads);
+//   x rows (64 B) are conflict-free as they lie.
 constexpr int DG_PITCH = 2 * G4 + 64;     // 1088
-constexpr int H_PITCH = 2 * GH + 64;      // 320
+constexpr int H_PITCH = 2 * GH;           // 256
 constexpr int X_PITCH = 2 * XW;           // 64
 constexpr int LDS_DG = TR * DG_PITCH, LDS_H = TR * H_PITCH, LDS_X = TR * X_PITCH;
-constexpr int DW_LDS = 2 * LDS_DG + LDS_H + LDS_X;  // 163 840 B = the whole LDS of a CU: two dG buffers (LDS-DMA), one h | x buffer
+constexpr int SLOT = LDS_DG + LDS_H + LDS_X;        // 45 056 B
+constexpr int DW_LDS = NBUF * SLOT;                 // 135 168 B: one workgroup per CU
 constexpr int DW_OUT = 2 * G4 * NW;                 // outputs per partial: [dir][gate row][h cols | x cols]
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -74,10 +79,10 @@ __global__ __launch_bounds__(256) void lstm_pack_kernel(LstmParams p, int I, int
 
 // ------------------------------------------------------------------------------------------------ fused dW (encoder)
 struct DwArgs {
-    const __bf16* dg;      // (R,B,2,4H) gate gradients
-    const __bf16* out;     // (R,B,2H)   the layer's own outputs h_t (forward | reverse)
-    const __bf16* x;       // (R,B,XW)   packed inputs
-    const float* h0;       // (2,B,H) initial hidden state or NULL (zeros)
+    const __bf16* dg;      // (R*B, 2, 4H) gate gradients
+    const __bf16* hext;    // ((R+2)*B, 2H)  the layer's outputs with one extra time slot at either end: slot 0 holds h0 of the forward
+                           //                direction in [:H], slot R+1 h0 of the reverse direction in [H:] (zeros without an h0)
+    const __bf16* x;       // (R*B, XW)      packed inputs
     float* partials;       // (gridDim.x, 2, 4H, NW) per-workgroup sums
     int R, B;
 };
@@ -85,83 +90,75 @@ struct DwArgs {
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
+// LDS-DMA written as asm so that hipcc does NOT count it: with the builtin, the compiler's LDS-DMA tracking puts an
+// s_waitcnt vmcnt(0) in front of the first ds_read after any outstanding DMA (it cannot tell the ring slots apart), which
+// serialises load and compute.  Uncounted, the loop's own counted vmcnt + raw s_barrier are the only waits; the loop issues
+// no other vector-memory instruction, so nothing of the compiler's bookkeeping is disturbed.  M0 = LDS destination base
+// (lane i lands at base + 16 i / 4 i); saved and restored around the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_dst) {      // 64 lanes x 16 B -> 1 KiB at lds_dst
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* sbase, unsigned voff, unsigned lds_dst) {       // 64 lanes x 4 B -> 256 B at lds_dst
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 
-// grid (nch, 2 directions), 256 threads = 4 waves, one workgroup per CU.  Wave w owns gate rows [128w, 128w+128) of its
-// direction: 4 m-blocks x 5 n-blocks of 32x32 f32 accumulators (320 VGPRs).  Tiles of 64 (t, b) rows stream through LDS: the dG
-// rows (1 KiB each) by LDS-DMA into one of two buffers -- no staging registers, the next tile lands while the matrix cores
-// work on the current one -- the narrow h / x rows through registers.
-__global__ __launch_bounds__(256, 1) void lstm_dw_kernel(DwArgs a) {
+// grid (nch, 2 directions), 512 threads = 8 waves (two per SIMD), one workgroup per CU.  Wave w owns gate rows [64w, 64w+64) of
+// its direction: 2 m-blocks x 5 n-blocks of 32x32 f32 accumulators (160 registers; four waves x 320 spilled accumulators).  The R*B rows are cut into tiles of 32 without
+// regard to the (t, b) structure: the recurrent input of row i is row i (forward) / i + 2B (reverse) of the extended output
+// buffer.  Every byte comes in by LDS-DMA into a ring of three tile images; per tile ONE raw s_barrier and a COUNTED
+// s_waitcnt vmcnt, so two tiles (90 KB per CU) stay in flight across the barrier while the matrix cores work on the third
+// (a __syncthreads() here drains the DMA queue: measured 0.55 ms instead of the 0.4 ms HBM floor).
+__global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
     extern __shared__ __align__(16) unsigned char dwsm[];
-    unsigned char* sdg0 = dwsm;
-    unsigned char* sh = dwsm + 2 * LDS_DG;
-    unsigned char* sx = sh + LDS_H;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int dir = blockIdx.y, B = a.B, R = a.R;
-    const int nbt = (B + TR - 1) / TR, ntiles = R * nbt, nch = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const long nrows = (long)a.R * a.B;
+    const int ntiles = (int)((nrows + TR - 1) / TR), nch = gridDim.x;
+    const __bf16* hsrc = a.hext + (dir ? (size_t)2 * a.B * 2 * GH + GH : 0);        // row i of this view = h_prev of row i
 
-    f32x16 acc[4][5];
+    f32x16 acc[2][5];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 5; ++nb)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[mb][nb][k] = 0.f;
 
-    uint4 rh[4], rx;
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    auto request_dg = [&](int idx, int buf) {      // rows past the batch are clamped: their h / x rows are zero, so they add nothing
-        const int t = idx / nbt, b0 = (idx - t * nbt) * TR;
+    // a tile = rows [r0, r0 + 32), r0 = min(32 tile, nrows - 32): the last tile of a ragged row count is shifted back so that it ends
+    // with the data; the rows it shares with its predecessor get their h / x rows zeroed after landing
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)dwsm);
+    const unsigned v_dg = lane * 16;                                                     // per-lane byte offsets of the three streams
+    const unsigned v_h = (lane >> 4) * (2 * GH * 2) + (((lane & 15) ^ ((lane >> 4) << 2)) * 16);
+    const unsigned v_x = lane * 4;
+    auto request = [&](int tile, int slot) {
+        const long r0 = min((long)tile * TR, nrows - TR);
+        const unsigned base = lds0 + slot * SLOT;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int row = p * 4 + w;
-            const int b = min(b0 + row, B - 1);
-            const __bf16* src = a.dg + (((size_t)t * B + b) * 2 + dir) * G4 + lane * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sdg0 + buf * LDS_DG + row * DG_PITCH), 16, 0, 0);
+        for (int p = 0; p < 4; ++p) {              // dG: one row (1 KiB of this direction) per instruction
+            const int row = p * 8 + w;
+            dma16(a.dg + ((size_t)(r0 + row) * 2 + dir) * G4, v_dg, base + row * DG_PITCH);
         }
-    };
-    auto load_hx = [&](int idx) {
-        const int t = idx / nbt, b0 = (idx - t * nbt) * TR;
-        const int tp = dir ? t + 1 : t - 1;     // the step whose output fed this step's recurrent product
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = p * 16 + (tid >> 4), ch = tid & 15;
-            const int b = b0 + row;
-            uint4 v = zero4;
-            if (b < B) {
-                if (tp >= 0 && tp < R) {
-                    v = *reinterpret_cast<const uint4*>(a.out + ((size_t)tp * B + b) * 2 * GH + dir * GH + ch * 8);
-                } else if (a.h0) {
-                    const float* hp = a.h0 + ((size_t)dir * B + b) * GH + ch * 8;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(hp), hi = *reinterpret_cast<const f32x4*>(hp + 4);
-                    bf16x8 hb;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { hb[j] = (__bf16)lo[j]; hb[4 + j] = (__bf16)hi[j]; }
-                    v = *reinterpret_cast<const uint4*>(&hb);
-                }
-            }
-            rh[p] = v;
-        }
-        {
-            const int row = tid >> 2, ch = tid & 3;
-            const int b = b0 + row;
-            rx = b < B ? *reinterpret_cast<const uint4*>(a.x + ((size_t)t * B + b) * XW + ch * 8) : zero4;
-        }
-    };
-    auto store_hx = [&]() {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(sh + (p * 16 + (tid >> 4)) * H_PITCH + (tid & 15) * 16) = rh[p];
-        *reinterpret_cast<uint4*>(sx + (tid >> 2) * X_PITCH + (tid & 3) * 16) = rx;
+        // h: four 256-B rows per instruction, 16-B pieces XOR-swizzled through the source address
+        dma16(hsrc + (size_t)(r0 + w * 4) * 2 * GH, v_h, base + LDS_DG + w * 4 * H_PITCH);
+        // x: four 64-B rows per 4-B-per-lane instruction (every wave issues the same number of instructions: one counted wait fits all)
+        dma4(a.x + (size_t)r0 * XW + w * 128, v_x, base + LDS_DG + LDS_H + w * 256);
     };
 
     // transposed-read addressing (ds_read_b64_tr_b16): within each 16-lane group, lane 4q+p supplies row q, columns 4p..4p+3 of a
     // 4-row x 16-column block and lane i receives column i of those 4 rows.  For the 32x32x16 operand lane l needs column
     // (l & 31) and rows 8*(l >> 5) + 0..7 of the k-step: group (l >> 4) & 1 takes columns 16.., two reads take rows +0..3, +4..7.
     const int kq = (lane & 15) >> 2, kp = lane & 3, cb = (lane >> 4) & 1, hh = lane >> 5;
-    const int rowoff = 8 * hh + kq;
-    const unsigned char* pa0 = sdg0 + rowoff * DG_PITCH + (128 * w + 16 * cb + 4 * kp) * 2;
-    const unsigned char* ph = sh + rowoff * H_PITCH + (16 * cb + 4 * kp) * 2;
-    const unsigned char* px = sx + rowoff * X_PITCH + (16 * cb + 4 * kp) * 2;
+    const int rowoff = 8 * hh + kq;                                    // (rowoff & 3) == kq for both reads (+4 rows)
+    const int pa_off = rowoff * DG_PITCH + (64 * w + 16 * cb + 4 * kp) * 2;
+    const int px_off = LDS_DG + LDS_H + rowoff * X_PITCH + (16 * cb + 4 * kp) * 2;
+    int ph_off[4];                                                      // 16-B piece (4 nb + 2 cb + (kp >> 1)) ^ (kq << 2), 8-B half kp & 1
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) ph_off[nb] = LDS_DG + rowoff * H_PITCH + (((4 * nb + 2 * cb + (kp >> 1)) ^ (kq << 2)) * 16) + (kp & 1) * 8;
     auto frag = [&](const unsigned char* p, int pitch) {
         const s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 4 * pitch);
         s16x8 f;
@@ -170,40 +167,51 @@ __global__ __launch_bounds__(256, 1) void lstm_dw_kernel(DwArgs a) {
         return __builtin_bit_cast(bf16x8, f);
     };
 
-    int idx = blockIdx.x, cur = 0;
-    if (idx < ntiles) { request_dg(idx, 0); load_hx(idx); }
-    while (idx < ntiles) {
-        __syncthreads();                       // every wave's DMA of this tile has landed (the barrier waits for vmcnt 0) and the
-                                               // previous tile's LDS reads have retired
-        store_hx();
-        const int next = idx + nch;
-        if (next < ntiles) { request_dg(next, cur ^ 1); load_hx(next); }
-        __syncthreads();                       // h | x rows visible
-        const unsigned char* pa = pa0 + cur * LDS_DG;
-#pragma unroll 1                               // (unrolled, the compiler hoists all 72 fragment reads of a tile and spills)
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[4];
+    int tile = blockIdx.x, slot = 0;
+    if (tile < ntiles) request(tile, 0);
+    if (tile + nch < ntiles) request(tile + nch, 1);
+    for (; tile < ntiles; tile += nch) {
+        // this wave's DMA of the current tile has landed once at most the next tile's instructions are outstanding
+        if (tile + nch < ntiles) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // 6 = LDS-DMA instructions per wave and tile: 4 dG + 1 h + 1 x
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // ... and every other wave's; all waves are done reading the slot refilled next
+        if (tile + 2 * nch < ntiles) request(tile + 2 * nch, slot == 0 ? 2 : slot - 1);
+        unsigned char* base = dwsm + slot * SLOT;
+        if ((long)tile * TR + TR > nrows) {        // the shifted last tile: its first rows were summed by the previous tile already
+            const int dup = (int)((long)tile * TR + TR - nrows);
+            for (int i = tid; i < dup * (H_PITCH + X_PITCH) / 16; i += 512) {
+                const int nh = dup * H_PITCH / 16;
+                unsigned char* dst = i < nh ? base + LDS_DG + i * 16 : base + LDS_DG + LDS_H + (i - nh) * 16;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll 1                               // (unrolled, the compiler hoists every fragment read of a tile and spills)
+        for (int ks = 0; ks < TR / 16; ++ks) {
+            const unsigned char* kb = base + ks * 16 * DG_PITCH;
+            bf16x8 af[2];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) af[mb] = frag(pa + ks * 16 * DG_PITCH + mb * 64, DG_PITCH);
+            for (int mb = 0; mb < 2; ++mb) af[mb] = frag(kb + pa_off + mb * 64, DG_PITCH);
 #pragma unroll
             for (int nb = 0; nb < 5; ++nb) {
-                const bf16x8 bfg = nb < 4 ? frag(ph + ks * 16 * H_PITCH + nb * 64, H_PITCH) : frag(px + ks * 16 * X_PITCH, X_PITCH);
+                const bf16x8 bfg = nb < 4 ? frag(base + ks * 16 * H_PITCH + ph_off[nb < 4 ? nb : 0], H_PITCH)
+                                          : frag(base + ks * 16 * X_PITCH + px_off, X_PITCH);
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfg, acc[mb][nb], 0, 0, 0);
+                for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfg, acc[mb][nb], 0, 0, 0);
             }
         }
-        idx = next;
-        cur ^= 1;
+        slot = slot == NBUF - 1 ? 0 : slot + 1;
     }
     // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     float* o = a.partials + ((size_t)blockIdx.x * 2 + dir) * G4 * NW;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 5; ++nb)
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int m = 128 * w + 32 * mb + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                const int m = 64 * w + 32 * mb + (k & 3) + 8 * (k >> 2) + 4 * hh;
                 o[(size_t)m * NW + 32 * nb + (lane & 31)] = acc[mb][nb][k];
             }
 }
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void lstm_unpack_grads_kernel(const float* dw_
 }
 
 static int dw_chunks(int R, int B) {
-    const int ntiles = R * ((B + TR - 1) / TR);
+    const int ntiles = (int)(((long)R * B + TR - 1) / TR);
     return max(1, min(ntiles, kNumCU / 2));        // x 2 directions = one workgroup per CU
 }
 
@@ -292,12 +300,13 @@ size_t dic_lstm_dw_workspace(int R, int B) {
     return (size_t)dw_chunks(R, B) * DW_OUT * sizeof(float);
 }
 
-int dic_lstm_dw(const void* dgx, const void* out, const void* x, const float* h0, int R, int B, int H, int I, int Ip,
+int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, int R, int B, int H, int I, int Ip,
                 float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_dw: non-positive size");
     DIC_REQUIRE(H == GH, DIC_ERR_UNSUPPORTED, "lstm_dw: hidden size %d (compiled for %d)", H, GH);
     DIC_REQUIRE(Ip == XW && I > 0 && I <= XW, DIC_ERR_UNSUPPORTED, "lstm_dw: packed input width %d / %d (compiled for %d)", I, Ip, XW);
-    DIC_REQUIRE(dgx && out && x && workspace, DIC_ERR_INVALID_ARG, "lstm_dw: NULL pointer");
+    DIC_REQUIRE(dgx && out_ext && x && workspace, DIC_ERR_INVALID_ARG, "lstm_dw: NULL pointer");
+    DIC_REQUIRE((long)R * B >= TR, DIC_ERR_UNSUPPORTED, "lstm_dw: R*B = %ld rows < one %d-row tile (use the GEMM path)", (long)R * B, TR);
     LstmGrads g;
     int rc = grads_from(grads, &g, true, false, "lstm_dw");
     if (rc) return rc;
@@ -311,8 +320,8 @@ int dic_lstm_dw(const void* dgx, const void* out, const void* x, const float* h0
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    DwArgs a{(const __bf16*)dgx, (const __bf16*)out, (const __bf16*)x, h0, (float*)workspace, R, B};
-    hipLaunchKernelGGL(lstm_dw_kernel, dim3(nch, 2), dim3(256), DW_LDS, st, a);
+    DwArgs a{(const __bf16*)dgx, (const __bf16*)out_ext, (const __bf16*)x, (float*)workspace, R, B};
+    hipLaunchKernelGGL(lstm_dw_kernel, dim3(nch, 2), dim3(512), DW_LDS, st, a);
     hipLaunchKernelGGL(lstm_dw_finalize, dim3((DW_OUT + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, I, g,
                        accumulate ? 1.0f : 0.0f);
     return check_launch("lstm_dw");

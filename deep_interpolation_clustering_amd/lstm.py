@@ -78,7 +78,7 @@ class _BiLstm(torch.autograd.Function):
                 xb[..., I].fill_(1.0)                              # the bias rides along as a constant-one input column
         out_ext = torch.empty((R + 2, B, 2 * H), device=dev, dtype=bf)      # [h0 | h_1..h_R | h0]: every step's h_prev is a row above / below
         out = out_ext[1:R + 1]
-        if need and not proj:                                      # boundary rows of the dW_hh products (backward); the other halves are never read
+        if need:                                                   # boundary rows of the dW_hh products (backward); the other halves are never read
             if h0 is None:
                 out_ext[0, :, :H].zero_()
                 out_ext[R + 1, :, H:].zero_()
@@ -138,10 +138,10 @@ class _BiLstm(torch.autograd.Function):
         if any(needs):
             sinks, accumulate = _grad_sinks(params, needs)
             gp = N.ptr_array(sinks)
-            if proj:
-                # dW_ih and dW_hh of both directions from one pass over dG (csrc/dic_lstmgrad.hip)
+            if proj and R * B >= 32:
+                # dW_ih and dW_hh of both directions from one pass over dG (csrc/dic_lstmgrad.hip; it tiles the R*B rows by 32)
                 ws2 = torch.empty(max(16, Lb.dic_lstm_dw_workspace(R, B)), device=dev, dtype=torch.uint8)
-                N.check(Lb.dic_lstm_dw(N.ptr(dgx), N.ptr(out), N.ptr(xb), N.ptr(h0c), R, B, H, I, Ip, gp, int(accumulate), N.ptr(ws2),
+                N.check(Lb.dic_lstm_dw(N.ptr(dgx), N.ptr(out_ext), N.ptr(xb), R, B, H, I, Ip, gp, int(accumulate), N.ptr(ws2),
                                        ws2.numel(), st), 'dic_lstm_dw')
                 N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             else:

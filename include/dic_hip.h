@@ -236,8 +236,10 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
  *     constant-one input column); rest 0], whh (2,4H,H) bf16, whh_t (2,H,4H) bf16 or NULL, bias (2*4H) bf16 = b_ih + b_hh
  *     or NULL.  One launch replaces the stack / add / cast / pad / transpose sequence of torch ops.
  *   dic_lstm_dw (encoder, packed input width Ip == 32): weight gradients from ONE pass over the gate gradients,
- *     dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d] (h_{t-1} for d = 0, h_{t+1} for d = 1, h0 or zeros at the ends; `out` is the
- *     layer's own output (R,B,2H) bf16) and dW_ih[d] = sum_t dG_t[d]^T x_t[:, :I] (x (R,B,Ip) bf16), MFMA with transposed LDS
+ *     dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d] (h_{t-1} for d = 0, h_{t+1} for d = 1) and dW_ih[d] = sum_t dG_t[d]^T x_t[:, :I]
+ *     (x (R,B,Ip) bf16).  out_ext (R+2,B,2H) bf16 = the layer's own output in time slots 1..R (pass &out_ext[1] to
+ *     dic_lstm_fwd*), slot 0 [:, :H] = h0 of the forward direction and slot R+1 [:, H:] = h0 of the reverse direction (zeros
+ *     without an h0): every step's recurrent input is then the row B above / below its dG row.  MFMA with transposed LDS
  *     reads, deterministic two-stage reduction, written (accumulate = 0) or added (accumulate = 1) straight into the
  *     parameter gradients `grads` (host array of 8 device pointers, same order; the bias entries are not touched).
  *   dic_lstm_unpack_grads: staging tensors dw_ih (2*4H, ldw) / dw_hh (2,4H,H) / dbias (2*4H) f32 (each may be NULL) ->
@@ -245,7 +247,7 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
 int dic_lstm_pack(const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
                   dic_stream_t stream);
 size_t dic_lstm_dw_workspace(int R, int B);
-int dic_lstm_dw(const void* dgx, const void* out, const void* x, const float* h0, int R, int B, int H, int I, int Ip,
+int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, int R, int B, int H, int I, int Ip,
                 float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,
                           int accumulate, dic_stream_t stream);

@@ -353,7 +353,7 @@ def test_lstm_pack_matches_torch(I):
 
 
 @pytest.mark.parametrize('R,B,I,init,accumulate', [(24, 200, 18, False, False), (3, 64, 18, True, True), (5, 130, 31, True, False),
-                                                     (1, 7, 6, False, True), (2, 4099, 18, True, False)])
+                                                     (1, 37, 6, False, True), (2, 4099, 18, True, False), (3, 11, 18, True, True)])
 def test_lstm_dw_matches_matmul(R, B, I, init, accumulate):
     """dic_lstm_dw (one pass over dG, MFMA with transposed LDS reads) against f64 products of the same bf16 operands:
     dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d], dW_ih[d] = sum_t dG_t[d]^T x_t; written or accumulated into the eight gradients."""
@@ -373,7 +373,11 @@ def test_lstm_dw_matches_matmul(R, B, I, init, accumulate):
     before = [g.clone() for g in grads]
     L = N.lib()
     ws = torch.empty(L.dic_lstm_dw_workspace(R, B), dtype=torch.uint8, device=dev)
-    N.check(L.dic_lstm_dw(N.ptr(dg), N.ptr(out), N.ptr(x), N.ptr(h0), R, B, H, I, 32, N.ptr_array(grads), int(accumulate), N.ptr(ws), ws.numel(),
+    out_ext = torch.full((R + 2, B, 2 * H), float('nan'), device=dev, dtype=bf)      # the halves the kernel must not read stay NaN
+    out_ext[1:R + 1] = out
+    out_ext[0, :, :H] = h0[0] if init else 0.0
+    out_ext[R + 1, :, H:] = h0[1] if init else 0.0
+    N.check(L.dic_lstm_dw(N.ptr(dg), N.ptr(out_ext), N.ptr(x), R, B, H, I, 32, N.ptr_array(grads), int(accumulate), N.ptr(ws), ws.numel(),
                           N.stream_of(dg)), 'dic_lstm_dw')
     torch.cuda.synchronize()
     d64, o64, x64 = dg.double(), out.double(), x.double()
