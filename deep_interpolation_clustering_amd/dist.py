@@ -93,7 +93,9 @@ class FlatParams:
     def active_mask(self):
         """Per-element byte mask of the parameters the last backward reached, or None when it reached all of them.  Cached per
         reach pattern (it is a property of the loss configuration, constant from step to step)."""
-        key = tuple(self._reached)
+        # (kernels that add a parameter gradient straight into its .grad view -- lstm._grad_sinks -- bypass autograd's
+        # AccumulateGrad and therefore the hook: they leave the mark `_dic_grad_written` on the parameter instead)
+        key = tuple(r or getattr(p, '_dic_grad_written', False) for r, p in zip(self._reached, self.params))
         if all(key) or not any(key):          # nothing recorded (e.g. a replayed hipGraph) counts as 'all', the common case
             return None
         if key != self._mask_key:
@@ -123,6 +125,8 @@ class FlatParams:
         self.grad.zero_()
         self._attach()          # re-attach in case something replaced .data / .grad
         self._reached = [False] * len(self.params)
+        for p in self.params:
+            p._dic_grad_written = False
 
     def all_reduce_grads(self):
         """Sum over ranks: each rank's loss is already normalised by GLOBAL batch statistics, so

@@ -42,6 +42,8 @@ def _grad_sinks(params, needs):
     When every parameter already owns a dense f32 ``.grad`` (the views of the flat bucket, zeroed at the start of the step) the
     kernels add into it and autograd is handed ``None``; otherwise fresh tensors are returned through autograd."""
     if all(needs) and all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params):
+        for p in params:
+            p._dic_grad_written = True         # dist.FlatParams.active_mask: autograd's accumulate hook will not fire for these
         return [p.grad for p in params], True
     return [torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format) for p in params], False
 

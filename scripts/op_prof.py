@@ -18,18 +18,18 @@ st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), bench.make
 for _ in range(3): st.step(X, OB, None, LEN)
 torch.cuda.synchronize()
 N = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for _ in range(N): st.step(X, OB, None, LEN)
     torch.cuda.synchronize()
 # ops that directly launch kernels: self device time > 0
 rows = []
-for e in prof.key_averages(group_by_stack_n=6):
+for e in prof.key_averages(group_by_input_shape=True):
     sd = getattr(e, 'self_device_time_total', 0)
     if sd > 0 and e.key.startswith('aten::'):
-        rows.append((sd / N, e.count / N, e.key, [s for s in e.stack if 'deep_interpolation' in s or 'bench' in s][:3]))
+        rows.append((sd / N, e.count / N, e.key, [str(e.input_shapes)[:110]]))
 rows.sort(reverse=True)
 tot = 0
-for sd, cnt, key, stack in rows[:70]:
+for sd, cnt, key, stack in rows[:90]:
     tot += sd
     print('%8.1f us/step x%-5.1f %-28s %s' % (sd, cnt, key, ' <- '.join(s.split('/')[-1] for s in stack)))
 print('total aten self device time/step: %.1f us' % sum(r[0] for r in rows))

@@ -244,3 +244,35 @@ def test_hip_graph_replays_draw_fresh_dropout_masks():
     net.eval()                                    # dropout off: the (re-captured, eval-mode) step is deterministic
     e = [float(st.forward_loss(X, OB, None, LEN)[0]['ae_mse'].detach()) for _ in range(2)]
     assert e[0] == e[1]
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_bf16_step_updates_every_parameter(graphs):
+    """The fast mode writes some gradients (the LSTMs') straight into the flat bucket, past autograd's accumulate hooks that tell
+    the optimiser which parameters a backward reached: after two steps EVERY parameter tensor must have moved, and by the same
+    amount as when all gradients travel through autograd (the f32 mode), up to bf16 effects on their direction."""
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=4, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    coh = synthetic.make_cohort(256, seed=21)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    moved = {}
+    for mode in ('bf16', 'f32'):
+        torch.manual_seed(4)
+        net = Net(args, dev).to(dev)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16 if mode == 'bf16' else None,
+                     use_graphs=graphs and mode == 'bf16')
+        before = {k: v.detach().clone() for k, v in net.named_parameters()}
+        for _ in range(2):
+            st.step(X, OB, None, LEN)
+        moved[mode] = {k: float((v.detach() - before[k]).abs().mean()) for k, v in net.named_parameters()}
+    for k, d in moved['bf16'].items():
+        assert d > 0, f'{k} did not move'
+        assert 0.5 * moved['f32'][k] < d < 2.0 * moved['f32'][k], f"{k}: mean |update| {d:.3e} vs {moved['f32'][k]:.3e} through autograd"
