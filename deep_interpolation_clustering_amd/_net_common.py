@@ -33,11 +33,12 @@ class EncoderRNN(nn.Module):
         self.num_directions = 2 if bidirectional else 1
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
 
-    def forward(self, x, packed=False):
+    def forward(self, x, packed=False, batch_major_state=False):
+        """``batch_major_state`` (fused path only): hidden / cell_state come back as (B,2,H) -- see lstm.bilstm."""
         if packed:                                           # (R,B,32) bf16 rows straight from ops.sci_cci_packed
-            output, (hidden, cell_state) = fused_lstm.bilstm_packed(x, self.lstm)
+            output, (hidden, cell_state) = fused_lstm.bilstm_packed(x, self.lstm, batch_major_state=batch_major_state)
         elif fused_lstm.fused_available(x, self.lstm):      # bf16 autocast on the GPU: persistent HIP recurrence
-            output, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm)
+            output, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, batch_major_state=batch_major_state)
         else:
             output, (hidden, cell_state) = self.lstm(x)
         return output, hidden, cell_state
@@ -49,10 +50,10 @@ class DecoderRNN(nn.Module):
         self.device, self.hidden_size = device, hidden_size
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
 
-    def forward(self, x, hidden, context):
+    def forward(self, x, hidden, context, batch_major_state=False):
         x = F.relu(x)                                                           # clustering_interp.py:38-41
         if fused_lstm.fused_available(x, self.lstm):
-            x, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, hidden, context)
+            x, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, hidden, context, batch_major_state=batch_major_state)
         else:
             x, (hidden, cell_state) = self.lstm(x, (hidden, context))
         return x, (hidden, cell_state)
@@ -129,6 +130,11 @@ class NetBase(nn.Module):
         dist.convert_batchnorm_(self)
 
     # ------------------------------------------------------------------------------ forward
+    @staticmethod
+    def _latent(hidden, batch_major):
+        """z = cat(h_fwd, h_rev) (clustering_interp.py:139): a view when the states are batch-major."""
+        return hidden.reshape(hidden.size(0), -1) if batch_major else torch.cat([h for h in hidden], dim=-1)
+
     def _packed_path(self, x):
         """bf16 step on the GPU with 3C < 32 features: the interpolation kernel writes the encoder LSTM's input rows itself."""
         return 3 * self.num_variables < ops.PACKED_WIDTH and fused_lstm.fused_available(x, self.encoder.lstm)
@@ -152,20 +158,24 @@ class NetBase(nn.Module):
             feats.append(self._interp(fake_x, lengths, packed))
         if want_pos:
             feats.append(self._interp(positive_x, lengths, packed))
+        # fused recurrence (bf16 step): final states in batch-major (B,2,H) layout -- the latent z = [h_fwd | h_rev] is then a VIEW of
+        # h_n, and the decoder takes (h_n, c_n) as they lie: no cat / slice / copy kernels between encoder, DEC head and decoder
+        bm = fused_lstm.fused_available(feats[0], self.encoder.lstm)
         if len(feats) > 1 and B * feats[0].size(0) >= SEPARATE_ENCODER_ROWS:
             # large batches: one encoder call per branch.  Each already fills the chip, and the shared call would cost three
             # 100-MB-class copies (stacking the inputs, slicing the real half of the context and of the final states back out)
-            outs = [self.encoder(f, packed) for f in feats]
+            outs = [self.encoder(f, packed, bm) for f in feats]
             context, hidden, cell = outs[0]
-            z_all = torch.cat([torch.cat([h for h in o[1]], dim=-1) for o in outs], dim=0)          # (nB, 256)
+            z_all = torch.cat([self._latent(o[1], bm) for o in outs], dim=0)                     # (nB, 256)
         else:
             seq = feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)                        # (R, nB, .)
-            context, hidden, cell = self.encoder(seq, packed)
-            z_all = torch.cat([h for h in hidden], dim=-1)                # (nB, 256)
+            context, hidden, cell = self.encoder(seq, packed, bm)
+            z_all = self._latent(hidden, bm)                                                      # (nB, 256)
             if len(feats) > 1:
-                context, hidden, cell = context[:, :B], hidden[:, :B].contiguous(), cell[:, :B].contiguous()
+                context = context[:, :B]
+                hidden, cell = (hidden[:B], cell[:B]) if bm else (hidden[:, :B].contiguous(), cell[:, :B].contiguous())
         cat_hidden = z_all[:B]
-        y, _ = self.decoder(context, hidden, cell)
+        y, _ = self.decoder(context, hidden, cell, bm) if bm else self.decoder(context, hidden, cell)
         y = self.rbf(y.permute(1, 2, 0), x, lengths)                      # (B,C,T)
 
         aux = dict()

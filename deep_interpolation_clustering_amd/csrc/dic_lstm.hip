@@ -58,6 +58,10 @@ __device__ __forceinline__ size_t native_off(int t, int nbt, int bt, int dir, in
     return o * 4;
 }
 
+// (h0, c0, hn, cn and their gradients) element offset of (direction, batch row): nn.LSTM's (2,B,H) layout, or batch-major (B,2,H)
+// -- the latter makes hn.view(B, 2H) the concatenated latent [h_fwd | h_rev] and feeds the next LSTM with no copy
+__device__ __forceinline__ size_t state_off(int bm, int dir, int b, int B) { return (bm ? (size_t)b * 2 + dir : (size_t)dir * B + b) * LH; }
+
 constexpr int LXK = 32;            // input width of the fused-projection variant (two MFMA k-steps)
 constexpr int XSTR = LXK + 8;      // bf16 elements per LDS row of the x tile (80 B: conflict-free ds_read_b128)
 
@@ -83,6 +87,7 @@ struct LstmFwdArgs {
     __bf16* gates;         // lane-native (R,Bpad,2,4,H) post-activation i,f,g,o, or NULL (inference)
     __bf16* cs;            // lane-native (R,Bpad,2,H) cell states rounded to bf16 (the recurrence itself carries c in f32), or NULL
     int R, B;
+    int bm;                // state tensors batch-major (B,2,H) instead of (2,B,H)
 };
 
 // PROJ = false: G_t starts from a precomputed gx_t (the projection was a library GEMM: decoder, input width 256).
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
             const int u = 32 * w + 8 * q + 4 * hh;
             f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
             if (b < B) {
-                if (a.h0) hv = *reinterpret_cast<const f32x4*>(a.h0 + ((size_t)dir * B + b) * LH + u);
-                if (a.c0) cv = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + b) * LH + u);
+                if (a.h0) hv = *reinterpret_cast<const f32x4*>(a.h0 + state_off(a.bm, dir, b, B) + u);
+                if (a.c0) cv = *reinterpret_cast<const f32x4*>(a.c0 + state_off(a.bm, dir, b, B) + u);
             }
             bf16x4 hb;
 #pragma unroll
@@ -261,8 +266,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                     const size_t row = (size_t)t * B + b;
                     *reinterpret_cast<bf16x4*>(a.out + row * 2 * LH + dir * LH + u) = hb;
                     if (last) {
-                        *reinterpret_cast<f32x4*>(a.hn + ((size_t)dir * B + b) * LH + u) = hv;
-                        *reinterpret_cast<f32x4*>(a.cn + ((size_t)dir * B + b) * LH + u) = cv;
+                        *reinterpret_cast<f32x4*>(a.hn + state_off(a.bm, dir, b, B) + u) = hv;
+                        *reinterpret_cast<f32x4*>(a.cn + state_off(a.bm, dir, b, B) + u) = cv;
                     }
                 }
                     };
@@ -299,6 +304,7 @@ struct LstmBwdArgs {
     float* dh0; float* dc0;               // (2,B,H)
     float* dbias_part;     // (gridDim.x, 2, 4H) per-workgroup sums of dG over its rows and all steps, or NULL
     int R, B;
+    int bm;                // state tensors (c0, dhn, dcn, dh0, dc0) batch-major (B,2,H) instead of (2,B,H)
 };
 
 __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwdArgs a) {
@@ -327,8 +333,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             const int u = 32 * w + 8 * q + 4 * hh;
             f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
             if (b < B) {
-                if (a.dhn) hv = *reinterpret_cast<const f32x4*>(a.dhn + ((size_t)dir * B + b) * LH + u);
-                if (a.dcn) cv = *reinterpret_cast<const f32x4*>(a.dcn + ((size_t)dir * B + b) * LH + u);
+                if (a.dhn) hv = *reinterpret_cast<const f32x4*>(a.dhn + state_off(a.bm, dir, b, B) + u);
+                if (a.dcn) cv = *reinterpret_cast<const f32x4*>(a.dcn + state_off(a.bm, dir, b, B) + u);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { dh[nb][4 * q + j] = hv[j]; dc[nb][4 * q + j] = cv[j]; }
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             bf16x4 cp = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
             else if (a.c0) {
-                const f32x4 c0v = *reinterpret_cast<const f32x4*>(a.c0 + ((size_t)dir * B + b) * LH + u);
+                const f32x4 c0v = *reinterpret_cast<const f32x4*>(a.c0 + state_off(a.bm, dir, b, B) + u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cp[j] = (__bf16)c0v[j];
             }
@@ -491,8 +497,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             f32x4 hv, cv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { hv[j] = dh[nb][4 * q + j]; cv[j] = dc[nb][4 * q + j]; }
-            *reinterpret_cast<f32x4*>(a.dh0 + ((size_t)dir * B + b) * LH + u) = hv;
-            *reinterpret_cast<f32x4*>(a.dc0 + ((size_t)dir * B + b) * LH + u) = cv;
+            *reinterpret_cast<f32x4*>(a.dh0 + state_off(a.bm, dir, b, B) + u) = hv;
+            *reinterpret_cast<f32x4*>(a.dc0 + state_off(a.bm, dir, b, B) + u) = cv;
         }
     }
 }
@@ -527,23 +533,23 @@ static int lstm_fwd_launch(bool proj, const LstmFwdArgs& a, hipStream_t st) {
 }
 
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                 void* out, float* hn, float* cn, void* gates, void* cs, dic_stream_t stream) {
+                 void* out, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd: gates and cs go together");
-    LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B};
+    LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0};
     return lstm_fwd_launch(false, a, (hipStream_t)stream);
 }
 
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                      int I, void* out, float* hn, float* cn, void* gates, void* cs, dic_stream_t stream) {
+                      int I, void* out, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(I == LXK, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: input width %d (compiled for %d: zero-pad narrower inputs)", I, LXK);
     DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd_proj: gates and cs go together");
-    LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B};
+    LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0};
     return lstm_fwd_launch(true, a, (hipStream_t)stream);
 }
 
@@ -557,7 +563,7 @@ size_t dic_lstm_bwd_workspace(int B) { return B > 0 ? (size_t)((B + LBM - 1) / L
 
 int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
-                 float* dbias, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+                 float* dbias, void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_bwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_bwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(whh_t && gates && cs && dgx && dh0 && dc0, DIC_ERR_INVALID_ARG, "lstm_bwd: NULL pointer");
@@ -572,7 +578,7 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
     DIC_REQUIRE(!dbias || (workspace && workspace_bytes >= dic_lstm_bwd_workspace(B)), DIC_ERR_WORKSPACE,
                 "lstm_bwd: dbias needs %zu B of workspace", dic_lstm_bwd_workspace(B));
     LstmBwdArgs a{(const __bf16*)whh_t, (const __bf16*)gates, (const __bf16*)cs, c0, (const __bf16*)dout, dhn, dcn, (__bf16*)dgx, dh0, dc0,
-                  dbias ? (float*)workspace : nullptr, R, B};
+                  dbias ? (float*)workspace : nullptr, R, B, state_batch_major != 0};
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nwg, 2), dim3(256), lds, (hipStream_t)stream, a);
     if (dbias)
         hipLaunchKernelGGL(lstm_dbias_finalize, dim3(2 * 4 * LH / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nwg,

@@ -50,7 +50,7 @@ def _grad_sinks(params, needs):
 
 class _BiLstm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h0, c0, packed, *params):
+    def forward(ctx, x, h0, c0, packed, bm, *params):
         R, B, I_in = x.shape
         bf = torch.bfloat16
         dev = x.device
@@ -85,9 +85,9 @@ class _BiLstm(torch.autograd.Function):
                 out_ext[0, :, :H].zero_()
                 out_ext[R + 1, :, H:].zero_()
             else:
-                out_ext[0, :, :H].copy_(h0[0])
-                out_ext[R + 1, :, H:].copy_(h0[1])
-        hn = torch.empty((2, B, H), device=dev, dtype=torch.float32)
+                out_ext[0, :, :H].copy_(h0[:, 0] if bm else h0[0])
+                out_ext[R + 1, :, H:].copy_(h0[:, 1] if bm else h0[1])
+        hn = torch.empty((B, 2, H) if bm else (2, B, H), device=dev, dtype=torch.float32)
         cn = torch.empty_like(hn)
         Bp = (B + 63) // 64 * 64                                   # kernel-native saved state is tiled by 64 rows
         gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=bf) if need else None
@@ -96,12 +96,12 @@ class _BiLstm(torch.autograd.Function):
         c0c = None if c0 is None else N.f32c(c0)
         if proj:
             N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wihb), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out),
-                                        N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), st), 'dic_lstm_fwd_proj')
+                                        N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd_proj')
         else:
             gx = torch.addmm(bias, xb.view(R * B, Ip), wihb.t())    # (R*B, 2*4*H)
             N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
-                                   N.ptr(cn), N.ptr(gates), N.ptr(cs), st), 'dic_lstm_fwd')
-        ctx.dims = (R, B, I, Ip, proj, bool(packed))
+                                   N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd')
+        ctx.dims = (R, B, I, Ip, proj, bool(packed), bool(bm))
         ctx.x_dtype = x.dtype
         ctx.has_init = h0 is not None
         ctx.params = params
@@ -111,13 +111,13 @@ class _BiLstm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dhn, dcn):
         xb, wihb, whh_t, gates, cs, out_ext, h0c, c0c = ctx.saved_tensors
-        R, B, I, Ip, proj, packed = ctx.dims
+        R, B, I, Ip, proj, packed, bm = ctx.dims
         params = ctx.params
         bf = torch.bfloat16
         dev = out_ext.device
         out = out_ext[1:R + 1]
         dgx = torch.empty((R, B, 2, 4, H), device=dev, dtype=bf)
-        dh0 = torch.empty((2, B, H), device=dev, dtype=torch.float32)
+        dh0 = torch.empty((B, 2, H) if bm else (2, B, H), device=dev, dtype=torch.float32)
         dc0 = torch.empty_like(dh0)
         doutb = None if dout is None else (dout if dout.dtype == bf else dout.to(bf)).contiguous()
         dhnc = None if dhn is None else N.f32c(dhn)
@@ -126,7 +126,7 @@ class _BiLstm(torch.autograd.Function):
         dbias = torch.empty((2, 4 * H), device=dev, dtype=torch.float32)         # summed inside the kernel, f32
         ws = torch.empty(max(16, Lb.dic_lstm_bwd_workspace(B)), device=dev, dtype=torch.uint8)
         N.check(Lb.dic_lstm_bwd(N.ptr(whh_t), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
-                                R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), st), 'dic_lstm_bwd')
+                                R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), st), 'dic_lstm_bwd')
         dg2 = dgx.view(R * B, 8 * H)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -135,7 +135,7 @@ class _BiLstm(torch.autograd.Function):
                 dx = dx.view(R, B, Ip)                               # consumed in this layout by ops._SciCciPacked.backward
             else:
                 dx = (dx[:, :I] if Ip != I else dx).reshape(R, B, I).to(ctx.x_dtype)
-        needs = ctx.needs_input_grad[4:]
+        needs = ctx.needs_input_grad[5:]
         grads = [None] * 8
         if any(needs):
             sinks, accumulate = _grad_sinks(params, needs)
@@ -159,23 +159,25 @@ class _BiLstm(torch.autograd.Function):
                 N.check(Lb.dic_lstm_unpack_grads(N.ptr(dw_ih), Ip, N.ptr(dw_hh), N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             if not accumulate:
                 grads = [g if n else None for g, n in zip(sinks, needs)]
-        return (dx, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None), None, *grads)
+        return (dx, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None), None, None, *grads)
 
 
 def _params(lstm):
     return [getattr(lstm, n) for n in PARAM_NAMES]
 
 
-def bilstm(x, lstm, h0=None, c0=None):
-    """(out (R,B,2H) bf16, (h_n, c_n) (2,B,H) f32) = bidirectional LSTM of x (R,B,I) with ``lstm``'s parameters."""
+def bilstm(x, lstm, h0=None, c0=None, batch_major_state=False):
+    """(out (R,B,2H) bf16, (h_n, c_n) (2,B,H) f32) = bidirectional LSTM of x (R,B,I) with ``lstm``'s parameters.
+    ``batch_major_state``: h0, c0, h_n, c_n are (B,2,H) instead -- h_n.view(B, 2H) is then the concatenated latent
+    [h_fwd | h_rev] of clustering_interp.py:139, and feeds the next LSTM as it lies."""
     with torch.autocast('cuda', enabled=False):
-        out, hn, cn = _BiLstm.apply(x, h0, c0, False, *_params(lstm))
+        out, hn, cn = _BiLstm.apply(x, h0, c0, False, batch_major_state, *_params(lstm))
     return out, (hn, cn)
 
 
-def bilstm_packed(xenc, lstm, h0=None, c0=None):
+def bilstm_packed(xenc, lstm, h0=None, c0=None, batch_major_state=False):
     """The same for an input already in the recurrence kernel's layout: xenc (R,B,32) bf16 rows [features | 1 | 0...]
     (``ops.sci_cci_packed``); its gradient comes back in that layout too."""
     with torch.autocast('cuda', enabled=False):
-        out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, *_params(lstm))
+        out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, batch_major_state, *_params(lstm))
     return out, (hn, cn)

@@ -214,19 +214,21 @@ int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, 
  *   64: opaque, lane-native layout exchanged only between these two calls (both NULL for inference).
  * Backward: dout (R,B,2H) bf16 / dhn, dcn (2,B,H) f32 (each may be NULL) -> dgx (R,B,2,4,H) bf16
  * pre-activation gate gradients (the caller turns them into dX, dW_ih, dW_hh by GEMMs), dh0, dc0, and
- * dbias (2,4H) f32 or NULL = sum of dG over steps and batch rows (needs dic_lstm_bwd_workspace(B) bytes). */
+ * dbias (2,4H) f32 or NULL = sum of dG over steps and batch rows (needs dic_lstm_bwd_workspace(B) bytes).
+ * state_batch_major != 0: h0, c0, hn, cn and their gradients are laid out (B,2,H) instead of nn.LSTM's (2,B,H), so that
+ * hn viewed as (B,2H) is the concatenated latent [h_fwd | h_rev] (clustering_interp.py:139) and feeds the decoder with no copy. */
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                 void* out, float* hn, float* cn, void* gates, void* cs, dic_stream_t stream);
+                 void* out, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
 /* Same recurrence with the input projection computed in-kernel, for narrow inputs (the encoder's 3C channels):
  * G_t = x_t.wih^T + h_{t-1}.whh^T with x (R,B,I) bf16 and wih (2,4H,I) bf16, I == 32 (zero-pad narrower inputs; fold
  * the bias in as a constant-one input column whose weights are b_ih + b_hh).  Everything else as dic_lstm_fwd; the
  * backward is dic_lstm_bwd unchanged. */
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                      int I, void* out, float* hn, float* cn, void* gates, void* cs, dic_stream_t stream);
+                      int I, void* out, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
 size_t dic_lstm_bwd_workspace(int B);
 int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
-                 float* dbias, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+                 float* dbias, void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream);
 
 /* ------------------------------------------------------------------ bi-LSTM parameters --------
  * The eight f32 parameters of one bidirectional nn.LSTM layer (clustering_interp.py:22,35: weight_ih_l0, weight_hh_l0,

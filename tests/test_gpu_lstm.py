@@ -463,3 +463,32 @@ def test_packed_interp_encoder_path_matches_unpacked():
             continue
         a, b = res['packed'][k].cpu().numpy(), res['module'][k].cpu().numpy()
         np.testing.assert_allclose(a, b, rtol=2e-2, atol=4e-3 * np.abs(b).max(), err_msg=k)     # dX stays bf16 on the packed path
+
+
+@pytest.mark.parametrize('I', [18, 256])
+def test_batch_major_state_layout_is_a_relabelling(I):
+    """batch_major_state=True moves h0/c0/h_n/c_n and their gradients to (B,2,H): same numbers as the (2,B,H) layout, bit for bit."""
+    from deep_interpolation_clustering_amd import lstm as L
+    torch.manual_seed(12)
+    dev = torch.device('cuda')
+    R, B = 5, 70
+    net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, I, device=dev)
+    h0, c0 = torch.randn(2, B, H, device=dev) * 0.5, torch.randn(2, B, H, device=dev) * 0.5
+    go, gh, gc = torch.randn(R, B, 2 * H, device=dev), torch.randn(2, B, H, device=dev), torch.randn(2, B, H, device=dev)
+    res = {}
+    for bm in (False, True):
+        net.zero_grad()
+        xi = x.clone().requires_grad_()
+        hi = (h0.transpose(0, 1).contiguous() if bm else h0.clone()).requires_grad_()
+        ci = (c0.transpose(0, 1).contiguous() if bm else c0.clone()).requires_grad_()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out, (hn, cn) = L.bilstm(xi, net, hi, ci, batch_major_state=bm)
+        assert tuple(hn.shape) == ((B, 2, H) if bm else (2, B, H))
+        hn_, cn_ = (hn.transpose(0, 1), cn.transpose(0, 1)) if bm else (hn, cn)
+        ((out.float() * go).sum() + (hn_ * gh).sum() + (cn_ * gc).sum()).backward()
+        res[bm] = dict(out=out.detach().clone(), hn=hn_.detach().clone(), cn=cn_.detach().clone(), dx=xi.grad.clone(),
+                       dh0=(hi.grad.transpose(0, 1) if bm else hi.grad).clone(), dc0=(ci.grad.transpose(0, 1) if bm else ci.grad).clone(),
+                       **{k: p.grad.clone() for k, p in net.named_parameters()})
+    for k in res[False]:
+        assert torch.equal(res[False][k], res[True][k]), k
