@@ -20,6 +20,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dic_hip.h')
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 KM_STATUS_WORDS = 8
+DTYPE_F32, DTYPE_BF16 = 0, 1
 MAX_CHANNELS, MAX_REFPOINTS, MAX_CLUSTERS, LATENT_MAX_DIM = 16, 64, 32, 256
 
 _lib = None
@@ -63,7 +64,10 @@ SIGNATURES = {
     'dic_lstm_fwd_proj': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     'dic_lstm_bwd_workspace': (_sz, [_i]),
     'dic_lstm_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _i, _p]),
-    'dic_lstm_pack': (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'dic_lstm_pack': (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'dic_lstm_rec_fwd': (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
+    'dic_lstm_rec_bwd_workspace': (_sz, [_i]),
+    'dic_lstm_rec_bwd': (_i, [_i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _i, _p]),
     'dic_lstm_dw_workspace': (_sz, [_i, _i]),
     'dic_lstm_dw': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
     'dic_lstm_unpack_grads': (_i, [_p, _i, _p, _p, _i, _i, _p, _i, _p]),

@@ -37,7 +37,7 @@ class EncoderRNN(nn.Module):
         """``batch_major_state`` (fused path only): hidden / cell_state come back as (B,2,H) -- see lstm.bilstm."""
         if packed:                                           # (R,B,32) bf16 rows straight from ops.sci_cci_packed
             output, (hidden, cell_state) = fused_lstm.bilstm_packed(x, self.lstm, batch_major_state=batch_major_state)
-        elif fused_lstm.fused_available(x, self.lstm):      # bf16 autocast on the GPU: persistent HIP recurrence
+        elif fused_lstm.fused_available(x, self.lstm) or fused_lstm.f32_available(x, self.lstm):      # on the GPU: persistent HIP recurrence
             output, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, batch_major_state=batch_major_state)
         else:
             output, (hidden, cell_state) = self.lstm(x)
@@ -52,7 +52,7 @@ class DecoderRNN(nn.Module):
 
     def forward(self, x, hidden, context, batch_major_state=False):
         x = F.relu(x)                                                           # clustering_interp.py:38-41
-        if fused_lstm.fused_available(x, self.lstm):
+        if fused_lstm.fused_available(x, self.lstm) or fused_lstm.f32_available(x, self.lstm):
             x, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, hidden, context, batch_major_state=batch_major_state)
         else:
             x, (hidden, cell_state) = self.lstm(x, (hidden, context))
@@ -160,7 +160,7 @@ class NetBase(nn.Module):
             feats.append(self._interp(positive_x, lengths, packed))
         # fused recurrence (bf16 step): final states in batch-major (B,2,H) layout -- the latent z = [h_fwd | h_rev] is then a VIEW of
         # h_n, and the decoder takes (h_n, c_n) as they lie: no cat / slice / copy kernels between encoder, DEC head and decoder
-        bm = fused_lstm.fused_available(feats[0], self.encoder.lstm)
+        bm = fused_lstm.fused_available(feats[0], self.encoder.lstm) or fused_lstm.f32_available(feats[0], self.encoder.lstm)
         if len(feats) > 1 and B * feats[0].size(0) >= SEPARATE_ENCODER_ROWS:
             # large batches: one encoder call per branch.  Each already fills the chip, and the shared call would cost three
             # 100-MB-class copies (stacking the inputs, slicing the real half of the context and of the final states back out)

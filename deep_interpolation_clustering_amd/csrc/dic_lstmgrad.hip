@@ -52,8 +52,8 @@ struct LstmGrads {
 // wih (2*4H, Ip) bf16: columns [0,I) = W_ih, column I = b_ih + b_hh when `bias_col` (narrow inputs: the projection runs inside
 // the recurrence kernel with a constant-one input column), other padding 0;  whh (2,4H,H) bf16;  whh_t (2,H,4H) bf16;
 // bias (2*4H) bf16 = b_ih + b_hh (the addmm operand of the library projection).
-__global__ __launch_bounds__(256) void lstm_pack_kernel(LstmParams p, int I, int Ip, int bias_col, __bf16* wih, __bf16* whh,
-                                                       __bf16* whh_t, __bf16* bias) {
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_pack_kernel(LstmParams p, int I, int Ip, int bias_col, T* wih, T* whh, T* whh_t, T* bias) {
     const int n_ih = 2 * G4 * Ip, n_hh = 2 * G4 * GH;
     const int total = n_ih + 2 * n_hh + 2 * G4;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -62,17 +62,17 @@ __global__ __launch_bounds__(256) void lstm_pack_kernel(LstmParams p, int I, int
             float v = 0.f;
             if (c < I) v = p.w_ih[d][(size_t)g * I + c];
             else if (c == I && bias_col) v = p.b_ih[d][g] + p.b_hh[d][g];
-            wih[i] = (__bf16)v;
+            wih[i] = (T)v;
         } else if (i < n_ih + n_hh) {
             const int j = i - n_ih, d = j / (G4 * GH), k = j - d * (G4 * GH);
-            whh[j] = (__bf16)p.w_hh[d][k];
+            whh[j] = (T)p.w_hh[d][k];
         } else if (i < n_ih + 2 * n_hh) {
             // whh_t[d][u][n] = whh[d][n][u]: consecutive threads walk n (coalesced writes; the 256-KB source stays in L2)
             const int j = i - n_ih - n_hh, d = j / (G4 * GH), k = j - d * (G4 * GH), u = k / G4, n = k - u * G4;
-            if (whh_t) whh_t[j] = (__bf16)p.w_hh[d][(size_t)n * GH + u];
+            if (whh_t) whh_t[j] = (T)p.w_hh[d][(size_t)n * GH + u];
         } else {
             const int j = i - n_ih - 2 * n_hh, d = j / G4, g = j - d * G4;
-            if (bias) bias[j] = (__bf16)(p.b_ih[d][g] + p.b_hh[d][g]);
+            if (bias) bias[j] = (T)(p.b_ih[d][g] + p.b_hh[d][g]);
         }
     }
 }
@@ -269,8 +269,9 @@ using namespace dic;
 
 extern "C" {
 
-int dic_lstm_pack(const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
+int dic_lstm_pack(int dtype, const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
                   dic_stream_t stream) {
+    DIC_REQUIRE(dtype == DIC_DTYPE_F32 || dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "lstm_pack: dtype %d", dtype);
     DIC_REQUIRE(H == GH, DIC_ERR_UNSUPPORTED, "lstm_pack: hidden size %d (compiled for %d)", H, GH);
     DIC_REQUIRE(params && wih && whh, DIC_ERR_INVALID_ARG, "lstm_pack: NULL pointer");
     DIC_REQUIRE(I > 0 && Ip >= I + (bias_col ? 1 : 0) && Ip <= 1024, DIC_ERR_INVALID_ARG, "lstm_pack: I=%d Ip=%d bias_col=%d", I, Ip, bias_col);
@@ -280,8 +281,13 @@ int dic_lstm_pack(const float* const* params, int H, int I, int Ip, int bias_col
         DIC_REQUIRE(p.w_ih[d] && p.w_hh[d] && p.b_ih[d] && p.b_hh[d], DIC_ERR_INVALID_ARG, "lstm_pack: NULL parameter (direction %d)", d);
     }
     const int total = 2 * G4 * Ip + 4 * G4 * GH + 2 * G4;
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3(min((total + 255) / 256, 2 * kNumCU)), dim3(256), 0, (hipStream_t)stream, p, I, Ip, bias_col,
-                       (__bf16*)wih, (__bf16*)whh, (__bf16*)whh_t, (__bf16*)bias);
+    const dim3 grid(min((total + 255) / 256, 2 * kNumCU));
+    if (dtype == DIC_DTYPE_BF16)
+        hipLaunchKernelGGL(lstm_pack_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, p, I, Ip, bias_col, (__bf16*)wih, (__bf16*)whh,
+                           (__bf16*)whh_t, (__bf16*)bias);
+    else
+        hipLaunchKernelGGL(lstm_pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p, I, Ip, bias_col, (float*)wih, (float*)whh,
+                           (float*)whh_t, (float*)bias);
     return check_launch("lstm_pack");
 }
 

@@ -17,8 +17,10 @@ under bf16 autocast on the GPU:
   Parameter gradients are written by the kernels straight into ``param.grad`` when those exist (the flat gradient bucket of
   ``dist.FlatParams``): no (2,4H,.) staging copies, no per-parameter AccumulateGrad add launches.
 
-In f32 (no autocast) the stock ``nn.LSTM`` (MIOpen) is used: that is the configuration the 1e-5 parity
-tests run in.  The bf16 path is checked against an f32 emulation with the same rounding points.
+In f32 (no autocast: the configuration of the 1e-5 parity tests) the same structure runs with f32 tensors throughout and the
+recurrence on exact-f32 MFMA (csrc/dic_lstm32.hip) instead of MIOpen's nn.LSTM; batches up to SMALL_BATCH use that file's
+one-tile-per-workgroup bf16 kernels too.  The bf16 path is checked against an f32 emulation with the same rounding points, the
+f32 path against nn.LSTM itself.
 """
 import torch
 
@@ -31,10 +33,23 @@ PARAM_NAMES = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
                'weight_ih_l0_reverse', 'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
 
-def fused_available(x, lstm):
-    return (x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
-            and lstm.hidden_size == H and lstm.num_layers == 1 and lstm.bidirectional and lstm.bias
+SMALL_BATCH = 4096             # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
+
+
+def _lstm_ok(lstm):
+    return (lstm.hidden_size == H and lstm.num_layers == 1 and lstm.bidirectional and lstm.bias
             and not lstm.batch_first and lstm.proj_size == 0)
+
+
+def fused_available(x, lstm):
+    """bf16 step: autocast(bf16) on the GPU."""
+    return x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16 and _lstm_ok(lstm)
+
+
+def f32_available(x, lstm):
+    """f32 step (no autocast) on the GPU: the exact-f32 MFMA recurrence instead of MIOpen's nn.LSTM."""
+    return (x.is_cuda and not torch.is_autocast_enabled() and x.dtype == torch.float32 and _lstm_ok(lstm)
+            and all(p.dtype == torch.float32 for p in lstm.parameters()))
 
 
 def _grad_sinks(params, needs):
@@ -50,35 +65,38 @@ def _grad_sinks(params, needs):
 
 class _BiLstm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h0, c0, packed, bm, *params):
+    def forward(ctx, x, h0, c0, packed, bm, f32, *params):
         R, B, I_in = x.shape
-        bf = torch.bfloat16
+        T = torch.float32 if f32 else torch.bfloat16
+        code = N.DTYPE_F32 if f32 else N.DTYPE_BF16
         dev = x.device
         I = params[0].shape[1]
-        proj = I < PROJ_WIDTH                                      # narrow input (encoder): projection inside the recurrence
-        Ip = PROJ_WIDTH if proj else (I + 15) // 16 * 16           # K of the projection padded to the MFMA step
+        small = f32 or B <= SMALL_BATCH                           # one 32-row tile per workgroup (csrc/dic_lstm32.hip)
+        narrow = (not f32) and I < PROJ_WIDTH                      # bf16, narrow input (encoder): rows packed to 32 with the bias as a constant-one column
+        proj = narrow and not small                                # ... and projected inside the 64-row recurrence kernel
+        Ip = I if f32 else (PROJ_WIDTH if narrow else (I + 15) // 16 * 16)      # K of the projection (bf16: padded to the MFMA step)
         need = any(ctx.needs_input_grad)
         pf = [N.f32c(p.detach()) for p in params]
-        wihb = torch.empty((8 * H, Ip), device=dev, dtype=bf)
-        whhb = torch.empty((2, 4 * H, H), device=dev, dtype=bf)
-        whh_t = torch.empty((2, H, 4 * H), device=dev, dtype=bf) if need else None
-        bias = None if proj else torch.empty(8 * H, device=dev, dtype=bf)
+        wih = torch.empty((8 * H, Ip), device=dev, dtype=T)
+        whh = torch.empty((2, 4 * H, H), device=dev, dtype=T)
+        whh_t = torch.empty((2, H, 4 * H), device=dev, dtype=T) if (need and not f32) else None
+        bias = None if narrow else torch.empty(8 * H, device=dev, dtype=T)
         L, st = N.lib(), N.stream_of(x)
-        N.check(L.dic_lstm_pack(N.ptr_array(pf), H, I, Ip, int(proj), N.ptr(wihb), N.ptr(whhb), N.ptr(whh_t), N.ptr(bias), st), 'dic_lstm_pack')
+        N.check(L.dic_lstm_pack(code, N.ptr_array(pf), H, I, Ip, int(narrow), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), st), 'dic_lstm_pack')
         if packed:                                                 # (R,B,32) bf16 rows [features | 1 | 0...] from ops.sci_cci_packed
-            if not proj or I_in != Ip or x.dtype != bf:
+            if not narrow or I_in != Ip or x.dtype != T:
                 raise ValueError(f'packed input must be (R,B,{PROJ_WIDTH}) bf16 for an LSTM of input size < {PROJ_WIDTH}')
             xb = x if x.is_contiguous() else x.contiguous()
         else:
             if I_in != I:
                 raise ValueError(f'input width {I_in} does not match the LSTM input size {I}')
-            xb = x.to(bf)
+            xb = x.to(T)
             if Ip != I:
                 xb = torch.nn.functional.pad(xb, (0, Ip - I))
             xb = xb.contiguous()
-            if proj:
+            if narrow:
                 xb[..., I].fill_(1.0)                              # the bias rides along as a constant-one input column
-        out_ext = torch.empty((R + 2, B, 2 * H), device=dev, dtype=bf)      # [h0 | h_1..h_R | h0]: every step's h_prev is a row above / below
+        out_ext = torch.empty((R + 2, B, 2 * H), device=dev, dtype=T)       # [h0 | h_1..h_R | h0]: every step's h_prev is a row above / below
         out = out_ext[1:R + 1]
         if need:                                                   # boundary rows of the dW_hh products (backward); the other halves are never read
             if h0 is None:
@@ -89,58 +107,73 @@ class _BiLstm(torch.autograd.Function):
                 out_ext[R + 1, :, H:].copy_(h0[:, 1] if bm else h0[1])
         hn = torch.empty((B, 2, H) if bm else (2, B, H), device=dev, dtype=torch.float32)
         cn = torch.empty_like(hn)
-        Bp = (B + 63) // 64 * 64                                   # kernel-native saved state is tiled by 64 rows
-        gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=bf) if need else None
-        cs = torch.empty((R, Bp, 2, H), device=dev, dtype=bf) if need else None    # bf16 copy for the backward; c itself stays f32 on chip
         h0c = None if h0 is None else N.f32c(h0)
         c0c = None if c0 is None else N.f32c(c0)
-        if proj:
-            N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wihb), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out),
-                                        N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd_proj')
+        gates = cs = None
+        if small:
+            if need:
+                gates = torch.empty((R, B, 2, 4, H), device=dev, dtype=T)
+                cs = torch.empty((R, B, 2, H), device=dev, dtype=T)
+            gx = torch.mm(xb.view(R * B, Ip), wih.t()) if narrow else torch.addmm(bias, xb.view(R * B, Ip), wih.t())     # (R*B, 2*4*H)
+            N.check(L.dic_lstm_rec_fwd(code, N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
+                                       N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_rec_fwd')
         else:
-            gx = torch.addmm(bias, xb.view(R * B, Ip), wihb.t())    # (R*B, 2*4*H)
-            N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whhb), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
-                                   N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd')
-        ctx.dims = (R, B, I, Ip, proj, bool(packed), bool(bm))
+            if need:
+                Bp = (B + 63) // 64 * 64                           # kernel-native saved state is tiled by 64 rows
+                gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=T)
+                cs = torch.empty((R, Bp, 2, H), device=dev, dtype=T)    # bf16 copy for the backward; c itself stays f32 on chip
+            if proj:
+                N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out),
+                                            N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd_proj')
+            else:
+                gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
+                N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
+                                       N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd')
+        ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32))
         ctx.x_dtype = x.dtype
         ctx.has_init = h0 is not None
         ctx.params = params
-        ctx.save_for_backward(xb, wihb, whh_t, gates, cs, out_ext, h0c, c0c)
+        ctx.save_for_backward(xb, wih, whh if f32 else whh_t, gates, cs, out_ext, h0c, c0c)
         return out, hn, cn
 
     @staticmethod
     def backward(ctx, dout, dhn, dcn):
-        xb, wihb, whh_t, gates, cs, out_ext, h0c, c0c = ctx.saved_tensors
-        R, B, I, Ip, proj, packed, bm = ctx.dims
+        xb, wih, whh_b, gates, cs, out_ext, h0c, c0c = ctx.saved_tensors
+        R, B, I, Ip, narrow, small, packed, bm, f32 = ctx.dims
         params = ctx.params
-        bf = torch.bfloat16
+        T = torch.float32 if f32 else torch.bfloat16
+        code = N.DTYPE_F32 if f32 else N.DTYPE_BF16
         dev = out_ext.device
-        out = out_ext[1:R + 1]
-        dgx = torch.empty((R, B, 2, 4, H), device=dev, dtype=bf)
+        dgx = torch.empty((R, B, 2, 4, H), device=dev, dtype=T)
         dh0 = torch.empty((B, 2, H) if bm else (2, B, H), device=dev, dtype=torch.float32)
         dc0 = torch.empty_like(dh0)
-        doutb = None if dout is None else (dout if dout.dtype == bf else dout.to(bf)).contiguous()
+        doutb = None if dout is None else (dout if dout.dtype == T else dout.to(T)).contiguous()
         dhnc = None if dhn is None else N.f32c(dhn)
         dcnc = None if dcn is None else N.f32c(dcn)
         Lb, st = N.lib(), N.stream_of(out_ext)
         dbias = torch.empty((2, 4 * H), device=dev, dtype=torch.float32)         # summed inside the kernel, f32
-        ws = torch.empty(max(16, Lb.dic_lstm_bwd_workspace(B)), device=dev, dtype=torch.uint8)
-        N.check(Lb.dic_lstm_bwd(N.ptr(whh_t), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
-                                R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), st), 'dic_lstm_bwd')
+        if small:
+            ws = torch.empty(max(16, Lb.dic_lstm_rec_bwd_workspace(B)), device=dev, dtype=torch.uint8)
+            N.check(Lb.dic_lstm_rec_bwd(code, N.ptr(whh_b), int(not f32), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
+                                        R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), st), 'dic_lstm_rec_bwd')
+        else:
+            ws = torch.empty(max(16, Lb.dic_lstm_bwd_workspace(B)), device=dev, dtype=torch.uint8)
+            N.check(Lb.dic_lstm_bwd(N.ptr(whh_b), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
+                                    R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), st), 'dic_lstm_bwd')
         dg2 = dgx.view(R * B, 8 * H)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = dg2 @ wihb                                          # (R*B, Ip) bf16
+            dx = dg2 @ wih                                           # (R*B, Ip)
             if packed:
                 dx = dx.view(R, B, Ip)                               # consumed in this layout by ops._SciCciPacked.backward
             else:
                 dx = (dx[:, :I] if Ip != I else dx).reshape(R, B, I).to(ctx.x_dtype)
-        needs = ctx.needs_input_grad[5:]
+        needs = ctx.needs_input_grad[6:]
         grads = [None] * 8
         if any(needs):
             sinks, accumulate = _grad_sinks(params, needs)
             gp = N.ptr_array(sinks)
-            if proj and R * B >= 32:
+            if narrow and R * B >= 32:
                 # dW_ih and dW_hh of both directions from one pass over dG (csrc/dic_lstmgrad.hip; it tiles the R*B rows by 32)
                 ws2 = torch.empty(max(16, Lb.dic_lstm_dw_workspace(R, B)), device=dev, dtype=torch.uint8)
                 N.check(Lb.dic_lstm_dw(N.ptr(dgx), N.ptr(out_ext), N.ptr(xb), R, B, H, I, Ip, gp, int(accumulate), N.ptr(ws2),
@@ -159,7 +192,7 @@ class _BiLstm(torch.autograd.Function):
                 N.check(Lb.dic_lstm_unpack_grads(N.ptr(dw_ih), Ip, N.ptr(dw_hh), N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             if not accumulate:
                 grads = [g if n else None for g, n in zip(sinks, needs)]
-        return (dx, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None), None, None, *grads)
+        return (dx, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None), None, None, None, *grads)
 
 
 def _params(lstm):
@@ -167,11 +200,13 @@ def _params(lstm):
 
 
 def bilstm(x, lstm, h0=None, c0=None, batch_major_state=False):
-    """(out (R,B,2H) bf16, (h_n, c_n) (2,B,H) f32) = bidirectional LSTM of x (R,B,I) with ``lstm``'s parameters.
+    """(out (R,B,2H), (h_n, c_n) (2,B,H) f32) = bidirectional LSTM of x (R,B,I) with ``lstm``'s parameters: bf16 operands under
+    autocast(bf16) (out is bf16), exact f32 otherwise (x f32, no autocast; out is f32).
     ``batch_major_state``: h0, c0, h_n, c_n are (B,2,H) instead -- h_n.view(B, 2H) is then the concatenated latent
     [h_fwd | h_rev] of clustering_interp.py:139, and feeds the next LSTM as it lies."""
+    f32 = x.dtype == torch.float32 and not torch.is_autocast_enabled()
     with torch.autocast('cuda', enabled=False):
-        out, hn, cn = _BiLstm.apply(x, h0, c0, False, batch_major_state, *_params(lstm))
+        out, hn, cn = _BiLstm.apply(x, h0, c0, False, batch_major_state, f32, *_params(lstm))
     return out, (hn, cn)
 
 
@@ -179,5 +214,5 @@ def bilstm_packed(xenc, lstm, h0=None, c0=None, batch_major_state=False):
     """The same for an input already in the recurrence kernel's layout: xenc (R,B,32) bf16 rows [features | 1 | 0...]
     (``ops.sci_cci_packed``); its gradient comes back in that layout too."""
     with torch.autocast('cuda', enabled=False):
-        out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, batch_major_state, *_params(lstm))
+        out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, batch_major_state, False, *_params(lstm))
     return out, (hn, cn)

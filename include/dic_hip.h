@@ -230,11 +230,26 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
                  float* dbias, void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream);
 
+/* The same recurrence for the two regimes the 64-row bf16 kernels above do not serve (csrc/dic_lstm32.hip): dtype =
+ * DIC_DTYPE_F32 -- every tensor f32, the recurrent product on v_mfma_f32_32x32x2_f32 (exact f32: the configuration of the 1e-5
+ * parity tests, which round 1 left on MIOpen's nn.LSTM) -- and dtype = DIC_DTYPE_BF16 for small batches (the reference's own
+ * B = 256: one 32-row tile per workgroup instead of two).  Element type T of gx, whh, out, gates, cs, dout, dgx follows dtype;
+ * gates (R,B,2,4,H) and cs (R,B,2,H) are plain row-major here.  whh (2,4H,H); the backward takes either that (read transposed
+ * once at start-up) or the transposed copy (2,H,4H) with whh_is_transposed != 0. */
+#define DIC_DTYPE_F32 0
+#define DIC_DTYPE_BF16 1
+int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H, void* out,
+                     float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
+size_t dic_lstm_rec_bwd_workspace(int B);
+int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const float* c0, const void* dout,
+                     const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
+                     void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream);
+
 /* ------------------------------------------------------------------ bi-LSTM parameters --------
  * The eight f32 parameters of one bidirectional nn.LSTM layer (clustering_interp.py:22,35: weight_ih_l0, weight_hh_l0,
  * bias_ih_l0, bias_hh_l0, then the same four with the _reverse suffix) are passed as a HOST array of 8 device pointers in
  * that order.
- *   dic_lstm_pack: -> wih (2*4H, Ip) bf16 [columns [0,I) = W_ih; column I = b_ih + b_hh when bias_col (dic_lstm_fwd_proj's
+ *   dic_lstm_pack: (dtype = DIC_DTYPE_BF16 or DIC_DTYPE_F32 selects the OUTPUT element type) -> wih (2*4H, Ip) bf16 [columns [0,I) = W_ih; column I = b_ih + b_hh when bias_col (dic_lstm_fwd_proj's
  *     constant-one input column); rest 0], whh (2,4H,H) bf16, whh_t (2,H,4H) bf16 or NULL, bias (2*4H) bf16 = b_ih + b_hh
  *     or NULL.  One launch replaces the stack / add / cast / pad / transpose sequence of torch ops.
  *   dic_lstm_dw (encoder, packed input width Ip == 32): weight gradients from ONE pass over the gate gradients,
@@ -246,7 +261,7 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
  *     parameter gradients `grads` (host array of 8 device pointers, same order; the bias entries are not touched).
  *   dic_lstm_unpack_grads: staging tensors dw_ih (2*4H, ldw) / dw_hh (2,4H,H) / dbias (2*4H) f32 (each may be NULL) ->
  *     the parameter gradients (dbias goes to bias_ih AND bias_hh). */
-int dic_lstm_pack(const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
+int dic_lstm_pack(int dtype, const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
                   dic_stream_t stream);
 size_t dic_lstm_dw_workspace(int R, int B);
 int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, int R, int B, int H, int I, int Ip,

@@ -13,7 +13,7 @@ def rb(x):
     return x.to(torch.bfloat16).float()
 
 
-def emulate(x, lstm, h0=None, c0=None):
+def emulate(x, lstm, h0=None, c0=None, gx_bf16=False):
     """Differentiable f32 torch loop with the kernel's bf16 rounding points: X, W_ih, W_hh, gx, the h fed back."""
     R, B, I = x.shape
     outs, hn, cn = [None, None], [], []
@@ -21,7 +21,7 @@ def emulate(x, lstm, h0=None, c0=None):
         w_ih, w_hh = getattr(lstm, 'weight_ih_l0' + sfx), getattr(lstm, 'weight_hh_l0' + sfx)
         bias = getattr(lstm, 'bias_ih_l0' + sfx) + getattr(lstm, 'bias_hh_l0' + sfx)
         gx = (rb(x).reshape(R * B, I) @ rb(w_ih).t() + rb(bias)).reshape(R, B, 4 * H)
-        if I >= 32:                 # library-GEMM projection: gx itself is stored in bf16; I < 32 is projected in-kernel (f32)
+        if I >= 32 or gx_bf16:      # library-GEMM projection: gx itself is stored in bf16; I < 32 is projected in-kernel (f32) by the 64-row kernels
             gx = rb(gx)
         h = torch.zeros(B, H, device=x.device) if h0 is None else h0[d]
         c = torch.zeros(B, H, device=x.device) if c0 is None else c0[d]
@@ -38,9 +38,18 @@ def emulate(x, lstm, h0=None, c0=None):
     return torch.cat(outs, dim=-1), torch.stack(hn), torch.stack(cn)
 
 
+@pytest.fixture(params=['pipelined64', 'tile32'])
+def kernel_family(request, monkeypatch):
+    """Both bf16 recurrence kernel families on every case: the 64-row software-pipelined kernels (csrc/dic_lstm.hip, large batches)
+    and the one-tile-per-workgroup kernels (csrc/dic_lstm32.hip, batches up to lstm.SMALL_BATCH)."""
+    from deep_interpolation_clustering_amd import lstm as L
+    monkeypatch.setattr(L, 'SMALL_BATCH', 0 if request.param == 'pipelined64' else 1 << 30)
+    return request.param
+
+
 @pytest.mark.parametrize('R,B,I,init', [(24, 200, 18, False), (24, 96, 256, True), (6, 64, 18, False), (5, 1, 256, True), (3, 130, 40, True),
                                           (7, 70, 31, True), (4, 33, 32, False), (2, 5, 1, False)])
-def test_fused_bilstm_matches_emulation(R, B, I, init):
+def test_fused_bilstm_matches_emulation(R, B, I, init, kernel_family):
     from deep_interpolation_clustering_amd import lstm as L
     torch.manual_seed(R * 1000 + B)
     dev = torch.device('cuda')
@@ -64,7 +73,7 @@ def test_fused_bilstm_matches_emulation(R, B, I, init):
         h0.grad = c0.grad = None
 
     x2 = x.clone().requires_grad_()
-    eo, ehn, ecn = emulate(x2, net, h0, c0)
+    eo, ehn, ecn = emulate(x2, net, h0, c0, gx_bf16=kernel_family == 'tile32')
     ((eo * rb(go)).sum() + (ehn * ghn).sum() + (ecn * gcn).sum()).backward()
     # forward: same rounding points -> differences only from accumulation order / fast sigmoid
     np.testing.assert_allclose(out.detach().float().cpu().numpy(), eo.detach().cpu().numpy(), rtol=2e-2, atol=6e-3)
@@ -83,7 +92,7 @@ def test_fused_bilstm_matches_emulation(R, B, I, init):
         close(gh0[1], c0.grad, 'dc0')
 
 
-def test_fused_bilstm_close_to_f32_lstm():
+def test_fused_bilstm_close_to_f32_lstm(kernel_family):
     from deep_interpolation_clustering_amd import lstm as L
     torch.manual_seed(7)
     dev = torch.device('cuda')
@@ -337,7 +346,7 @@ def test_lstm_pack_matches_torch(I):
     whh, whh_t = torch.empty((2, 4 * H, H), device=dev, dtype=bf), torch.empty((2, H, 4 * H), device=dev, dtype=bf)
     bias = torch.empty(8 * H, device=dev, dtype=bf)
     ps = [p.detach() for p in _lstm_params(net)]
-    N.check(N.lib().dic_lstm_pack(N.ptr_array(ps), H, I, Ip, int(proj), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), N.stream_of(wih)),
+    N.check(N.lib().dic_lstm_pack(N.DTYPE_BF16, N.ptr_array(ps), H, I, Ip, int(proj), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), N.stream_of(wih)),
             'dic_lstm_pack')
     w_ih = torch.stack([net.weight_ih_l0, net.weight_ih_l0_reverse]).detach()
     w_hh = torch.stack([net.weight_hh_l0, net.weight_hh_l0_reverse]).detach()
@@ -350,6 +359,11 @@ def test_lstm_pack_matches_torch(I):
     assert torch.equal(whh, w_hh.to(bf))
     assert torch.equal(whh_t, w_hh.transpose(1, 2).contiguous().to(bf))
     assert torch.equal(bias, b.reshape(8 * H).to(bf))
+    # f32 outputs: the parameters themselves, re-arranged
+    wih32, whh32, bias32 = torch.empty((8 * H, I), device=dev), torch.empty((2, 4 * H, H), device=dev), torch.empty(8 * H, device=dev)
+    N.check(N.lib().dic_lstm_pack(N.DTYPE_F32, N.ptr_array(ps), H, I, I, 0, N.ptr(wih32), N.ptr(whh32), None, N.ptr(bias32), N.stream_of(wih)),
+            'dic_lstm_pack')
+    assert torch.equal(wih32, w_ih.reshape(8 * H, I)) and torch.equal(whh32, w_hh) and torch.equal(bias32, b.reshape(8 * H))
 
 
 @pytest.mark.parametrize('R,B,I,init,accumulate', [(24, 200, 18, False, False), (3, 64, 18, True, True), (5, 130, 31, True, False),
@@ -492,3 +506,42 @@ def test_batch_major_state_layout_is_a_relabelling(I):
                        **{k: p.grad.clone() for k, p in net.named_parameters()})
     for k in res[False]:
         assert torch.equal(res[False][k], res[True][k]), k
+
+
+@pytest.mark.parametrize('R,B,I,init,bm', [(24, 200, 18, False, False), (24, 96, 256, True, True), (5, 1, 256, True, False), (3, 130, 40, True, True),
+                                             (2, 33, 1, False, False)])
+def test_f32_recurrence_matches_nn_lstm(R, B, I, init, bm):
+    """The f32 step's recurrence (v_mfma_f32_32x32x2_f32: exact f32 products and sums) against torch.nn.LSTM in f32 on the same
+    device: outputs, final states and every gradient to f32 rounding -- the configuration of the 1e-5 loss parity."""
+    from deep_interpolation_clustering_amd import lstm as L
+    torch.manual_seed(R * 100 + B)
+    dev = torch.device('cuda')
+    net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, I, device=dev) * (1.0 if I < 100 else 0.5)
+    h0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    c0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    go, gh, gc = torch.randn(R, B, 2 * H, device=dev), torch.randn(2, B, H, device=dev), torch.randn(2, B, H, device=dev)
+    res = {}
+    for mode in ('hip', 'torch'):
+        net.zero_grad()
+        xi = x.clone().requires_grad_()
+        hi = None if not init else h0.clone().requires_grad_()
+        ci = None if not init else c0.clone().requires_grad_()
+        if mode == 'hip':
+            assert L.f32_available(xi, net)
+            hin = hi.transpose(0, 1).contiguous() if (init and bm) else hi
+            cin = ci.transpose(0, 1).contiguous() if (init and bm) else ci
+            out, (hn, cn) = L.bilstm(xi, net, hin, cin, batch_major_state=bm)
+            assert out.dtype == torch.float32
+            if bm:
+                hn, cn = hn.transpose(0, 1), cn.transpose(0, 1)
+        else:
+            out, (hn, cn) = net(xi) if not init else net(xi, (hi, ci))
+        ((out * go).sum() + (hn * gh).sum() + (cn * gc).sum()).backward()
+        res[mode] = dict(out=out.detach(), hn=hn.detach(), cn=cn.detach(), dx=xi.grad, **{k: p.grad.clone() for k, p in net.named_parameters()})
+        if init:
+            res[mode].update(dh0=hi.grad, dc0=ci.grad)
+    for k, ref in res['torch'].items():
+        a, b = res['hip'][k].cpu().numpy(), ref.cpu().numpy()
+        tol = 2e-6 if k in ('out', 'hn', 'cn') else 1e-5
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=tol * max(1.0, float(np.abs(b).max())), err_msg=k)
