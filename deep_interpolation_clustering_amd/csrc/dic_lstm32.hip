@@ -13,7 +13,10 @@
 // One 256-thread workgroup owns 32 batch rows of one direction for the whole sequence.  The MFMA is issued transposed, as in
 // dic_lstm.hip: D[gate unit][batch] = W[gate unit][k] . h^T[k][batch], so wave w's A operand is the W_hh slice of hidden units
 // [32w, 32w+32) and the four gates of a unit land in the same lane and register: the gate math is register-local.
-// Saved state is plain row-major: gates (R,B,2,4,H) and cell states (R,B,2,H) in T -- the layouts the GEMMs / tests read.
+// Memory traffic follows dic_lstm.hip's findings (8-byte accesses in the accumulator layout, 32 rows per wave instruction, are
+// address-coalescer bound): the saved gates / cell states use the lane-native layout (every wave instruction one contiguous
+// 512-B / 1-KiB piece; opaque, exchanged only between these two kernels), gx rows enter through LDS by whole-row LDS-DMA, and
+// dG rows leave from the LDS tile as whole rows.
 #include "dic_common.h"
 
 namespace dic {
@@ -38,11 +41,30 @@ template <> __device__ __forceinline__ float tanh_acc<float>(float x) { return t
 template <> __device__ __forceinline__ float sigmoid_acc<__bf16>(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp2(-kLog2e * x)); }
 template <> __device__ __forceinline__ float tanh_acc<__bf16>(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp2(2.0f * kLog2e * x)); }
 
+// element (t, 32-row tile bt, dir, wave w, gate g of G, unit group q, lane half hh, row r, j) of the saved state
+__device__ __forceinline__ size_t snative_off(int t, int nbt, int bt, int dir, int w, int G, int g, int q, int hh, int r) {
+    size_t o = (size_t)t * nbt + bt;
+    o = (o * 2 + dir) * 4 + w;
+    o = (o * G + g) * 4 + q;
+    o = (o * 2 + hh) * 32 + r;
+    return o * 4;
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() carries a fence that also drains the vector-memory queue
+// (s_waitcnt vmcnt(0)), i.e. it waits for every global store / prefetch load in flight -- ~1-2 us per recurrence step with one
+// wave per SIMD.  Here the stores of a step retire under the next step's MFMAs.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <typename T> struct Rec;
 // ---- f32: v_mfma_f32_32x32x2_f32.  MFMA n = 2m + e multiplies k = 4m + 2 (lane >> 5) + e: a lane's two operands of an MFMA pair
 // are adjacent floats (one 8-byte load for A at setup, one ds_read_b64 for B per pair).
 template <> struct Rec<float> {
-    static constexpr int PITCH(int K) { return K + 2; }       // LDS row pitch in elements: == 2 (mod 64) words -> conflict-free b64 reads over 32 rows
+    static constexpr int PITCH(int K) { return K + 4; }       // LDS row pitch in elements: 16-B aligned rows (128-bit stores / row copies); the b64 B-operand
+                                                              // reads are 2-way conflicted at this pitch, invisible under 64-cycle MFMAs
     template <int K> struct Frag { float v[K / 2]; };       // [m*2 + e], m < K/4
     template <int K> __device__ static void load_a(Frag<K>& f, const float* row, int hh, int stride) {
 #pragma unroll
@@ -96,8 +118,8 @@ struct RecFwdArgs {
     const float* h0; const float* c0;      // state layout per `bm`, or NULL
     T* out;                // (R,B,2H)
     float* hn; float* cn;
-    T* gates;              // (R,B,2,4,H) post-activation i,f,g,o or NULL
-    T* cs;                 // (R,B,2,H) cell states or NULL
+    T* gates;              // lane-native (R,Bp,2,4,H) post-activation i,f,g,o or NULL (Bp = B rounded up to 32)
+    T* cs;                 // lane-native (R+1,Bp,2,H) cell states or NULL; time slot R receives c0 (zeros without one): the backward's c_prev of the first step
     int R, B, bm;
 };
 
@@ -105,9 +127,13 @@ template <typename T>
 __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
     typedef typename Vec4<T>::type V4;
     constexpr int HP = Rec<T>::PITCH(SH);
-    __shared__ __align__(16) T hbuf[2][SROWS * HP];
+    constexpr int GXP = S4 + 16 / sizeof(T);               // staged gx row pitch (elements): whole rows + 16 B
+    extern __shared__ __align__(16) unsigned char fsm32[];
+    T* hbuf0 = reinterpret_cast<T*>(fsm32);               // [2][SROWS*HP]
+    T* gst = hbuf0 + 2 * SROWS * HP;                       // [SROWS][GXP]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
+    const int nbt = gridDim.x, bt = blockIdx.x;
     const int b = b0 + r;
     const bool ok = b < B;
     const int bc = min(b, B - 1);
@@ -126,35 +152,46 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
             if (a.h0) hv = *reinterpret_cast<const sf32x4*>(a.h0 + sstate_off(a.bm, dir, b, B) + u);
             if (a.c0) cv = *reinterpret_cast<const sf32x4*>(a.c0 + sstate_off(a.bm, dir, b, B) + u);
         }
+        V4 hb, cb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { hbuf[0][r * HP + u + j] = (T)hv[j]; c[4 * q + j] = cv[j]; }
+        for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; cb[j] = (T)cv[j]; c[4 * q + j] = cv[j]; }
+        *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
+        if (a.cs) *reinterpret_cast<V4*>(a.cs + snative_off(R, nbt, bt, dir, w, 1, 0, q, hh, r)) = cb;
     }
-    // the step's input projection arrives directly in the accumulator layout: 16 loads of 4 adjacent units per lane
-    V4 gnext[4][4];
-    auto load_gx = [&](int step) {
+    // gx tile of a step -> LDS by LDS-DMA: one instruction moves 1 KiB of a row (a whole bf16 row, half an f32 row)
+    constexpr int PIECES = S4 * sizeof(T) / 1024;          // 1 (bf16) or 2 (f32) per row
+    auto request_gx = [&](int step) {
         const int t = dir ? R - 1 - step : step;
-        const T* base = a.gx + (((size_t)t * B + bc) * 2 + dir) * S4 + 32 * w + 4 * hh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gnext[g][q] = *reinterpret_cast<const V4*>(base + g * SH + 8 * q);
+        for (int k = 0; k < SROWS * PIECES / 4; ++k) {
+            const int piece = k * 4 + w, rowl = piece / PIECES, part = piece % PIECES;
+            const int bb = min(b0 + rowl, B - 1);
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(a.gx + (((size_t)t * B + bb) * 2 + dir) * S4) + part * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(gst + rowl * GXP) + part * 1024), 16, 0, 0);
+        }
     };
-    load_gx(0);
+    request_gx(0);
     __syncthreads();
 
     for (int step = 0; step < R; ++step) {
         const int t = dir ? R - 1 - step : step;
         const int cur = step & 1;
+        const T* hcur = hbuf0 + cur * SROWS * HP;
+        T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
         sf32x16 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                const V4 gv = *reinterpret_cast<const V4*>(gst + r * GXP + g * SH + 32 * w + 8 * q + 4 * hh);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][4 * q + j] = (float)gnext[g][q][j];
-        if (step + 1 < R) load_gx(step + 1);             // in flight across the MFMAs and the gate math
+                for (int j = 0; j < 4; ++j) acc[g][4 * q + j] = (float)gv[j];
+            }
+        lds_barrier();                                     // every wave has read its part of the staged tile
+        if (step + 1 < R) request_gx(step + 1);            // lands during the MFMAs / gate math (the closing barrier waits for it)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = Rec<T>::template mma<SH>(wf[g], &hbuf[cur][r * HP], hh, acc[g]);
+        for (int g = 0; g < 4; ++g) acc[g] = Rec<T>::template mma<SH>(wf[g], hcur + r * HP, hh, acc[g]);
         const bool last = step == R - 1;
         const size_t row = (size_t)t * B + bc;
 #pragma unroll
@@ -172,34 +209,35 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
                 cv[j] = cn; hv[j] = hn;
                 hb[j] = (T)hn; ib[j] = (T)ig; fb[j] = (T)fg; gb[j] = (T)gg; ob[j] = (T)og; cb[j] = (T)cn;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) hbuf[cur ^ 1][r * HP + u + j] = hb[j];
+            *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
+            if (a.gates) {
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 0, q, hh, r)) = ib;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 1, q, hh, r)) = fb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 2, q, hh, r)) = gb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 3, q, hh, r)) = ob;
+                *reinterpret_cast<V4*>(a.cs + snative_off(t, nbt, bt, dir, w, 1, 0, q, hh, r)) = cb;
+            }
             if (ok) {
                 *reinterpret_cast<V4*>(a.out + row * 2 * SH + dir * SH + u) = hb;
-                if (a.gates) {
-                    T* gp = a.gates + (row * 2 + dir) * S4 + u;
-                    *reinterpret_cast<V4*>(gp) = ib;
-                    *reinterpret_cast<V4*>(gp + SH) = fb;
-                    *reinterpret_cast<V4*>(gp + 2 * SH) = gb;
-                    *reinterpret_cast<V4*>(gp + 3 * SH) = ob;
-                    *reinterpret_cast<V4*>(a.cs + (row * 2 + dir) * SH + u) = cb;
-                }
                 if (last) {
                     *reinterpret_cast<sf32x4*>(a.hn + sstate_off(a.bm, dir, b, B) + u) = hv;
                     *reinterpret_cast<sf32x4*>(a.cn + sstate_off(a.bm, dir, b, B) + u) = cv;
                 }
             }
         }
-        __syncthreads();
+        // this wave's gx pieces of the next step have landed once only stores issued after them are still in flight: the saved
+        // state stores (20 per wave; the 4 `out` stores may have been branched over) -- a counted wait instead of a drain
+        if (a.gates) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
     }
 }
 
 template <typename T>
 struct RecBwdArgs {
     const T* whh;          // (2,4H,H) -- read transposed (strided) once at start-up;  or whh_t (2,H,4H) when `transposed`
-    const T* gates;        // (R,B,2,4,H)
-    const T* cs;           // (R,B,2,H)
-    const float* c0;
+    const T* gates;        // lane-native, as written by lstm_rec_fwd_kernel
+    const T* cs;           // (R+1 time slots: slot R = c0)
     const T* dout;         // (R,B,2H) or NULL
     const float* dhn; const float* dcn;
     T* dgx;                // (R,B,2,4,H)
@@ -227,7 +265,9 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
 
     sf32x16 dh;
     float dc[16], ccar[16];
-    float bsum0 = 0.f, bsum1 = 0.f;                      // bias gradient: columns tid and tid + 256 of dG, summed over rows and steps
+    float bsum[8];                                       // bias gradient: column sums of the dG pieces this wave copies out (see the row copy)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
     {
         const int t0 = dir ? 0 : R - 1;                  // first visited step = last forward step
 #pragma unroll
@@ -238,38 +278,44 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
                 if (a.dhn) hv = *reinterpret_cast<const sf32x4*>(a.dhn + sstate_off(a.bm, dir, b, B) + u);
                 if (a.dcn) cv = *reinterpret_cast<const sf32x4*>(a.dcn + sstate_off(a.bm, dir, b, B) + u);
             }
-            const V4 ct = *reinterpret_cast<const V4*>(a.cs + (((size_t)t0 * B + bc) * 2 + dir) * SH + u);
+            const V4 ct = *reinterpret_cast<const V4*>(a.cs + snative_off(t0, gridDim.x, blockIdx.x, dir, w, 1, 0, q, hh, r));
 #pragma unroll
             for (int j = 0; j < 4; ++j) { dh[4 * q + j] = hv[j]; dc[4 * q + j] = cv[j]; ccar[4 * q + j] = (float)ct[j]; }
         }
     }
-    for (int step = 0; step < R; ++step) {
+    // the inputs of a step: requested one step ahead for bf16 (48 registers: the global-load latency -- ~2 us per step at one
+    // wave per SIMD -- hides behind the previous step's MFMAs and row stores); the f32 variant has no registers to spare for that
+    // and is bound by its 256 MFMAs per step anyway
+    struct StepIn { V4 ib[4], fb[4], gb[4], ob[4], cp[4], go[4]; };      // raw loads: converting here would put a wait behind every load
+    constexpr bool PREFETCH = sizeof(T) == 2;
+    auto load_in = [&](int step, StepIn& d) {
         const int t = dir ? step : R - 1 - step;           // reverse of the forward visiting order
-        const bool first_fwd = step == R - 1;
-        const int tp = dir ? t + 1 : t - 1;                 // forward predecessor
+        const int tp = step == R - 1 ? R : (dir ? t + 1 : t - 1);      // forward predecessor; the forward's first step reads c0 from slot R
         const size_t row = (size_t)t * B + bc;
+        const int nbt = gridDim.x, bt = blockIdx.x;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int u = 32 * w + 8 * q + 4 * hh;
-            const T* gp = a.gates + (row * 2 + dir) * S4 + u;
-            const V4 ib = *reinterpret_cast<const V4*>(gp), fb = *reinterpret_cast<const V4*>(gp + SH);
-            const V4 gb = *reinterpret_cast<const V4*>(gp + 2 * SH), ob = *reinterpret_cast<const V4*>(gp + 3 * SH);
-            sf32x4 cp = {0.f, 0.f, 0.f, 0.f};
-            if (!first_fwd) {
-                const V4 cpv = *reinterpret_cast<const V4*>(a.cs + (((size_t)tp * B + bc) * 2 + dir) * SH + u);
+            d.ib[q] = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
+            d.fb[q] = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
+            d.gb[q] = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
+            d.ob[q] = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
+            d.cp[q] = *reinterpret_cast<const V4*>(a.cs + snative_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
+            if (a.dout) d.go[q] = *reinterpret_cast<const V4*>(a.dout + row * 2 * SH + dir * SH + u);
+        }
+    };
+    StepIn in, nxt;
+    if (PREFETCH) load_in(0, in);
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? step : R - 1 - step;
+        if (!PREFETCH) load_in(step, in);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cp[j] = (float)cpv[j];
-            } else if (a.c0 && ok) {
-                const sf32x4 c0v = *reinterpret_cast<const sf32x4*>(a.c0 + sstate_off(a.bm, dir, b, B) + u);
+        for (int q = 0; q < 4; ++q) {
+            const int u = 32 * w + 8 * q + 4 * hh;
+            const V4 ib = in.ib[q], fb = in.fb[q], gb = in.gb[q], ob = in.ob[q], cpv = in.cp[q], gov = in.go[q];
+            sf32x4 cp, go;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cp[j] = (float)(T)c0v[j];
-            }
-            sf32x4 go = {0.f, 0.f, 0.f, 0.f};
-            if (a.dout) {
-                const V4 gov = *reinterpret_cast<const V4*>(a.dout + row * 2 * SH + dir * SH + u);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) go[j] = (float)gov[j];
-            }
+            for (int j = 0; j < 4; ++j) { cp[j] = (float)cpv[j]; go[j] = a.dout ? (float)gov[j] : 0.f; }
             V4 di, df, dg, dO;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -286,30 +332,56 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
                 ccar[k] = cp[j];
             }
             T* lp = dgt + r * GP + u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { lp[j] = di[j]; lp[SH + j] = df[j]; lp[2 * SH + j] = dg[j]; lp[3 * SH + j] = dO[j]; }
-            if (ok) {
-                T* op = a.dgx + (row * 2 + dir) * S4 + u;
-                *reinterpret_cast<V4*>(op) = di;
-                *reinterpret_cast<V4*>(op + SH) = df;
-                *reinterpret_cast<V4*>(op + 2 * SH) = dg;
-                *reinterpret_cast<V4*>(op + 3 * SH) = dO;
-            }
+            *reinterpret_cast<V4*>(lp) = di;
+            *reinterpret_cast<V4*>(lp + SH) = df;
+            *reinterpret_cast<V4*>(lp + 2 * SH) = dg;
+            *reinterpret_cast<V4*>(lp + 3 * SH) = dO;
         }
-        __syncthreads();                                   // the dG tile of this step is complete
-        if (a.dbias_part) {
-#pragma unroll 8
-            for (int i = 0; i < SROWS; ++i) { bsum0 += (float)dgt[i * GP + tid]; bsum1 += (float)dgt[i * GP + 256 + tid]; }
+        if (PREFETCH && step + 1 < R) load_in(step + 1, nxt);
+        lds_barrier();                                     // the dG tile of this step is complete
+        {   // dG rows LDS -> global, 16 B per lane: whole 1-KiB pieces per wave instruction (row-major for the weight-gradient GEMMs)
+            constexpr int PIECES = S4 * sizeof(T) / 1024, NP = SROWS * PIECES / 4;
+#pragma unroll
+            for (int k0 = 0; k0 < NP; k0 += 8) {       // 8 pieces in flight: all LDS reads of a group are issued before its stores
+                uint4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int piece = (k0 + k) * 4 + w, rowl = piece / PIECES, part = piece % PIECES;
+                    v[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(dgt + rowl * GP) + part * 1024 + lane * 16);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int piece = (k0 + k) * 4 + w, rowl = piece / PIECES, part = piece % PIECES;
+                    if (b0 + rowl < B)
+                        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.dgx + (((size_t)t * B + b0 + rowl) * 2 + dir) * S4) + part * 1024 + lane * 16) = v[k];
+                    if constexpr (sizeof(T) == 2) {        // lane holds columns 8 lane .. +7 of the row (rows past the batch are zero)
+                        const sbf16x8 x = __builtin_bit_cast(sbf16x8, v[k]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) bsum[e] += (float)x[e];
+                    } else {                               // lane holds columns 256 part + 4 lane .. +3
+                        const sf32x4 x = __builtin_bit_cast(sf32x4, v[k]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bsum[part * 4 + e] += x[e];
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) dh[k] = 0.f;
         dh = Rec<T>::template mma<S4>(wt, dgt + r * GP, hh, dh);          // dh_{prev}[u][b] = sum_n W_hh[n][u] dG[b][n]
-        __syncthreads();                                   // every wave is done reading the tile
+        lds_barrier();                                     // every wave is done reading the tile
+        if (PREFETCH) in = nxt;
     }
-    if (a.dbias_part) {
+    if (a.dbias_part) {      // add the 4 waves' column sums through LDS (the dG tile is free now): one partial per workgroup
+        float* red = reinterpret_cast<float*>(rsm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = sizeof(T) == 2 ? lane * 8 + e : (e >> 2) * 256 + lane * 4 + (e & 3);
+            red[w * S4 + col] = bsum[e];
+        }
+        __syncthreads();
         float* o = a.dbias_part + ((size_t)blockIdx.x * 2 + dir) * S4;
-        o[tid] = bsum0;
-        o[256 + tid] = bsum1;
+        for (int i = tid; i < S4; i += 256) o[i] = red[i] + red[S4 + i] + red[2 * S4 + i] + red[3 * S4 + i];
     }
     if (ok) {
 #pragma unroll
@@ -336,12 +408,19 @@ template <typename T>
 static int rec_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, void* out, float* hn, float* cn,
                    void* gates, void* cs, int bm, hipStream_t st) {
     RecFwdArgs<T> a{(const T*)gx, (const T*)whh, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B, bm != 0};
-    hipLaunchKernelGGL(lstm_rec_fwd_kernel<T>, dim3((B + SROWS - 1) / SROWS, 2), dim3(256), 0, st, a);
+    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)SROWS * (S4 + 16 / sizeof(T))) * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lstm_rec_fwd_kernel<T>, dim3((B + SROWS - 1) / SROWS, 2), dim3(256), lds, st, a);
     return check_launch("lstm_rec_fwd");
 }
 
 template <typename T>
-static int rec_bwd(const void* whh, int transposed, const void* gates, const void* cs, const float* c0, const void* dout, const float* dhn,
+static int rec_bwd(const void* whh, int transposed, const void* gates, const void* cs, const void* dout, const float* dhn,
                    const float* dcn, int R, int B, void* dgx, float* dh0, float* dc0, float* dbias, void* workspace, int bm, hipStream_t st) {
     const size_t lds = (size_t)SROWS * Rec<T>::PITCH(S4) * sizeof(T);
     static bool attr_set = false;
@@ -351,7 +430,7 @@ static int rec_bwd(const void* whh, int transposed, const void* gates, const voi
         attr_set = true;
     }
     const int nwg = (B + SROWS - 1) / SROWS;
-    RecBwdArgs<T> a{(const T*)whh, (const T*)gates, (const T*)cs, c0, (const T*)dout, dhn, dcn, (T*)dgx, dh0, dc0,
+    RecBwdArgs<T> a{(const T*)whh, (const T*)gates, (const T*)cs, (const T*)dout, dhn, dcn, (T*)dgx, dh0, dc0,
                     dbias ? (float*)workspace : nullptr, R, B, bm != 0, transposed};
     hipLaunchKernelGGL(lstm_rec_bwd_kernel<T>, dim3(nwg, 2), dim3(256), lds, st, a);
     if (dbias) hipLaunchKernelGGL(lstm_rec_dbias_finalize, dim3(2 * S4 / 32), dim3(256), 0, st, (const float*)workspace, nwg, dbias);
@@ -377,7 +456,7 @@ int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0
 
 size_t dic_lstm_rec_bwd_workspace(int B) { return B > 0 ? (size_t)((B + SROWS - 1) / SROWS) * 2 * S4 * sizeof(float) : 0; }
 
-int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const float* c0, const void* dout,
+int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const void* dout,
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
                      void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_rec_bwd: non-positive size");
@@ -387,8 +466,8 @@ int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const vo
     DIC_REQUIRE(!dbias || (workspace && workspace_bytes >= dic_lstm_rec_bwd_workspace(B)), DIC_ERR_WORKSPACE,
                 "lstm_rec_bwd: dbias needs %zu B of workspace", dic_lstm_rec_bwd_workspace(B));
     if (dtype == DIC_DTYPE_F32)
-        return rec_bwd<float>(whh, whh_is_transposed, gates, cs, c0, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, (hipStream_t)stream);
-    return rec_bwd<__bf16>(whh, whh_is_transposed, gates, cs, c0, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, (hipStream_t)stream);
+        return rec_bwd<float>(whh, whh_is_transposed, gates, cs, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, (hipStream_t)stream);
+    return rec_bwd<__bf16>(whh, whh_is_transposed, gates, cs, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, (hipStream_t)stream);
 }
 
 }  // extern "C"

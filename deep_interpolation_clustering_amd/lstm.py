@@ -112,8 +112,9 @@ class _BiLstm(torch.autograd.Function):
         gates = cs = None
         if small:
             if need:
-                gates = torch.empty((R, B, 2, 4, H), device=dev, dtype=T)
-                cs = torch.empty((R, B, 2, H), device=dev, dtype=T)
+                Bp = (B + 31) // 32 * 32                           # kernel-native saved state is tiled by 32 rows
+                gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=T)
+                cs = torch.empty((R + 1, Bp, 2, H), device=dev, dtype=T)     # (time slot R: c0, written by the forward)
             gx = torch.mm(xb.view(R * B, Ip), wih.t()) if narrow else torch.addmm(bias, xb.view(R * B, Ip), wih.t())     # (R*B, 2*4*H)
             N.check(L.dic_lstm_rec_fwd(code, N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
                                        N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_rec_fwd')
@@ -154,7 +155,7 @@ class _BiLstm(torch.autograd.Function):
         dbias = torch.empty((2, 4 * H), device=dev, dtype=torch.float32)         # summed inside the kernel, f32
         if small:
             ws = torch.empty(max(16, Lb.dic_lstm_rec_bwd_workspace(B)), device=dev, dtype=torch.uint8)
-            N.check(Lb.dic_lstm_rec_bwd(code, N.ptr(whh_b), int(not f32), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
+            N.check(Lb.dic_lstm_rec_bwd(code, N.ptr(whh_b), int(not f32), N.ptr(gates), N.ptr(cs), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
                                         R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), st), 'dic_lstm_rec_bwd')
         else:
             ws = torch.empty(max(16, Lb.dic_lstm_bwd_workspace(B)), device=dev, dtype=torch.uint8)

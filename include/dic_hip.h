@@ -234,14 +234,15 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
  * DIC_DTYPE_F32 -- every tensor f32, the recurrent product on v_mfma_f32_32x32x2_f32 (exact f32: the configuration of the 1e-5
  * parity tests, which round 1 left on MIOpen's nn.LSTM) -- and dtype = DIC_DTYPE_BF16 for small batches (the reference's own
  * B = 256: one 32-row tile per workgroup instead of two).  Element type T of gx, whh, out, gates, cs, dout, dgx follows dtype;
- * gates (R,B,2,4,H) and cs (R,B,2,H) are plain row-major here.  whh (2,4H,H); the backward takes either that (read transposed
+ * gates (R,Bp,2,4,H) and cs (R+1,Bp,2,H), Bp = B rounded up to 32, are an opaque lane-native layout exchanged between the two
+ * calls (time slot R of cs carries c0, so the backward takes no c0).  whh (2,4H,H); the backward takes either that (read transposed
  * once at start-up) or the transposed copy (2,H,4H) with whh_is_transposed != 0. */
 #define DIC_DTYPE_F32 0
 #define DIC_DTYPE_BF16 1
 int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H, void* out,
                      float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
 size_t dic_lstm_rec_bwd_workspace(int B);
-int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const float* c0, const void* dout,
+int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const void* dout,
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
                      void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream);
 
