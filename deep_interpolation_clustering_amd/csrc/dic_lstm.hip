@@ -62,6 +62,15 @@ __device__ __forceinline__ size_t native_off(int t, int nbt, int bt, int dir, in
 // -- the latter makes hn.view(B, 2H) the concatenated latent [h_fwd | h_rev] and feeds the next LSTM with no copy
 __device__ __forceinline__ size_t state_off(int bm, int dir, int b, int B) { return (bm ? (size_t)b * 2 + dir : (size_t)dir * B + b) * LH; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a fence that also drains the vector-memory queue
+// (s_waitcnt vmcnt(0)): every saved-state / output store and every prefetch load of the step would have to retire before the
+// barrier releases.  With this form they stay in flight across it (measured on the 32-row kernels of dic_lstm32.hip).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 constexpr int LXK = 32;            // input width of the fused-projection variant (two MFMA k-steps)
 constexpr int XSTR = LXK + 8;      // bf16 elements per LDS row of the x tile (80 B: conflict-free ds_read_b128)
 
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                     z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eye[0], *reinterpret_cast<const bf16x8*>(gp), z, 0, 0, 0);
                     acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eye[1], *reinterpret_cast<const bf16x8*>(gp + 16), z, 0, 0, 0);
                 }
-            __syncthreads();                                   // every wave has read its part of the staged tile
+            lds_barrier();                                     // every wave has read its part of the staged tile
             if (step + 1 < R) request_gx(step + 1);
         }
         DIC_STAMP(0, step, 1);
@@ -288,7 +297,13 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
             if (step + 1 < R) *reinterpret_cast<bf16x8*>(gst + (cur ^ 1) * LBM * XSTR + xrow * XSTR + xpc * 8) = xnext;
         }
         DIC_STAMP(0, step, 3);
-        __syncthreads();
+        if constexpr (!PROJ) {
+            // this wave's LDS-DMA pieces of the next gx tile have landed once only operations issued after them remain in flight:
+            // the saved-state stores (5 per unit group x 8 groups; the `out` stores may have been branched over) -- a counted wait
+            if (a.gates) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        lds_barrier();
         DIC_STAMP(0, step, 4);
     }
 }
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
     for (int step = 0; step < R; ++step) {
         const int t = dir ? step : R - 1 - step;
         DIC_STAMP(1, step, 0);
-        __syncthreads();                                   // half 0 of dG_t is complete; nobody reads half 1 of the previous step any more
+        lds_barrier();                                     // half 0 of dG_t is complete; nobody reads half 1 of the previous step any more
         DIC_STAMP(1, step, 1);
         // ---- phase X: MFMA + stores of half 0  ||  math of half 1
 #pragma unroll
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         DIC_BWD_X(0) DIC_BWD_X(1) DIC_BWD_X(2) DIC_BWD_X(3)
 #undef DIC_BWD_X
         DIC_STAMP(1, step, 2);
-        __syncthreads();                                   // half 1 of dG_t is complete; the reads of half 0 have retired
+        lds_barrier();                                     // half 1 of dG_t is complete; the reads of half 0 have retired
         DIC_STAMP(1, step, 3);
         // ---- phase Y: MFMA + stores of half 1  ||  math of half 0 for the next step
 #pragma unroll
