@@ -217,12 +217,13 @@ class NetBase(nn.Module):
             if task == 'future_vital':
                 continue
             pw = torch.tensor(self.args.aux_pos_weights[task]).to(self.device)
-            out[task] = F.binary_cross_entropy_with_logits(aux_pred_dict[task], aux_label_dict[task], pos_weight=pw) \
-                / dist.world_size()
+            pred = aux_pred_dict[task]
+            out[task] = dist.global_mean(F.binary_cross_entropy_with_logits(pred, aux_label_dict[task], pos_weight=pw, reduction='sum'),
+                                         pred.numel())             # mean over the GLOBAL batch (ranks' shards may differ by a row)
         return out
 
     def fake_det_loss(self, label, pred):
-        return {'fake_detection': F.nll_loss(pred, label, reduction='mean') / dist.world_size()}
+        return {'fake_detection': dist.global_mean(F.nll_loss(pred, label, reduction='sum'), label.numel())}
 
     def multi_task_loss(self, aux_tasks, rec_loss_dict, aux_loss_dict):
         """ae_mse + sum_k w_k * loss_k (clustering_interp.py:239-247)."""

@@ -21,5 +21,5 @@ class Net(NetBase):
         return {'kl': ops.kl_batchmean(label, pred)}
 
     def triplet_loss(self, anchor, positive, negative, margin):
-        triple = F.triplet_margin_loss(anchor, positive, negative, margin=margin, reduction='mean')
-        return {'triplet': triple / dist.world_size()}
+        triple = F.triplet_margin_loss(anchor, positive, negative, margin=margin, reduction='sum')
+        return {'triplet': dist.global_mean(triple, anchor.size(0))}

@@ -7,8 +7,8 @@
 //   g <- coef * g  (written back, as clip_grad_norm_ does) ;  g += wd * p
 //   m = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2 ;  vmax = max(vmax, v)
 //   denom = sqrt(vmax) / sqrt(1 - b2^t) + eps ;  p -= lr / (1 - b1^t) * m / denom
-// `step` (t, already incremented by the caller) and `coef` are read from device memory so that the whole step can
-// be replayed from a hipGraph.
+// `step` (t, already incremented by the caller), `coef` and -- when `hyper` = [lr, beta1, beta2, eps, weight_decay] is given -- the
+// hyper-parameters are read from device memory, so that ONE captured hipGraph serves every learning rate a scheduler sets.
 #include "dic_common.h"
 
 namespace dic {
@@ -16,7 +16,9 @@ namespace dic {
 __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                            float* __restrict__ v, float* __restrict__ vmax, long n, float lr, float b1,
                                                            float b2, float eps, float wd, const float* __restrict__ step,
-                                                           const float* __restrict__ coef, const unsigned char* __restrict__ active) {
+                                                           const float* __restrict__ coef, const unsigned char* __restrict__ active,
+                                                           const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }      // device-resident: a captured graph follows the scheduler
     const float t = step[0];
     const float c = coef ? coef[0] : 1.0f;
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
@@ -45,12 +47,12 @@ extern "C" {
 
 int dic_adam_amsgrad_step(float* p, float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
                           float eps, float weight_decay, const float* step, const float* grad_scale, const unsigned char* active,
-                          dic_stream_t stream) {
+                          const float* hyper, dic_stream_t stream) {
     DIC_REQUIRE(n > 0, DIC_ERR_INVALID_ARG, "adam_amsgrad_step: non-positive size");
     DIC_REQUIRE(p && g && m && v && vmax && step, DIC_ERR_INVALID_ARG, "adam_amsgrad_step: NULL pointer");
     const int grid = (int)max(1L, min(((long)n + 255) / 256, (long)8 * kNumCU));
     hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, (long)n, lr, beta1, beta2,
-                       eps, weight_decay, step, grad_scale, active);
+                       eps, weight_decay, step, grad_scale, active, hyper);
     return check_launch("adam_amsgrad_step");
 }
 

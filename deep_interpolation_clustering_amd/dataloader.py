@@ -175,10 +175,17 @@ class DeviceLoader:
         self.host_gen.manual_seed(seed)
         self.rank, self.world = (dist.rank(), dist.world_size()) if shard else (0, 1)
         self.dataset = ds
+        if min(len(ds), self.batch_size) < self.world:
+            raise ValueError(f'DeviceLoader: batches of {min(len(ds), self.batch_size)} rows cannot be sharded over {self.world} ranks')
 
     def __len__(self):
         n = len(self.ds)
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        full = n // self.batch_size
+        tail = n - full * self.batch_size
+        # a trailing batch with fewer rows than ranks would leave some rank an EMPTY shard (its kernels raise while the other ranks
+        # wait in the all-reduces): it is dropped, identically on every rank
+        keep_tail = tail >= self.world and not self.drop_last
+        return full + (1 if keep_tail else 0)
 
     def _noise(self, t, mask, std):
         return (t + torch.randn(t.shape, device=self.device, generator=self.gen) * std) * mask

@@ -33,6 +33,31 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+class _GlobalMean(torch.autograd.Function):
+    """sum over ranks of ``local_sum`` / sum over ranks of ``local_count``: the value every rank reports is the global-batch mean,
+    and d/d local_sum = 1 / global count, so the SUM of the ranks' gradients (FlatParams.all_reduce_grads) is the gradient of that
+    mean -- also when the shards differ in size."""
+
+    @staticmethod
+    def forward(ctx, local_sum, local_count):
+        both = torch.stack([local_sum.detach().float().reshape(()), torch.as_tensor(local_count, dtype=torch.float32, device=local_sum.device).reshape(())])
+        all_reduce_sum_(both)
+        ctx.save_for_backward(both[1])
+        return (both[0] / both[1]).to(local_sum.dtype)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (count,) = ctx.saved_tensors
+        return grad / count.to(grad.dtype), None
+
+
+def global_mean(local_sum: torch.Tensor, local_count) -> torch.Tensor:
+    """Mean over the GLOBAL batch of a quantity each rank holds as (sum over its rows, number of its rows)."""
+    if not is_sharded():
+        return local_sum / local_count
+    return _GlobalMean.apply(local_sum, local_count)
+
+
 def barrier():
     """Rank barrier (no-op when not sharded): rank 0 writes checkpoints / feature files that the other ranks read."""
     if is_sharded():

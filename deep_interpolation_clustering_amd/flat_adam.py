@@ -30,8 +30,20 @@ class FlatAdam(torch.optim.Optimizer):
         self._v = torch.zeros_like(self._m)
         self._vmax = torch.zeros_like(self._m)
         self._step = torch.zeros((), device=dev, dtype=torch.float32)
+        # [lr, beta1, beta2, eps, weight_decay] on the device: the kernel reads them there, so a captured hipGraph of the step keeps
+        # following the learning-rate scheduler (sync_hyper uploads a changed value OUTSIDE the captured region)
+        self._hyper = torch.zeros(5, device=dev, dtype=torch.float32)
+        self._hyper_host = None
+        self.sync_hyper()
         self._views()
         return self
+
+    def sync_hyper(self):
+        g = self.param_groups[0]
+        now = (float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']))
+        if now != self._hyper_host:
+            self._hyper.copy_(torch.tensor(now, dtype=torch.float32))
+            self._hyper_host = now
 
     def _views(self):
         o = 0
@@ -72,10 +84,12 @@ class FlatAdam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         f = self._flat
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
         self._step += 1
         N.check(N.lib().dic_adam_amsgrad_step(N.ptr(f.flat), N.ptr(f.grad), N.ptr(self._m), N.ptr(self._v), N.ptr(self._vmax), f.flat.numel(),
                                               float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                                               float(g['weight_decay']), N.ptr(self._step), N.ptr(grad_scale), N.ptr(f.active_mask()),
-                                              N.stream_of(f.flat)),
+                                              N.ptr(self._hyper), N.stream_of(f.flat)),
                 'dic_adam_amsgrad_step')
         return loss

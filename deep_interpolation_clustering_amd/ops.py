@@ -319,14 +319,21 @@ class _KlBatchMean(torch.autograd.Function):
         N.require_gpu(p, q)
         pd, qd = N.f32c(p.detach()), N.f32c(q)
         B, K = qd.shape
-        bdiv = float(B * dist.world_size())          # 'batchmean' over the GLOBAL batch
+        sharded = dist.is_sharded()
         kl = torch.empty(1, device=qd.device, dtype=torch.float32)
         gq = torch.empty_like(qd) if ctx.needs_input_grad[1] else None
         L = N.lib()
         ws = _ws(L.dic_dec_kl_workspace(B, K), qd.device)
-        N.check(L.dic_dec_kl(N.ptr(qd), N.ptr(pd), B, K, bdiv, 1.0, N.ptr(kl), N.ptr(gq), N.ptr(ws), ws.numel(),
+        # 'batchmean' over the GLOBAL batch: single device -> the kernel divides by B; sharded -> it returns this rank's sum and the
+        # division by the all-reduced row count happens here (the shards of a batch may differ by a row)
+        N.check(L.dic_dec_kl(N.ptr(qd), N.ptr(pd), B, K, 1.0 if sharded else float(B), 1.0, N.ptr(kl), N.ptr(gq), N.ptr(ws), ws.numel(),
                              N.stream_of(qd)), 'dic_dec_kl')
-        dist.all_reduce_sum_(kl)
+        if sharded:
+            both = torch.cat([kl, torch.full((1,), float(B), device=qd.device)])
+            dist.all_reduce_sum_(both)
+            kl = both[:1] / both[1]
+            if gq is not None:
+                gq = gq / both[1]
         ctx.save_for_backward(gq)
         return kl[0]
 

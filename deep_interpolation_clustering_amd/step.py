@@ -73,8 +73,11 @@ class Stepper:
         return losses, hidden, rec_ob, aux_pred
 
     # ------------------------------------------------------------------------------ hipGraph path
+    MAX_GRAPHS = 3        # captured steps kept (full batch, the short last batch, ...): least recently used first out
+
     def _graph_key(self, tensors):
-        lrs = tuple(float(g['lr']) for g in self.optimizer.param_groups)
+        # (the fused optimiser reads lr / betas / eps / weight decay from device memory: they are not part of the key)
+        lrs = () if self._fused_tail else tuple(float(g['lr']) for g in self.optimizer.param_groups)
         return tuple((k, tuple(v.shape), v.dtype) for k, v in tensors.items()) + (lrs, self.model.training)
 
     def _step_graphed(self, tensors):
@@ -86,12 +89,13 @@ class Stepper:
             def run():
                 return self._step_eager(static.get('x'), static.get('ob'), static.get('padding_mask'), static.get('lengths'),
                                         **{k: static[k] for k in static if k not in ('x', 'ob', 'padding_mask', 'lengths')})
-            # warm-up outside capture (lazy initialisation, hipFuncSetAttribute, allocator), with the training state
-            # snapshotted and put back so that the warm-up leaves no trace: capturing executes nothing, the first
-            # replay below IS this call's step
+            # warm-up outside capture (lazy initialisation, hipFuncSetAttribute, allocator), with the training state (parameters,
+            # buffers, optimiser state, the device RNG stream) snapshotted and put back so that the warm-up leaves no trace:
+            # capturing executes nothing, the first replay below IS this call's step
             snap_flat = self.flat.flat.clone()
             snap_buf = [b.clone() for b in self.model.buffers()]
             snap_opt = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.optimizer.state.items()}
+            snap_rng = torch.cuda.get_rng_state(static['x'].device)      # dropout / randperm draws of the warm-up must not shift the stream
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -106,11 +110,19 @@ class Stepper:
                     for k, v in st.items():
                         if torch.is_tensor(v):
                             v.copy_(snap_opt[p_][k]) if p_ in snap_opt and k in snap_opt[p_] else v.zero_()
+            torch.cuda.set_rng_state(snap_rng, static['x'].device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = run()
+            while len(self._graphs) >= self.MAX_GRAPHS:                  # bound the memory held by captured steps (private pools, static inputs)
+                old_graph, _, _ = self._graphs.pop(next(iter(self._graphs)))
+                old_graph.reset()
             entry = self._graphs[key] = (graph, static, out)
+        else:
+            self._graphs[key] = self._graphs.pop(key)                    # most recently used last
         graph, static, out = entry
+        if self._fused_tail:
+            self.optimizer.sync_hyper()
         for k, v in tensors.items():
             static[k].copy_(v, non_blocking=True)
         graph.replay()

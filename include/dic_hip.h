@@ -323,9 +323,11 @@ int dic_cluster_pairdist(const float* X, const int32_t* seg, int N, int D, int K
  * over one flat f32 bucket of n elements: p, g (scaled in place by *grad_scale, NULL = 1), exp_avg m, exp_avg_sq v,
  * max_exp_avg_sq vmax.  `step` = device pointer to the already incremented step count t (f32); `grad_scale` = device
  * pointer to the clip coefficient min(1, max_norm / (||g|| + 1e-6)); `active` = per-element byte mask or NULL (all):
- * elements with 0 are left untouched, as torch.optim skips parameters whose .grad is None. */
+ * elements with 0 are left untouched, as torch.optim skips parameters whose .grad is None.  `hyper` = device pointer to
+ * [lr, beta1, beta2, eps, weight_decay] overriding the scalar arguments, or NULL: read on the device so that one captured hipGraph
+ * of the step follows a learning-rate scheduler. */
 int dic_adam_amsgrad_step(float* p, float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
-                          float eps, float weight_decay, const float* step, const float* grad_scale, const unsigned char* active,
+                          float eps, float weight_decay, const float* step, const float* grad_scale, const unsigned char* active, const float* hyper,
                           dic_stream_t stream);
 
 #ifdef __cplusplus

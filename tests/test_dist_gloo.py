@@ -91,3 +91,38 @@ def test_flat_params_views_survive_state_dict_load():
     assert float(flat.flat.sum()) == 12.0 and net.weight.data_ptr() == flat.flat.data_ptr()
     net(torch.ones(2, 4)).sum().backward()
     assert float(flat.grad.abs().sum()) > 0 and net.weight.grad.data_ptr() == flat.grad.data_ptr()
+
+
+def _mean_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as td
+    from deep_interpolation_clustering_amd import dist
+    dist.init_from_env('gloo')
+    try:
+        g = torch.Generator().manual_seed(3)
+        X, w = torch.randn(7, 5, generator=g), torch.randn(5, generator=g).requires_grad_()
+        lo, hi = (0, 3) if rank == 0 else (3, 7)                     # uneven shards of the global batch of 7
+        loss = dist.global_mean(((X[lo:hi] @ w) ** 2).sum(), hi - lo)
+        loss.backward()
+        grad = w.grad.clone()
+        dist.all_reduce_sum_(grad)                                   # what FlatParams.all_reduce_grads does
+        torch.save({'loss': float(loss.detach()), 'grad': grad}, os.path.join(out, f'm{rank}.pt'))
+    finally:
+        td.destroy_process_group()
+
+
+def test_global_mean_with_uneven_shards(tmp_path):
+    """dist.global_mean: every rank reports the global-batch mean, and the sum of the ranks' gradients is its gradient, with shards
+    of 3 and 4 rows (a global batch that does not divide by the world size)."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_mean_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'm0.pt'), torch.load(tmp_path / 'm1.pt')
+    g = torch.Generator().manual_seed(3)
+    X, w = torch.randn(7, 5, generator=g), torch.randn(5, generator=g).requires_grad_()
+    ref = ((X @ w) ** 2).mean()
+    ref.backward()
+    assert r0['loss'] == r1['loss']
+    np.testing.assert_allclose(r0['loss'], float(ref.detach()), rtol=1e-6)
+    np.testing.assert_allclose(r0['grad'].numpy(), w.grad.numpy(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(r0['grad'], r1['grad'])

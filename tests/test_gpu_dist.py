@@ -20,6 +20,67 @@ def _args():
                            unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
 
 
+def _run_fake(rank, world, port, out):
+    """Upstream's default unsupervised objective (fake detection + KL) on an ODD global batch: shards of 127 and 128 rows."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      DIC_DIST_BACKEND='gloo')
+    from deep_interpolation_clustering_amd import dist, synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    if world > 1:
+        dist.init_from_env()
+    dev = torch.device('cuda', 0)
+    Bg = 255
+    coh = synthetic.make_cohort(Bg, seed=22)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    rng = np.random.default_rng(1)
+    fake_np = x_np.copy()
+    hit = (x_np[:, 6:12] > 0) & (rng.random(x_np[:, :6].shape) < 0.5)
+    fake_np[:, :6] = np.where(hit, rng.uniform(-2.5, 2.5, hit.shape).astype(np.float32), x_np[:, :6])
+    lo, hi = dist.shard_bounds(Bg)
+    x, fx, ob, lens = (torch.tensor(a[lo:hi], device=dev) for a in (x_np, fake_np, ob_np, n))
+    args = _args()
+    args.fake_detection, args.loss = True, 'ae_mse_fake_detect_kl'
+    torch.manual_seed(5)
+    net = Net(args, dev).to(dev)
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args)
+    b = hi - lo
+    perm = torch.arange(2 * b, device=dev)
+    label = torch.cat([torch.ones(b, device=dev), torch.zeros(b, device=dev)]).to(torch.int64)
+    res = {}
+    for mode in ('train', 'eval'):
+        net.train(mode == 'train')
+        if mode == 'train':
+            losses, gnorm, _ = st.step(x, ob, None, lens, fake_x=fx, fake_perm_idx=perm, fake_det_label=label)
+            res['gnorm'] = float(gnorm)
+        else:
+            with torch.no_grad():
+                losses, _, _, _ = st.forward_loss(x, ob, None, lens, fake_x=fx, fake_perm_idx=perm, fake_det_label=label)
+        res[mode] = {k: float(v.detach()) for k, v in losses.items()}
+    torch.save(res, os.path.join(out, f'f{world}_r{rank}.pt'))
+    if world > 1:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+def test_two_rank_fake_detection_odd_batch_losses_are_global(tmp_path):
+    """every loss term a rank reports must be the GLOBAL-batch value (it feeds ReduceLROnPlateau, best-checkpoint
+    selection and early stopping), and the sharded gradient must equal the single-device one, also when the global batch (255)
+    does not divide by the world size."""
+    port = 29900 + (os.getpid() % 1000)
+    mp.spawn(_run_fake, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_run_fake, args=(2, port + 1, str(tmp_path)), nprocs=2, join=True)
+    one = torch.load(tmp_path / 'f1_r0.pt', weights_only=False)
+    r0, r1 = torch.load(tmp_path / 'f2_r0.pt', weights_only=False), torch.load(tmp_path / 'f2_r1.pt', weights_only=False)
+    for mode in ('train', 'eval'):
+        assert r0[mode] == r1[mode]
+        for k, v in one[mode].items():
+            np.testing.assert_allclose(r0[mode][k], v, rtol=5e-6 if k != 'kl' else 2e-3, atol=1e-7, err_msg=f'{mode}:{k}')
+    np.testing.assert_allclose(r0['gnorm'], one['gnorm'], rtol=1e-4)
+
+
 def _run(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),

@@ -69,3 +69,38 @@ def test_flat_adam_requires_binding():
     m = _model(torch.device('cuda'))
     with pytest.raises(RuntimeError):
         FlatAdam(m.parameters(), lr=1e-3).step()
+
+
+def test_captured_step_follows_the_scheduler_and_cache_is_bounded():
+    """the fused optimiser reads lr from device memory, so ONE captured hipGraph serves every learning rate (no
+    re-capture per scheduler step), the graph cache is bounded, and a graphed trajectory with a changing lr equals the eager one."""
+    from types import SimpleNamespace
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=4, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    coh = synthetic.make_cohort(384, seed=8)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    traj = {}
+    for graphs in (False, True):
+        torch.manual_seed(4)
+        net = Net(args, dev).to(dev)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16, use_graphs=graphs)
+        out = []
+        for i in range(6):
+            st.optimizer.param_groups[0]['lr'] = 3e-3 * (0.5 ** i)             # a scheduler step before every batch
+            losses, gnorm, _ = st.step(X[:256], OB[:256], None, LEN[:256])
+            out.append([float(losses['loss'].detach()), float(gnorm)])
+        if graphs:
+            assert len(st._graphs) == 1                                          # lr is not part of the graph key
+            for b in (64, 96, 128, 160):                                         # four more shapes: the cache stays bounded
+                st.step(X[:b], OB[:b], None, LEN[:b])
+            assert len(st._graphs) <= st.MAX_GRAPHS
+        traj[graphs] = np.array(out)
+    np.testing.assert_allclose(traj[True], traj[False], rtol=2e-3)
