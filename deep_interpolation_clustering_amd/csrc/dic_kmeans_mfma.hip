@@ -1,0 +1,234 @@
+// k4 at K >= 9: the Lloyd E-step + partial M-step (sklearn _k_means_lloyd.pyx:167-218: pairwise = ||c||^2 - 2 X C^T by sgemm,
+// first-minimum label, per-cluster sums / counts) on the matrix cores.
+//
+// Why: the one-wave-per-row kernel of dic_latent.hip reduces K per-lane partial distances across the wave with a shuffle
+// butterfly; at K = 16 / 32 that is a long dependent chain with 172 registers per lane (two waves per SIMD): 0.56 / 1.7 ms per
+// iteration of 10 restarts on 75 000 x 256 latents, 55 % of the p2 K-sweep's 68 s (rocprofv3, round 2).  Both halves of the
+// iteration are GEMMs:
+//     scores  D'[centroid][row] = C . X^T                (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation, as sgemm)
+//     sums    S[centroid][d]    = onehot(label)^T . X     (the A operand is 0 / 1: the MFMA adds exactly the assigned rows)
+// One workgroup serves the 64 centroid columns of 64/KP restarts at once (the restarts share every X tile), keeps those
+// centroids in LDS, and gives each of its 4 waves its own 32-row tiles.  The score product is issued transposed so that a LANE
+// owns a row and the centroids sit in its registers: the argmin is 15 in-lane compares + one cross-half exchange, no butterfly.
+// Outputs are the per-workgroup partials the existing reduce / update kernels consume (fixed-order f64 second stage).
+#include "dic_common.h"
+
+namespace dic {
+
+constexpr int MCOLS = 64;            // centroid columns per workgroup
+constexpr int MCP = 256 + 2;         // LDS pitch of a centroid row (floats): == 2 (mod 64) words -> conflict-free b64 reads over 32 rows
+
+typedef float kf32x16 __attribute__((ext_vector_type(16)));
+typedef float kf32x2 __attribute__((ext_vector_type(2)));
+typedef float kf32x4 __attribute__((ext_vector_type(4)));
+
+struct KmMfmaArgs {
+    const float* X; const float* xnorm; int N, D, K, n_runs, nblk;
+    const float* centers;      // (n_runs,K,D)
+    int32_t* labels;           // (n_runs,N)
+    const float* status;       // (n_runs,8): status[0] != 0 -> converged, skipped
+    float* mind;               // (n_runs,N)
+    float* psum;               // (n_runs,nblk,K*D)
+    int* pcnt;                 // (n_runs,nblk,K+1): counts | #changed
+};
+
+template <int KP>
+__global__ __launch_bounds__(256, 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a) {
+    constexpr int G = MCOLS / KP;                       // restarts per workgroup
+    extern __shared__ __align__(16) unsigned char ksm[];
+    float* cent = reinterpret_cast<float*>(ksm);                         // [64][MCP]; reused for the cross-wave sum at the end
+    float* cnorm = cent + MCOLS * MCP;                                   // [64]
+    int* cnt = reinterpret_cast<int*>(cnorm + MCOLS);                    // [64] members per centroid column
+    int* chg = cnt + MCOLS;                                              // [G] labels changed per restart
+    unsigned char* lab8 = reinterpret_cast<unsigned char*>(chg + 4);     // [4 waves][G][32]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, hh = lane >> 5;
+    const int N = a.N, D = a.D, K = a.K;
+    const int run0 = blockIdx.y * G;
+    bool any = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) any = any || (run0 + g < a.n_runs && a.status[(run0 + g) * DIC_KM_STATUS_WORDS] == 0.f);
+    if (!any) return;                                    // uniform over the workgroup
+
+    // ---- centroids of the G restarts -> LDS (zero rows for k >= K / finished restarts), their squared norms
+    for (int i = tid; i < MCOLS * 64; i += 256) {        // float4 pieces
+        const int col = i >> 6, d4 = (i & 63) * 4;
+        const int g = col / KP, k = col - g * KP, run = run0 + g;
+        kf32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (run < a.n_runs && k < K && d4 < D) v = *reinterpret_cast<const kf32x4*>(a.centers + ((size_t)run * K + k) * D + d4);
+        float* dst = cent + col * MCP + d4;              // (pitch 258: 8-byte aligned rows)
+        *reinterpret_cast<kf32x2*>(dst) = kf32x2{v[0], v[1]};
+        *reinterpret_cast<kf32x2*>(dst + 2) = kf32x2{v[2], v[3]};
+    }
+    if (tid < MCOLS) cnt[tid] = 0;
+    if (tid < 4) chg[tid] = 0;
+    __syncthreads();
+    for (int col = w; col < MCOLS; col += 4) {           // row_norms (_k_means_lloyd.pyx:99), one wave per centroid
+        const kf32x4 c = kf32x4{cent[col * MCP + lane * 4], cent[col * MCP + lane * 4 + 1], cent[col * MCP + lane * 4 + 2], cent[col * MCP + lane * 4 + 3]};
+        const float s = wave_sum(fmaf(c[3], c[3], fmaf(c[2], c[2], fmaf(c[1], c[1], c[0] * c[0]))));
+        const int g = col / KP, k = col - g * KP;
+        if (lane == 0) cnorm[col] = (k < K) ? s : INFINITY;          // padding columns can never win the argmin
+    }
+    __syncthreads();
+    // the centroid of accumulator register `reg` of M-block mb in this lane: m = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 hh
+    float cn[2][16];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) cn[mb][reg] = cnorm[32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * hh];
+
+    kf32x16 S[2][8];                                     // sums[centroid column block][d block]: column jj of d-block nb is d = 128 (nb >> 2) + 4 jj + (nb & 3)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) S[mb][nb][k] = 0.f;
+
+    const int ntiles = (N + 31) / 32;
+    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += a.nblk * 4) {
+        const int r0 = tile * 32, row = r0 + j;
+        const bool valid = row < N;
+        const float* xr = a.X + (size_t)min(row, N - 1) * D;
+        // ---- scores: D'[centroid][row] = sum_k C[centroid][k] X[row][k]; MFMA 2m + e multiplies k = 4m + 2hh + e
+        kf32x16 dacc[2];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { dacc[0][k] = 0.f; dacc[1][k] = 0.f; }
+#pragma unroll 8
+        for (int m = 0; m < 64; ++m) {
+            const int kk = 4 * m + 2 * hh;
+            kf32x2 x2 = {0.f, 0.f};
+            if (kk < D) x2 = *reinterpret_cast<const kf32x2*>(xr + kk);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const kf32x2 c2 = *reinterpret_cast<const kf32x2*>(cent + (32 * mb + j) * MCP + kk);
+                dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[0], x2[0], dacc[mb], 0, 0, 0);
+                dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[1], x2[1], dacc[mb], 0, 0, 0);
+            }
+        }
+        // ---- argmin per restart: in-lane over this half's centroids (ascending index, strict <: first minimum wins), then across halves
+        const float xn = valid && a.xnorm ? a.xnorm[row] : 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int run = run0 + g;
+            float best = INFINITY;
+            int bi = 1 << 20;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int mcol = 32 * mb + (reg & 3) + 8 * (reg >> 2);      // + 4 hh
+                    if (mcol / KP != g) continue;                               // compile-time: (mcol + 4 hh) / KP == mcol / KP for KP >= 8
+                    const float s = fmaf(-2.0f, dacc[mb][reg], cn[mb][reg]);
+                    const int kidx = mcol + 4 * hh - g * KP;
+                    if (s < best) { best = s; bi = kidx; }
+                }
+            const float ob = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            const bool active = run < a.n_runs && a.status[run * DIC_KM_STATUS_WORDS] == 0.f;
+            if (hh == 0) {
+                unsigned char code = 255;                                       // rows past the end / finished restarts add to no sum
+                if (valid && active) {
+                    int32_t* lp = a.labels + (size_t)run * N + row;
+                    if (*lp != bi) atomicAdd(&chg[g], 1);
+                    *lp = bi;
+                    a.mind[(size_t)run * N + row] = fmaxf(0.f, xn + best);
+                    atomicAdd(&cnt[g * KP + bi], 1);
+                    code = (unsigned char)bi;
+                }
+                lab8[(w * G + g) * 32 + j] = code;
+            }
+        }
+        // (lab8 of this wave is written and read by this wave only: wave-local ordering through the LDS queue)
+        // ---- sums: S[col][d] += sum_rows onehot[col][row] X[row][d]; MFMA n multiplies rows 2n + hh
+        unsigned lw[2][8];                                   // labels of the 32 rows for the restarts of this lane's two centroid columns
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int g = (32 * mb + j) / KP;
+            const unsigned* lp = reinterpret_cast<const unsigned*>(lab8 + (w * G + g) * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) lw[mb][q] = lp[q];
+        }
+        const int kc0 = j % KP, kc1 = (32 + j) % KP;
+#pragma unroll 4
+        for (int n = 0; n < 16; ++n) {
+            const int rr = 2 * n + hh;
+            const float* xrow = a.X + (size_t)min(r0 + rr, N - 1) * D;
+            kf32x4 xlo = {0.f, 0.f, 0.f, 0.f}, xhi = {0.f, 0.f, 0.f, 0.f};
+            if (4 * j < D) xlo = *reinterpret_cast<const kf32x4*>(xrow + 4 * j);
+            if (128 + 4 * j < D) xhi = *reinterpret_cast<const kf32x4*>(xrow + 128 + 4 * j);
+            // byte rr of the packed labels: dword rr >> 2, byte rr & 3 (rr = 2n + hh)
+            const unsigned b0 = (hh ? (lw[0][n >> 1] >> (16 * (n & 1) + 8)) : (lw[0][n >> 1] >> (16 * (n & 1)))) & 255u;
+            const unsigned b1 = (hh ? (lw[1][n >> 1] >> (16 * (n & 1) + 8)) : (lw[1][n >> 1] >> (16 * (n & 1)))) & 255u;
+            const float a0 = b0 == (unsigned)kc0 ? 1.0f : 0.0f, a1 = b1 == (unsigned)kc1 ? 1.0f : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                S[0][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, xlo[e], S[0][e], 0, 0, 0);
+                S[1][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, xlo[e], S[1][e], 0, 0, 0);
+                S[0][4 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, xhi[e], S[0][4 + e], 0, 0, 0);
+                S[1][4 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, xhi[e], S[1][4 + e], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the 4 waves' sums -> one partial per workgroup (through the centroid area), counts, #changed
+    __syncthreads();
+    float* red = cent;                                   // [64 cols][256 d]
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int col = 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                        const int d = 128 * (nb >> 2) + 4 * j + (nb & 3);
+                        float* p = red + col * 256 + d;
+                        *p = (ww == 0) ? S[mb][nb][reg] : *p + S[mb][nb][reg];
+                    }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int run = run0 + g;
+        if (run >= a.n_runs || a.status[run * DIC_KM_STATUS_WORDS] != 0.f) continue;
+        const size_t pb = (size_t)run * a.nblk + blockIdx.x;
+        for (int i = tid; i < K * D; i += 256) {
+            const int k = i / D, d = i - k * D;
+            a.psum[pb * K * D + i] = red[(g * KP + k) * 256 + d];
+        }
+        if (tid < K) a.pcnt[pb * (K + 1) + tid] = cnt[g * KP + tid];
+        if (tid == 0) a.pcnt[pb * (K + 1) + K] = chg[g];
+    }
+}
+
+// Row-chunk workgroups per restart group: one workgroup per CU over ALL groups (67 KB of LDS, ~500 registers: one resident workgroup
+// per CU), so that each pays its centroid staging and its cross-wave reduction once and walks several tiles per wave
+// (0.34 -> 0.2 ms per iteration of 10 restarts at K = 16 against three rounds of 256 workgroups).
+int kmeans_mfma_blocks(int N, int K, int n_runs) {
+    const int G = MCOLS / (K <= 16 ? 16 : 32), groups = (n_runs + G - 1) / G;
+    return (int)max(1L, min(((long)N + 127) / 128, (long)max(1, kNumCU / groups)));
+}
+
+// Launches the E-step + partial M-step for K in (8, 32].  nblk = kmeans_mfma_blocks(N, K, n_runs) partial slots per restart are written.
+int kmeans_assign_mfma_launch(const float* X, const float* xnorm, int N, int D, int K, int n_runs, const float* centers, int32_t* labels,
+                              const float* status, float* mind, float* psum, int* pcnt, hipStream_t st) {
+    const int KP = K <= 16 ? 16 : 32;
+    const int G = MCOLS / KP;
+    const size_t lds = (size_t)MCOLS * MCP * 4 + MCOLS * 4 + MCOLS * 4 + 16 + 4 * G * 32;
+    KmMfmaArgs a{X, xnorm, N, D, K, n_runs, kmeans_mfma_blocks(N, K, n_runs), centers, labels, status, mind, psum, pcnt};
+    static bool attr_set[2] = {false, false};
+    const void* fn = KP == 16 ? (const void*)kmeans_assign_mfma_kernel<16> : (const void*)kmeans_assign_mfma_kernel<32>;
+    if (!attr_set[KP == 32]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "kmeans_assign_mfma: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set[KP == 32] = true;
+    }
+    const dim3 grid(a.nblk, (n_runs + G - 1) / G);
+    if (KP == 16) hipLaunchKernelGGL(kmeans_assign_mfma_kernel<16>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(kmeans_assign_mfma_kernel<32>, grid, dim3(256), lds, st, a);
+    return check_launch("kmeans_assign_mfma");
+}
+
+}  // namespace dic

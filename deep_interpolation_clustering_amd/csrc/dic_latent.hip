@@ -716,12 +716,19 @@ int dic_kmeans_lloyd_iter(const float* X, const float* xnorm, int N, int D, int 
     float* psum = (float*)(ws + w.psum); int* pcnt = (int*)(ws + w.pcnt); int* pchg = (int*)(ws + w.pchg);
     double* sums = (double*)(ws + w.sums); float* mind = (float*)(ws + w.mind);
     hipStream_t st = (hipStream_t)stream;
-    DIC_DISPATCH_KP(pad_k(K), hipLaunchKernelGGL((kmeans_assign_kernel<KP, true>), dim3(nblk, n_runs), dim3(kLatBlock), 0, st, X,
-                                                 xnorm, N, D, K, (const float*)centers, labels, (const float*)status, mind, psum,
-                                                 pcnt, pchg));
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((K * D + 31) / 32, n_runs), dim3(256), 0, st, (const float*)psum, nblk, K, D,
+    int np = nblk;                                    // partial slots per restart actually written
+    if (K > 8) {                                      // matrix-core E-step (dic_kmeans_mfma.hip); fewer, fatter workgroups
+        np = kmeans_mfma_blocks(N, K, n_runs);
+        rc = kmeans_assign_mfma_launch(X, xnorm, N, D, K, n_runs, centers, labels, status, mind, psum, pcnt, st);
+        if (rc) return rc;
+    } else {
+        DIC_DISPATCH_KP(pad_k(K), hipLaunchKernelGGL((kmeans_assign_kernel<KP, true>), dim3(nblk, n_runs), dim3(kLatBlock), 0, st, X,
+                                                     xnorm, N, D, K, (const float*)centers, labels, (const float*)status, mind, psum,
+                                                     pcnt, pchg));
+    }
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((K * D + 31) / 32, n_runs), dim3(256), 0, st, (const float*)psum, np, K, D,
                        (const float*)status, sums);
-    hipLaunchKernelGGL(kmeans_update_kernel, dim3(n_runs), dim3(256), 0, st, X, N, D, K, nblk, (const int*)pcnt,
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(n_runs), dim3(256), 0, st, X, N, D, K, np, (const int*)pcnt,
                        (const int*)pchg, sums, mind, (const int32_t*)labels, centers, status);
     return check_launch("kmeans_lloyd_iter");
 }
@@ -743,15 +750,22 @@ int dic_kmeans_lloyd_partial(const float* X, const float* xnorm, int N, int D, i
     double* sums = (double*)(ws + w.sums); float* mind = (float*)(ws + w.mind);
     hipStream_t st = (hipStream_t)stream;
     const size_t words = dic_kmeans_stats_words(D, K);
-    DIC_DISPATCH_KP(pad_k(K), hipLaunchKernelGGL((kmeans_assign_kernel<KP, true>), dim3(nblk, n_runs), dim3(kLatBlock), 0, st, X,
-                                                 xnorm, N, D, K, centers, labels, status, mind, psum, pcnt, pchg));
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((K * D + 31) / 32, n_runs), dim3(256), 0, st, (const float*)psum, nblk, K, D,
+    int np = nblk;
+    if (K > 8) {
+        np = kmeans_mfma_blocks(N, K, n_runs);
+        rc = kmeans_assign_mfma_launch(X, xnorm, N, D, K, n_runs, centers, labels, status, mind, psum, pcnt, st);
+        if (rc) return rc;
+    } else {
+        DIC_DISPATCH_KP(pad_k(K), hipLaunchKernelGGL((kmeans_assign_kernel<KP, true>), dim3(nblk, n_runs), dim3(kLatBlock), 0, st, X,
+                                                     xnorm, N, D, K, centers, labels, status, mind, psum, pcnt, pchg));
+    }
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3((K * D + 31) / 32, n_runs), dim3(256), 0, st, (const float*)psum, np, K, D,
                        status, sums);
     // sums -> the head of each run's stats record (strided device copy), counts / #changed behind them
     hipError_t e = hipMemcpy2DAsync(stats, words * sizeof(double), sums, (size_t)K * D * sizeof(double), (size_t)K * D * sizeof(double),
                                     (size_t)n_runs, hipMemcpyDeviceToDevice, st);
     DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "kmeans_lloyd_partial: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kmeans_pack_counts_kernel, dim3(n_runs), dim3(256), 0, st, (const int*)pcnt, nblk, K, D, status, stats);
+    hipLaunchKernelGGL(kmeans_pack_counts_kernel, dim3(n_runs), dim3(256), 0, st, (const int*)pcnt, np, K, D, status, stats);
     return check_launch("kmeans_lloyd_partial");
 }
 
