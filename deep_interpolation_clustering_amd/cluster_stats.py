@@ -35,6 +35,14 @@ def _encode(labels, device):
     return inv.to(torch.int64), int(uniq.numel())
 
 
+def _segment_sum(values, lab, K):
+    """(K, ...) f64 sums of ``values`` rows per label: a one-hot f64 GEMM (rocBLAS dgemm on the matrix cores) -- index_add_ on
+    f64 is an atomic scatter that took 65 ms per call on 75 000 x 256 (4 s of the K sweep)."""
+    oh = torch.nn.functional.one_hot(lab, K).to(torch.float64).t()              # (K, N)
+    v = values.double()
+    return oh @ v if v.dim() == 2 else (oh @ v[:, None])[:, 0]
+
+
 class PairStats:
     """Result of one pair pass: ``labels`` (N) encoded 0..K-1, ``counts`` (K), ``S`` / ``Dmin`` (N,K) f32 and ``own_max`` (N),
     all in the caller's row order."""
@@ -46,7 +54,7 @@ class PairStats:
     def intra_sums(self):
         """(K,) f64: sum over ordered pairs (i, j) of one cluster of ||x_i - x_j||  (= np.sum(pairwise_distances(X_c)))."""
         own = self.S.gather(1, self.labels[:, None])[:, 0].double()
-        return torch.zeros(self.K, dtype=torch.float64, device=own.device).index_add_(0, self.labels, own)
+        return _segment_sum(own, self.labels, self.K)
 
 
 def pair_stats(x, labels, need_min=True, need_max=True):
@@ -128,7 +136,7 @@ def dunn_index(x, labels, stats=None):
 def _centroids(x, lab, K):
     x64 = x.double()
     cnt = torch.bincount(lab, minlength=K).double()
-    cen = torch.zeros((K, x.shape[1]), dtype=torch.float64, device=x.device).index_add_(0, lab, x64) / cnt[:, None]
+    cen = _segment_sum(x64, lab, K) / cnt[:, None]
     return x64, cnt, cen
 
 
@@ -154,7 +162,7 @@ def davies_bouldin_score(x, labels):
         raise ValueError('Number of labels is %d. Valid values are 2 to n_samples - 1 (inclusive)' % K)
     x64, cnt, cen = _centroids(x, lab, K)
     dist = ((x64 - cen[lab]) ** 2).sum(1).sqrt()
-    intra = torch.zeros(K, dtype=torch.float64, device=x.device).index_add_(0, lab, dist) / cnt
+    intra = _segment_sum(dist, lab, K) / cnt
     cd = torch.cdist(cen, cen)
     if bool(torch.allclose(intra, torch.zeros_like(intra))) or bool(torch.allclose(cd, torch.zeros_like(cd))):
         return 0.0
