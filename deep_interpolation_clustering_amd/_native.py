@@ -41,9 +41,9 @@ SIGNATURES = {
     'dic_cci_fwd': (_i, [_p, _p, _i, _i, _i, _p, _p]),
     'dic_cci_bwd_workspace': (_sz, [_i, _i, _i]),
     'dic_cci_bwd': (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
-    'dic_rbf_fwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    'dic_rbf_fwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
     'dic_rbf_bwd_workspace': (_sz, [_i, _i, _i, _i]),
-    'dic_rbf_bwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'dic_rbf_bwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'dic_masked_sse_workspace': (_sz, [_i, _i, _i]),
     'dic_masked_sse_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p]),
     'dic_masked_sse_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
@@ -76,12 +76,15 @@ SIGNATURES = {
     'dic_head_bwd': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _p, _p, _p, _sz, _p]),
     'dic_bn_colstats_workspace': (_sz, [C.c_int64, _i]),
     'dic_bn_colstats': (_i, [_p, C.c_int64, _i, _p, _p, _sz, _p]),
+    'dic_bn_moments': (_i, [_p, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     'dic_bnhead_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p]),
     'dic_bnhead_bwd_workspace': (_sz, [C.c_int64, _i, _i]),
     'dic_bnhead_bwd_reduce': (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p, _sz, _p]),
-    'dic_bnhead_bwd_input': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_int64, _i, _i, _i, _f, _p, _p, _p]),
+    'dic_bnhead_bwd_input': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_double, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p]),
     'dic_cluster_pairdist': (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
     'dic_adam_amsgrad_step': (_i, [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
+    'dic_grad_norm_workspace': (_sz, [C.c_int64]),
+    'dic_grad_norm_clip': (_i, [_p, C.c_int64, _f, _p, _p, _sz, _p]),
     'dic_kmeans_pp_workspace': (_sz, [_i, _i]),
     'dic_kmeans_pp_candidates': (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _sz, _p]),
 }

@@ -111,10 +111,35 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const __bf16* z, long 
     partials[(size_t)blockIdx.x * 2 * BK + i] = red[0][i >> 7][i & 127] + red[1][i >> 7][i & 127] + red[2][i >> 7][i & 127] + red[3][i >> 7][i & 127];
 }
 
-__global__ __launch_bounds__(256) void bn_colstats_finalize(const float* partials, int nblk, double* sums) {
+__global__ __launch_bounds__(256) void bn_colstats_finalize(const float* partials, int nblk, double nrows, double* sums) {
     __shared__ double red[256];
     const double s = reduce_partials_32x8(partials, nblk, 2 * BK, blockIdx.x * 32, red);
     if (threadIdx.x < 32) sums[blockIdx.x * 32 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * BK] = nrows;        // the row count rides along in the (all-reduced) record
+}
+
+// sums [sum z | sum z^2 | rows] (f64, summed over ranks) -> batch moments, and nn.BatchNorm1d's running statistics in the same
+// launch (replaces ~15 element-wise torch launches on 128-float vectors per head and step)
+__global__ __launch_bounds__(BK) void bn_moments_kernel(const double* sums, float eps, float momentum, float* running_mean,
+                                                       float* running_var, long long* num_batches_tracked, float* mean, float* rstd,
+                                                       float* count) {
+    const int i = threadIdx.x;
+    const double n = sums[2 * BK];
+    const double m = sums[i] / n;
+    const double var = fmax(sums[BK + i] / n - m * m, 0.0);
+    mean[i] = (float)m;
+    rstd[i] = rsqrtf((float)var + eps);
+    if (i == 0) count[0] = (float)n;
+    if (running_mean) {
+        long long nbt = 0;
+        if (num_batches_tracked) nbt = num_batches_tracked[0] + 1;
+        const float mom = momentum >= 0.f ? momentum : 1.0f / (float)(nbt > 0 ? nbt : 1);      // momentum=None: cumulative average
+        const float unbiased = (float)var * (float)(n / fmax(n - 1.0, 1.0));
+        running_mean[i] = (1.0f - mom) * running_mean[i] + mom * (float)m;
+        running_var[i] = (1.0f - mom) * running_var[i] + mom * unbiased;
+        __syncthreads();
+        if (i == 0 && num_batches_tracked) num_batches_tracked[0] = nbt;
+    }
 }
 
 template <int C>
@@ -284,8 +309,9 @@ __global__ __launch_bounds__(256) void bnhead_bwd_finalize(const float* partials
 template <int C>
 __global__ __launch_bounds__(256) void bnhead_bwd_input_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
                                                                const float* beta, const float* W, const float* dv, const float* sum_da,
-                                                               const float* sum_dax, float inv_n, long N, float floor_, float drop_p, const unsigned long long* rng,
-                                                               __bf16* dz) {
+                                                               const float* sum_dax, float inv_n, const float* count, long N, float floor_, float drop_p,
+                                                               const unsigned long long* rng, __bf16* dz) {
+    if (count) inv_n = 1.0f / count[0];                      // global row count of the batch moments, on the device
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
     const ColParams p = load_cols(mean, rstd, gamma, beta, kc);
     const Drop drop = load_drop(drop_p, rng);
@@ -352,8 +378,18 @@ int dic_bn_colstats(const void* z, int64_t N, int K, double* sums, void* workspa
     DIC_REQUIRE(workspace_bytes >= (size_t)nblk * 2 * BK * sizeof(float), DIC_ERR_WORKSPACE, "bn_colstats: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_colstats_kernel, dim3(nblk), dim3(256), 0, st, (const __bf16*)z, (long)N, (float*)workspace);
-    hipLaunchKernelGGL(bn_colstats_finalize, dim3(2 * BK / 32), dim3(256), 0, st, (const float*)workspace, nblk, sums);
+    hipLaunchKernelGGL(bn_colstats_finalize, dim3(2 * BK / 32), dim3(256), 0, st, (const float*)workspace, nblk, (double)N, sums);
     return check_launch("bn_colstats");
+}
+
+int dic_bn_moments(const double* sums, int K, float eps, float momentum, float* running_mean, float* running_var,
+                   int64_t* num_batches_tracked, float* mean, float* rstd, float* count, dic_stream_t stream) {
+    DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bn_moments: width %d (compiled for %d)", K, BK);
+    DIC_REQUIRE(sums && mean && rstd && count, DIC_ERR_INVALID_ARG, "bn_moments: NULL pointer");
+    DIC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DIC_ERR_INVALID_ARG, "bn_moments: running_mean and running_var go together");
+    hipLaunchKernelGGL(bn_moments_kernel, dim3(1), dim3(BK), 0, (hipStream_t)stream, sums, eps, momentum, running_mean, running_var,
+                       (long long*)num_batches_tracked, mean, rstd, count);
+    return check_launch("bn_moments");
 }
 
 int dic_bnhead_fwd(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
@@ -389,14 +425,14 @@ int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, c
 }
 
 int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, int relu,
+                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, const float* count, int64_t N, int K, int C, int relu,
                          float drop_p, const uint64_t* rng, void* dz, dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_bwd_input: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_bwd_input: in_features %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && mean && rstd && gamma && beta && W && dv && sum_da && sum_dax && dz, DIC_ERR_INVALID_ARG, "bnhead_bwd_input: NULL pointer");
     const int grid = bnhead_blocks(N);
     DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_bwd_input_kernel<C>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)z, mean,
-                                                rstd, gamma, beta, W, dv, sum_da, sum_dax, (float)inv_n, (long)N, relu ? 0.f : -INFINITY, drop_p,
+                                                rstd, gamma, beta, W, dv, sum_da, sum_dax, (float)inv_n, count, (long)N, relu ? 0.f : -INFINITY, drop_p,
                                                 (const unsigned long long*)rng, (__bf16*)dz));
     return check_launch("bnhead_bwd_input");
 }

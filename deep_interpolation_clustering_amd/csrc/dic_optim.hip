@@ -39,6 +39,29 @@ __global__ __launch_bounds__(256) void adam_amsgrad_kernel(float* __restrict__ p
     }
 }
 
+// clip_grad_norm_'s two scalars over the flat bucket: total = ||g||_2 (f64 accumulation of per-workgroup partials, fixed order),
+// coef = min(1, max_norm / (total + 1e-6)) (torch/nn/utils/clip_grad.py) -- two launches instead of norm + add + div + clamp
+__global__ __launch_bounds__(256) void grad_sqsum_kernel(const float* g, long n, double* partials) {
+    __shared__ double red[4];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+    const double w = wave_sum((double)acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void grad_norm_finalize(const double* partials, int nblk, float max_norm, float* out2) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(partials, nblk, 1, 0, red);
+    if (threadIdx.x == 0) {
+        const float total = (float)sqrt(s);
+        out2[0] = total;
+        out2[1] = fminf(1.0f, max_norm / (total + 1e-6f));
+    }
+}
+
+static int norm_blocks(long n) { return (int)max(1L, min((n + 1023) / 1024, (long)2 * kNumCU)); }
+
 }  // namespace dic
 
 using namespace dic;
@@ -54,6 +77,19 @@ int dic_adam_amsgrad_step(float* p, float* g, float* m, float* v, float* vmax, i
     hipLaunchKernelGGL(adam_amsgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, (long)n, lr, beta1, beta2,
                        eps, weight_decay, step, grad_scale, active, hyper);
     return check_launch("adam_amsgrad_step");
+}
+
+size_t dic_grad_norm_workspace(int64_t n) { return n > 0 ? (size_t)norm_blocks((long)n) * sizeof(double) : 0; }
+
+int dic_grad_norm_clip(const float* g, int64_t n, float max_norm, float* out2, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(n > 0, DIC_ERR_INVALID_ARG, "grad_norm_clip: non-positive size");
+    DIC_REQUIRE(g && out2 && workspace, DIC_ERR_INVALID_ARG, "grad_norm_clip: NULL pointer");
+    const int nblk = norm_blocks((long)n);
+    DIC_REQUIRE(workspace_bytes >= (size_t)nblk * sizeof(double), DIC_ERR_WORKSPACE, "grad_norm_clip: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(grad_sqsum_kernel, dim3(nblk), dim3(256), 0, st, g, (long)n, (double*)workspace);
+    hipLaunchKernelGGL(grad_norm_finalize, dim3(1), dim3(256), 0, st, (const double*)workspace, nblk, max_norm, out2);
+    return check_launch("grad_norm_clip");
 }
 
 }  // extern "C"

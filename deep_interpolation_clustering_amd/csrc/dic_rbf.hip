@@ -19,6 +19,7 @@ struct RbfArgs {
     const float* x; const int32_t* lengths; int B, C, T, R, E;
     const float* ref_grid; const float* rbf_kernel; const float* v;
     float* y; float* norm;                       // forward outputs (norm optional)
+    int v_rbc;                                   // v is laid out (R,B,C) -- the row order CompressFC produces it in -- instead of (B,C,R)
 };
 
 __host__ __device__ inline int rbf_fwd_words(int E, int C, int R) { return E * C * R + R + C + E * C; }
@@ -32,7 +33,14 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
     int* cnt = reinterpret_cast<int*>(nbeta + C);   // [E*C]
     const int tid = threadIdx.x, e0 = blockIdx.x * E, Ev = min(E, a.B - e0), nrows = Ev * C;
 
-    for (int i = tid; i < nrows * R; i += kBlock) vs[i] = a.v[(size_t)e0 * C * R + i];
+    if (a.v_rbc) {
+        for (int i = tid; i < nrows * R; i += kBlock) {      // i = r * nrows + (e * C + c): consecutive lanes read consecutive floats of a grid point's rows
+            const int r = i / nrows, ec = i - r * nrows;
+            vs[ec * R + r] = a.v[((size_t)r * a.B + e0) * C + ec];
+        }
+    } else {
+        for (int i = tid; i < nrows * R; i += kBlock) vs[i] = a.v[(size_t)e0 * C * R + i];
+    }
     for (int i = tid; i < R; i += kBlock) refg[i] = a.ref_grid[i];
     for (int i = tid; i < C; i += kBlock) nbeta[i] = -softplus_raw(a.rbf_kernel[i]) * kLog2e;
     for (int i = tid; i < nrows; i += kBlock)
@@ -77,6 +85,7 @@ struct RbfBwdArgs {
     const float* ref_grid; const float* rbf_kernel; const float* v;
     const float* y; const float* norm; const float* grad_y;
     float* grad_v; float* partials;
+    int v_rbc;                                   // v and grad_v are laid out (R,B,C) instead of (B,C,R)
 };
 
 struct RbfBwdLayout { int cnt, refg, nbeta, vs, gbeta, obs, stride, total_words; };
@@ -121,7 +130,14 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
         __syncthreads();
         if (tid == 0) *tile_max = 0;
         __syncthreads();
-        for (int i = tid; i < nrows * R; i += kBlock) vs[i] = a.v[(size_t)e0 * C * R + i];
+        if (a.v_rbc) {
+            for (int i = tid; i < nrows * R; i += kBlock) {
+                const int r = i / nrows, ec = i - r * nrows;
+                vs[ec * R + r] = a.v[((size_t)r * a.B + e0) * C + ec];
+            }
+        } else {
+            for (int i = tid; i < nrows * R; i += kBlock) vs[i] = a.v[(size_t)e0 * C * R + i];
+        }
         for (int i = tid; i < nrows; i += kBlock) {
             const int n = a.lengths ? max(0, min(a.lengths[(size_t)e0 * C + i], T)) : T;
             cnt[i] = n;
@@ -193,7 +209,8 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
 #pragma unroll
             for (int m = 1; m < S; m <<= 1) { gv += __shfl_xor(gv, m); gbt += __shfl_xor(gbt, m); }
             if (live && s == 0) {
-                a.grad_v[((size_t)e0 * C + row) * R + r] = gv;
+                if (a.v_rbc) a.grad_v[((size_t)r * a.B + e0) * C + row] = gv;
+                else a.grad_v[((size_t)e0 * C + row) * R + r] = gv;
                 gb[row * R + r] = gbt;
             }
         }
@@ -305,11 +322,11 @@ using namespace dic;
 extern "C" {
 
 int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
-                const float* rbf_kernel, const float* v, float* y, float* norm, dic_stream_t stream) {
+                const float* rbf_kernel, const float* v, int v_time_major, float* y, float* norm, dic_stream_t stream) {
     DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_fwd: non-positive size");
     DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_fwd: C=%d R=%d", C, R);
     DIC_REQUIRE(x && ref_grid && rbf_kernel && v && y, DIC_ERR_INVALID_ARG, "rbf_fwd: NULL pointer");
-    RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm};
+    RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm, v_time_major != 0};
     const int per_enc = rbf_fwd_words(2, C, R) - rbf_fwd_words(1, C, R);
     a.E = rbf_tile(B, per_enc, rbf_fwd_words(1, C, R) - per_enc, 32 * 1024);
     hipLaunchKernelGGL(rbf_fwd_kernel, dim3((B + a.E - 1) / a.E), dim3(kBlock), (size_t)rbf_fwd_words(a.E, C, R) * 4,
@@ -332,7 +349,7 @@ size_t dic_rbf_bwd_workspace(int B, int C, int T, int R) {
 }
 
 int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
-                const float* rbf_kernel, const float* v, const float* y, const float* norm, const float* grad_y,
+                const float* rbf_kernel, const float* v, int v_time_major, const float* y, const float* norm, const float* grad_y,
                 float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_bwd: non-positive size");
     DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_bwd: C=%d R=%d", C, R);
@@ -341,7 +358,7 @@ int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int
     RbfBwdArgs a{};
     a.x = x; a.lengths = lengths; a.B = B; a.C = C; a.T = T; a.R = R;
     a.ref_grid = ref_grid; a.rbf_kernel = rbf_kernel; a.v = v; a.y = y; a.norm = norm; a.grad_y = grad_y;
-    a.grad_v = grad_v; a.partials = (float*)workspace;
+    a.grad_v = grad_v; a.partials = (float*)workspace; a.v_rbc = v_time_major != 0;
     size_t lds;
     rbf_bwd_geometry(B, C, T, R, &a.E, &a.nblk, &lds);
     DIC_REQUIRE(lds <= 64 * 1024, DIC_ERR_UNSUPPORTED, "rbf_bwd: one encounter needs %zu B of LDS", lds);

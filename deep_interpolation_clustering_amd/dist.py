@@ -107,6 +107,7 @@ class FlatParams:
         # no state), and with pre-allocated gradient views "None" has to be observed instead -- a hook per parameter flags it
         self._reached = [False] * len(self.params)
         self._mask_key, self._mask = None, None
+        self._norm_ws = None
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -160,6 +161,15 @@ class FlatParams:
 
     def clip_coef(self, max_norm: float):
         """(total norm, clip coefficient) of torch.nn.utils.clip_grad_norm_ (pretrain_trainer.py:228), both on the device."""
+        if self.grad.is_cuda:          # one reduction kernel + one scalar kernel (csrc/dic_optim.hip) instead of five torch launches
+            from . import _native as N
+            L = N.lib()
+            if self._norm_ws is None:
+                self._norm_ws = torch.empty(max(16, L.dic_grad_norm_workspace(self.grad.numel())), dtype=torch.uint8, device=self.grad.device)
+            out2 = torch.empty(2, device=self.grad.device, dtype=torch.float32)
+            N.check(L.dic_grad_norm_clip(N.ptr(self.grad), self.grad.numel(), float(max_norm), N.ptr(out2), N.ptr(self._norm_ws),
+                                         self._norm_ws.numel(), N.stream_of(self.grad)), 'dic_grad_norm_clip')
+            return out2[0], out2[1]
         total = torch.linalg.vector_norm(self.grad)
         return total, torch.clamp(max_norm / (total + 1e-6), max=1.0)
 

@@ -181,40 +181,42 @@ class _Rbf(torch.autograd.Function):
     def forward(ctx, v, raw_input, rbf_kernel, grid, lengths):
         N.require_gpu(v, raw_input, rbf_kernel, grid)
         x = N.f32c(raw_input)
-        v = N.f32c(v)
         B, C4, T = x.shape
         C = rbf_kernel.numel()
         R = grid.numel()
         if C4 != 4 * C or tuple(v.shape) != (B, C, R):
             raise ValueError(f'rbf: raw_input {tuple(x.shape)} / v {tuple(v.shape)} do not match C={C}, R={R}')
+        # v usually arrives as a permuted VIEW of the (R,B,C) rows the FC head wrote: the kernels read that layout as it lies
+        tm = v.dtype == torch.float32 and not v.is_contiguous() and v.permute(2, 0, 1).is_contiguous()
+        vb = v.permute(2, 0, 1) if tm else N.f32c(v)
         lengths = _lengths_arg(lengths, B, C, x.device)
         rk = N.f32c(rbf_kernel.detach())
         need_grad = any(ctx.needs_input_grad)
         y = torch.empty((B, C, T), device=x.device, dtype=torch.float32)
         norm = torch.empty_like(y) if need_grad else None
-        N.check(N.lib().dic_rbf_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(v), N.ptr(y),
+        N.check(N.lib().dic_rbf_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y),
                                     N.ptr(norm), N.stream_of(x)), 'dic_rbf_fwd')
-        ctx.dims = (B, C, T, R)
-        ctx.save_for_backward(x, lengths, grid, rk, v, y, norm)
+        ctx.dims = (B, C, T, R, bool(tm))
+        ctx.save_for_backward(x, lengths, grid, rk, vb, y, norm)
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        x, lengths, grid, rk, v, y, norm = ctx.saved_tensors
-        B, C, T, R = ctx.dims
+        x, lengths, grid, rk, vb, y, norm = ctx.saved_tensors
+        B, C, T, R, tm = ctx.dims
         g = N.f32c(grad_y)
-        gv = torch.empty((B, C, R), device=g.device, dtype=torch.float32)
+        gv = torch.empty((R, B, C) if tm else (B, C, R), device=g.device, dtype=torch.float32)
         gk = torch.empty(C, device=g.device, dtype=torch.float32)
         L = N.lib()
         ws = _ws(L.dic_rbf_bwd_workspace(B, C, T, R), g.device)
-        N.check(L.dic_rbf_bwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(v), N.ptr(y), N.ptr(norm),
+        N.check(L.dic_rbf_bwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y), N.ptr(norm),
                               N.ptr(g), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_rbf_bwd')
-        return gv, None, gk, None, None
+        return (gv.permute(1, 2, 0) if tm else gv), None, gk, None, None
 
 
 def rbf_deinterp(v, raw_input, rbf_kernel, grid, lengths=None):
     """v (B,C,R) grid values -> (B,C,T) values at the observed time stamps of ``raw_input``."""
-    return _Rbf.apply(v.float(), raw_input, rbf_kernel, grid, lengths)   # .float(): bf16 autocast producers
+    return _Rbf.apply(v if v.dtype == torch.float32 else v.float(), raw_input, rbf_kernel, grid, lengths)   # .float(): bf16 autocast producers
 
 
 class _MaskedMse(torch.autograd.Function):
@@ -387,11 +389,11 @@ def head_linear(h, weight, bias):
 
 
 class _BnReluHead(torch.autograd.Function):
-    """BatchNorm1d(128) -> ReLU -> Linear(128, C) over (N,128) bf16 rows (csrc/dic_bnhead.hip).  Returns
-    (v, mean, biased var, global row count); the moments are for the caller's running statistics."""
+    """BatchNorm1d(128) -> ReLU -> Linear(128, C) over (N,128) bf16 rows (csrc/dic_bnhead.hip), with nn.BatchNorm1d's running
+    statistics updated by the same moments kernel (training mode)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, training, relu, drop_p=0.0):
+    def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, nbt, momentum, training, relu, drop_p=0.0):
         N.require_gpu(z, gamma, beta, weight, bias)
         zb = z.to(torch.bfloat16).contiguous()
         n, k = zb.shape
@@ -400,29 +402,29 @@ class _BnReluHead(torch.autograd.Function):
         if training:
             sums = torch.empty(2 * k + 1, device=dev, dtype=torch.float64)
             ws = _ws(L.dic_bn_colstats_workspace(n, k), dev)
-            N.check(L.dic_bn_colstats(N.ptr(zb), n, k, N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bn_colstats')
-            sums[2 * k:].fill_(n)                 # (a fill kernel: item assignment is a host-to-device copy, not capturable)
+            N.check(L.dic_bn_colstats(N.ptr(zb), n, k, N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bn_colstats')      # [sum z | sum z^2 | rows]
             dist.all_reduce_sum_(sums)            # the moments of the GLOBAL batch
-            cnt = sums[2 * k]
-            mean64 = sums[:k] / cnt
-            var = (sums[k:2 * k] / cnt - mean64 * mean64).clamp_min_(0).float()
-            mean, cnt = mean64.float(), cnt.float()
+            mean = torch.empty(k, device=dev, dtype=torch.float32)
+            rstd, cnt = torch.empty_like(mean), torch.empty(1, device=dev, dtype=torch.float32)
+            track = running_mean is not None
+            N.check(L.dic_bn_moments(N.ptr(sums), k, float(eps), -1.0 if momentum is None else float(momentum),
+                                     N.ptr(running_mean) if track else None, N.ptr(running_var) if track else None,
+                                     N.ptr(nbt) if (track and nbt is not None) else None, N.ptr(mean), N.ptr(rstd), N.ptr(cnt), st), 'dic_bn_moments')
         else:
-            mean, var = N.f32c(running_mean), N.f32c(running_var)
-            cnt = torch.ones((), device=dev, dtype=torch.float32)
-        rstd = torch.rsqrt(var + eps)
+            mean = N.f32c(running_mean)
+            rstd = torch.rsqrt(N.f32c(running_var) + eps)
+            cnt = None
         g, bt, w, b = N.f32c(gamma.detach()), N.f32c(beta.detach()), N.f32c(weight.detach()), N.f32c(bias.detach())
         v = torch.empty((n, c), device=dev, dtype=torch.float32)
-        rng = _dropout_rng(dev) if drop_p > 0 else torch.zeros(2, dtype=torch.int64, device=dev)
+        rng = _dropout_rng(dev) if drop_p > 0 else None
         N.check(L.dic_bnhead_fwd(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(b), n, k, c, int(relu), float(drop_p), N.ptr(rng), N.ptr(v), st),
                 'dic_bnhead_fwd')
         ctx.save_for_backward(zb, mean, rstd, g, bt, w, cnt, rng)
         ctx.z_dtype, ctx.training, ctx.relu, ctx.drop_p = z.dtype, bool(training), int(relu), float(drop_p)
-        ctx.mark_non_differentiable(mean, var, cnt)
-        return v, mean, var, cnt
+        return v
 
     @staticmethod
-    def backward(ctx, dv, _m, _v, _c):
+    def backward(ctx, dv):
         zb, mean, rstd, g, bt, w, cnt, rng = ctx.saved_tensors
         n, k = zb.shape
         c = w.shape[0]
@@ -437,16 +439,19 @@ class _BnReluHead(torch.autograd.Function):
         dz = None
         if ctx.needs_input_grad[0]:
             if ctx.training:
-                red = sums[:2 * k].clone()
-                dist.all_reduce_sum_(red)
-                red /= cnt                          # global row count, on the device (shards may differ by a row)
+                red = sums[:2 * k]
+                if dist.is_sharded():
+                    red = red.clone()
+                    dist.all_reduce_sum_(red)
+                count = cnt                         # sums / global row count, divided in-kernel (shards may differ by a row)
             else:
                 red = torch.zeros(2 * k, device=dev, dtype=torch.float32)
+                count = None
             dz = torch.empty_like(zb)
             N.check(L.dic_bnhead_bwd_input(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), N.ptr(red),
-                                           N.ptr(red[k:]), 1.0, n, k, c, ctx.relu, ctx.drop_p, N.ptr(rng), N.ptr(dz), st), 'dic_bnhead_bwd_input')
+                                           N.ptr(red[k:]), 1.0, N.ptr(count), n, k, c, ctx.relu, ctx.drop_p, N.ptr(rng), N.ptr(dz), st), 'dic_bnhead_bwd_input')
             dz = dz.to(ctx.z_dtype)
-        return dz, dgamma, dbeta, dw, db, None, None, None, None, None, None
+        return dz, dgamma, dbeta, dw, db, None, None, None, None, None, None, None, None
 
 
 BNHEAD_OUT = (1, 2, 3, 4, 5, 6, 7, 8)
@@ -471,17 +476,10 @@ def bn_relu_head(z, bn, linear, relu=True, dropout=None):
     nn.Dropout between the activation and ``linear`` (active when in training mode with p > 0; the mask is drawn in-kernel)."""
     training = bn.training or bn.running_mean is None
     drop_p = float(dropout.p) if (dropout is not None and dropout.training) else 0.0
-    v, mean, var, cnt = _BnReluHead.apply(z, bn.weight, bn.bias, linear.weight, linear.bias, bn.eps, bn.running_mean,
-                                          bn.running_var, training, relu, drop_p)
-    if bn.training and bn.track_running_stats:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
-            # momentum=None (cumulative average) needs the step count on the host: not used on the reference path
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
-            unbiased = var * (cnt / (cnt - 1).clamp_min(1))
-            bn.running_var.mul_(1 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
-    return v
+    track = bn.training and bn.track_running_stats and bn.running_mean is not None
+    return _BnReluHead.apply(z, bn.weight, bn.bias, linear.weight, linear.bias, bn.eps, bn.running_mean if (track or not training) else None,
+                             bn.running_var if (track or not training) else None, bn.num_batches_tracked if track else None, bn.momentum,
+                             training, relu, drop_p)
 
 
 def splitk_tn(a, b, chunks=(8192, 4096, 2048)):

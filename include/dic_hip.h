@@ -107,16 +107,18 @@ int dic_sci_cci_bwd_packed(const void* grad_packed, int xw, const float* saved, 
 /* ------------------------------------------------------------------ k2: RBF de-interpolation
  * Replaces RBF.forward minus compress_fc (rbf.py:57-108, gaussian rbf.py:129-131).
  *   v (B,C,R) = compress_fc output;  y (B,C,T) OVERWRITTEN (0 in masked slots).
- * Limits: C<=16, R<=64. */
+ * Limits: C<=16, R<=64.  * v_time_major != 0: v (and grad_v) are laid out (R,B,C) -- the row order TimeDistributed(CompressFC) produces them in on the
+ * decoder's (R,B,.) output -- instead of (B,C,R): no transposing copy between the FC head and this kernel.
+ */
 int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
-                const float* rbf_kernel, const float* v, float* y, float* norm /* (B,C,T) or NULL: sum_r phi,
+                const float* rbf_kernel, const float* v, int v_time_major, float* y, float* norm /* (B,C,T) or NULL: sum_r phi,
                 saved for the backward */, dic_stream_t stream);
 
 /* grad_y (B,C,T) -> grad_v (B,C,R), grad_rbf_kernel (C); both OVERWRITTEN.  y, norm: forward outputs.
  * Masks are binary upstream; a non-zero mask value is treated as 1. */
 size_t dic_rbf_bwd_workspace(int B, int C, int T, int R);
 int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
-                const float* rbf_kernel, const float* v, const float* y, const float* norm,
+                const float* rbf_kernel, const float* v, int v_time_major, const float* y, const float* norm,
                 const float* grad_y, float* grad_v, float* grad_rbf_kernel,
                 void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
@@ -283,19 +285,25 @@ int dic_head_bwd(const void* h, const float* W, const float* dv, int64_t N, int 
  * BatchNorm1d(128) -> ReLU -> Linear(128, C) (rbf.py:116-123 with dropout p = 0 or eval mode) over N rows
  * without materialising the hidden activation.  z (N,128) bf16 = output of the first Linear; mean, rstd,
  * gamma, beta (128) f32; W (C,128), b (C) f32; C in 1..8.
- *   dic_bn_colstats:       sums[0:128] = sum_rows z, sums[128:256] = sum_rows z^2 (f64; the caller forms the
- *                          batch moments, all-reducing the sums first when the batch is sharded over ranks)
+ *   dic_bn_colstats:       sums[0:128] = sum_rows z, sums[128:256] = sum_rows z^2, sums[256] = N (f64, 257 entries; the caller
+ *                          all-reduces the record first when the batch is sharded over ranks)
+ *   dic_bn_moments:        that record -> mean, rstd = 1/sqrt(biased var + eps) (128 f32 each), count (1 f32), and -- when
+ *                          running_mean / running_var are given -- nn.BatchNorm1d's running statistics (momentum < 0 =
+ *                          cumulative average) and num_batches_tracked += 1, all in one launch
  *   dic_bnhead_fwd:        v (N,C) f32 = b + W relu(gamma (z - mean) rstd + beta)
  *   dic_bnhead_bwd_reduce: sums[(2+C)*128 + C] f32 = sum da | sum da*xhat | dW (C,128) | db (C), where
  *                          da = (dv W) 1[h > 0]; the first two rows are d beta and d gamma
  *   dic_bnhead_bwd_input:  dz (N,128) bf16 = gamma rstd (da - sum_da*inv_n - xhat sum_dax*inv_n); inv_n = 1 /
- *                          global row count in training mode; pass zero sums for eval-mode BatchNorm.
+ *                          global row count in training mode (count != NULL: read from that device scalar instead); pass
+ *                          zero sums for eval-mode BatchNorm.
  * relu = 0 drops the ReLU: BatchNorm1d(128) -> Linear(128, C), the tail of the auxiliary / fake-detection heads
  * (clustering_interp.py:43-87).  drop_p > 0 applies nn.Dropout(p) between the activation and the Linear (rbf.py:120): the
  * keep mask is a hash of (rng[0] = seed, rng[1] = call counter, element index) -- rng is a 2-word device buffer that the
  * caller keeps unchanged between a forward and its backward calls -- so no mask tensor exists. */
 size_t dic_bn_colstats_workspace(int64_t N, int K);
 int dic_bn_colstats(const void* z, int64_t N, int K, double* sums, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+int dic_bn_moments(const double* sums, int K, float eps, float momentum, float* running_mean, float* running_var,
+                   int64_t* num_batches_tracked, float* mean, float* rstd, float* count, dic_stream_t stream);
 int dic_bnhead_fwd(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
                    const float* b, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* v, dic_stream_t stream);
 size_t dic_bnhead_bwd_workspace(int64_t N, int K, int C);
@@ -303,7 +311,7 @@ int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, c
                           const float* dv, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* sums,
                           void* workspace, size_t workspace_bytes, dic_stream_t stream);
 int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, int64_t N, int K, int C, int relu,
+                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, const float* count, int64_t N, int K, int C, int relu,
                          float drop_p, const uint64_t* rng, void* dz, dic_stream_t stream);
 
 /* ------------------------------------------------- K-sweep statistics (p2, internal_eval) ------
@@ -329,6 +337,10 @@ int dic_cluster_pairdist(const float* X, const int32_t* seg, int N, int D, int K
 int dic_adam_amsgrad_step(float* p, float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
                           float eps, float weight_decay, const float* step, const float* grad_scale, const unsigned char* active, const float* hyper,
                           dic_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_'s scalars for the flat gradient bucket (pretrain_trainer.py:228): out2[0] = ||g||_2,
+ * out2[1] = min(1, max_norm / (||g||_2 + 1e-6)) -- the `grad_scale` of dic_adam_amsgrad_step.  Deterministic two-stage sum. */
+size_t dic_grad_norm_workspace(int64_t n);
+int dic_grad_norm_clip(const float* g, int64_t n, float max_norm, float* out2, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
 #ifdef __cplusplus
 }
