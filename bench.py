@@ -116,13 +116,13 @@ def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True):
                         8 * nsum + 4 * B * C + 12 * B * C * R),
         'sci_cci_bwd': (lambda: L.dic_sci_cci_bwd(P(gout), P(saved), P(sk), P(ck), B, C, R, P(gs), P(gc), P(ws1), ws1.numel(), st),
                         8 * nsum + 24 * B * C * R),
-        'rbf_fwd': (lambda: L.dic_rbf_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(rk), P(v), 0, P(y), P(norm), st),
+        'rbf_fwd': (lambda: L.dic_rbf_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(rk), P(v), 0, P(y), P(norm), 1, st),
                     12 * nsum + 4 * B * C * R),
         'rbf_bwd': (lambda: L.dic_rbf_bwd(P(x), P(lengths), B, C, T, R, P(grid), P(rk), P(v), 0, P(y), P(norm), P(gy), P(gv), P(gk),
                                           P(ws2), ws2.numel(), st), 8 * nsum + 8 * B * C * R),
         'masked_sse_fwd': (lambda: L.dic_masked_sse_fwd(P(ob), P(y), None, P(lengths), B, C, T, P(out2), P(ws3), ws3.numel(), st),
                            8 * nsum),
-        'masked_sse_bwd': (lambda: L.dic_masked_sse_bwd(P(ob), P(y), None, P(lengths), B, C, T, P(out2), P(gl), P(gy), st),
+        'masked_sse_bwd': (lambda: L.dic_masked_sse_bwd(P(ob), P(y), None, P(lengths), B, C, T, P(out2), P(gl), P(gy), 1, st),
                            12 * nsum),
         'dec_fwd': (lambda: L.dic_dec_fwd(P(z), P(mu), B, D, K, 1.0, P(q), P(ts), P(colsum), P(ws4), ws4.numel(), st),
                     4.0 * B * (D + 2 * K)),

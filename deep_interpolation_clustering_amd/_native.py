@@ -41,12 +41,12 @@ SIGNATURES = {
     'dic_cci_fwd': (_i, [_p, _p, _i, _i, _i, _p, _p]),
     'dic_cci_bwd_workspace': (_sz, [_i, _i, _i]),
     'dic_cci_bwd': (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
-    'dic_rbf_fwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    'dic_rbf_fwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
     'dic_rbf_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'dic_rbf_bwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'dic_masked_sse_workspace': (_sz, [_i, _i, _i]),
     'dic_masked_sse_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p]),
-    'dic_masked_sse_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    'dic_masked_sse_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     'dic_dec_fwd_workspace': (_sz, [_i, _i, _i]),
     'dic_dec_fwd': (_i, [_p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),
     'dic_dec_target': (_i, [_p, _p, _i, _i, _p, _p]),

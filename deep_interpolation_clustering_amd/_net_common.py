@@ -102,6 +102,7 @@ class FakeDetFc(_Head):
 
 class NetBase(nn.Module):
     clustering = False
+    internal_step = False      # set by step.Stepper around its own forward + loss + backward (see forward / rec_loss)
 
     def __init__(self, args, device):
         super().__init__()
@@ -176,7 +177,9 @@ class NetBase(nn.Module):
                 hidden, cell = (hidden[:B], cell[:B]) if bm else (hidden[:, :B].contiguous(), cell[:, :B].contiguous())
         cat_hidden = z_all[:B]
         y, _ = self.decoder(context, hidden, cell, bm) if bm else self.decoder(context, hidden, cell)
-        y = self.rbf(y.permute(1, 2, 0), x, lengths)                      # (B,C,T)
+        # (B,C,T).  Inside step.Stepper's optimisation step (`internal_step`: the reconstruction is consumed by rec_loss alone and never
+        # handed out) only the observed slots are materialised; every other caller gets zeros in the padding, as upstream's `* mask`
+        y = self.rbf(y.permute(1, 2, 0), x, lengths, prefix_only=self.internal_step)
 
         aux = dict()
         n_aux = len(args.aux_tasks)
@@ -203,7 +206,7 @@ class NetBase(nn.Module):
     # ------------------------------------------------------------------------------ losses
     def rec_loss(self, org_ob, rec_ob, padding_mask, lengths=None):
         """Masked SSE / #observed over the global batch (clustering_interp.py:197-203), one HIP reduction."""
-        mse = ops.masked_mse(org_ob, rec_ob, padding_mask, lengths)
+        mse = ops.masked_mse(org_ob, rec_ob, padding_mask, lengths, prefix_only=self.internal_step and padding_mask is None)
         return {'loss': mse, 'ae_mse': mse}
 
     def sup_aux_loss(self, aux_tasks, aux_label_dict, aux_pred_dict, future_vital_mask=None):

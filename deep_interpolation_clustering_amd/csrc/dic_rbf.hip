@@ -18,7 +18,8 @@ constexpr float kRbfEps = 1e-10f;   // rbf.py:107
 struct RbfArgs {
     const float* x; const int32_t* lengths; int B, C, T, R, E;
     const float* ref_grid; const float* rbf_kernel; const float* v;
-    float* y; float* norm;                       // forward outputs (norm optional)
+    float* y; float* norm;                       // forward outputs; norm (optional) = 1 / (sum_r phi + eps) per valid slot
+    int prefix_only;                             // lengths given: write only the first n slots of each row (the padding stays as the caller allocated it)
     int v_rbc;                                   // v is laid out (R,B,C) -- the row order CompressFC produces it in -- instead of (B,C,R)
 };
 
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
         const int row = u / nchunk;
         const int i = (u - row * nchunk) * kWave + lane;
         if (i >= T) continue;
+        if (a.prefix_only && (u - row * nchunk) * kWave >= cnt[row]) continue;      // wave-uniform: the whole chunk is padding
         const int e = row / C, c = row - e * C;
         const float* base = a.x + (size_t)(e0 + e) * 4 * C * T;
         bool valid = i < cnt[row];
@@ -73,9 +75,11 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
                 S = fmaf(phi, vr[r], S);
             }
         }
+        if (a.prefix_only && !valid) continue;
         const size_t o = ((size_t)(e0 + e) * C + c) * T + i;
-        a.y[o] = valid ? S / (N + kRbfEps) : 0.f;
-        if (a.norm) a.norm[o] = valid ? N : 0.f;
+        const float inv = 1.0f / (N + kRbfEps);
+        a.y[o] = valid ? S * inv : 0.f;
+        if (a.norm) a.norm[o] = valid ? inv : 0.f;
     }
 }
 
@@ -168,9 +172,8 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
                             const size_t o = ((size_t)(e0 + e) * C + c) * T + i;
                             const float t = base[(size_t)(2 * C + c) * T + i];
                             const float m = a.lengths ? 1.f : base[(size_t)(C + c) * T + i];
-                            const float den = a.norm[o] + kRbfEps;
-                            // y = m*S/den upstream, so dL/dS = g*m/den; S/den = y for a valid slot
-                            if (m != 0.f) val[k] = make_float4(t, a.grad_y[o] / den, a.y[o], 0.f);
+                            // y = m*S/den upstream, so dL/dS = g*m/den (the forward saved 1/den); S/den = y for a valid slot
+                            if (m != 0.f) val[k] = make_float4(t, a.grad_y[o] * a.norm[o], a.y[o], 0.f);
                         }
                     }
                 }
@@ -289,13 +292,14 @@ __global__ __launch_bounds__(256) void masked_sse_finalize(const double* partial
 __global__ __launch_bounds__(kBlock) void masked_sse_bwd_kernel(const float* ob, const float* rec, const float* mask,
                                                                const int32_t* lengths, long total, int T,
                                                                const float* sse_count, const float* grad_loss,
-                                                               float* grad_rec) {
+                                                               float* grad_rec, int prefix_only) {
     const float scale = 2.0f * grad_loss[0] / sse_count[1];
     for (long o = (long)blockIdx.x * kBlock + threadIdx.x; o < total; o += (long)gridDim.x * kBlock) {
         float m;
         if (lengths) {
             const long row = o / T;
             m = ((int)(o - row * T) < lengths[row]) ? 1.f : 0.f;
+            if (prefix_only && m == 0.f) continue;          // padding: never read by the de-interpolation backward
             if (mask && m != 0.f) m = mask[o];
         } else {
             m = mask[o];
@@ -322,11 +326,11 @@ using namespace dic;
 extern "C" {
 
 int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
-                const float* rbf_kernel, const float* v, int v_time_major, float* y, float* norm, dic_stream_t stream) {
+                const float* rbf_kernel, const float* v, int v_time_major, float* y, float* norm, int prefix_only, dic_stream_t stream) {
     DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_fwd: non-positive size");
     DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_fwd: C=%d R=%d", C, R);
     DIC_REQUIRE(x && ref_grid && rbf_kernel && v && y, DIC_ERR_INVALID_ARG, "rbf_fwd: NULL pointer");
-    RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm, v_time_major != 0};
+    RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm, (prefix_only && lengths) ? 1 : 0, v_time_major != 0};
     const int per_enc = rbf_fwd_words(2, C, R) - rbf_fwd_words(1, C, R);
     a.E = rbf_tile(B, per_enc, rbf_fwd_words(1, C, R) - per_enc, 32 * 1024);
     hipLaunchKernelGGL(rbf_fwd_kernel, dim3((B + a.E - 1) / a.E), dim3(kBlock), (size_t)rbf_fwd_words(a.E, C, R) * 4,
@@ -406,14 +410,14 @@ int dic_masked_sse_fwd(const float* ob, const float* rec, const float* mask, con
 }
 
 int dic_masked_sse_bwd(const float* ob, const float* rec, const float* mask, const int32_t* lengths, int B, int C, int T,
-                       const float* sse_count, const float* grad_loss, float* grad_rec, dic_stream_t stream) {
+                       const float* sse_count, const float* grad_loss, float* grad_rec, int prefix_only, dic_stream_t stream) {
     DIC_REQUIRE(B > 0 && C > 0 && T > 0, DIC_ERR_INVALID_ARG, "masked_sse_bwd: non-positive size");
     DIC_REQUIRE(ob && rec && sse_count && grad_loss && grad_rec && (mask || lengths), DIC_ERR_INVALID_ARG,
                 "masked_sse_bwd: NULL pointer");
     const long total = (long)B * C * T;
     const int grid = (int)min((total + kBlock - 1) / kBlock, (long)16 * kNumCU);
     hipLaunchKernelGGL(masked_sse_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, ob, rec, mask, lengths,
-                       total, T, sse_count, grad_loss, grad_rec);
+                       total, T, sse_count, grad_loss, grad_rec, (prefix_only && lengths) ? 1 : 0);
     return check_launch("masked_sse_bwd");
 }
 

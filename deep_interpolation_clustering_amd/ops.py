@@ -178,7 +178,7 @@ def cci(s, cci_kernel):
 # ----------------------------------------------------------------------------------------- k2
 class _Rbf(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, v, raw_input, rbf_kernel, grid, lengths):
+    def forward(ctx, v, raw_input, rbf_kernel, grid, lengths, prefix_only=False):
         N.require_gpu(v, raw_input, rbf_kernel, grid)
         x = N.f32c(raw_input)
         B, C4, T = x.shape
@@ -195,7 +195,7 @@ class _Rbf(torch.autograd.Function):
         y = torch.empty((B, C, T), device=x.device, dtype=torch.float32)
         norm = torch.empty_like(y) if need_grad else None
         N.check(N.lib().dic_rbf_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y),
-                                    N.ptr(norm), N.stream_of(x)), 'dic_rbf_fwd')
+                                    N.ptr(norm), int(bool(prefix_only)), N.stream_of(x)), 'dic_rbf_fwd')
         ctx.dims = (B, C, T, R, bool(tm))
         ctx.save_for_backward(x, lengths, grid, rk, vb, y, norm)
         return y
@@ -211,17 +211,19 @@ class _Rbf(torch.autograd.Function):
         ws = _ws(L.dic_rbf_bwd_workspace(B, C, T, R), g.device)
         N.check(L.dic_rbf_bwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y), N.ptr(norm),
                               N.ptr(g), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_rbf_bwd')
-        return (gv.permute(1, 2, 0) if tm else gv), None, gk, None, None
+        return (gv.permute(1, 2, 0) if tm else gv), None, gk, None, None, None
 
 
-def rbf_deinterp(v, raw_input, rbf_kernel, grid, lengths=None):
-    """v (B,C,R) grid values -> (B,C,T) values at the observed time stamps of ``raw_input``."""
-    return _Rbf.apply(v if v.dtype == torch.float32 else v.float(), raw_input, rbf_kernel, grid, lengths)   # .float(): bf16 autocast producers
+def rbf_deinterp(v, raw_input, rbf_kernel, grid, lengths=None, prefix_only=False):
+    """v (B,C,R) grid values -> (B,C,T) values at the observed time stamps of ``raw_input``.
+    ``prefix_only`` (needs ``lengths``): only the first n slots of each row are written -- the padding, which upstream zeroes, is
+    left uninitialised.  For callers that consume the result through ``masked_mse(..., lengths)`` alone (the training step)."""
+    return _Rbf.apply(v if v.dtype == torch.float32 else v.float(), raw_input, rbf_kernel, grid, lengths, prefix_only)   # .float(): bf16 autocast producers
 
 
 class _MaskedMse(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, org_ob, rec_ob, mask, lengths):
+    def forward(ctx, org_ob, rec_ob, mask, lengths, prefix_only=False):
         N.require_gpu(org_ob, rec_ob)
         ob, rec = N.f32c(org_ob), N.f32c(rec_ob)
         B, C, T = rec.shape
@@ -234,6 +236,7 @@ class _MaskedMse(torch.autograd.Function):
                                      ws.numel(), N.stream_of(rec)), 'dic_masked_sse_fwd')
         dist.all_reduce_sum_(out2)          # global SSE and global #{mask == 1}
         ctx.dims = (B, C, T)
+        ctx.prefix_only = bool(prefix_only) and lengths is not None and mask is None
         ctx.save_for_backward(ob, rec, mask, lengths, out2)
         return out2[0] / out2[1]
 
@@ -244,15 +247,16 @@ class _MaskedMse(torch.autograd.Function):
         gl = N.f32c(grad_loss.reshape(1))
         grad_rec = torch.empty_like(rec)
         N.check(N.lib().dic_masked_sse_bwd(N.ptr(ob), N.ptr(rec), N.ptr(mask), N.ptr(lengths), B, C, T, N.ptr(out2),
-                                           N.ptr(gl), N.ptr(grad_rec), N.stream_of(rec)), 'dic_masked_sse_bwd')
-        return None, grad_rec, None, None
+                                           N.ptr(gl), N.ptr(grad_rec), int(ctx.prefix_only), N.stream_of(rec)), 'dic_masked_sse_bwd')
+        return None, grad_rec, None, None, None
 
 
-def masked_mse(org_ob, rec_ob, padding_mask=None, lengths=None):
-    """sum((rec*m - ob*m)^2) / #{m == 1} over the (global) batch."""
+def masked_mse(org_ob, rec_ob, padding_mask=None, lengths=None, prefix_only=False):
+    """sum((rec*m - ob*m)^2) / #{m == 1} over the (global) batch.  ``prefix_only`` (lengths, no mask): the gradient wrt ``rec_ob`` is
+    written for the first n slots of each row only (see rbf_deinterp)."""
     if padding_mask is None and lengths is None:
         raise ValueError('masked_mse needs a mask or prefix lengths')
-    return _MaskedMse.apply(org_ob, rec_ob.float(), padding_mask, lengths)
+    return _MaskedMse.apply(org_ob, rec_ob.float(), padding_mask, lengths, prefix_only)
 
 
 # ----------------------------------------------------------------------------------------- k3

@@ -63,7 +63,7 @@ class RBF(nn.Module):
         self.compress_fc = TimeDistributed(CompressFC(in_dim, out_dim, dropout))
         self.kernel = nn.Parameter(torch.rand(out_dim, device=device), requires_grad=True)
 
-    def forward(self, interp_data, raw_input, lengths=None):
+    def forward(self, interp_data, raw_input, lengths=None, prefix_only=False):
         """interp_data (B,256,R), raw_input (B,4C,T) -> (B,C,T) (rbf.py:57-108)."""
         native = interp_data.permute(2, 0, 1)                                     # (R,B,256)
         if native.is_contiguous():
@@ -74,4 +74,5 @@ class RBF(nn.Module):
             v = self.compress_fc(interp_data.permute(0, 2, 1)).permute(0, 2, 1)   # (B,C,R)
         if self.interp_t.device != v.device:
             self.interp_t = self.interp_t.to(v.device)
-        return ops.rbf_deinterp(v, raw_input, self.kernel, self.interp_t, lengths)
+        # training step with prefix lengths: the padded slots of the reconstruction are never read (rec_loss goes by the same lengths)
+        return ops.rbf_deinterp(v, raw_input, self.kernel, self.interp_t, lengths, prefix_only=bool(prefix_only) and lengths is not None)

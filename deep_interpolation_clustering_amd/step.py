@@ -143,8 +143,12 @@ class Stepper:
 
     def _step_eager(self, x, ob, padding_mask, lengths=None, **kw):
         self.flat.zero_grad()
-        losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
-        losses['loss'].backward()
+        self.model.internal_step = True          # the reconstruction stays inside this step: its padded slots need not be written
+        try:
+            losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
+            losses['loss'].backward()
+        finally:
+            self.model.internal_step = False
         self.flat.all_reduce_grads()
         if self._fused_tail:
             gnorm, coef = self.flat.clip_coef(self.args.grad_clip)

@@ -109,10 +109,13 @@ int dic_sci_cci_bwd_packed(const void* grad_packed, int xw, const float* saved, 
  *   v (B,C,R) = compress_fc output;  y (B,C,T) OVERWRITTEN (0 in masked slots).
  * Limits: C<=16, R<=64.  * v_time_major != 0: v (and grad_v) are laid out (R,B,C) -- the row order TimeDistributed(CompressFC) produces them in on the
  * decoder's (R,B,.) output -- instead of (B,C,R): no transposing copy between the FC head and this kernel.
+  * norm (optional, saved for the backward) = 1 / (sum_r phi + 1e-10) per valid slot.  prefix_only != 0 (with lengths): only the first
+ * n slots of each row of y / norm (dic_masked_sse_bwd: of grad_rec) are written -- the training step never reads the padding, which
+ * is half of the 96-slot rows at ~50 observations per channel; with 0 the padding is written as zeros, as upstream's `* mask` does.
  */
 int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
-                const float* rbf_kernel, const float* v, int v_time_major, float* y, float* norm /* (B,C,T) or NULL: sum_r phi,
-                saved for the backward */, dic_stream_t stream);
+                const float* rbf_kernel, const float* v, int v_time_major, float* y, float* norm /* (B,C,T) or NULL: saved for the
+                backward */, int prefix_only, dic_stream_t stream);
 
 /* grad_y (B,C,T) -> grad_v (B,C,R), grad_rbf_kernel (C); both OVERWRITTEN.  y, norm: forward outputs.
  * Masks are binary upstream; a non-zero mask value is treated as 1. */
@@ -131,7 +134,7 @@ int dic_masked_sse_fwd(const float* ob, const float* rec, const float* mask, con
 /* grad_rec = grad_loss[0] * 2*m*(rec*m-ob*m)/sse_count[1]   (all device pointers). */
 int dic_masked_sse_bwd(const float* ob, const float* rec, const float* mask, const int32_t* lengths,
                        int B, int C, int T, const float* sse_count, const float* grad_loss,
-                       float* grad_rec, dic_stream_t stream);
+                       float* grad_rec, int prefix_only, dic_stream_t stream);
 
 /* ------------------------------------------------------------------ k3: DEC ---------------
  * Replaces ClusterAssignment.forward (dec.py:49-63).

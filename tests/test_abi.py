@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.dic_dec_fwd(None, None, 8, 256, 64, 1.0, None, None, None, None, 0, None) == -2    # K > 32
     assert lib.dic_sci_cci_fwd(None, None, 8, 6, 96, 24, None, None, None, None, None, None) == -1
     assert lib.dic_kmeans_lloyd_iter(None, None, 0, 256, 4, 1, None, None, None, None, 0, None) == -1
-    assert lib.dic_rbf_fwd(None, None, 8, 40, 96, 24, None, None, None, 0, None, None, None) == -2    # C > 16
+    assert lib.dic_rbf_fwd(None, None, 8, 40, 96, 24, None, None, None, 0, None, None, 0, None) == -2    # C > 16
 
 
 def test_workspace_queries(lib):
