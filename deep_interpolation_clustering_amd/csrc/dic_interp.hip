@@ -126,12 +126,14 @@ __device__ unsigned long long dic_k1_stamps[64][8];
 #endif
 
 // S = lanes that split one (row, grid point) item; U = unroll of the streaming loops.
-template <bool RAGGED, int S>
+// CT / RT: compile-time channel / grid-point counts (0 = run time): the flat-index decodes (/ R, / C, / (R * C) ...) of every phase
+// become multiply-shifts for the reference's shapes.
+template <bool RAGGED, int S, int CT, int RT>
 __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
     constexpr int U = S >= 4 ? 1 : 4 / S;
     constexpr int LOGS = S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : S == 8 ? 3 : 4;
     extern __shared__ __align__(16) float smem[];
-    const int C = a.C, R = a.R, E = a.E, Tcap = a.Tcap;
+    const int C = CT ? CT : a.C, R = RT ? RT : a.R, E = a.E, Tcap = a.Tcap;
     const InterpLayout L = interp_layout(E, C, R, Tcap);
     const int stride = L.stride;
     int* cnt = reinterpret_cast<int*>(smem + L.cnt);
@@ -466,9 +468,11 @@ __device__ float cci_backward_lds(float* sm, const BwdLayout& L, int Ev, int C, 
 }
 
 // Fused backward: grad_out (B,R,3C) + saved (B,7,C,R) -> per-block partials [C | C*C].
+template <int CT, int RT>
 __global__ __launch_bounds__(kBlock) void sci_cci_bwd_kernel(const float* grad_out, const __bf16* grad_packed, int xw,
-                                                            const float* saved, const float* cci_kernel, int B, int C, int R, int E,
+                                                            const float* saved, const float* cci_kernel, int B, int C_, int R_, int E,
                                                             int nblk, float* partials) {
+    const int C = CT ? CT : C_, R = RT ? RT : R_;
     extern __shared__ __align__(16) float smem[];
     const BwdLayout L = bwd_layout(E, C, R);
     const int tid = threadIdx.x, CR = C * R;
@@ -605,7 +609,12 @@ static int interp_fwd_launch(InterpArgs a, bool ragged, hipStream_t st) {
     const InterpLayout L = interp_layout(a.E, a.C, a.R, a.Tcap);
     const int grid = (a.B + a.E - 1) / a.E;
     const size_t lds = (size_t)L.total_words * 4;
-#define DIC_LAUNCH_FWD(RG, SS) hipLaunchKernelGGL((sci_cci_fwd_kernel<RG, SS>), dim3(grid), dim3(kBlock), lds, st, a)
+#define DIC_LAUNCH_FWD(RG, SS)                                                                                                  \
+    do {                                                                                                                       \
+        if (a.C == 6 && a.R == 24) hipLaunchKernelGGL((sci_cci_fwd_kernel<RG, SS, 6, 24>), dim3(grid), dim3(kBlock), lds, st, a);        \
+        else if (a.C == 12 && a.R == 24) hipLaunchKernelGGL((sci_cci_fwd_kernel<RG, SS, 12, 24>), dim3(grid), dim3(kBlock), lds, st, a); \
+        else hipLaunchKernelGGL((sci_cci_fwd_kernel<RG, SS, 0, 0>), dim3(grid), dim3(kBlock), lds, st, a);                                \
+    } while (0)
 #define DIC_LAUNCH_FWD_S(RG)                     \
     switch (S) {                                 \
         case 1: DIC_LAUNCH_FWD(RG, 1); break;    \
@@ -694,8 +703,15 @@ static int sci_cci_bwd_launch(const float* grad_out, const void* grad_packed, in
     DIC_REQUIRE(workspace_bytes >= (size_t)nblk * (C + C * C) * sizeof(float), DIC_ERR_WORKSPACE,
                 "sci_cci_bwd: workspace %zu B too small", workspace_bytes);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sci_cci_bwd_kernel, dim3(nblk), dim3(kBlock), lds, st, grad_out, (const __bf16*)grad_packed, xw, saved, cci_kernel,
-                       B, C, R, E, nblk, (float*)workspace);
+    if (C == 6 && R == 24)
+        hipLaunchKernelGGL((sci_cci_bwd_kernel<6, 24>), dim3(nblk), dim3(kBlock), lds, st, grad_out, (const __bf16*)grad_packed, xw, saved, cci_kernel,
+                           B, C, R, E, nblk, (float*)workspace);
+    else if (C == 12 && R == 24)
+        hipLaunchKernelGGL((sci_cci_bwd_kernel<12, 24>), dim3(nblk), dim3(kBlock), lds, st, grad_out, (const __bf16*)grad_packed, xw, saved, cci_kernel,
+                           B, C, R, E, nblk, (float*)workspace);
+    else
+        hipLaunchKernelGGL((sci_cci_bwd_kernel<0, 0>), dim3(nblk), dim3(kBlock), lds, st, grad_out, (const __bf16*)grad_packed, xw, saved, cci_kernel,
+                           B, C, R, E, nblk, (float*)workspace);
     const int n = C + C * C;
     hipLaunchKernelGGL(interp_bwd_finalize, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)workspace, nblk, C,
                        sci_kernel, grad_sci_kernel, cci_kernel ? grad_cci_kernel : nullptr);

@@ -25,9 +25,12 @@ struct RbfArgs {
 
 __host__ __device__ inline int rbf_fwd_words(int E, int C, int R) { return E * C * R + R + C + E * C; }
 
+// CT / RT: compile-time channel / grid-point counts (0 = run time).  The kernels decode (encounter, channel, grid point, slot) from flat
+// indices everywhere; with the reference's shapes (C = 6 or 12, R = 24) as constants those divisions become multiply-shifts.
+template <int CT, int RT>
 __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
     extern __shared__ __align__(16) float smem[];
-    const int C = a.C, R = a.R, T = a.T, E = a.E;
+    const int C = CT ? CT : a.C, R = RT ? RT : a.R, T = a.T, E = a.E;
     float* vs = smem;                  // [E][C][R]
     float* refg = vs + E * C * R;      // [R]
     float* nbeta = refg + R;           // [C]  -beta*log2(e)
@@ -111,12 +114,12 @@ __host__ __device__ inline RbfBwdLayout rbf_bwd_layout(int E, int C, int R, int 
     return L;
 }
 
-template <int S>
+template <int S, int CT, int RT>
 __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
     constexpr int U = S >= 4 ? 1 : 4 / S;
     constexpr int LOGS = S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : S == 8 ? 3 : 4;
     extern __shared__ __align__(16) float smem[];
-    const int C = a.C, R = a.R, T = a.T, E = a.E;
+    const int C = CT ? CT : a.C, R = RT ? RT : a.R, T = a.T, E = a.E;
     const RbfBwdLayout L = rbf_bwd_layout(E, C, R, T);
     const int stride = L.stride;
     int* cnt = reinterpret_cast<int*>(smem + L.cnt);
@@ -333,8 +336,11 @@ int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int
     RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm, (prefix_only && lengths) ? 1 : 0, v_time_major != 0};
     const int per_enc = rbf_fwd_words(2, C, R) - rbf_fwd_words(1, C, R);
     a.E = rbf_tile(B, per_enc, rbf_fwd_words(1, C, R) - per_enc, 32 * 1024);
-    hipLaunchKernelGGL(rbf_fwd_kernel, dim3((B + a.E - 1) / a.E), dim3(kBlock), (size_t)rbf_fwd_words(a.E, C, R) * 4,
-                       (hipStream_t)stream, a);
+    const dim3 grid((B + a.E - 1) / a.E);
+    const size_t lds = (size_t)rbf_fwd_words(a.E, C, R) * 4;
+    if (C == 6 && R == 24) hipLaunchKernelGGL((rbf_fwd_kernel<6, 24>), grid, dim3(kBlock), lds, (hipStream_t)stream, a);
+    else if (C == 12 && R == 24) hipLaunchKernelGGL((rbf_fwd_kernel<12, 24>), grid, dim3(kBlock), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((rbf_fwd_kernel<0, 0>), grid, dim3(kBlock), lds, (hipStream_t)stream, a);
     return check_launch("rbf_fwd");
 }
 
@@ -380,11 +386,17 @@ int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int
     }
     hipStream_t st = (hipStream_t)stream;
     switch (a.S) {
-        case 1: hipLaunchKernelGGL(rbf_bwd_kernel<1>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(rbf_bwd_kernel<2>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
-        case 4: hipLaunchKernelGGL(rbf_bwd_kernel<4>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
-        case 8: hipLaunchKernelGGL(rbf_bwd_kernel<8>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
-        default: hipLaunchKernelGGL(rbf_bwd_kernel<16>, dim3(a.nblk), dim3(kBlock), lds, st, a); break;
+#define DIC_RBF_BWD(SS)                                                                                                   \
+        if (C == 6 && R == 24) hipLaunchKernelGGL((rbf_bwd_kernel<SS, 6, 24>), dim3(a.nblk), dim3(kBlock), lds, st, a);       \
+        else if (C == 12 && R == 24) hipLaunchKernelGGL((rbf_bwd_kernel<SS, 12, 24>), dim3(a.nblk), dim3(kBlock), lds, st, a); \
+        else hipLaunchKernelGGL((rbf_bwd_kernel<SS, 0, 0>), dim3(a.nblk), dim3(kBlock), lds, st, a);                          \
+        break;
+        case 1: DIC_RBF_BWD(1)
+        case 2: DIC_RBF_BWD(2)
+        case 4: DIC_RBF_BWD(4)
+        case 8: DIC_RBF_BWD(8)
+        default: DIC_RBF_BWD(16)
+#undef DIC_RBF_BWD
     }
     hipLaunchKernelGGL(rbf_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)workspace, a.nblk, C, rbf_kernel,
                        grad_rbf_kernel);
