@@ -87,6 +87,7 @@ SIGNATURES = {
     'dic_grad_norm_clip': (_i, [_p, C.c_int64, _f, _p, _p, _sz, _p]),
     'dic_kmeans_pp_workspace': (_sz, [_i, _i]),
     'dic_kmeans_pp_candidates': (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    'dic_kmeans_pp_candidates_rows': (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _sz, _p]),
 }
 
 

@@ -103,6 +103,7 @@ class FakeDetFc(_Head):
 class NetBase(nn.Module):
     clustering = False
     internal_step = False      # set by step.Stepper around its own forward + loss + backward (see forward / rec_loss)
+    on_decoder_side_grads = None      # callable (set by step.Stepper when sharded): every gradient behind the encoder output is complete
 
     def __init__(self, args, device):
         super().__init__()
@@ -176,6 +177,9 @@ class NetBase(nn.Module):
                 context = context[:, :B]
                 hidden, cell = (hidden[:B], cell[:B]) if bm else (hidden[:, :B].contiguous(), cell[:, :B].contiguous())
         cat_hidden = z_all[:B]
+        if self.on_decoder_side_grads is not None and context.requires_grad:
+            cb = self.on_decoder_side_grads
+            context.register_hook(lambda g: cb())           # fires when the backward has passed the decoder, its head and the latent heads
         y, _ = self.decoder(context, hidden, cell, bm) if bm else self.decoder(context, hidden, cell)
         # (B,C,T).  Inside step.Stepper's optimisation step (`internal_step`: the reconstruction is consumed by rec_loss alone and never
         # handed out) only the observed slots are materialised; every other caller gets zeros in the padding, as upstream's `* mask`

@@ -66,18 +66,36 @@ class TrainerBase(object):
         return {'training': self.train_dl, 'validation': self.valid_dl, 'testing': self.test_dl}.get(cohort)
 
     def _eval_dl(self, cohort):
-        """Loader for evaluation / feature passes.  When the training loader is sharded over ranks (one process per GPU),
-        feature dumps, the k-means initialisation and label-change statistics still need EVERY encounter on every rank: an
-        unsharded, unshuffled loader over the same device-resident cohort is used instead (identical work and results on all
-        ranks, so the collectives inside the loss operators stay matched)."""
+        """Loader for evaluation / feature passes.  When the job is sharded over ranks (one process per GPU) the pass is sharded
+        too: an unshuffled loader over the same device-resident cohort gives every rank its contiguous slice of each batch (no
+        encounter dropped: a tail batch too small to shard joins the previous one).  The loss operators all-reduce their batch
+        statistics, so every rank logs the global-batch metrics; what a caller needs in full (latents for k-means, predicted
+        labels, the feature dumps) is assembled by ``_all_rows`` -- one collective per tensor and pass instead of P-fold
+        redundant evaluation."""
         dl = self._get_dl(cohort)
-        if getattr(dl, 'world', 1) > 1:
-            cache = self.__dict__.setdefault('_full_loaders', {})
+        if dist.is_sharded() and hasattr(dl, 'ds'):
+            cache = self.__dict__.setdefault('_eval_loaders', {})
             if cohort not in cache:
                 from .dataloader import DeviceLoader
-                cache[cohort] = DeviceLoader(dl.ds, dl.batch_size, False, dl.device, seed=0, shard=False)
+                cache[cohort] = DeviceLoader(dl.ds, dl.batch_size, False, dl.device, seed=0, shard=True, keep_every_row=True)
             return cache[cohort]
         return dl
+
+    def _all_rows(self, local, dl):
+        """Rows every rank produced over one pass of the sharded, unshuffled loader ``dl`` -> the full tensor, in dataset order, on
+        every rank.  One sum all-reduce of a zero-filled buffer (disjoint rows: the sum is the concatenation; works on RCCL and on
+        gloo alike)."""
+        if getattr(dl, 'world', 1) <= 1:
+            return local
+        rows = dl.shard_rows().to(local.device)
+        if rows.numel() != local.shape[0]:
+            raise RuntimeError(f'sharded pass produced {local.shape[0]} rows, the loader promises {rows.numel()}')
+        kind = local.dtype
+        work = local.to(torch.int32) if kind in (torch.bool, torch.uint8, torch.int8, torch.int16) else local
+        full = torch.zeros((len(dl.ds),) + tuple(local.shape[1:]), dtype=work.dtype, device=local.device)
+        full[rows] = work
+        dist.all_reduce_sum_(full)
+        return full.to(kind)
 
     def _to_device(self, sample):
         return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in sample.items()}
@@ -174,15 +192,25 @@ class TrainerBase(object):
                         self.summary.add_summary(self.epoch * total + i_batch, scope='{}_batch'.format(scope), **now)
         metrics = {'scope': scope}
         metrics.update({k: float(v) / max(n_batches, 1) for k, v in sums.items()})
+        self._last_eval_dl = dl
         return metrics, ob_pred_lst
 
-    def merge_ob_pred(self, ob_pred_lst):
-        """Concatenate the per-batch records; tensors leave the device here, once per key."""
+    def merge_ob_pred(self, ob_pred_lst, dl=None):
+        """Concatenate the per-batch records; tensors leave the device here, once per key.  After a sharded evaluation pass
+        (``dl``: its loader, default the last one used) every key is first assembled over ranks, in dataset order."""
+        dl = dl if dl is not None else getattr(self, '_last_eval_dl', None)
+        sharded = getattr(dl, 'world', 1) > 1
         merged = {}
         for k in (ob_pred_lst[0].keys() if ob_pred_lst else ()):
             vals = [d[k] for d in ob_pred_lst]
             if torch.is_tensor(vals[0]):
-                merged[k] = torch.cat([v.float() for v in vals], dim=0).cpu().numpy()
+                t = torch.cat([v.float() for v in vals], dim=0)
+                merged[k] = (self._all_rows(t, dl) if sharded else t).cpu().numpy()
+            elif sharded and k == 'encounter_id':
+                merged[k] = np.asarray(dl.ids)                   # the unshuffled pass covers the cohort in dataset order
+            elif sharded:
+                local = torch.as_tensor(np.concatenate([np.asarray(v) for v in vals], axis=0), device=self.device)
+                merged[k] = self._all_rows(local, dl).cpu().numpy()
             else:
                 merged[k] = np.concatenate([np.asarray(v) for v in vals], axis=0)
         return merged

@@ -47,9 +47,11 @@ class TrainerCluster(TrainerBase):
 
     def _latents(self, cohort, denoise=False):
         """Feature pass that keeps the latents on the device: (hidden (N,256) cuda tensor, metrics)."""
-        metrics, recs = self.eval_one_epoch(COHORT2SCOPE[cohort], self._eval_dl(cohort), denoise)    # all encounters on every rank
+        dl = self._eval_dl(cohort)                                    # sharded over ranks when there are several
+        metrics, recs = self.eval_one_epoch(COHORT2SCOPE[cohort], dl, denoise)
         logger.info('{}, {}'.format(COHORT2SCOPE[cohort], format_metric_dict(metrics)))
-        return torch.cat([r['hidden'].float() for r in recs], dim=0), recs
+        hidden = torch.cat([r['hidden'].float() for r in recs], dim=0)
+        return self._all_rows(hidden, dl), recs                       # ONE collective: every rank gets all latents, in dataset order
 
     def generate_pretrain_feat(self, cohort, denoise=False):
         hidden, recs = self._latents(cohort, denoise)
@@ -59,7 +61,7 @@ class TrainerCluster(TrainerBase):
         """argmax_j q_ij on the validation cohort and the fraction of labels that changed (clustering_trainer.py:473-484)."""
         metrics, recs = self.eval_one_epoch(scope, dl, denoise=denoise)
         logger.info('{}'.format(format_metric_dict(metrics)))
-        cluster_pred = torch.cat([r['cluster_pred'] for r in recs], dim=0).argmax(dim=1)
+        cluster_pred = self._all_rows(torch.cat([r['cluster_pred'] for r in recs], dim=0).argmax(dim=1), dl)    # labels of ALL encounters
         if prev_pred is None:
             delta = 1.0
         else:
@@ -94,7 +96,7 @@ class TrainerCluster(TrainerBase):
             for epoch in range(1, args.max_epochs):
                 train_metrics = self.train_one_epoch(self.train_dl, denoise=args.denoise)
                 logger.info('==> Epoch: {}, Train, {}'.format(epoch, format_metric_dict(train_metrics)))
-                delta, valid_pred, valid_metrics = self.generate_pred_cluster('valid', self.valid_dl, valid_prev)
+                delta, valid_pred, valid_metrics = self.generate_pred_cluster('valid', self._eval_dl('validation'), valid_prev)
                 logger.info('Epoch: {}: valid delta of cluster label change: {}'.format(epoch, delta))
                 valid_metrics['delta'] = delta
                 self.aly_pred('valid', valid_metrics)

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void inertia_kernel(const float* mind_all, int
 }
 
 // k-means++ inner step: exact (f64) squared distances to L candidate rows, min with `closest`, potential.
-__global__ __launch_bounds__(kLatBlock) void kmeans_pp_kernel(const float* X, int N, int D, const int64_t* cand, int L,
+__global__ __launch_bounds__(kLatBlock) void kmeans_pp_kernel(const float* X, int N, int D, int row_lo, int row_hi, const int64_t* cand, int L,
                                                              int group, const float* closest_all, float* dist_out,
                                                              double* ppart) {
     __shared__ double red[kLatWaves];
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kLatBlock) void kmeans_pp_kernel(const float* X, in
     const float4 c = load_row4(X, cand[l], D, lane);
     double pot = 0.0;
     const long nw = (long)gridDim.x * kLatWaves;
-    for (long row = (long)blockIdx.x * kLatWaves + wave; row < N; row += nw) {
+    for (long row = (long)row_lo + (long)blockIdx.x * kLatWaves + wave; row < row_hi; row += nw) {      // this rank's rows of the (.,N) arrays
         const float4 x = load_row4(X, row, D, lane);
         const double d0 = (double)x.x - c.x, d1 = (double)x.y - c.y, d2 = (double)x.z - c.z, d3 = (double)x.w - c.w;
         const double dist = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
@@ -799,20 +799,33 @@ int dic_kmeans_predict(const float* X, int N, int D, int K, int n_runs, const fl
     return check_launch("kmeans_predict");
 }
 
-int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, int L, int group,
-                             const float* closest, float* dist_out, double* pot_out, void* workspace,
-                             size_t workspace_bytes, dic_stream_t stream) {
+static int pp_candidates(const float* X, int N, int D, int row_lo, int row_hi, const int64_t* cand, int L, int group,
+                         const float* closest, float* dist_out, double* pot_out, void* workspace,
+                         size_t workspace_bytes, dic_stream_t stream) {
     int rc = latent_check("kmeans_pp_candidates", N, D, 1);
     if (rc) return rc;
     DIC_REQUIRE(L > 0 && L <= 65535 && group > 0 && L % group == 0, DIC_ERR_INVALID_ARG, "kmeans_pp_candidates: L=%d group=%d", L, group);
+    DIC_REQUIRE(0 <= row_lo && row_lo < row_hi && row_hi <= N, DIC_ERR_INVALID_ARG, "kmeans_pp_candidates: rows [%d, %d) of %d", row_lo, row_hi, N);
     DIC_REQUIRE(X && cand && closest && dist_out && pot_out && workspace, DIC_ERR_INVALID_ARG, "kmeans_pp_candidates: NULL pointer");
-    const int nblk = km_blocks(N);
+    const int nblk = km_blocks(row_hi - row_lo);
     DIC_REQUIRE(workspace_bytes >= (size_t)L * nblk * sizeof(double), DIC_ERR_WORKSPACE, "kmeans_pp_candidates: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(kmeans_pp_kernel, dim3(nblk, L), dim3(kLatBlock), 0, st, X, N, D, cand, L, group, closest, dist_out,
+    hipLaunchKernelGGL(kmeans_pp_kernel, dim3(nblk, L), dim3(kLatBlock), 0, st, X, N, D, row_lo, row_hi, cand, L, group, closest, dist_out,
                        (double*)workspace);
     hipLaunchKernelGGL(kmeans_pp_finalize, dim3((L + 31) / 32), dim3(256), 0, st, (const double*)workspace, nblk, L, pot_out);
     return check_launch("kmeans_pp_candidates");
+}
+
+int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, int L, int group,
+                             const float* closest, float* dist_out, double* pot_out, void* workspace,
+                             size_t workspace_bytes, dic_stream_t stream) {
+    return pp_candidates(X, N, D, 0, N, cand, L, group, closest, dist_out, pot_out, workspace, workspace_bytes, stream);
+}
+
+int dic_kmeans_pp_candidates_rows(const float* X, int N, int D, int row_lo, int row_hi, const int64_t* cand, int L, int group,
+                                  const float* closest, float* dist_out, double* pot_out, void* workspace,
+                                  size_t workspace_bytes, dic_stream_t stream) {
+    return pp_candidates(X, N, D, row_lo, row_hi, cand, L, group, closest, dist_out, pot_out, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

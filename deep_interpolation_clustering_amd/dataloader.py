@@ -156,7 +156,7 @@ class DeviceLoader:
 
     When the job is sharded (one process per GPU) each rank iterates its contiguous shard of every global batch."""
 
-    def __init__(self, ds: DataSet, batch_size, shuffle, device, drop_last=False, seed=None, shard=True):
+    def __init__(self, ds: DataSet, batch_size, shuffle, device, drop_last=False, seed=None, shard=True, keep_every_row=False):
         from . import dist
         self.ds, self.batch_size, self.shuffle, self.device, self.drop_last = ds, int(batch_size), shuffle, device, drop_last
         self.C = ds.num_features
@@ -175,6 +175,8 @@ class DeviceLoader:
         self.host_gen.manual_seed(seed)
         self.rank, self.world = (dist.rank(), dist.world_size()) if shard else (0, 1)
         self.dataset = ds
+        # evaluation / feature passes must see every encounter: a trailing batch too small to shard is merged into the one before it
+        self.keep_every_row = bool(keep_every_row)
         if min(len(ds), self.batch_size) < self.world:
             raise ValueError(f'DeviceLoader: batches of {min(len(ds), self.batch_size)} rows cannot be sharded over {self.world} ranks')
 
@@ -185,7 +187,26 @@ class DeviceLoader:
         # a trailing batch with fewer rows than ranks would leave some rank an EMPTY shard (its kernels raise while the other ranks
         # wait in the all-reduces): it is dropped, identically on every rank
         keep_tail = tail >= self.world and not self.drop_last
+        if self.keep_every_row and full == 0:
+            return 1
         return full + (1 if keep_tail else 0)
+
+    def _bounds(self, b):
+        """[lo, hi) of global batch b in the epoch's order, and this rank's [lo, hi) inside it."""
+        n, nb = len(self.ds), len(self)
+        lo = b * self.batch_size
+        hi = n if (b == nb - 1 and self.keep_every_row) else min((b + 1) * self.batch_size, n)
+        if self.world > 1:
+            m = hi - lo
+            return lo, hi, lo + (m * self.rank) // self.world, lo + (m * (self.rank + 1)) // self.world
+        return lo, hi, lo, hi
+
+    def shard_rows(self):
+        """Dataset rows this rank yields over one UNSHUFFLED pass, in iteration order (the scatter index of trainers' row gather)."""
+        if self.shuffle:
+            raise ValueError('shard_rows: the loader shuffles')
+        parts = [torch.arange(*self._bounds(b)[2:]) for b in range(len(self))]
+        return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64)
 
     def _noise(self, t, mask, std):
         return (t + torch.randn(t.shape, device=self.device, generator=self.gen) * std) * mask
@@ -210,10 +231,7 @@ class DeviceLoader:
         order = order_h.to(self.device)
         C = self.C
         for b in range(len(self)):
-            lo, hi = b * self.batch_size, min((b + 1) * self.batch_size, n)
-            if self.world > 1:
-                m = hi - lo
-                lo, hi = lo + (m * self.rank) // self.world, lo + (m * (self.rank + 1)) // self.world
+            _, _, lo, hi = self._bounds(b)
             idx, idx_h = order[lo:hi], order_h[lo:hi].numpy()
             rows = self.data.index_select(0, idx)
             ob, mask, ts, ae = rows[:, 0:C], rows[:, C:2 * C], rows[:, 2 * C:3 * C], rows[:, 3 * C:4 * C]

@@ -108,6 +108,7 @@ class FlatParams:
         self._reached = [False] * len(self.params)
         self._mask_key, self._mask = None, None
         self._norm_ws = None
+        self._split, self._split_index, self._tail_work = None, 0, None
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -154,10 +155,38 @@ class FlatParams:
         for p in self.params:
             p._dic_grad_written = False
 
+    # ---- gradient exchange.  The bucket is reduced in two pieces so that the larger one travels during the rest of the backward:
+    # everything registered from `split_at` on (decoder LSTM, de-interpolation head, auxiliary heads, centroids: 74 % of the
+    # bucket) is complete when the backward reaches the encoder -- begin_tail_reduce() is called there (a tensor hook the model
+    # places on the encoder output) -- and its all-reduce overlaps the encoder LSTM / interpolation backward.
+    def set_split(self, first_tail_param):
+        """``first_tail_param``: the first parameter (in registration order) of the piece that finishes early."""
+        o = 0
+        for i, p in enumerate(self.params):
+            if p is first_tail_param:
+                self._split, self._split_index = o, i
+                return
+            o += p.numel()
+        raise ValueError('set_split: not a parameter of this bucket')
+
+    def begin_tail_reduce(self):
+        """Start the asynchronous all-reduce of grad[split:] -- only if every parameter of that piece has its gradient already."""
+        if not is_sharded() or self._split is None or self._tail_work is not None:
+            return
+        done = all(r or getattr(p, '_dic_grad_written', False) for r, p in zip(self._reached[self._split_index:], self.params[self._split_index:]))
+        if done and self._split < self.grad.numel():
+            self._tail_work = td.all_reduce(self.grad[self._split:], op=td.ReduceOp.SUM, async_op=True)
+
     def all_reduce_grads(self):
         """Sum over ranks: each rank's loss is already normalised by GLOBAL batch statistics, so
         the sum (not the mean) of rank gradients is the gradient of the global-batch loss."""
-        all_reduce_sum_(self.grad)
+        if self._tail_work is not None:
+            if self._split > 0:
+                all_reduce_sum_(self.grad[:self._split])
+            self._tail_work.wait()
+            self._tail_work = None
+        else:
+            all_reduce_sum_(self.grad)
 
     def clip_coef(self, max_norm: float):
         """(total norm, clip coefficient) of torch.nn.utils.clip_grad_norm_ (pretrain_trainer.py:228), both on the device."""

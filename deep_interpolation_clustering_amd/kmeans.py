@@ -136,7 +136,7 @@ def lloyd_sharded(X, xnorm, centers, tol, max_iter):
     return labels, inertia, status
 
 
-def _pp_init(X, K, n_runs, rs, after_draws=None):
+def _pp_init(X, K, n_runs, rs, after_draws=None, shard=False):
     """k-means++ (greedy, 2+log K local trials) for n_runs restarts at once.  Every random number is
     drawn from ``rs`` up front in scikit-learn's order (per restart: one ``choice`` then K-1
     ``uniform(size=trials)``), which is possible because the Lloyd runs consume no randomness."""
@@ -161,8 +161,22 @@ def _pp_init(X, K, n_runs, rs, after_draws=None):
     closest = torch.empty((n_runs, Nn), dtype=torch.float32, device=dev)
     pot = torch.empty(n_runs, dtype=torch.float64, device=dev)
     ws = _ws(L.dic_kmeans_pp_workspace(Nn, n_runs * trials), dev)
-    N.check(L.dic_kmeans_pp_candidates(N.ptr(X), Nn, D, N.ptr(centers_idx[:, 0].contiguous()), n_runs, 1, N.ptr(inf),
-                                       N.ptr(closest), N.ptr(pot), N.ptr(ws), ws.numel(), st), 'dic_kmeans_pp_candidates')
+    lo, hi = dist.shard_bounds(Nn) if shard else (0, Nn)
+
+    def candidates(cand, n_cand, group, closest_in, dist_out, pot_out):
+        """Squared distances to the candidate rows, min with the running closest distance, potentials.  With the points sharded
+        over ranks each rank evaluates its row range and the (L,N) distances / L potentials are summed over ranks (disjoint rows:
+        the sum of the zero-initialised buffers is the concatenation) -- every rank then draws the same next centre."""
+        if shard:
+            dist_out.zero_()
+            N.check(L.dic_kmeans_pp_candidates_rows(N.ptr(X), Nn, D, lo, hi, N.ptr(cand), n_cand, group, N.ptr(closest_in), N.ptr(dist_out),
+                                                    N.ptr(pot_out), N.ptr(ws), ws.numel(), st), 'dic_kmeans_pp_candidates_rows')
+            dist.all_reduce_sum_(dist_out)
+            dist.all_reduce_sum_(pot_out)
+        else:
+            N.check(L.dic_kmeans_pp_candidates(N.ptr(X), Nn, D, N.ptr(cand), n_cand, group, N.ptr(closest_in), N.ptr(dist_out), N.ptr(pot_out),
+                                               N.ptr(ws), ws.numel(), st), 'dic_kmeans_pp_candidates')
+    candidates(centers_idx[:, 0].contiguous(), n_runs, 1, inf, closest, pot)
     dist_c = torch.empty((n_runs * trials, Nn), dtype=torch.float32, device=dev)
     pot_c = torch.empty(n_runs * trials, dtype=torch.float64, device=dev)
     ar = torch.arange(n_runs, device=dev)
@@ -170,9 +184,7 @@ def _pp_init(X, K, n_runs, rs, after_draws=None):
         cur = pot.float().double()                                   # current_pot is an f32 scalar upstream
         cum = torch.cumsum(closest, dim=1, dtype=torch.float64)      # stable_cumsum(sample_weight * closest)
         cand = torch.searchsorted(cum, u[:, c - 1] * cur[:, None]).clamp_(max=Nn - 1)      # (n_runs, trials)
-        N.check(L.dic_kmeans_pp_candidates(N.ptr(X), Nn, D, N.ptr(cand.contiguous()), n_runs * trials, trials,
-                                           N.ptr(closest), N.ptr(dist_c), N.ptr(pot_c), N.ptr(ws), ws.numel(), st),
-                'dic_kmeans_pp_candidates')
+        candidates(cand.contiguous(), n_runs * trials, trials, closest, dist_c, pot_c)
         best = torch.argmin(pot_c.view(n_runs, trials), dim=1)
         centers_idx[:, c] = cand[ar, best]
         closest = dist_c.view(n_runs, trials, Nn)[ar, best].contiguous()
@@ -199,7 +211,8 @@ class KMeans:
         self.copy_x = copy_x
         self.algorithm = algorithm
         # (extra) one process per GPU: every rank passes the SAME X to fit(); the Lloyd iterations then run on this rank's row
-        # shard with one all-reduce of centroid partial sums per iteration (lloyd_sharded).  Seeding stays unsharded.
+        # shard with one all-reduce of centroid partial sums per iteration (lloyd_sharded), and the k-means++ candidate distances
+        # are evaluated per row shard too (the random draws stay replicated: same stream on every rank).
         self.shard_points = shard_points
         # (private) called once the fit has drawn its last random number (k-means++ draws everything up front): p2 uses it to start
         # drawing the next gap-statistic reference set on a worker thread while this fit's GPU work runs, in the same stream order
@@ -252,7 +265,7 @@ class KMeans:
                 raise ValueError(f'The shape of the initial centers {tuple(c0.shape)} does not match (n_clusters, n_features)')
             centers = _pad_features(c0 - mean)[None].contiguous()
         elif self.init == 'k-means++':
-            centers = _pp_init(Xc, K, n_init, rs, self._after_seeding).contiguous()
+            centers = _pp_init(Xc, K, n_init, rs, self._after_seeding, shard=self.shard_points and dist.is_sharded() and Nn >= dist.world_size()).contiguous()
         elif self.init == 'random':
             p = np.full(Nn, 1.0 / Nn)
             seeds = np.stack([rs.choice(Nn, size=K, replace=False, p=p) for _ in range(n_init)])

@@ -19,7 +19,7 @@ class Trainer(TrainerBase):
             for epoch in range(1, self.args.max_epochs):
                 train_metrics = self.train_one_epoch(self.train_dl, denoise=self.args.denoise)
                 logger.info('==> Epoch: {}, Train, {}'.format(epoch, format_metric_dict(train_metrics)))
-                valid_metrics, _ = self.eval_one_epoch('valid', self.valid_dl, denoise=self.args.denoise)
+                valid_metrics, _ = self.eval_one_epoch('valid', self._eval_dl('validation'), denoise=self.args.denoise)
                 verdict = self.aly_pred('valid', valid_metrics)
                 self.epoch += 1
                 if verdict['early_stop']:

@@ -54,6 +54,9 @@ class Stepper:
         if self._fused_tail:
             self.optimizer.bind(self.flat)
         self.autocast_dtype = autocast_dtype
+        if dist.is_sharded() and hasattr(model, 'decoder'):       # overlap the larger piece of the gradient all-reduce with the encoder backward
+            self.flat.set_split(next(model.decoder.parameters()))
+            model.on_decoder_side_grads = self.flat.begin_tail_reduce
         # hipGraph capture of the whole step (single-GPU): at the reference's batch size (256) the ~250 launches of a
         # step are launch-bound (2.5 ms); one graph replay runs them back to back.
         self.use_graphs = bool(use_graphs) and not dist.is_sharded()

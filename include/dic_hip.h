@@ -207,6 +207,12 @@ size_t dic_kmeans_pp_workspace(int N, int L);
 int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, int L, int group,
                              const float* closest, float* dist_out, double* pot_out,
                              void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* The same for the rows [row_lo, row_hi) only (points sharded over ranks): X, closest and dist_out keep their full
+ * (., N) shapes, only those columns are read / written, pot_out = the partial potential of the range (the caller sums dist_out
+ * and pot_out over ranks).  Candidate rows are still addressed in the full X. */
+int dic_kmeans_pp_candidates_rows(const float* X, int N, int D, int row_lo, int row_hi, const int64_t* cand, int L, int group,
+                                  const float* closest, float* dist_out, double* pot_out,
+                                  void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
 /* ------------------------------------------------------------------ bi-LSTM recurrence -----
  * Sequential half of one bidirectional torch.nn.LSTM layer with hidden size H = 128 (EncoderRNN /

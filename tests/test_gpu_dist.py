@@ -155,8 +155,9 @@ def _run_drivers(rank, world, port, base):
                    os.path.join(base, f'replica_r{rank}.pt'))
     ct.TrainerCluster.train = train_and_dump
     p3.main(a3)
-    import torch.distributed as td
-    td.destroy_process_group()
+    if world > 1:
+        import torch.distributed as td
+        td.destroy_process_group()
 
 
 def test_two_rank_drivers_keep_replicas_identical_and_dump_every_encounter(tmp_path):
@@ -175,6 +176,35 @@ def test_two_rank_drivers_keep_replicas_identical_and_dump_every_encounter(tmp_p
     assert feat['hidden'].shape == (400, 256) and len(set(feat['encounter_id'].tolist())) == 400
     pre = np.load(os.path.join(base, 'run/Results/Pretrain/out_feat/ae_mse/training.npy'), allow_pickle=True).item()
     assert pre['hidden'].shape == (400, 256)
+    # the evaluation / feature passes are SHARDED over the ranks and assembled by one collective per tensor: from the SAME checkpoints
+    # a single process must write the same dumps (the two-rank dumps are moved aside, p1 --mode eval regenerates them)
+    feat2 = os.path.join(base, 'run/Results/Pretrain/out_feat_2rank')
+    os.rename(os.path.join(base, 'run/Results/Pretrain/out_feat'), feat2)
+    mp.spawn(_run_p1_eval, args=(base,), nprocs=1, join=True)
+    for cohort in ('training', 'validation', 'testing'):
+        two = np.load(os.path.join(feat2, f'ae_mse/{cohort}.npy'), allow_pickle=True).item()
+        one = np.load(os.path.join(base, f'run/Results/Pretrain/out_feat/ae_mse/{cohort}.npy'), allow_pickle=True).item()
+        assert set(two.keys()) == set(one.keys())
+        # (a single process dumps the training cohort in its shuffled loader's order, as upstream does: align by encounter)
+        o2, o1 = np.argsort(two['encounter_id']), np.argsort(one['encounter_id'])
+        assert np.array_equal(two['encounter_id'][o2], one['encounter_id'][o1])
+        for k in one:
+            a, b_ = two[k][o2], one[k][o1]
+            if k in ('ob', 'padding_mask', 'timestamp', 'ae_mask', 'encounter_id'):
+                np.testing.assert_array_equal(a, b_, err_msg=f'{cohort}/{k}')                        # inputs: the same rows
+            else:
+                np.testing.assert_allclose(a, b_, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(b_).max())), err_msg=f'{cohort}/{k}')
+
+
+def _run_p1_eval(rank, base):
+    sys.path.insert(0, ROOT)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        os.environ.pop(k, None)
+    from deep_interpolation_clustering_amd import dataloader
+    from deep_interpolation_clustering_amd import p1_pretrain_main as p1
+    os.chdir(os.path.join(base, 'run'))
+    dataloader.BASE_PATH = base
+    p1.main(p1.get_arguments(COMMON + ['--mode', 'eval', '--loss', 'ae_mse']))
 
 
 def _run_kmeans(rank, world, port, out):
