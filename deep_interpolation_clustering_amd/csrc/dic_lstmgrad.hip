@@ -32,7 +32,12 @@ constexpr int H_PITCH = 2 * GH;           // 256
 constexpr int X_PITCH = 2 * XW;           // 64
 constexpr int LDS_DG = TR * DG_PITCH, LDS_H = TR * H_PITCH, LDS_X = TR * X_PITCH;
 constexpr int SLOT = LDS_DG + LDS_H + LDS_X;        // 45 056 B
-constexpr int DW_LDS = NBUF * SLOT;                 // 135 168 B: one workgroup per CU
+// the input gradient dX = dG . W_ih rides along (the library GEMM for it re-read the whole 1.6 GB dG): W_ih^T of this direction
+// sits in LDS ([19 input columns][512 gate rows], the 18 features + nothing else is ever read downstream), 16x16x32 MFMAs
+constexpr int WT_COLS = 19, WT_PITCH = 2 * G4 + 16;  // 1040 B rows: 16 lanes x 16 B reads spread over the banks
+constexpr int LDS_WT = WT_COLS * WT_PITCH;           // 19 760 B
+constexpr int LDS_RED = 2 * 4 * 1024;                // two parities x four 1-KiB partial tiles (k-halves are summed across wave pairs)
+constexpr int DW_LDS = NBUF * SLOT + LDS_WT + LDS_RED;   // 163 120 B of the CU's 163 840: one workgroup per CU
 constexpr int DW_OUT = 2 * G4 * NW;                 // outputs per partial: [dir][gate row][h cols | x cols]
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -84,8 +89,11 @@ struct DwArgs {
                            //                direction in [:H], slot R+1 h0 of the reverse direction in [H:] (zeros without an h0)
     const __bf16* x;       // (R*B, XW)      packed inputs
     float* partials;       // (gridDim.x, 2, 4H, NW) per-workgroup sums
+    const __bf16* wih;     // (2*4H, XW) packed input weights, or NULL: no input gradient wanted
+    __bf16* dxp;           // (2, R*B, XW) per-direction input gradients dG[d] . W_ih[d] (columns >= 19 are not written)
     int R, B;
 };
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
@@ -167,14 +175,42 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
         return __builtin_bit_cast(bf16x8, f);
     };
 
+    // ---- dX: this direction's W_ih^T -> LDS once; per tile, wave w multiplies quadrant (rows 16 (q >> 1).., input columns 16 (q & 1)..),
+    // q = w & 3, over half of the 512 gate columns (w >> 2); the two halves meet through LDS one tile later (no extra barrier)
+    unsigned char* wt = dwsm + NBUF * SLOT;
+    float* red = reinterpret_cast<float*>(wt + LDS_WT);
+    const bool want_dx = a.wih != nullptr;
+    if (want_dx) {
+        for (int i = tid; i < WT_COLS * G4; i += 512) {
+            const int xc = i / G4, k = i - xc * G4;
+            *reinterpret_cast<__bf16*>(wt + xc * WT_PITCH + k * 2) = a.wih[((size_t)dir * G4 + k) * XW + xc];
+        }
+    }
+    const int q4 = w & 3, rw = q4 >> 1, xcb = q4 & 1, khalf = w >> 2, li = lane & 15, kq4 = lane >> 4;
+    const int dxa_off = (16 * rw + li) * DG_PITCH + (khalf * 256 + 8 * kq4) * 2;
+    const int dxb_off = min(16 * xcb + li, WT_COLS - 1) * WT_PITCH + (khalf * 256 + 8 * kq4) * 2;
+    long prev_r0 = -1;
+    int parity = 0;
+    f32x4_t own_prev = {0.f, 0.f, 0.f, 0.f};
+    auto finish_dx = [&](int par, long r0p) {          // waves 0-3: add the other k-half (parked in LDS by waves 4-7), round, store the 16x16 tile
+        if (want_dx && khalf == 0 && r0p >= 0) {
+            const f32x4_t o = *reinterpret_cast<const f32x4_t*>(red + (par * 4 + q4) * 256 + lane * 4);
+            __bf16* dst = a.dxp + ((size_t)dir * nrows + r0p + 16 * rw + 4 * kq4) * XW + 16 * xcb + li;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(size_t)e * XW] = (__bf16)(o[e] + own_prev[e]);
+        }
+    };
+
     int tile = blockIdx.x, slot = 0;
     if (tile < ntiles) request(tile, 0);
     if (tile + nch < ntiles) request(tile + nch, 1);
     for (; tile < ntiles; tile += nch) {
         // this wave's DMA of the current tile has landed once at most the next tile's instructions are outstanding
-        if (tile + nch < ntiles) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // 6 = LDS-DMA instructions per wave and tile: 4 dG + 1 h + 1 x
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the dX stores of waves 0-3 are ordinary global stores issued after the DMAs they must not be confused with: up to 4 per tile)
+        if (tile + nch < ntiles) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");       // 6 = LDS-DMA instructions per wave and tile: 4 dG + 1 h + 1 x
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();              // ... and every other wave's; all waves are done reading the slot refilled next
+        finish_dx(parity ^ 1, prev_r0);            // the previous tile's input gradients (its partials were parked before this barrier)
         if (tile + 2 * nch < ntiles) request(tile + 2 * nch, slot == 0 ? 2 : slot - 1);
         unsigned char* base = dwsm + slot * SLOT;
         if ((long)tile * TR + TR > nrows) {        // the shifted last tile: its first rows were summed by the previous tile already
@@ -201,7 +237,25 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
                 for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfg, acc[mb][nb], 0, 0, 0);
             }
         }
+        if (want_dx) {       // D[row][input column] = sum over this wave's 256 gate columns of dG[row][k] W_ih[k][column]
+            f32x4_t dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(base + dxa_off + ks * 64);
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(wt + dxb_off + ks * 64);
+                dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, dacc, 0, 0, 0);
+            }
+            if (khalf) *reinterpret_cast<f32x4_t*>(red + (parity * 4 + q4) * 256 + lane * 4) = dacc;
+            else own_prev = dacc;
+            prev_r0 = min((long)tile * TR, nrows - TR);
+            parity ^= 1;
+        }
         slot = slot == NBUF - 1 ? 0 : slot + 1;
+    }
+    if (want_dx) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        finish_dx(parity ^ 1, prev_r0);
     }
     // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     float* o = a.partials + ((size_t)blockIdx.x * 2 + dir) * G4 * NW;
@@ -306,7 +360,7 @@ size_t dic_lstm_dw_workspace(int R, int B) {
     return (size_t)dw_chunks(R, B) * DW_OUT * sizeof(float);
 }
 
-int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, int R, int B, int H, int I, int Ip,
+int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, const void* wih, void* dx_parts, int R, int B, int H, int I, int Ip,
                 float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_dw: non-positive size");
     DIC_REQUIRE(H == GH, DIC_ERR_UNSUPPORTED, "lstm_dw: hidden size %d (compiled for %d)", H, GH);
@@ -326,7 +380,9 @@ int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, int R, int 
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    DwArgs a{(const __bf16*)dgx, (const __bf16*)out_ext, (const __bf16*)x, (float*)workspace, R, B};
+    DIC_REQUIRE((wih == nullptr) == (dx_parts == nullptr), DIC_ERR_INVALID_ARG, "lstm_dw: wih and dx_parts go together");
+    DIC_REQUIRE(!wih || I <= WT_COLS, DIC_ERR_UNSUPPORTED, "lstm_dw: the fused input gradient covers %d input columns, got %d", WT_COLS, I);
+    DwArgs a{(const __bf16*)dgx, (const __bf16*)out_ext, (const __bf16*)x, (float*)workspace, (const __bf16*)wih, (__bf16*)dx_parts, R, B};
     hipLaunchKernelGGL(lstm_dw_kernel, dim3(nch, 2), dim3(512), DW_LDS, st, a);
     hipLaunchKernelGGL(lstm_dw_finalize, dim3((DW_OUT + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, I, g,
                        accumulate ? 1.0f : 0.0f);

@@ -162,8 +162,11 @@ class _BiLstm(torch.autograd.Function):
             N.check(Lb.dic_lstm_bwd(N.ptr(whh_b), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
                                     R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), st), 'dic_lstm_bwd')
         dg2 = dgx.view(R * B, 8 * H)
+        use_dw = narrow and R * B >= 32                              # one-pass weight-gradient kernel (csrc/dic_lstmgrad.hip; it tiles the R*B rows by 32)
+        fuse_dx = use_dw and I <= 19 and any(ctx.needs_input_grad[6:])       # ... which then also forms dX = dG.W_ih per direction
+        dxp = torch.empty((2, R * B, Ip), device=dev, dtype=T) if (fuse_dx and ctx.needs_input_grad[0]) else None
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and dxp is None:
             dx = dg2 @ wih                                           # (R*B, Ip)
             if packed:
                 dx = dx.view(R, B, Ip)                               # consumed in this layout by ops._SciCciPacked.backward
@@ -174,11 +177,14 @@ class _BiLstm(torch.autograd.Function):
         if any(needs):
             sinks, accumulate = _grad_sinks(params, needs)
             gp = N.ptr_array(sinks)
-            if narrow and R * B >= 32:
-                # dW_ih and dW_hh of both directions from one pass over dG (csrc/dic_lstmgrad.hip; it tiles the R*B rows by 32)
+            if use_dw:
+                # dW_ih and dW_hh of both directions (and the per-direction dX) from one pass over dG
                 ws2 = torch.empty(max(16, Lb.dic_lstm_dw_workspace(R, B)), device=dev, dtype=torch.uint8)
-                N.check(Lb.dic_lstm_dw(N.ptr(dgx), N.ptr(out_ext), N.ptr(xb), R, B, H, I, Ip, gp, int(accumulate), N.ptr(ws2),
-                                       ws2.numel(), st), 'dic_lstm_dw')
+                N.check(Lb.dic_lstm_dw(N.ptr(dgx), N.ptr(out_ext), N.ptr(xb), N.ptr(wih) if dxp is not None else None, N.ptr(dxp), R, B, H, I, Ip, gp,
+                                       int(accumulate), N.ptr(ws2), ws2.numel(), st), 'dic_lstm_dw')
+                if dxp is not None:
+                    dx = dxp[0] + dxp[1]                             # (columns >= 19 of the partials are never written, nor read downstream)
+                    dx = dx.view(R, B, Ip) if packed else dx[:, :I].reshape(R, B, I).to(ctx.x_dtype)
                 N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             else:
                 # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split-K bmm (ops.splitk_tn).

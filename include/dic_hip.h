@@ -269,14 +269,17 @@ int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const vo
  *     (x (R,B,Ip) bf16).  out_ext (R+2,B,2H) bf16 = the layer's own output in time slots 1..R (pass &out_ext[1] to
  *     dic_lstm_fwd*), slot 0 [:, :H] = h0 of the forward direction and slot R+1 [:, H:] = h0 of the reverse direction (zeros
  *     without an h0): every step's recurrent input is then the row B above / below its dG row.  MFMA with transposed LDS
- *     reads, deterministic two-stage reduction, written (accumulate = 0) or added (accumulate = 1) straight into the
+ *     reads.  With wih (2*4H, Ip) bf16 (dic_lstm_pack's) and dx_parts (2, R*B, Ip) bf16 given (both or neither), the same pass also
+ *     writes the per-direction input gradients dx_parts[d] = dG[d] . W_ih[d] (columns [0, I), I <= 19; the caller adds the two
+ *     directions) -- the third GEMM that used to re-read dG.  Deterministic two-stage reduction of the weight gradients, written
+ *     (accumulate = 0) or added (accumulate = 1) straight into the
  *     parameter gradients `grads` (host array of 8 device pointers, same order; the bias entries are not touched).
  *   dic_lstm_unpack_grads: staging tensors dw_ih (2*4H, ldw) / dw_hh (2,4H,H) / dbias (2*4H) f32 (each may be NULL) ->
  *     the parameter gradients (dbias goes to bias_ih AND bias_hh). */
 int dic_lstm_pack(int dtype, const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
                   dic_stream_t stream);
 size_t dic_lstm_dw_workspace(int R, int B);
-int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, int R, int B, int H, int I, int Ip,
+int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, const void* wih, void* dx_parts, int R, int B, int H, int I, int Ip,
                 float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,
                           int accumulate, dic_stream_t stream);
