@@ -72,7 +72,8 @@ P3_ONLY = [
 EXTRA = [   # not upstream
     ('MI355X options', ('--host_loader',), dict(action='store_true', help='use torch DataLoader workers like upstream instead of the HBM-resident loader')),
     ('MI355X options', ('--amp_bf16',), dict(action='store_true', help='bf16 autocast for the bi-LSTMs / FC heads')),
-    ('MI355X options', ('--hip_graph',), dict(action='store_true', help='capture the training step in a hipGraph (single GPU; pays off at small batch sizes)')),
+    ('MI355X options', ('--hip_graph',), dict(action='store_true', default=None, help='always replay the training step from a captured hipGraph (single GPU); default: automatically for batches up to 8192 encounters, where the step is launch-bound')),
+    ('MI355X options', ('--no_hip_graph',), dict(action='store_true', help='never capture the training step (eager launches)')),
     ('MI355X options', ('--no_aux',), dict(action='store_true', help='shorthand: aux_tasks={} (the synthetic cohorts carry no outcome tables)')),
     ('MI355X options', ('--no_fake',), dict(action='store_true', help='shorthand: fake_detection=False')),
 ]
