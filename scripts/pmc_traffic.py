@@ -11,13 +11,20 @@ KEYS = {'sci_cci_fwd_kernel': 'sci_cci_fwd', 'sci_cci_bwd_kernel': 'sci_cci_bwd'
         'lstm_bwd_kernel': 'lstm_bwd'}
 
 
+def match(kernel_name, pat):
+    base = 'dic::' + pat
+    if '<' in pat:
+        return base in kernel_name
+    return (base + '(') in kernel_name or (base + '<') in kernel_name
+
+
 def per_kernel(path, counter):
     acc = {}
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
         for pat, key in KEYS.items():
-            if 'dic::' + pat + '(' in r['Kernel_Name'] or 'dic::' + pat + '<' in r['Kernel_Name'] and '<' not in pat:
+            if match(r['Kernel_Name'], pat):
                 a = acc.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += float(r['Counter_Value'])
                 break
     return {k: v[1] / v[0] for k, v in acc.items()}
@@ -27,7 +34,7 @@ fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'W
 out = {'_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/kbench.py %s 3; see '
                 'scripts/pmc_traffic.py): bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; the factor 2 is the gfx950 correction of '
                 'MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read stream). bench.py scales it linearly with the batch.' % sys.argv[3],
-       '_batch': int(sys.argv[3])}
+       '_batch': int(sys.argv[3]), '_round': int(sys.argv[4]) if len(sys.argv) > 4 else 2}
 for k in KEYS.values():
     if k in fetch and k in write:
         out[k] = {'fetch_size_kb': round(fetch[k], 1), 'write_size_kb': round(write[k], 1), 'hbm_bytes': int((2 * fetch[k] + write[k]) * 1024)}

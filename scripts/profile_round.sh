@@ -1,0 +1,32 @@
+#!/bin/bash
+# Everything the judged profiles/ files come from, in one GPU lease (run from the repo root on the GPU box):
+#   bash scripts/profile_round.sh 2
+# Counters are collected in passes of their own (--pmc with --kernel-trace only), as gpurun requires.
+set -e
+R=${1:-2}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_r$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. kernel statistics of the bench command itself
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+cp /tmp/p_stats/b_kernel_stats.csv $OUT/bench_kernel_stats.csv
+echo "[profile] kernel stats done"
+# 2. HBM traffic per kernel (micro table at the bench batch)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_fetch -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_write -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
+python3 $ROOT/scripts/pmc_traffic.py /tmp/p_fetch/p_counter_collection.csv /tmp/p_write/p_counter_collection.csv 32768 $R > $OUT/traffic.txt
+cp $ROOT/profiles/traffic.json $OUT/traffic.json
+echo "[profile] kernel traffic done"
+# 3. HBM traffic of the whole step
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/s_fetch -o p -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline --steps 6 --warmup 2 --kernel-iters 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/s_write -o p -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline --steps 6 --warmup 2 --kernel-iters 1 > /dev/null 2>&1
+python3 $ROOT/scripts/step_traffic.py /tmp/s_fetch/p_counter_collection.csv /tmp/s_write/p_counter_collection.csv $R > $OUT/step_traffic.txt
+cp $ROOT/profiles/step_traffic.json $OUT/step_traffic.json
+echo "[profile] step traffic done"
+# 4. SQ counters of the hand-written kernels at the bench batch
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d /tmp/sq1 -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/sq2 -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
+python3 $ROOT/scripts/pmc_sq.py $OUT/kernels_pmc_sq.json /tmp/sq1/p_counter_collection.csv /tmp/sq2/p_counter_collection.csv > $OUT/kernels_pmc_sq.txt
+echo "[profile] SQ counters done"
+ls -la $OUT

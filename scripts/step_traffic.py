@@ -10,7 +10,8 @@ def per_step(path, counter, n=4):
     rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     marks = [i for i, r in enumerate(rows) if 'adam_amsgrad_kernel' in r['Kernel_Name']]
-    lo, hi = marks[-n - 1] + 1, marks[-1] + 1
+    # steps 2..5 of the run (2 warm-up + 6 timed steps come first; bench.py's kernel table and step trace launch more kernels afterwards)
+    lo, hi = marks[1] + 1, marks[1 + n] + 1
     by = {}
     for r in rows[lo:hi]:
         k = r['Kernel_Name']
@@ -25,5 +26,6 @@ out = {'_note': 'HBM bytes per joint step at B=32768 (bench.py defaults): read =
 for c in sorted(set(f) | set(w)):
     out[c] = {'read_bytes': int(2 * f.get(c, 0)), 'write_bytes': int(w.get(c, 0))}
 out['total_bytes'] = int(sum(v['read_bytes'] + v['write_bytes'] for k, v in out.items() if isinstance(v, dict)))
-json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r1_step_hbm_traffic.json'), 'w'), indent=1)
+out['_batch'], out['_round'] = 32768, int(sys.argv[3]) if len(sys.argv) > 3 else 2
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'step_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
