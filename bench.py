@@ -97,6 +97,8 @@ def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True):
     out = torch.empty((B, R, 3 * C), **f32)
     saved = torch.empty((B, 7, C, R), **f32)
     gout = torch.randn((B, R, 3 * C), **f32)
+    xenc_k1 = torch.empty((R, B, 32), device=dev, dtype=torch.bfloat16)
+    gx_k1 = torch.randn((R, B, 32), **f32).to(torch.bfloat16)
     gs, gc = torch.empty(C, **f32), torch.empty((C, C), **f32)
     ws1 = torch.empty(max(16, L.dic_sci_cci_bwd_workspace(B, C, R)), dtype=torch.uint8, device=dev)
     v = torch.randn((B, C, R), **f32)
@@ -112,9 +114,13 @@ def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True):
     ws5 = torch.empty(max(16, L.dic_dec_bwd_workspace(B, D, K)), dtype=torch.uint8, device=dev)
     P = N.ptr
     calls = {
-        'sci_cci_fwd': (lambda: L.dic_sci_cci_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(sk), P(ck), P(out), P(saved), st),
+        # (the entry points the bf16 step uses when 3C < 32: the forward writes the encoder LSTM's packed bf16 input rows, the backward
+        #  reads the input gradient in that layout; algorithmic bytes as SURVEY.md 8d counts them, for the f32 (B,R,3C) tensors)
+        'sci_cci_fwd': ((lambda: L.dic_sci_cci_fwd_packed(P(x), P(lengths), B, C, T, R, P(grid), P(sk), P(ck), None, P(saved), P(xenc_k1), 32, st))
+                        if 3 * C < 32 else (lambda: L.dic_sci_cci_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(sk), P(ck), P(out), P(saved), st)),
                         8 * nsum + 4 * B * C + 12 * B * C * R),
-        'sci_cci_bwd': (lambda: L.dic_sci_cci_bwd(P(gout), P(saved), P(sk), P(ck), B, C, R, P(gs), P(gc), P(ws1), ws1.numel(), st),
+        'sci_cci_bwd': ((lambda: L.dic_sci_cci_bwd_packed(P(gx_k1), 32, P(saved), P(sk), P(ck), B, C, R, P(gs), P(gc), P(ws1), ws1.numel(), st))
+                        if 3 * C < 32 else (lambda: L.dic_sci_cci_bwd(P(gout), P(saved), P(sk), P(ck), B, C, R, P(gs), P(gc), P(ws1), ws1.numel(), st)),
                         8 * nsum + 24 * B * C * R),
         'rbf_fwd': (lambda: L.dic_rbf_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(rk), P(v), 0, P(y), P(norm), 1, st),
                     12 * nsum + 4 * B * C * R),
@@ -167,7 +173,7 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
     ldb = torch.empty((2, 4 * Hh), **f32)
     ws6 = torch.empty(max(16, L.dic_lstm_bwd_workspace(B)), dtype=torch.uint8, device=dev)
     calls['lstm_bwd'] = (lambda: L.dic_lstm_bwd(P(whh_t), P(lgates), P(lcs), None, P(ldout), None, None, R, B, Hh, P(ldgx), P(ldh0),
-                                                P(ldc0), P(ldb), P(ws6), ws6.numel(), 0, st),
+                                                P(ldc0), P(ldb), P(ws6), ws6.numel(), 0, 0, st),
                          rows * (4 * Hh * 2 + Hh * 2 + Hh * 2 + 4 * Hh * 2))      # gates, c, dout in; dG out
 
 

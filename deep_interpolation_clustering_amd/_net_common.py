@@ -33,12 +33,13 @@ class EncoderRNN(nn.Module):
         self.num_directions = 2 if bidirectional else 1
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
 
-    def forward(self, x, packed=False, batch_major_state=False):
-        """``batch_major_state`` (fused path only): hidden / cell_state come back as (B,2,H) -- see lstm.bilstm."""
+    def forward(self, x, packed=False, batch_major_state=False, rectified_out=False):
+        """``batch_major_state`` (fused path only): hidden / cell_state come back as (B,2,H) -- see lstm.bilstm.
+        ``rectified_out`` (fused path only): output is relu(output), which is all the decoder reads of it (DecoderRNN.forward)."""
         if packed:                                           # (R,B,32) bf16 rows straight from ops.sci_cci_packed
-            output, (hidden, cell_state) = fused_lstm.bilstm_packed(x, self.lstm, batch_major_state=batch_major_state)
+            output, (hidden, cell_state) = fused_lstm.bilstm_packed(x, self.lstm, batch_major_state=batch_major_state, rectified_out=rectified_out)
         elif fused_lstm.fused_available(x, self.lstm) or fused_lstm.f32_available(x, self.lstm):      # on the GPU: persistent HIP recurrence
-            output, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, batch_major_state=batch_major_state)
+            output, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, batch_major_state=batch_major_state, rectified_out=rectified_out)
         else:
             output, (hidden, cell_state) = self.lstm(x)
         return output, hidden, cell_state
@@ -50,8 +51,9 @@ class DecoderRNN(nn.Module):
         self.device, self.hidden_size = device, hidden_size
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
 
-    def forward(self, x, hidden, context, batch_major_state=False):
-        x = F.relu(x)                                                           # clustering_interp.py:38-41
+    def forward(self, x, hidden, context, batch_major_state=False, rectified=False):
+        if not rectified:                                                       # (the fused encoder hands its output over rectified)
+            x = F.relu(x)                                                       # clustering_interp.py:38-41
         if fused_lstm.fused_available(x, self.lstm) or fused_lstm.f32_available(x, self.lstm):
             x, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, hidden, context, batch_major_state=batch_major_state)
         else:
@@ -166,12 +168,12 @@ class NetBase(nn.Module):
         if len(feats) > 1 and B * feats[0].size(0) >= SEPARATE_ENCODER_ROWS:
             # large batches: one encoder call per branch.  Each already fills the chip, and the shared call would cost three
             # 100-MB-class copies (stacking the inputs, slicing the real half of the context and of the final states back out)
-            outs = [self.encoder(f, packed, bm) for f in feats]
+            outs = [self.encoder(f, packed, bm, bm) for f in feats]
             context, hidden, cell = outs[0]
             z_all = torch.cat([self._latent(o[1], bm) for o in outs], dim=0)                     # (nB, 256)
         else:
             seq = feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)                        # (R, nB, .)
-            context, hidden, cell = self.encoder(seq, packed, bm)
+            context, hidden, cell = self.encoder(seq, packed, bm, bm)
             z_all = self._latent(hidden, bm)                                                      # (nB, 256)
             if len(feats) > 1:
                 context = context[:, :B]
@@ -180,7 +182,7 @@ class NetBase(nn.Module):
         if self.on_decoder_side_grads is not None and context.requires_grad:
             cb = self.on_decoder_side_grads
             context.register_hook(lambda g: cb())           # fires when the backward has passed the decoder, its head and the latent heads
-        y, _ = self.decoder(context, hidden, cell, bm) if bm else self.decoder(context, hidden, cell)
+        y, _ = self.decoder(context, hidden, cell, bm, bm) if bm else self.decoder(context, hidden, cell)
         # (B,C,T).  Inside step.Stepper's optimisation step (`internal_step`: the reconstruction is consumed by rec_loss alone and never
         # handed out) only the observed slots are materialised; every other caller gets zeros in the padding, as upstream's `* mask`
         y = self.rbf(y.permute(1, 2, 0), x, lengths, prefix_only=self.internal_step)

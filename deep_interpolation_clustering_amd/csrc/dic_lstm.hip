@@ -320,6 +320,7 @@ struct LstmBwdArgs {
     float* dbias_part;     // (gridDim.x, 2, 4H) per-workgroup sums of dG over its rows and all steps, or NULL
     int R, B;
     int bm;                // state tensors (c0, dhn, dcn, dh0, dc0) batch-major (B,2,H) instead of (2,B,H)
+    int relu;              // dout is the gradient of relu(out): it passes where h_t > 0, i.e. (o being a sigmoid) where tanh(c_t) > 0
 };
 
 __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwdArgs a) {
@@ -406,8 +407,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         for (int j = 0; j < 4; ++j) {
             const int k = 4 * q + j;
             const float ig = (float)x.ib[j], fg = (float)x.fb[j], gg = (float)x.gb[j], og = (float)x.ob[j];
-            const float dht = dh[nb][k] + (float)x.go[j];
             const float tc = tanh_fast(ccar[nb][k]);
+            const float dht = dh[nb][k] + ((a.relu && !(tc > 0.f)) ? 0.f : (float)x.go[j]);
             const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
             const float vi = dct * gg * ig * (1.0f - ig), vf = dct * (float)x.cp[j] * fg * (1.0f - fg);
             const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
@@ -578,7 +579,7 @@ size_t dic_lstm_bwd_workspace(int B) { return B > 0 ? (size_t)((B + LBM - 1) / L
 
 int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
-                 float* dbias, void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream) {
+                 float* dbias, void* workspace, size_t workspace_bytes, int state_batch_major, int dout_of_relu, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_bwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_bwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(whh_t && gates && cs && dgx && dh0 && dc0, DIC_ERR_INVALID_ARG, "lstm_bwd: NULL pointer");
@@ -593,7 +594,7 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
     DIC_REQUIRE(!dbias || (workspace && workspace_bytes >= dic_lstm_bwd_workspace(B)), DIC_ERR_WORKSPACE,
                 "lstm_bwd: dbias needs %zu B of workspace", dic_lstm_bwd_workspace(B));
     LstmBwdArgs a{(const __bf16*)whh_t, (const __bf16*)gates, (const __bf16*)cs, c0, (const __bf16*)dout, dhn, dcn, (__bf16*)dgx, dh0, dc0,
-                  dbias ? (float*)workspace : nullptr, R, B, state_batch_major != 0};
+                  dbias ? (float*)workspace : nullptr, R, B, state_batch_major != 0, dout_of_relu != 0};
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nwg, 2), dim3(256), lds, (hipStream_t)stream, a);
     if (dbias)
         hipLaunchKernelGGL(lstm_dbias_finalize, dim3(2 * 4 * LH / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nwg,

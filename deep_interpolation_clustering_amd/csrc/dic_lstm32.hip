@@ -244,6 +244,7 @@ struct RecBwdArgs {
     float* dh0; float* dc0;
     float* dbias_part;     // (gridDim.x, 2, 4H) or NULL
     int R, B, bm, transposed;
+    int relu;              // dout is the gradient of relu(out): it passes where h_t > 0, i.e. where tanh(c_t) > 0
 };
 
 template <typename T>
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * q + j;
                 const float ig = (float)ib[j], fg = (float)fb[j], gg = (float)gb[j], og = (float)ob[j];
-                const float dht = dh[k] + go[j];
                 const float tc = tanh_acc<T>(ccar[k]);
+                const float dht = dh[k] + ((a.relu && !(tc > 0.f)) ? 0.f : go[j]);
                 const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[k]);
                 const float vi = dct * gg * ig * (1.0f - ig), vf = dct * cp[j] * fg * (1.0f - fg);
                 const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
@@ -421,7 +422,7 @@ static int rec_fwd(const void* gx, const void* whh, const float* h0, const float
 
 template <typename T>
 static int rec_bwd(const void* whh, int transposed, const void* gates, const void* cs, const void* dout, const float* dhn,
-                   const float* dcn, int R, int B, void* dgx, float* dh0, float* dc0, float* dbias, void* workspace, int bm, hipStream_t st) {
+                   const float* dcn, int R, int B, void* dgx, float* dh0, float* dc0, float* dbias, void* workspace, int bm, int relu, hipStream_t st) {
     const size_t lds = (size_t)SROWS * Rec<T>::PITCH(S4) * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
@@ -431,7 +432,7 @@ static int rec_bwd(const void* whh, int transposed, const void* gates, const voi
     }
     const int nwg = (B + SROWS - 1) / SROWS;
     RecBwdArgs<T> a{(const T*)whh, (const T*)gates, (const T*)cs, (const T*)dout, dhn, dcn, (T*)dgx, dh0, dc0,
-                    dbias ? (float*)workspace : nullptr, R, B, bm != 0, transposed};
+                    dbias ? (float*)workspace : nullptr, R, B, bm != 0, transposed, relu != 0};
     hipLaunchKernelGGL(lstm_rec_bwd_kernel<T>, dim3(nwg, 2), dim3(256), lds, st, a);
     if (dbias) hipLaunchKernelGGL(lstm_rec_dbias_finalize, dim3(2 * S4 / 32), dim3(256), 0, st, (const float*)workspace, nwg, dbias);
     return check_launch("lstm_rec_bwd");
@@ -458,7 +459,7 @@ size_t dic_lstm_rec_bwd_workspace(int B) { return B > 0 ? (size_t)((B + SROWS - 
 
 int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const void* dout,
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
-                     void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream) {
+                     void* workspace, size_t workspace_bytes, int state_batch_major, int dout_of_relu, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_rec_bwd: non-positive size");
     DIC_REQUIRE(H == SH, DIC_ERR_UNSUPPORTED, "lstm_rec_bwd: hidden size %d (compiled for %d)", H, SH);
     DIC_REQUIRE(dtype == DIC_DTYPE_F32 || dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "lstm_rec_bwd: dtype %d", dtype);
@@ -466,8 +467,8 @@ int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const vo
     DIC_REQUIRE(!dbias || (workspace && workspace_bytes >= dic_lstm_rec_bwd_workspace(B)), DIC_ERR_WORKSPACE,
                 "lstm_rec_bwd: dbias needs %zu B of workspace", dic_lstm_rec_bwd_workspace(B));
     if (dtype == DIC_DTYPE_F32)
-        return rec_bwd<float>(whh, whh_is_transposed, gates, cs, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, (hipStream_t)stream);
-    return rec_bwd<__bf16>(whh, whh_is_transposed, gates, cs, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, (hipStream_t)stream);
+        return rec_bwd<float>(whh, whh_is_transposed, gates, cs, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, dout_of_relu, (hipStream_t)stream);
+    return rec_bwd<__bf16>(whh, whh_is_transposed, gates, cs, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, dout_of_relu, (hipStream_t)stream);
 }
 
 }  // extern "C"

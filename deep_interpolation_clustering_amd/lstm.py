@@ -65,7 +65,7 @@ def _grad_sinks(params, needs):
 
 class _BiLstm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h0, c0, packed, bm, f32, *params):
+    def forward(ctx, x, h0, c0, packed, bm, f32, relu, *params):
         R, B, I_in = x.shape
         T = torch.float32 if f32 else torch.bfloat16
         code = N.DTYPE_F32 if f32 else N.DTYPE_BF16
@@ -130,17 +130,19 @@ class _BiLstm(torch.autograd.Function):
                 gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
                 N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
                                        N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd')
-        ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32))
+        ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32), bool(relu))
         ctx.x_dtype = x.dtype
         ctx.has_init = h0 is not None
         ctx.params = params
         ctx.save_for_backward(xb, wih, whh if f32 else whh_t, gates, cs, out_ext, h0c, c0c)
-        return out, hn, cn
+        # relu: the caller consumes relu(out) only (the decoder's input, clustering_interp.py:38-41).  The raw rows stay in out_ext for the
+        # weight-gradient products; the backward kernel applies the ReLU mask itself (sign of tanh(c_t)), so no mask pass and no saved copy
+        return (torch.relu(out) if relu else out), hn, cn
 
     @staticmethod
     def backward(ctx, dout, dhn, dcn):
         xb, wih, whh_b, gates, cs, out_ext, h0c, c0c = ctx.saved_tensors
-        R, B, I, Ip, narrow, small, packed, bm, f32 = ctx.dims
+        R, B, I, Ip, narrow, small, packed, bm, f32, relu = ctx.dims
         params = ctx.params
         T = torch.float32 if f32 else torch.bfloat16
         code = N.DTYPE_F32 if f32 else N.DTYPE_BF16
@@ -156,14 +158,14 @@ class _BiLstm(torch.autograd.Function):
         if small:
             ws = torch.empty(max(16, Lb.dic_lstm_rec_bwd_workspace(B)), device=dev, dtype=torch.uint8)
             N.check(Lb.dic_lstm_rec_bwd(code, N.ptr(whh_b), int(not f32), N.ptr(gates), N.ptr(cs), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
-                                        R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), st), 'dic_lstm_rec_bwd')
+                                        R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), int(relu), st), 'dic_lstm_rec_bwd')
         else:
             ws = torch.empty(max(16, Lb.dic_lstm_bwd_workspace(B)), device=dev, dtype=torch.uint8)
             N.check(Lb.dic_lstm_bwd(N.ptr(whh_b), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
-                                    R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), st), 'dic_lstm_bwd')
+                                    R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), int(relu), st), 'dic_lstm_bwd')
         dg2 = dgx.view(R * B, 8 * H)
         use_dw = narrow and R * B >= 32                              # one-pass weight-gradient kernel (csrc/dic_lstmgrad.hip; it tiles the R*B rows by 32)
-        fuse_dx = use_dw and I <= 19 and any(ctx.needs_input_grad[6:])       # ... which then also forms dX = dG.W_ih per direction
+        fuse_dx = use_dw and I <= 19 and any(ctx.needs_input_grad[7:])       # ... which then also forms dX = dG.W_ih per direction
         dxp = torch.empty((2, R * B, Ip), device=dev, dtype=T) if (fuse_dx and ctx.needs_input_grad[0]) else None
         dx = None
         if ctx.needs_input_grad[0] and dxp is None:
@@ -172,7 +174,7 @@ class _BiLstm(torch.autograd.Function):
                 dx = dx.view(R, B, Ip)                               # consumed in this layout by ops._SciCciPacked.backward
             else:
                 dx = (dx[:, :I] if Ip != I else dx).reshape(R, B, I).to(ctx.x_dtype)
-        needs = ctx.needs_input_grad[6:]
+        needs = ctx.needs_input_grad[7:]
         grads = [None] * 8
         if any(needs):
             sinks, accumulate = _grad_sinks(params, needs)
@@ -199,27 +201,28 @@ class _BiLstm(torch.autograd.Function):
                 N.check(Lb.dic_lstm_unpack_grads(N.ptr(dw_ih), Ip, N.ptr(dw_hh), N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             if not accumulate:
                 grads = [g if n else None for g, n in zip(sinks, needs)]
-        return (dx, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None), None, None, None, *grads)
+        return (dx, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None), None, None, None, None, *grads)
 
 
 def _params(lstm):
     return [getattr(lstm, n) for n in PARAM_NAMES]
 
 
-def bilstm(x, lstm, h0=None, c0=None, batch_major_state=False):
+def bilstm(x, lstm, h0=None, c0=None, batch_major_state=False, rectified_out=False):
     """(out (R,B,2H), (h_n, c_n) (2,B,H) f32) = bidirectional LSTM of x (R,B,I) with ``lstm``'s parameters: bf16 operands under
     autocast(bf16) (out is bf16), exact f32 otherwise (x f32, no autocast; out is f32).
     ``batch_major_state``: h0, c0, h_n, c_n are (B,2,H) instead -- h_n.view(B, 2H) is then the concatenated latent
-    [h_fwd | h_rev] of clustering_interp.py:139, and feeds the next LSTM as it lies."""
+    [h_fwd | h_rev] of clustering_interp.py:139, and feeds the next LSTM as it lies.
+    ``rectified_out``: out is relu(out) (what the decoder feeds on); the ReLU's backward is applied inside the recurrence kernel."""
     f32 = x.dtype == torch.float32 and not torch.is_autocast_enabled()
     with torch.autocast('cuda', enabled=False):
-        out, hn, cn = _BiLstm.apply(x, h0, c0, False, batch_major_state, f32, *_params(lstm))
+        out, hn, cn = _BiLstm.apply(x, h0, c0, False, batch_major_state, f32, rectified_out, *_params(lstm))
     return out, (hn, cn)
 
 
-def bilstm_packed(xenc, lstm, h0=None, c0=None, batch_major_state=False):
+def bilstm_packed(xenc, lstm, h0=None, c0=None, batch_major_state=False, rectified_out=False):
     """The same for an input already in the recurrence kernel's layout: xenc (R,B,32) bf16 rows [features | 1 | 0...]
     (``ops.sci_cci_packed``); its gradient comes back in that layout too."""
     with torch.autocast('cuda', enabled=False):
-        out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, batch_major_state, False, *_params(lstm))
+        out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, batch_major_state, False, rectified_out, *_params(lstm))
     return out, (hn, cn)

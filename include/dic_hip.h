@@ -239,7 +239,10 @@ int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const flo
 size_t dic_lstm_bwd_workspace(int B);
 int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
-                 float* dbias, void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream);
+                 float* dbias, void* workspace, size_t workspace_bytes, int state_batch_major, int dout_of_relu, dic_stream_t stream);
+/* dout_of_relu != 0: the consumer of `out` was relu(out) (the decoder rectifies the encoder output, clustering_interp.py:38-41) and
+ * dout is the gradient of THAT: the kernel passes it where h_t > 0, read off the sign of tanh(c_t) it computes anyway (o_t is a
+ * sigmoid) -- the element-wise ReLU backward pass over (R,B,2H) disappears. */
 
 /* The same recurrence for the two regimes the 64-row bf16 kernels above do not serve (csrc/dic_lstm32.hip): dtype =
  * DIC_DTYPE_F32 -- every tensor f32, the recurrent product on v_mfma_f32_32x32x2_f32 (exact f32: the configuration of the 1e-5
@@ -255,7 +258,7 @@ int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0
 size_t dic_lstm_rec_bwd_workspace(int B);
 int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const void* dout,
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
-                     void* workspace, size_t workspace_bytes, int state_batch_major, dic_stream_t stream);
+                     void* workspace, size_t workspace_bytes, int state_batch_major, int dout_of_relu, dic_stream_t stream);
 
 /* ------------------------------------------------------------------ bi-LSTM parameters --------
  * The eight f32 parameters of one bidirectional nn.LSTM layer (clustering_interp.py:22,35: weight_ih_l0, weight_hh_l0,

@@ -553,3 +553,35 @@ def test_f32_recurrence_matches_nn_lstm(R, B, I, init, bm):
         a, b = res['hip'][k].cpu().numpy(), ref.cpu().numpy()
         tol = 2e-6 if k in ('out', 'hn', 'cn') else 1e-5
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=tol * max(1.0, float(np.abs(b).max())), err_msg=k)
+
+
+@pytest.mark.parametrize('mode', ['pipelined64', 'tile32', 'f32'])
+@pytest.mark.parametrize('I,B', [(18, 200), (256, 70)])
+def test_rectified_output_equals_relu_applied_outside(mode, I, B, monkeypatch):
+    """rectified_out=True hands out relu(out) and applies the ReLU's backward inside the recurrence kernel (mask = sign of tanh(c_t),
+    which is the sign of h_t since o_t is a sigmoid): same numbers as relu(bilstm(...)) with torch's threshold backward."""
+    from deep_interpolation_clustering_amd import lstm as L
+    monkeypatch.setattr(L, 'SMALL_BATCH', 0 if mode == 'pipelined64' else 1 << 30)
+    torch.manual_seed(5)
+    dev = torch.device('cuda')
+    R = 7
+    net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, I, device=dev) * (1.0 if I < 100 else 0.5)
+    go, gh = torch.randn(R, B, 2 * H, device=dev), torch.randn(2, B, H, device=dev)
+    res = {}
+    for inside in (False, True):
+        net.zero_grad()
+        xi = x.clone().requires_grad_()
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=mode != 'f32'):
+            out, (hn, cn) = L.bilstm(xi, net, rectified_out=inside)
+            if not inside:
+                out = torch.relu(out)
+        ((out.float() * go).sum() + (hn * gh).sum()).backward()
+        res[inside] = dict(out=out.detach().float(), hn=hn.detach(), dx=xi.grad.clone(), **{k: p.grad.clone() for k, p in net.named_parameters()})
+    assert float((res[True]['out'] == 0).float().mean()) > 0.3            # the mask is doing something
+    for k in res[False]:
+        if k in ('out', 'hn'):
+            assert torch.equal(res[False][k], res[True][k]), k
+        else:       # (an element whose h rounds to exactly +-0 may take the other branch: none in practice, but not a bit-level contract)
+            a, b = res[True][k].cpu().numpy(), res[False][k].cpu().numpy()
+            np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6 * float(np.abs(b).max()), err_msg=k)
