@@ -59,30 +59,33 @@ __device__ __forceinline__ float softplus_raw(float k) { return logf(1.0f + expf
 __device__ __forceinline__ float sigmoidf(float k) { return 1.0f / (1.0f + expf(-k)); }
 
 // Fixed-order (deterministic) second-stage reduction: out_i = sum_b partials[b*n + i].
-// Call from a 256-thread workgroup; it covers outputs i0 .. i0+31 as 32 outputs x 8 slices of b
-// (coalesced 128-B reads per slice row).  The result is valid in threads 0..31 (for i = i0 + tid).
+// Call from a 256-thread workgroup; it covers outputs i0 .. i0+31 as W outputs x 256/W slices of b, W = 32 (coalesced 128-B reads
+// per slice row), or W = 8 / 16 when there are no more outputs than that (then i0 = 0): a handful of outputs over thousands of
+// partial rows is a chain of dependent loads, and 32 / 16 slices shorten it 4x / 2x (rbf_bwd's 6 outputs: 20 -> 6 us).
+// The result is valid in threads 0..31 (for i = i0 + tid).
 template <typename T>
 __device__ __forceinline__ double reduce_partials_32x8(const T* partials, int nblk, int n, int i0, double* lds256) {
-    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5, i = i0 + o;
+    const int W = n <= 8 ? 8 : (n <= 16 ? 16 : 32), nsl = 256 / W;
+    const int o = threadIdx.x & (W - 1), sl = threadIdx.x / W, i = i0 + o;
     double acc = 0.0;
     if (i < n) {
         // four independent chains so that four loads are in flight per thread (the loop is latency-bound otherwise)
         double a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int b = sl;
-        for (; b + 24 < nblk; b += 32) {
+        for (; b + 3 * nsl < nblk; b += 4 * nsl) {
             acc += (double)partials[(size_t)b * n + i];
-            a1 += (double)partials[(size_t)(b + 8) * n + i];
-            a2 += (double)partials[(size_t)(b + 16) * n + i];
-            a3 += (double)partials[(size_t)(b + 24) * n + i];
+            a1 += (double)partials[(size_t)(b + nsl) * n + i];
+            a2 += (double)partials[(size_t)(b + 2 * nsl) * n + i];
+            a3 += (double)partials[(size_t)(b + 3 * nsl) * n + i];
         }
-        for (; b < nblk; b += 8) acc += (double)partials[(size_t)b * n + i];
+        for (; b < nblk; b += nsl) acc += (double)partials[(size_t)b * n + i];
         acc = (acc + a1) + (a2 + a3);
     }
     lds256[threadIdx.x] = acc;
     __syncthreads();
     double r = 0.0;
-    if (threadIdx.x < 32)
-        for (int k = 0; k < 8; ++k) r += lds256[k * 32 + threadIdx.x];
+    if (threadIdx.x < W)
+        for (int k = 0; k < nsl; ++k) r += lds256[k * W + threadIdx.x];
     return r;
 }
 

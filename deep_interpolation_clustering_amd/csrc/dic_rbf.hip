@@ -116,7 +116,7 @@ __host__ __device__ inline RbfBwdLayout rbf_bwd_layout(int E, int C, int R, int 
 
 template <int S, int CT, int RT>
 __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
-    constexpr int U = S >= 4 ? 1 : 4 / S;
+    constexpr int U = S >= 16 ? 1 : S >= 4 ? 2 : 4 / S;     // slots per trip and lane: U * S <= kRbfMaxSplit (the zero-weight padding behind each row)
     constexpr int LOGS = S == 1 ? 0 : S == 2 ? 1 : S == 4 ? 2 : S == 8 ? 3 : 4;
     extern __shared__ __align__(16) float smem[];
     const int C = CT ? CT : a.C, R = RT ? RT : a.R, T = a.T, E = a.E;
@@ -151,39 +151,72 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
             atomicMax(tile_max, n);
         }
         __syncthreads();
-        // stage (t, g*m/(N+eps), S/(N+eps), -) per slot, 4 chunks in flight per wave; masked slots and the
-        // padding up to the tile maximum get weight 0 (so the streaming loop needs no bounds checks)
+        // stage (t, a = g*m/(N+eps), a*y, -) per slot (y = S/(N+eps) for a valid slot), 4 chunks in flight per wave; masked slots and
+        // the padding up to the tile maximum get weight 0 (so the streaming loop needs no bounds checks)
         const int npad = min(*tile_max + kRbfMaxSplit, stride);
         const int nchunk = (npad + kWave - 1) / kWave, units = nrows * nchunk;
         constexpr int NW = kBlock / kWave, G = 4;
-        for (int u0 = wave * G; u0 < units; u0 += NW * G) {
-            float4 val[G];
-            int dst[G];
+        if (a.lengths) {
+            // prefix masks: every address is known up front -- the 16 loads of a trip are issued back to back from clamped (always
+            // valid) addresses and the padding is selected away afterwards (it may hold anything: prefix-only producers never write it)
+            for (int u0 = wave * G; u0 < units; u0 += NW * G) {
+                float tv[G], gy[G], nm[G], yv[G];
+                int dst[G];
+                bool valid[G];
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const int u = u0 + k;
-                dst[k] = -1;
-                val[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (u < units) {
+                for (int k = 0; k < G; ++k) {
+                    const int u = min(u0 + k, units - 1);
                     const int row = u / nchunk;
                     const int i = (u - row * nchunk) * kWave + lane;
-                    if (i < npad) {
-                        dst[k] = row * stride + i;
-                        if (i < cnt[row]) {
-                            const int e = row / C, c = row - e * C;
-                            const float* base = a.x + (size_t)(e0 + e) * 4 * C * T;
-                            const size_t o = ((size_t)(e0 + e) * C + c) * T + i;
-                            const float t = base[(size_t)(2 * C + c) * T + i];
-                            const float m = a.lengths ? 1.f : base[(size_t)(C + c) * T + i];
-                            // y = m*S/den upstream, so dL/dS = g*m/den (the forward saved 1/den); S/den = y for a valid slot
-                            if (m != 0.f) val[k] = make_float4(t, a.grad_y[o] * a.norm[o], a.y[o], 0.f);
+                    dst[k] = (u0 + k < units && i < npad) ? row * stride + i : -1;
+                    valid[k] = i < cnt[row];
+                    const int e = row / C, c = row - e * C, ic = min(i, T - 1);
+                    const size_t o = ((size_t)(e0 + e) * C + c) * T + ic;
+#ifdef DIC_K2_EXP_NOSTAGE     // experiment: no global loads in the staging phase
+                    tv[k] = (float)ic; gy[k] = 1.f; nm[k] = 0.5f; yv[k] = (float)o;
+#else
+                    tv[k] = a.x[((size_t)(e0 + e) * 4 * C + 2 * C + c) * T + ic];
+                    gy[k] = a.grad_y[o]; nm[k] = a.norm[o]; yv[k] = a.y[o];
+#endif
+                }
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const float w = valid[k] ? gy[k] * nm[k] : 0.f;      // dL/dS = g/den (the forward saved 1/den)
+                    if (dst[k] >= 0) obs[dst[k]] = make_float4(valid[k] ? tv[k] : 0.f, w, valid[k] ? w * yv[k] : 0.f, 0.f);
+                }
+            }
+        } else {
+            for (int u0 = wave * G; u0 < units; u0 += NW * G) {
+                float4 val[G];
+                int dst[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const int u = u0 + k;
+                    dst[k] = -1;
+                    val[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (u < units) {
+                        const int row = u / nchunk;
+                        const int i = (u - row * nchunk) * kWave + lane;
+                        if (i < npad) {
+                            dst[k] = row * stride + i;
+                            if (i < cnt[row]) {
+                                const int e = row / C, c = row - e * C;
+                                const float* base = a.x + (size_t)(e0 + e) * 4 * C * T;
+                                const size_t o = ((size_t)(e0 + e) * C + c) * T + i;
+                                const float t = base[(size_t)(2 * C + c) * T + i];
+                                const float m = base[(size_t)(C + c) * T + i];
+                                if (m != 0.f) {
+                                    const float w = a.grad_y[o] * a.norm[o];
+                                    val[k] = make_float4(t, w, w * a.y[o], 0.f);
+                                }
+                            }
                         }
                     }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < G; ++k)
-                if (dst[k] >= 0) obs[dst[k]] = val[k];
+                for (int k = 0; k < G; ++k)
+                    if (dst[k] >= 0) obs[dst[k]] = val[k];
+            }
         }
         __syncthreads();
         const int nitems = nrows * R * S;
@@ -199,19 +232,30 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) nw = max(nw, __shfl_xor(nw, m));
             nw = __builtin_amdgcn_readfirstlane(nw);
+#ifdef DIC_K2_EXP_NOLOOP      // experiment (scripts/k2_experiments.sh): everything but the (slot, grid point) loop
+            const int nj = a.B < 0 ? 2 : 0;
+#else
             const int nj = ((nw + S - 1) / S + U - 1) / U * U;
-            float gv = 0.f, gbt = 0.f;
+#endif
+            // dL/dv_r = sum_t a*phi;  dL/dbeta = -sum_t a*phi*u*(y - v_r), u = (t - ref)^2, kept as two sums (a*y was staged):
+            // 7 vector operations + 1 exp per (slot, grid point)
+            float gv = 0.f, q1 = 0.f, q2 = 0.f;
             for (int j = 0; j < nj; j += U) {
+                float4 o[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) o[k] = p[(j + k) * S];
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
-                    const float4 o = p[(j + k) * S];
-                    const float d = o.x - ref;
+                    const float d = o[k].x - ref;
                     const float u = d * d;
-                    const float wphi = o.y * fast_exp2(nb * u);
-                    gv += wphi;
-                    gbt = fmaf(wphi * u, o.z - vr, gbt);
+                    const float e = fast_exp2(nb * u);
+                    gv = fmaf(o[k].y, e, gv);
+                    const float eu = e * u;
+                    q2 = fmaf(o[k].y, eu, q2);
+                    q1 = fmaf(o[k].z, eu, q1);
                 }
             }
+            float gbt = fmaf(-vr, q2, q1);
 #pragma unroll
             for (int m = 1; m < S; m <<= 1) { gv += __shfl_xor(gv, m); gbt += __shfl_xor(gbt, m); }
             if (live && s == 0) {
@@ -225,6 +269,166 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
     }
     const int lpc = channel_group_lanes(C);
     if (tid % lpc == 0 && tid / lpc < C) a.partials[(size_t)blockIdx.x * C + tid / lpc] = gbeta_acc;
+}
+
+// The same backward for the reference's own shape (C = 6 channels, R = 24 grid points, prefix masks), one ENCOUNTER PER WAVE:
+// the generic kernel above spends more vector instructions on index arithmetic, tile bookkeeping and barrier phases than on the
+// (slot, grid point) math (scripts/k2_experiments.sh: 104 of its 217 us remain with both the loop and the loads removed).  Here
+//   * an encounter is C*R*4 = 576 (row, grid point, split) items = exactly 9 rounds of one wave, so the (row, grid point) of a lane in
+//     round k never changes: its LDS offset, grid point, bandwidth and the offset of its v / grad_v element are computed once per
+//     kernel, and each round's trip count is the larger of two SCALAR row lengths;
+//   * waves share nothing -- no workgroup barrier inside the encounter loop (LDS operations of one wave execute in order), so the
+//     waves of a CU drift apart and one wave's load latency is another's compute;
+//   * the next encounter's rows (first 64 slots of t, g, 1/den, y per channel), its v elements and lengths are requested right
+//     after the current one has been staged, and land during its 9 rounds;
+//   * dL/dbeta stays in 9 per-lane accumulators over all encounters of the wave and is reduced once at the end (fixed order).
+constexpr int kRbfWaveSplit = 4;
+#ifndef DIC_K2_WAVE_U
+#define DIC_K2_WAVE_U 2
+#endif
+constexpr int WU = DIC_K2_WAVE_U;      // slots per lane and trip of the (slot, grid point) loop: the LDS reads of one trip are issued together
+// (Packed arithmetic was tried here -- slot planes read in pairs by ds_read2_b32, 7 v_pk_*_f32 + 2 v_exp_f32 per slot pair: 140 us
+//  against 122 us for this scalar loop at the same occupancy.  v_pk_*_f32 saves instruction slots on gfx950, not cycles, and the
+//  pair operands cost registers, i.e. occupancy.)
+template <int C, int R>
+__global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
+    constexpr int S = kRbfWaveSplit, ROUNDS = C * R * S / kWave, QPR = kWave / S;       // QPR (row, grid point) pairs per round
+    static_assert(C * R * S % kWave == 0, "an encounter must be a whole number of wave rounds");
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, s = lane & (S - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B, stride = rbf_row_stride(T);
+    float4* obs = reinterpret_cast<float4*>(smem) + wave * C * stride;       // [C][stride] x (t, a = g/den, a*y, -)
+    const int nwaves = a.nblk * (kBlock / kWave);
+
+    int poff[ROUNDS], voff[ROUNDS], rowl[ROUNDS];
+    float ref[ROUNDS], nb[ROUNDS], gacc[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int q = QPR * k + (lane >> 2), row = q / R, r = q - row * R;
+        rowl[k] = row;
+        poff[k] = row * stride + s;
+        voff[k] = a.v_rbc ? r * B * C + row : q;
+        ref[k] = a.ref_grid[r];
+        nb[k] = -softplus_raw(a.rbf_kernel[row]) * kLog2e;
+        gacc[k] = 0.f;
+    }
+    const int ic = min(lane, T - 1);
+    const size_t vstep = a.v_rbc ? (size_t)C : (size_t)C * R;       // v / grad_v offset of encounter e = e * vstep + voff[k]
+
+    float pt[C], pg[C], pn[C], py[C], pv[ROUNDS];
+    int plen[C];
+    auto request = [&](int e) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const size_t o = ((size_t)e * C + c) * T + ic;
+#ifdef DIC_K2_EXP_NOSTAGE
+            pt[c] = (float)ic; pg[c] = 1.f; pn[c] = 0.5f; py[c] = (float)o;
+#else
+            pt[c] = a.x[((size_t)e * 4 * C + 2 * C + c) * T + ic];
+            pg[c] = a.grad_y[o]; pn[c] = a.norm[o]; py[c] = a.y[o];
+#endif
+            plen[c] = a.lengths[(size_t)e * C + c];
+        }
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) pv[k] = a.v[(size_t)e * vstep + voff[k]];
+    };
+    const int e_first = blockIdx.x * (kBlock / kWave) + wave;
+    if (e_first < B) request(e_first);
+
+    for (int e = e_first; e < B; e += nwaves) {
+        int n[C], maxn = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            n[c] = __builtin_amdgcn_readfirstlane(max(0, min(plen[c], T)));
+            maxn = max(maxn, n[c]);
+        }
+        // slots 0..63 of every row: (t, a = g/den, a*y, -), zero weight behind the row's length
+        if (lane < stride) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const bool valid = lane < n[c];
+                const float w = valid ? pg[c] * pn[c] : 0.f;
+                obs[c * stride + lane] = make_float4(valid ? pt[c] : 0.f, w, valid ? w * py[c] : 0.f, 0.f);
+            }
+        }
+        if (maxn + kRbfMaxSplit > kWave) {        // (wave-uniform, rare at the reference's ~50 samples per channel) the rest of the rows
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                for (int i = kWave + lane; i < stride; i += kWave) {
+                    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < n[c]) {
+                        const size_t o = ((size_t)e * C + c) * T + i;
+                        const float w = a.grad_y[o] * a.norm[o];
+                        val = make_float4(a.x[((size_t)e * 4 * C + 2 * C + c) * T + i], w, w * a.y[o], 0.f);
+                    }
+                    obs[c * stride + i] = val;
+                }
+        }
+        float vr[ROUNDS];
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) vr[k] = pv[k];
+        if (e + nwaves < B) request(e + nwaves);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int row_lo = (QPR * k) / R, row_hi = (QPR * k + QPR - 1) / R;
+            const int nw = max(n[row_lo], n[row_hi]);
+#ifdef DIC_K2_EXP_NOLOOP
+            const int nj = a.B < 0 ? 2 : 0;
+#else
+            const int nj = ((nw + S - 1) / S + WU - 1) / WU * WU;
+#endif
+            // dL/dv_r = sum_t a*phi;  dL/dbeta = -sum_t a*phi*u*(y - v_r), u = (t - ref)^2, kept as two sums (a*y was staged):
+            // 7 vector operations + 1 exp per (slot, grid point)
+            const float4* p = obs + poff[k];
+            float gv = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll 1
+            for (int j = 0; j < nj; j += WU) {
+                float4 o[WU];
+#pragma unroll
+                for (int i = 0; i < WU; ++i) o[i] = p[(j + i) * S];     // (at most slot nw + 10: zero weight)
+#pragma unroll
+                for (int i = 0; i < WU; ++i) {
+                    const float d = o[i].x - ref[k];
+                    const float u = d * d;
+                    const float ex = fast_exp2(nb[k] * u);
+                    gv = fmaf(o[i].y, ex, gv);
+                    const float eu = ex * u;
+                    q2 = fmaf(o[i].y, eu, q2);
+                    q1 = fmaf(o[i].z, eu, q1);
+                }
+            }
+            gacc[k] += fmaf(-vr[k], q2, q1);
+            // sum over the 4 splits of a (row, grid point): two quad permutes on the vector ALU (no LDS round trip)
+            gv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gv), 0xB1, 0xF, 0xF, false));
+            gv += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gv), 0x4E, 0xF, 0xF, false));
+            if (s == 0) a.grad_v[(size_t)e * vstep + voff[k]] = gv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // per-channel sums of this wave's dL/dbeta terms, then the 4 waves of the workgroup: one partial row per workgroup
+    float chan[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) chan[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int row_lo = (QPR * k) / R, row_hi = (QPR * k + QPR - 1) / R;
+        chan[row_lo] += rowl[k] == row_lo ? gacc[k] : 0.f;
+        if (row_hi != row_lo) chan[row_hi] += rowl[k] == row_hi ? gacc[k] : 0.f;
+    }
+    float* red = smem + (kBlock / kWave) * C * stride * 4;       // behind the 4 waves' slot buffers
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float t = wave_sum(chan[c]);
+        if (lane == 0) red[wave * C + c] = t;
+    }
+    __syncthreads();
+    if (tid < C) a.partials[(size_t)blockIdx.x * C + tid] = (red[tid] + red[C + tid]) + (red[2 * C + tid] + red[3 * C + tid]);
 }
 
 __global__ __launch_bounds__(256) void rbf_bwd_finalize(const float* partials, int nblk, int C, const float* rbf_kernel,
@@ -351,11 +555,26 @@ static void rbf_bwd_geometry(int B, int C, int T, int R, int* E, int* nblk, size
     *lds = (size_t)rbf_bwd_layout(*E, C, R, T).total_words * 4;
 }
 
+// wave-per-encounter variant (rbf_bwd_wave_kernel): workgroups of 4 waves, as many as stay resident, trimmed so that every wave
+// gets the same number of encounters (to within one)
+static bool rbf_bwd_wave_geometry(int B, int C, int T, int R, int* nblk, size_t* lds) {
+    if (!(C == 6 && R == 24)) return false;
+    const int wpb = kBlock / kWave;
+    *lds = (size_t)wpb * C * rbf_row_stride(T) * sizeof(float4) + (size_t)wpb * C * sizeof(float);
+    if (*lds > 48 * 1024) return false;
+    const int resident = (int)min((size_t)8, (size_t)160 * 1024 / *lds) * kNumCU;
+    int n = min((B + wpb - 1) / wpb, resident);
+    const int per = (B + n * wpb - 1) / (n * wpb);         // encounters per wave
+    *nblk = (B + per * wpb - 1) / (per * wpb);
+    return true;
+}
+
 size_t dic_rbf_bwd_workspace(int B, int C, int T, int R) {
     if (B <= 0 || C <= 0 || T <= 0 || R <= 0) return 0;
-    int E, nblk; size_t lds;
+    int E, nblk, nblk2 = 0; size_t lds;
     rbf_bwd_geometry(B, C, T, R, &E, &nblk, &lds);
-    return (size_t)nblk * C * sizeof(float);
+    rbf_bwd_wave_geometry(B, C, T, R, &nblk2, &lds);
+    return (size_t)max(nblk, nblk2) * C * sizeof(float);
 }
 
 int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
@@ -370,6 +589,14 @@ int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int
     a.ref_grid = ref_grid; a.rbf_kernel = rbf_kernel; a.v = v; a.y = y; a.norm = norm; a.grad_y = grad_y;
     a.grad_v = grad_v; a.partials = (float*)workspace; a.v_rbc = v_time_major != 0;
     size_t lds;
+    hipStream_t st = (hipStream_t)stream;
+    if (lengths && (size_t)B * C * R < ((size_t)1 << 31) && rbf_bwd_wave_geometry(B, C, T, R, &a.nblk, &lds)) {
+        DIC_REQUIRE(workspace_bytes >= (size_t)a.nblk * C * sizeof(float), DIC_ERR_WORKSPACE, "rbf_bwd: workspace too small");
+        hipLaunchKernelGGL((rbf_bwd_wave_kernel<6, 24>), dim3(a.nblk), dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL(rbf_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)workspace, a.nblk, C, rbf_kernel,
+                           grad_rbf_kernel);
+        return check_launch("rbf_bwd");
+    }
     rbf_bwd_geometry(B, C, T, R, &a.E, &a.nblk, &lds);
     DIC_REQUIRE(lds <= 64 * 1024, DIC_ERR_UNSUPPORTED, "rbf_bwd: one encounter needs %zu B of LDS", lds);
     DIC_REQUIRE(workspace_bytes >= (size_t)a.nblk * C * sizeof(float), DIC_ERR_WORKSPACE, "rbf_bwd: workspace too small");
@@ -384,7 +611,6 @@ int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int
             if (cost < best * 0.97) { best = cost; a.S = cand; a.logS = lg; }
         }
     }
-    hipStream_t st = (hipStream_t)stream;
     switch (a.S) {
 #define DIC_RBF_BWD(SS)                                                                                                   \
         if (C == 6 && R == 24) hipLaunchKernelGGL((rbf_bwd_kernel<SS, 6, 24>), dim3(a.nblk), dim3(kBlock), lds, st, a);       \

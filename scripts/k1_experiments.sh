@@ -1,5 +1,6 @@
 #!/bin/bash
-# Where does sci_cci_fwd's time go?  Rebuild with the streaming passes removed and compare (scripts/kbench.py).
+# Where does sci_cci_fwd's time go?  Rebuild dic_interp.hip with each flag set given as an argument (default: with and without the
+# streaming passes) and time it with scripts/kbench.py; "timing" = per-phase cycle stamps of the generic tile kernel.  Run on the GPU box.
 set -e
 cd "$(dirname "$0")/.."
 build() {
@@ -10,7 +11,8 @@ if [ "$1" == "timing" ]; then
   build "-DDIC_K1_EXP_TIMING"; python scripts/k1_timing.py 2>&1 | grep -v amdgpu.ids
   build ""; exit 0
 fi
-for flags in "" "-DDIC_K1_EXP_NOLOOP"; do
+if [ $# -eq 0 ]; then set -- "" "-DDIC_K1_EXP_NOLOOP"; fi
+for flags in "$@"; do
   build "$flags"; echo "== flags: [$flags]"
   python scripts/kbench.py 32768 10 2>/dev/null | grep "sci_cci_fwd"
 done

@@ -119,6 +119,53 @@ def test_sci_cci_vs_oracle(ops, shape):
     np.testing.assert_allclose(kc.grad.cpu().numpy(), k2.grad.numpy(), rtol=2e-4, atol=2e-4 * float(k2.grad.abs().max()))
 
 
+@pytest.mark.parametrize('B,T,lam,packed', [(1, 30, 9, False), (37, 96, 80, True), (1027, 96, 50, True), (130, 64, 40, False), (9, 100, 3, True)])
+def test_sci_cci_forward_reference_shape_corner_cases(ops, B, T, lam, packed):
+    """The reference's own shape (C = 6, R = 24, prefix masks): rows longer than one 64-slot chunk next to short ones, an empty channel
+    (NaN / -inf exactly as upstream), odd batch sizes, both output layouts and the saved moments (through the parameter
+    gradients) -- against the fp64 oracle."""
+    C, R, H = 6, 24, 24.0
+    x, n = vitals_stack(500 + B, B, C, T, H, lam)
+    if B > 8:
+        n[3, 2] = 0                                                  # an empty channel
+        for pl in range(4):
+            x[3, pl * C + 2, :] = 0.0
+        n[5, 1] = min(T, int(n[5, 1]) + 30)                          # a long row next to short ones
+        k = int(n[5, 1])
+        rng5 = np.random.default_rng(1)
+        x[5, C + 1, :k] = 1.0
+        x[5, 2 * C + 1, :k] = np.sort(rng5.uniform(0, H, k)).astype(np.float32)
+        x[5, 1, :k] = rng5.normal(0, 1.2, k).astype(np.float32)
+    rng = np.random.default_rng(B)
+    ks_np = rng.uniform(-0.5, 1.5, C).astype(np.float32)
+    kc_np = (np.eye(C) + rng.normal(0, 0.2, (C, C))).astype(np.float32)
+    cot_np = rng.normal(0, 1, (B, R, 3 * C)).astype(np.float32)
+    grid = ops.ref_grid(H, R, 'cuda')
+    ks, kc = G(ks_np, True), G(kc_np, True)
+    lens = G(n, dtype=torch.int32)
+    x64 = torch.tensor(x, dtype=torch.float64)
+    k1, k2 = torch.tensor(ks_np, dtype=torch.float64, requires_grad=True), torch.tensor(kc_np, dtype=torch.float64, requires_grad=True)
+    ref = O.sci_cci_forward(x64, k1, k2, R, H)
+    refn = ref.detach().numpy()
+    if packed:
+        rows = ops.sci_cci_packed(G(x), ks, kc, grid, lens)                     # (R,B,32) bf16 [features | 1 | 0...]
+        got = rows[:, :, :3 * C].float().permute(1, 0, 2).detach().cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(refn))
+        np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(refn), rtol=1e-2, atol=1e-2)      # bf16 rows
+        tail = rows[:, :, 3 * C:].float().detach().cpu().numpy()
+        assert (tail[:, :, 0] == 1).all() and (tail[:, :, 1:] == 0).all()
+        return
+    out = ops.sci_cci(G(x), ks, kc, grid, lengths=lens)
+    assert np.array_equal(np.isnan(out.detach().cpu().numpy()), np.isnan(refn))
+    np.testing.assert_allclose(np.nan_to_num(out.detach().cpu().numpy()), np.nan_to_num(refn), rtol=RT, atol=AT)
+    if B > 8:
+        return                                                       # (an empty channel makes the parameter gradients NaN, upstream too)
+    (out * G(cot_np)).sum().backward()
+    (ref * torch.tensor(cot_np, dtype=torch.float64)).sum().backward()
+    np.testing.assert_allclose(ks.grad.cpu().numpy(), k1.grad.numpy(), rtol=2e-4, atol=2e-4 * float(k1.grad.abs().max()))
+    np.testing.assert_allclose(kc.grad.cpu().numpy(), k2.grad.numpy(), rtol=2e-4, atol=2e-4 * float(k2.grad.abs().max()))
+
+
 # ------------------------------------------------------------------------------------ k2 golden
 @pytest.mark.parametrize('name', RBF)
 def test_rbf_golden(ops, name):
@@ -167,6 +214,45 @@ def test_rbf_vs_oracle(ops, shape):
     (ref * torch.tensor(cot, dtype=torch.float64)).sum().backward()
     np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), rtol=RT, atol=3e-6)
     np.testing.assert_allclose(v.grad.cpu().numpy(), v64.grad.numpy(), rtol=2e-4, atol=2e-5 * float(v64.grad.abs().max()))
+    np.testing.assert_allclose(k.grad.cpu().numpy(), k64.grad.numpy(), rtol=3e-4, atol=3e-5 * float(k64.grad.abs().max()))
+
+
+@pytest.mark.parametrize('B,T,lam,time_major,prefix_only', [(1, 30, 9, False, False), (37, 96, 80, True, True), (1027, 96, 50, True, True),
+                                                           (130, 64, 40, False, True), (9, 100, 3, True, False)])
+def test_rbf_backward_reference_shape_kernel(ops, B, T, lam, time_major, prefix_only):
+    """The wave-per-encounter backward (C = 6, R = 24, prefix masks): rows longer than one 64-slot chunk, empty rows, a batch that is
+    not a multiple of the wave count, v / grad_v in CompressFC's (R,B,C) row order, and padding the forward never wrote
+    (prefix_only: poisoned with NaN here) -- against the fp64 oracle."""
+    C, R, H = 6, 24, 24.0
+    x, n = vitals_stack(300 + B, B, C, T, H, lam)
+    if B > 8:
+        n[3, 2] = 0                                                  # an empty channel
+        x[3, 2, :] = 0.0; x[3, C + 2, :] = 0.0; x[3, 2 * C + 2, :] = 0.0; x[3, 3 * C + 2, :] = 0.0
+        n[5, 1] = min(T, int(n[5, 1]) + 30)                          # a long row next to short ones
+        x[5, C + 1, :n[5, 1]] = 1.0
+        x[5, 2 * C + 1, :n[5, 1]] = np.sort(np.random.default_rng(1).uniform(0, H, n[5, 1])).astype(np.float32)
+    rng = np.random.default_rng(B)
+    v_np = rng.normal(0, 1, (B, C, R)).astype(np.float32)
+    k_np = rng.uniform(-0.5, 1.5, C).astype(np.float32)
+    cot = rng.normal(0, 1, (B, C, T)).astype(np.float32)
+    grid = ops.ref_grid(H, R, 'cuda')
+    k = G(k_np, True)
+    if time_major:
+        v_rows = G(np.ascontiguousarray(v_np.transpose(2, 0, 1)), True)          # (R,B,C) leaf; the op sees the permuted view
+        v = v_rows.permute(1, 2, 0)
+    else:
+        v_rows = v = G(v_np, True)
+    lens = G(n, dtype=torch.int32)
+    y = ops.rbf_deinterp(v, G(x), k, grid, lengths=lens, prefix_only=prefix_only)
+    keep = torch.arange(T, device='cuda')[None, None, :] < lens[:, :, None]
+    g = torch.where(keep, G(cot), torch.full_like(y, float('nan')) if prefix_only else torch.zeros_like(y))
+    y.backward(g)
+    v64 = torch.tensor(v_np, dtype=torch.float64, requires_grad=True)
+    k64 = torch.tensor(k_np, dtype=torch.float64, requires_grad=True)
+    ref = O.rbf_deinterp(v64, torch.tensor(x, dtype=torch.float64), k64, R, H)
+    (ref * torch.tensor(cot, dtype=torch.float64)).sum().backward()
+    gv = v_rows.grad.permute(1, 2, 0) if time_major else v_rows.grad
+    np.testing.assert_allclose(gv.cpu().numpy(), v64.grad.numpy(), rtol=2e-4, atol=2e-5 * float(v64.grad.abs().max()))
     np.testing.assert_allclose(k.grad.cpu().numpy(), k64.grad.numpy(), rtol=3e-4, atol=3e-5 * float(k64.grad.abs().max()))
 
 
