@@ -270,6 +270,162 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
             }
 }
 
+// ------------------------------------------------------------------------------------------------ fused dW (decoder, 256-wide input)
+// The same one-pass product for the decoder LSTM, whose input rows are the 256 rectified encoder outputs: per direction
+// dW[512 gate rows][128 h | 256 x] = sum over (t, b) rows.  The 384 output columns are 12 n-blocks, so a workgroup takes HALF of a
+// direction's gate rows: grid (nch, 4 = direction x half); wave w owns 2 m-blocks (64 gate rows, w & 3) x 6 n-blocks (w >> 2) = 192
+// accumulator registers and reads 2 + 6 operand fragments per k-step (1 x 12 would read 13: the kernel is bound by LDS fragment
+// reads + MFMA issue, 0.55 ms that way).
+// The four workgroups of a chunk walk the same rows at the same time and sit on the same XCD (nch is a multiple of 8 and the
+// dispatcher deals workgroup ids round-robin over the 8 XCDs), so the x and h tiles they share come out of that XCD's L2 for three
+// of them: HBM sees dG once and x, h about once, instead of the three library GEMMs' 1.6 + 1.6 + 0.8 GB.
+// Tile image: dG half rows, x rows (512 B each, two per LDS-DMA instruction) and h rows (256 B, four per instruction), all with the
+// 16-B pieces XOR-swizzled by (row & 3) << 2 through the DMA's SOURCE addresses (rows at a 256-B-multiple pitch would otherwise put
+// the 4 rows of a transposed read on the same banks).
+constexpr int DXW = 256;                    // decoder input width
+constexpr int DNW = GH + DXW;               // 384 B-operand columns [h_prev | x]
+constexpr int DMH = G4 / 2;                 // gate rows per workgroup
+static_assert(DNW / 32 == 12, "12 n-blocks = 2 wave groups x 6");
+constexpr int WD_DG = TR * DMH * 2, WD_H = TR * GH * 2, WD_X = TR * DXW * 2;      // 16 KB, 8 KB, 16 KB
+constexpr int WD_SLOT = WD_DG + WD_H + WD_X;                                       // 40 960 B
+constexpr int WD_LDS = NBUF * WD_SLOT;                                             // 122 880 B
+constexpr int WD_OUT = 4 * DMH * DNW;       // outputs per partial: [direction x half][gate row][h cols | x cols]
+
+struct DwWideArgs {
+    const __bf16* dg;      // (R*B, 2, 4H)
+    const __bf16* hext;    // ((R+2)*B, 2H): see DwArgs
+    const __bf16* x;       // (R*B, 256)
+    float* partials;       // (gridDim.x, 4, 256, 384)
+    int R, B;
+};
+
+__global__ __launch_bounds__(512) void lstm_dw_wide_kernel(DwWideArgs a) {
+    extern __shared__ __align__(16) unsigned char dwsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y >> 1, mh = blockIdx.y & 1;
+    const long nrows = (long)a.R * a.B;
+    const int ntiles = (int)((nrows + TR - 1) / TR), nch = gridDim.x;
+    const __bf16* hsrc = a.hext + (dir ? (size_t)2 * a.B * 2 * GH + GH : 0);        // row i of this view = h_prev of row i
+    const __bf16* gsrc = a.dg + (size_t)dir * G4 + mh * DMH;                           // row i: + i * 2 * G4
+
+    const int mg = w & 3, ng = w >> 2;
+    f32x16 acc[2][6];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 6; ++nb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[mb][nb][k] = 0.f;
+
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)dwsm);
+    // 512-B rows, two per instruction: lane = 32 (row in pair) + stored piece; rows 2 p + (lane >> 5) with p = w, w + 8: (row & 3) is a
+    // per-lane constant.  256-B rows, four per instruction: lane = 16 (row in quad) + stored piece, rows 4 w + (lane >> 4).
+    const int r2 = lane >> 5, sw2 = ((2 * (w & 1) + r2) & 3) << 2;
+    const unsigned v_dg = r2 * (2 * G4 * 2) + (((lane & 31) ^ sw2) * 16);
+    const unsigned v_x = r2 * (DXW * 2) + (((lane & 31) ^ sw2) * 16);
+    const unsigned v_h = (lane >> 4) * (2 * GH * 2) + (((lane & 15) ^ ((lane >> 4) << 2)) * 16);
+    auto request = [&](int tile, int slot) {
+        const long r0 = min((long)tile * TR, nrows - TR);
+        const unsigned base = lds0 + slot * WD_SLOT;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int row = 2 * (w + 8 * p);
+            dma16(gsrc + (size_t)(r0 + row) * 2 * G4, v_dg, base + row * (DMH * 2));
+            dma16(a.x + (size_t)(r0 + row) * DXW, v_x, base + WD_DG + WD_H + row * (DXW * 2));
+        }
+        dma16(hsrc + (size_t)(r0 + w * 4) * 2 * GH, v_h, base + WD_DG + w * 4 * (GH * 2));
+    };
+
+    // transposed reads: see lstm_dw_kernel.  Piece (16 B) index of columns 16 cb + 4 kp.. of 32-column block j: 4 j + 2 cb + (kp >> 1),
+    // stored at index ^ (kq << 2) ((row & 3) == kq for both reads of a fragment)
+    const int kq = (lane & 15) >> 2, kp = lane & 3, cb = (lane >> 4) & 1, hh = lane >> 5;
+    const int rowoff = 8 * hh + kq;
+    auto piece = [&](int j) { return (((4 * j + 2 * cb + (kp >> 1)) ^ (kq << 2)) * 16) + (kp & 1) * 8; };
+    int pa_off[2], pb_off[6], pb_pitch[6];         // n-block j = 6 ng + i of [h (4 blocks) | x (8 blocks)]
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) pa_off[mb] = rowoff * (DMH * 2) + piece(2 * mg + mb);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int j = 6 * ng + i;
+        pb_pitch[i] = j < 4 ? GH * 2 : DXW * 2;
+        pb_off[i] = j < 4 ? WD_DG + rowoff * (GH * 2) + piece(j) : WD_DG + WD_H + rowoff * (DXW * 2) + piece(j - 4);
+    }
+    auto frag = [&](const unsigned char* p, int pitch) {
+        const s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 4 * pitch);
+        s16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+        return __builtin_bit_cast(bf16x8, f);
+    };
+
+    int tile = blockIdx.x, slot = 0;
+    if (tile < ntiles) request(tile, 0);
+    if (tile + nch < ntiles) request(tile + nch, 1);
+    for (; tile < ntiles; tile += nch) {
+        if (tile + nch < ntiles) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");       // 5 = LDS-DMA instructions per wave and tile
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tile + 2 * nch < ntiles) request(tile + 2 * nch, slot == 0 ? 2 : slot - 1);
+        unsigned char* base = dwsm + slot * WD_SLOT;
+        if ((long)tile * TR + TR > nrows) {        // the shifted last tile: its first rows were summed by the previous tile already
+            const int dup = (int)((long)tile * TR + TR - nrows);
+            const int nh = dup * GH * 2 / 16, nx = dup * DXW * 2 / 16;
+            for (int i = tid; i < nh + nx; i += 512) {
+                unsigned char* dst = i < nh ? base + WD_DG + i * 16 : base + WD_DG + WD_H + (i - nh) * 16;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+#ifdef DIC_DWW_EXP_NOMMA        // experiment (scripts/dww_experiments.sh): the DMA ring and barriers alone
+        const int nks = a.R < 0 ? 1 : 0;
+#else
+        const int nks = TR / 16;
+#endif
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            bf16x8 af[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) af[mb] = frag(base + ks * 16 * (DMH * 2) + pa_off[mb], DMH * 2);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bf16x8 bfg = frag(base + ks * 16 * pb_pitch[i] + pb_off[i], pb_pitch[i]);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfg, acc[mb][i], 0, 0, 0);
+            }
+        }
+        slot = slot == NBUF - 1 ? 0 : slot + 1;
+    }
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float* o = a.partials + ((size_t)blockIdx.x * 4 + blockIdx.y) * DMH * DNW;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int m = 64 * mg + 32 * mb + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                o[(size_t)m * DNW + 32 * (6 * ng + i) + (lane & 31)] = acc[mb][i][k];
+            }
+}
+
+__global__ __launch_bounds__(256) void lstm_dw_wide_finalize(const float* partials, int nch, LstmGrads g, float beta) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(partials, nch, WD_OUT, blockIdx.x * 32, red);
+    const int i = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x >= 32 || i >= WD_OUT) return;
+    const int part = i / (DMH * DNW), rem = i - part * (DMH * DNW), m = (part & 1) * DMH + rem / DNW, n = rem % DNW, d = part >> 1;
+    float* dst = n < GH ? g.w_hh[d] + (size_t)m * GH + n : g.w_ih[d] + (size_t)m * DXW + (n - GH);
+    *dst = beta != 0.f ? fmaf(beta, *dst, (float)s) : (float)s;
+}
+
+static int dw_wide_chunks(int R, int B) {
+    const int ntiles = (int)(((long)R * B + TR - 1) / TR);
+    const int n = max(1, min(ntiles, kNumCU / 4));      // x 4 (direction, half) = one workgroup per CU
+    return n >= 8 ? n / 8 * 8 : n;                      // a multiple of 8: the four workgroups of a chunk land on one XCD
+}
+
 // out_i = sum over workgroups of partial_i (fixed order, f64), scattered into the nn.LSTM gradients: h columns -> weight_hh,
 // x columns [0, I) -> weight_ih (column I of the packed input is the constant one: its sum is the bias gradient, which the
 // recurrence backward already delivers in f32).  beta = 0 overwrites, 1 accumulates.
@@ -387,6 +543,37 @@ int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, const void*
     hipLaunchKernelGGL(lstm_dw_finalize, dim3((DW_OUT + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, I, g,
                        accumulate ? 1.0f : 0.0f);
     return check_launch("lstm_dw");
+}
+
+size_t dic_lstm_dw_wide_workspace(int R, int B) {
+    if (R <= 0 || B <= 0) return 0;
+    return (size_t)dw_wide_chunks(R, B) * WD_OUT * sizeof(float);
+}
+
+int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int R, int B, int H, int I, float* const* grads, int accumulate,
+                     void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_dw_wide: non-positive size");
+    DIC_REQUIRE(H == GH, DIC_ERR_UNSUPPORTED, "lstm_dw_wide: hidden size %d (compiled for %d)", H, GH);
+    DIC_REQUIRE(I == DXW, DIC_ERR_UNSUPPORTED, "lstm_dw_wide: input width %d (compiled for %d)", I, DXW);
+    DIC_REQUIRE(dgx && out_ext && x && workspace, DIC_ERR_INVALID_ARG, "lstm_dw_wide: NULL pointer");
+    DIC_REQUIRE((long)R * B >= TR, DIC_ERR_UNSUPPORTED, "lstm_dw_wide: R*B = %ld rows < one %d-row tile (use the GEMM path)", (long)R * B, TR);
+    LstmGrads g;
+    int rc = grads_from(grads, &g, true, false, "lstm_dw_wide");
+    if (rc) return rc;
+    const int nch = dw_wide_chunks(R, B);
+    DIC_REQUIRE(workspace_bytes >= (size_t)nch * WD_OUT * sizeof(float), DIC_ERR_WORKSPACE, "lstm_dw_wide: workspace %zu < %zu", workspace_bytes,
+                (size_t)nch * WD_OUT * sizeof(float));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_dw_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WD_LDS);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_dw_wide: cannot reserve %d B of LDS: %s", WD_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    DwWideArgs a{(const __bf16*)dgx, (const __bf16*)out_ext, (const __bf16*)x, (float*)workspace, R, B};
+    hipLaunchKernelGGL(lstm_dw_wide_kernel, dim3(nch, 4), dim3(512), WD_LDS, st, a);
+    hipLaunchKernelGGL(lstm_dw_wide_finalize, dim3((WD_OUT + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, g, accumulate ? 1.0f : 0.0f);
+    return check_launch("lstm_dw_wide");
 }
 
 int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,

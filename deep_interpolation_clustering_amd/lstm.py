@@ -33,6 +33,7 @@ PARAM_NAMES = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
                'weight_ih_l0_reverse', 'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
 
+WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
 SMALL_BATCH = 4096             # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
 
 
@@ -187,6 +188,12 @@ class _BiLstm(torch.autograd.Function):
                 if dxp is not None:
                     dx = dxp[0] + dxp[1]                             # (columns >= 19 of the partials are never written, nor read downstream)
                     dx = dx.view(R, B, Ip) if packed else dx[:, :I].reshape(R, B, I).to(ctx.x_dtype)
+                N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
+            elif (not f32) and I == WIDE_INPUT and Ip == I and R * B >= 32:
+                # decoder: dW_ih and dW_hh of both directions from one pass over dG (csrc/dic_lstmgrad.hip, lstm_dw_wide_kernel)
+                ws2 = torch.empty(max(16, Lb.dic_lstm_dw_wide_workspace(R, B)), device=dev, dtype=torch.uint8)
+                N.check(Lb.dic_lstm_dw_wide(N.ptr(dgx), N.ptr(out_ext), N.ptr(xb), R, B, H, I, gp, int(accumulate), N.ptr(ws2), ws2.numel(), st),
+                        'dic_lstm_dw_wide')
                 N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             else:
                 # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split-K bmm (ops.splitk_tn).

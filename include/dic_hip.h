@@ -277,6 +277,9 @@ int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const vo
  *     directions) -- the third GEMM that used to re-read dG.  Deterministic two-stage reduction of the weight gradients, written
  *     (accumulate = 0) or added (accumulate = 1) straight into the
  *     parameter gradients `grads` (host array of 8 device pointers, same order; the bias entries are not touched).
+ *   dic_lstm_dw_wide (decoder, input width I == 256 = the rectified encoder outputs, x (R,B,256) bf16): the same one-pass weight
+ *     gradients -- four workgroups (direction x half of the gate rows) per chunk of rows, placed on one XCD so that the x / h tiles they
+ *     share are served by its L2 -- instead of the three split-K library products that each re-read dG (decoder dW 0.90 -> see DESIGN.md).
  *   dic_lstm_unpack_grads: staging tensors dw_ih (2*4H, ldw) / dw_hh (2,4H,H) / dbias (2*4H) f32 (each may be NULL) ->
  *     the parameter gradients (dbias goes to bias_ih AND bias_hh). */
 int dic_lstm_pack(int dtype, const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
@@ -284,6 +287,9 @@ int dic_lstm_pack(int dtype, const float* const* params, int H, int I, int Ip, i
 size_t dic_lstm_dw_workspace(int R, int B);
 int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, const void* wih, void* dx_parts, int R, int B, int H, int I, int Ip,
                 float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+size_t dic_lstm_dw_wide_workspace(int R, int B);
+int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int R, int B, int H, int I, float* const* grads, int accumulate,
+                     void* workspace, size_t workspace_bytes, dic_stream_t stream);
 int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,
                           int accumulate, dic_stream_t stream);
 

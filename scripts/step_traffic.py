@@ -12,20 +12,24 @@ def per_step(path, counter, n=4):
     marks = [i for i, r in enumerate(rows) if 'adam_amsgrad_kernel' in r['Kernel_Name']]
     # steps 2..5 of the run (2 warm-up + 6 timed steps come first; bench.py's kernel table and step trace launch more kernels afterwards)
     lo, hi = marks[1] + 1, marks[1 + n] + 1
-    by = {}
+    by, kern = {}, {}
     for r in rows[lo:hi]:
         k = r['Kernel_Name']
         c = 'lstm_recurrence' if 'lstm_' in k else 'library_gemm' if 'Cijk' in k else 'other_hip_kernels' if 'dic' in k else 'torch_elementwise'
         by[c] = by.get(c, 0.0) + float(r['Counter_Value']) * 1024 / n
-    return by
+        short = k.split('(')[0].replace('void ', '')[:64]
+        kern[short] = kern.get(short, 0.0) + float(r['Counter_Value']) * 1024 / n
+    return by, kern
 
 
-f, w = per_step(sys.argv[1], 'FETCH_SIZE'), per_step(sys.argv[2], 'WRITE_SIZE')
+(f, fk), (w, wk) = per_step(sys.argv[1], 'FETCH_SIZE'), per_step(sys.argv[2], 'WRITE_SIZE')
 out = {'_note': 'HBM bytes per joint step at B=32768 (bench.py defaults): read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024; '
                 'separate rocprofv3 --pmc passes, mean of 4 steps (scripts/step_traffic.py)'}
 for c in sorted(set(f) | set(w)):
     out[c] = {'read_bytes': int(2 * f.get(c, 0)), 'write_bytes': int(w.get(c, 0))}
-out['total_bytes'] = int(sum(v['read_bytes'] + v['write_bytes'] for k, v in out.items() if isinstance(v, dict)))
+per_kernel = {k: int(2 * fk.get(k, 0) + wk.get(k, 0)) for k in set(fk) | set(wk)}
+out['per_kernel_bytes(top)'] = dict(sorted(per_kernel.items(), key=lambda kv: -kv[1])[:24])
+out['total_bytes'] = int(sum(v['read_bytes'] + v['write_bytes'] for k, v in out.items() if isinstance(v, dict) and 'read_bytes' in v))
 out['_batch'], out['_round'] = 32768, int(sys.argv[3]) if len(sys.argv) > 3 else 2
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'step_traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))

@@ -420,6 +420,48 @@ def test_lstm_dw_matches_matmul(R, B, I, init, accumulate):
         assert torch.equal(grads[4 * d + 2], before[4 * d + 2]) and torch.equal(grads[4 * d + 3], before[4 * d + 3])     # biases untouched
 
 
+@pytest.mark.parametrize('R,B,init,accumulate', [(24, 200, False, False), (3, 64, True, True), (5, 130, True, False), (1, 37, False, True),
+                                                   (2, 4099, True, False), (24, 1024, True, True)])
+def test_lstm_dw_wide_matches_matmul(R, B, init, accumulate):
+    """dic_lstm_dw_wide (decoder: 256-wide input, one pass over dG by four workgroups per row chunk) against f64 products of the
+    same bf16 operands, incl. the shifted last tile of a row count that is not a multiple of 32."""
+    from deep_interpolation_clustering_amd import _native as N
+    torch.manual_seed(R * 100 + B)
+    dev = torch.device('cuda')
+    bf, I = torch.bfloat16, 256
+    dg = (torch.randn(R, B, 2, 4 * H, device=dev) * 0.3).to(bf)
+    out = (torch.randn(R, B, 2 * H, device=dev) * 0.5).to(bf)
+    x = torch.randn(R, B, I, device=dev).clamp_min(0).to(bf)
+    h0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    grads = [torch.randn(4 * H, I, device=dev), torch.randn(4 * H, H, device=dev), torch.randn(4 * H, device=dev), torch.randn(4 * H, device=dev)] * 2
+    grads = [g.clone() for g in grads]
+    before = [g.clone() for g in grads]
+    L = N.lib()
+    ws = torch.empty(L.dic_lstm_dw_wide_workspace(R, B), dtype=torch.uint8, device=dev)
+    out_ext = torch.full((R + 2, B, 2 * H), float('nan'), device=dev, dtype=bf)      # the halves the kernel must not read stay NaN
+    out_ext[1:R + 1] = out
+    out_ext[0, :, :H] = h0[0] if init else 0.0
+    out_ext[R + 1, :, H:] = h0[1] if init else 0.0
+    N.check(L.dic_lstm_dw_wide(N.ptr(dg), N.ptr(out_ext), N.ptr(x), R, B, H, I, N.ptr_array(grads), int(accumulate), N.ptr(ws), ws.numel(),
+                               N.stream_of(dg)), 'dic_lstm_dw_wide')
+    torch.cuda.synchronize()
+    d64, o64, x64 = dg.double(), out.double(), x.double()
+    for d in range(2):
+        hp = torch.zeros(R, B, H, device=dev, dtype=torch.float64)
+        h0d = h0[d].to(bf).double() if init else torch.zeros(B, H, device=dev, dtype=torch.float64)
+        if d == 0:
+            hp[0], hp[1:] = h0d, o64[:-1, :, :H]
+        else:
+            hp[-1], hp[:-1] = h0d, o64[1:, :, H:]
+        w_hh = torch.einsum('tbg,tbh->gh', d64[:, :, d], hp)
+        w_ih = torch.einsum('tbg,tbi->gi', d64[:, :, d], x64)
+        base_ih = before[4 * d].double() if accumulate else 0.0
+        base_hh = before[4 * d + 1].double() if accumulate else 0.0
+        assert float((grads[4 * d + 1].double() - (w_hh + base_hh)).abs().max()) <= 2e-5 * float(w_hh.abs().max()) + 1e-5
+        assert float((grads[4 * d].double() - (w_ih + base_ih)).abs().max()) <= 2e-5 * float(w_ih.abs().max()) + 1e-5
+        assert torch.equal(grads[4 * d + 2], before[4 * d + 2]) and torch.equal(grads[4 * d + 3], before[4 * d + 3])     # biases untouched
+
+
 @pytest.mark.parametrize('I,init', [(18, False), (256, True)])
 def test_lstm_param_grads_written_in_place(I, init):
     """With ``.grad`` tensors present (the flat bucket's views) the kernels ADD the parameter gradients into them and hand autograd
