@@ -175,6 +175,24 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
     calls['lstm_bwd'] = (lambda: L.dic_lstm_bwd(P(whh_t), P(lgates), P(lcs), None, P(ldout), None, None, R, B, Hh, P(ldgx), P(ldh0),
                                                 P(ldc0), P(ldb), P(ws6), ws6.numel(), 0, 0, st),
                          rows * (4 * Hh * 2 + Hh * 2 + Hh * 2 + 4 * Hh * 2))      # gates, c, dout in; dG out
+    # one-pass weight-gradient kernels (csrc/dic_lstmgrad.hip): encoder (32-wide packed input, dX fused) and decoder (256-wide input)
+    from deep_interpolation_clustering_amd import _native as N
+    if R * B >= 32:
+        oext = (torch.randn((R + 2, B, 2 * Hh), **f32) * 0.5).to(bf)
+        gr = [torch.zeros(4 * Hh, 18, **f32), torch.zeros(4 * Hh, Hh, **f32), torch.zeros(4 * Hh, **f32), torch.zeros(4 * Hh, **f32)]
+        grads_e = [g.clone() for g in gr + gr]
+        gr[0] = torch.zeros(4 * Hh, 256, **f32)
+        grads_d = [g.clone() for g in gr + gr]
+        gpe, gpd = N.ptr_array(grads_e), N.ptr_array(grads_d)
+        dxp = torch.empty((2, R * B, 32), device=dev, dtype=bf)
+        ws7 = torch.empty(max(16, L.dic_lstm_dw_workspace(R, B)), dtype=torch.uint8, device=dev)
+        ws8 = torch.empty(max(16, L.dic_lstm_dw_wide_workspace(R, B)), dtype=torch.uint8, device=dev)
+        xdec = torch.randn((R, B, 256), **f32).clamp_min(0).to(bf)
+        keep = (oext, grads_e, grads_d, dxp, ws7, ws8, xdec)
+        calls['lstm_dw'] = (lambda: L.dic_lstm_dw(P(ldgx), P(oext), P(xenc), P(wih), P(dxp), R, B, Hh, 18, 32, gpe, 0, P(ws7), ws7.numel(), st) + 0 * len(keep),
+                            rows * 4 * Hh * 2 + R * B * (2 * Hh * 2 + 32 * 2 + 2 * 32 * 2))   # dG once; h, x in; per-direction dX out
+        calls['lstm_dw_wide'] = (lambda: L.dic_lstm_dw_wide(P(ldgx), P(oext), P(xdec), R, B, Hh, 256, gpd, 0, P(ws8), ws8.numel(), st) + 0 * len(keep),
+                                 rows * 4 * Hh * 2 + R * B * (2 * Hh * 2 + 256 * 2))           # dG once; h, x once
 
 
 # ------------------------------------------------------------------------------------------ step trace
@@ -195,6 +213,8 @@ def _short(name):
 
 
 def _group(name):
+    if name.startswith('dic::lstm_dw'):
+        return 'lstm_weight_grad'
     if name.startswith('dic::lstm_'):
         return 'lstm_recurrence'
     if name.startswith('dic::'):
@@ -518,9 +538,10 @@ def main():
         log('kernel table done:', {k: v['ms'] for k, v in table.items()})
         # which kernel dominates the STEP: launches x duration from a trace of the timed step itself
         trace_name = {'sci_cci_fwd': 'dic::sci_cci_fwd_kernel', 'sci_cci_bwd': 'dic::sci_cci_bwd_kernel', 'rbf_fwd': 'dic::rbf_fwd_kernel',
-                      'rbf_bwd': 'dic::rbf_bwd_kernel', 'masked_sse_fwd': 'dic::masked_sse_kernel', 'masked_sse_bwd': 'dic::masked_sse_bwd_kernel',
+                      'rbf_bwd': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'), 'masked_sse_fwd': 'dic::masked_sse_kernel', 'masked_sse_bwd': 'dic::masked_sse_bwd_kernel',
                       'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': 'dic::lstm_fwd_kernel',
-                      'lstm_fwd_proj': 'dic::lstm_fwd_kernel', 'lstm_bwd': 'dic::lstm_bwd_kernel'}
+                      'lstm_fwd_proj': 'dic::lstm_fwd_kernel', 'lstm_bwd': 'dic::lstm_bwd_kernel', 'lstm_dw': 'dic::lstm_dw_kernel',
+                      'lstm_dw_wide': 'dic::lstm_dw_wide_kernel'}
         kernels = groups = None
         try:
             kernels, groups = step_trace(one_step, a.warmup + a.steps, 3)
@@ -530,7 +551,7 @@ def main():
         for name, row in table.items():
             launches = 1.0
             if kernels is not None:
-                hits = [v for k, v in kernels.items() if k.startswith(trace_name[name])]
+                hits = [v for k, v in kernels.items() if k.startswith(trace_name[name])]        # (str.startswith takes a tuple of prefixes too)
                 launches = sum(v['launches_per_step'] for v in hits)
                 if name in ('lstm_fwd', 'lstm_fwd_proj'):
                     launches = launches / 2            # one template, two instantiations (decoder / encoder), one launch each
