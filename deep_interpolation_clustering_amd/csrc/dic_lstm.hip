@@ -92,6 +92,7 @@ struct LstmFwdArgs {
     const __bf16* whh;     // (2,4H,H)
     const float* h0; const float* c0;     // (2,B,H) or NULL (zeros)
     __bf16* out;           // (R,B,2H): forward direction in [:H], reverse in [H:]
+    __bf16* out_relu;      // optional second output relu(out), same layout (what the decoder reads of the encoder: clustering_interp.py:38-41)
     float* hn; float* cn;  // (2,B,H)
     __bf16* gates;         // lane-native (R,Bpad,2,4,H) post-activation i,f,g,o, or NULL (inference)
     __bf16* cs;            // lane-native (R,Bpad,2,H) cell states rounded to bf16 (the recurrence itself carries c in f32), or NULL
@@ -183,7 +184,25 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
         request_gx(0);
     }
     __syncthreads();
-
+    // The rectified copy of the output (what the decoder reads of the encoder) leaves through the LDS tile of h that the next step
+    // multiplies anyway, as whole 256-B row halves per 16 lanes, issued at the start of the following step so that the stores drain
+    // under its MFMAs: four 16-B stores per lane and step replace an element-wise pass over (R,B,2H) (read + write, 0.15 ms at
+    // B = 32768).  (The raw rows keep going out of the accumulator registers: moving them to this path as well was measured 9 %
+    // slower for the whole kernel.)
+    auto store_relu_rows = [&](int t_of_rows, int buf) {
+        if (!a.out_relu) return;
+#pragma unroll
+        for (int k = 0; k < LBM * 16 / 256; ++k) {
+            const int i = k * 256 + tid, row = i >> 4, pc = i & 15;
+            if (b0 + row < B) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&hbuf[buf][row * HSTR + pc * 8]);
+                // relu on packed bf16 pairs: a half with its sign bit set becomes 0 ((sign >> 15) * 0xffff = that half's mask)
+                auto rl = [](unsigned x) { return x & ~(((x & 0x80008000u) >> 15) * 0xffffu); };
+                *reinterpret_cast<uint4*>(a.out_relu + ((size_t)t_of_rows * B + b0 + row) * 2 * LH + dir * LH + pc * 8) =
+                    make_uint4(rl(v.x), rl(v.y), rl(v.z), rl(v.w));
+            }
+        }
+    };
     for (int step = 0; step < R; ++step) {
         const int t = dir ? R - 1 - step : step;
         const int cur = step & 1;
@@ -191,6 +210,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
         DIC_STAMP(0, step, 0);
         if constexpr (PROJ) {
             if (step + 1 < R) xnext = load_x(step + 1);        // in flight across the MFMA and gate-math phases
+            if (step > 0) store_relu_rows(dir ? R - step : step - 1, cur);
         } else {
             // accumulators start from the input projection of this step, brought into the accumulator layout BY the matrix core:
             // acc = I . gx^T with two 32x16 slices of the identity as A operand and 16-B row pieces of the staged tile as B
@@ -208,6 +228,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                 }
             lds_barrier();                                     // every wave has read its part of the staged tile
             if (step + 1 < R) request_gx(step + 1);
+            if (step > 0) store_relu_rows(dir ? R - step : step - 1, cur);      // (issued after the DMA: the counted wait below stays conservative)
         }
         DIC_STAMP(0, step, 1);
         const bool last = step == R - 1;
@@ -306,6 +327,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
         lds_barrier();
         DIC_STAMP(0, step, 4);
     }
+    store_relu_rows(dir ? 0 : R - 1, R & 1);               // the last step's rows (its h went to buffer (R - 1) & 1 ^ 1)
 }
 
 struct LstmBwdArgs {
@@ -549,23 +571,23 @@ static int lstm_fwd_launch(bool proj, const LstmFwdArgs& a, hipStream_t st) {
 }
 
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                 void* out, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream) {
+                 void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd: gates and cs go together");
-    LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0};
+    LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0};
     return lstm_fwd_launch(false, a, (hipStream_t)stream);
 }
 
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                      int I, void* out, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream) {
+                      int I, void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(I == LXK, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: input width %d (compiled for %d: zero-pad narrower inputs)", I, LXK);
     DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd_proj: gates and cs go together");
-    LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0};
+    LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0};
     return lstm_fwd_launch(true, a, (hipStream_t)stream);
 }
 

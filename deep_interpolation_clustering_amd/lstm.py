@@ -22,6 +22,8 @@ recurrence on exact-f32 MFMA (csrc/dic_lstm32.hip) instead of MIOpen's nn.LSTM; 
 one-tile-per-workgroup bf16 kernels too.  The bf16 path is checked against an f32 emulation with the same rounding points, the
 f32 path against nn.LSTM itself.
 """
+import os
+
 import torch
 
 from . import _native as N
@@ -33,6 +35,7 @@ PARAM_NAMES = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
                'weight_ih_l0_reverse', 'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
 
+RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B switch: 0 = rectify the encoder output with a torch pass)
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
 SMALL_BATCH = 4096             # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
 
@@ -111,6 +114,7 @@ class _BiLstm(torch.autograd.Function):
         h0c = None if h0 is None else N.f32c(h0)
         c0c = None if c0 is None else N.f32c(c0)
         gates = cs = None
+        out_r = torch.empty((R, B, 2 * H), device=dev, dtype=T) if (relu and not small and RELU_IN_KERNEL) else None     # written by the 64-row kernels themselves
         if small:
             if need:
                 Bp = (B + 31) // 32 * 32                           # kernel-native saved state is tiled by 32 rows
@@ -125,11 +129,11 @@ class _BiLstm(torch.autograd.Function):
                 gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=T)
                 cs = torch.empty((R, Bp, 2, H), device=dev, dtype=T)    # bf16 copy for the backward; c itself stays f32 on chip
             if proj:
-                N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out),
+                N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out), N.ptr(out_r),
                                             N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd_proj')
             else:
                 gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
-                N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn),
+                N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
                                        N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd')
         ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32), bool(relu))
         ctx.x_dtype = x.dtype
@@ -137,8 +141,11 @@ class _BiLstm(torch.autograd.Function):
         ctx.params = params
         ctx.save_for_backward(xb, wih, whh if f32 else whh_t, gates, cs, out_ext, h0c, c0c)
         # relu: the caller consumes relu(out) only (the decoder's input, clustering_interp.py:38-41).  The raw rows stay in out_ext for the
-        # weight-gradient products; the backward kernel applies the ReLU mask itself (sign of tanh(c_t)), so no mask pass and no saved copy
-        return (torch.relu(out) if relu else out), hn, cn
+        # weight-gradient products (the 64-row kernels write the rectified copy next to them); the backward kernel applies the ReLU
+        # mask itself (sign of tanh(c_t)), so no mask pass and no saved copy
+        if relu:
+            return (out_r if out_r is not None else torch.relu(out)), hn, cn
+        return out, hn, cn
 
     @staticmethod
     def backward(ctx, dout, dhn, dcn):

@@ -229,13 +229,16 @@ int dic_kmeans_pp_candidates_rows(const float* X, int N, int D, int row_lo, int 
  * state_batch_major != 0: h0, c0, hn, cn and their gradients are laid out (B,2,H) instead of nn.LSTM's (2,B,H), so that
  * hn viewed as (B,2H) is the concatenated latent [h_fwd | h_rev] (clustering_interp.py:139) and feeds the decoder with no copy. */
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                 void* out, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
+                 void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
+/* out_relu (R,B,2H) bf16 or NULL: a second copy of the output with relu applied -- what DecoderRNN.forward reads of the encoder's
+ * output (clustering_interp.py:38-41).  It leaves through the LDS tile of h the next step multiplies, as whole 256-B row halves;
+ * the element-wise ReLU pass over (R,B,2H) disappears (its backward: dic_lstm_bwd's dout_of_relu). */
 /* Same recurrence with the input projection computed in-kernel, for narrow inputs (the encoder's 3C channels):
  * G_t = x_t.wih^T + h_{t-1}.whh^T with x (R,B,I) bf16 and wih (2,4H,I) bf16, I == 32 (zero-pad narrower inputs; fold
  * the bias in as a constant-one input column whose weights are b_ih + b_hh).  Everything else as dic_lstm_fwd; the
  * backward is dic_lstm_bwd unchanged. */
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                      int I, void* out, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
+                      int I, void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
 size_t dic_lstm_bwd_workspace(int B);
 int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
