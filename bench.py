@@ -227,7 +227,10 @@ def _group(name):
     return 'other(copies, fills, rng)'
 
 
-def step_trace(one_step, first, n=3):
+TRACE_STEPS = 3
+
+
+def step_trace(one_step, first, n=TRACE_STEPS):
     """GPU time of every kernel of n joint steps, from the ROCm tracer behind torch.profiler (the same per-dispatch durations
     rocprofv3 --kernel-trace reports), aggregated per step: {kernel: launches/step, us/launch, ms/step} and per group."""
     from torch.autograd import DeviceType
@@ -544,10 +547,17 @@ def main():
                       'lstm_fwd_proj': 'dic::lstm_fwd_kernel', 'lstm_bwd': 'dic::lstm_bwd_kernel', 'lstm_dw': 'dic::lstm_dw_kernel',
                       'lstm_dw_wide': 'dic::lstm_dw_wide_kernel'}
         kernels = groups = None
+        ran = [0]
+
+        def counted_step(i):
+            ran[0] += 1
+            return one_step(i)
         try:
-            kernels, groups = step_trace(one_step, a.warmup + a.steps, 3)
+            kernels, groups = step_trace(counted_step, a.warmup + a.steps, TRACE_STEPS)    # (sharded: the other ranks run these steps with it, below)
         except Exception as e:
             log('step trace unavailable:', repr(e))
+        for i in range(ran[0], TRACE_STEPS if world > 1 else 0):                              # stay in lockstep with the other ranks whatever the tracer did
+            one_step(a.warmup + a.steps + i)
         per_step = {}
         for name, row in table.items():
             launches = 1.0
@@ -626,6 +636,12 @@ def main():
             out['cfg5'] = guarded(record_cfg5, dev, not a.no_sweep)
             log('cfg5 done')
         print(json.dumps(out))
+    elif world > 1:
+        # rank 0 traces TRACE_STEPS more optimisation steps for the roofline record: a sharded step is full of collectives (loss
+        # sums, BatchNorm moments, the gradient bucket), so every rank has to run them with it or rank 0 waits forever
+        for i in range(TRACE_STEPS):
+            one_step(a.warmup + a.steps + i)
+        torch.cuda.synchronize()
     if world > 1:
         td.barrier()
         td.destroy_process_group()

@@ -247,3 +247,26 @@ def test_sharded_kmeans_equals_single_device(tmp_path):
             np.testing.assert_allclose(ca, cb, rtol=1e-5, atol=1e-6, err_msg=case)
             np.testing.assert_allclose(ia, ib, rtol=1e-5, err_msg=case)
     assert len(np.unique(one['empty'][0])) == 4               # the empty cluster was relocated, as scikit-learn does
+
+
+def test_bench_runs_sharded_on_two_ranks(tmp_path):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), two ranks sharing the
+    test GPU over gloo: it must finish (every rank runs the traced steps rank 0 profiles -- a sharded step is full of collectives)
+    and print ONE JSON line with the whole-job rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIC_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '512',
+           '--encounters', '4096', '--no-secondary', '--no-cpu-baseline', '--kernel-iters', '1']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['scaling'] == 'weak' and rec['config']['global_batch'] == 1024
+    assert abs(rec['value'] - 2 * 512 * 3 / (rec['ms_per_step'] * 3e-3)) <= 0.01 * rec['value']      # whole-job rate over all ranks
