@@ -168,7 +168,7 @@ class NetBase(nn.Module):
         if len(feats) > 1 and B * feats[0].size(0) >= SEPARATE_ENCODER_ROWS:
             # large batches: one encoder call per branch.  Each already fills the chip, and the shared call would cost three
             # 100-MB-class copies (stacking the inputs, slicing the real half of the context and of the final states back out)
-            outs = [self.encoder(f, packed, bm, bm) for f in feats]
+            outs = [self.encoder(f, packed, bm, bm and i == 0) for i, f in enumerate(feats)]      # (only the real branch's output feeds the decoder)
             context, hidden, cell = outs[0]
             z_all = torch.cat([self._latent(o[1], bm) for o in outs], dim=0)                     # (nB, 256)
         else:
