@@ -8,7 +8,7 @@ import csv, json, os, sys
 KEYS = {'sci_cci_fwd_kernel': 'sci_cci_fwd', 'sci_cci_bwd_kernel': 'sci_cci_bwd', 'rbf_fwd_kernel': 'rbf_fwd', 'rbf_bwd_kernel': 'rbf_bwd',
         'masked_sse_kernel': 'masked_sse_fwd', 'masked_sse_bwd_kernel': 'masked_sse_bwd', 'dec_fwd_kernel': 'dec_fwd',
         'dec_bwd_kernel': 'dec_bwd', 'lstm_fwd_kernel<false>': 'lstm_fwd', 'lstm_fwd_kernel<true>': 'lstm_fwd_proj',
-        'lstm_bwd_kernel': 'lstm_bwd'}
+        'lstm_bwd_kernel': 'lstm_bwd', 'rbf_bwd_wave_kernel': 'rbf_bwd', 'lstm_dw_kernel': 'lstm_dw', 'lstm_dw_wide_kernel': 'lstm_dw_wide'}
 
 
 def match(kernel_name, pat):
@@ -35,7 +35,7 @@ out = {'_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SI
                 'scripts/pmc_traffic.py): bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; the factor 2 is the gfx950 correction of '
                 'MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read stream). bench.py scales it linearly with the batch.' % sys.argv[3],
        '_batch': int(sys.argv[3]), '_round': int(sys.argv[4]) if len(sys.argv) > 4 else 2}
-for k in KEYS.values():
+for k in dict.fromkeys(KEYS.values()):
     if k in fetch and k in write:
         out[k] = {'fetch_size_kb': round(fetch[k], 1), 'write_size_kb': round(write[k], 1), 'hbm_bytes': int((2 * fetch[k] + write[k]) * 1024)}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'traffic.json'), 'w'), indent=1)
