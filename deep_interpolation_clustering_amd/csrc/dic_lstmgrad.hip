@@ -27,7 +27,10 @@ constexpr int NBUF = 3;            // LDS ring: one tile being read, two in flig
 //   h rows (256 B) arrive four to a DMA instruction, contiguous, so the spreading is an XOR on the 16-B piece index instead
 //   (piece c of row r is stored at position c ^ ((r & 3) << 2): applied to the SOURCE address of the DMA and to the reads);
 //   x rows (64 B) are conflict-free as they lie.
-constexpr int DG_PITCH = 2 * G4 + 64;     // 1088
+#ifndef DIC_DW_DGPAD
+#define DIC_DW_DGPAD 64
+#endif
+constexpr int DG_PITCH = 2 * G4 + DIC_DW_DGPAD;     // 1088
 constexpr int H_PITCH = 2 * GH;           // 256
 constexpr int X_PITCH = 2 * XW;           // 64
 constexpr int LDS_DG = TR * DG_PITCH, LDS_H = TR * H_PITCH, LDS_X = TR * X_PITCH;

@@ -10,5 +10,6 @@ if [ $# -eq 0 ]; then set -- "" "-DDIC_DWW_EXP_NOMMA"; fi
 for flags in "$@"; do
   build "$flags"; echo "== flags: [$flags]"
   python scripts/dww_timing.py 2>/dev/null
+  python scripts/kbench.py 32768 20 2>/dev/null | grep "lstm_dw "
 done
 build ""
