@@ -28,6 +28,8 @@ for name, cs in acc.items():
     if d.get('SQ_BUSY_CYCLES') and d.get('SQ_ACTIVE_INST_VALU'):
         # VALU issue cycles per SIMD-busy cycle: SQ_BUSY_CYCLES is per SE (32) x cycles; ACTIVE_INST_VALU quad-cycles over all waves
         d['valu_quadcycles_per_busy_cycle'] = round(d['SQ_ACTIVE_INST_VALU'] / d['SQ_BUSY_CYCLES'], 3)
+        # share of SIMD cycles with a vector instruction executing: quad-cycles * 4 over (per-SE busy cycles x 1024 SIMDs)
+        d['valu_busy_frac_of_simd_cycles'] = round(d['SQ_ACTIVE_INST_VALU'] * 4 * 32 / (d['SQ_BUSY_CYCLES'] * 1024), 3)
     if d.get('SQ_LDS_IDX_ACTIVE'):
         d['lds_bank_conflict_frac'] = round(d.get('SQ_LDS_BANK_CONFLICT', 0.0) / d['SQ_LDS_IDX_ACTIVE'], 4)
     out[name] = {k: (round(v, 1) if isinstance(v, float) and v > 10 else v) for k, v in d.items()}
