@@ -44,6 +44,9 @@ SIGNATURES = {
     'dic_rbf_fwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p]),
     'dic_rbf_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'dic_rbf_bwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'dic_rbf_fwd_loss_workspace': (_sz, [_i, _i, _i, _i]),
+    'dic_rbf_fwd_loss': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _sz, _p]),
+    'dic_rbf_bwd_loss': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'dic_masked_sse_workspace': (_sz, [_i, _i, _i]),
     'dic_masked_sse_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _sz, _p]),
     'dic_masked_sse_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p]),

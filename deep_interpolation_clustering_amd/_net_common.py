@@ -106,6 +106,8 @@ class NetBase(nn.Module):
     clustering = False
     internal_step = False      # set by step.Stepper around its own forward + loss + backward (see forward / rec_loss)
     on_decoder_side_grads = None      # callable (set by step.Stepper when sharded): every gradient behind the encoder output is complete
+    rec_target = None                 # (set by step.Stepper around its own step, prefix lengths only) the observations: k2 then also returns the
+    _fused_rec = None                 #   reconstruction loss (ops.rbf_rec_loss); (reconstruction, mse) waits here for rec_loss
 
     def __init__(self, args, device):
         super().__init__()
@@ -185,7 +187,11 @@ class NetBase(nn.Module):
         y, _ = self.decoder(context, hidden, cell, bm, bm) if bm else self.decoder(context, hidden, cell)
         # (B,C,T).  Inside step.Stepper's optimisation step (`internal_step`: the reconstruction is consumed by rec_loss alone and never
         # handed out) only the observed slots are materialised; every other caller gets zeros in the padding, as upstream's `* mask`
-        y = self.rbf(y.permute(1, 2, 0), x, lengths, prefix_only=self.internal_step)
+        if self.internal_step and self.rec_target is not None and lengths is not None:
+            y, mse = self.rbf(y.permute(1, 2, 0), x, lengths, rec_target=self.rec_target)
+            self._fused_rec = (y, mse)
+        else:
+            y = self.rbf(y.permute(1, 2, 0), x, lengths, prefix_only=self.internal_step)
 
         aux = dict()
         n_aux = len(args.aux_tasks)
@@ -212,6 +218,9 @@ class NetBase(nn.Module):
     # ------------------------------------------------------------------------------ losses
     def rec_loss(self, org_ob, rec_ob, padding_mask, lengths=None):
         """Masked SSE / #observed over the global batch (clustering_interp.py:197-203), one HIP reduction."""
+        fused, self._fused_rec = self._fused_rec, None
+        if fused is not None and fused[0] is rec_ob and padding_mask is None and org_ob is self.rec_target:
+            return {'loss': fused[1], 'ae_mse': fused[1]}          # came out of the de-interpolation kernel (forward)
         mse = ops.masked_mse(org_ob, rec_ob, padding_mask, lengths, prefix_only=self.internal_step and padding_mask is None)
         return {'loss': mse, 'ae_mse': mse}
 

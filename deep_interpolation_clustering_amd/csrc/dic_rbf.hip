@@ -21,6 +21,8 @@ struct RbfArgs {
     float* y; float* norm;                       // forward outputs; norm (optional) = 1 / (sum_r phi + eps) per valid slot
     int prefix_only;                             // lengths given: write only the first n slots of each row (the padding stays as the caller allocated it)
     int v_rbc;                                   // v is laid out (R,B,C) -- the row order CompressFC produces it in -- instead of (B,C,R)
+    const float* ob;                             // optional (B,C,T) observations: the reconstruction loss rides along (Net.rec_loss,
+    double* sse_part;                            //   clustering_interp.py:197-203): per-workgroup [sum (y - ob)^2, #valid] over the valid slots
 };
 
 __host__ __device__ inline int rbf_fwd_words(int E, int C, int R) { return E * C * R + R + C + E * C; }
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
 
     const int nchunk = (T + kWave - 1) / kWave, units = nrows * nchunk;
     const int wave = tid >> 6, lane = tid & 63;
+    float sse = 0.f, nvalid = 0.f;
 #pragma unroll 2
     for (int u = wave; u < units; u += kBlock / kWave) {
         const int row = u / nchunk;
@@ -83,7 +86,40 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
         const float inv = 1.0f / (N + kRbfEps);
         a.y[o] = valid ? S * inv : 0.f;
         if (a.norm) a.norm[o] = valid ? inv : 0.f;
+        if (a.ob && valid) {
+            const float d = S * inv - a.ob[o];
+            sse = fmaf(d, d, sse);
+            nvalid += 1.f;
+        }
     }
+    if (a.ob) {          // fixed-order sums: lanes -> waves -> one pair per workgroup
+        __syncthreads();                             // (the v tile is dead: its first words carry the wave sums)
+        const double ws = wave_sum((double)sse), wc = wave_sum((double)nvalid);
+        double* red = reinterpret_cast<double*>(smem);
+        if (lane == 0) { red[wave] = ws; red[kBlock / kWave + wave] = wc; }
+        __syncthreads();
+        if (tid == 0) {
+            double s2 = 0, c2 = 0;
+            for (int w2 = 0; w2 < kBlock / kWave; ++w2) { s2 += red[w2]; c2 += red[kBlock / kWave + w2]; }
+            a.sse_part[2 * blockIdx.x] = s2;
+            a.sse_part[2 * blockIdx.x + 1] = c2;
+        }
+    }
+}
+
+// thousands of per-workgroup [sse, count] pairs -> out2: 512 slices x 2 columns, fixed order (f64)
+__global__ __launch_bounds__(1024) void sse_pairs_finalize(const double* partials, int nblk, float* out2) {
+    __shared__ double red[1024];
+    const int col = threadIdx.x & 1, sl = threadIdx.x >> 1;
+    double acc = 0.0;
+    for (int b = sl; b < nblk; b += 512) acc += partials[2 * (size_t)b + col];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int m = 512; m >= 2; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) out2[threadIdx.x] = (float)red[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------- backward
@@ -93,6 +129,8 @@ struct RbfBwdArgs {
     const float* y; const float* norm; const float* grad_y;
     float* grad_v; float* partials;
     int v_rbc;                                   // v and grad_v are laid out (R,B,C) instead of (B,C,R)
+    // the fused reconstruction loss (dic_rbf_bwd_loss): grad_y is not materialised, dL/dy = 2 grad_loss (y - ob) / #valid on the valid slots
+    const float* ob; const float* sse_count; const float* grad_loss;
 };
 
 struct RbfBwdLayout { int cnt, refg, nbeta, vs, gbeta, obs, stride, total_words; };
@@ -130,6 +168,7 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
 
     for (int i = tid; i < R; i += kBlock) refg[i] = a.ref_grid[i];
     for (int i = tid; i < C; i += kBlock) nbeta[i] = -softplus_raw(a.rbf_kernel[i]) * kLog2e;
+    const float gscale = a.ob ? 2.0f * a.grad_loss[0] / a.sse_count[1] : 0.f;
     float gbeta_acc = 0.f;          // channel tid / lanes-per-channel (every lane of the group carries it)
 
     for (int e0 = blockIdx.x * E; e0 < a.B; e0 += a.nblk * E) {
@@ -176,11 +215,12 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
                     tv[k] = (float)ic; gy[k] = 1.f; nm[k] = 0.5f; yv[k] = (float)o;
 #else
                     tv[k] = a.x[((size_t)(e0 + e) * 4 * C + 2 * C + c) * T + ic];
-                    gy[k] = a.grad_y[o]; nm[k] = a.norm[o]; yv[k] = a.y[o];
+                    gy[k] = a.ob ? a.ob[o] : a.grad_y[o]; nm[k] = a.norm[o]; yv[k] = a.y[o];
 #endif
                 }
 #pragma unroll
                 for (int k = 0; k < G; ++k) {
+                    if (a.ob) gy[k] = gscale * (yv[k] - gy[k]);
                     const float w = valid[k] ? gy[k] * nm[k] : 0.f;      // dL/dS = g/den (the forward saved 1/den)
                     if (dst[k] >= 0) obs[dst[k]] = make_float4(valid[k] ? tv[k] : 0.f, w, valid[k] ? w * yv[k] : 0.f, 0.f);
                 }
@@ -315,6 +355,8 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
     }
     const int ic = min(lane, T - 1);
     const size_t vstep = a.v_rbc ? (size_t)C : (size_t)C * R;       // v / grad_v offset of encounter e = e * vstep + voff[k]
+    const float* gsrc = a.ob ? a.ob : a.grad_y;                     // fused loss: the observations stand in for the incoming gradient
+    const float gscale = a.ob ? 2.0f * a.grad_loss[0] / a.sse_count[1] : 0.f;
 
     float pt[C], pg[C], pn[C], py[C], pv[ROUNDS];
     int plen[C];
@@ -326,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
             pt[c] = (float)ic; pg[c] = 1.f; pn[c] = 0.5f; py[c] = (float)o;
 #else
             pt[c] = a.x[((size_t)e * 4 * C + 2 * C + c) * T + ic];
-            pg[c] = a.grad_y[o]; pn[c] = a.norm[o]; py[c] = a.y[o];
+            pg[c] = gsrc[o]; pn[c] = a.norm[o]; py[c] = a.y[o];
 #endif
             plen[c] = a.lengths[(size_t)e * C + c];
         }
@@ -348,7 +390,8 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const bool valid = lane < n[c];
-                const float w = valid ? pg[c] * pn[c] : 0.f;
+                const float g = a.ob ? gscale * (py[c] - pg[c]) : pg[c];
+                const float w = valid ? g * pn[c] : 0.f;
                 obs[c * stride + lane] = make_float4(valid ? pt[c] : 0.f, w, valid ? w * py[c] : 0.f, 0.f);
             }
         }
@@ -359,8 +402,9 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
                     float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (i < n[c]) {
                         const size_t o = ((size_t)e * C + c) * T + i;
-                        const float w = a.grad_y[o] * a.norm[o];
-                        val = make_float4(a.x[((size_t)e * 4 * C + 2 * C + c) * T + i], w, w * a.y[o], 0.f);
+                        const float yo = a.y[o];
+                        const float w = (a.ob ? gscale * (yo - gsrc[o]) : gsrc[o]) * a.norm[o];
+                        val = make_float4(a.x[((size_t)e * 4 * C + 2 * C + c) * T + i], w, w * yo, 0.f);
                     }
                     obs[c * stride + i] = val;
                 }
@@ -532,20 +576,45 @@ using namespace dic;
 
 extern "C" {
 
-int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
-                const float* rbf_kernel, const float* v, int v_time_major, float* y, float* norm, int prefix_only, dic_stream_t stream) {
+static int rbf_fwd_grid(int B, int C, int R, int* E) {
+    const int per_enc = rbf_fwd_words(2, C, R) - rbf_fwd_words(1, C, R);
+    *E = rbf_tile(B, per_enc, rbf_fwd_words(1, C, R) - per_enc, 32 * 1024);
+    return (B + *E - 1) / *E;
+}
+
+static int rbf_fwd_launch(RbfArgs a, float* out2, hipStream_t st) {
+    const int B = a.B, C = a.C, T = a.T, R = a.R;
     DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_fwd: non-positive size");
     DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_fwd: C=%d R=%d", C, R);
-    DIC_REQUIRE(x && ref_grid && rbf_kernel && v && y, DIC_ERR_INVALID_ARG, "rbf_fwd: NULL pointer");
-    RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm, (prefix_only && lengths) ? 1 : 0, v_time_major != 0};
-    const int per_enc = rbf_fwd_words(2, C, R) - rbf_fwd_words(1, C, R);
-    a.E = rbf_tile(B, per_enc, rbf_fwd_words(1, C, R) - per_enc, 32 * 1024);
-    const dim3 grid((B + a.E - 1) / a.E);
+    DIC_REQUIRE(a.x && a.ref_grid && a.rbf_kernel && a.v && a.y, DIC_ERR_INVALID_ARG, "rbf_fwd: NULL pointer");
+    const dim3 grid(rbf_fwd_grid(B, C, R, &a.E));
     const size_t lds = (size_t)rbf_fwd_words(a.E, C, R) * 4;
-    if (C == 6 && R == 24) hipLaunchKernelGGL((rbf_fwd_kernel<6, 24>), grid, dim3(kBlock), lds, (hipStream_t)stream, a);
-    else if (C == 12 && R == 24) hipLaunchKernelGGL((rbf_fwd_kernel<12, 24>), grid, dim3(kBlock), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((rbf_fwd_kernel<0, 0>), grid, dim3(kBlock), lds, (hipStream_t)stream, a);
+    if (C == 6 && R == 24) hipLaunchKernelGGL((rbf_fwd_kernel<6, 24>), grid, dim3(kBlock), lds, st, a);
+    else if (C == 12 && R == 24) hipLaunchKernelGGL((rbf_fwd_kernel<12, 24>), grid, dim3(kBlock), lds, st, a);
+    else hipLaunchKernelGGL((rbf_fwd_kernel<0, 0>), grid, dim3(kBlock), lds, st, a);
+    if (a.ob) hipLaunchKernelGGL(sse_pairs_finalize, dim3(1), dim3(1024), 0, st, (const double*)a.sse_part, (int)grid.x, out2);
     return check_launch("rbf_fwd");
+}
+
+int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                const float* rbf_kernel, const float* v, int v_time_major, float* y, float* norm, int prefix_only, dic_stream_t stream) {
+    RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm, (prefix_only && lengths) ? 1 : 0, v_time_major != 0, nullptr, nullptr};
+    return rbf_fwd_launch(a, nullptr, (hipStream_t)stream);
+}
+
+size_t dic_rbf_fwd_loss_workspace(int B, int C, int T, int R) {
+    if (B <= 0 || C <= 0 || T <= 0 || R <= 0) return 0;
+    int E;
+    return (size_t)rbf_fwd_grid(B, C, R, &E) * 2 * sizeof(double);
+}
+
+int dic_rbf_fwd_loss(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid, const float* rbf_kernel,
+                     const float* v, int v_time_major, const float* ob, float* y, float* norm, int prefix_only, float* out2,
+                     void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(ob && out2 && workspace, DIC_ERR_INVALID_ARG, "rbf_fwd_loss: NULL pointer");
+    DIC_REQUIRE(workspace_bytes >= dic_rbf_fwd_loss_workspace(B, C, T, R), DIC_ERR_WORKSPACE, "rbf_fwd_loss: workspace too small");
+    RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm, (prefix_only && lengths) ? 1 : 0, v_time_major != 0, ob, (double*)workspace};
+    return rbf_fwd_launch(a, out2, (hipStream_t)stream);
 }
 
 static void rbf_bwd_geometry(int B, int C, int T, int R, int* E, int* nblk, size_t* lds) {
@@ -577,17 +646,20 @@ size_t dic_rbf_bwd_workspace(int B, int C, int T, int R) {
     return (size_t)max(nblk, nblk2) * C * sizeof(float);
 }
 
-int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
-                const float* rbf_kernel, const float* v, int v_time_major, const float* y, const float* norm, const float* grad_y,
-                float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+static int rbf_bwd_launch(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                          const float* rbf_kernel, const float* v, int v_time_major, const float* y, const float* norm, const float* grad_y,
+                          const float* ob, const float* sse_count, const float* grad_loss,
+                          float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_bwd: non-positive size");
     DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_bwd: C=%d R=%d", C, R);
-    DIC_REQUIRE(x && ref_grid && rbf_kernel && v && y && norm && grad_y && grad_v && grad_rbf_kernel && workspace,
+    DIC_REQUIRE(x && ref_grid && rbf_kernel && v && y && norm && (grad_y || ob) && grad_v && grad_rbf_kernel && workspace,
                 DIC_ERR_INVALID_ARG, "rbf_bwd: NULL pointer");
+    DIC_REQUIRE(!ob || (lengths && sse_count && grad_loss), DIC_ERR_INVALID_ARG, "rbf_bwd_loss: needs lengths, sse_count and grad_loss");
     RbfBwdArgs a{};
     a.x = x; a.lengths = lengths; a.B = B; a.C = C; a.T = T; a.R = R;
     a.ref_grid = ref_grid; a.rbf_kernel = rbf_kernel; a.v = v; a.y = y; a.norm = norm; a.grad_y = grad_y;
     a.grad_v = grad_v; a.partials = (float*)workspace; a.v_rbc = v_time_major != 0;
+    a.ob = ob; a.sse_count = sse_count; a.grad_loss = grad_loss;
     size_t lds;
     hipStream_t st = (hipStream_t)stream;
     if (lengths && (size_t)B * C * R < ((size_t)1 << 31) && rbf_bwd_wave_geometry(B, C, T, R, &a.nblk, &lds)) {
@@ -627,6 +699,23 @@ int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int
     hipLaunchKernelGGL(rbf_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)workspace, a.nblk, C, rbf_kernel,
                        grad_rbf_kernel);
     return check_launch("rbf_bwd");
+}
+
+int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
+                const float* rbf_kernel, const float* v, int v_time_major, const float* y, const float* norm, const float* grad_y,
+                float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(grad_y, DIC_ERR_INVALID_ARG, "rbf_bwd: grad_y is NULL");
+    return rbf_bwd_launch(x, lengths, B, C, T, R, ref_grid, rbf_kernel, v, v_time_major, y, norm, grad_y, nullptr, nullptr, nullptr, grad_v,
+                          grad_rbf_kernel, workspace, workspace_bytes, stream);
+}
+
+int dic_rbf_bwd_loss(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid, const float* rbf_kernel,
+                     const float* v, int v_time_major, const float* y, const float* norm, const float* ob, const float* sse_count,
+                     const float* grad_loss, float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes,
+                     dic_stream_t stream) {
+    DIC_REQUIRE(ob, DIC_ERR_INVALID_ARG, "rbf_bwd_loss: ob is NULL");
+    return rbf_bwd_launch(x, lengths, B, C, T, R, ref_grid, rbf_kernel, v, v_time_major, y, norm, nullptr, ob, sse_count, grad_loss, grad_v,
+                          grad_rbf_kernel, workspace, workspace_bytes, stream);
 }
 
 size_t dic_masked_sse_workspace(int B, int C, int T) {

@@ -221,6 +221,60 @@ def rbf_deinterp(v, raw_input, rbf_kernel, grid, lengths=None, prefix_only=False
     return _Rbf.apply(v if v.dtype == torch.float32 else v.float(), raw_input, rbf_kernel, grid, lengths, prefix_only)   # .float(): bf16 autocast producers
 
 
+class _RbfRecLoss(torch.autograd.Function):
+    """k2 and Net.rec_loss in one node (training step with prefix lengths): forward = dic_rbf_fwd_loss (the masked SSE comes out of the
+    registers that hold y), backward = dic_rbf_bwd_loss (dL/dy formed on the fly from ob).  Returns (y, mse); y is handed out for
+    callers that look at it, but a gradient arriving through y is not supported here (the step consumes it through mse alone)."""
+
+    @staticmethod
+    def forward(ctx, v, raw_input, rbf_kernel, grid, lengths, ob):
+        N.require_gpu(v, raw_input, rbf_kernel, grid, ob)
+        x, obc = N.f32c(raw_input), N.f32c(ob)
+        B, C4, T = x.shape
+        C, R = rbf_kernel.numel(), grid.numel()
+        if C4 != 4 * C or tuple(v.shape) != (B, C, R) or tuple(obc.shape) != (B, C, T):
+            raise ValueError(f'rbf_rec_loss: raw_input {tuple(x.shape)} / v {tuple(v.shape)} / ob {tuple(obc.shape)} do not match C={C}, R={R}')
+        tm = v.dtype == torch.float32 and not v.is_contiguous() and v.permute(2, 0, 1).is_contiguous()
+        vb = v.permute(2, 0, 1) if tm else N.f32c(v)
+        lengths = _lengths_arg(lengths, B, C, x.device)
+        rk = N.f32c(rbf_kernel.detach())
+        y = torch.empty((B, C, T), device=x.device, dtype=torch.float32)
+        norm = torch.empty_like(y)
+        out2 = torch.empty(2, device=x.device, dtype=torch.float32)
+        L = N.lib()
+        ws = _ws(L.dic_rbf_fwd_loss_workspace(B, C, T, R), x.device)
+        N.check(L.dic_rbf_fwd_loss(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(obc), N.ptr(y),
+                                   N.ptr(norm), 1, N.ptr(out2), N.ptr(ws), ws.numel(), N.stream_of(x)), 'dic_rbf_fwd_loss')
+        dist.all_reduce_sum_(out2)          # global SSE and global #valid slots
+        ctx.dims = (B, C, T, R, bool(tm))
+        ctx.save_for_backward(x, lengths, grid, rk, vb, y, norm, obc, out2)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(y)
+        return y, out2[0] / out2[1]
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_mse):
+        x, lengths, grid, rk, vb, y, norm, obc, out2 = ctx.saved_tensors
+        B, C, T, R, tm = ctx.dims
+        if grad_mse is None:
+            return None, None, None, None, None, None
+        gl = N.f32c(grad_mse.reshape(1))
+        gv = torch.empty((R, B, C) if tm else (B, C, R), device=x.device, dtype=torch.float32)
+        gk = torch.empty(C, device=x.device, dtype=torch.float32)
+        L = N.lib()
+        ws = _ws(L.dic_rbf_bwd_workspace(B, C, T, R), x.device)
+        N.check(L.dic_rbf_bwd_loss(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y), N.ptr(norm),
+                                   N.ptr(obc), N.ptr(out2), N.ptr(gl), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(x)),
+                'dic_rbf_bwd_loss')
+        return (gv.permute(1, 2, 0) if tm else gv), None, gk, None, None, None
+
+
+def rbf_rec_loss(v, raw_input, rbf_kernel, grid, lengths, ob):
+    """(y, mse) = (rbf_deinterp(v, ..., prefix_only=True), masked_mse(ob, y, lengths=lengths)) from one forward and one backward
+    kernel.  ``y`` (B,C,T) holds the observed prefix of each row only and carries no gradient (it is consumed through ``mse``)."""
+    return _RbfRecLoss.apply(v if v.dtype == torch.float32 else v.float(), raw_input, rbf_kernel, grid, lengths, ob)
+
+
 class _MaskedMse(torch.autograd.Function):
     @staticmethod
     def forward(ctx, org_ob, rec_ob, mask, lengths, prefix_only=False):

@@ -63,8 +63,10 @@ class RBF(nn.Module):
         self.compress_fc = TimeDistributed(CompressFC(in_dim, out_dim, dropout))
         self.kernel = nn.Parameter(torch.rand(out_dim, device=device), requires_grad=True)
 
-    def forward(self, interp_data, raw_input, lengths=None, prefix_only=False):
-        """interp_data (B,256,R), raw_input (B,4C,T) -> (B,C,T) (rbf.py:57-108)."""
+    def forward(self, interp_data, raw_input, lengths=None, prefix_only=False, rec_target=None):
+        """interp_data (B,256,R), raw_input (B,4C,T) -> (B,C,T) (rbf.py:57-108).
+        ``rec_target`` (B,C,T) observations (training step with prefix ``lengths`` only): returns (reconstruction, masked MSE against
+        it) from the fused kernels of ops.rbf_rec_loss instead."""
         native = interp_data.permute(2, 0, 1)                                     # (R,B,256)
         if native.is_contiguous():
             # the decoder emits (R,B,256); CompressFC is row-wise and its BatchNorm moments are order-invariant, so run
@@ -74,5 +76,9 @@ class RBF(nn.Module):
             v = self.compress_fc(interp_data.permute(0, 2, 1)).permute(0, 2, 1)   # (B,C,R)
         if self.interp_t.device != v.device:
             self.interp_t = self.interp_t.to(v.device)
+        if rec_target is not None:
+            if lengths is None:
+                raise ValueError('rec_target needs prefix lengths')
+            return ops.rbf_rec_loss(v, raw_input, self.kernel, self.interp_t, lengths, rec_target)
         # training step with prefix lengths: the padded slots of the reconstruction are never read (rec_loss goes by the same lengths)
         return ops.rbf_deinterp(v, raw_input, self.kernel, self.interp_t, lengths, prefix_only=bool(prefix_only) and lengths is not None)

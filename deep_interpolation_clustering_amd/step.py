@@ -151,11 +151,15 @@ class Stepper:
     def _step_eager(self, x, ob, padding_mask, lengths=None, **kw):
         self.flat.zero_grad()
         self.model.internal_step = True          # the reconstruction stays inside this step: its padded slots need not be written
+        # ... and with prefix lengths its loss comes out of the de-interpolation kernels themselves (ops.rbf_rec_loss)
+        self.model.rec_target = ob if (padding_mask is None and lengths is not None and ob.is_cuda) else None
         try:
             losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
             losses['loss'].backward()
         finally:
             self.model.internal_step = False
+            self.model.rec_target = None
+            self.model._fused_rec = None
         self.flat.all_reduce_grads()
         if self._fused_tail:
             gnorm, coef = self.flat.clip_coef(self.args.grad_clip)

@@ -125,6 +125,22 @@ int dic_rbf_bwd(const float* x, const int32_t* lengths, int B, int C, int T, int
                 const float* grad_y, float* grad_v, float* grad_rbf_kernel,
                 void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
+/* k2 with the reconstruction loss riding along (RBF.forward + Net.rec_loss, rbf.py:57-108 + clustering_interp.py:197-203), for the
+ * training step, where the reconstruction is consumed by the loss alone:
+ *   dic_rbf_fwd_loss: as dic_rbf_fwd, and out2[0] = sum over the valid slots of (y - ob)^2, out2[1] = #valid slots (what
+ *     dic_masked_sse_fwd returns for a binary mask) from the values the kernel holds in registers -- no second pass over y and ob;
+ *   dic_rbf_bwd_loss: as dic_rbf_bwd with dL/dy = grad_loss[0] * 2 (y - ob) / sse_count[1] on the valid slots formed on the fly from ob
+ *     (prefix masks: lengths required) -- the (B,C,T) gradient of the reconstruction is never written or read.
+ * sse_count = out2 after the caller's all-reduce over ranks; grad_loss (1) = dL/d(out2[0] / out2[1]); all device pointers. */
+size_t dic_rbf_fwd_loss_workspace(int B, int C, int T, int R);
+int dic_rbf_fwd_loss(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid, const float* rbf_kernel,
+                     const float* v, int v_time_major, const float* ob, float* y, float* norm, int prefix_only, float* out2,
+                     void* workspace, size_t workspace_bytes, dic_stream_t stream);
+int dic_rbf_bwd_loss(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid, const float* rbf_kernel,
+                     const float* v, int v_time_major, const float* y, const float* norm, const float* ob, const float* sse_count,
+                     const float* grad_loss, float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes,
+                     dic_stream_t stream);
+
 /* Net.rec_loss (clustering_interp.py:197-203): out2[0]=sum((rec*m-ob*m)^2), out2[1]=#{m==1}.
  * mask (B,C,T) may be NULL when lengths is given.  The loss is out2[0]/out2[1]. */
 size_t dic_masked_sse_workspace(int B, int C, int T);

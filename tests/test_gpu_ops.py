@@ -256,6 +256,42 @@ def test_rbf_backward_reference_shape_kernel(ops, B, T, lam, time_major, prefix_
     np.testing.assert_allclose(k.grad.cpu().numpy(), k64.grad.numpy(), rtol=3e-4, atol=3e-5 * float(k64.grad.abs().max()))
 
 
+@pytest.mark.parametrize('B,C,T,R,H,lam,time_major', [(1027, 6, 96, 24, 24.0, 50, True), (37, 6, 96, 24, 24.0, 80, False), (33, 12, 288, 24, 24.0, 200, True),
+                                                       (5, 3, 40, 9, 12.0, 20, False)])
+def test_rbf_with_fused_reconstruction_loss_matches_separate_kernels(ops, B, C, T, R, H, lam, time_major):
+    """ops.rbf_rec_loss (k2 forward emitting the masked SSE, k2 backward forming dL/dy from the observations) against
+    rbf_deinterp + masked_mse: same reconstruction on the observed slots, same loss and same gradients (to summation order)."""
+    x, n = vitals_stack(900 + B, B, C, T, H, lam)
+    rng = np.random.default_rng(B)
+    v_np = rng.normal(0, 1, (B, C, R)).astype(np.float32)
+    k_np = rng.uniform(-0.5, 1.5, C).astype(np.float32)
+    ob_np = (rng.normal(0, 1, (B, C, T)) * x[:, C:2 * C]).astype(np.float32)
+    grid = ops.ref_grid(H, R, 'cuda')
+    lens, xg, ob = G(n, dtype=torch.int32), G(x), G(ob_np)
+    res = {}
+    for fused in (False, True):
+        k = G(k_np, True)
+        if time_major:
+            leaf = G(np.ascontiguousarray(v_np.transpose(2, 0, 1)), True)
+            v = leaf.permute(1, 2, 0)
+        else:
+            leaf = v = G(v_np, True)
+        if fused:
+            y, mse = ops.rbf_rec_loss(v, xg, k, grid, lens, ob)
+        else:
+            y = ops.rbf_deinterp(v, xg, k, grid, lengths=lens, prefix_only=True)
+            mse = ops.masked_mse(ob, y, None, lengths=lens, prefix_only=True)
+        (3.0 * mse).backward()
+        keep = torch.arange(T, device='cuda')[None, None, :] < lens[:, :, None]
+        res[fused] = dict(y=torch.where(keep, y.detach(), torch.zeros_like(y)), mse=mse.detach(),
+                          gv=(leaf.grad.permute(1, 2, 0) if time_major else leaf.grad).clone(), gk=k.grad.clone())
+    assert torch.equal(res[True]['y'], res[False]['y'])
+    np.testing.assert_allclose(float(res[True]['mse']), float(res[False]['mse']), rtol=2e-6)
+    for key, tol in (('gv', 2e-5), ('gk', 1e-4)):
+        a, b = res[True][key].cpu().numpy(), res[False][key].cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=tol, atol=tol * np.abs(b).max(), err_msg=key)
+
+
 # ------------------------------------------------------------------------------------ k3 golden
 @pytest.mark.parametrize('name', DEC)
 def test_dec_golden(ops, name):
