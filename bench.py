@@ -200,7 +200,8 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
 def _short(name):
     if name.startswith('Cijk') or name.startswith('Custom_Cijk'):
         mt = name.split('_MT')[1].split('_')[0] if '_MT' in name else '?'
-        return 'gemm:' + name.split('_')[1 if name.startswith('Cijk') else 2] + '_' + name.split('_')[2 if name.startswith('Cijk') else 3] + '_MT' + mt
+        sk = '_SK' + name.split('_SK')[1].split('_')[0] if '_SK' in name else ''          # stream-K variants are different kernels
+        return 'gemm:' + name.split('_')[1 if name.startswith('Cijk') else 2] + '_' + name.split('_')[2 if name.startswith('Cijk') else 3] + '_MT' + mt + sk
     n = name.replace('void ', '')
     if n.startswith('_ZN3dic'):
         import re

@@ -1,0 +1,211 @@
+// Backward of the first CompressFC layer, Linear(256, 128) applied to every (time step, encounter) row of the decoder output
+// (rbf.py:111-125 `nn.Linear(in_dim, 128)`, TimeDistributed utils.py:202-224), from ONE pass over the rows:
+//     dX[row][i] = sum_o dZ[row][o] W[o][i]            (N x 256, bf16: the decoder LSTM's output gradient)
+//     dW[o][i]   = sum_row dZ[row][o] X[row][i]        (128 x 256, f32)
+// The two library GEMMs this replaces each read dZ (N x 128 bf16, 201 MB at B = 32768) and ran at ~4 TB/s of their own traffic;
+// here dZ and X are read once, dX is written once: 1.0 GB instead of 1.2 GB, and no split-K chunk products to sum.
+//
+// 512 threads = 8 waves, one workgroup per CU, 32-row tiles.  Wave w owns the input columns i in [32 w, 32 w + 32):
+//   dX: one 32x32 block, K = the 128 outputs in 8 MFMA k-steps; A = dZ rows straight from the LDS tile (16-B row pieces),
+//       B = W[o][i] for its 32 columns, resident in 32 registers for the whole kernel;
+//   dW: four 32x32 blocks (all 128 outputs x its 32 columns), K = the tile's 32 rows in 2 k-steps; both operands come out of
+//       LDS transposed (ds_read_b64_tr_b16): the reduction index (row) is the slow index of dZ and X in memory.
+// Tiles go global -> registers -> LDS (one 16-B piece of dZ and two of X per thread and tile, requested one tile ahead), two LDS
+// images so that a single barrier per tile suffices; the dX block leaves through an LDS staging tile as whole 512-B rows.
+// Row pitches of 256 + 48 / 512 + 48 B keep the straight 16-B reads (32 rows, same piece) and the transposed reads (4 rows x 32 B)
+// both free of bank conflicts.  Deterministic: per-workgroup dW partials, fixed-order f64 second stage.
+#include "dic_common.h"
+
+namespace dic {
+
+constexpr int FO = 128, FI = 256;                    // out / in features of the layer
+constexpr int FT = 32;                               // rows per tile
+constexpr int FZ_PITCH = FO * 2 + 48;                // 304 B
+constexpr int FX_PITCH = FI * 2 + 48;                // 560 B
+constexpr int FS_PITCH = FI * 2 + 16;                // 528 B: dX staging rows
+constexpr int F_TILE = FT * (FZ_PITCH + FX_PITCH);   // 27 648 B per tile image
+constexpr int F_STAGE = FT * FS_PITCH;               // 16 896 B
+constexpr int F_LDS = 2 * F_TILE + 2 * F_STAGE;      // 89 088 B
+
+typedef __bf16 fbf16x8 __attribute__((ext_vector_type(8)));
+typedef short fs16x4 __attribute__((ext_vector_type(4)));
+typedef short fs16x8 __attribute__((ext_vector_type(8)));
+typedef float ff32x16 __attribute__((ext_vector_type(16)));
+
+struct FcBwdArgs {
+    const __bf16* dz;      // (N, 128)
+    const __bf16* x;       // (N, 256)
+    const __bf16* w;       // (128, 256)
+    __bf16* dx;            // (N, 256) or NULL
+    float* partials;       // (gridDim.x, 128, 256)
+    long N;
+};
+
+__device__ __forceinline__ fs16x4 f_lds_tr16(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fs16x4*)(p));
+}
+
+__global__ __launch_bounds__(512) void fc_bwd_kernel(FcBwdArgs a) {
+    extern __shared__ __align__(16) unsigned char fsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long N = a.N;
+    const int ntiles = (int)((N + FT - 1) / FT), nwg = gridDim.x;
+    unsigned char* stage = fsm + 2 * F_TILE;
+
+    // B operand of dX: W[o = 16 ks + 8 kg + j][i = 32 w + (lane & 31)], j = 0..7 -- resident
+    fbf16x8 wreg[FO / 16];
+    {
+        const int i = 32 * w + (lane & 31), kg = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < FO / 16; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wreg[ks][j] = a.w[(size_t)(16 * ks + 8 * kg + j) * FI + i];
+    }
+    ff32x16 dw[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dw[mb][k] = 0.f;
+
+    // global -> register pieces of a tile (rows past the end read as zeros: they add nothing to dW and their dX is not stored)
+    const int zrow = tid >> 4, zpc = tid & 15;               // dZ: 32 rows x 16 pieces
+    const int xrow = tid >> 5, xpc = tid & 31;               // X: rows xrow, xrow + 16, 32 pieces each
+    uint4 pz, px0, px1;
+    auto request = [&](int tile) {           // (loads from clamped, always valid rows; the rows past the end are zeroed by a select)
+        const long r0 = (long)tile * FT;
+        const long rz = min(r0 + zrow, N - 1), ra = min(r0 + xrow, N - 1), rb = min(r0 + xrow + 16, N - 1);
+        const uint4 vz = *reinterpret_cast<const uint4*>(a.dz + (size_t)rz * FO + zpc * 8);
+        const uint4 va = *reinterpret_cast<const uint4*>(a.x + (size_t)ra * FI + xpc * 8);
+        const uint4 vb = *reinterpret_cast<const uint4*>(a.x + (size_t)rb * FI + xpc * 8);
+        const bool kz = r0 + zrow < N, ka = r0 + xrow < N, kb = r0 + xrow + 16 < N;
+        pz = make_uint4(kz ? vz.x : 0u, kz ? vz.y : 0u, kz ? vz.z : 0u, kz ? vz.w : 0u);
+        px0 = make_uint4(ka ? va.x : 0u, ka ? va.y : 0u, ka ? va.z : 0u, ka ? va.w : 0u);
+        px1 = make_uint4(kb ? vb.x : 0u, kb ? vb.y : 0u, kb ? vb.z : 0u, kb ? vb.w : 0u);
+    };
+    auto land = [&](int slot) {
+        unsigned char* base = fsm + slot * F_TILE;
+        *reinterpret_cast<uint4*>(base + zrow * FZ_PITCH + zpc * 16) = pz;
+        *reinterpret_cast<uint4*>(base + FT * FZ_PITCH + xrow * FX_PITCH + xpc * 16) = px0;
+        *reinterpret_cast<uint4*>(base + FT * FZ_PITCH + (xrow + 16) * FX_PITCH + xpc * 16) = px1;
+    };
+
+    // transposed-read addressing (see lstm_dw_kernel): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3; lane l of the
+    // 32x32x16 operand needs column (l & 31) and rows 8 (l >> 5) + 0..7 of the k-step
+    const int kq = (lane & 15) >> 2, kp = lane & 3, cb = (lane >> 4) & 1, hh = lane >> 5;
+    const int rowoff = 8 * hh + kq;
+    auto frag = [&](const unsigned char* p, int pitch) {
+        const fs16x4 lo = f_lds_tr16(p), hi = f_lds_tr16(p + 4 * pitch);
+        fs16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+        return __builtin_bit_cast(fbf16x8, f);
+    };
+    const int za_off = (lane & 31) * FZ_PITCH + hh * 16;                               // dX's A: row (lane & 31), 16-B piece 2 ks + hh
+    const int zt_off = rowoff * FZ_PITCH + (16 * cb + 4 * kp) * 2;                     // dW's A: + 64 mb (column block), + 16 ks rows
+    const int xt_off = FT * FZ_PITCH + rowoff * FX_PITCH + (32 * w + 16 * cb + 4 * kp) * 2;
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) { request(tile); land(0); }
+    if (tile + nwg < ntiles) request(tile + nwg);
+    __syncthreads();
+    int slot = 0;
+    auto store_rows = [&](int st_slot, long r0) {             // the dX block of a tile: staging -> global, whole 512-B rows
+        if (!a.dx || r0 < 0) return;
+        const unsigned char* sb = stage + st_slot * F_STAGE;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int p = tid + 512 * k, row = p >> 5, pc = p & 31;
+            if (r0 + row < N)
+                *reinterpret_cast<uint4*>(a.dx + (size_t)(r0 + row) * FI + pc * 8) = *reinterpret_cast<const uint4*>(sb + row * FS_PITCH + pc * 16);
+        }
+    };
+    for (; tile < ntiles; tile += nwg) {
+        const unsigned char* base = fsm + slot * F_TILE;
+        // ---- dX block of this wave
+        ff32x16 acc;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < FO / 16; ++ks) {
+            const fbf16x8 af = *reinterpret_cast<const fbf16x8*>(base + za_off + ks * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wreg[ks], acc, 0, 0, 0);
+        }
+        // ---- dW blocks
+#pragma unroll
+        for (int ks = 0; ks < FT / 16; ++ks) {
+            const fbf16x8 bf = frag(base + xt_off + ks * 16 * FX_PITCH, FX_PITCH);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const fbf16x8 af = frag(base + zt_off + ks * 16 * FZ_PITCH + mb * 64, FZ_PITCH);
+                dw[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, dw[mb], 0, 0, 0);
+            }
+        }
+        // ---- next tile's pieces -> the other image, the one after that requested; this tile's dX block -> staging
+        if (tile + nwg < ntiles) land(slot ^ 1);
+        if (tile + 2 * nwg < ntiles) request(tile + 2 * nwg);
+        if (a.dx) {
+            unsigned char* sb = stage + slot * F_STAGE;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int m = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                *reinterpret_cast<__bf16*>(sb + m * FS_PITCH + (32 * w + (lane & 31)) * 2) = (__bf16)acc[k];
+            }
+        }
+        __syncthreads();
+        store_rows(slot, (long)tile * FT);
+        slot ^= 1;
+    }
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float* o = a.partials + (size_t)blockIdx.x * FO * FI;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = 32 * mb + (k & 3) + 8 * (k >> 2) + 4 * hh;
+            o[(size_t)m * FI + 32 * w + (lane & 31)] = dw[mb][k];
+        }
+}
+
+__global__ __launch_bounds__(256) void fc_bwd_finalize(const float* partials, int nwg, float* dw) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(partials, nwg, FO * FI, blockIdx.x * 32, red);
+    const int i = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x < 32 && i < FO * FI) dw[i] = (float)s;
+}
+
+static int fc_bwd_blocks(long N) { return (int)max(1L, min((N + FT - 1) / FT, (long)kNumCU)); }
+
+}  // namespace dic
+
+using namespace dic;
+
+extern "C" {
+
+size_t dic_fc_bwd_workspace(int64_t N, int in_features, int out_features) {
+    if (N <= 0 || in_features != FI || out_features != FO) return 0;
+    return (size_t)fc_bwd_blocks(N) * FO * FI * sizeof(float);
+}
+
+int dic_fc_bwd(const void* dz, const void* x, const void* w, int64_t N, int in_features, int out_features, void* dx, float* dw,
+               void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(N > 0, DIC_ERR_INVALID_ARG, "fc_bwd: non-positive row count");
+    DIC_REQUIRE(in_features == FI && out_features == FO, DIC_ERR_UNSUPPORTED, "fc_bwd: Linear(%d, %d) (compiled for Linear(%d, %d))", in_features,
+                out_features, FI, FO);
+    DIC_REQUIRE(dz && x && w && dw && workspace, DIC_ERR_INVALID_ARG, "fc_bwd: NULL pointer");
+    const int nwg = fc_bwd_blocks(N);
+    DIC_REQUIRE(workspace_bytes >= (size_t)nwg * FO * FI * sizeof(float), DIC_ERR_WORKSPACE, "fc_bwd: workspace %zu B too small", workspace_bytes);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fc_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "fc_bwd: cannot reserve %d B of LDS: %s", F_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    FcBwdArgs a{(const __bf16*)dz, (const __bf16*)x, (const __bf16*)w, (__bf16*)dx, (float*)workspace, (long)N};
+    hipLaunchKernelGGL(fc_bwd_kernel, dim3(nwg), dim3(512), F_LDS, st, a);
+    hipLaunchKernelGGL(fc_bwd_finalize, dim3(FO * FI / 32), dim3(256), 0, st, (const float*)workspace, nwg, dw);
+    return check_launch("fc_bwd");
+}
+
+}  // extern "C"

@@ -18,6 +18,8 @@ reconstruction loss, the DEC column sums f_j, the KL batch divisor -- are all-re
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _native as N
@@ -557,6 +559,10 @@ def splitk_tn(a, b, chunks=(8192, 4096, 2048)):
     return (a.t() @ b).float()
 
 
+FC_BWD_SHAPE = (128, 256)      # dic_fc_bwd's compiled Linear(256, 128)
+FC_BWD_MIN_ROWS = int(os.environ.get('DIC_FC_BWD_MIN_ROWS', 8192))          # below this the two library GEMMs are launch-bound anyway
+
+
 class _RowsLinear(torch.autograd.Function):
     """y = x W^T + b on (N, I) bf16 rows with N in the hundreds of thousands (library GEMMs).  Only the weight
     gradient is special: dW = dy^T x has K = N and a tiny output (see splitk_tn)."""
@@ -572,11 +578,21 @@ class _RowsLinear(torch.autograd.Function):
     def backward(ctx, dy):
         xb, wb = ctx.saved_tensors
         dyb = dy.to(torch.bfloat16).contiguous()
-        dx = (dyb @ wb).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
         if ctx.zero_db:
             db = torch.zeros(wb.shape[0], device=dyb.device, dtype=torch.float32)
         else:
             db = torch.sum(dyb, dim=0, dtype=torch.float32)
+        n = dyb.shape[0]
+        if dyb.is_cuda and tuple(wb.shape) == FC_BWD_SHAPE and n >= FC_BWD_MIN_ROWS and xb.is_contiguous():
+            # CompressFC's first layer over all (time step, encounter) rows: dx and dW from one pass over dy (csrc/dic_fcgrad.hip)
+            L = N.lib()
+            dxb = torch.empty_like(xb) if ctx.needs_input_grad[0] else None
+            dw = torch.empty(wb.shape, device=dyb.device, dtype=torch.float32)
+            ws = _ws(L.dic_fc_bwd_workspace(n, wb.shape[1], wb.shape[0]), dyb.device)
+            N.check(L.dic_fc_bwd(N.ptr(dyb), N.ptr(xb), N.ptr(wb.contiguous()), n, wb.shape[1], wb.shape[0], N.ptr(dxb), N.ptr(dw), N.ptr(ws),
+                                 ws.numel(), N.stream_of(dyb)), 'dic_fc_bwd')
+            return (None if dxb is None else dxb.to(ctx.x_dtype)), dw, db, None
+        dx = (dyb @ wb).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
         return dx, splitk_tn(dyb, xb), db, None
 
 

@@ -312,6 +312,14 @@ int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int R,
 int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,
                           int accumulate, dic_stream_t stream);
 
+/* ------------------------------------------------------------------ CompressFC first layer, backward ---
+ * Linear(256, 128) over all N = B*R decoder rows (rbf.py:111-125, first layer; TimeDistributed utils.py:202-224): from ONE pass over
+ * the rows, dx (N,256) bf16 = dz . W (or NULL) and dw (128,256) f32 = dz^T . x, for dz (N,128), x (N,256), w (128,256) bf16 -- instead of
+ * two library GEMMs that each read dz.  MFMA with transposed LDS reads for the weight gradient; deterministic two-stage reduction. */
+size_t dic_fc_bwd_workspace(int64_t N, int in_features, int out_features);
+int dic_fc_bwd(const void* dz, const void* x, const void* w, int64_t N, int in_features, int out_features, void* dx, float* dw,
+               void* workspace, size_t workspace_bytes, dic_stream_t stream);
+
 /* ------------------------------------------------------------------ CompressFC output layer ---
  * Linear(128, C) over all N = B*R decoder rows (rbf.py:111-125, last layer; TimeDistributed utils.py:202-224)
  * for small C (1..8, 12, 16): h (N,128) bf16, W (C,128) f32, b (C) f32 -> v (N,C) f32; backward:

@@ -627,3 +627,45 @@ def test_rectified_output_equals_relu_applied_outside(mode, I, B, monkeypatch):
         else:       # (an element whose h rounds to exactly +-0 may take the other branch: none in practice, but not a bit-level contract)
             a, b = res[True][k].cpu().numpy(), res[False][k].cpu().numpy()
             np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6 * float(np.abs(b).max()), err_msg=k)
+
+
+@pytest.mark.parametrize('n,want_dx', [(24 * 200, True), (32, True), (70000, True), (8192 * 3 + 5, False), (1, True)])
+def test_fc_bwd_matches_matmul(n, want_dx):
+    """dic_fc_bwd (first CompressFC layer's backward: dx = dz . W and dW = dz^T . x from one pass over the rows) against f64
+    products of the same bf16 operands, for row counts that are not a multiple of the 32-row tile."""
+    from deep_interpolation_clustering_amd import _native as N
+    torch.manual_seed(n)
+    dev, bf = torch.device('cuda'), torch.bfloat16
+    dz = (torch.randn(n, 128, device=dev) * 0.3).to(bf)
+    x = (torch.randn(n, 256, device=dev) * 0.5).to(bf)
+    w = (torch.randn(128, 256, device=dev) * 0.1).to(bf)
+    L = N.lib()
+    dx = torch.full((n, 256), float('nan'), device=dev, dtype=bf) if want_dx else None
+    dw = torch.full((128, 256), float('nan'), device=dev)
+    ws = torch.empty(L.dic_fc_bwd_workspace(n, 256, 128), dtype=torch.uint8, device=dev)
+    N.check(L.dic_fc_bwd(N.ptr(dz), N.ptr(x), N.ptr(w), n, 256, 128, N.ptr(dx), N.ptr(dw), N.ptr(ws), ws.numel(), N.stream_of(dz)), 'dic_fc_bwd')
+    torch.cuda.synchronize()
+    want_w = dz.double().t() @ x.double()
+    assert float((dw.double() - want_w).abs().max()) <= 2e-5 * float(want_w.abs().max()) + 1e-5
+    if want_dx:
+        want_x = dz.double() @ w.double()
+        assert float((dx.double() - want_x).abs().max()) <= 8e-3 * float(want_x.abs().max()) + 1e-3        # bf16 output
+
+
+def test_rows_linear_backward_uses_the_one_pass_kernel_and_matches_the_gemm_path(monkeypatch):
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(3)
+    dev = torch.device('cuda')
+    n = 24 * 512
+    x0 = torch.randn(n, 256, device=dev).to(torch.bfloat16)
+    lin = torch.nn.Linear(256, 128).to(dev)
+    g = torch.randn(n, 128, device=dev).to(torch.bfloat16)
+    res = {}
+    for rows in (1 << 40, 1):          # library GEMMs, then the fused kernel
+        monkeypatch.setattr(ops, 'FC_BWD_MIN_ROWS', rows)
+        lin.zero_grad()
+        x = x0.clone().requires_grad_()
+        ops.rows_linear(x, lin.weight, lin.bias).backward(g)
+        res[rows] = (x.grad.float().clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    for a, b in zip(res[1], res[1 << 40]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-2, atol=2e-3 * float(b.abs().max()))
