@@ -35,6 +35,7 @@ PARAM_NAMES = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
                'weight_ih_l0_reverse', 'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
 
+ROW_PROJ = os.environ.get('DIC_ROW_PROJ', '1') != '0'                  # (A/B switch: 0 = library GEMM for the decoder's input projection)
 RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B switch: 0 = rectify the encoder output with a torch pass)
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
 SMALL_BATCH = 4096             # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
@@ -132,7 +133,12 @@ class _BiLstm(torch.autograd.Function):
                 N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out), N.ptr(out_r),
                                             N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd_proj')
             else:
-                gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
+                if Ip == WIDE_INPUT and ROW_PROJ:
+                    # decoder: the input projection with the weights resident in registers (csrc/dic_rowproj.hip)
+                    gx = torch.empty((R * B, 8 * H), device=dev, dtype=T)
+                    N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), st), 'dic_row_proj')
+                else:
+                    gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
                 N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
                                        N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd')
         ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32), bool(relu))

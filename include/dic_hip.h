@@ -312,6 +312,12 @@ int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int R,
 int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,
                           int accumulate, dic_stream_t stream);
 
+/* ------------------------------------------------------------------ row-wise projection, 256 inputs ---
+ * out (N,Nout) bf16 = x (N,256) . w (Nout,256)^T + bias (Nout) (bias bf16 or NULL), Nout a multiple of 256: the decoder LSTM's input
+ * projection gx over all N = R*B rows (nn.LSTM inside DecoderRNN, clustering_interp.py:47-59) with the weights resident in
+ * registers -- the library GEMM for this K = 256 shape cannot overlap its short main loop with its epilogue. */
+int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, dic_stream_t stream);
+
 /* ------------------------------------------------------------------ CompressFC first layer, backward ---
  * Linear(256, 128) over all N = B*R decoder rows (rbf.py:111-125, first layer; TimeDistributed utils.py:202-224): from ONE pass over
  * the rows, dx (N,256) bf16 = dz . W (or NULL) and dw (128,256) f32 = dz^T . x, for dz (N,128), x (N,256), w (128,256) bf16 -- instead of

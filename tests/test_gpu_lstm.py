@@ -669,3 +669,20 @@ def test_rows_linear_backward_uses_the_one_pass_kernel_and_matches_the_gemm_path
         res[rows] = (x.grad.float().clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
     for a, b in zip(res[1], res[1 << 40]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-2, atol=2e-3 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize('n,nout,bias', [(24 * 200, 1024, True), (33, 256, False), (70001, 1024, True), (1, 512, True)])
+def test_row_proj_matches_addmm(n, nout, bias):
+    """dic_row_proj (weights resident in registers, x tiles through LDS) against f64 products of the same bf16 operands."""
+    from deep_interpolation_clustering_amd import _native as N
+    torch.manual_seed(n)
+    dev, bf = torch.device('cuda'), torch.bfloat16
+    x = (torch.randn(n, 256, device=dev) * 0.5).clamp_min(0).to(bf)
+    w = (torch.randn(nout, 256, device=dev) * 0.1).to(bf)
+    b = (torch.randn(nout, device=dev) * 0.3).to(bf) if bias else None
+    out = torch.full((n, nout), float('nan'), device=dev, dtype=bf)
+    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, nout, N.ptr(out), N.stream_of(x)), 'dic_row_proj')
+    want = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    assert float((out.double() - want).abs().max()) <= 8e-3 * float(want.abs().max()) + 1e-3        # bf16 output
+    ref = torch.addmm(b, x, w.t()) if bias else x @ w.t()
+    assert float((out.float() - ref.float()).abs().max()) <= 8e-3 * float(want.abs().max()) + 1e-3
