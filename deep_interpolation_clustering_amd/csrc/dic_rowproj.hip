@@ -1,6 +1,6 @@
 // Row-wise projections with a 256-wide input applied to every (time step, encounter) row:
 //     out[row][n] = bias[n] + sum_k x[row][k] W[n][k]          x (N,256) bf16, W (Nout,256) bf16, out (N,Nout) bf16
-// i.e. the decoder LSTM's input projection gx = relu(enc_out) . W_ih^T + (b_ih + b_hh) (clustering_interp.py:47-59 through nn.LSTM:
+// i.e. (a) the decoder LSTM's input projection gx = relu(enc_out) . W_ih^T + (b_ih + b_hh) (clustering_interp.py:47-59 through nn.LSTM:
 // N = 786 432 rows, Nout = 1024, 412 GFLOP, 1.6 GB of output at B = 32 768).  The library GEMM for this shape has K = 256 only --
 // four k-iterations per 256x256 macro-tile, so its prologue / epilogue never overlap -- and ran at 0.58-0.60 ms (3.4 TB/s of its
 // own traffic).  Here the weights never move: wave w of a workgroup keeps W[n][0..255] for its 32 output columns in 64 registers
@@ -8,6 +8,9 @@
 // tile ahead, two images, one barrier per tile), and the 32 x 256 output block leaves through an LDS staging tile as whole
 // 512-B row segments.  grid (chunks, Nout / 256): the workgroups of a row chunk sit on one XCD (chunk count a multiple of 8), so
 // x is fetched from HBM about once and served to the other column stripes by that XCD's L2.
+// (b) CompressFC's first layer Linear(256, 128) over the same rows (rbf.py:111-125): 4 waves per workgroup, one 128-column stripe,
+// and -- the layer feeds a training-mode BatchNorm1d -- the per-column sums of z and z^2 (of the bf16 values actually stored) ride
+// along in registers: the separate column-statistics pass over the 201 MB z tensor disappears.
 #include "dic_common.h"
 
 namespace dic {
@@ -15,9 +18,9 @@ namespace dic {
 constexpr int PK = 256;                              // input width (K)
 constexpr int PT = 32;                               // rows per tile
 constexpr int PX_PITCH = PK * 2 + 48;                // 560 B: the 32 rows of a straight 16-B read fall on disjoint bank groups
-constexpr int PS_PITCH = 256 * 2 + 16;               // 528 B: staging rows of the 256-column output block
-constexpr int P_TILE = PT * PX_PITCH, P_STAGE = PT * PS_PITCH;
-constexpr int P_LDS = 2 * P_TILE + 2 * P_STAGE;      // 69 632 B: two workgroups per CU
+constexpr int P_TILE = PT * PX_PITCH;
+__host__ __device__ constexpr int p_stage_pitch(int nw) { return nw * 64 + 16; }          // staging rows of the (32 nw)-column output block
+__host__ __device__ constexpr int p_lds(int nw) { return 2 * P_TILE + 2 * PT * p_stage_pitch(nw); }    // 69 632 B (8 waves) / 53 248 B (4 waves)
 
 typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 typedef float pf32x16 __attribute__((ext_vector_type(16)));
@@ -29,15 +32,18 @@ struct RowProjArgs {
     __bf16* out;           // (N, Nout)
     long N;
     int Nout;
+    float* stat_part;      // STATS: (gridDim.x, 2, 32 NW) per-workgroup column sums of out and out^2
 };
 
-__global__ __launch_bounds__(512, 2) void row_proj_kernel(RowProjArgs a) {
+template <int NW, bool STATS>
+__global__ __launch_bounds__(NW * 64, 2) void row_proj_kernel(RowProjArgs a) {
+    constexpr int NT = NW * 64, PS_PITCH = p_stage_pitch(NW), P_STAGE = PT * PS_PITCH, NCOLS = 32 * NW, PPT = PT * 32 / NT;   // PPT: x pieces per thread and tile
     extern __shared__ __align__(16) unsigned char psm[];
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long N = a.N;
     const int ntiles = (int)((N + PT - 1) / PT), nch = gridDim.x;
-    const int n0 = blockIdx.y * 256, ncol = n0 + 32 * w + (lane & 31);
+    const int n0 = blockIdx.y * NCOLS, ncol = n0 + 32 * w + (lane & 31);
     unsigned char* stage = psm + 2 * P_TILE;
 
     pbf16x8 wreg[PK / 16];                 // B operand: W[ncol][16 ks + 8 hh .. + 7]
@@ -45,25 +51,36 @@ __global__ __launch_bounds__(512, 2) void row_proj_kernel(RowProjArgs a) {
     for (int ks = 0; ks < PK / 16; ++ks) wreg[ks] = *reinterpret_cast<const pbf16x8*>(a.w + (size_t)ncol * PK + 16 * ks + 8 * hh);
     const float bn = a.bias ? (float)a.bias[ncol] : 0.f;
 
-    const int xrow = tid >> 5, xpc = tid & 31;               // rows xrow, xrow + 16; 32 pieces of 16 B per row
-    uint4 p0, p1;
-    auto request = [&](int tile) {           // (clamped, always valid addresses; rows past the end are never stored)
-        const long r0 = (long)tile * PT;
-        p0 = *reinterpret_cast<const uint4*>(a.x + (size_t)min(r0 + xrow, N - 1) * PK + xpc * 8);
-        p1 = *reinterpret_cast<const uint4*>(a.x + (size_t)min(r0 + xrow + 16, N - 1) * PK + xpc * 8);
+    const int xrow = tid >> 5, xpc = tid & 31;               // rows xrow + (NT / 32) j; 32 pieces of 16 B per row
+    static_assert(PPT == 2 || PPT == 4, "x pieces per thread and tile");
+    uint4 px0, px1, px2 = {}, px3 = {};      // (named registers: an indexed array of these ends up in scratch memory)
+    auto piece = [&](long r0, int j) {       // (clamped, always valid addresses; rows past the end are never stored nor counted)
+        return *reinterpret_cast<const uint4*>(a.x + (size_t)min(r0 + xrow + (NT / 32) * j, N - 1) * PK + xpc * 8);
     };
-    auto land = [&](int slot) {
-        unsigned char* base = psm + slot * P_TILE;
-        *reinterpret_cast<uint4*>(base + xrow * PX_PITCH + xpc * 16) = p0;
-        *reinterpret_cast<uint4*>(base + (xrow + 16) * PX_PITCH + xpc * 16) = p1;
-    };
+#define DIC_RP_REQUEST(TILE)                                                         \
+    do {                                                                             \
+        const long r0_ = (long)(TILE) * PT;                                          \
+        px0 = piece(r0_, 0); px1 = piece(r0_, 1);                                    \
+        if constexpr (PPT == 4) { px2 = piece(r0_, 2); px3 = piece(r0_, 3); }        \
+    } while (0)
+#define DIC_RP_LAND(SLOT)                                                                                              \
+    do {                                                                                                               \
+        unsigned char* base_ = psm + (SLOT) * P_TILE + xrow * PX_PITCH + xpc * 16;                                     \
+        *reinterpret_cast<uint4*>(base_) = px0;                                                                        \
+        *reinterpret_cast<uint4*>(base_ + (NT / 32) * PX_PITCH) = px1;                                                 \
+        if constexpr (PPT == 4) {                                                                                      \
+            *reinterpret_cast<uint4*>(base_ + 2 * (NT / 32) * PX_PITCH) = px2;                                         \
+            *reinterpret_cast<uint4*>(base_ + 3 * (NT / 32) * PX_PITCH) = px3;                                         \
+        }                                                                                                              \
+    } while (0)
     const int a_off = (lane & 31) * PX_PITCH + hh * 16;       // A operand: row (lane & 31), 16-B piece 2 ks + hh
 
     int tile = blockIdx.x;
-    if (tile < ntiles) { request(tile); land(0); }
-    if (tile + nch < ntiles) request(tile + nch);
+    if (tile < ntiles) { DIC_RP_REQUEST(tile); DIC_RP_LAND(0); }
+    if (tile + nch < ntiles) DIC_RP_REQUEST(tile + nch);
     __syncthreads();
     int slot = 0;
+    double s1 = 0.0, s2 = 0.0;             // STATS: this lane's column, its 16 rows of every tile
     for (; tile < ntiles; tile += nch) {
         const unsigned char* base = psm + slot * P_TILE;
         pf32x16 acc;
@@ -74,25 +91,69 @@ __global__ __launch_bounds__(512, 2) void row_proj_kernel(RowProjArgs a) {
             const pbf16x8 af = *reinterpret_cast<const pbf16x8*>(base + a_off + ks * 32);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wreg[ks], acc, 0, 0, 0);
         }
-        if (tile + nch < ntiles) land(slot ^ 1);
-        if (tile + 2 * nch < ntiles) request(tile + 2 * nch);
+        if (tile + nch < ntiles) DIC_RP_LAND(slot ^ 1);
+        if (tile + 2 * nch < ntiles) DIC_RP_REQUEST(tile + 2 * nch);
         // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         unsigned char* sb = stage + slot * P_STAGE;
+        const long r0 = (long)tile * PT;
+        float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int m = (k & 3) + 8 * (k >> 2) + 4 * hh;
-            *reinterpret_cast<__bf16*>(sb + m * PS_PITCH + (32 * w + (lane & 31)) * 2) = (__bf16)acc[k];
+            const __bf16 ob = (__bf16)acc[k];
+            *reinterpret_cast<__bf16*>(sb + m * PS_PITCH + (32 * w + (lane & 31)) * 2) = ob;
+            if (STATS && r0 + m < N) {
+                const float of = (float)ob;
+                t1 += of;
+                t2 = fmaf(of, of, t2);
+            }
         }
+        if (STATS) { s1 += (double)t1; s2 += (double)t2; }
         __syncthreads();
-        const long r0 = (long)tile * PT;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int p = tid + 512 * k, row = p >> 5, pc = p & 31;
+        for (int k = 0; k < PT * (NCOLS / 8) / NT; ++k) {
+            const int p = tid + NT * k, row = p / (NCOLS / 8), pc = p % (NCOLS / 8);
             if (r0 + row < N)
                 *reinterpret_cast<uint4*>(a.out + (size_t)(r0 + row) * a.Nout + n0 + pc * 8) = *reinterpret_cast<const uint4*>(sb + row * PS_PITCH + pc * 16);
         }
         slot ^= 1;
     }
+#undef DIC_RP_REQUEST
+#undef DIC_RP_LAND
+    if (STATS) {        // the two row halves of a column meet, then one partial row per workgroup (columns are wave-private)
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (hh == 0) {
+            a.stat_part[(size_t)blockIdx.x * 2 * NCOLS + 32 * w + (lane & 31)] = (float)s1;
+            a.stat_part[(size_t)blockIdx.x * 2 * NCOLS + NCOLS + 32 * w + (lane & 31)] = (float)s2;
+        }
+    }
+}
+
+// [sum z | sum z^2 | rows] in f64 (what dic_bn_colstats delivers): fixed-order reduction of the per-workgroup sums
+__global__ __launch_bounds__(256) void row_proj_stats_finalize(const float* partials, int nblk, int n, double nrows, double* sums) {
+    __shared__ double red[256];
+    const double s = reduce_partials_32x8(partials, nblk, n, blockIdx.x * 32, red);
+    if (threadIdx.x < 32 && blockIdx.x * 32 + (int)threadIdx.x < n) sums[blockIdx.x * 32 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[n] = nrows;
+}
+
+static int row_proj_chunks(long N, int stripes, int wg_per_cu) {
+    const int ntiles = (int)((N + PT - 1) / PT);
+    int nch = max(1, min(ntiles, wg_per_cu * kNumCU / stripes));
+    return nch >= 8 ? nch / 8 * 8 : nch;                          // a multiple of 8: the stripes of a row chunk share an XCD (and its L2)
+}
+
+template <int NW, bool STATS>
+static int row_proj_launch(const RowProjArgs& a, int nch, int stripes, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)row_proj_kernel<NW, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, p_lds(NW));
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "row_proj: cannot reserve %d B of LDS: %s", p_lds(NW), hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((row_proj_kernel<NW, STATS>), dim3(nch, stripes), dim3(NW * 64), p_lds(NW), st, a);
+    return DIC_OK;
 }
 
 }  // namespace dic
@@ -106,19 +167,30 @@ int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int 
     DIC_REQUIRE(in_features == PK && out_features > 0 && out_features % 256 == 0, DIC_ERR_UNSUPPORTED,
                 "row_proj: (%d -> %d) (compiled for 256 inputs and a multiple of 256 outputs)", in_features, out_features);
     DIC_REQUIRE(x && w && out, DIC_ERR_INVALID_ARG, "row_proj: NULL pointer");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)row_proj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "row_proj: cannot reserve %d B of LDS: %s", P_LDS, hipGetErrorString(e));
-        attr_set = true;
-    }
     const int stripes = out_features / 256;
-    const int ntiles = (int)((N + PT - 1) / PT);
-    int nch = max(1, min(ntiles, 2 * kNumCU / stripes));          // two workgroups per CU
-    if (nch >= 8) nch = nch / 8 * 8;                             // a multiple of 8: the stripes of a row chunk share an XCD (and its L2)
-    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features};
-    hipLaunchKernelGGL(row_proj_kernel, dim3(nch, stripes), dim3(512), P_LDS, (hipStream_t)stream, a);
-    return check_launch("row_proj");
+    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, nullptr};
+    int rc = row_proj_launch<8, false>(a, row_proj_chunks(N, stripes, 2), stripes, (hipStream_t)stream);
+    return rc ? rc : check_launch("row_proj");
+}
+
+size_t dic_row_proj_stats_workspace(int64_t N, int out_features) {
+    if (N <= 0 || out_features != 128) return 0;
+    return (size_t)row_proj_chunks(N, 1, 3) * 2 * 128 * sizeof(float);
+}
+
+int dic_row_proj_stats(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, double* sums,
+                       void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(N > 0, DIC_ERR_INVALID_ARG, "row_proj_stats: non-positive row count");
+    DIC_REQUIRE(in_features == PK && out_features == 128, DIC_ERR_UNSUPPORTED, "row_proj_stats: (%d -> %d) (compiled for 256 -> 128)", in_features,
+                out_features);
+    DIC_REQUIRE(x && w && out && sums && workspace, DIC_ERR_INVALID_ARG, "row_proj_stats: NULL pointer");
+    const int nch = row_proj_chunks(N, 1, 3);
+    DIC_REQUIRE(workspace_bytes >= (size_t)nch * 2 * 128 * sizeof(float), DIC_ERR_WORKSPACE, "row_proj_stats: workspace too small");
+    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, (float*)workspace};
+    int rc = row_proj_launch<4, true>(a, nch, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(row_proj_stats_finalize, dim3(2 * 128 / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nch, 2 * 128, (double)N, sums);
+    return check_launch("row_proj_stats");
 }
 
 }  // extern "C"

@@ -453,16 +453,19 @@ class _BnReluHead(torch.autograd.Function):
     statistics updated by the same moments kernel (training mode)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, nbt, momentum, training, relu, drop_p=0.0):
+    def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, nbt, momentum, training, relu, drop_p=0.0, col_sums=None):
         N.require_gpu(z, gamma, beta, weight, bias)
         zb = z.to(torch.bfloat16).contiguous()
         n, k = zb.shape
         c = weight.shape[0]
         L, dev, st = N.lib(), zb.device, N.stream_of(zb)
         if training:
-            sums = torch.empty(2 * k + 1, device=dev, dtype=torch.float64)
-            ws = _ws(L.dic_bn_colstats_workspace(n, k), dev)
-            N.check(L.dic_bn_colstats(N.ptr(zb), n, k, N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bn_colstats')      # [sum z | sum z^2 | rows]
+            if col_sums is not None and col_sums.numel() == 2 * k + 1:
+                sums = col_sums                   # came out of the kernel that produced z (rows_linear(..., with_stats=True))
+            else:
+                sums = torch.empty(2 * k + 1, device=dev, dtype=torch.float64)
+                ws = _ws(L.dic_bn_colstats_workspace(n, k), dev)
+                N.check(L.dic_bn_colstats(N.ptr(zb), n, k, N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bn_colstats')      # [sum z | sum z^2 | rows]
             dist.all_reduce_sum_(sums)            # the moments of the GLOBAL batch (SURVEY.md 8e)
             mean = torch.empty(k, device=dev, dtype=torch.float32)
             rstd, cnt = torch.empty_like(mean), torch.empty(1, device=dev, dtype=torch.float32)
@@ -511,7 +514,7 @@ class _BnReluHead(torch.autograd.Function):
             N.check(L.dic_bnhead_bwd_input(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), N.ptr(red),
                                            N.ptr(red[k:]), 1.0, N.ptr(count), n, k, c, ctx.relu, ctx.drop_p, N.ptr(rng), N.ptr(dz), st), 'dic_bnhead_bwd_input')
             dz = dz.to(ctx.z_dtype)
-        return dz, dgamma, dbeta, dw, db, None, None, None, None, None, None, None, None
+        return dz, dgamma, dbeta, dw, db, None, None, None, None, None, None, None, None, None
 
 
 BNHEAD_OUT = (1, 2, 3, 4, 5, 6, 7, 8)
@@ -529,17 +532,18 @@ def _dropout_rng(device):
     return st.clone()
 
 
-def bn_relu_head(z, bn, linear, relu=True, dropout=None):
+def bn_relu_head(z, bn, linear, relu=True, dropout=None, col_sums=None):
     """``linear(relu(bn(z)))`` (``relu=False``: ``linear(bn(z))``) for an nn.BatchNorm1d(128) and an nn.Linear(128, C <= 8) on (N,128) bf16 rows, with the
     module semantics of BatchNorm1d (batch moments + running statistics in training mode, running statistics in
     eval mode) and moments over the GLOBAL batch when the batch is sharded over ranks (dist.GlobalBatchNorm1d).  ``dropout``: the
-    nn.Dropout between the activation and ``linear`` (active when in training mode with p > 0; the mask is drawn in-kernel)."""
+    nn.Dropout between the activation and ``linear`` (active when in training mode with p > 0; the mask is drawn in-kernel).
+    ``col_sums``: this rank's [sum z | sum z^2 | rows] (f64) when the producer of ``z`` already has them (rows_linear(with_stats=True))."""
     training = bn.training or bn.running_mean is None
     drop_p = float(dropout.p) if (dropout is not None and dropout.training) else 0.0
     track = bn.training and bn.track_running_stats and bn.running_mean is not None
     return _BnReluHead.apply(z, bn.weight, bn.bias, linear.weight, linear.bias, bn.eps, bn.running_mean if (track or not training) else None,
                              bn.running_var if (track or not training) else None, bn.num_batches_tracked if track else None, bn.momentum,
-                             training, relu, drop_p)
+                             training, relu, drop_p, col_sums if (training and col_sums is not None) else None)
 
 
 def splitk_tn(a, b, chunks=(8192, 4096, 2048)):
@@ -568,14 +572,30 @@ class _RowsLinear(torch.autograd.Function):
     gradient is special: dW = dy^T x has K = N and a tiny output (see splitk_tn)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, bias_grad_is_zero):
+    def forward(ctx, x, weight, bias, bias_grad_is_zero, with_stats=False):
         xb, wb = x.to(torch.bfloat16), weight.to(torch.bfloat16)
         ctx.save_for_backward(xb, wb)
         ctx.x_dtype, ctx.zero_db = x.dtype, bool(bias_grad_is_zero)
-        return torch.addmm(bias.to(torch.bfloat16), xb, wb.t())
+        n = xb.shape[0]
+        if with_stats and xb.is_cuda and tuple(wb.shape) == FC_BWD_SHAPE and n >= FC_BWD_MIN_ROWS and xb.is_contiguous():
+            # CompressFC's first layer in front of its BatchNorm: z and its column sums from one kernel (csrc/dic_rowproj.hip)
+            L = N.lib()
+            z = torch.empty((n, wb.shape[0]), device=xb.device, dtype=torch.bfloat16)
+            sums = torch.empty(2 * wb.shape[0] + 1, device=xb.device, dtype=torch.float64)
+            ws = _ws(L.dic_row_proj_stats_workspace(n, wb.shape[0]), xb.device)
+            N.check(L.dic_row_proj_stats(N.ptr(xb), N.ptr(wb.contiguous()), N.ptr(bias.detach().to(torch.bfloat16)), n, wb.shape[1], wb.shape[0],
+                                         N.ptr(z), N.ptr(sums), N.ptr(ws), ws.numel(), N.stream_of(xb)), 'dic_row_proj_stats')
+            ctx.mark_non_differentiable(sums)
+            return z, sums
+        z = torch.addmm(bias.to(torch.bfloat16), xb, wb.t())
+        if not with_stats:
+            return z
+        none = torch.empty(0, device=xb.device, dtype=torch.float64)
+        ctx.mark_non_differentiable(none)
+        return z, none
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         xb, wb = ctx.saved_tensors
         dyb = dy.to(torch.bfloat16).contiguous()
         if ctx.zero_db:
@@ -591,13 +611,18 @@ class _RowsLinear(torch.autograd.Function):
             ws = _ws(L.dic_fc_bwd_workspace(n, wb.shape[1], wb.shape[0]), dyb.device)
             N.check(L.dic_fc_bwd(N.ptr(dyb), N.ptr(xb), N.ptr(wb.contiguous()), n, wb.shape[1], wb.shape[0], N.ptr(dxb), N.ptr(dw), N.ptr(ws),
                                  ws.numel(), N.stream_of(dyb)), 'dic_fc_bwd')
-            return (None if dxb is None else dxb.to(ctx.x_dtype)), dw, db, None
+            return (None if dxb is None else dxb.to(ctx.x_dtype)), dw, db, None, None
         dx = (dyb @ wb).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
-        return dx, splitk_tn(dyb, xb), db, None
+        return dx, splitk_tn(dyb, xb), db, None, None
 
 
-def rows_linear(x, weight, bias, bias_grad_is_zero=False):
+def rows_linear(x, weight, bias, bias_grad_is_zero=False, with_stats=False):
     """``bias_grad_is_zero``: the caller knows d loss / d bias == 0 identically -- a bias in front of a training-mode
     BatchNorm, whose mean subtraction cancels it (sum over rows of the BatchNorm input gradient is 0) -- so the (N, out)
-    column reduction is skipped.  (The reference computes that sum and gets rounding noise around 0.)"""
-    return _RowsLinear.apply(x, weight, bias, bias_grad_is_zero)
+    column reduction is skipped.  (The reference computes that sum and gets rounding noise around 0.)
+    ``with_stats``: returns (z, col_sums) -- col_sums = [sum z | sum z^2 | rows] in f64 for bn_relu_head(col_sums=...) when the
+    producing kernel can deliver them (else None)."""
+    if not with_stats:
+        return _RowsLinear.apply(x, weight, bias, bias_grad_is_zero, False)
+    z, sums = _RowsLinear.apply(x, weight, bias, bias_grad_is_zero, True)
+    return z, (sums if sums.numel() else None)

@@ -29,11 +29,14 @@ class CompressFC(nn.Module):
         bn, drop = self.model[1], self.model[3]
         with torch.autocast('cuda', enabled=False):
             # split-K weight gradient; the bias sits in front of BatchNorm: its gradient is identically 0 in training mode
-            z = ops.rows_linear(rec_input, first.weight, first.bias, bias_grad_is_zero=bn.training)
+            # (training mode: the layer's kernel also delivers the column sums the BatchNorm behind it needs)
+            z, col_sums = ops.rows_linear(rec_input, first.weight, first.bias, bias_grad_is_zero=bn.training, with_stats=True)
+            if not (bn.training and last.out_features in ops.BNHEAD_OUT):
+                col_sums = None
         if last.out_features in ops.BNHEAD_OUT:
             # BatchNorm -> ReLU -> Dropout -> Linear in four streaming passes over z, the hidden activation never materialised
             with torch.autocast('cuda', enabled=False):
-                return ops.bn_relu_head(z, bn, last, dropout=drop)
+                return ops.bn_relu_head(z, bn, last, dropout=drop, col_sums=col_sums)
         hidden = drop(self.model[2](bn(z)))
         with torch.autocast('cuda', enabled=False):
             return ops.head_linear(hidden, last.weight, last.bias)

@@ -317,6 +317,11 @@ int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const
  * projection gx over all N = R*B rows (nn.LSTM inside DecoderRNN, clustering_interp.py:47-59) with the weights resident in
  * registers -- the library GEMM for this K = 256 shape cannot overlap its short main loop with its epilogue. */
 int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, dic_stream_t stream);
+/* The same for CompressFC's first layer Linear(256, 128) (rbf.py:111-125) in front of its training-mode BatchNorm1d: out (N,128) bf16 and
+ * sums (2*128 + 1) f64 = [column sums of out | of out^2 | N] -- what dic_bn_colstats would compute in a second pass over out. */
+size_t dic_row_proj_stats_workspace(int64_t N, int out_features);
+int dic_row_proj_stats(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, double* sums,
+                       void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
 /* ------------------------------------------------------------------ CompressFC first layer, backward ---
  * Linear(256, 128) over all N = B*R decoder rows (rbf.py:111-125, first layer; TimeDistributed utils.py:202-224): from ONE pass over

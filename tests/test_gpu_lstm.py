@@ -686,3 +686,25 @@ def test_row_proj_matches_addmm(n, nout, bias):
     assert float((out.double() - want).abs().max()) <= 8e-3 * float(want.abs().max()) + 1e-3        # bf16 output
     ref = torch.addmm(b, x, w.t()) if bias else x @ w.t()
     assert float((out.float() - ref.float()).abs().max()) <= 8e-3 * float(want.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize('n', [24 * 512, 70001, 8192])
+def test_row_proj_stats_matches_addmm_and_colstats(n):
+    """dic_row_proj_stats: z = x W^T + b for Linear(256, 128) and the column sums of z, z^2 (of the stored bf16 values) + row count."""
+    from deep_interpolation_clustering_amd import _native as N
+    torch.manual_seed(n)
+    dev, bf = torch.device('cuda'), torch.bfloat16
+    x = (torch.randn(n, 256, device=dev) * 0.5).to(bf)
+    w = (torch.randn(128, 256, device=dev) * 0.1).to(bf)
+    b = (torch.randn(128, device=dev) * 0.3).to(bf)
+    L = N.lib()
+    z = torch.full((n, 128), float('nan'), device=dev, dtype=bf)
+    sums = torch.full((257,), float('nan'), device=dev, dtype=torch.float64)
+    ws = torch.empty(L.dic_row_proj_stats_workspace(n, 128), dtype=torch.uint8, device=dev)
+    N.check(L.dic_row_proj_stats(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 128, N.ptr(z), N.ptr(sums), N.ptr(ws), ws.numel(), N.stream_of(x)), 'dic_row_proj_stats')
+    want = x.double() @ w.double().t() + b.double()
+    assert float((z.double() - want).abs().max()) <= 8e-3 * float(want.abs().max()) + 1e-3
+    zd = z.double()
+    assert float(sums[256]) == n
+    np.testing.assert_allclose(sums[:128].cpu().numpy(), zd.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5 * n)
+    np.testing.assert_allclose(sums[128:256].cpu().numpy(), (zd * zd).sum(0).cpu().numpy(), rtol=1e-5)
