@@ -276,3 +276,35 @@ def test_bf16_step_updates_every_parameter(graphs):
     for k, d in moved['bf16'].items():
         assert d > 0, f'{k} did not move'
         assert 0.5 * moved['f32'][k] < d < 2.0 * moved['f32'][k], f"{k}: mean |update| {d:.3e} vs {moved['f32'][k]:.3e} through autograd"
+
+
+@pytest.mark.parametrize('B', [1, 31, 257, 1000, 4097, 9000])
+def test_bf16_step_tracks_f32_step_at_odd_batch_sizes(B):
+    """The bf16 fast mode switches kernels with the batch size (32-row / 64-row recurrences, one-pass weight gradients from 32 rows up,
+    resident-weight projections and the fused CompressFC layer from 8192 rows up, the wave-per-encounter k2 backward, tails of
+    every tile size): its losses over three steps must follow the f32 mode's to bf16 accuracy at sizes that are multiples of nothing."""
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=4, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    coh = synthetic.make_cohort(B, seed=100 + B)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    traj = {}
+    for mode in ('bf16', 'f32'):
+        torch.manual_seed(4)
+        net = Net(args, dev).to(dev)
+        net.train()
+        if B == 1:
+            net.eval()                     # BatchNorm needs more than one row in training mode (upstream raises too)
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16 if mode == 'bf16' else None,
+                     use_graphs=False)
+        traj[mode] = [float(st.step(X, OB, None, LEN)[0]['ae_mse']) for _ in range(3)]
+    for a, b in zip(traj['bf16'], traj['f32']):
+        assert np.isfinite(a) and abs(a - b) <= 2e-2 * abs(b) + 1e-3, (traj['bf16'], traj['f32'])
+    if B > 1:
+        assert traj['f32'][2] < traj['f32'][0] and traj['bf16'][2] < traj['bf16'][0]
