@@ -7,13 +7,14 @@
 under bf16 autocast on the GPU:
 
   dic_lstm_pack (one launch): the eight f32 parameters -> bf16 operands (W_ih padded, bias column / bias vector, W_hh, W_hh^T)
-  time-parallel GEMMs (hipBLASLt, bf16 in / f32 accumulate), issued here:
-      gx = X.W_ih^T + b_ih + b_hh            (R*B x I) . (I x 8H)     [I >= 32: decoder; the encoder's 18-wide
-                                                                       projection runs inside the recurrence kernel]
-      dX = dG.W_ih;  decoder: dW_ih = dG^T.X, dW_hh = dG^T.H_prev as split-K products
-  encoder: dW_ih and dW_hh from ONE pass over dG (dic_lstm_dw, MFMA with transposed LDS reads)
-  sequential recurrence (dic_lstm_fwd / dic_lstm_bwd): one workgroup per 64 batch rows and direction keeps
-  h, c (dh, dc) on chip for all R steps with W_hh resident in registers.
+  input projection gx = X.W_ih^T + b_ih + b_hh   (R*B x I) . (I x 8H):
+      encoder (18 features packed to 32): inside the recurrence kernel (dic_lstm_fwd_proj), gx never exists;
+      decoder (I = 256): dic_row_proj, weights resident in registers (smaller batches / other widths: library addmm)
+  sequential recurrence (dic_lstm_fwd / dic_lstm_bwd, dic_lstm_rec_* for batches up to SMALL_BATCH): one workgroup per 64 (32)
+      batch rows and direction keeps h, c (dh, dc) on chip for all R steps with W_hh resident in registers; the encoder's forward
+      also writes the rectified copy of its output the decoder reads, its backward applies that ReLU's mask
+  weight gradients dW_ih, dW_hh of both directions from ONE pass over dG (dic_lstm_dw: encoder, with its dX fused;
+      dic_lstm_dw_wide: decoder); the decoder's dX = dG.W_ih is the one library GEMM left
   Parameter gradients are written by the kernels straight into ``param.grad`` when those exist (the flat gradient bucket of
   ``dist.FlatParams``): no (2,4H,.) staging copies, no per-parameter AccumulateGrad add launches.
 
