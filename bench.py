@@ -286,6 +286,39 @@ def record_small_batch(make_stepper, X, OB, LEN, batch=256, steps=100):
     return out
 
 
+def record_fake_detection(K, dev, X, OB, LEN, batch, steps=12, warmup=4):
+    """Upstream's default unsupervised objective (p3:78 without the private supervised labels: ae_mse + fake detection + 10 kl): sci / cci /
+    encoder run a second time on corrupted samples (dataloader.py:182-193) and the detection head is trained.  ms per step, same batch."""
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = make_args(K, True, 0.0)
+    torch.manual_seed(1234)
+    net = Net(args, dev).to(dev)
+    net.train()
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16, use_graphs=False)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x, ob, ln = X[:batch], OB[:batch], LEN[:batch]
+    m = x[:, C:2 * C] > 0
+    hit = m & (torch.rand(m.shape, device=dev, generator=g) < 0.5)
+    xf = x.clone()
+    xf[:, :C] = torch.where(hit, torch.rand(m.shape, device=dev, generator=g) * 5.0 - 2.5, x[:, :C])
+    label2 = torch.cat([torch.ones(batch, device=dev), torch.zeros(batch, device=dev)])
+
+    def one():
+        perm = torch.randperm(2 * batch, device=dev)
+        return st.step(x, ob, None, ln, fake_x=xf, fake_perm_idx=perm, fake_det_label=label2[perm].to(torch.int64))
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    return {'loss': 'ae_mse + fake_detection + 10*kl', 'per_gpu_batch': batch, 'ms_per_step': round(ms, 3), 'encounters_per_s': round(batch / ms * 1e3, 1)}
+
+
 def record_f32(make_stepper_f32, X, OB, LEN, batch=4096, steps=10):
     """No autocast: every GEMM / recurrence operand in f32 -- the configuration of the 1e-5 parity tests."""
     st = make_stepper_f32()
@@ -630,6 +663,8 @@ def main():
             log('batch256 done', out['batch256'])
             out['f32'] = guarded(record_f32, lambda: fresh(None, False), X, OB, LEN)
             log('f32 done', out['f32'])
+            out['fake_detection_objective'] = guarded(record_fake_detection, K, dev, X, OB, LEN, a.batch)
+            log('fake-detection objective done', out['fake_detection_objective'])
             out['loss_rel_dev_vs_oracle'] = guarded(record_loss_deviation, K, dev)
             log('loss deviation done', out['loss_rel_dev_vs_oracle'])
             out['cfg4'] = guarded(record_cfg4, dev, a.kernel_iters)

@@ -411,15 +411,18 @@ __device__ float cci_backward_lds(float* sm, const BwdLayout& L, int Ev, int C, 
         gs[i] = g[cr] - g[2 * CR + cr];
     }
     __syncthreads();
-    // dL/dK[i][j] = sum_{e,r} a[e][i][r] * gs[e][j][r]
+    // dL/dK[i][j] = sum_{e,r} a[e][i][r] * gs[e][j][r]: the (e, r) terms of an output are dealt over kBlock / C^2 threads (slices of a
+    // fixed stride: each thread keeps its partial across all tiles, the caller folds the slices once at the end -- C^2 threads walking
+    // all Ev * R terms alone was a chain of dependent LDS reads a fifth of the tile's lifetime long)
     float gk = 0.f;
-    if (tid < C * C) {
-        const int i = tid / C, j = tid % C;
-        for (int e = 0; e < Ev; ++e) {
-            const float* ar = amat + e * CR + i * R;
-            const float* gr = gs + e * CR + j * R;
-            for (int r = 0; r < R; ++r) gk = fmaf(ar[r], gr[r], gk);
-        }
+    {
+        const int cc = C * C, nsl = kBlock / cc;
+        const int o = tid % cc, sl = tid / cc, i = o / C, j = o - i * C;
+        if (sl < nsl)
+            for (int k = sl; k < Ev * R; k += nsl) {
+                const int e = k / R, r = k - e * R;
+                gk = fmaf(amat[e * CR + i * R + r], gs[e * CR + j * R + r], gk);
+            }
     }
     // ga[e][c][r] = sum_j gs[e][j][r] * K[c][j]
     for (int i = tid; i < Ev * CR; i += kBlock) {
@@ -465,6 +468,19 @@ __device__ float cci_backward_lds(float* sm, const BwdLayout& L, int Ev, int C, 
     }
     __syncthreads();
     return gk;
+}
+
+// the per-thread dL/dK slices of cci_backward_lds (thread = slice * C^2 + output) -> out[C^2], in slice order (fixed)
+__device__ __forceinline__ void fold_gk_slices(float* sm, float gk, int C, float* out) {
+    const int tid = threadIdx.x, cc = C * C, nsl = kBlock / cc;
+    __syncthreads();
+    sm[tid] = gk;                                   // (the first kBlock words of the workgroup's LDS: everything there is dead by now)
+    __syncthreads();
+    if (tid < cc) {
+        float s = 0.f;
+        for (int k = 0; k < nsl; ++k) s += sm[k * cc + tid];
+        out[tid] = s;
+    }
 }
 
 // Fused backward: grad_out (B,R,3C) + saved (B,7,C,R) -> per-block partials [C | C*C].
@@ -523,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_bwd_kernel(const float* grad_o
     float* o = partials + (size_t)blockIdx.x * (C + C * C);
     const int lpc = channel_group_lanes(C);
     if (tid % lpc == 0 && tid / lpc < C) o[tid / lpc] = ga_acc;
-    if (tid < C * C) o[C + tid] = gk_acc;
+    fold_gk_slices(smem, gk_acc, C, o + C);
 }
 
 // Stand-alone CCI backward: grad wrt s (B,R,3C) and per-block dL/dK partials.
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void cci_bwd_kernel(const float* grad_out, 
             grad_s[(size_t)e0 * R * 3 * C + i] = gout[(e * 3 * C + qc) * R + r];
         }
     }
-    if (tid < C * C) partials[(size_t)blockIdx.x * (C + C * C) + C + tid] = gk_acc;
+    fold_gk_slices(smem, gk_acc, C, partials + (size_t)blockIdx.x * (C + C * C) + C);
     if (tid < C) partials[(size_t)blockIdx.x * (C + C * C) + tid] = 0.f;
 }
 
