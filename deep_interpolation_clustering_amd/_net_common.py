@@ -5,9 +5,10 @@ Layer inventory and ``state_dict`` keys are upstream's: ``sci.kernel``, ``cci.ke
 optional ``predict_future / aux_head / fake_det_head`` ``.model.*`` and (clustering only)
 ``cluster_assignment.cluster_centers`` -- checkpoints are interchangeable with the reference's.
 
-What runs where: interpolation (k1), de-interpolation (k2), reconstruction loss, DEC soft assignment,
-target and KL (k3) are HIP kernels; the two bi-LSTMs and the small FC heads are PyTorch-ROCm
-(MIOpen / hipBLASLt).  Differences from upstream that do not change results: at small batch sizes the fake / positive
+What runs where: interpolation (k1), de-interpolation (k2) with the reconstruction loss, DEC soft assignment, target and KL (k3), the
+bi-LSTM recurrences, their input projections and weight gradients, and CompressFC / the heads' BatchNorm tails are HIP kernels
+(csrc/); what is left to the libraries is the decoder LSTM's input-gradient GEMM, the heads' small first layers, and -- off the GPU,
+or for LSTM shapes the kernels are not compiled for -- torch.nn.LSTM itself.  Differences from upstream that do not change results: at small batch sizes the fake / positive
 branches share ONE encoder call with the real batch (rows are independent in sci, cci and the LSTM),
 and BatchNorm uses global-batch moments when the batch is sharded over ranks.
 """

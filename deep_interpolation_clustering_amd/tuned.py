@@ -1,9 +1,9 @@
 """Pre-tuned library GEMM selections for the dense layers of the joint step.
 
-The time-parallel GEMMs around the LSTM recurrence kernels (input projection, dX, the split-K weight gradients, the
-CompressFC layers) go to hipBLASLt / rocBLAS through PyTorch.  Their default heuristics are off for several of the
-step's shapes (K = 256 with a 786 432-row output; 184-batch 4096-row split-K products): PyTorch's TunableOp picks the
-fastest solution per shape, 3-4 % of the step at B = 32 768.  ``tuned_gemm_gfx950.csv`` holds the result of
+The GEMMs the hand-written kernels do not cover (the decoder LSTM's dX; at batch sizes / shapes below the kernels' thresholds
+also the input projection, the split-K weight gradients and the CompressFC layers) go to hipBLASLt / rocBLAS through PyTorch.
+Their default heuristics are off for several of the step's shapes (K = 256 with a 786 432-row output; 184-batch 4096-row split-K
+products): PyTorch's TunableOp picks the fastest solution per shape (3-4 % of the round-1 step at B = 32 768).  ``tuned_gemm_gfx950.csv`` holds the result of
 ``scripts/tune_gemms.py`` on an MI355X (ROCm 7.x validators inside the file: it is ignored on any other stack);
 ``enable()`` switches TunableOp on in read-only mode with that table.  Shapes not in the table use the default.
 """
