@@ -15,7 +15,6 @@
 
 namespace dic {
 
-constexpr int MCOLS = 64;            // centroid columns per workgroup
 constexpr int MCP = 256 + 2;         // LDS pitch of a centroid row (floats): == 2 (mod 64) words -> conflict-free b64 reads over 32 rows
 
 typedef float kf32x16 __attribute__((ext_vector_type(16)));
@@ -32,9 +31,11 @@ struct KmMfmaArgs {
     int* pcnt;                 // (n_runs,nblk,K+1): counts | #changed
 };
 
-template <int KP>
-__global__ __launch_bounds__(256, 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a) {
+template <int KP, int NMB>
+__global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a) {
+    constexpr int MCOLS = 32 * NMB;
     constexpr int G = MCOLS / KP;                       // restarts per workgroup
+    static_assert(G >= 1, "a restart's centroids must fit the workgroup's columns");
     extern __shared__ __align__(16) unsigned char ksm[];
     float* cent = reinterpret_cast<float*>(ksm);                         // [64][MCP]; reused for the cross-wave sum at the end
     float* cnorm = cent + MCOLS * MCP;                                   // [64]
@@ -70,15 +71,15 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a
     }
     __syncthreads();
     // the centroid of accumulator register `reg` of M-block mb in this lane: m = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 hh
-    float cn[2][16];
+    float cn[NMB][16];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) cn[mb][reg] = cnorm[32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * hh];
 
-    kf32x16 S[2][8];                                     // sums[centroid column block][d block]: column jj of d-block nb is d = 128 (nb >> 2) + 4 jj + (nb & 3)
+    kf32x16 S[NMB][8];                                   // sums[centroid column block][d block]: column jj of d-block nb is d = 128 (nb >> 2) + 4 jj + (nb & 3)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
@@ -90,16 +91,18 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a
         const bool valid = row < N;
         const float* xr = a.X + (size_t)min(row, N - 1) * D;
         // ---- scores: D'[centroid][row] = sum_k C[centroid][k] X[row][k]; MFMA 2m + e multiplies k = 4m + 2hh + e
-        kf32x16 dacc[2];
+        kf32x16 dacc[NMB];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { dacc[0][k] = 0.f; dacc[1][k] = 0.f; }
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dacc[mb][k] = 0.f;
 #pragma unroll 8
         for (int m = 0; m < 64; ++m) {
             const int kk = 4 * m + 2 * hh;
             kf32x2 x2 = {0.f, 0.f};
             if (kk < D) x2 = *reinterpret_cast<const kf32x2*>(xr + kk);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < NMB; ++mb) {
                 const kf32x2 c2 = *reinterpret_cast<const kf32x2*>(cent + (32 * mb + j) * MCP + kk);
                 dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[0], x2[0], dacc[mb], 0, 0, 0);
                 dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[1], x2[1], dacc[mb], 0, 0, 0);
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a
             float best = INFINITY;
             int bi = 1 << 20;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int mcol = 32 * mb + (reg & 3) + 8 * (reg >> 2);      // + 4 hh
@@ -141,15 +144,17 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a
         }
         // (lab8 of this wave is written and read by this wave only: wave-local ordering through the LDS queue)
         // ---- sums: S[col][d] += sum_rows onehot[col][row] X[row][d]; MFMA n multiplies rows 2n + hh
-        unsigned lw[2][8];                                   // labels of the 32 rows for the restarts of this lane's two centroid columns
+        unsigned lw[NMB][8];                                 // labels of the 32 rows for the restarts of this lane's centroid column(s)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < NMB; ++mb) {
             const int g = (32 * mb + j) / KP;
             const unsigned* lp = reinterpret_cast<const unsigned*>(lab8 + (w * G + g) * 32);
 #pragma unroll
             for (int q = 0; q < 8; ++q) lw[mb][q] = lp[q];
         }
-        const int kc0 = j % KP, kc1 = (32 + j) % KP;
+        int kc[NMB];
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) kc[mb] = (32 * mb + j) % KP;
 #pragma unroll 4
         for (int n = 0; n < 16; ++n) {
             const int rr = 2 * n + hh;
@@ -158,16 +163,19 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a
             if (4 * j < D) xlo = *reinterpret_cast<const kf32x4*>(xrow + 4 * j);
             if (128 + 4 * j < D) xhi = *reinterpret_cast<const kf32x4*>(xrow + 128 + 4 * j);
             // byte rr of the packed labels: dword rr >> 2, byte rr & 3 (rr = 2n + hh)
-            const unsigned b0 = (hh ? (lw[0][n >> 1] >> (16 * (n & 1) + 8)) : (lw[0][n >> 1] >> (16 * (n & 1)))) & 255u;
-            const unsigned b1 = (hh ? (lw[1][n >> 1] >> (16 * (n & 1) + 8)) : (lw[1][n >> 1] >> (16 * (n & 1)))) & 255u;
-            const float a0 = b0 == (unsigned)kc0 ? 1.0f : 0.0f, a1 = b1 == (unsigned)kc1 ? 1.0f : 0.0f;
+            float onehot[NMB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                S[0][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, xlo[e], S[0][e], 0, 0, 0);
-                S[1][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, xlo[e], S[1][e], 0, 0, 0);
-                S[0][4 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, xhi[e], S[0][4 + e], 0, 0, 0);
-                S[1][4 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, xhi[e], S[1][4 + e], 0, 0, 0);
+            for (int mb = 0; mb < NMB; ++mb) {
+                const unsigned b = (hh ? (lw[mb][n >> 1] >> (16 * (n & 1) + 8)) : (lw[mb][n >> 1] >> (16 * (n & 1)))) & 255u;
+                onehot[mb] = b == (unsigned)kc[mb] ? 1.0f : 0.0f;
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb) {
+                    S[mb][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(onehot[mb], xlo[e], S[mb][e], 0, 0, 0);
+                    S[mb][4 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(onehot[mb], xhi[e], S[mb][4 + e], 0, 0, 0);
+                }
         }
     }
     // ---- the 4 waves' sums -> one partial per workgroup (through the centroid area), counts, #changed
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a
     for (int ww = 0; ww < 4; ++ww) {
         if (w == ww) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
@@ -206,29 +214,45 @@ __global__ __launch_bounds__(256, 1) void kmeans_assign_mfma_kernel(KmMfmaArgs a
 // Row-chunk workgroups per restart group: one workgroup per CU over ALL groups (67 KB of LDS, ~500 registers: one resident workgroup
 // per CU), so that each pays its centroid staging and its cross-wave reduction once and walks several tiles per wave
 // (0.34 -> 0.2 ms per iteration of 10 restarts at K = 16 against three rounds of 256 workgroups).
+// one (NMB = 1) or two MFMA row blocks of centroid columns per workgroup: whichever leaves fewer padding columns over all restarts
+// (10 restarts of K = 16: five groups of 32 columns = 160, against three groups of 64 = 192 with a half-empty last one)
+static int kmeans_mfma_nmb(int K, int n_runs) {
+    const int KP = K <= 16 ? 16 : 32;
+    const int c1 = (n_runs + 32 / KP - 1) / (32 / KP) * 32, c2 = (n_runs + 64 / KP - 1) / (64 / KP) * 64;
+    return c1 <= c2 ? 1 : 2;        // (ties go to the one-block variant: half the accumulators, two workgroups per CU)
+}
+static int kmeans_mfma_groups(int K, int n_runs) {
+    const int G = 32 * kmeans_mfma_nmb(K, n_runs) / (K <= 16 ? 16 : 32);
+    return (n_runs + G - 1) / G;
+}
 int kmeans_mfma_blocks(int N, int K, int n_runs) {
-    const int G = MCOLS / (K <= 16 ? 16 : 32), groups = (n_runs + G - 1) / G;
-    return (int)max(1L, min(((long)N + 127) / 128, (long)max(1, kNumCU / groups)));
+    const int per_cu = kmeans_mfma_nmb(K, n_runs) == 1 ? 2 : 1;          // (one row block: half the accumulators, two workgroups per CU)
+    return (int)max(1L, min(((long)N + 127) / 128, (long)max(1, per_cu * kNumCU / kmeans_mfma_groups(K, n_runs))));
+}
+
+template <int KP, int NMB>
+static int kmeans_assign_mfma_launch_t(const KmMfmaArgs& a, int groups, hipStream_t st) {
+    constexpr int MCOLS = 32 * NMB, G = MCOLS / KP;
+    const size_t lds = (size_t)MCOLS * MCP * 4 + MCOLS * 4 + MCOLS * 4 + 16 + 4 * G * 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kmeans_assign_mfma_kernel<KP, NMB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "kmeans_assign_mfma: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((kmeans_assign_mfma_kernel<KP, NMB>), dim3(a.nblk, groups), dim3(256), lds, st, a);
+    return DIC_OK;
 }
 
 // Launches the E-step + partial M-step for K in (8, 32].  nblk = kmeans_mfma_blocks(N, K, n_runs) partial slots per restart are written.
 int kmeans_assign_mfma_launch(const float* X, const float* xnorm, int N, int D, int K, int n_runs, const float* centers, int32_t* labels,
                               const float* status, float* mind, float* psum, int* pcnt, hipStream_t st) {
-    const int KP = K <= 16 ? 16 : 32;
-    const int G = MCOLS / KP;
-    const size_t lds = (size_t)MCOLS * MCP * 4 + MCOLS * 4 + MCOLS * 4 + 16 + 4 * G * 32;
     KmMfmaArgs a{X, xnorm, N, D, K, n_runs, kmeans_mfma_blocks(N, K, n_runs), centers, labels, status, mind, psum, pcnt};
-    static bool attr_set[2] = {false, false};
-    const void* fn = KP == 16 ? (const void*)kmeans_assign_mfma_kernel<16> : (const void*)kmeans_assign_mfma_kernel<32>;
-    if (!attr_set[KP == 32]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "kmeans_assign_mfma: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-        attr_set[KP == 32] = true;
-    }
-    const dim3 grid(a.nblk, (n_runs + G - 1) / G);
-    if (KP == 16) hipLaunchKernelGGL(kmeans_assign_mfma_kernel<16>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(kmeans_assign_mfma_kernel<32>, grid, dim3(256), lds, st, a);
-    return check_launch("kmeans_assign_mfma");
+    const int nmb = kmeans_mfma_nmb(K, n_runs), groups = kmeans_mfma_groups(K, n_runs);
+    int rc;
+    if (K <= 16) rc = nmb == 1 ? kmeans_assign_mfma_launch_t<16, 1>(a, groups, st) : kmeans_assign_mfma_launch_t<16, 2>(a, groups, st);
+    else rc = nmb == 1 ? kmeans_assign_mfma_launch_t<32, 1>(a, groups, st) : kmeans_assign_mfma_launch_t<32, 2>(a, groups, st);
+    return rc ? rc : check_launch("kmeans_assign_mfma");
 }
 
 }  // namespace dic

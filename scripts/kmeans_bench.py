@@ -35,7 +35,7 @@ for K, n_init in ((4, 20), (8, 20), (16, 10)):
     print(f'HIP  KMeans(K={K}, n_init={n_init}).fit: {dt * 1e3:8.1f} ms  inertia {km.inertia_:.1f}  n_iter {km.n_iter_}')
 # one Lloyd iteration, all restarts in one launch: algorithmic bytes = n_runs * N * (4D + 4)
 L = N.lib()
-for K, runs in ((4, 1), (4, 20), (16, 10)):
+for K, runs in ((4, 1), (4, 20), (16, 10), (16, 20), (20, 10)):
     Xc = Xd - Xd.mean(0)
     xn = (Xc * Xc).sum(1)
     cent = Xc[torch.randint(0, n, (runs, K), device='cuda')].contiguous()
