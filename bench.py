@@ -459,8 +459,9 @@ def guarded(fn, *a, **kw):
         return {'error': repr(e)[:300]}
 
 
-def cpu_baseline(K, seconds):
-    """The CPU oracle (a port of the reference's PyTorch path: oracle/dic_oracle.py) timed on this host."""
+def cpu_baseline(K, seconds, B=256, threads=None, max_steps=200):
+    """The CPU oracle (a port of the reference's PyTorch path: oracle/dic_oracle.py) timed on this host.
+    B = 256 is the reference's own batch size (p1_pretrain_main.py:43); SURVEY.md 8d also asks for B = 2048 and for 8 threads."""
     from deep_interpolation_clustering_amd import synthetic
     from oracle import dic_oracle as O
     try:
@@ -468,8 +469,9 @@ def cpu_baseline(K, seconds):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get('DIC_CPU_THREADS', 16))))    # the GPU box grants ~16 cores per GPU
+    if threads:
+        cores = max(1, min(cores, threads))
     torch.set_num_threads(cores)
-    B = 256                                          # the reference's own batch size (p1_pretrain_main.py:43)
     coh = synthetic.make_cohort(B, C=C, T=T, H=H, lam=LAM, G=K, seed=99)
     x_np, ob_np, _ = synthetic.stacked_batch(coh)
     x, ob = torch.tensor(x_np), torch.tensor(ob_np)
@@ -484,7 +486,7 @@ def cpu_baseline(K, seconds):
         O.train_step(net, opt, x, ob, x[:, C:2 * C], 10.0, 15.0)
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
+        if el >= seconds or n >= max_steps:
             break
     return {'value': round(B * n / el, 1), 'unit': 'encounters/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} joint steps of B={B} (C={C}, T={T}, R={R}, K={K}, f32) on torch-CPU, {el:.1f} s',
@@ -649,6 +651,8 @@ def main():
                                                     'profile_round': sj.get('_round')}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(K, a.cpu_seconds)
+            if not a.no_secondary:        # the other two points of SURVEY.md 8d's CPU comparison, a few seconds each
+                out['cpu_baseline_more'] = [guarded(cpu_baseline, K, 6.0, 256, 8, 60), guarded(cpu_baseline, K, 8.0, 2048, None, 12)]
         if world == 1 and not a.no_secondary:
             del stepper
             torch.cuda.empty_cache()
