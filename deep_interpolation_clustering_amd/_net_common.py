@@ -181,7 +181,7 @@ class NetBase(nn.Module):
             if len(feats) > 1:
                 context = context[:, :B]
                 hidden, cell = (hidden[:B], cell[:B]) if bm else (hidden[:, :B].contiguous(), cell[:, :B].contiguous())
-        cat_hidden = z_all[:B]
+        cat_hidden = z_all if z_all.size(0) == B else z_all[:B]        # (no slice node -- and no zero-filled slice_backward -- without extra branches)
         if self.on_decoder_side_grads is not None and context.requires_grad:
             cb = self.on_decoder_side_grads
             context.register_hook(lambda g: cb())           # fires when the backward has passed the decoder, its head and the latent heads

@@ -147,6 +147,7 @@ class _BiLstm(torch.autograd.Function):
         ctx.has_init = h0 is not None
         ctx.params = params
         ctx.save_for_backward(xb, wih, whh if f32 else whh_t, gates, cs, out_ext, h0c, c0c)
+        ctx.set_materialize_grads(False)       # an output nobody differentiates (c_n, often h_n or out) arrives as None, not as a zero tensor
         # relu: the caller consumes relu(out) only (the decoder's input, clustering_interp.py:38-41).  The raw rows stay in out_ext for the
         # weight-gradient products (the 64-row kernels write the rectified copy next to them); the backward kernel applies the ReLU
         # mask itself (sign of tanh(c_t)), so no mask pass and no saved copy
