@@ -98,6 +98,8 @@ struct LstmFwdArgs {
     __bf16* cs;            // lane-native (R,Bpad,2,H) cell states rounded to bf16 (the recurrence itself carries c in f32), or NULL
     int R, B;
     int bm;                // state tensors batch-major (B,2,H) instead of (2,B,H)
+    int boundary;          // out is time slots 1..R of an (R+2,B,2H) buffer: also write h0 (bf16; zeros without one) into slot 0 [:, :H]
+                           // (forward direction) / slot R+1 [:, H:] (reverse) -- every step's recurrent input for the weight-gradient kernels
 };
 
 // PROJ = false: G_t starts from a precomputed gx_t (the projection was a library GEMM: decoder, input width 256).
@@ -153,6 +155,10 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
 #pragma unroll
             for (int j = 0; j < 4; ++j) { hb[j] = (__bf16)hv[j]; c[nb][4 * q + j] = cv[j]; }
             *reinterpret_cast<bf16x4*>(&hbuf[0][(nb * 32 + r) * HSTR + u]) = hb;
+            if (a.boundary && b < B) {
+                __bf16* slot = dir ? a.out + (size_t)R * B * 2 * LH : a.out - (size_t)B * 2 * LH;
+                *reinterpret_cast<bf16x4*>(slot + (size_t)b * 2 * LH + dir * LH + u) = hb;
+            }
         }
     }
     // gx tile of a step -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, asynchronous): one instruction moves
@@ -571,23 +577,24 @@ static int lstm_fwd_launch(bool proj, const LstmFwdArgs& a, hipStream_t st) {
 }
 
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                 void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream) {
+                 void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, int write_boundary, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd: gates and cs go together");
-    LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0};
+    LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0, write_boundary != 0};
     return lstm_fwd_launch(false, a, (hipStream_t)stream);
 }
 
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                      int I, void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream) {
+                      int I, void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, int write_boundary,
+                      dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(I == LXK, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: input width %d (compiled for %d: zero-pad narrower inputs)", I, LXK);
     DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd_proj: gates and cs go together");
-    LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0};
+    LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0, write_boundary != 0};
     return lstm_fwd_launch(true, a, (hipStream_t)stream);
 }
 

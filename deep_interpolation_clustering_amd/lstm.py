@@ -104,7 +104,8 @@ class _BiLstm(torch.autograd.Function):
                 xb[..., I].fill_(1.0)                              # the bias rides along as a constant-one input column
         out_ext = torch.empty((R + 2, B, 2 * H), device=dev, dtype=T)       # [h0 | h_1..h_R | h0]: every step's h_prev is a row above / below
         out = out_ext[1:R + 1]
-        if need:                                                   # boundary rows of the dW_hh products (backward); the other halves are never read
+        kernel_boundary = need and not small                       # the 64-row kernels write the boundary rows of the dW_hh products themselves
+        if need and small:                                         # (h0 into time slot 0 [:H] / slot R+1 [H:]; the other halves are never read)
             if h0 is None:
                 out_ext[0, :, :H].zero_()
                 out_ext[R + 1, :, H:].zero_()
@@ -132,7 +133,7 @@ class _BiLstm(torch.autograd.Function):
                 cs = torch.empty((R, Bp, 2, H), device=dev, dtype=T)    # bf16 copy for the backward; c itself stays f32 on chip
             if proj:
                 N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out), N.ptr(out_r),
-                                            N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd_proj')
+                                            N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), st), 'dic_lstm_fwd_proj')
             else:
                 if Ip == WIDE_INPUT and ROW_PROJ:
                     # decoder: the input projection with the weights resident in registers (csrc/dic_rowproj.hip)
@@ -141,7 +142,7 @@ class _BiLstm(torch.autograd.Function):
                 else:
                     gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
                 N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
-                                       N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_fwd')
+                                       N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), st), 'dic_lstm_fwd')
         ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32), bool(relu))
         ctx.x_dtype = x.dtype
         ctx.has_init = h0 is not None

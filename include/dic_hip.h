@@ -245,7 +245,10 @@ int dic_kmeans_pp_candidates_rows(const float* X, int N, int D, int row_lo, int 
  * state_batch_major != 0: h0, c0, hn, cn and their gradients are laid out (B,2,H) instead of nn.LSTM's (2,B,H), so that
  * hn viewed as (B,2H) is the concatenated latent [h_fwd | h_rev] (clustering_interp.py:139) and feeds the decoder with no copy. */
 int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                 void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
+                 void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, int write_boundary,
+                 dic_stream_t stream);
+/* write_boundary != 0: `out` points at time slot 1 of an (R+2,B,2H) buffer (dic_lstm_dw's out_ext); the kernel also writes h0 (bf16;
+ * zeros without one) into slot 0 [:, :H] and slot R+1 [:, H:], the recurrent inputs of the first forward / reverse step. */
 /* out_relu (R,B,2H) bf16 or NULL: a second copy of the output with relu applied -- what DecoderRNN.forward reads of the encoder's
  * output (clustering_interp.py:38-41).  It leaves through the LDS tile of h the next step multiplies, as whole 256-B row halves;
  * the element-wise ReLU pass over (R,B,2H) disappears (its backward: dic_lstm_bwd's dout_of_relu). */
@@ -254,7 +257,8 @@ int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* 
  * the bias in as a constant-one input column whose weights are b_ih + b_hh).  Everything else as dic_lstm_fwd; the
  * backward is dic_lstm_bwd unchanged. */
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
-                      int I, void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
+                      int I, void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, int write_boundary,
+                      dic_stream_t stream);
 size_t dic_lstm_bwd_workspace(int B);
 int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,
