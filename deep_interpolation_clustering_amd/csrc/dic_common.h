@@ -52,6 +52,13 @@ __device__ __forceinline__ float wave_max(float v) {
 // 2^x on the transcendental unit (v_exp_f32).  Callers pass x <= 0 (max-subtracted logits),
 // so the missing denormal handling only flushes weights below 2^-126 to zero.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// e^x and ln x on the transcendental unit (one multiply + v_exp_f32 / v_log_f32 + one multiply: ~1 ulp of the hardware op plus the
+// rounding of the scaled argument, i.e. a relative error of |x| * 6e-8 for e^x) instead of libm's ~25-instruction sequences.  Used
+// where the argument is O(10) at most and the result feeds 3e-5-tolerance outputs: the cross-channel epilogue of k1 spends as many
+// vector instructions in expf / logf as a third of its streaming passes.  Arguments of fast_log are >= 1 there (sums whose largest
+// term is 1), so its missing denormal handling never shows; e^-inf = 0, NaN propagates.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
 // log(1 + e^k): the positive bandwidth upstream derives from its raw `kernel` parameter
 // (interpolation_layer.py:51, rbf.py:78).

@@ -80,15 +80,15 @@ __device__ void cci_epilogue(const float* res, const float* kmat, float* mean, f
         float mx = -INFINITY;
         for (int c = 0; c < C; ++c) mx = fmaxf(mx, w[c * R]);
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(w[c * R] - mx);
-        lse[i] = (mx == -INFINITY) ? -INFINITY : mx + logf(s);
+        for (int c = 0; c < C; ++c) s += fast_exp(w[c * R] - mx);
+        lse[i] = (mx == -INFINITY) ? -INFINITY : mx + fast_log(s);
     }
     __syncthreads();
     for (int i = tid; i < Ev * R * C; i += kBlock) {      // a = softmax_c(w) * (y - mean)
         const int e = i / (R * C), rc = i % (R * C), r = rc / C, c = rc % C;
         const float* base = res + e * 3 * C * R;
         const float y = base[c * R + r], w = base[(C + c) * R + r];
-        amat[i] = expf(w - lse[e * R + r]) * (y - mean[e * C + c]);
+        amat[i] = fast_exp(w - lse[e * R + r]) * (y - mean[e * C + c]);
     }
     __syncthreads();
     for (int i = tid; i < Ev * R * C; i += kBlock) {      // smooth = a @ K + mean
@@ -98,7 +98,7 @@ __device__ void cci_epilogue(const float* res, const float* kmat, float* mean, f
         float s = 0.f;
         for (int c = 0; c < C; ++c) s = fmaf(arow[c], kmat[c * C + j], s);
         s += mean[e * C + j];
-        const float inten = expf(base[(C + j) * R + r]), trans = base[(2 * C + j) * R + r] - s;
+        const float inten = fast_exp(base[(C + j) * R + r]), trans = base[(2 * C + j) * R + r] - s;
         if (out) {
             float* o = out + ((size_t)(e0 + e) * R + r) * 3 * C;
             o[j] = s;
@@ -305,9 +305,9 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
         if (live && s == 0) {
             float y, w, yt, eu1, exu1, eu10, exu10;
             if (umin < kEmptyU) {
-                const float i1 = 1.0f / s1, i10 = 1.0f / s10;
+                const float i1 = __builtin_amdgcn_rcpf(s1), i10 = __builtin_amdgcn_rcpf(s10);       // (s >= 1: the largest weight is exactly 1)
                 y = sx1 * i1;  yt = sx10 * i10;
-                w = logf(s1) - al * umin;
+                w = fast_log(s1) - al * umin;
                 eu1 = su1 * i1;  exu1 = sxu1 * i1;  eu10 = su10 * i10;  exu10 = sxu10 * i10;
             } else {   // no observation on this channel: upstream yields exp(-inf+inf)=NaN and LSE=-inf
                 y = yt = eu1 = exu1 = eu10 = exu10 = NAN;
@@ -422,15 +422,15 @@ __device__ float cci_backward_lds(float* sm, const BwdLayout& L, int Ev, int C, 
         float mx = -INFINITY;
         for (int c = 0; c < C; ++c) mx = fmaxf(mx, w[c * R]);
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(w[c * R] - mx);
-        lse[i] = (mx == -INFINITY) ? -INFINITY : mx + logf(s);
+        for (int c = 0; c < C; ++c) s += fast_exp(w[c * R] - mx);
+        lse[i] = (mx == -INFINITY) ? -INFINITY : mx + fast_log(s);
     }
     __syncthreads();
     for (int i = tid; i < Ev * CR; i += kBlock) {
         const int e = i / CR, cr = i % CR, c = cr / R, r = cr % R;
         const float* v = val + e * 3 * CR;
         const float* g = grd + e * 3 * CR;
-        const float wh = expf(v[CR + cr] - lse[e * R + r]);
+        const float wh = fast_exp(v[CR + cr] - lse[e * R + r]);
         what[i] = wh;
         amat[i] = wh * (v[cr] - mean[e * C + c]);
         gs[i] = g[cr] - g[2 * CR + cr];
@@ -488,7 +488,7 @@ __device__ float cci_backward_lds(float* sm, const BwdLayout& L, int Ev, int C, 
         const float gwh = ga[i] * (v[cr] - mean[e * C + c]);
         float* go = gout + e * 3 * CR;
         go[cr] = ga[i] * wh + (sgs[e * C + c] - sgaw[e * C + c]) * invR;
-        go[CR + cr] = g[CR + cr] * expf(v[CR + cr]) + wh * (gwh - gww[e * R + r]);
+        go[CR + cr] = g[CR + cr] * fast_exp(v[CR + cr]) + wh * (gwh - gww[e * R + r]);
         go[2 * CR + cr] = g[2 * CR + cr];
     }
     __syncthreads();
