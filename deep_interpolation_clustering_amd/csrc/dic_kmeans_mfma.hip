@@ -7,7 +7,7 @@
 // iteration are GEMMs:
 //     scores  D'[centroid][row] = C . X^T                (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation, as sgemm)
 //     sums    S[centroid][d]    = onehot(label)^T . X     (the A operand is 0 / 1: the MFMA adds exactly the assigned rows)
-// One workgroup serves the 64 centroid columns of 64/KP restarts at once (the restarts share every X tile), keeps those
+// One workgroup serves the 32 centroid columns of 32/KP restarts at once (the restarts share every X tile), keeps those
 // centroids in LDS, and gives each of its 4 waves its own 32-row tiles.  The score product is issued transposed so that a LANE
 // owns a row and the centroids sit in its registers: the argmin is 15 in-lane compares + one cross-half exchange, no butterfly.
 // Outputs are the per-workgroup partials the existing reduce / update kernels consume (fixed-order f64 second stage).
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
         int kc[NMB];
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb) kc[mb] = (32 * mb + j) % KP;
-#pragma unroll 4
+#pragma unroll
         for (int n = 0; n < 16; ++n) {
             const int rr = 2 * n + hh;
             const float* xrow = a.X + (size_t)min(r0 + rr, N - 1) * D;
@@ -214,20 +214,15 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
 // Row-chunk workgroups per restart group: one workgroup per CU over ALL groups (67 KB of LDS, ~500 registers: one resident workgroup
 // per CU), so that each pays its centroid staging and its cross-wave reduction once and walks several tiles per wave
 // (0.34 -> 0.2 ms per iteration of 10 restarts at K = 16 against three rounds of 256 workgroups).
-// one (NMB = 1) or two MFMA row blocks of centroid columns per workgroup: whichever leaves fewer padding columns over all restarts
-// (10 restarts of K = 16: five groups of 32 columns = 160, against three groups of 64 = 192 with a half-empty last one)
-static int kmeans_mfma_nmb(int K, int n_runs) {
-    const int KP = K <= 16 ? 16 : 32;
-    const int c1 = (n_runs + 32 / KP - 1) / (32 / KP) * 32, c2 = (n_runs + 64 / KP - 1) / (64 / KP) * 64;
-    return c1 <= c2 ? 1 : 2;        // (ties go to the one-block variant: half the accumulators, two workgroups per CU)
-}
+// One MFMA row block (32 centroid columns) per workgroup: 32 / KP restarts share its X tiles.  (Two row blocks = 64 columns per
+// workgroup was the first layout: it needs all 512 registers -- one workgroup per CU, spilling -- and pads 10 restarts of K = 16 to
+// 192 columns where 32-column groups need 160; with half the accumulators two workgroups fit a CU: 284 -> 254 us per iteration.)
 static int kmeans_mfma_groups(int K, int n_runs) {
-    const int G = 32 * kmeans_mfma_nmb(K, n_runs) / (K <= 16 ? 16 : 32);
+    const int G = 32 / (K <= 16 ? 16 : 32);
     return (n_runs + G - 1) / G;
 }
 int kmeans_mfma_blocks(int N, int K, int n_runs) {
-    const int per_cu = kmeans_mfma_nmb(K, n_runs) == 1 ? 2 : 1;          // (one row block: half the accumulators, two workgroups per CU)
-    return (int)max(1L, min(((long)N + 127) / 128, (long)max(1, per_cu * kNumCU / kmeans_mfma_groups(K, n_runs))));
+    return (int)max(1L, min(((long)N + 127) / 128, (long)max(1, 2 * kNumCU / kmeans_mfma_groups(K, n_runs))));      // two workgroups per CU
 }
 
 template <int KP, int NMB>
@@ -248,10 +243,8 @@ static int kmeans_assign_mfma_launch_t(const KmMfmaArgs& a, int groups, hipStrea
 int kmeans_assign_mfma_launch(const float* X, const float* xnorm, int N, int D, int K, int n_runs, const float* centers, int32_t* labels,
                               const float* status, float* mind, float* psum, int* pcnt, hipStream_t st) {
     KmMfmaArgs a{X, xnorm, N, D, K, n_runs, kmeans_mfma_blocks(N, K, n_runs), centers, labels, status, mind, psum, pcnt};
-    const int nmb = kmeans_mfma_nmb(K, n_runs), groups = kmeans_mfma_groups(K, n_runs);
-    int rc;
-    if (K <= 16) rc = nmb == 1 ? kmeans_assign_mfma_launch_t<16, 1>(a, groups, st) : kmeans_assign_mfma_launch_t<16, 2>(a, groups, st);
-    else rc = nmb == 1 ? kmeans_assign_mfma_launch_t<32, 1>(a, groups, st) : kmeans_assign_mfma_launch_t<32, 2>(a, groups, st);
+    const int groups = kmeans_mfma_groups(K, n_runs);
+    const int rc = K <= 16 ? kmeans_assign_mfma_launch_t<16, 1>(a, groups, st) : kmeans_assign_mfma_launch_t<32, 1>(a, groups, st);
     return rc ? rc : check_launch("kmeans_assign_mfma");
 }
 

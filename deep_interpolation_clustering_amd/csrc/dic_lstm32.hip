@@ -287,33 +287,34 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
     // the inputs of a step: requested one step ahead for bf16 (48 registers: the global-load latency -- ~2 us per step at one
     // wave per SIMD -- hides behind the previous step's MFMAs and row stores); the f32 variant has no registers to spare for that
     // and is bound by its 256 MFMAs per step anyway
-    struct StepIn { V4 ib[4], fb[4], gb[4], ob[4], cp[4], go[4]; };      // raw loads: converting here would put a wait behind every load
+    struct StepQ { V4 ib, fb, gb, ob, cp, go; };      // one unit group's raw loads (converting at load time would put a wait behind every load)
     constexpr bool PREFETCH = sizeof(T) == 2;
-    auto load_in = [&](int step, StepIn& d) {
+    auto load_q = [&](int step, int q, StepQ& d) {
         const int t = dir ? step : R - 1 - step;           // reverse of the forward visiting order
         const int tp = step == R - 1 ? R : (dir ? t + 1 : t - 1);      // forward predecessor; the forward's first step reads c0 from slot R
         const size_t row = (size_t)t * B + bc;
         const int nbt = gridDim.x, bt = blockIdx.x;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int u = 32 * w + 8 * q + 4 * hh;
-            d.ib[q] = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
-            d.fb[q] = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
-            d.gb[q] = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
-            d.ob[q] = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
-            d.cp[q] = *reinterpret_cast<const V4*>(a.cs + snative_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
-            if (a.dout) d.go[q] = *reinterpret_cast<const V4*>(a.dout + row * 2 * SH + dir * SH + u);
-        }
+        const int u = 32 * w + 8 * q + 4 * hh;
+        d.ib = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
+        d.fb = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
+        d.gb = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
+        d.ob = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
+        d.cp = *reinterpret_cast<const V4*>(a.cs + snative_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
+        if (a.dout) d.go = *reinterpret_cast<const V4*>(a.dout + row * 2 * SH + dir * SH + u);
     };
-    StepIn in, nxt;
-    if (PREFETCH) load_in(0, in);
+    // bf16: all four groups of the next step in flight (48 registers).  f32: one group at a time, loaded where it is used -- the whole
+    // step's 96 registers of inputs next to the f32 W_hh fragments sent part of them to scratch memory
+    StepQ in0, in1, in2, in3, nx0, nx1, nx2, nx3;
+    if (PREFETCH) { load_q(0, 0, in0); load_q(0, 1, in1); load_q(0, 2, in2); load_q(0, 3, in3); }
     for (int step = 0; step < R; ++step) {
         const int t = dir ? step : R - 1 - step;
-        if (!PREFETCH) load_in(step, in);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int u = 32 * w + 8 * q + 4 * hh;
-            const V4 ib = in.ib[q], fb = in.fb[q], gb = in.gb[q], ob = in.ob[q], cpv = in.cp[q], gov = in.go[q];
+            StepQ cur;
+            if (PREFETCH) cur = q == 0 ? in0 : q == 1 ? in1 : q == 2 ? in2 : in3;
+            else load_q(step, q, cur);
+            const V4 ib = cur.ib, fb = cur.fb, gb = cur.gb, ob = cur.ob, cpv = cur.cp, gov = cur.go;
             sf32x4 cp, go;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { cp[j] = (float)cpv[j]; go[j] = a.dout ? (float)gov[j] : 0.f; }
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
             *reinterpret_cast<V4*>(lp + 2 * SH) = dg;
             *reinterpret_cast<V4*>(lp + 3 * SH) = dO;
         }
-        if (PREFETCH && step + 1 < R) load_in(step + 1, nxt);
+        if (PREFETCH && step + 1 < R) { load_q(step + 1, 0, nx0); load_q(step + 1, 1, nx1); load_q(step + 1, 2, nx2); load_q(step + 1, 3, nx3); }
         lds_barrier();                                     // the dG tile of this step is complete
         {   // dG rows LDS -> global, 16 B per lane: whole 1-KiB pieces per wave instruction (row-major for the weight-gradient GEMMs)
             constexpr int PIECES = S4 * sizeof(T) / 1024, NP = SROWS * PIECES / 4;
@@ -360,9 +361,14 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) bsum[e] += (float)x[e];
                     } else {                               // lane holds columns 256 part + 4 lane .. +3
+                        // (`part` depends on the wave index: a run-time subscript would send bsum to scratch memory)
+                        static_assert(sizeof(T) == 2 || PIECES == 2, "two 1-KiB pieces per f32 row");
                         const sf32x4 x = __builtin_bit_cast(sf32x4, v[k]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) bsum[part * 4 + e] += x[e];
+                        for (int e = 0; e < 4; ++e) {
+                            bsum[e] += part == 0 ? x[e] : 0.f;
+                            bsum[4 + e] += part == 0 ? 0.f : x[e];
+                        }
                     }
                 }
             }
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
         for (int k = 0; k < 16; ++k) dh[k] = 0.f;
         dh = Rec<T>::template mma<S4>(wt, dgt + r * GP, hh, dh);          // dh_{prev}[u][b] = sum_n W_hh[n][u] dG[b][n]
         lds_barrier();                                     // every wave is done reading the tile
-        if (PREFETCH) in = nxt;
+        if (PREFETCH) { in0 = nx0; in1 = nx1; in2 = nx2; in3 = nx3; }
     }
     if (a.dbias_part) {      // add the 4 waves' column sums through LDS (the dG tile is free now): one partial per workgroup
         float* red = reinterpret_cast<float*>(rsm);
