@@ -36,3 +36,28 @@ def test_pair_stats_consistency():
     d = CO.distance_matrix(x)
     np.testing.assert_allclose(S.sum(1), d.sum(1), rtol=1e-12)
     assert (Dmin[np.arange(50), lab] == 0).all() and (own_max <= d.max(1) + 1e-12).all()
+
+
+def test_reference_draws_into_a_buffer_replay_numpys_global_stream():
+    """p2's gap statistic draws its uniform reference sets from NumPy's GLOBAL legacy stream (p2_clustering_optK.py:372-375 upstream:
+    np.random.random_sample(shape)).  global_uniform_into fills a reused buffer instead: same doubles, and the stream continues
+    exactly where the original call would have left it (the k-means++ seeds that follow depend on it)."""
+    import numpy as np
+    from deep_interpolation_clustering_amd.p2_clustering_optK import global_uniform_into
+    np.random.seed(123)
+    want, after = np.random.random_sample((1000, 37)), np.random.random_sample(4)
+    np.random.seed(123)
+    np.random.standard_normal(3)                     # (a cached Gaussian in the legacy state must survive the detour)
+    np.random.seed(123)
+    buf = np.full((1000, 37), -1.0)
+    got = global_uniform_into(buf)
+    assert got is buf and np.array_equal(buf, want)
+    assert np.array_equal(np.random.random_sample(4), after)
+    np.random.seed(7)
+    g1 = np.random.standard_normal(1)                # leaves has_gauss = 1
+    global_uniform_into(buf)
+    tail = np.random.standard_normal(2)
+    np.random.seed(7)
+    assert np.array_equal(np.random.standard_normal(1), g1)
+    np.random.random_sample((1000, 37))
+    assert np.array_equal(np.random.standard_normal(2), tail)
