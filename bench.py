@@ -507,6 +507,9 @@ def main():
     import torch.distributed as td
 
     rank, world, local = dist.init_from_env()
+    sharded = dist.is_sharded()         # world > 1 (or the one-rank RCCL rehearsal of tests/test_gpu_dist.py)
+    if sharded and rank == 0:
+        log(f'process group: {td.get_backend()}, world {world}')
     if a.gpus != world and world > 1:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
@@ -551,7 +554,7 @@ def main():
                             fake_perm_idx=perm, fake_det_label=label2[perm].to(torch.int64))
 
     def barrier():
-        if world > 1:
+        if sharded:
             td.barrier()
         torch.cuda.synchronize()
 
@@ -563,7 +566,7 @@ def main():
         losses, gnorm, _ = one_step(a.warmup + i)
     barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         el = float(tt)
@@ -592,7 +595,7 @@ def main():
             kernels, groups = step_trace(counted_step, a.warmup + a.steps, TRACE_STEPS)    # (sharded: the other ranks run these steps with it, below)
         except Exception as e:
             log('step trace unavailable:', repr(e))
-        for i in range(ran[0], TRACE_STEPS if world > 1 else 0):                              # stay in lockstep with the other ranks whatever the tracer did
+        for i in range(ran[0], TRACE_STEPS if sharded else 0):                              # stay in lockstep with the other ranks whatever the tracer did
             one_step(a.warmup + a.steps + i)
         per_step = {}
         for name, row in table.items():
@@ -682,7 +685,7 @@ def main():
         for i in range(TRACE_STEPS):
             one_step(a.warmup + a.steps + i)
         torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         td.barrier()
         td.destroy_process_group()
 

@@ -86,8 +86,8 @@ __device__ unsigned long long dic_lstm_stamps[2][32][8];
 #endif
 
 struct LstmFwdArgs {
-    const __bf16* gx;      // (R,B,2,4,H) input projection + both biases      [lstm_fwd_kernel<false>]
-    const __bf16* x;       // (R,B,32) inputs and  wih (2,4H,32) input weights [lstm_fwd_kernel<true>: projection in-kernel]
+    const __bf16* gx;      // (R,B,2,4,H) input projection + both biases      [lstm_fwd_kernel<FWD_GX>; FWD_GXN: the lane-native form, gxn_off]
+    const __bf16* x;       // (R,B,32) inputs and  wih (2,4H,32) input weights [lstm_fwd_kernel<FWD_PROJ>: projection in-kernel]
     const __bf16* wih;
     const __bf16* whh;     // (2,4H,H)
     const float* h0; const float* c0;     // (2,B,H) or NULL (zeros)
@@ -102,13 +102,27 @@ struct LstmFwdArgs {
                            // (forward direction) / slot R+1 [:, H:] (reverse) -- every step's recurrent input for the weight-gradient kernels
 };
 
-// PROJ = false: G_t starts from a precomputed gx_t (the projection was a library GEMM: decoder, input width 256).
-// PROJ = true:  G_t = x_t.W_ih^T + h_{t-1}.W_hh^T with W_ih (4H x 32) resident in registers next to W_hh, for narrow
-//               inputs (encoder: 3C = 18 channels): the (R,B,8H) gx tensor -- a 1.6 GB write and a 1.6 GB read at
-//               B = 32768 for 50 MB of actual input -- never exists.  The caller folds the bias in as a constant-one
-//               input column.
-template <bool PROJ>
+// Lane-native form of gx (written by dic_row_proj in its lane-native mode, read only here): element (t, 32-row tile bt, dir,
+// wave w, gate g, half qp of the lane's 16 units, hh, batch row r, e) with hidden unit u = 32 w + 16 qp + 4 hh + 8 (e / 4) + e % 4,
+// i.e. accumulator register 8 qp + e of lane (r, hh) -- every wave-wide 16-B access is one contiguous 1-KiB piece and both
+// kernels touch it straight from / into their MFMA accumulator registers.  B must be a multiple of 64.
+__host__ __device__ __forceinline__ size_t gxn_off(int t, int nbt, int bt, int dir, int w, int g, int qp, int hh, int r) {
+    size_t o = ((size_t)t * nbt + bt) * 2 + dir;
+    o = ((o * 4 + w) * 4 + g) * 2 + qp;
+    return ((o * 2 + hh) * 32 + r) * 8;
+}
+
+enum { FWD_GX = 0, FWD_PROJ = 1, FWD_GXN = 2 };
+// FWD_GX:   G_t starts from a precomputed row-major gx_t (library GEMM / row-major dic_row_proj: any batch size).
+// FWD_PROJ: G_t = x_t.W_ih^T + h_{t-1}.W_hh^T with W_ih (4H x 32) resident in registers next to W_hh, for narrow
+//           inputs (encoder: 3C = 18 channels): the (R,B,8H) gx tensor -- a 1.6 GB write and a 1.6 GB read at
+//           B = 32768 for 50 MB of actual input -- never exists.  The caller folds the bias in as a constant-one
+//           input column.
+// FWD_GXN:  gx_t in the lane-native form: 16 register loads of 16 B per lane and step, requested a step ahead, replace the
+//           LDS staging of the row-major tile (LDS-DMA, identity MFMAs, a second barrier per step).
+template <int MODE>
 __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwdArgs a) {
+    constexpr bool PROJ = MODE == FWD_PROJ, GXN = MODE == FWD_GXN;
     extern __shared__ __align__(16) __bf16 fsm[];
     __bf16 (*hbuf)[LBM * HSTR] = reinterpret_cast<__bf16 (*)[LBM * HSTR]>(fsm);      // [2][LBM*HSTR]
     __bf16* gst = fsm + 2 * LBM * HSTR;                    // PROJ ? [2][LBM][XSTR] x tiles : [LBM][GSTR] staged gx tile
@@ -184,8 +198,22 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
         return *reinterpret_cast<const bf16x8*>(a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * LXK + xpc * 8);
     };
     bf16x8 xnext = {};
+    // FWD_GXN: the lane's 2 x 4 x 16 pre-activations of a step, as they lie in the accumulators (64 VGPRs), a step ahead
+    bf16x8 gxn[LNB][4][2];
+    auto load_gxn = [&](auto nbc, int step) {
+        constexpr int nb = decltype(nbc)::value;
+        const int t = dir ? R - 1 - step : step;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp)
+                gxn[nb][g][qp] = *reinterpret_cast<const bf16x8*>(a.gx + gxn_off(t, nbt, blockIdx.x * LNB + nb, dir, w, g, qp, hh, r));
+    };
     if constexpr (PROJ) {
         *reinterpret_cast<bf16x8*>(gst + xrow * XSTR + xpc * 8) = load_x(0);
+    } else if constexpr (GXN) {
+        load_gxn(IC<0>{}, 0);
+        load_gxn(IC<1>{}, 0);
     } else {
         request_gx(0);
     }
@@ -216,6 +244,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
         DIC_STAMP(0, step, 0);
         if constexpr (PROJ) {
             if (step + 1 < R) xnext = load_x(step + 1);        // in flight across the MFMA and gate-math phases
+            if (step > 0) store_relu_rows(dir ? R - step : step - 1, cur);
+        } else if constexpr (GXN) {
             if (step > 0) store_relu_rows(dir ? R - step : step - 1, cur);
         } else {
             // accumulators start from the input projection of this step, brought into the accumulator layout BY the matrix core:
@@ -255,6 +285,16 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
 #pragma unroll
                     for (int g = 0; g < 4; ++g) acc[g][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[g][ks], xb, acc[g][nb], 0, 0, 0);
                 }
+            }
+        };
+        auto gxn_part = [&](auto nbc) {            // accumulators of a half <- its prefetched pre-activations; the registers refill for the next step
+            constexpr int nb = decltype(nbc)::value;
+            if constexpr (GXN) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[g][nb][k] = (float)gxn[nb][g][k >> 3][k & 7];
+                if (step + 1 < R) load_gxn(nbc, step + 1);
             }
         };
         auto h_part = [&](int nb, int ks) {        // G += W_hh . h_{t-1}^T, one k-step
@@ -308,9 +348,11 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
                 }
                     };
         x_part(0);
+        gxn_part(IC<0>{});
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) h_part(0, ks);
         x_part(1);
+        gxn_part(IC<1>{});
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             gate_math(0, q);
@@ -324,7 +366,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
             if (step + 1 < R) *reinterpret_cast<bf16x8*>(gst + (cur ^ 1) * LBM * XSTR + xrow * XSTR + xpc * 8) = xnext;
         }
         DIC_STAMP(0, step, 3);
-        if constexpr (!PROJ) {
+        if constexpr (MODE == FWD_GX) {
             // this wave's LDS-DMA pieces of the next gx tile have landed once only operations issued after them remain in flight:
             // the saved-state stores (5 per unit group x 8 groups; the `out` stores may have been branched over) -- a counted wait
             if (a.gates) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
@@ -561,29 +603,32 @@ using namespace dic;
 
 extern "C" {
 
-static int lstm_fwd_launch(bool proj, const LstmFwdArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)(2 * LBM * HSTR + (proj ? 2 * LBM * XSTR : LBM * GSTR)) * sizeof(__bf16);
-    static bool attr_set[2] = {false, false};
-    const void* fn = proj ? (const void*)lstm_fwd_kernel<true> : (const void*)lstm_fwd_kernel<false>;
-    if (!attr_set[proj]) {
+static int lstm_fwd_launch(int mode, const LstmFwdArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(2 * LBM * HSTR + (mode == FWD_PROJ ? 2 * LBM * XSTR : mode == FWD_GX ? LBM * GSTR : 0)) * sizeof(__bf16);
+    static bool attr_set[3] = {false, false, false};
+    const void* fn = mode == FWD_PROJ ? (const void*)lstm_fwd_kernel<FWD_PROJ>
+                   : mode == FWD_GXN ? (const void*)lstm_fwd_kernel<FWD_GXN> : (const void*)lstm_fwd_kernel<FWD_GX>;
+    if (!attr_set[mode]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-        attr_set[proj] = true;
+        attr_set[mode] = true;
     }
     const dim3 grid((a.B + LBM - 1) / LBM, 2);
-    if (proj) hipLaunchKernelGGL(lstm_fwd_kernel<true>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(lstm_fwd_kernel<false>, grid, dim3(256), lds, st, a);
+    if (mode == FWD_PROJ) hipLaunchKernelGGL(lstm_fwd_kernel<FWD_PROJ>, grid, dim3(256), lds, st, a);
+    else if (mode == FWD_GXN) hipLaunchKernelGGL(lstm_fwd_kernel<FWD_GXN>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(lstm_fwd_kernel<FWD_GX>, grid, dim3(256), lds, st, a);
     return check_launch("lstm_fwd");
 }
 
-int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
+int dic_lstm_fwd(const void* gx, int gx_lane_native, const void* whh, const float* h0, const float* c0, int R, int B, int H,
                  void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, int write_boundary, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd: gates and cs go together");
+    DIC_REQUIRE(!gx_lane_native || B % LBM == 0, DIC_ERR_INVALID_ARG, "lstm_fwd: lane-native gx needs a batch that is a multiple of %d (got %d)", LBM, B);
     LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0, write_boundary != 0};
-    return lstm_fwd_launch(false, a, (hipStream_t)stream);
+    return lstm_fwd_launch(gx_lane_native ? FWD_GXN : FWD_GX, a, (hipStream_t)stream);
 }
 
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
@@ -595,7 +640,7 @@ int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const flo
     DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd_proj: gates and cs go together");
     LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0, write_boundary != 0};
-    return lstm_fwd_launch(true, a, (hipStream_t)stream);
+    return lstm_fwd_launch(FWD_PROJ, a, (hipStream_t)stream);
 }
 
 #ifdef DIC_LSTM_EXP_TIMING

@@ -14,8 +14,13 @@ import torch
 import torch.distributed as td
 
 
+# DIC_DIST_SINGLE_RANK=1: a world of ONE rank counts as sharded, so that every collective of the sharded step / k-means / bench
+# runs on the real backend (RCCL on a 1-GPU box: tests/test_gpu_dist.py) -- a rehearsal switch, never set in production
+_SINGLE_RANK_REHEARSAL = os.environ.get('DIC_DIST_SINGLE_RANK') == '1'
+
+
 def is_sharded() -> bool:
-    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+    return td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or _SINGLE_RANK_REHEARSAL)
 
 
 def world_size() -> int:
@@ -70,7 +75,7 @@ def init_from_env(backend=None):
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     rk = int(os.environ.get('RANK', '0'))
     lr = int(os.environ.get('LOCAL_RANK', '0'))
-    if ws > 1 and not td.is_initialized():
+    if (ws > 1 or _SINGLE_RANK_REHEARSAL) and not td.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:     # DIC_DIST_BACKEND=gloo lets several ranks share ONE GPU (rehearsal of the N>1 path on a 1-GPU box)

@@ -20,17 +20,41 @@ def _args():
                            unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
 
 
-def _run_fake(rank, world, port, out):
+def _env(rank, world, port, rccl):
+    """gloo between ranks that share the test GPU -- or (rccl) ONE rank on RCCL with the sharded code paths switched on."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    if rccl:
+        os.environ.pop('DIC_DIST_BACKEND', None)
+        os.environ['DIC_DIST_SINGLE_RANK'] = '1'
+    else:
+        os.environ['DIC_DIST_BACKEND'] = 'gloo'
+
+
+def _join(rccl):
+    from deep_interpolation_clustering_amd import dist
+    import torch.distributed as td
+    if rccl:
+        assert td.get_backend() == 'nccl' and dist.is_sharded() and dist.world_size() == 1
+    return dist
+
+
+def _leave():
+    import torch.distributed as td
+    if td.is_initialized():
+        td.destroy_process_group()
+
+
+def _run_fake(rank, world, port, out, rccl=False):
     """Upstream's default unsupervised objective (fake detection + KL) on an ODD global batch: shards of 127 and 128 rows."""
     sys.path.insert(0, ROOT)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      DIC_DIST_BACKEND='gloo')
+    _env(rank, world, port, rccl)
     from deep_interpolation_clustering_amd import dist, synthetic
     from deep_interpolation_clustering_amd.clustering_interp import Net
     from deep_interpolation_clustering_amd.step import Stepper
     from deep_interpolation_clustering_amd.utils import pytorch_optimizer
-    if world > 1:
+    if world > 1 or rccl:
         dist.init_from_env()
+        _join(rccl)
     dev = torch.device('cuda', 0)
     Bg = 255
     coh = synthetic.make_cohort(Bg, seed=22)
@@ -59,10 +83,8 @@ def _run_fake(rank, world, port, out):
             with torch.no_grad():
                 losses, _, _, _ = st.forward_loss(x, ob, None, lens, fake_x=fx, fake_perm_idx=perm, fake_det_label=label)
         res[mode] = {k: float(v.detach()) for k, v in losses.items()}
-    torch.save(res, os.path.join(out, f'f{world}_r{rank}.pt'))
-    if world > 1:
-        import torch.distributed as td
-        td.destroy_process_group()
+    torch.save(res, os.path.join(out, f'f{world}{"x" if rccl else ""}_r{rank}.pt'))
+    _leave()
 
 
 def test_two_rank_fake_detection_odd_batch_losses_are_global(tmp_path):
@@ -81,16 +103,16 @@ def test_two_rank_fake_detection_odd_batch_losses_are_global(tmp_path):
     np.testing.assert_allclose(r0['gnorm'], one['gnorm'], rtol=1e-4)
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, rccl=False):
     sys.path.insert(0, ROOT)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      DIC_DIST_BACKEND='gloo')
+    _env(rank, world, port, rccl)
     from deep_interpolation_clustering_amd import dist, synthetic
     from deep_interpolation_clustering_amd.clustering_interp import Net
     from deep_interpolation_clustering_amd.step import Stepper
     from deep_interpolation_clustering_amd.utils import pytorch_optimizer
-    if world > 1:
+    if world > 1 or rccl:
         dist.init_from_env()
+        _join(rccl)
     dev = torch.device('cuda', 0)
     coh = synthetic.make_cohort(256, seed=21)
     x_np, ob_np, n = synthetic.stacked_batch(coh)
@@ -105,10 +127,8 @@ def _run(rank, world, port, out):
         losses, gnorm, _ = st.step(x, ob, None, lens)
         res.append([float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(losses['kl'].detach()), float(gnorm)])
     torch.save({'traj': np.array(res), 'flat': st.flat.flat.detach().cpu(), 'bn_mean': net.rbf.compress_fc.module.model[1].running_mean.cpu()},
-               os.path.join(out, f'w{world}_r{rank}.pt'))
-    if world > 1:
-        import torch.distributed as td
-        td.destroy_process_group()
+               os.path.join(out, f'w{world}{"x" if rccl else ""}_r{rank}.pt'))
+    _leave()
 
 
 def test_two_rank_step_equals_single_device(tmp_path):
@@ -207,15 +227,15 @@ def _run_p1_eval(rank, base):
     p1.main(p1.get_arguments(COMMON + ['--mode', 'eval', '--loss', 'ae_mse']))
 
 
-def _run_kmeans(rank, world, port, out):
+def _run_kmeans(rank, world, port, out, rccl=False):
     sys.path.insert(0, ROOT)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      DIC_DIST_BACKEND='gloo')
+    _env(rank, world, port, rccl)
     from deep_interpolation_clustering_amd import dist
     from deep_interpolation_clustering_amd.kmeans import KMeans
     from oracle.synth import latent_blobs
-    if world > 1:
+    if world > 1 or rccl:
         dist.init_from_env()
+        _join(rccl)
     X, _ = latent_blobs(3, 20011, 256, 5)                       # odd size: uneven shards
     res = {}
     km = KMeans(n_clusters=5, n_init=4, random_state=7, shard_points=True).fit(X)
@@ -224,10 +244,8 @@ def _run_kmeans(rank, world, port, out):
     init = np.concatenate([X[:3], X[:1] + 100.0], axis=0).astype(np.float32)
     km = KMeans(n_clusters=4, init=init, n_init=1, shard_points=True).fit(X)
     res['empty'] = (km.labels_, km.cluster_centers_, km.inertia_, km.n_iter_)
-    torch.save(res, os.path.join(out, f'km_w{world}_r{rank}.pt'))
-    if world > 1:
-        import torch.distributed as td
-        td.destroy_process_group()
+    torch.save(res, os.path.join(out, f'km_w{world}{"x" if rccl else ""}_r{rank}.pt'))
+    _leave()
 
 
 def test_sharded_kmeans_equals_single_device(tmp_path):
@@ -270,3 +288,50 @@ def test_bench_runs_sharded_on_two_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['scaling'] == 'weak' and rec['config']['global_batch'] == 1024
     assert abs(rec['value'] - 2 * 512 * 3 / (rec['ms_per_step'] * 3e-3)) <= 0.01 * rec['value']      # whole-job rate over all ranks
+
+
+def test_sharded_paths_on_rccl_with_one_rank(tmp_path):
+    """The box has one GPU, and RCCL wants one GPU per rank: so ONE rank joins a `nccl` process group (dist.init_from_env as on a real
+    node: device_id, current device) with DIC_DIST_SINGLE_RANK=1, which makes that world count as sharded.  Every collective of the
+    sharded joint step (loss sums, global BatchNorm moments and their backward, DEC column sums, the split gradient bucket), of the
+    default fake-detection objective and of the sharded k-means then runs on RCCL, on device tensors, on the HIP streams the
+    kernels use -- and has to reproduce the unsharded run (a one-rank sum is the identity)."""
+    port = 29900 + (os.getpid() % 1000)
+    for worker in (_run, _run_fake, _run_kmeans):
+        mp.spawn(worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+        mp.spawn(worker, args=(1, port + 1, str(tmp_path), True), nprocs=1, join=True)
+        port += 2
+    a, b = torch.load(tmp_path / 'w1_r0.pt', weights_only=False), torch.load(tmp_path / 'w1x_r0.pt', weights_only=False)
+    np.testing.assert_allclose(b['traj'][0, :2], a['traj'][0, :2], rtol=2e-6)
+    np.testing.assert_allclose(b['traj'][:, :2], a['traj'][:, :2], rtol=2e-4)
+    np.testing.assert_allclose(b['traj'][:, 3], a['traj'][:, 3], rtol=2e-3)
+    np.testing.assert_allclose(b['bn_mean'].numpy(), a['bn_mean'].numpy(), rtol=1e-3, atol=1e-4)
+    a, b = torch.load(tmp_path / 'f1_r0.pt', weights_only=False), torch.load(tmp_path / 'f1x_r0.pt', weights_only=False)
+    for mode in ('train', 'eval'):
+        for k, v in a[mode].items():
+            np.testing.assert_allclose(b[mode][k], v, rtol=5e-5, atol=1e-7, err_msg=f'{mode} {k}')
+    np.testing.assert_allclose(b['gnorm'], a['gnorm'], rtol=1e-3)
+    a, b = torch.load(tmp_path / 'km_w1_r0.pt', weights_only=False), torch.load(tmp_path / 'km_w1x_r0.pt', weights_only=False)
+    for case in ('pp', 'empty'):
+        assert np.array_equal(a[case][0], b[case][0]) and a[case][3] == b[case][3], case
+        np.testing.assert_allclose(a[case][1], b[case][1], rtol=1e-5, atol=1e-6, err_msg=case)
+
+
+def test_bench_runs_on_rccl_with_one_rank():
+    """bench.py under torch.distributed.run as the driver launches it, one rank, the process group on RCCL and the sharded code paths
+    on (DIC_DIST_SINGLE_RANK=1): barriers, the max-over-ranks timing all-reduce and the lockstep trace steps all execute on `nccl`."""
+    import json
+    import subprocess
+    env = dict(os.environ, DIC_DIST_SINGLE_RANK='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'DIC_DIST_BACKEND'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29577', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--batch', '512',
+           '--encounters', '4096', '--no-secondary', '--no-cpu-baseline', '--kernel-iters', '1']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert 'process group: nccl' in res.stderr, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 1 and rec['value'] > 0 and np.isfinite(rec['final_loss'])
