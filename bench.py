@@ -163,7 +163,7 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
     ldout = (torch.randn((R, B, 2 * Hh), **f32) * 0.1).to(bf)
     ldgx, ldh0, ldc0 = torch.empty((R, B, 2, 4, Hh), device=dev, dtype=bf), torch.empty((2, B, Hh), **f32), torch.empty((2, B, Hh), **f32)
     rows = 2.0 * R * B                     # (step, batch row, direction) units
-    calls['lstm_fwd'] = (lambda: L.dic_lstm_fwd(P(gxl), P(whh), None, None, R, B, Hh, P(lout), None, P(lhn), P(lcn), P(lgates), P(lcs), 0, 0, st),
+    calls['lstm_fwd'] = (lambda: L.dic_lstm_fwd(P(gxl), int(B % 64 == 0), P(whh), None, None, R, B, Hh, P(lout), None, P(lhn), P(lcn), P(lgates), P(lcs), 0, 0, st),
                          rows * (4 * Hh * 2 + Hh * 2 + 4 * Hh * 2 + Hh * 2))      # gx in; h, gates, c (bf16 copy) out
     xenc = (torch.randn((R, B, 32), **f32)).to(bf)
     lout_r = torch.empty_like(lout)            # the encoder also writes the rectified copy the decoder reads

@@ -33,10 +33,18 @@ struct RowProjArgs {
     long N;
     int Nout;
     float* stat_part;      // STATS: (gridDim.x, 2, 32 NW) per-workgroup column sums of out and out^2
+    int nbt;               // NATIVE: 32-row tiles per time step (batch / 32)
 };
 
-template <int NW, bool STATS>
+// NATIVE (the decoder's gx, Nout = 1024 = 2 directions x 4 gates x 128 units, read back only by the recurrence kernel): the product is
+// issued TRANSPOSED -- D[output column][row] = W . x^T, the same fragments with the operands swapped -- so lane (row r, hh) ends up
+// with the 16 pre-activations the recurrence kernel's lane (r, hh) of wave (column / 32) % 4 wants in its accumulators, and writes
+// them as two 16-B pieces of the lane-native gx form (gxn_off in dic_lstm.hip: ((((((t nbt + bt) 2 + dir) 4 + w) 4 + g) 2 + qp) 2 + hh)
+// 32 + r) 8): 1 KiB per wave instruction, no staging tile, one barrier per tile.
+
+template <int NW, bool STATS, bool NATIVE>
 __global__ __launch_bounds__(NW * 64, 2) void row_proj_kernel(RowProjArgs a) {
+    static_assert(!NATIVE || (NW == 8 && !STATS), "lane-native output: 256-column stripes of the 1024 gate columns");
     constexpr int NT = NW * 64, PS_PITCH = p_stage_pitch(NW), P_STAGE = PT * PS_PITCH, NCOLS = 32 * NW, PPT = PT * 32 / NT;   // PPT: x pieces per thread and tile
     extern __shared__ __align__(16) unsigned char psm[];
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
@@ -50,6 +58,11 @@ __global__ __launch_bounds__(NW * 64, 2) void row_proj_kernel(RowProjArgs a) {
 #pragma unroll
     for (int ks = 0; ks < PK / 16; ++ks) wreg[ks] = *reinterpret_cast<const pbf16x8*>(a.w + (size_t)ncol * PK + 16 * ks + 8 * hh);
     const float bn = a.bias ? (float)a.bias[ncol] : 0.f;
+    float bk[16];                          // NATIVE: the bias of the 16 output columns this lane accumulates
+    if constexpr (NATIVE) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bk[k] = a.bias ? (float)a.bias[n0 + 32 * w + (k & 3) + 8 * (k >> 2) + 4 * hh] : 0.f;
+    }
 
     const int xrow = tid >> 5, xpc = tid & 31;               // rows xrow + (NT / 32) j; 32 pieces of 16 B per row
     static_assert(PPT == 2 || PPT == 4, "x pieces per thread and tile");
@@ -85,14 +98,29 @@ __global__ __launch_bounds__(NW * 64, 2) void row_proj_kernel(RowProjArgs a) {
         const unsigned char* base = psm + slot * P_TILE;
         pf32x16 acc;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = bn;
+        for (int k = 0; k < 16; ++k) acc[k] = NATIVE ? bk[k] : bn;
 #pragma unroll
         for (int ks = 0; ks < PK / 16; ++ks) {
             const pbf16x8 af = *reinterpret_cast<const pbf16x8*>(base + a_off + ks * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wreg[ks], acc, 0, 0, 0);
+            if constexpr (NATIVE) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ks], af, acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wreg[ks], acc, 0, 0, 0);
         }
         if (tile + nch < ntiles) DIC_RP_LAND(slot ^ 1);
         if (tile + 2 * nch < ntiles) DIC_RP_REQUEST(tile + 2 * nch);
+        if constexpr (NATIVE) {
+            // tile = 32 rows of one time step (the batch is a multiple of 32): t = tile / nbt, bt = tile % nbt; stripe y = direction y / 2,
+            // gates 2 (y % 2) + w / 4; recurrence wave w % 4.  C/D layout: output column (reg & 3) + 8 (reg >> 2) + 4 hh, row = lane & 31
+            const size_t blk = ((size_t)tile * 2 + (blockIdx.y >> 1)) * 4 + (w & 3);
+            const size_t o = ((blk * 4 + 2 * (blockIdx.y & 1) + (w >> 2)) * 2 * 2 + hh) * 32 + (lane & 31);
+            pbf16x8 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { lo[e] = (__bf16)acc[e]; hi[e] = (__bf16)acc[8 + e]; }
+            *reinterpret_cast<pbf16x8*>(a.out + o * 8) = lo;
+            *reinterpret_cast<pbf16x8*>(a.out + (o + 2 * 32) * 8) = hi;
+            __syncthreads();
+            slot ^= 1;
+            continue;
+        }
         // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         unsigned char* sb = stage + slot * P_STAGE;
         const long r0 = (long)tile * PT;
@@ -144,15 +172,16 @@ static int row_proj_chunks(long N, int stripes, int wg_per_cu) {
     return nch >= 8 ? nch / 8 * 8 : nch;                          // a multiple of 8: the stripes of a row chunk share an XCD (and its L2)
 }
 
-template <int NW, bool STATS>
+template <int NW, bool STATS, bool NATIVE>
 static int row_proj_launch(const RowProjArgs& a, int nch, int stripes, hipStream_t st) {
+    constexpr int lds = NATIVE ? 2 * P_TILE : p_lds(NW);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)row_proj_kernel<NW, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, p_lds(NW));
-        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "row_proj: cannot reserve %d B of LDS: %s", p_lds(NW), hipGetErrorString(e));
+        hipError_t e = hipFuncSetAttribute((const void*)row_proj_kernel<NW, STATS, NATIVE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "row_proj: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((row_proj_kernel<NW, STATS>), dim3(nch, stripes), dim3(NW * 64), p_lds(NW), st, a);
+    hipLaunchKernelGGL((row_proj_kernel<NW, STATS, NATIVE>), dim3(nch, stripes), dim3(NW * 64), lds, st, a);
     return DIC_OK;
 }
 
@@ -162,14 +191,19 @@ using namespace dic;
 
 extern "C" {
 
-int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, dic_stream_t stream) {
+int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, int lane_native_batch,
+                 dic_stream_t stream) {
     DIC_REQUIRE(N > 0, DIC_ERR_INVALID_ARG, "row_proj: non-positive row count");
     DIC_REQUIRE(in_features == PK && out_features > 0 && out_features % 256 == 0, DIC_ERR_UNSUPPORTED,
                 "row_proj: (%d -> %d) (compiled for 256 inputs and a multiple of 256 outputs)", in_features, out_features);
     DIC_REQUIRE(x && w && out, DIC_ERR_INVALID_ARG, "row_proj: NULL pointer");
     const int stripes = out_features / 256;
-    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, nullptr};
-    int rc = row_proj_launch<8, false>(a, row_proj_chunks(N, stripes, 2), stripes, (hipStream_t)stream);
+    DIC_REQUIRE(lane_native_batch == 0 || (out_features == 1024 && lane_native_batch > 0 && lane_native_batch % 64 == 0 && N % lane_native_batch == 0),
+                DIC_ERR_INVALID_ARG, "row_proj: lane-native output needs 1024 output columns and rows = steps x a batch that is a multiple of 64 (batch %d, %lld rows)",
+                lane_native_batch, (long long)N);
+    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, nullptr, lane_native_batch / 32};
+    int rc = lane_native_batch ? row_proj_launch<8, false, true>(a, row_proj_chunks(N, stripes, 2), stripes, (hipStream_t)stream)
+                               : row_proj_launch<8, false, false>(a, row_proj_chunks(N, stripes, 2), stripes, (hipStream_t)stream);
     return rc ? rc : check_launch("row_proj");
 }
 
@@ -186,8 +220,8 @@ int dic_row_proj_stats(const void* x, const void* w, const void* bias, int64_t N
     DIC_REQUIRE(x && w && out && sums && workspace, DIC_ERR_INVALID_ARG, "row_proj_stats: NULL pointer");
     const int nch = row_proj_chunks(N, 1, 3);
     DIC_REQUIRE(workspace_bytes >= (size_t)nch * 2 * 128 * sizeof(float), DIC_ERR_WORKSPACE, "row_proj_stats: workspace too small");
-    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, (float*)workspace};
-    int rc = row_proj_launch<4, true>(a, nch, 1, (hipStream_t)stream);
+    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, (float*)workspace, 0};
+    int rc = row_proj_launch<4, true, false>(a, nch, 1, (hipStream_t)stream);
     if (rc) return rc;
     hipLaunchKernelGGL(row_proj_stats_finalize, dim3(2 * 128 / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nch, 2 * 128, (double)N, sums);
     return check_launch("row_proj_stats");

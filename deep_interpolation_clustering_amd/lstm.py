@@ -36,6 +36,7 @@ PARAM_NAMES = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
                'weight_ih_l0_reverse', 'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
 
+GX_LANE_NATIVE = os.environ.get('DIC_GX_LANE_NATIVE', '1') != '0'     # (A/B switch: 0 = row-major gx between dic_row_proj and dic_lstm_fwd)
 ROW_PROJ = os.environ.get('DIC_ROW_PROJ', '1') != '0'                  # (A/B switch: 0 = library GEMM for the decoder's input projection)
 RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B switch: 0 = rectify the encoder output with a torch pass)
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
@@ -135,13 +136,16 @@ class _BiLstm(torch.autograd.Function):
                 N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out), N.ptr(out_r),
                                             N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), st), 'dic_lstm_fwd_proj')
             else:
+                native = 0
                 if Ip == WIDE_INPUT and ROW_PROJ:
-                    # decoder: the input projection with the weights resident in registers (csrc/dic_rowproj.hip)
+                    # decoder: the input projection with the weights resident in registers (csrc/dic_rowproj.hip); batches that tile by 64
+                    # rows get gx in the order of the recurrence kernel's accumulators (no LDS staging of the gx tile over there)
+                    native = B if (GX_LANE_NATIVE and B % 64 == 0) else 0
                     gx = torch.empty((R * B, 8 * H), device=dev, dtype=T)
-                    N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), st), 'dic_row_proj')
+                    N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), native, st), 'dic_row_proj')
                 else:
                     gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
-                N.check(L.dic_lstm_fwd(N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
+                N.check(L.dic_lstm_fwd(N.ptr(gx), int(native > 0), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
                                        N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), st), 'dic_lstm_fwd')
         ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32), bool(relu))
         ctx.x_dtype = x.dtype

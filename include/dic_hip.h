@@ -244,9 +244,12 @@ int dic_kmeans_pp_candidates_rows(const float* X, int N, int D, int row_lo, int 
  * dbias (2,4H) f32 or NULL = sum of dG over steps and batch rows (needs dic_lstm_bwd_workspace(B) bytes).
  * state_batch_major != 0: h0, c0, hn, cn and their gradients are laid out (B,2,H) instead of nn.LSTM's (2,B,H), so that
  * hn viewed as (B,2H) is the concatenated latent [h_fwd | h_rev] (clustering_interp.py:139) and feeds the decoder with no copy. */
-int dic_lstm_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H,
+int dic_lstm_fwd(const void* gx, int gx_lane_native, const void* whh, const float* h0, const float* c0, int R, int B, int H,
                  void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, int write_boundary,
                  dic_stream_t stream);
+/* gx_lane_native != 0 (B a multiple of 64): gx is not row-major but in the opaque form dic_row_proj(..., lane_native_batch = B) writes --
+ * the order of the recurrence kernel's MFMA accumulators, 1-KiB pieces per wave access -- and is read straight into registers a step
+ * ahead (no LDS staging of the gx tile, one barrier per step). */
 /* write_boundary != 0: `out` points at time slot 1 of an (R+2,B,2H) buffer (dic_lstm_dw's out_ext); the kernel also writes h0 (bf16;
  * zeros without one) into slot 0 [:, :H] and slot R+1 [:, H:], the recurrent inputs of the first forward / reverse step. */
 /* out_relu (R,B,2H) bf16 or NULL: a second copy of the output with relu applied -- what DecoderRNN.forward reads of the encoder's
@@ -320,7 +323,10 @@ int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const
  * out (N,Nout) bf16 = x (N,256) . w (Nout,256)^T + bias (Nout) (bias bf16 or NULL), Nout a multiple of 256: the decoder LSTM's input
  * projection gx over all N = R*B rows (nn.LSTM inside DecoderRNN, clustering_interp.py:47-59) with the weights resident in
  * registers -- the library GEMM for this K = 256 shape cannot overlap its short main loop with its epilogue. */
-int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, dic_stream_t stream);
+int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, int lane_native_batch,
+                 dic_stream_t stream);
+/* lane_native_batch = B > 0 (Nout = 1024 = 2 directions x 4 gates x 128 units, N = R*B, B a multiple of 64): out is written in the
+ * lane-native form dic_lstm_fwd(gx_lane_native = 1) reads (same bytes, same values, another order); 0: row-major (N,Nout). */
 /* The same for CompressFC's first layer Linear(256, 128) (rbf.py:111-125) in front of its training-mode BatchNorm1d: out (N,128) bf16 and
  * sums (2*128 + 1) f64 = [column sums of out | of out^2 | N] -- what dic_bn_colstats would compute in a second pass over out. */
 size_t dic_row_proj_stats_workspace(int64_t N, int out_features);

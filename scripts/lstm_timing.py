@@ -15,7 +15,7 @@ cs = torch.empty(R, B, 2, H, device=dev, dtype=bf); hn = torch.empty(2, B, H, de
 P, st = N.ptr, N.stream_of(gx)
 for _ in range(3):
     if proj: L.dic_lstm_fwd_proj(P(x), P(wih), P(whh), None, None, R, B, H, 32, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st)
-    else: L.dic_lstm_fwd(P(gx), P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st)
+    else: L.dic_lstm_fwd(P(gx), 0, P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st)
 torch.cuda.synchronize()
 buf = np.zeros((2, 32, 8), dtype=np.uint64)
 fn = L.dic_lstm_debug_stamps; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p]

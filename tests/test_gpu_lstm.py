@@ -681,7 +681,7 @@ def test_row_proj_matches_addmm(n, nout, bias):
     w = (torch.randn(nout, 256, device=dev) * 0.1).to(bf)
     b = (torch.randn(nout, device=dev) * 0.3).to(bf) if bias else None
     out = torch.full((n, nout), float('nan'), device=dev, dtype=bf)
-    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, nout, N.ptr(out), N.stream_of(x)), 'dic_row_proj')
+    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, nout, N.ptr(out), 0, N.stream_of(x)), 'dic_row_proj')
     want = x.double() @ w.double().t() + (b.double() if bias else 0.0)
     assert float((out.double() - want).abs().max()) <= 8e-3 * float(want.abs().max()) + 1e-3        # bf16 output
     ref = torch.addmm(b, x, w.t()) if bias else x @ w.t()
@@ -708,3 +708,52 @@ def test_row_proj_stats_matches_addmm_and_colstats(n):
     assert float(sums[256]) == n
     np.testing.assert_allclose(sums[:128].cpu().numpy(), zd.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5 * n)
     np.testing.assert_allclose(sums[128:256].cpu().numpy(), (zd * zd).sum(0).cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize('R,B', [(5, 128), (24, 64), (3, 192)])
+def test_row_proj_lane_native_output_is_a_reordering_of_the_row_major_one(R, B):
+    """dic_row_proj(lane_native_batch = B): the decoder's gx in the order of the recurrence kernel's MFMA accumulators -- element
+    (t, 32-row tile, direction, wave, gate, unit half, hh, row, e) -- holds exactly the values of the row-major (R*B, 2*4*128) product."""
+    from deep_interpolation_clustering_amd import _native as N
+    torch.manual_seed(R * B)
+    dev, bf = torch.device('cuda'), torch.bfloat16
+    n = R * B
+    x = (torch.randn(n, 256, device=dev) * 0.5).clamp_min(0).to(bf)
+    w = (torch.randn(1024, 256, device=dev) * 0.1).to(bf)
+    b = (torch.randn(1024, device=dev) * 0.3).to(bf)
+    rows = torch.full((n, 1024), float('nan'), device=dev, dtype=bf)
+    nat = torch.full((n, 1024), float('nan'), device=dev, dtype=bf)
+    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(rows), 0, N.stream_of(x)), 'dic_row_proj')
+    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(nat), B, N.stream_of(x)), 'dic_row_proj')
+    # (t, tile, dir, wave, gate, qp, hh, row, e / 4, e % 4) -> (t, tile, row, dir, gate, wave, qp, e / 4, hh, e % 4): unit = 32 wave + 16 qp + 8 (e / 4) + 4 hh + e % 4
+    back = nat.view(R, B // 32, 2, 4, 4, 2, 2, 32, 2, 4).permute(0, 1, 7, 2, 4, 3, 5, 8, 6, 9).reshape(n, 1024)
+    assert not torch.isnan(back.float()).any()
+    assert torch.equal(back, rows)
+    with pytest.raises(RuntimeError):          # batches that do not tile by 64 rows are refused, not mangled
+        N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(nat), 96, N.stream_of(x)), 'dic_row_proj')
+
+
+@pytest.mark.parametrize('R,B,init', [(24, 64, True), (7, 192, False)])
+def test_lane_native_gx_path_equals_row_major_path(R, B, init, monkeypatch):
+    """Decoder-shaped LSTM (input width 256) on the 64-row kernels: gx handed from dic_row_proj to dic_lstm_fwd in the lane-native form
+    (registers, a step ahead) or row-major (LDS-staged tile) -- the same numbers go into the same accumulators: bit-equal results."""
+    from deep_interpolation_clustering_amd import lstm as L
+    monkeypatch.setattr(L, 'SMALL_BATCH', 0)
+    torch.manual_seed(R + B)
+    dev = torch.device('cuda')
+    net = torch.nn.LSTM(256, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, 256, device=dev) * 0.5
+    h0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    c0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    go, gh = torch.randn(R, B, 2 * H, device=dev), torch.randn(2, B, H, device=dev)
+    res = {}
+    for native in (False, True):
+        monkeypatch.setattr(L, 'GX_LANE_NATIVE', native)
+        net.zero_grad()
+        xi = x.clone().requires_grad_()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out, (hn, cn) = L.bilstm(xi, net, h0, c0)
+        ((out.float() * go).sum() + (hn * gh).sum() + cn.sum()).backward()
+        res[native] = dict(out=out.detach().float(), hn=hn.detach(), cn=cn.detach(), dx=xi.grad.clone(), **{k: p.grad.clone() for k, p in net.named_parameters()})
+    for k in res[False]:
+        assert torch.equal(res[False][k], res[True][k]), k
