@@ -194,6 +194,23 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
                             rows * 4 * Hh * 2 + R * B * (2 * Hh * 2 + 32 * 2 + 2 * 32 * 2))   # dG once; h, x in; per-direction dX out
         calls['lstm_dw_wide'] = (lambda: L.dic_lstm_dw_wide(P(ldgx), P(oext), P(xdec), R, B, Hh, 256, gpd, 0, P(ws8), ws8.numel(), st) + 0 * len(keep),
                                  rows * 4 * Hh * 2 + R * B * (2 * Hh * 2 + 256 * 2))           # dG once; h, x once
+        # resident-weight projections (csrc/dic_rowproj.hip) and the one-pass CompressFC Linear(256,128) backward (csrc/dic_fcgrad.hip)
+        wdec = (torch.randn((8 * Hh, 256), **f32) * 0.06).to(bf)
+        bdec = (torch.randn((8 * Hh,), **f32) * 0.1).to(bf)
+        w1 = (torch.randn((128, 256), **f32) * 0.06).to(bf)
+        b1 = (torch.randn((128,), **f32) * 0.1).to(bf)
+        zfc, dzfc = torch.empty((R * B, 128), device=dev, dtype=bf), (torch.randn((R * B, 128), **f32) * 0.1).to(bf)
+        sums = torch.empty(257, device=dev, dtype=torch.float64)
+        dxfc, dw1 = torch.empty((R * B, 256), device=dev, dtype=bf), torch.zeros((128, 256), **f32)
+        ws9 = torch.empty(max(16, L.dic_row_proj_stats_workspace(R * B, 128)), dtype=torch.uint8, device=dev)
+        ws10 = torch.empty(max(16, L.dic_fc_bwd_workspace(R * B, 256, 128)), dtype=torch.uint8, device=dev)
+        keep2 = (wdec, bdec, w1, b1, zfc, dzfc, sums, dxfc, dw1, ws9, ws10)
+        calls['row_proj'] = (lambda: L.dic_row_proj(P(xdec), P(wdec), P(bdec), R * B, 256, 8 * Hh, P(ldgx), B if B % 64 == 0 else 0, st) + 0 * len(keep2),
+                             R * B * (256 * 2 + 8 * Hh * 2))                                   # x once; gx out
+        calls['row_proj_stats'] = (lambda: L.dic_row_proj_stats(P(xdec), P(w1), P(b1), R * B, 256, 128, P(zfc), P(sums), P(ws9), ws9.numel(), st),
+                                   R * B * (256 * 2 + 128 * 2))                                # x once; z out (+ the column sums)
+        calls['fc_bwd'] = (lambda: L.dic_fc_bwd(P(dzfc), P(xdec), P(w1), R * B, 256, 128, P(dxfc), P(dw1), P(ws10), ws10.numel(), st),
+                           R * B * (128 * 2 + 256 * 2 + 256 * 2))                               # dz, x in; dx out
 
 
 # ------------------------------------------------------------------------------------------ step trace
@@ -584,6 +601,7 @@ def main():
                       'rbf_bwd': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'), 'masked_sse_fwd': 'dic::masked_sse_kernel', 'masked_sse_bwd': 'dic::masked_sse_bwd_kernel',
                       'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': 'dic::lstm_fwd_kernel',
                       'lstm_fwd_proj': 'dic::lstm_fwd_kernel', 'lstm_bwd': 'dic::lstm_bwd_kernel', 'lstm_dw': 'dic::lstm_dw_kernel',
+                      'row_proj': 'dic::row_proj_kernel', 'row_proj_stats': 'dic::row_proj_kernel', 'fc_bwd': 'dic::fc_bwd_kernel',
                       'lstm_dw_wide': 'dic::lstm_dw_wide_kernel'}
         kernels = groups = None
         ran = [0]
@@ -603,8 +621,8 @@ def main():
             if kernels is not None:
                 hits = [v for k, v in kernels.items() if k.startswith(trace_name[name])]        # (str.startswith takes a tuple of prefixes too)
                 launches = sum(v['launches_per_step'] for v in hits)
-                if name in ('lstm_fwd', 'lstm_fwd_proj'):
-                    launches = launches / 2            # one template, two instantiations (decoder / encoder), one launch each
+                if name in ('lstm_fwd', 'lstm_fwd_proj', 'row_proj', 'row_proj_stats'):
+                    launches = launches / 2            # one template, two instantiations (decoder / encoder, gx / CompressFC), one launch each
             per_step[name] = launches * row['ms']
         dom = max(per_step, key=per_step.get)
         traffic, traffic_src = None, None
