@@ -81,6 +81,7 @@ SIGNATURES = {
     'dic_row_proj_stats': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _p, _p, _sz, _p]),
     'dic_fc_bwd_workspace': (_sz, [C.c_int64, _i, _i]),
     'dic_fc_bwd': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _p, _p, _sz, _p]),
+    'dic_fc_bwd_bnhead': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, C.c_float, _p, _p, _p, C.c_int64, _i, _i, _p, _p, _p, _sz, _p]),
     'dic_head_fwd': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _p]),
     'dic_head_bwd_workspace': (_sz, [C.c_int64, _i, _i]),
     'dic_head_bwd': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _p, _p, _p, _sz, _p]),

@@ -14,7 +14,7 @@
 // images so that a single barrier per tile suffices; the dX block leaves through an LDS staging tile as whole 512-B rows.
 // Row pitches of 256 + 48 / 512 + 48 B keep the straight 16-B reads (32 rows, same piece) and the transposed reads (4 rows x 32 B)
 // both free of bank conflicts.  Deterministic: per-workgroup dW partials, fixed-order f64 second stage.
-#include "dic_common.h"
+#include "dic_bnhead.h"
 
 namespace dic {
 
@@ -26,6 +26,8 @@ constexpr int FS_PITCH = FI * 2 + 16;                // 528 B: dX staging rows
 constexpr int F_TILE = FT * (FZ_PITCH + FX_PITCH);   // 27 648 B per tile image
 constexpr int F_STAGE = FT * FS_PITCH;               // 16 896 B
 constexpr int F_LDS = 2 * F_TILE + 2 * F_STAGE;      // 89 088 B
+constexpr int F_W2_MAX = 12;                         // FUSED: 128-float rows kept behind the staging tiles: the head weight W2 (C rows) + 6 rows of column constants
+constexpr int F_LDS_FUSED = F_LDS + F_W2_MAX * FO * 4;
 
 typedef __bf16 fbf16x8 __attribute__((ext_vector_type(8)));
 typedef short fs16x4 __attribute__((ext_vector_type(4)));
@@ -39,12 +41,22 @@ struct FcBwdArgs {
     __bf16* dx;            // (N, 256) or NULL
     float* partials;       // (gridDim.x, 128, 256)
     long N;
+    // FUSED: dZ is not read but formed on the way into LDS from the BatchNorm -> ReLU -> Dropout -> Linear(128, C) tail behind this layer
+    // (what dic_bnhead_bwd_input would have written, same arithmetic in the same order): z = this layer's own output, dv = the gradient
+    // of the tail's output, the tail's parameters, and the column sums of its first backward pass (dic_bnhead_bwd_reduce)
+    const __bf16* z;       // (N, 128)
+    const float* dv;       // (N, C)
+    const float *mean, *rstd, *gamma, *beta, *w2;      // (128) x 4, (C, 128)
+    const float *sum_da, *sum_dax, *count;             // (128), (128), (1): global row count of the batch moments
+    float floor_, drop_p;
+    const unsigned long long* rng;
 };
 
 __device__ __forceinline__ fs16x4 f_lds_tr16(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fs16x4*)(p));
 }
 
+template <bool FUSED, int C>
 __global__ __launch_bounds__(512) void fc_bwd_kernel(FcBwdArgs a) {
     extern __shared__ __align__(16) unsigned char fsm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -72,10 +84,42 @@ __global__ __launch_bounds__(512) void fc_bwd_kernel(FcBwdArgs a) {
     const int zrow = tid >> 4, zpc = tid & 15;               // dZ: 32 rows x 16 pieces
     const int xrow = tid >> 5, xpc = tid & 31;               // X: rows xrow, xrow + 16, 32 pieces each
     uint4 pz, px0, px1;
+    // FUSED: this thread's 8 columns (zpc) of the tail: BatchNorm constants, the two mean terms of its backward; W2 in LDS
+    // h = max(scale z + shift, floor),  dz = scale (da - c1 - xhat c2),  xhat = (z - mean) rstd,  c1 = sum_da / n,  c2 = sum_dax / n:
+    // the arithmetic of dic_bnhead_bwd_input, operation for operation (bit-identical dZ).  The six constants per column live in LDS
+    // behind W2 (the kernel is at its register limit).
+    static_assert(C + 6 <= F_W2_MAX, "LDS rows behind the staging tiles: W2, scale, shift, mean, rstd, c1, c2");
+    Drop drop;
+    float pg[C];
+    long prow = 0;
+    float* w2s = reinterpret_cast<float*>(fsm + F_LDS);
+    if constexpr (FUSED) {
+        const ColParams cp = load_cols(a.mean, a.rstd, a.gamma, a.beta, zpc);
+        drop = load_drop(a.drop_p, a.rng);
+        const float inv_n = 1.0f / a.count[0];
+        if (zrow == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = zpc * 8 + e;
+                w2s[(C + 0) * FO + k] = cp.scale[e];
+                w2s[(C + 1) * FO + k] = cp.shift[e];
+                w2s[(C + 2) * FO + k] = cp.mean[e];
+                w2s[(C + 3) * FO + k] = cp.rstd[e];
+                w2s[(C + 4) * FO + k] = a.sum_da[k] * inv_n;
+                w2s[(C + 5) * FO + k] = a.sum_dax[k] * inv_n;
+            }
+        }
+        for (int i = tid; i < C * FO; i += 512) w2s[i] = a.w2[i];
+    }
     auto request = [&](int tile) {           // (loads from clamped, always valid rows; the rows past the end are zeroed by a select)
         const long r0 = (long)tile * FT;
         const long rz = min(r0 + zrow, N - 1), ra = min(r0 + xrow, N - 1), rb = min(r0 + xrow + 16, N - 1);
-        const uint4 vz = *reinterpret_cast<const uint4*>(a.dz + (size_t)rz * FO + zpc * 8);
+        const uint4 vz = *reinterpret_cast<const uint4*>((FUSED ? a.z : a.dz) + (size_t)rz * FO + zpc * 8);
+        if constexpr (FUSED) {
+            prow = r0 + zrow;
+#pragma unroll
+            for (int j = 0; j < C; ++j) pg[j] = a.dv[(size_t)rz * C + j];
+        }
         const uint4 va = *reinterpret_cast<const uint4*>(a.x + (size_t)ra * FI + xpc * 8);
         const uint4 vb = *reinterpret_cast<const uint4*>(a.x + (size_t)rb * FI + xpc * 8);
         const bool kz = r0 + zrow < N, ka = r0 + xrow < N, kb = r0 + xrow + 16 < N;
@@ -85,6 +129,43 @@ __global__ __launch_bounds__(512) void fc_bwd_kernel(FcBwdArgs a) {
     };
     auto land = [&](int slot) {
         unsigned char* base = fsm + slot * F_TILE;
+        if constexpr (FUSED) {
+            // da = (dv W2) keep 1[h > floor]   (dic_bnhead.hip: recompute_row + bwd B, the mean terms folded into ca + cb z)
+            const fbf16x8 x = __builtin_bit_cast(fbf16x8, pz);
+            float keep[8];
+            drop_factors(drop, prow, zpc, keep);
+            fbf16x8 o;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {        // four columns at a time: all the LDS operands of eight at once overflow the register file
+                const float* col = w2s + zpc * 8 + 4 * half;
+                float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < C; ++j) {      // (W2 and the column constants come from LDS: held in registers they spill -- 96 values per thread)
+                    const float4 wj = *reinterpret_cast<const float4*>(col + j * FO);
+                    sacc.x = fmaf(pg[j], wj.x, sacc.x); sacc.y = fmaf(pg[j], wj.y, sacc.y);
+                    sacc.z = fmaf(pg[j], wj.z, sacc.z); sacc.w = fmaf(pg[j], wj.w, sacc.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 k0 = *reinterpret_cast<const float4*>(col + C * FO), k1 = *reinterpret_cast<const float4*>(col + (C + 1) * FO);
+                const float4 k2 = *reinterpret_cast<const float4*>(col + (C + 2) * FO), k3 = *reinterpret_cast<const float4*>(col + (C + 3) * FO);
+                const float4 k4 = *reinterpret_cast<const float4*>(col + (C + 4) * FO), k5 = *reinterpret_cast<const float4*>(col + (C + 5) * FO);
+                const float sv[4] = {sacc.x, sacc.y, sacc.z, sacc.w}, scale[4] = {k0.x, k0.y, k0.z, k0.w}, shift[4] = {k1.x, k1.y, k1.z, k1.w};
+                const float mean[4] = {k2.x, k2.y, k2.z, k2.w}, rstd[4] = {k3.x, k3.y, k3.z, k3.w}, c1[4] = {k4.x, k4.y, k4.z, k4.w}, c2[4] = {k5.x, k5.y, k5.z, k5.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 4 * half + i;
+                    const float xe = (float)x[e];
+                    const float act = fmaxf(fmaf(xe, scale[i], shift[i]), a.floor_);
+                    const float xhat = (xe - mean[i]) * rstd[i];
+                    const float da = act > a.floor_ ? sv[i] * keep[e] : 0.f;
+                    o[e] = (__bf16)(scale[i] * (da - c1[i] - xhat * c2[i]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const uint4 v = __builtin_bit_cast(uint4, o);
+            const bool kz = prow < N;
+            pz = make_uint4(kz ? v.x : 0u, kz ? v.y : 0u, kz ? v.z : 0u, kz ? v.w : 0u);
+        }
         *reinterpret_cast<uint4*>(base + zrow * FZ_PITCH + zpc * 16) = pz;
         *reinterpret_cast<uint4*>(base + FT * FZ_PITCH + xrow * FX_PITCH + xpc * 16) = px0;
         *reinterpret_cast<uint4*>(base + FT * FZ_PITCH + (xrow + 16) * FX_PITCH + xpc * 16) = px1;
@@ -106,6 +187,7 @@ __global__ __launch_bounds__(512) void fc_bwd_kernel(FcBwdArgs a) {
     const int xt_off = FT * FZ_PITCH + rowoff * FX_PITCH + (32 * w + 16 * cb + 4 * kp) * 2;
 
     int tile = blockIdx.x;
+    if constexpr (FUSED) __syncthreads();                    // W2 is in LDS
     if (tile < ntiles) { request(tile); land(0); }
     if (tile + nwg < ntiles) request(tile + nwg);
     __syncthreads();
@@ -174,6 +256,20 @@ __global__ __launch_bounds__(256) void fc_bwd_finalize(const float* partials, in
     if (threadIdx.x < 32 && i < FO * FI) dw[i] = (float)s;
 }
 
+template <bool FUSED, int C>
+static int fc_bwd_launch(const FcBwdArgs& a, int nwg, float* dw, hipStream_t st) {
+    constexpr int lds = FUSED ? F_LDS_FUSED : F_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fc_bwd_kernel<FUSED, C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "fc_bwd: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((fc_bwd_kernel<FUSED, C>), dim3(nwg), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(fc_bwd_finalize, dim3(FO * FI / 32), dim3(256), 0, st, (const float*)a.partials, nwg, dw);
+    return check_launch("fc_bwd");
+}
+
 static int fc_bwd_blocks(long N) { return (int)max(1L, min((N + FT - 1) / FT, (long)kNumCU)); }
 
 }  // namespace dic
@@ -195,17 +291,28 @@ int dic_fc_bwd(const void* dz, const void* x, const void* w, int64_t N, int in_f
     DIC_REQUIRE(dz && x && w && dw && workspace, DIC_ERR_INVALID_ARG, "fc_bwd: NULL pointer");
     const int nwg = fc_bwd_blocks(N);
     DIC_REQUIRE(workspace_bytes >= (size_t)nwg * FO * FI * sizeof(float), DIC_ERR_WORKSPACE, "fc_bwd: workspace %zu B too small", workspace_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fc_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
-        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "fc_bwd: cannot reserve %d B of LDS: %s", F_LDS, hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    FcBwdArgs a{(const __bf16*)dz, (const __bf16*)x, (const __bf16*)w, (__bf16*)dx, (float*)workspace, (long)N};
-    hipLaunchKernelGGL(fc_bwd_kernel, dim3(nwg), dim3(512), F_LDS, st, a);
-    hipLaunchKernelGGL(fc_bwd_finalize, dim3(FO * FI / 32), dim3(256), 0, st, (const float*)workspace, nwg, dw);
-    return check_launch("fc_bwd");
+    FcBwdArgs a{};
+    a.dz = (const __bf16*)dz; a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.dx = (__bf16*)dx; a.partials = (float*)workspace; a.N = (long)N;
+    return fc_bwd_launch<false, 1>(a, nwg, dw, (hipStream_t)stream);
+}
+
+int dic_fc_bwd_bnhead(const void* z, const float* dv, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w2,
+                      const float* sum_da, const float* sum_dax, const float* count, int C, int relu, float drop_p, const uint64_t* rng,
+                      const void* x, const void* w, int64_t N, int in_features, int out_features, void* dx, float* dw,
+                      void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(N > 0, DIC_ERR_INVALID_ARG, "fc_bwd_bnhead: non-positive row count");
+    DIC_REQUIRE(in_features == FI && out_features == FO, DIC_ERR_UNSUPPORTED, "fc_bwd_bnhead: Linear(%d, %d) (compiled for Linear(%d, %d))", in_features,
+                out_features, FI, FO);
+    DIC_REQUIRE(C == 6, DIC_ERR_UNSUPPORTED, "fc_bwd_bnhead: head width %d (compiled for the reference's 6 channels; use dic_bnhead_bwd_input + dic_fc_bwd)", C);
+    DIC_REQUIRE(z && dv && mean && rstd && gamma && beta && w2 && sum_da && sum_dax && count && x && w && dw && workspace, DIC_ERR_INVALID_ARG,
+                "fc_bwd_bnhead: NULL pointer");
+    const int nwg = fc_bwd_blocks(N);
+    DIC_REQUIRE(workspace_bytes >= (size_t)nwg * FO * FI * sizeof(float), DIC_ERR_WORKSPACE, "fc_bwd_bnhead: workspace %zu B too small", workspace_bytes);
+    FcBwdArgs a{};
+    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.dx = (__bf16*)dx; a.partials = (float*)workspace; a.N = (long)N;
+    a.z = (const __bf16*)z; a.dv = dv; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.w2 = w2;
+    a.sum_da = sum_da; a.sum_dax = sum_dax; a.count = count; a.floor_ = relu ? 0.f : -INFINITY; a.drop_p = drop_p; a.rng = (const unsigned long long*)rng;
+    return fc_bwd_launch<true, 6>(a, nwg, dw, (hipStream_t)stream);
 }
 
 }  // extern "C"

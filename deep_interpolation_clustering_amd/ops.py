@@ -616,6 +616,86 @@ class _RowsLinear(torch.autograd.Function):
         return dx, splitk_tn(dyb, xb), db, None, None
 
 
+COMPRESS_FUSED = os.environ.get('DIC_COMPRESS_FUSED', '1') != '0'       # (A/B switch: 0 = rows_linear + bn_relu_head as two autograd nodes)
+COMPRESS_FUSED_OUT = 6           # head width dic_fc_bwd_bnhead is compiled for (the reference's six vitals)
+
+
+class _CompressFC(torch.autograd.Function):
+    """CompressFC (rbf.py:111-125) in training mode, Linear(256,128) -> BatchNorm1d(128) -> ReLU -> Dropout -> Linear(128,6) over the
+    (N,256) bf16 decoder rows, as ONE autograd node.  Forward: the kernels of rows_linear(with_stats=True) and bn_relu_head
+    (dic_row_proj_stats -> dic_bn_moments -> dic_bnhead_fwd).  Backward: dic_bnhead_bwd_reduce, then dic_fc_bwd_bnhead forms the
+    gradient of the 128-wide pre-activation on its way into LDS instead of reading it -- dic_bnhead_bwd_input's pass over z and the
+    (N,128) dZ tensor (a 201 MB write and read at B = 32768) are gone; same arithmetic, same bits."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, eps, running_mean, running_var, nbt, momentum, drop_p):
+        N.require_gpu(x, w1, b1, gamma, beta, w2, b2)
+        xb, wb = x.to(torch.bfloat16).contiguous(), w1.detach().to(torch.bfloat16).contiguous()
+        n, k, c = xb.shape[0], wb.shape[0], w2.shape[0]
+        L, dev, st = N.lib(), xb.device, N.stream_of(xb)
+        z = torch.empty((n, k), device=dev, dtype=torch.bfloat16)
+        sums = torch.empty(2 * k + 1, device=dev, dtype=torch.float64)
+        ws = _ws(L.dic_row_proj_stats_workspace(n, k), dev)
+        N.check(L.dic_row_proj_stats(N.ptr(xb), N.ptr(wb), N.ptr(b1.detach().to(torch.bfloat16)), n, wb.shape[1], k, N.ptr(z), N.ptr(sums), N.ptr(ws),
+                                     ws.numel(), st), 'dic_row_proj_stats')
+        dist.all_reduce_sum_(sums)                # the moments of the GLOBAL batch (SURVEY.md 8e)
+        mean = torch.empty(k, device=dev, dtype=torch.float32)
+        rstd, cnt = torch.empty_like(mean), torch.empty(1, device=dev, dtype=torch.float32)
+        track = running_mean is not None
+        N.check(L.dic_bn_moments(N.ptr(sums), k, float(eps), -1.0 if momentum is None else float(momentum),
+                                 N.ptr(running_mean) if track else None, N.ptr(running_var) if track else None,
+                                 N.ptr(nbt) if (track and nbt is not None) else None, N.ptr(mean), N.ptr(rstd), N.ptr(cnt), st), 'dic_bn_moments')
+        g, bt, w2f, b2f = N.f32c(gamma.detach()), N.f32c(beta.detach()), N.f32c(w2.detach()), N.f32c(b2.detach())
+        v = torch.empty((n, c), device=dev, dtype=torch.float32)
+        rng = _dropout_rng(dev) if drop_p > 0 else None
+        N.check(L.dic_bnhead_fwd(N.ptr(z), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w2f), N.ptr(b2f), n, k, c, 1, float(drop_p), N.ptr(rng), N.ptr(v), st),
+                'dic_bnhead_fwd')
+        ctx.save_for_backward(xb, wb, z, mean, rstd, g, bt, w2f, cnt, rng)
+        ctx.x_dtype, ctx.drop_p = x.dtype, float(drop_p)
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        xb, wb, z, mean, rstd, g, bt, w2f, cnt, rng = ctx.saved_tensors
+        n, k, c = xb.shape[0], wb.shape[0], w2f.shape[0]
+        L, dev, st = N.lib(), xb.device, N.stream_of(xb)
+        gv = N.f32c(dv)
+        sums = torch.empty((2 + c) * k + c, device=dev, dtype=torch.float32)
+        ws = _ws(L.dic_bnhead_bwd_workspace(n, k, c), dev)
+        N.check(L.dic_bnhead_bwd_reduce(N.ptr(z), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w2f), N.ptr(gv), n, k, c, 1, ctx.drop_p, N.ptr(rng),
+                                        N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bnhead_bwd_reduce')
+        dbeta, dgamma = sums[:k], sums[k:2 * k]                 # this rank's share; the gradient all-reduce sums them
+        dw2, db2 = sums[2 * k:(2 + c) * k].view(c, k), sums[(2 + c) * k:]
+        red = sums[:2 * k]
+        if dist.is_sharded():
+            red = red.clone()
+            dist.all_reduce_sum_(red)
+        dxb = torch.empty_like(xb) if ctx.needs_input_grad[0] else None
+        dw1 = torch.empty(wb.shape, device=dev, dtype=torch.float32)
+        ws2 = _ws(L.dic_fc_bwd_workspace(n, wb.shape[1], k), dev)
+        N.check(L.dic_fc_bwd_bnhead(N.ptr(z), N.ptr(gv), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w2f), N.ptr(red), N.ptr(red[k:]), N.ptr(cnt),
+                                    c, 1, ctx.drop_p, N.ptr(rng), N.ptr(xb), N.ptr(wb), n, wb.shape[1], k, N.ptr(dxb), N.ptr(dw1), N.ptr(ws2), ws2.numel(), st),
+                'dic_fc_bwd_bnhead')
+        # (the bias of the first layer sits in front of a training-mode BatchNorm: its gradient is identically 0)
+        db1 = torch.zeros(k, device=dev, dtype=torch.float32)
+        return (None if dxb is None else dxb.to(ctx.x_dtype)), dw1, db1, dgamma, dbeta, dw2, db2, None, None, None, None, None, None
+
+
+def compress_fc_fused_ok(x, first, bn, last):
+    """The one-node CompressFC applies to the training step of the large-batch path: (N >= FC_BWD_MIN_ROWS, 256) contiguous rows,
+    Linear(256,128), a training-mode BatchNorm1d, the six-channel head."""
+    return (COMPRESS_FUSED and x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.shape[0] >= FC_BWD_MIN_ROWS
+            and tuple(first.weight.shape) == FC_BWD_SHAPE and bn.training and last.out_features == COMPRESS_FUSED_OUT
+            and last.in_features == first.out_features)
+
+
+def compress_fc(x, first, bn, dropout, last):
+    drop_p = float(dropout.p) if (dropout is not None and dropout.training) else 0.0
+    track = bn.track_running_stats and bn.running_mean is not None
+    return _CompressFC.apply(x, first.weight, first.bias, bn.weight, bn.bias, last.weight, last.bias, bn.eps, bn.running_mean if track else None,
+                             bn.running_var if track else None, bn.num_batches_tracked if track else None, bn.momentum, drop_p)
+
+
 def rows_linear(x, weight, bias, bias_grad_is_zero=False, with_stats=False):
     """``bias_grad_is_zero``: the caller knows d loss / d bias == 0 identically -- a bias in front of a training-mode
     BatchNorm, whose mean subtraction cancels it (sum over rows of the BatchNorm input gradient is 0) -- so the (N, out)

@@ -27,6 +27,10 @@ class CompressFC(nn.Module):
         # bf16 step: the C-wide output layer over all B*R rows is a 100 MB stream, not a GEMM (csrc/dic_head.hip)
         first = self.model[0]
         bn, drop = self.model[1], self.model[3]
+        if ops.compress_fc_fused_ok(rec_input, first, bn, last):
+            # the large-batch training step: the whole module as one autograd node (the 128-wide gradient is never materialised either)
+            with torch.autocast('cuda', enabled=False):
+                return ops.compress_fc(rec_input, first, bn, drop, last)
         with torch.autocast('cuda', enabled=False):
             # split-K weight gradient; the bias sits in front of BatchNorm: its gradient is identically 0 in training mode
             # (training mode: the layer's kernel also delivers the column sums the BatchNorm behind it needs)

@@ -340,6 +340,15 @@ int dic_row_proj_stats(const void* x, const void* w, const void* bias, int64_t N
 size_t dic_fc_bwd_workspace(int64_t N, int in_features, int out_features);
 int dic_fc_bwd(const void* dz, const void* x, const void* w, int64_t N, int in_features, int out_features, void* dx, float* dw,
                void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* The same with dz formed inside the kernel instead of read: the layer's own output z (N,128) bf16 goes through the backward of the
+ * tail behind it -- BatchNorm1d(128, training) -> ReLU -> Dropout -> Linear(128, C) (rbf.py:114-124) -- on its way into LDS, with the
+ * arithmetic of dic_bnhead_bwd_input (bit-identical dz): dv (N,C) f32 the gradient of the tail's output; mean, rstd, gamma, beta (128),
+ * w2 (C,128) f32; sum_da, sum_dax (128) the column sums of dic_bnhead_bwd_reduce (summed over ranks); count (1) the global row count
+ * of the batch moments (dic_bn_moments); relu / drop_p / rng as in dic_bnhead_bwd_input.  Compiled for C = 6. */
+int dic_fc_bwd_bnhead(const void* z, const float* dv, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* w2,
+                      const float* sum_da, const float* sum_dax, const float* count, int C, int relu, float drop_p, const uint64_t* rng,
+                      const void* x, const void* w, int64_t N, int in_features, int out_features, void* dx, float* dw,
+                      void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
 /* ------------------------------------------------------------------ CompressFC output layer ---
  * Linear(128, C) over all N = B*R decoder rows (rbf.py:111-125, last layer; TimeDistributed utils.py:202-224)

@@ -757,3 +757,35 @@ def test_lane_native_gx_path_equals_row_major_path(R, B, init, monkeypatch):
         res[native] = dict(out=out.detach().float(), hn=hn.detach(), cn=cn.detach(), dx=xi.grad.clone(), **{k: p.grad.clone() for k, p in net.named_parameters()})
     for k in res[False]:
         assert torch.equal(res[False][k], res[True][k]), k
+
+
+@pytest.mark.parametrize('n,p', [(24 * 512, 0.0), (8192 + 37, 0.0), (24 * 512, 0.25)])
+def test_compress_fc_as_one_node_equals_the_two_node_path(n, p, monkeypatch):
+    """CompressFC's training step as one autograd node (ops._CompressFC: dic_fc_bwd_bnhead forms the gradient of the 128-wide
+    pre-activation inside the kernel) against rows_linear + bn_relu_head (dic_bnhead_bwd_input writes it, dic_fc_bwd reads it): the
+    same arithmetic in the same order -- outputs, every gradient and the BatchNorm running statistics are bit-equal; also with the
+    in-kernel dropout mask (same seed and call counter: same mask)."""
+    from deep_interpolation_clustering_amd import ops
+    from deep_interpolation_clustering_amd.rbf import CompressFC
+    dev = torch.device('cuda')
+    torch.manual_seed(n)
+    base = CompressFC(256, 6, p).to(dev).train()
+    x = torch.randn(n, 256, device=dev) * 0.7
+    gv = torch.randn(n, 6, device=dev)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(ops, 'COMPRESS_FUSED', fused)
+        ops._DROP_STATE.clear()                             # both runs draw the first mask of the same seed
+        torch.manual_seed(99)
+        fc = CompressFC(256, 6, p).to(dev).train()
+        fc.load_state_dict(base.state_dict())
+        xi = x.clone().requires_grad_()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            assert ops.compress_fc_fused_ok(xi.to(torch.bfloat16), fc.model[0], fc.model[1], fc.model[4]) == fused
+            v = fc(xi.to(torch.bfloat16))
+        (v * gv).sum().backward()
+        res[fused] = dict(v=v.detach(), dx=xi.grad.clone(), rm=fc.model[1].running_mean.clone(), rv=fc.model[1].running_var.clone(),
+                          **{k: q.grad.clone() for k, q in fc.named_parameters()})
+    assert float(res[True]['dx'].abs().max()) > 0
+    for k in res[False]:
+        assert torch.equal(res[False][k], res[True][k]), k
