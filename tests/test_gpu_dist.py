@@ -23,6 +23,7 @@ def _args():
 def _env(rank, world, port, rccl):
     """gloo between ranks that share the test GPU -- or (rccl) ONE rank on RCCL with the sharded code paths switched on."""
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ['DIC_FC_BWD_MIN_ROWS'] = '1024'        # the shards of these small batches take the large-batch CompressFC path (one autograd node)
     if rccl:
         os.environ.pop('DIC_DIST_BACKEND', None)
         os.environ['DIC_DIST_SINGLE_RANK'] = '1'

@@ -109,8 +109,10 @@ def test_forward_matches_oracle_bigger_batch():
     assert (aux['cluster_pred'].argmax(1).cpu() == aux_ref['cluster_pred'].argmax(1)).all()
 
 
-def test_hip_graph_step_matches_eager():
-    """Stepper(use_graphs=True) captures the whole step in a hipGraph; the trajectory must equal the eager one."""
+@pytest.mark.parametrize('bs', [256, 512])
+def test_hip_graph_step_matches_eager(bs):
+    """Stepper(use_graphs=True) captures the whole step in a hipGraph; the trajectory must equal the eager one.  (512 rows x 24 steps
+    reach the row count from which CompressFC runs as one autograd node on the resident-weight kernels.)"""
     from deep_interpolation_clustering_amd import synthetic
     from deep_interpolation_clustering_amd.clustering_interp import Net
     from deep_interpolation_clustering_amd.step import Stepper
@@ -119,7 +121,7 @@ def test_hip_graph_step_matches_eager():
                            fake_detection=False, triple_margin=0.0, cluster_number=4, loss='ae_mse_kl', grad_clip=15.0,
                            unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
     dev = torch.device('cuda')
-    coh = synthetic.make_cohort(512, seed=8)
+    coh = synthetic.make_cohort(2 * bs, seed=8)
     x_np, ob_np, n = synthetic.stacked_batch(coh)
     X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
     traj = {}
@@ -130,8 +132,8 @@ def test_hip_graph_step_matches_eager():
         st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16, use_graphs=mode)
         out = []
         for i in range(8):
-            lo = (i % 2) * 256
-            losses, gnorm, _ = st.step(X[lo:lo + 256], OB[lo:lo + 256], None, LEN[lo:lo + 256])
+            lo = (i % 2) * bs
+            losses, gnorm, _ = st.step(X[lo:lo + bs], OB[lo:lo + bs], None, LEN[lo:lo + bs])
             out.append([float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(gnorm)])
         traj[mode] = np.array(out)
         if mode:
