@@ -789,3 +789,39 @@ def test_compress_fc_as_one_node_equals_the_two_node_path(n, p, monkeypatch):
     assert float(res[True]['dx'].abs().max()) > 0
     for k in res[False]:
         assert torch.equal(res[False][k], res[True][k]), k
+
+
+def test_decoder_projection_and_recurrence_at_bench_size():
+    """BASELINE configs[1] size (B = 32768 rows per step, R = 24): the lane-native hand-over between dic_row_proj and dic_lstm_fwd
+    against the row-major one -- a pure reordering of gx, so out / h_n / c_n and the saved gates are bit-equal; plus linearity of the
+    projection in its bias (gx(b) - gx(0) == b to bf16 rounding) as a size-independent check of the 786 432 x 1024 product."""
+    from deep_interpolation_clustering_amd import _native as N
+    L = N.lib()
+    R, B = 24, 32768
+    dev, bf = torch.device('cuda'), torch.bfloat16
+    torch.manual_seed(3)
+    x = (torch.randn(R * B, 256, device=dev) * 0.5).clamp_min(0).to(bf)
+    wih = (torch.randn(8 * H, 256, device=dev) * 0.06).to(bf)
+    bias = (torch.randn(8 * H, device=dev) * 0.1).to(bf)
+    whh = (torch.randn(2, 4 * H, H, device=dev) * 0.08).to(bf)
+    st = N.stream_of(x)
+    res = {}
+    for native in (0, B):
+        gx = torch.empty(R * B, 8 * H, device=dev, dtype=bf)
+        out = torch.empty(R, B, 2 * H, device=dev, dtype=bf)
+        gates, cs = torch.empty(R, B, 2, 4, H, device=dev, dtype=bf), torch.empty(R, B, 2, H, device=dev, dtype=bf)
+        hn, cn = torch.empty(2, B, H, device=dev), torch.empty(2, B, H, device=dev)
+        N.check(L.dic_row_proj(N.ptr(x), N.ptr(wih), N.ptr(bias), R * B, 256, 8 * H, N.ptr(gx), native, st), 'dic_row_proj')
+        N.check(L.dic_lstm_fwd(N.ptr(gx), int(native > 0), N.ptr(whh), None, None, R, B, H, N.ptr(out), None, N.ptr(hn), N.ptr(cn), N.ptr(gates),
+                               N.ptr(cs), 0, 0, st), 'dic_lstm_fwd')
+        res[native] = (out, hn, cn, gates, cs)
+        if not native:
+            g0 = torch.empty_like(gx)
+            N.check(L.dic_row_proj(N.ptr(x), N.ptr(wih), None, R * B, 256, 8 * H, N.ptr(g0), 0, st), 'dic_row_proj')
+            d = (gx[::97].float() - g0[::97].float()) - bias.float()
+            assert float(d.abs().max()) <= 2.0 ** -7 * float(gx[::97].float().abs().max())      # two bf16 roundings
+            del g0
+        del gx
+    for a, b in zip(res[0], res[B]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[0][0].float()).all() and float(res[0][0].float().abs().mean()) > 0.01
