@@ -192,7 +192,7 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
         keep = (oext, grads_e, grads_d, dxp, ws7, ws8, xdec)
         calls['lstm_dw'] = (lambda: L.dic_lstm_dw(P(ldgx), P(oext), P(xenc), P(wih), P(dxp), R, B, Hh, 18, 32, gpe, 0, P(ws7), ws7.numel(), st) + 0 * len(keep),
                             rows * 4 * Hh * 2 + R * B * (2 * Hh * 2 + 32 * 2 + 2 * 32 * 2))   # dG once; h, x in; per-direction dX out
-        calls['lstm_dw_wide'] = (lambda: L.dic_lstm_dw_wide(P(ldgx), P(oext), P(xdec), R, B, Hh, 256, gpd, 0, P(ws8), ws8.numel(), st) + 0 * len(keep),
+        calls['lstm_dw_wide'] = (lambda: L.dic_lstm_dw_wide(P(ldgx), P(oext), P(xdec), 1, R, B, Hh, 256, gpd, 0, P(ws8), ws8.numel(), st) + 0 * len(keep),
                                  rows * 4 * Hh * 2 + R * B * (2 * Hh * 2 + 256 * 2))           # dG once; h, x once
         # resident-weight projections (csrc/dic_rowproj.hip) and the one-pass CompressFC Linear(256,128) backward (csrc/dic_fcgrad.hip)
         wdec = (torch.randn((8 * Hh, 256), **f32) * 0.06).to(bf)
@@ -205,7 +205,7 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
         ws9 = torch.empty(max(16, L.dic_row_proj_stats_workspace(R * B, 128)), dtype=torch.uint8, device=dev)
         ws10 = torch.empty(max(16, L.dic_fc_bwd_workspace(R * B, 256, 128)), dtype=torch.uint8, device=dev)
         keep2 = (wdec, bdec, w1, b1, zfc, dzfc, sums, dxfc, dw1, ws9, ws10)
-        calls['row_proj'] = (lambda: L.dic_row_proj(P(xdec), P(wdec), P(bdec), R * B, 256, 8 * Hh, P(ldgx), B if B % 64 == 0 else 0, st) + 0 * len(keep2),
+        calls['row_proj'] = (lambda: L.dic_row_proj(P(xdec), P(wdec), P(bdec), R * B, 256, 8 * Hh, P(ldgx), B if B % 64 == 0 else 0, 1, st) + 0 * len(keep2),
                              R * B * (256 * 2 + 8 * Hh * 2))                                   # x once; gx out
         calls['row_proj_stats'] = (lambda: L.dic_row_proj_stats(P(xdec), P(w1), P(b1), R * B, 256, 128, P(zfc), P(sums), P(ws9), ws9.numel(), st),
                                    R * B * (256 * 2 + 128 * 2))                                # x once; z out (+ the column sums)

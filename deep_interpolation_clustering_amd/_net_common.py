@@ -36,7 +36,9 @@ class EncoderRNN(nn.Module):
 
     def forward(self, x, packed=False, batch_major_state=False, rectified_out=False):
         """``batch_major_state`` (fused path only): hidden / cell_state come back as (B,2,H) -- see lstm.bilstm.
-        ``rectified_out`` (fused path only): output is relu(output), which is all the decoder reads of it (DecoderRNN.forward)."""
+        ``rectified_out`` (fused path only): output is relu(output), which is all the decoder reads of it (DecoderRNN.forward);
+        ``'deferred'``: the output stays raw and the decoder's kernels rectify it on load (lstm.deferred_relu_ok), the ReLU's backward
+        is still applied by the encoder's recurrence kernel."""
         if packed:                                           # (R,B,32) bf16 rows straight from ops.sci_cci_packed
             output, (hidden, cell_state) = fused_lstm.bilstm_packed(x, self.lstm, batch_major_state=batch_major_state, rectified_out=rectified_out)
         elif fused_lstm.fused_available(x, self.lstm) or fused_lstm.f32_available(x, self.lstm):      # on the GPU: persistent HIP recurrence
@@ -53,11 +55,14 @@ class DecoderRNN(nn.Module):
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers=num_layers, dropout=dropout, bidirectional=bidirectional)
 
     def forward(self, x, hidden, context, batch_major_state=False, rectified=False):
+        defer = rectified == 'deferred'                                         # raw encoder output, rectified on load by the decoder's kernels
         if not rectified:                                                       # (the fused encoder hands its output over rectified)
             x = F.relu(x)                                                       # clustering_interp.py:38-41
         if fused_lstm.fused_available(x, self.lstm) or fused_lstm.f32_available(x, self.lstm):
-            x, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, hidden, context, batch_major_state=batch_major_state)
+            x, (hidden, cell_state) = fused_lstm.bilstm(x, self.lstm, hidden, context, batch_major_state=batch_major_state, input_rectify=defer)
         else:
+            if defer:
+                x = F.relu(x)
             x, (hidden, cell_state) = self.lstm(x, (hidden, context))
         return x, (hidden, cell_state)
 
@@ -168,15 +173,18 @@ class NetBase(nn.Module):
         # fused recurrence (bf16 step): final states in batch-major (B,2,H) layout -- the latent z = [h_fwd | h_rev] is then a VIEW of
         # h_n, and the decoder takes (h_n, c_n) as they lie: no cat / slice / copy kernels between encoder, DEC head and decoder
         bm = fused_lstm.fused_available(feats[0], self.encoder.lstm) or fused_lstm.f32_available(feats[0], self.encoder.lstm)
+        # the F.relu between encoder and decoder: large bf16 batches leave it to the decoder's kernels (no rectified copy), else the encoder
+        # hands its output over rectified
+        rect = ('deferred' if fused_lstm.deferred_relu_ok(B) else True) if bm else False
         if len(feats) > 1 and B * feats[0].size(0) >= SEPARATE_ENCODER_ROWS:
             # large batches: one encoder call per branch.  Each already fills the chip, and the shared call would cost three
             # 100-MB-class copies (stacking the inputs, slicing the real half of the context and of the final states back out)
-            outs = [self.encoder(f, packed, bm, bm and i == 0) for i, f in enumerate(feats)]      # (only the real branch's output feeds the decoder)
+            outs = [self.encoder(f, packed, bm, rect if i == 0 else False) for i, f in enumerate(feats)]      # (only the real branch's output feeds the decoder)
             context, hidden, cell = outs[0]
             z_all = torch.cat([self._latent(o[1], bm) for o in outs], dim=0)                     # (nB, 256)
         else:
             seq = feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)                        # (R, nB, .)
-            context, hidden, cell = self.encoder(seq, packed, bm, bm)
+            context, hidden, cell = self.encoder(seq, packed, bm, rect)
             z_all = self._latent(hidden, bm)                                                      # (nB, 256)
             if len(feats) > 1:
                 context = context[:, :B]
@@ -185,7 +193,7 @@ class NetBase(nn.Module):
         if self.on_decoder_side_grads is not None and context.requires_grad:
             cb = self.on_decoder_side_grads
             context.register_hook(lambda g: cb())           # fires when the backward has passed the decoder, its head and the latent heads
-        y, _ = self.decoder(context, hidden, cell, bm, bm) if bm else self.decoder(context, hidden, cell)
+        y, _ = self.decoder(context, hidden, cell, bm, rect) if bm else self.decoder(context, hidden, cell)
         # (B,C,T).  Inside step.Stepper's optimisation step (`internal_step`: the reconstruction is consumed by rec_loss alone and never
         # handed out) only the observed slots are materialised; every other caller gets zeros in the padding, as upstream's `* mask`
         if self.internal_step and self.rec_target is not None and lengths is not None:

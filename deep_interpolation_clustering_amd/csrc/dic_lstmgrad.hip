@@ -300,6 +300,7 @@ struct DwWideArgs {
     const __bf16* x;       // (R*B, 256)
     float* partials;       // (gridDim.x, 4, 256, 384)
     int R, B;
+    int x_relu;            // x is the raw encoder output: the input the LSTM saw is relu(x) (rectified in the B fragments, one v_pk_max_i16 each)
 };
 
 __global__ __launch_bounds__(512) void lstm_dw_wide_kernel(DwWideArgs a) {
@@ -346,12 +347,14 @@ __global__ __launch_bounds__(512) void lstm_dw_wide_kernel(DwWideArgs a) {
     const int rowoff = 8 * hh + kq;
     auto piece = [&](int j) { return (((4 * j + 2 * cb + (kp >> 1)) ^ (kq << 2)) * 16) + (kp & 1) * 8; };
     int pa_off[2], pb_off[6], pb_pitch[6];         // n-block j = 6 ng + i of [h (4 blocks) | x (8 blocks)]
+    short pb_floor[6];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) pa_off[mb] = rowoff * (DMH * 2) + piece(2 * mg + mb);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int j = 6 * ng + i;
         pb_pitch[i] = j < 4 ? GH * 2 : DXW * 2;
+        pb_floor[i] = (j >= 4 && a.x_relu) ? (short)0 : (short)-32768;
         pb_off[i] = j < 4 ? WD_DG + rowoff * (GH * 2) + piece(j) : WD_DG + WD_H + rowoff * (DXW * 2) + piece(j - 4);
     }
     auto frag = [&](const unsigned char* p, int pitch) {
@@ -393,7 +396,13 @@ __global__ __launch_bounds__(512) void lstm_dw_wide_kernel(DwWideArgs a) {
             for (int mb = 0; mb < 2; ++mb) af[mb] = frag(base + ks * 16 * (DMH * 2) + pa_off[mb], DMH * 2);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const bf16x8 bfg = frag(base + ks * 16 * pb_pitch[i] + pb_off[i], pb_pitch[i]);
+                bf16x8 bfg = frag(base + ks * 16 * pb_pitch[i] + pb_off[i], pb_pitch[i]);
+                {   // relu of the x columns (h columns: identity floor): max on the int16 halves, see pk_relu in dic_rowproj.hip
+                    typedef short s16x8v __attribute__((ext_vector_type(8)));
+                    const short fl = pb_floor[i];
+                    const s16x8v flv = {fl, fl, fl, fl, fl, fl, fl, fl};
+                    bfg = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8v, bfg), flv));
+                }
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfg, acc[mb][i], 0, 0, 0);
             }
@@ -553,7 +562,7 @@ size_t dic_lstm_dw_wide_workspace(int R, int B) {
     return (size_t)dw_wide_chunks(R, B) * WD_OUT * sizeof(float);
 }
 
-int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int R, int B, int H, int I, float* const* grads, int accumulate,
+int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int x_relu, int R, int B, int H, int I, float* const* grads, int accumulate,
                      void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_dw_wide: non-positive size");
     DIC_REQUIRE(H == GH, DIC_ERR_UNSUPPORTED, "lstm_dw_wide: hidden size %d (compiled for %d)", H, GH);
@@ -573,7 +582,7 @@ int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int R,
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    DwWideArgs a{(const __bf16*)dgx, (const __bf16*)out_ext, (const __bf16*)x, (float*)workspace, R, B};
+    DwWideArgs a{(const __bf16*)dgx, (const __bf16*)out_ext, (const __bf16*)x, (float*)workspace, R, B, x_relu != 0};
     hipLaunchKernelGGL(lstm_dw_wide_kernel, dim3(nch, 4), dim3(512), WD_LDS, st, a);
     hipLaunchKernelGGL(lstm_dw_wide_finalize, dim3((WD_OUT + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, g, accumulate ? 1.0f : 0.0f);
     return check_launch("lstm_dw_wide");

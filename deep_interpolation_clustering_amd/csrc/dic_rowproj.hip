@@ -34,7 +34,19 @@ struct RowProjArgs {
     int Nout;
     float* stat_part;      // STATS: (gridDim.x, 2, 32 NW) per-workgroup column sums of out and out^2
     int nbt;               // NATIVE: 32-row tiles per time step (batch / 32)
+    int relu_in;           // the product is taken of relu(x): x is the raw output of the encoder LSTM (clustering_interp.py:38-41 applies
+                           // F.relu between the two), rectified on its way into LDS -- no rectified copy of the encoder output in HBM
 };
+
+// relu of packed bf16 pairs as ONE integer instruction per register: a negative bf16 is a negative int16, so max(x, 0) on the 16-bit
+// halves (v_pk_max_i16) zeroes exactly the negative halves (and -0.0); `floor` = 0 applies it, 0x8000 per half (INT16_MIN) is the identity
+typedef short ps16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_relu(unsigned x, unsigned floor) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ps16x2, x), __builtin_bit_cast(ps16x2, floor)));
+}
+__device__ __forceinline__ uint4 pk_relu4(uint4 v, unsigned floor) {
+    return make_uint4(pk_relu(v.x, floor), pk_relu(v.y, floor), pk_relu(v.z, floor), pk_relu(v.w, floor));
+}
 
 // NATIVE (the decoder's gx, Nout = 1024 = 2 directions x 4 gates x 128 units, read back only by the recurrence kernel): the product is
 // issued TRANSPOSED -- D[output column][row] = W . x^T, the same fragments with the operands swapped -- so lane (row r, hh) ends up
@@ -79,13 +91,14 @@ __global__ __launch_bounds__(NW * 64, 2) void row_proj_kernel(RowProjArgs a) {
 #define DIC_RP_LAND(SLOT)                                                                                              \
     do {                                                                                                               \
         unsigned char* base_ = psm + (SLOT) * P_TILE + xrow * PX_PITCH + xpc * 16;                                     \
-        *reinterpret_cast<uint4*>(base_) = px0;                                                                        \
-        *reinterpret_cast<uint4*>(base_ + (NT / 32) * PX_PITCH) = px1;                                                 \
+        *reinterpret_cast<uint4*>(base_) = pk_relu4(px0, xfloor);                                                      \
+        *reinterpret_cast<uint4*>(base_ + (NT / 32) * PX_PITCH) = pk_relu4(px1, xfloor);                               \
         if constexpr (PPT == 4) {                                                                                      \
-            *reinterpret_cast<uint4*>(base_ + 2 * (NT / 32) * PX_PITCH) = px2;                                         \
-            *reinterpret_cast<uint4*>(base_ + 3 * (NT / 32) * PX_PITCH) = px3;                                         \
+            *reinterpret_cast<uint4*>(base_ + 2 * (NT / 32) * PX_PITCH) = pk_relu4(px2, xfloor);                       \
+            *reinterpret_cast<uint4*>(base_ + 3 * (NT / 32) * PX_PITCH) = pk_relu4(px3, xfloor);                       \
         }                                                                                                              \
     } while (0)
+    const unsigned xfloor = a.relu_in ? 0u : 0x80008000u;
     const int a_off = (lane & 31) * PX_PITCH + hh * 16;       // A operand: row (lane & 31), 16-B piece 2 ks + hh
 
     int tile = blockIdx.x;
@@ -192,7 +205,7 @@ using namespace dic;
 extern "C" {
 
 int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, int lane_native_batch,
-                 dic_stream_t stream) {
+                 int relu_input, dic_stream_t stream) {
     DIC_REQUIRE(N > 0, DIC_ERR_INVALID_ARG, "row_proj: non-positive row count");
     DIC_REQUIRE(in_features == PK && out_features > 0 && out_features % 256 == 0, DIC_ERR_UNSUPPORTED,
                 "row_proj: (%d -> %d) (compiled for 256 inputs and a multiple of 256 outputs)", in_features, out_features);
@@ -201,7 +214,7 @@ int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int 
     DIC_REQUIRE(lane_native_batch == 0 || (out_features == 1024 && lane_native_batch > 0 && lane_native_batch % 64 == 0 && N % lane_native_batch == 0),
                 DIC_ERR_INVALID_ARG, "row_proj: lane-native output needs 1024 output columns and rows = steps x a batch that is a multiple of 64 (batch %d, %lld rows)",
                 lane_native_batch, (long long)N);
-    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, nullptr, lane_native_batch / 32};
+    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, nullptr, lane_native_batch / 32, relu_input != 0};
     int rc = lane_native_batch ? row_proj_launch<8, false, true>(a, row_proj_chunks(N, stripes, 2), stripes, (hipStream_t)stream)
                                : row_proj_launch<8, false, false>(a, row_proj_chunks(N, stripes, 2), stripes, (hipStream_t)stream);
     return rc ? rc : check_launch("row_proj");
@@ -220,7 +233,7 @@ int dic_row_proj_stats(const void* x, const void* w, const void* bias, int64_t N
     DIC_REQUIRE(x && w && out && sums && workspace, DIC_ERR_INVALID_ARG, "row_proj_stats: NULL pointer");
     const int nch = row_proj_chunks(N, 1, 3);
     DIC_REQUIRE(workspace_bytes >= (size_t)nch * 2 * 128 * sizeof(float), DIC_ERR_WORKSPACE, "row_proj_stats: workspace too small");
-    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, (float*)workspace, 0};
+    RowProjArgs a{(const __bf16*)x, (const __bf16*)w, (const __bf16*)bias, (__bf16*)out, (long)N, out_features, (float*)workspace, 0, 0};
     int rc = row_proj_launch<4, true, false>(a, nch, 1, (hipStream_t)stream);
     if (rc) return rc;
     hipLaunchKernelGGL(row_proj_stats_finalize, dim3(2 * 128 / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nch, 2 * 128, (double)N, sums);

@@ -36,6 +36,7 @@ PARAM_NAMES = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
                'weight_ih_l0_reverse', 'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
 
+DEFER_RELU = os.environ.get('DIC_DEFER_RELU', '1') != '0'             # (A/B switch: 0 = the encoder writes a rectified copy of its output for the decoder)
 GX_LANE_NATIVE = os.environ.get('DIC_GX_LANE_NATIVE', '1') != '0'     # (A/B switch: 0 = row-major gx between dic_row_proj and dic_lstm_fwd)
 ROW_PROJ = os.environ.get('DIC_ROW_PROJ', '1') != '0'                  # (A/B switch: 0 = library GEMM for the decoder's input projection)
 RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B switch: 0 = rectify the encoder output with a torch pass)
@@ -72,7 +73,7 @@ def _grad_sinks(params, needs):
 
 class _BiLstm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h0, c0, packed, bm, f32, relu, *params):
+    def forward(ctx, x, h0, c0, packed, bm, f32, relu, relu_in, *params):
         R, B, I_in = x.shape
         T = torch.float32 if f32 else torch.bfloat16
         code = N.DTYPE_F32 if f32 else N.DTYPE_BF16
@@ -103,6 +104,10 @@ class _BiLstm(torch.autograd.Function):
             xb = xb.contiguous()
             if narrow:
                 xb[..., I].fill_(1.0)                              # the bias rides along as a constant-one input column
+        # input_rectify: relu(x) is applied by the projection / weight-gradient kernels on the raw x (large decoder path), else here
+        relu_kernel = bool(relu_in) and (not small) and (not proj) and Ip == WIDE_INPUT and ROW_PROJ
+        if relu_in and not relu_kernel:
+            xb = torch.relu(xb)
         out_ext = torch.empty((R + 2, B, 2 * H), device=dev, dtype=T)       # [h0 | h_1..h_R | h0]: every step's h_prev is a row above / below
         out = out_ext[1:R + 1]
         kernel_boundary = need and not small                       # the 64-row kernels write the boundary rows of the dW_hh products themselves
@@ -118,7 +123,7 @@ class _BiLstm(torch.autograd.Function):
         h0c = None if h0 is None else N.f32c(h0)
         c0c = None if c0 is None else N.f32c(c0)
         gates = cs = None
-        out_r = torch.empty((R, B, 2 * H), device=dev, dtype=T) if (relu and not small and RELU_IN_KERNEL) else None     # written by the 64-row kernels themselves
+        out_r = torch.empty((R, B, 2 * H), device=dev, dtype=T) if (relu == 1 and not small and RELU_IN_KERNEL) else None     # written by the 64-row kernels themselves
         if small:
             if need:
                 Bp = (B + 31) // 32 * 32                           # kernel-native saved state is tiled by 32 rows
@@ -142,12 +147,13 @@ class _BiLstm(torch.autograd.Function):
                     # rows get gx in the order of the recurrence kernel's accumulators (no LDS staging of the gx tile over there)
                     native = B if (GX_LANE_NATIVE and B % 64 == 0) else 0
                     gx = torch.empty((R * B, 8 * H), device=dev, dtype=T)
-                    N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), native, st), 'dic_row_proj')
+                    N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), native, int(relu_kernel), st), 'dic_row_proj')
                 else:
                     gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
                 N.check(L.dic_lstm_fwd(N.ptr(gx), int(native > 0), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
                                        N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), st), 'dic_lstm_fwd')
         ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32), bool(relu))
+        ctx.x_relu_in_kernel = relu_kernel
         ctx.x_dtype = x.dtype
         ctx.has_init = h0 is not None
         ctx.params = params
@@ -156,7 +162,9 @@ class _BiLstm(torch.autograd.Function):
         # relu: the caller consumes relu(out) only (the decoder's input, clustering_interp.py:38-41).  The raw rows stay in out_ext for the
         # weight-gradient products (the 64-row kernels write the rectified copy next to them); the backward kernel applies the ReLU
         # mask itself (sign of tanh(c_t)), so no mask pass and no saved copy
-        if relu:
+        # relu == 2 (deferred): the raw rows are handed out and the CONSUMER rectifies them on load (bilstm(input_rectify=True) of the
+        # decoder); the backward of the ReLU is applied here all the same, so the pair behaves like relu between the two LSTMs
+        if relu == 1:
             return (out_r if out_r is not None else torch.relu(out)), hn, cn
         return out, hn, cn
 
@@ -186,7 +194,7 @@ class _BiLstm(torch.autograd.Function):
                                     R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), int(relu), st), 'dic_lstm_bwd')
         dg2 = dgx.view(R * B, 8 * H)
         use_dw = narrow and R * B >= 32                              # one-pass weight-gradient kernel (csrc/dic_lstmgrad.hip; it tiles the R*B rows by 32)
-        fuse_dx = use_dw and I <= 19 and any(ctx.needs_input_grad[7:])       # ... which then also forms dX = dG.W_ih per direction
+        fuse_dx = use_dw and I <= 19 and any(ctx.needs_input_grad[8:])       # ... which then also forms dX = dG.W_ih per direction
         dxp = torch.empty((2, R * B, Ip), device=dev, dtype=T) if (fuse_dx and ctx.needs_input_grad[0]) else None
         dx = None
         if ctx.needs_input_grad[0] and dxp is None:
@@ -195,7 +203,7 @@ class _BiLstm(torch.autograd.Function):
                 dx = dx.view(R, B, Ip)                               # consumed in this layout by ops._SciCciPacked.backward
             else:
                 dx = (dx[:, :I] if Ip != I else dx).reshape(R, B, I).to(ctx.x_dtype)
-        needs = ctx.needs_input_grad[7:]
+        needs = ctx.needs_input_grad[8:]
         grads = [None] * 8
         if any(needs):
             sinks, accumulate = _grad_sinks(params, needs)
@@ -212,7 +220,7 @@ class _BiLstm(torch.autograd.Function):
             elif (not f32) and I == WIDE_INPUT and Ip == I and R * B >= 32:
                 # decoder: dW_ih and dW_hh of both directions from one pass over dG (csrc/dic_lstmgrad.hip, lstm_dw_wide_kernel)
                 ws2 = torch.empty(max(16, Lb.dic_lstm_dw_wide_workspace(R, B)), device=dev, dtype=torch.uint8)
-                N.check(Lb.dic_lstm_dw_wide(N.ptr(dgx), N.ptr(out_ext), N.ptr(xb), R, B, H, I, gp, int(accumulate), N.ptr(ws2), ws2.numel(), st),
+                N.check(Lb.dic_lstm_dw_wide(N.ptr(dgx), N.ptr(out_ext), N.ptr(xb), int(ctx.x_relu_in_kernel), R, B, H, I, gp, int(accumulate), N.ptr(ws2), ws2.numel(), st),
                         'dic_lstm_dw_wide')
                 N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             else:
@@ -228,28 +236,42 @@ class _BiLstm(torch.autograd.Function):
                 N.check(Lb.dic_lstm_unpack_grads(N.ptr(dw_ih), Ip, N.ptr(dw_hh), N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             if not accumulate:
                 grads = [g if n else None for g, n in zip(sinks, needs)]
-        return (dx, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None), None, None, None, None, *grads)
+        return (dx, (dh0 if ctx.has_init else None), (dc0 if ctx.has_init else None), None, None, None, None, None, *grads)
 
 
 def _params(lstm):
     return [getattr(lstm, n) for n in PARAM_NAMES]
 
 
-def bilstm(x, lstm, h0=None, c0=None, batch_major_state=False, rectified_out=False):
+def deferred_relu_ok(x_or_batch):
+    """The F.relu between encoder and decoder (clustering_interp.py:38-41) can be left to the decoder's kernels -- its input projection and
+    its weight-gradient kernel rectify the raw encoder output on load -- on the large-batch bf16 path: no rectified copy is written."""
+    B = x_or_batch if isinstance(x_or_batch, int) else x_or_batch.shape[1]
+    return DEFER_RELU and ROW_PROJ and RELU_IN_KERNEL and B > SMALL_BATCH and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
+def bilstm(x, lstm, h0=None, c0=None, batch_major_state=False, rectified_out=False, input_rectify=False):
     """(out (R,B,2H), (h_n, c_n) (2,B,H) f32) = bidirectional LSTM of x (R,B,I) with ``lstm``'s parameters: bf16 operands under
     autocast(bf16) (out is bf16), exact f32 otherwise (x f32, no autocast; out is f32).
     ``batch_major_state``: h0, c0, h_n, c_n are (B,2,H) instead -- h_n.view(B, 2H) is then the concatenated latent
     [h_fwd | h_rev] of clustering_interp.py:139, and feeds the next LSTM as it lies.
-    ``rectified_out``: out is relu(out) (what the decoder feeds on); the ReLU's backward is applied inside the recurrence kernel."""
+    ``rectified_out``: out is relu(out) (what the decoder feeds on); the ReLU's backward is applied inside the recurrence kernel.
+    ``rectified_out='deferred'``: out stays raw, the consumer promises to rectify it on load (``input_rectify=True`` of the next
+    bilstm) and to hand back the gradient w.r.t. relu(out); the ReLU's backward is still applied here.
+    ``input_rectify``: the LSTM runs on relu(x); x's gradient is returned WITHOUT the ReLU mask (its producer applies it: 'deferred')."""
     f32 = x.dtype == torch.float32 and not torch.is_autocast_enabled()
     with torch.autocast('cuda', enabled=False):
-        out, hn, cn = _BiLstm.apply(x, h0, c0, False, batch_major_state, f32, rectified_out, *_params(lstm))
+        out, hn, cn = _BiLstm.apply(x, h0, c0, False, batch_major_state, f32, _relu_mode(rectified_out), bool(input_rectify), *_params(lstm))
     return out, (hn, cn)
+
+
+def _relu_mode(rectified_out):
+    return 2 if rectified_out == 'deferred' else int(bool(rectified_out))
 
 
 def bilstm_packed(xenc, lstm, h0=None, c0=None, batch_major_state=False, rectified_out=False):
     """The same for an input already in the recurrence kernel's layout: xenc (R,B,32) bf16 rows [features | 1 | 0...]
     (``ops.sci_cci_packed``); its gradient comes back in that layout too."""
     with torch.autocast('cuda', enabled=False):
-        out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, batch_major_state, False, rectified_out, *_params(lstm))
+        out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, batch_major_state, False, _relu_mode(rectified_out), False, *_params(lstm))
     return out, (hn, cn)

@@ -314,7 +314,7 @@ size_t dic_lstm_dw_workspace(int R, int B);
 int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, const void* wih, void* dx_parts, int R, int B, int H, int I, int Ip,
                 float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 size_t dic_lstm_dw_wide_workspace(int R, int B);
-int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int R, int B, int H, int I, float* const* grads, int accumulate,
+int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int x_relu, int R, int B, int H, int I, float* const* grads, int accumulate,
                      void* workspace, size_t workspace_bytes, dic_stream_t stream);
 int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,
                           int accumulate, dic_stream_t stream);
@@ -324,7 +324,10 @@ int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const
  * projection gx over all N = R*B rows (nn.LSTM inside DecoderRNN, clustering_interp.py:47-59) with the weights resident in
  * registers -- the library GEMM for this K = 256 shape cannot overlap its short main loop with its epilogue. */
 int dic_row_proj(const void* x, const void* w, const void* bias, int64_t N, int in_features, int out_features, void* out, int lane_native_batch,
-                 dic_stream_t stream);
+                 int relu_input, dic_stream_t stream);
+/* relu_input != 0 (and x_relu of dic_lstm_dw_wide): x is the RAW output of the encoder LSTM and the product is taken of relu(x) -- the F.relu
+ * between encoder and decoder (clustering_interp.py:38-41) applied to the operand on its way through the kernel, so that no rectified copy of
+ * the encoder output exists in HBM. */
 /* lane_native_batch = B > 0 (Nout = 1024 = 2 directions x 4 gates x 128 units, N = R*B, B a multiple of 64): out is written in the
  * lane-native form dic_lstm_fwd(gx_lane_native = 1) reads (same bytes, same values, another order); 0: row-major (N,Nout). */
 /* The same for CompressFC's first layer Linear(256, 128) (rbf.py:111-125) in front of its training-mode BatchNorm1d: out (N,128) bf16 and

@@ -15,7 +15,7 @@ grads = [g.clone() for g in grads]
 L = N.lib()
 ws = torch.empty(L.dic_lstm_dw_wide_workspace(R, B), dtype=torch.uint8, device=dev)
 gp, st = N.ptr_array(grads), N.stream_of(dg)
-call = lambda: L.dic_lstm_dw_wide(N.ptr(dg), N.ptr(out_ext), N.ptr(x), R, B, H, I, gp, 0, N.ptr(ws), ws.numel(), st)
+call = lambda: L.dic_lstm_dw_wide(N.ptr(dg), N.ptr(out_ext), N.ptr(x), 0, R, B, H, I, gp, 0, N.ptr(ws), ws.numel(), st)
 for _ in range(3): call()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

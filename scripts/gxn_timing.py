@@ -28,7 +28,7 @@ def timed(fn, it=20):
 
 res = {}
 for native in (0, B, 0, B):
-    tp = timed(lambda: N.check(L.dic_row_proj(P(x), P(wih), P(bias), R * B, 256, 8 * H, P(gx), native, st), 'row_proj'))
+    tp = timed(lambda: N.check(L.dic_row_proj(P(x), P(wih), P(bias), R * B, 256, 8 * H, P(gx), native, 0, st), 'row_proj'))
     tf = timed(lambda: N.check(L.dic_lstm_fwd(P(gx), int(native > 0), P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st), 'lstm_fwd'))
     res[native] = out.float().abs().sum().item()
     print('%-11s row_proj %7.1f us   lstm_fwd %7.1f us   sum %7.1f' % ('lane-native' if native else 'row-major', tp, tf, tp + tf), flush=True)

@@ -442,7 +442,7 @@ def test_lstm_dw_wide_matches_matmul(R, B, init, accumulate):
     out_ext[1:R + 1] = out
     out_ext[0, :, :H] = h0[0] if init else 0.0
     out_ext[R + 1, :, H:] = h0[1] if init else 0.0
-    N.check(L.dic_lstm_dw_wide(N.ptr(dg), N.ptr(out_ext), N.ptr(x), R, B, H, I, N.ptr_array(grads), int(accumulate), N.ptr(ws), ws.numel(),
+    N.check(L.dic_lstm_dw_wide(N.ptr(dg), N.ptr(out_ext), N.ptr(x), 0, R, B, H, I, N.ptr_array(grads), int(accumulate), N.ptr(ws), ws.numel(),
                                N.stream_of(dg)), 'dic_lstm_dw_wide')
     torch.cuda.synchronize()
     d64, o64, x64 = dg.double(), out.double(), x.double()
@@ -681,7 +681,7 @@ def test_row_proj_matches_addmm(n, nout, bias):
     w = (torch.randn(nout, 256, device=dev) * 0.1).to(bf)
     b = (torch.randn(nout, device=dev) * 0.3).to(bf) if bias else None
     out = torch.full((n, nout), float('nan'), device=dev, dtype=bf)
-    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, nout, N.ptr(out), 0, N.stream_of(x)), 'dic_row_proj')
+    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, nout, N.ptr(out), 0, 0, N.stream_of(x)), 'dic_row_proj')
     want = x.double() @ w.double().t() + (b.double() if bias else 0.0)
     assert float((out.double() - want).abs().max()) <= 8e-3 * float(want.abs().max()) + 1e-3        # bf16 output
     ref = torch.addmm(b, x, w.t()) if bias else x @ w.t()
@@ -723,14 +723,14 @@ def test_row_proj_lane_native_output_is_a_reordering_of_the_row_major_one(R, B):
     b = (torch.randn(1024, device=dev) * 0.3).to(bf)
     rows = torch.full((n, 1024), float('nan'), device=dev, dtype=bf)
     nat = torch.full((n, 1024), float('nan'), device=dev, dtype=bf)
-    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(rows), 0, N.stream_of(x)), 'dic_row_proj')
-    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(nat), B, N.stream_of(x)), 'dic_row_proj')
+    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(rows), 0, 0, N.stream_of(x)), 'dic_row_proj')
+    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(nat), B, 0, N.stream_of(x)), 'dic_row_proj')
     # (t, tile, dir, wave, gate, qp, hh, row, e / 4, e % 4) -> (t, tile, row, dir, gate, wave, qp, e / 4, hh, e % 4): unit = 32 wave + 16 qp + 8 (e / 4) + 4 hh + e % 4
     back = nat.view(R, B // 32, 2, 4, 4, 2, 2, 32, 2, 4).permute(0, 1, 7, 2, 4, 3, 5, 8, 6, 9).reshape(n, 1024)
     assert not torch.isnan(back.float()).any()
     assert torch.equal(back, rows)
     with pytest.raises(RuntimeError):          # batches that do not tile by 64 rows are refused, not mangled
-        N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(nat), 96, N.stream_of(x)), 'dic_row_proj')
+        N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(nat), 96, 0, N.stream_of(x)), 'dic_row_proj')
 
 
 @pytest.mark.parametrize('R,B,init', [(24, 64, True), (7, 192, False)])
@@ -811,13 +811,13 @@ def test_decoder_projection_and_recurrence_at_bench_size():
         out = torch.empty(R, B, 2 * H, device=dev, dtype=bf)
         gates, cs = torch.empty(R, B, 2, 4, H, device=dev, dtype=bf), torch.empty(R, B, 2, H, device=dev, dtype=bf)
         hn, cn = torch.empty(2, B, H, device=dev), torch.empty(2, B, H, device=dev)
-        N.check(L.dic_row_proj(N.ptr(x), N.ptr(wih), N.ptr(bias), R * B, 256, 8 * H, N.ptr(gx), native, st), 'dic_row_proj')
+        N.check(L.dic_row_proj(N.ptr(x), N.ptr(wih), N.ptr(bias), R * B, 256, 8 * H, N.ptr(gx), native, 0, st), 'dic_row_proj')
         N.check(L.dic_lstm_fwd(N.ptr(gx), int(native > 0), N.ptr(whh), None, None, R, B, H, N.ptr(out), None, N.ptr(hn), N.ptr(cn), N.ptr(gates),
                                N.ptr(cs), 0, 0, st), 'dic_lstm_fwd')
         res[native] = (out, hn, cn, gates, cs)
         if not native:
             g0 = torch.empty_like(gx)
-            N.check(L.dic_row_proj(N.ptr(x), N.ptr(wih), None, R * B, 256, 8 * H, N.ptr(g0), 0, st), 'dic_row_proj')
+            N.check(L.dic_row_proj(N.ptr(x), N.ptr(wih), None, R * B, 256, 8 * H, N.ptr(g0), 0, 0, st), 'dic_row_proj')
             d = (gx[::97].float() - g0[::97].float()) - bias.float()
             assert float(d.abs().max()) <= 2.0 ** -7 * float(gx[::97].float().abs().max())      # two bf16 roundings
             del g0
@@ -825,3 +825,79 @@ def test_decoder_projection_and_recurrence_at_bench_size():
     for a, b in zip(res[0], res[B]):
         assert torch.equal(a, b)
     assert torch.isfinite(res[0][0].float()).all() and float(res[0][0].float().abs().mean()) > 0.01
+
+
+@pytest.mark.parametrize('native', [False, True])
+def test_row_proj_rectifies_its_input_on_load(native):
+    """relu_input: the product of relu(x), x raw (negative halves zeroed by an int16 max on the packed bf16 pairs) == the product of a
+    rectified copy of x, bit for bit."""
+    from deep_interpolation_clustering_amd import _native as N
+    torch.manual_seed(11)
+    dev, bf = torch.device('cuda'), torch.bfloat16
+    R, B = 6, 128
+    n = R * B
+    x = (torch.randn(n, 256, device=dev) * 0.5).to(bf)
+    x[5, :8] = torch.tensor([-0.0, 0.0, -3e38, 3e38, -1e-38, 1e-38, -3.0, 3.0], device=dev).to(bf)       # signed zeros, extremes, subnormals
+    w = (torch.randn(1024, 256, device=dev) * 0.1).to(bf)
+    w[:, 2:4] = 0                                   # (keep the two huge values out of the sums)
+    b = (torch.randn(1024, device=dev) * 0.3).to(bf)
+    a, c = torch.empty(n, 1024, device=dev, dtype=bf), torch.empty(n, 1024, device=dev, dtype=bf)
+    lane = B if native else 0
+    N.check(N.lib().dic_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(a), lane, 1, N.stream_of(x)), 'dic_row_proj')
+    xr = torch.relu(x)
+    N.check(N.lib().dic_row_proj(N.ptr(xr), N.ptr(w), N.ptr(b), n, 256, 1024, N.ptr(c), lane, 0, N.stream_of(x)), 'dic_row_proj')
+    assert torch.equal(a, c)
+    assert float((x < 0).float().mean()) > 0.4
+
+
+def test_lstm_dw_wide_rectifies_x_on_load():
+    """x_relu: dW_ih = dG^T relu(x) from the raw x == from a rectified copy (the h columns of the same operand stay untouched)."""
+    from deep_interpolation_clustering_amd import _native as N
+    torch.manual_seed(12)
+    dev, bf = torch.device('cuda'), torch.bfloat16
+    R, B, I = 5, 96, 256
+    L = N.lib()
+    dg = (torch.randn(R, B, 2, 4, H, device=dev) * 0.1).to(bf)
+    out_ext = (torch.randn(R + 2, B, 2 * H, device=dev) * 0.5).to(bf)          # (h has negative entries: they must survive)
+    x = (torch.randn(R, B, I, device=dev) * 0.5).to(bf)
+    ws = torch.empty(max(16, L.dic_lstm_dw_wide_workspace(R, B)), dtype=torch.uint8, device=dev)
+    res = []
+    for xin, flag in ((x, 1), (torch.relu(x), 0)):
+        grads = [torch.zeros(4 * H, I, device=dev), torch.zeros(4 * H, H, device=dev), torch.zeros(4 * H, device=dev), torch.zeros(4 * H, device=dev)]
+        grads = grads + [g.clone() for g in grads]
+        N.check(L.dic_lstm_dw_wide(N.ptr(dg), N.ptr(out_ext), N.ptr(xin), flag, R, B, H, I, N.ptr_array(grads), 0, N.ptr(ws), ws.numel(),
+                                   N.stream_of(dg)), 'dic_lstm_dw_wide')
+        res.append([g.clone() for g in grads])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][0].abs().max()) > 0 and float(res[0][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize('B', [128, 200])
+def test_relu_between_the_lstms_left_to_the_decoder_kernels(B, monkeypatch):
+    """Encoder -> F.relu -> decoder (clustering_interp.py:38-41) on the 64-row kernels, two ways: the encoder writes a rectified copy of
+    its output (rectified_out=True) / the encoder hands out the raw rows and the decoder's projection and weight-gradient kernels rectify
+    them on load (rectified_out='deferred' + input_rectify=True).  Same numbers everywhere: outputs and all gradients bit-equal."""
+    from deep_interpolation_clustering_amd import lstm as L
+    monkeypatch.setattr(L, 'SMALL_BATCH', 0)
+    torch.manual_seed(B)
+    dev = torch.device('cuda')
+    R = 6
+    enc = torch.nn.LSTM(18, H, num_layers=1, bidirectional=True).to(dev)
+    dec = torch.nn.LSTM(2 * H, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, 18, device=dev)
+    go = torch.randn(R, B, 2 * H, device=dev)
+    res = {}
+    for defer in (False, True):
+        enc.zero_grad(); dec.zero_grad()
+        xi = x.clone().requires_grad_()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            assert L.deferred_relu_ok(B)
+            ctxt, (hn, cn) = L.bilstm(xi, enc, batch_major_state=True, rectified_out='deferred' if defer else True)
+            assert bool((ctxt < 0).any()) == defer              # raw rows when deferred
+            y, (h2, c2) = L.bilstm(ctxt, dec, hn, cn, batch_major_state=True, input_rectify=defer)
+        ((y.float() * go).sum() + h2.sum()).backward()
+        res[defer] = dict(y=y.detach().float(), h2=h2.detach(), dx=xi.grad.clone(), **{'e.' + k: p.grad.clone() for k, p in enc.named_parameters()},
+                          **{'d.' + k: p.grad.clone() for k, p in dec.named_parameters()})
+    for k in res[False]:
+        assert torch.equal(res[False][k], res[True][k]), k
