@@ -166,11 +166,10 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
     calls['lstm_fwd'] = (lambda: L.dic_lstm_fwd(P(gxl), int(B % 64 == 0), P(whh), None, None, R, B, Hh, P(lout), None, P(lhn), P(lcn), P(lgates), P(lcs), 0, 0, st),
                          rows * (4 * Hh * 2 + Hh * 2 + 4 * Hh * 2 + Hh * 2))      # gx in; h, gates, c (bf16 copy) out
     xenc = (torch.randn((R, B, 32), **f32)).to(bf)
-    lout_r = torch.empty_like(lout)            # the encoder also writes the rectified copy the decoder reads
     wih = (torch.randn((2, 4 * Hh, 32), **f32) * 0.1).to(bf)
-    calls['lstm_fwd_proj'] = (lambda: L.dic_lstm_fwd_proj(P(xenc), P(wih), P(whh), None, None, R, B, Hh, 32, P(lout), P(lout_r), P(lhn), P(lcn),
+    calls['lstm_fwd_proj'] = (lambda: L.dic_lstm_fwd_proj(P(xenc), P(wih), P(whh), None, None, R, B, Hh, 32, P(lout), None, P(lhn), P(lcn),
                                                           P(lgates), P(lcs), 0, 0, st),
-                              R * B * 32 * 2 + rows * (2 * Hh * 2 + 4 * Hh * 2 + Hh * 2))   # x in; h, relu(h), gates, c out (encoder: no gx)
+                              R * B * 32 * 2 + rows * (Hh * 2 + 4 * Hh * 2 + Hh * 2))   # x in; h, gates, c out (encoder: no gx; the decoder rectifies h on load)
     ldb = torch.empty((2, 4 * Hh), **f32)
     ws6 = torch.empty(max(16, L.dic_lstm_bwd_workspace(B)), dtype=torch.uint8, device=dev)
     calls['lstm_bwd'] = (lambda: L.dic_lstm_bwd(P(whh_t), P(lgates), P(lcs), None, P(ldout), None, None, R, B, Hh, P(ldgx), P(ldh0),
