@@ -66,6 +66,22 @@ static int norm_blocks(long n) { return (int)max(1L, min((n + 1023) / 1024, (lon
 
 using namespace dic;
 
+// dst[j][0..n[j]) += src[j][0..n[j]) for up to 16 small tensors in ONE launch: the parameter gradients the hot-path kernels deliver as
+// separate little tensors (interpolation / RBF bandwidths, cross-channel matrix, centroids, CompressFC's six) go into their slots of the
+// flat gradient bucket this way instead of one 5-us AccumulateGrad add each (pretrain_trainer.py:223-231: backward, then the optimizer).
+constexpr int kAccumMax = 16;
+struct AccumMany {
+    const float* src[kAccumMax];
+    float* dst[kAccumMax];
+    int n[kAccumMax];
+};
+__global__ __launch_bounds__(256) void accumulate_many_kernel(AccumMany a) {
+    const int j = blockIdx.x;
+    const float* s = a.src[j];
+    float* d = a.dst[j];
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < a.n[j]; i += gridDim.y * 256) d[i] += s[i];
+}
+
 extern "C" {
 
 int dic_adam_amsgrad_step(float* p, float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1, float beta2,
@@ -90,6 +106,23 @@ int dic_grad_norm_clip(const float* g, int64_t n, float max_norm, float* out2, v
     hipLaunchKernelGGL(grad_sqsum_kernel, dim3(nblk), dim3(256), 0, st, g, (long)n, (double*)workspace);
     hipLaunchKernelGGL(grad_norm_finalize, dim3(1), dim3(256), 0, st, (const double*)workspace, nblk, max_norm, out2);
     return check_launch("grad_norm_clip");
+}
+
+int dic_accumulate_many(const float* const* src, float* const* dst, const int* n, int count, dic_stream_t stream) {
+    DIC_REQUIRE(count >= 0, DIC_ERR_INVALID_ARG, "accumulate_many: negative count");
+    DIC_REQUIRE(count == 0 || (src && dst && n), DIC_ERR_INVALID_ARG, "accumulate_many: NULL pointer");
+    for (int base = 0; base < count; base += kAccumMax) {
+        AccumMany a{};
+        const int m = min(kAccumMax, count - base);
+        int nmax = 0;
+        for (int j = 0; j < m; ++j) {
+            DIC_REQUIRE(src[base + j] && dst[base + j] && n[base + j] > 0, DIC_ERR_INVALID_ARG, "accumulate_many: entry %d is empty", base + j);
+            a.src[j] = src[base + j]; a.dst[j] = dst[base + j]; a.n[j] = n[base + j];
+            nmax = max(nmax, n[base + j]);
+        }
+        hipLaunchKernelGGL(accumulate_many_kernel, dim3(m, max(1, min(64, (nmax + 2047) / 2048))), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return check_launch("accumulate_many");
 }
 
 }  // extern "C"

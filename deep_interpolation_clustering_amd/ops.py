@@ -46,6 +46,54 @@ def ref_grid(hours, ref_points, device):
 
 
 # ----------------------------------------------------------------------------------------- k1
+# ------------------------------------------------------------------------------------------ small parameter gradients
+# Inside step.Stepper's backward (grad_sink_session) the small parameter gradients these Functions produce -- bandwidths, the cross-channel
+# matrix, centroids, CompressFC's six -- are not returned to autograd (one AccumulateGrad add launch each, ~5 us a piece) but queued and
+# added into the parameters' slots of the flat gradient bucket by ONE dic_accumulate_many launch when the session ends (or when the
+# sharded step starts the early all-reduce of the decoder-side gradients).
+_SINK = {'on': False, 'pairs': []}
+GRAD_SINKS = os.environ.get('DIC_GRAD_SINKS', '1') != '0'
+
+
+def _sink(param, grad):
+    """Inside a session: queue ``grad`` for ``param.grad`` and tell autograd nothing (None); else hand ``grad`` back unchanged."""
+    if grad is None or not (_SINK['on'] and GRAD_SINKS):
+        return grad
+    g = getattr(param, 'grad', None)
+    if (g is None or not param.is_leaf or g.dtype != torch.float32 or grad.dtype != torch.float32 or not g.is_contiguous()
+            or g.device != grad.device or g.numel() != grad.numel() or not grad.is_cuda):
+        return grad
+    _SINK['pairs'].append((grad if grad.is_contiguous() else grad.contiguous(), g))
+    param._dic_grad_written = True          # dist.FlatParams.active_mask: autograd's accumulate hook will not fire for this one
+    return None
+
+
+def flush_grad_sinks():
+    pairs, _SINK['pairs'] = _SINK['pairs'], []
+    if not pairs:
+        return
+    import ctypes as C
+    n = (C.c_int * len(pairs))(*[p[0].numel() for p in pairs])
+    src, dst = N.ptr_array([p[0] for p in pairs]), N.ptr_array([p[1] for p in pairs])
+    N.check(N.lib().dic_accumulate_many(src, dst, n, len(pairs), N.stream_of(pairs[0][1])), 'dic_accumulate_many')
+
+
+class grad_sink_session:
+    """``with grad_sink_session(): loss.backward()`` -- see _sink."""
+
+    def __enter__(self):
+        _SINK['on'], _SINK['pairs'] = True, []
+        return self
+
+    def __exit__(self, *exc):
+        _SINK['on'] = False
+        if exc[0] is None:
+            flush_grad_sinks()
+        else:
+            _SINK['pairs'] = []
+        return False
+
+
 class _SciCci(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sci_kernel, cci_kernel, grid, lengths):
@@ -120,6 +168,7 @@ class _SciCciPacked(torch.autograd.Function):
         N.check(N.lib().dic_sci_cci_fwd_packed(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), None,
                                                N.ptr(saved), N.ptr(xenc), PACKED_WIDTH, N.stream_of(x)), 'dic_sci_cci_fwd_packed')
         ctx.dims = (B, C, R)
+        ctx.sink_params = (sci_kernel, cci_kernel)
         ctx.save_for_backward(saved, sk, ck)
         return xenc
 
@@ -135,7 +184,7 @@ class _SciCciPacked(torch.autograd.Function):
         ws = _ws(L.dic_sci_cci_bwd_workspace(B, C, R), g.device)
         N.check(L.dic_sci_cci_bwd_packed(N.ptr(g), PACKED_WIDTH, N.ptr(saved), N.ptr(sk), N.ptr(ck), B, C, R, N.ptr(gs), N.ptr(gc),
                                          N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_sci_cci_bwd_packed')
-        return None, gs, gc, None, None
+        return None, _sink(ctx.sink_params[0], gs), _sink(ctx.sink_params[1], gc), None, None
 
 
 def sci_cci_packed(x, sci_kernel, cci_kernel, grid, lengths=None):
@@ -249,6 +298,7 @@ class _RbfRecLoss(torch.autograd.Function):
                                    N.ptr(norm), 1, N.ptr(out2), N.ptr(ws), ws.numel(), N.stream_of(x)), 'dic_rbf_fwd_loss')
         dist.all_reduce_sum_(out2)          # global SSE and global #valid slots
         ctx.dims = (B, C, T, R, bool(tm))
+        ctx.sink_params = (rbf_kernel,)
         ctx.save_for_backward(x, lengths, grid, rk, vb, y, norm, obc, out2)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(y)
@@ -268,7 +318,7 @@ class _RbfRecLoss(torch.autograd.Function):
         N.check(L.dic_rbf_bwd_loss(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y), N.ptr(norm),
                                    N.ptr(obc), N.ptr(out2), N.ptr(gl), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(x)),
                 'dic_rbf_bwd_loss')
-        return (gv.permute(1, 2, 0) if tm else gv), None, gk, None, None, None
+        return (gv.permute(1, 2, 0) if tm else gv), None, _sink(ctx.sink_params[0], gk), None, None, None
 
 
 def rbf_rec_loss(v, raw_input, rbf_kernel, grid, lengths, ob):
@@ -334,6 +384,7 @@ class _DecAssign(torch.autograd.Function):
         N.check(L.dic_dec_fwd(N.ptr(z), N.ptr(mu), B, D, K, float(alpha), N.ptr(q), N.ptr(ts), N.ptr(colsum), N.ptr(ws),
                               ws.numel(), N.stream_of(z)), 'dic_dec_fwd')
         ctx.dims = (B, D, K, float(alpha))
+        ctx.sink_params = (centers,)
         ctx.save_for_backward(z, mu, q, ts)
         if want_colsum:
             ctx.mark_non_differentiable(colsum)
@@ -351,7 +402,7 @@ class _DecAssign(torch.autograd.Function):
         ws = _ws(L.dic_dec_bwd_workspace(B, D, K), g.device)
         N.check(L.dic_dec_bwd(N.ptr(z), N.ptr(mu), N.ptr(q), N.ptr(ts), N.ptr(g), B, D, K, alpha, N.ptr(gz), N.ptr(gc),
                               N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_dec_bwd')
-        return gz, gc, None, None
+        return gz, _sink(ctx.sink_params[0], gc), None, None
 
 
 def dec_soft_assign(z, centers, alpha=1.0, return_colsum=False):
@@ -652,6 +703,7 @@ class _CompressFC(torch.autograd.Function):
                 'dic_bnhead_fwd')
         ctx.save_for_backward(xb, wb, z, mean, rstd, g, bt, w2f, cnt, rng)
         ctx.x_dtype, ctx.drop_p = x.dtype, float(drop_p)
+        ctx.sink_params = (w1, b1, gamma, beta, w2, b2)
         return v
 
     @staticmethod
@@ -677,8 +729,12 @@ class _CompressFC(torch.autograd.Function):
                                     c, 1, ctx.drop_p, N.ptr(rng), N.ptr(xb), N.ptr(wb), n, wb.shape[1], k, N.ptr(dxb), N.ptr(dw1), N.ptr(ws2), ws2.numel(), st),
                 'dic_fc_bwd_bnhead')
         # (the bias of the first layer sits in front of a training-mode BatchNorm: its gradient is identically 0)
-        db1 = torch.zeros(k, device=dev, dtype=torch.float32)
-        return (None if dxb is None else dxb.to(ctx.x_dtype)), dw1, db1, dgamma, dbeta, dw2, db2, None, None, None, None, None, None
+        sp = ctx.sink_params
+        db1 = None if (_SINK['on'] and GRAD_SINKS and getattr(sp[1], 'grad', None) is not None) else torch.zeros(k, device=dev, dtype=torch.float32)
+        if db1 is None:
+            sp[1]._dic_grad_written = True          # (adding zeros: nothing to queue)
+        return ((None if dxb is None else dxb.to(ctx.x_dtype)), _sink(sp[0], dw1), db1, _sink(sp[2], dgamma), _sink(sp[3], dbeta),
+                _sink(sp[4], dw2), _sink(sp[5], db2), None, None, None, None, None, None)
 
 
 def compress_fc_fused_ok(x, first, bn, last):

@@ -9,7 +9,7 @@ import contextlib
 
 import torch
 
-from . import dist
+from . import dist, ops
 
 LOSS_NAMES = ('ae_mse', 'ae_mse_sup', 'ae_mse_fake_detect', 'ae_mse_fake_detect_triplet', 'ae_mse_sup_fake_detect',
               'ae_mse_kl', 'ae_mse_fake_detect_kl', 'ae_mse_sup_kl', 'ae_mse_sup_fake_detect_kl')
@@ -155,7 +155,8 @@ class Stepper:
         self.model.rec_target = ob if (padding_mask is None and lengths is not None and ob.is_cuda) else None
         try:
             losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
-            losses['loss'].backward()
+            with ops.grad_sink_session():            # the small parameter gradients: one add launch for all of them at the end
+                losses['loss'].backward()
         finally:
             self.model.internal_step = False
             self.model.rec_target = None

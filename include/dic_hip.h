@@ -422,6 +422,10 @@ int dic_adam_amsgrad_step(float* p, float* g, float* m, float* v, float* vmax, i
  * out2[1] = min(1, max_norm / (||g||_2 + 1e-6)) -- the `grad_scale` of dic_adam_amsgrad_step.  Deterministic two-stage sum. */
 size_t dic_grad_norm_workspace(int64_t n);
 int dic_grad_norm_clip(const float* g, int64_t n, float max_norm, float* out2, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* dst[j][0..n[j]) += src[j][0..n[j]) for j < count (host arrays of device pointers / sizes) in one launch per 16 entries: the small
+ * parameter gradients of the hot-path kernels added into their slots of the flat gradient bucket (what autograd's AccumulateGrad does
+ * with one launch each between loss.backward() and the optimizer, pretrain_trainer.py:223-231). */
+int dic_accumulate_many(const float* const* src, float* const* dst, const int* n, int count, dic_stream_t stream);
 
 #ifdef __cplusplus
 }
