@@ -128,8 +128,15 @@ __global__ __launch_bounds__(NW * 64, 2) void row_proj_kernel(RowProjArgs a) {
             pbf16x8 lo, hi;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { lo[e] = (__bf16)acc[e]; hi[e] = (__bf16)acc[8 + e]; }
+#ifndef DIC_RP_PLAIN_STORES   // streaming (nontemporal) stores for gx, which only another kernel reads back: they do not push the x tiles the four
+            // stripes of a chunk share out of the XCD's L2 (same-box A/B: 477 -> 454 us)
+            typedef int pi32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(__builtin_bit_cast(pi32x4, lo), reinterpret_cast<pi32x4*>(a.out + o * 8));
+            __builtin_nontemporal_store(__builtin_bit_cast(pi32x4, hi), reinterpret_cast<pi32x4*>(a.out + (o + 2 * 32) * 8));
+#else
             *reinterpret_cast<pbf16x8*>(a.out + o * 8) = lo;
             *reinterpret_cast<pbf16x8*>(a.out + (o + 2 * 32) * 8) = hi;
+#endif
             __syncthreads();
             slot ^= 1;
             continue;

@@ -3,6 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 from deep_interpolation_clustering_amd import _native as N
+if os.environ.get('DIC_AB_LIB'):
+    N.LIB_PATH = os.path.abspath(os.environ['DIC_AB_LIB'])
 L = N.lib()
 R, B, H = 24, int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 128
 dev, bf = torch.device('cuda'), torch.bfloat16
