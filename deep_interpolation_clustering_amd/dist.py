@@ -178,7 +178,9 @@ class FlatParams:
         """Start the asynchronous all-reduce of grad[split:] -- only if every parameter of that piece has its gradient already."""
         if not is_sharded() or self._split is None or self._tail_work is not None:
             return
-        from . import ops
+        from . import lstm, ops
+        if lstm.side_work_pending():    # the decoder's weight gradients are still being formed on the side stream: one all-reduce at the end instead
+            return
         ops.flush_grad_sinks()          # gradients queued by the decoder-side kernels go into the bucket before its tail leaves
         done = all(r or getattr(p, '_dic_grad_written', False) for r, p in zip(self._reached[self._split_index:], self.params[self._split_index:]))
         if done and self._split < self.grad.numel():

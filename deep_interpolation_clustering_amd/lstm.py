@@ -60,6 +60,40 @@ def f32_available(x, lstm):
             and all(p.dtype == torch.float32 for p in lstm.parameters()))
 
 
+# The decoder's weight-gradient kernel (MFMA-bound) has no consumer before the optimizer: inside step.Stepper's backward it runs on a
+# side stream next to the bandwidth-bound encoder backward that follows on the main stream (side_stream_session joins at the end).
+DW_SIDE_STREAM = os.environ.get('DIC_DW_SIDE_STREAM', '1') != '0'
+_SIDE = {'on': False, 'streams': {}, 'pending': []}
+
+
+class side_stream_session:
+    def __enter__(self):
+        _SIDE['on'], _SIDE['pending'] = True, []
+        return self
+
+    def __exit__(self, *exc):
+        _SIDE['on'] = False
+        join_side_streams()
+        return False
+
+
+def side_work_pending():
+    return bool(_SIDE['pending'])
+
+
+def join_side_streams():
+    pending, _SIDE['pending'] = _SIDE['pending'], []
+    for s in pending:
+        torch.cuda.current_stream(s.device).wait_stream(s)
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE['streams']:
+        _SIDE['streams'][key] = torch.cuda.Stream(device=dev)
+    return _SIDE['streams'][key]
+
+
 def _grad_sinks(params, needs):
     """The tensors the kernels write the parameter gradients into, and whether they ACCUMULATE there.
     When every parameter already owns a dense f32 ``.grad`` (the views of the flat bucket, zeroed at the start of the step) the
@@ -219,10 +253,21 @@ class _BiLstm(torch.autograd.Function):
                 N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             elif (not f32) and I == WIDE_INPUT and Ip == I and R * B >= 32:
                 # decoder: dW_ih and dW_hh of both directions from one pass over dG (csrc/dic_lstmgrad.hip, lstm_dw_wide_kernel)
-                ws2 = torch.empty(max(16, Lb.dic_lstm_dw_wide_workspace(R, B)), device=dev, dtype=torch.uint8)
-                N.check(Lb.dic_lstm_dw_wide(N.ptr(dgx), N.ptr(out_ext), N.ptr(xb), int(ctx.x_relu_in_kernel), R, B, H, I, gp, int(accumulate), N.ptr(ws2), ws2.numel(), st),
-                        'dic_lstm_dw_wide')
-                N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
+                def weight_grads(stream):
+                    ws2 = torch.empty(max(16, Lb.dic_lstm_dw_wide_workspace(R, B)), device=dev, dtype=torch.uint8)
+                    N.check(Lb.dic_lstm_dw_wide(N.ptr(dgx), N.ptr(out_ext), N.ptr(xb), int(ctx.x_relu_in_kernel), R, B, H, I, gp, int(accumulate), N.ptr(ws2),
+                                                ws2.numel(), stream), 'dic_lstm_dw_wide')
+                    N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), stream), 'dic_lstm_unpack_grads')
+                if _SIDE['on'] and DW_SIDE_STREAM and accumulate and not torch.cuda.is_current_stream_capturing():
+                    side = _side_stream(dev)
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        weight_grads(N.stream_of(dgx))
+                    for t_ in (dgx, out_ext, xb, dbias):
+                        t_.record_stream(side)                       # (allocated on the main stream, still read over there)
+                    _SIDE['pending'].append(side)
+                else:
+                    weight_grads(st)
             else:
                 # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split-K bmm (ops.splitk_tn).
                 # dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d], h_prev = h_{t-1} (forward) / h_{t+1} (reverse): row-shifted views of the

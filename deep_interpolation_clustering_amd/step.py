@@ -10,6 +10,7 @@ import contextlib
 import torch
 
 from . import dist, ops
+from . import lstm as fused_lstm
 
 LOSS_NAMES = ('ae_mse', 'ae_mse_sup', 'ae_mse_fake_detect', 'ae_mse_fake_detect_triplet', 'ae_mse_sup_fake_detect',
               'ae_mse_kl', 'ae_mse_fake_detect_kl', 'ae_mse_sup_kl', 'ae_mse_sup_fake_detect_kl')
@@ -155,7 +156,8 @@ class Stepper:
         self.model.rec_target = ob if (padding_mask is None and lengths is not None and ob.is_cuda) else None
         try:
             losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
-            with ops.grad_sink_session():            # the small parameter gradients: one add launch for all of them at the end
+            # the small parameter gradients: one add launch for all of them at the end; the decoder's weight-gradient kernel on a side stream
+            with ops.grad_sink_session(), fused_lstm.side_stream_session():
                 losses['loss'].backward()
         finally:
             self.model.internal_step = False

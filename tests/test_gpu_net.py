@@ -310,3 +310,36 @@ def test_bf16_step_tracks_f32_step_at_odd_batch_sizes(B):
         assert np.isfinite(a) and abs(a - b) <= 2e-2 * abs(b) + 1e-3, (traj['bf16'], traj['f32'])
     if B > 1:
         assert traj['f32'][2] < traj['f32'][0] and traj['bf16'][2] < traj['bf16'][0]
+
+
+def test_side_stream_weight_gradients_leave_the_trajectory_unchanged(monkeypatch):
+    """The decoder's weight-gradient kernel on a side stream (lstm.side_stream_session inside Stepper's backward) against the same step
+    with everything on one stream: the same kernels on the same data -- identical losses, gradient norms and parameters."""
+    from deep_interpolation_clustering_amd import lstm as L
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=4, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    monkeypatch.setattr(L, 'SMALL_BATCH', 0)                 # the 64-row kernels and the one-pass weight-gradient kernels at a test-sized batch
+    coh = synthetic.make_cohort(512, seed=9)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    res = {}
+    for side in (False, True):
+        monkeypatch.setattr(L, 'DW_SIDE_STREAM', side)
+        torch.manual_seed(4)
+        net = Net(args, dev).to(dev)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16)
+        out = []
+        for i in range(4):
+            losses, gnorm, _ = st.step(X, OB, None, LEN)
+            out.append([float(losses['loss'].detach()), float(gnorm)])
+        torch.cuda.synchronize()
+        res[side] = (np.array(out), st.flat.flat.detach().clone())
+    np.testing.assert_array_equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
