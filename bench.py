@@ -648,7 +648,11 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': table[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': table[dom]['frac_hbm_peak'], 'traffic': traffic, 'traffic_source': traffic_src,
                          'ms_per_launch': table[dom]['ms'], 'ms_per_step': round(per_step[dom], 4),
-                         'chosen_by': 'launches per step (trace of the timed step) x HIP-event duration'},
+                         'chosen_by': 'launches per step (trace of the timed step) x HIP-event duration',
+                         'note': 'ms_per_launch is the stand-alone duration (HIP events around back-to-back launches on one stream).  Inside the step the '
+                                 'encoder-side launch of this kernel shares the chip with lstm_dw_wide on a side stream (DIC_DW_SIDE_STREAM=0 turns that '
+                                 'off): a rocprofv3 average over the whole bench command mixes both; its Min column and '
+                                 'profiles/*single_stream_kernel_stats.csv are the stand-alone figure'},
             'kernels': table,
             'whole_step': {'gflop_per_step_dense(lstm+fc, fwd+bwd)': round(gflop, 1), 'tflops': round(gflop / ms, 1),
                            'frac_bf16_mfma_peak(2500 TF)': round(gflop / ms / 2500.0, 4),

@@ -11,6 +11,12 @@ cd /tmp && export TMPDIR=/tmp
 # 1. kernel statistics of the bench command itself
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 cp /tmp/p_stats/b_kernel_stats.csv $OUT/bench_kernel_stats.csv
+# 1b. the same with the decoder's weight-gradient kernel on the main stream (DIC_DW_SIDE_STREAM=0): no two kernels share the chip, so
+#     every average is a stand-alone duration (in the default run the encoder's lstm_bwd launches of the step overlap with lstm_dw_wide)
+export DIC_DW_SIDE_STREAM=0
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats1 -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/bench_single_stream_under_rocprof.json 2> /dev/null
+unset DIC_DW_SIDE_STREAM
+cp /tmp/p_stats1/b_kernel_stats.csv $OUT/bench_single_stream_kernel_stats.csv
 echo "[profile] kernel stats done"
 # 2. HBM traffic per kernel (micro table at the bench batch)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_fetch -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
