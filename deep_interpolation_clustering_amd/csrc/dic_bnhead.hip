@@ -99,11 +99,22 @@ __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const 
     for (int j = 0; j < C; ++j)
         if (kc == j) bias = b[j];
     const long stride = (long)gridDim.x * 16;
-    for (long row0 = ((long)blockIdx.x * 4 + wave) * 4; row0 < N; row0 += stride) {       // wave-uniform trip count
+    // sum over the 16 lanes of a row on the vector ALU (DPP row rotations + quad permutes): every lane ends up with the total
+    auto row_sum = [](float a) {
+        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xF, 0xF, false));     // row_ror:8
+        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x124, 0xF, 0xF, false));     // row_ror:4
+        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+        return a;
+    };
+    long row0 = ((long)blockIdx.x * 4 + wave) * 4;
+    bf16x8 xn = {};
+    if (row0 + slot < N) xn = *reinterpret_cast<const bf16x8*>(z + (row0 + slot) * BK + kc * 8);
+    for (; row0 < N; row0 += stride) {       // wave-uniform trip count; the next row is in flight while this one is reduced
         const long row = row0 + slot;
         const bool live = row < N;
-        bf16x8 x = {};
-        if (live) x = *reinterpret_cast<const bf16x8*>(z + row * BK + kc * 8);
+        const bf16x8 x = xn;
+        if (row + stride < N) xn = *reinterpret_cast<const bf16x8*>(z + (row + stride) * BK + kc * 8);
         float acc[C], keep[8];
         drop_factors(drop, row, kc, keep);
 #pragma unroll
@@ -117,11 +128,7 @@ __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const 
         float out = 0.f;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            float a = acc[j];
-            a += __shfl_xor(a, 1);
-            a += __shfl_xor(a, 2);
-            a += __shfl_xor(a, 4);
-            a += __shfl_xor(a, 8);
+            const float a = row_sum(acc[j]);
             if (kc == j) out = a;
         }
         if (live && kc < C) v[row * C + kc] = out + bias;
