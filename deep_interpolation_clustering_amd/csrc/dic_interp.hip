@@ -253,11 +253,18 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
         const float2* p = obs + row * stride + s;
         const float ref = refg[r];
         const float al = alpha[c];
-        // wave-uniform trip count: the longest row any lane of this wave works on
-        int nw = live ? cnt[row] : 0;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) nw = max(nw, __shfl_xor(nw, m));
-        nw = __builtin_amdgcn_readfirstlane(nw);
+        // wave-uniform trip count: the longest row any lane of this wave works on.  The wave's 64 items are consecutive, i.e. a
+        // range of (row, grid point) pairs that spans a handful of rows: scalar loop over those rows' lengths (uniform LDS reads)
+        // instead of a 6-step cross-lane max
+        int nw = 0;
+        {
+            const int wbase = __builtin_amdgcn_readfirstlane(base + (tid & ~(kWave - 1)));
+            if (wbase < nitems) {
+                const int row_lo = (wbase >> LOGS) / R, row_hi = (min(wbase + kWave - 1, nitems - 1) >> LOGS) / R;
+                for (int rw = row_lo; rw <= row_hi; ++rw) nw = max(nw, cnt[rw]);
+            }
+            nw = __builtin_amdgcn_readfirstlane(nw);
+        }
 #ifdef DIC_K1_EXP_NOLOOP         // experiment (scripts/k1_experiments.sh): everything except the two streaming passes
         const int nj = 0;
 #else
