@@ -73,9 +73,19 @@ def flush_grad_sinks():
     if not pairs:
         return
     import ctypes as C
-    n = (C.c_int * len(pairs))(*[p[0].numel() for p in pairs])
-    src, dst = N.ptr_array([p[0] for p in pairs]), N.ptr_array([p[1] for p in pairs])
-    N.check(N.lib().dic_accumulate_many(src, dst, n, len(pairs), N.stream_of(pairs[0][1])), 'dic_accumulate_many')
+    # a parameter used by several nodes (the interpolation bandwidths: real, corrupted and positive branch) is queued once per node:
+    # one launch per occurrence rank, so that no two workgroups of a launch add into the same destination (and the order is fixed)
+    rounds, seen = [], {}
+    for src, dst in pairs:
+        k = seen.get(dst.data_ptr(), 0)
+        seen[dst.data_ptr()] = k + 1
+        if k == len(rounds):
+            rounds.append([])
+        rounds[k].append((src, dst))
+    for rnd in rounds:
+        n = (C.c_int * len(rnd))(*[p[0].numel() for p in rnd])
+        src, dst = N.ptr_array([p[0] for p in rnd]), N.ptr_array([p[1] for p in rnd])
+        N.check(N.lib().dic_accumulate_many(src, dst, n, len(rnd), N.stream_of(rnd[0][1])), 'dic_accumulate_many')
 
 
 class grad_sink_session:

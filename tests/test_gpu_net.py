@@ -343,3 +343,43 @@ def test_side_stream_weight_gradients_leave_the_trajectory_unchanged(monkeypatch
         res[side] = (np.array(out), st.flat.flat.detach().clone())
     np.testing.assert_array_equal(res[True][0], res[False][0])
     assert torch.equal(res[True][1], res[False][1])
+
+
+@pytest.mark.parametrize('loss,fake', [('ae_mse_kl', False), ('ae_mse_fake_detect_kl', True)])
+def test_queued_small_gradients_equal_autograd_accumulation(loss, fake, monkeypatch):
+    """ops.grad_sink_session (one dic_accumulate_many launch for the small parameter gradients of the k1 / k2 / DEC / CompressFC nodes)
+    against autograd's own AccumulateGrad path: adding into the zeroed bucket is exact, so losses, norms and parameters are identical --
+    also with the fake-detection branch, whose second interpolation pass adds a second gradient to the same bandwidth parameters."""
+    from deep_interpolation_clustering_amd import ops, synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=fake, triple_margin=0.0, cluster_number=4, loss=loss, grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    B = 384
+    coh = synthetic.make_cohort(B, seed=10)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    FX = X.clone()
+    FX[:, :6] = torch.where(X[:, 6:12] > 0, X[:, :6].flip(0), X[:, :6])
+    kw = {}
+    if fake:
+        kw = dict(fake_x=FX, fake_perm_idx=torch.arange(2 * B, device=dev),
+                  fake_det_label=torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)]).to(torch.int64))
+    res = {}
+    for sinks in (False, True):
+        monkeypatch.setattr(ops, 'GRAD_SINKS', sinks)
+        torch.manual_seed(4)
+        net = Net(args, dev).to(dev)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16)
+        out = []
+        for i in range(3):
+            losses, gnorm, _ = st.step(X, OB, None, LEN, **kw)
+            out.append([float(losses['loss'].detach()), float(gnorm)])
+        res[sinks] = (np.array(out), st.flat.flat.detach().clone())
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-6)
+    d = (res[True][1] - res[False][1]).abs()
+    assert float(d.max()) <= 1e-6 + 1e-5 * float(res[False][1].abs().max())
