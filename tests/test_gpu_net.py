@@ -383,3 +383,49 @@ def test_queued_small_gradients_equal_autograd_accumulation(loss, fake, monkeypa
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-6)
     d = (res[True][1] - res[False][1]).abs()
     assert float(d.max()) <= 1e-6 + 1e-5 * float(res[False][1].abs().max())
+
+
+@pytest.mark.parametrize('module,switch', [('lstm', 'DEFER_RELU'), ('lstm', 'GX_LANE_NATIVE'), ('ops', 'COMPRESS_FUSED'), ('lstm', 'DW_SIDE_STREAM')])
+@pytest.mark.parametrize('loss,fake', [('ae_mse_kl', False), ('ae_mse_fake_detect_kl', True)])
+def test_fast_path_switches_leave_the_step_unchanged(module, switch, loss, fake, monkeypatch):
+    """Each large-batch fast path of this round was built to be bit-identical to the path it replaces: the ReLU left to the decoder's
+    kernels, gx in accumulator order, CompressFC as one node, the side-stream weight gradients.  Three optimisation steps on the 64-row
+    kernels with the switch off and on: identical losses, gradient norms and parameters -- for the plain objective and for upstream's
+    default one (second encoder pass on corrupted samples + detection head)."""
+    import importlib
+    from deep_interpolation_clustering_amd import lstm as L
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    mod = importlib.import_module('deep_interpolation_clustering_amd.' + module)
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=fake, triple_margin=0.0, cluster_number=4, loss=loss, grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    monkeypatch.setattr(L, 'SMALL_BATCH', 0)                 # the large-batch kernels at a test-sized batch
+    B = 384
+    coh = synthetic.make_cohort(B, seed=12)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    kw = {}
+    if fake:
+        FX = X.clone()
+        FX[:, :6] = torch.where(X[:, 6:12] > 0, X[:, :6].flip(0), X[:, :6])
+        kw = dict(fake_x=FX, fake_perm_idx=torch.arange(2 * B, device=dev),
+                  fake_det_label=torch.cat([torch.ones(B, device=dev), torch.zeros(B, device=dev)]).to(torch.int64))
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(mod, switch, on)
+        torch.manual_seed(4)
+        net = Net(args, dev).to(dev)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16)
+        out = []
+        for i in range(3):
+            losses, gnorm, _ = st.step(X, OB, None, LEN, **kw)
+            out.append([float(losses['loss'].detach()), float(gnorm)])
+        torch.cuda.synchronize()
+        res[on] = (np.array(out), st.flat.flat.detach().clone())
+    np.testing.assert_array_equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
