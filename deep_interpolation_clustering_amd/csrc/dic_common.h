@@ -76,17 +76,21 @@ __device__ __forceinline__ double reduce_partials_32x8(const T* partials, int nb
     const int o = threadIdx.x & (W - 1), sl = threadIdx.x / W, i = i0 + o;
     double acc = 0.0;
     if (i < n) {
-        // four independent chains so that four loads are in flight per thread (the loop is latency-bound otherwise)
-        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        // eight independent chains so that eight loads are in flight per thread (the loop is latency-bound otherwise: a few dozen
+        // workgroups on the whole chip, every load a trip to HBM)
+        double ch[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ch[k] = 0.0;
         int b = sl;
-        for (; b + 3 * nsl < nblk; b += 4 * nsl) {
-            acc += (double)partials[(size_t)b * n + i];
-            a1 += (double)partials[(size_t)(b + nsl) * n + i];
-            a2 += (double)partials[(size_t)(b + 2 * nsl) * n + i];
-            a3 += (double)partials[(size_t)(b + 3 * nsl) * n + i];
+        for (; b + 7 * nsl < nblk; b += 8 * nsl) {
+            T v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partials[(size_t)(b + k * nsl) * n + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ch[k] += (double)v[k];
         }
-        for (; b < nblk; b += nsl) acc += (double)partials[(size_t)b * n + i];
-        acc = (acc + a1) + (a2 + a3);
+        for (; b < nblk; b += nsl) ch[0] += (double)partials[(size_t)b * n + i];
+        acc = ((ch[0] + ch[1]) + (ch[2] + ch[3])) + ((ch[4] + ch[5]) + (ch[6] + ch[7]));
     }
     lds256[threadIdx.x] = acc;
     __syncthreads();
