@@ -63,7 +63,8 @@ def f32_available(x, lstm):
 # The decoder's weight-gradient kernel (MFMA-bound) has no consumer before the optimizer: inside step.Stepper's backward it runs on a
 # side stream next to the bandwidth-bound encoder backward that follows on the main stream (side_stream_session joins at the end).
 DW_SIDE_STREAM = os.environ.get('DIC_DW_SIDE_STREAM', '1') != '0'
-_SIDE = {'on': False, 'streams': {}, 'pending': []}
+_SIDE = {'on': False, 'streams': {}, 'pending': [], 'keep': []}
+RECORD_STREAM = os.environ.get('DIC_SIDE_RECORD_STREAM', '0') == '1'      # (experiment switch: the allocator-side alternative)
 
 
 class side_stream_session:
@@ -85,6 +86,7 @@ def join_side_streams():
     pending, _SIDE['pending'] = _SIDE['pending'], []
     for s in pending:
         torch.cuda.current_stream(s.device).wait_stream(s)
+    _SIDE['keep'] = []                 # (from here on the main stream is ordered behind the side work: its operands may be freed and reused)
 
 
 def _side_stream(dev):
@@ -263,9 +265,14 @@ class _BiLstm(torch.autograd.Function):
                     side.wait_stream(torch.cuda.current_stream(dev))
                     with torch.cuda.stream(side):
                         weight_grads(N.stream_of(dgx))
-                    for t_ in (dgx, out_ext, xb, dbias):
-                        t_.record_stream(side)                       # (allocated on the main stream, still read over there)
+                    # the operands were allocated on the main stream and are read over there: instead of record_stream (deferred frees
+                    # the caching allocator has to poll for, and a 1.6 GB block it cannot hand out meanwhile) the session keeps them
+                    # alive until the main stream has waited for the side stream
+                    if RECORD_STREAM:
+                        for t_ in (dgx, out_ext, xb, dbias):
+                            t_.record_stream(side)
                     _SIDE['pending'].append(side)
+                    _SIDE['keep'].append((dgx, out_ext, xb, dbias, wih, sinks))
                 else:
                     weight_grads(st)
             else:
