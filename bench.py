@@ -168,7 +168,7 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
     xenc = (torch.randn((R, B, 32), **f32)).to(bf)
     wih = (torch.randn((2, 4 * Hh, 32), **f32) * 0.1).to(bf)
     calls['lstm_fwd_proj'] = (lambda: L.dic_lstm_fwd_proj(P(xenc), P(wih), P(whh), None, None, R, B, Hh, 32, P(lout), None, P(lhn), P(lcn),
-                                                          P(lgates), P(lcs), 0, 0, st),
+                                                          P(lgates), P(lcs), 0, 0, 1, st),
                               R * B * 32 * 2 + rows * (Hh * 2 + 4 * Hh * 2 + Hh * 2))   # x in; h, gates, c out (encoder: no gx; the decoder rectifies h on load)
     ldb = torch.empty((2, 4 * Hh), **f32)
     ws6 = torch.empty(max(16, L.dic_lstm_bwd_workspace(B)), dtype=torch.uint8, device=dev)

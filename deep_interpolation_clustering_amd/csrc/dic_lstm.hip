@@ -408,6 +408,166 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
     store_relu_rows(dir ? 0 : R - 1, R & 1);               // the last step's rows (its h went to buffer (R - 1) & 1 ^ 1)
 }
 
+// The fused-projection forward with EIGHT waves per workgroup (two per SIMD), 16 hidden units each.  Its per-step chain -- LDS reads,
+// MFMAs, gate math, barrier -- is what bounds this variant (scripts/lstm_scale.py: 126 us for a workgroup alone on the chip, 143 us with
+// all 256 CUs busy: it moves 40 % fewer bytes per step than the gx variants), and half the MFMAs and half the gate math per wave with a
+// second wave on the SIMD to fill the gaps shorten exactly that.  A wave's MFMA A operand stacks two gates of its 16 units in one
+// 32-row block ([i | f] and [g | o]): accumulator register k < 8 is the first gate of unit 16 w + (k & 3) + 8 (k >> 2) + 4 hh, register
+// 8 + k the second gate of the same unit -- the four gates of a unit still meet in one lane, and the unit <-> (lane, register) map
+// is the one of the 4-wave kernel (its wave w / 2, unit group 2 (w & 1) + q), so the saved gates / cell states land where lstm_bwd
+// expects them and every number is bit-identical (same MFMA k order).
+__global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
+    static_assert(LNB == 2, "two 32-row halves per workgroup");
+    extern __shared__ __align__(16) __bf16 fsm[];
+    __bf16 (*hbuf)[LBM * HSTR] = reinterpret_cast<__bf16 (*)[LBM * HSTR]>(fsm);      // [2][LBM*HSTR]
+    __bf16* gst = fsm + 2 * LBM * HSTR;                                               // [2][LBM][XSTR] x tiles
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                           // 0..7
+    const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
+    const int nbt = gridDim.x * LNB;
+    const int wq = w >> 1, qb = 2 * (w & 1);              // wave / first unit group of the 4-wave kernel's layout these 16 units belong to
+
+    bf16x8 wf[2][8], wx[2][LXK / 16];
+    {
+        const int grow = (dir * 4 + (r >> 4)) * LH + 16 * w + (r & 15);               // block 0: gates 0 / 1 (rows 0-15 / 16-31); block 1: + 2 gates
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                wf[bk][ks] = *reinterpret_cast<const bf16x8*>(a.whh + ((size_t)grow + 2 * bk * LH) * LH + ks * 16 + 8 * hh);
+#pragma unroll
+            for (int ks = 0; ks < LXK / 16; ++ks)
+                wx[bk][ks] = *reinterpret_cast<const bf16x8*>(a.wih + ((size_t)grow + 2 * bk * LH) * LXK + ks * 16 + 8 * hh);
+        }
+    }
+    // lane owns batch row (nb*32 + r) and hidden units 16 w + 8 q + 4 hh + {0..3}, q = 0..1: element 4 q + j
+    float c[LNB][8];
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) {
+        const int b = b0 + nb * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int u = 16 * w + 8 * q + 4 * hh;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+                if (a.h0) hv = *reinterpret_cast<const f32x4*>(a.h0 + state_off(a.bm, dir, b, B) + u);
+                if (a.c0) cv = *reinterpret_cast<const f32x4*>(a.c0 + state_off(a.bm, dir, b, B) + u);
+            }
+            bf16x4 hb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hb[j] = (__bf16)hv[j]; c[nb][4 * q + j] = cv[j]; }
+            *reinterpret_cast<bf16x4*>(&hbuf[0][(nb * 32 + r) * HSTR + u]) = hb;
+            if (a.boundary && b < B) {
+                __bf16* slot = dir ? a.out + (size_t)R * B * 2 * LH : a.out - (size_t)B * 2 * LH;
+                *reinterpret_cast<bf16x4*>(slot + (size_t)b * 2 * LH + dir * LH + u) = hb;
+            }
+        }
+    }
+    const bool xloader = tid < 256;                       // 64 rows x 4 pieces of 16 B
+    const int xrow = (tid & 255) >> 2, xpc = tid & 3;
+    auto load_x = [&](int step) {
+        const int t = dir ? R - 1 - step : step;
+        return *reinterpret_cast<const bf16x8*>(a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * LXK + xpc * 8);
+    };
+    bf16x8 xnext = {};
+    if (xloader) *reinterpret_cast<bf16x8*>(gst + xrow * XSTR + xpc * 8) = load_x(0);
+    __syncthreads();
+    auto store_relu_rows = [&](int t_of_rows, int buf) {
+        if (!a.out_relu) return;
+#pragma unroll
+        for (int k = 0; k < LBM * 16 / 512; ++k) {
+            const int i = k * 512 + tid, row = i >> 4, pc = i & 15;
+            if (b0 + row < B) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&hbuf[buf][row * HSTR + pc * 8]);
+                auto rl = [](unsigned x) { return x & ~(((x & 0x80008000u) >> 15) * 0xffffu); };
+                *reinterpret_cast<uint4*>(a.out_relu + ((size_t)t_of_rows * B + b0 + row) * 2 * LH + dir * LH + pc * 8) =
+                    make_uint4(rl(v.x), rl(v.y), rl(v.z), rl(v.w));
+            }
+        }
+    };
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? R - 1 - step : step;
+        const int cur = step & 1;
+        f32x16 acc[2][LNB];
+        if (xloader && step + 1 < R) xnext = load_x(step + 1);
+        if (step > 0) store_relu_rows(dir ? R - step : step - 1, cur);
+        const bool last = step == R - 1;
+        auto x_part = [&](int nb) {                // G = W_ih . x_t^T (bias included: constant-one input column)
+#pragma unroll
+            for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[bk][nb][k] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < LXK / 16; ++ks) {
+                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(gst + cur * LBM * XSTR + (nb * 32 + r) * XSTR + ks * 16 + 8 * hh);
+#pragma unroll
+                for (int bk = 0; bk < 2; ++bk) acc[bk][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[bk][ks], xb, acc[bk][nb], 0, 0, 0);
+            }
+        };
+        auto h_part = [&](int nb, int ks) {        // G += W_hh . h_{t-1}^T, one k-step
+            const bf16x8 hb = *reinterpret_cast<const bf16x8*>(&hbuf[cur][(nb * 32 + r) * HSTR + ks * 16 + 8 * hh]);
+#pragma unroll
+            for (int bk = 0; bk < 2; ++bk) acc[bk][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[bk][ks], hb, acc[bk][nb], 0, 0, 0);
+        };
+        auto gate_math = [&](int nb, int q) {
+            const int b = b0 + nb * 32 + r;
+            const bool ok = b < B;
+            const int u = 16 * w + 8 * q + 4 * hh;
+            bf16x4 hb, ib, fb, gb, ob;
+            f32x4 cv, hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * q + j;
+                const float ig = sigmoid_fast(acc[0][nb][e]);
+                const float fg = sigmoid_fast(acc[0][nb][8 + e]);
+                const float gg = tanh_fast(acc[1][nb][e]);
+                const float og = sigmoid_fast(acc[1][nb][8 + e]);
+                const float cn = fmaf(fg, c[nb][e], ig * gg);
+                const float hn = og * tanh_fast(cn);
+                c[nb][e] = cn;
+                cv[j] = cn; hv[j] = hn;
+                hb[j] = (__bf16)hn; ib[j] = (__bf16)ig; fb[j] = (__bf16)fg; gb[j] = (__bf16)gg; ob[j] = (__bf16)og;
+            }
+            *reinterpret_cast<bf16x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + u]) = hb;
+            if (a.gates) {
+                const int bt = blockIdx.x * LNB + nb;
+                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 0, qb + q, hh, r)) = ib;
+                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 1, qb + q, hh, r)) = fb;
+                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 2, qb + q, hh, r)) = gb;
+                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 3, qb + q, hh, r)) = ob;
+                bf16x4 cb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cb[j] = (__bf16)cv[j];
+                *reinterpret_cast<bf16x4*>(a.cs + native_off(t, nbt, bt, dir, wq, 1, 0, qb + q, hh, r)) = cb;
+            }
+            if (ok) {
+                const size_t row = (size_t)t * B + b;
+                *reinterpret_cast<bf16x4*>(a.out + row * 2 * LH + dir * LH + u) = hb;
+                if (last) {
+                    *reinterpret_cast<f32x4*>(a.hn + state_off(a.bm, dir, b, B) + u) = hv;
+                    *reinterpret_cast<f32x4*>(a.cn + state_off(a.bm, dir, b, B) + u) = cv;
+                }
+            }
+        };
+        x_part(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) h_part(0, ks);
+        x_part(1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            gate_math(0, q);
+#pragma unroll
+            for (int ks = 4 * q; ks < 4 * q + 4; ++ks) h_part(1, ks);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) gate_math(1, q);
+        if (xloader && step + 1 < R) *reinterpret_cast<bf16x8*>(gst + (cur ^ 1) * LBM * XSTR + xrow * XSTR + xpc * 8) = xnext;
+        lds_barrier();
+    }
+    store_relu_rows(dir ? 0 : R - 1, R & 1);
+}
+
+
 struct LstmBwdArgs {
     const __bf16* whh_t;   // (2,H,4H): whh_t[d][u][n] = whh[d][n][u]
     const __bf16* gates;   // lane-native, as written by lstm_fwd_kernel
@@ -663,13 +823,24 @@ int dic_lstm_fwd(const void* gx, int gx_lane_native, const void* whh, const floa
 
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
                       int I, void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, int write_boundary,
-                      dic_stream_t stream) {
+                      int eight_waves, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(I == LXK, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: input width %d (compiled for %d: zero-pad narrower inputs)", I, LXK);
     DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd_proj: gates and cs go together");
     LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0, write_boundary != 0};
+    if (eight_waves) {
+        const size_t lds = (size_t)(2 * LBM * HSTR + 2 * LBM * XSTR) * sizeof(__bf16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd8_proj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd_proj: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(lstm_fwd8_proj_kernel, dim3((B + LBM - 1) / LBM, 2), dim3(512), lds, (hipStream_t)stream, a);
+        return check_launch("lstm_fwd_proj");
+    }
     return lstm_fwd_launch(FWD_PROJ, a, (hipStream_t)stream);
 }
 

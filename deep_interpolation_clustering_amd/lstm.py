@@ -36,6 +36,7 @@ PARAM_NAMES = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
                'weight_ih_l0_reverse', 'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
 
+FWD_EIGHT_WAVES = os.environ.get('DIC_FWD_EIGHT_WAVES', '1') != '0'   # (A/B switch: 0 = four waves per workgroup in the encoder's fused-projection recurrence)
 DEFER_RELU = os.environ.get('DIC_DEFER_RELU', '1') != '0'             # (A/B switch: 0 = the encoder writes a rectified copy of its output for the decoder)
 GX_LANE_NATIVE = os.environ.get('DIC_GX_LANE_NATIVE', '1') != '0'     # (A/B switch: 0 = row-major gx between dic_row_proj and dic_lstm_fwd)
 ROW_PROJ = os.environ.get('DIC_ROW_PROJ', '1') != '0'                  # (A/B switch: 0 = library GEMM for the decoder's input projection)
@@ -175,7 +176,7 @@ class _BiLstm(torch.autograd.Function):
                 cs = torch.empty((R, Bp, 2, H), device=dev, dtype=T)    # bf16 copy for the backward; c itself stays f32 on chip
             if proj:
                 N.check(L.dic_lstm_fwd_proj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out), N.ptr(out_r),
-                                            N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), st), 'dic_lstm_fwd_proj')
+                                            N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), int(FWD_EIGHT_WAVES), st), 'dic_lstm_fwd_proj')
             else:
                 native = 0
                 if Ip == WIDE_INPUT and ROW_PROJ:

@@ -261,7 +261,9 @@ int dic_lstm_fwd(const void* gx, int gx_lane_native, const void* whh, const floa
  * backward is dic_lstm_bwd unchanged. */
 int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H,
                       int I, void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, int write_boundary,
-                      dic_stream_t stream);
+                      int eight_waves, dic_stream_t stream);
+/* eight_waves != 0: 512-thread workgroups, two waves per SIMD with 16 hidden units each (same results bit for bit): this variant's
+ * per-step chain, not its bandwidth, bounds it, and the second wave on a SIMD fills the first one's gaps. */
 size_t dic_lstm_bwd_workspace(int B);
 int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const float* c0, const void* dout,
                  const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0,

@@ -34,6 +34,6 @@ def timed(fn, it=20):
 for rep in range(2):
     t1 = timed(lambda: N.check(L.dic_lstm_fwd(P(gx), 1, P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st), 'fwd'))
     t0 = timed(lambda: N.check(L.dic_lstm_fwd(P(gx), 0, P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st), 'fwd'))
-    t2 = timed(lambda: N.check(L.dic_lstm_fwd_proj(P(x), P(wih), P(whh), None, None, R, B, H, 32, P(out), P(outr), P(hn), P(cn), P(gates), P(cs), 0, 0, st), 'proj'))
+    t2 = timed(lambda: N.check(L.dic_lstm_fwd_proj(P(x), P(wih), P(whh), None, None, R, B, H, 32, P(out), P(outr), P(hn), P(cn), P(gates), P(cs), 0, 0, int(os.environ.get('DIC_FWD8', '1')), st), 'proj'))
     t3 = timed(lambda: N.check(L.dic_lstm_bwd(P(whh_t), P(gates), P(cs), None, P(dout), None, None, R, B, H, P(dgx), P(dh0), P(dc0), P(db), P(ws), ws.numel(), 0, 0, st), 'bwd'))
     print('fwd(native) %6.1f  fwd(rows) %6.1f  fwd_proj %6.1f  bwd %6.1f us   checks %.1f %.1f' % (t1, t0, t2, t3, out.float().abs().sum().item(), dgx.float().abs().sum().item()), flush=True)

@@ -29,6 +29,8 @@ for B in (1024, 2048, 4096, 8192, 16384, 32768):
         b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / it * 1e3
     tf = timed(lambda: N.check(L.dic_lstm_fwd(P(gx), 0, P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st), 'fwd'))
+    x32 = torch.randn(R, B, 32, device=dev).to(bf); wih32 = (torch.randn(2, 4 * H, 32, device=dev) * 0.1).to(bf)
+    tp = timed(lambda: N.check(L.dic_lstm_fwd_proj(P(x32), P(wih32), P(whh), None, None, R, B, H, 32, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, int(os.environ.get('DIC_FWD8', '1')), st), 'proj'))
     tb = timed(lambda: N.check(L.dic_lstm_bwd(P(whh_t), P(gates), P(cs), None, P(dout), None, None, R, B, H, P(dgx), P(dh0), P(dc0), P(db), P(ws), ws.numel(), 0, 0, st), 'bwd'))
     wgs = B // 64 * 2
-    print('B %6d  workgroups %5d (%.2f per CU)  fwd %7.1f us  bwd %7.1f us   per round of 256: fwd %6.1f bwd %6.1f' % (B, wgs, wgs / 256, tf, tb, tf / max(1, wgs / 256), tb / max(1, wgs / 256)), flush=True)
+    print('B %6d  workgroups %5d (%.2f per CU)  fwd %7.1f us  fwd_proj %7.1f us  bwd %7.1f us   per round of 256: fwd %6.1f proj %6.1f bwd %6.1f' % (B, wgs, wgs / 256, tf, tp, tb, tf / max(1, wgs / 256), tp / max(1, wgs / 256), tb / max(1, wgs / 256)), flush=True)

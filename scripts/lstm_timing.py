@@ -14,7 +14,7 @@ out = torch.empty(R, B, 2 * H, device=dev, dtype=bf); gates = torch.empty(R, B, 
 cs = torch.empty(R, B, 2, H, device=dev, dtype=bf); hn = torch.empty(2, B, H, device=dev); cn = torch.empty(2, B, H, device=dev)
 P, st = N.ptr, N.stream_of(gx)
 for _ in range(3):
-    if proj: L.dic_lstm_fwd_proj(P(x), P(wih), P(whh), None, None, R, B, H, 32, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st)
+    if proj: L.dic_lstm_fwd_proj(P(x), P(wih), P(whh), None, None, R, B, H, 32, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, 0, st)
     else: L.dic_lstm_fwd(P(gx), 0, P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st)
 torch.cuda.synchronize()
 buf = np.zeros((2, 32, 8), dtype=np.uint64)

@@ -901,3 +901,40 @@ def test_relu_between_the_lstms_left_to_the_decoder_kernels(B, monkeypatch):
                           **{'d.' + k: p.grad.clone() for k, p in dec.named_parameters()})
     for k in res[False]:
         assert torch.equal(res[False][k], res[True][k]), k
+
+
+@pytest.mark.parametrize('R,B,init,relu', [(24, 128, True, True), (5, 70, False, False), (3, 1, True, True), (7, 333, False, True)])
+def test_eight_wave_encoder_recurrence_equals_the_four_wave_kernel(R, B, init, relu):
+    """dic_lstm_fwd_proj(eight_waves=1): 512-thread workgroups, 16 hidden units per wave with two gates stacked in one MFMA block --
+    the same k order in every accumulator, so out, the rectified copy, h_n, c_n and the saved gates / cell states (in the layout
+    lstm_bwd reads) are bit-equal to the 4-wave kernel's, for ragged batches and boundary rows too."""
+    from deep_interpolation_clustering_amd import _native as N
+    L = N.lib()
+    dev, bf = torch.device('cuda'), torch.bfloat16
+    torch.manual_seed(R * 100 + B)
+    x = torch.randn(R, B, 32, device=dev).to(bf)
+    wih = (torch.randn(2, 4 * H, 32, device=dev) * 0.1).to(bf)
+    whh = (torch.randn(2, 4 * H, H, device=dev) * 0.08).to(bf)
+    h0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    c0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    Bp = (B + 63) // 64 * 64
+    res = []
+    for eight in (0, 1):
+        ext = torch.full((R + 2, B, 2 * H), float('nan'), device=dev, dtype=bf)
+        out = ext[1:R + 1]
+        outr = torch.full((R, B, 2 * H), float('nan'), device=dev, dtype=bf) if relu else None
+        gates = torch.zeros(R, Bp, 2, 4, H, device=dev, dtype=bf)
+        cs = torch.zeros(R, Bp, 2, H, device=dev, dtype=bf)
+        hn, cn = torch.empty(2, B, H, device=dev), torch.empty(2, B, H, device=dev)
+        N.check(L.dic_lstm_fwd_proj(N.ptr(x), N.ptr(wih), N.ptr(whh), N.ptr(h0), N.ptr(c0), R, B, H, 32, N.ptr(out), N.ptr(outr), N.ptr(hn), N.ptr(cn),
+                                    N.ptr(gates), N.ptr(cs), 0, 1, eight, N.stream_of(x)), 'dic_lstm_fwd_proj')
+        # (padded rows of the saved state hold whatever the kernel computed for the clamped input row: compare the live rows only)
+        res.append([out.clone(), ext[0, :, :H].clone(), ext[R + 1, :, H:].clone(), hn, cn] + ([outr] if relu else []))
+        res[-1] += [gates.view(R, Bp // 32, 2, 4, 4, 4, 2, 32, 4), cs.view(R, Bp // 32, 2, 4, 1, 4, 2, 32, 4)]
+    live = torch.arange(Bp, device=dev).view(Bp // 32, 32) < B                     # [tile][row]
+    for a, b in zip(res[0][:-2], res[1][:-2]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][-2:], res[1][-2:]):
+        m = live.view(1, Bp // 32, 1, 1, 1, 1, 1, 32, 1).expand_as(a)
+        assert torch.equal(a[m], b[m])
+    assert torch.isfinite(res[0][0].float()).all()

@@ -385,7 +385,8 @@ def test_queued_small_gradients_equal_autograd_accumulation(loss, fake, monkeypa
     assert float(d.max()) <= 1e-6 + 1e-5 * float(res[False][1].abs().max())
 
 
-@pytest.mark.parametrize('module,switch', [('lstm', 'DEFER_RELU'), ('lstm', 'GX_LANE_NATIVE'), ('ops', 'COMPRESS_FUSED'), ('lstm', 'DW_SIDE_STREAM')])
+@pytest.mark.parametrize('module,switch', [('lstm', 'DEFER_RELU'), ('lstm', 'GX_LANE_NATIVE'), ('ops', 'COMPRESS_FUSED'), ('lstm', 'DW_SIDE_STREAM'),
+                                           ('lstm', 'FWD_EIGHT_WAVES')])
 @pytest.mark.parametrize('loss,fake', [('ae_mse_kl', False), ('ae_mse_fake_detect_kl', True)])
 def test_fast_path_switches_leave_the_step_unchanged(module, switch, loss, fake, monkeypatch):
     """Each large-batch fast path of this round was built to be bit-identical to the path it replaces: the ReLU left to the decoder's
