@@ -599,7 +599,7 @@ def main():
         trace_name = {'sci_cci_fwd': 'dic::sci_cci_fwd_kernel', 'sci_cci_bwd': 'dic::sci_cci_bwd_kernel', 'rbf_fwd': 'dic::rbf_fwd_kernel',
                       'rbf_bwd': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'), 'masked_sse_fwd': 'dic::masked_sse_kernel', 'masked_sse_bwd': 'dic::masked_sse_bwd_kernel',
                       'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': 'dic::lstm_fwd_kernel',
-                      'lstm_fwd_proj': 'dic::lstm_fwd_kernel', 'lstm_bwd': 'dic::lstm_bwd_kernel', 'lstm_dw': 'dic::lstm_dw_kernel',
+                      'lstm_fwd_proj': ('dic::lstm_fwd8_proj_kernel', 'dic::lstm_fwd_kernel'), 'lstm_bwd': 'dic::lstm_bwd_kernel', 'lstm_dw': 'dic::lstm_dw_kernel',
                       'row_proj': 'dic::row_proj_kernel', 'row_proj_stats': 'dic::row_proj_kernel', 'fc_bwd': 'dic::fc_bwd_kernel',
                       'lstm_dw_wide': 'dic::lstm_dw_wide_kernel'}
         kernels = groups = None
@@ -620,7 +620,10 @@ def main():
             if kernels is not None:
                 hits = [v for k, v in kernels.items() if k.startswith(trace_name[name])]        # (str.startswith takes a tuple of prefixes too)
                 launches = sum(v['launches_per_step'] for v in hits)
-                if name in ('lstm_fwd', 'lstm_fwd_proj', 'row_proj', 'row_proj_stats'):
+                eight = any(k.startswith('dic::lstm_fwd8') for k in kernels)          # the encoder's recurrence has a kernel name of its own then
+                if name == 'lstm_fwd_proj' and eight:
+                    launches = sum(v['launches_per_step'] for k, v in kernels.items() if k.startswith('dic::lstm_fwd8'))
+                elif name in ('row_proj', 'row_proj_stats') or (name in ('lstm_fwd', 'lstm_fwd_proj') and not eight):
                     launches = launches / 2            # one template, two instantiations (decoder / encoder, gx / CompressFC), one launch each
             per_step[name] = launches * row['ms']
         dom = max(per_step, key=per_step.get)
