@@ -163,7 +163,7 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
     ldout = (torch.randn((R, B, 2 * Hh), **f32) * 0.1).to(bf)
     ldgx, ldh0, ldc0 = torch.empty((R, B, 2, 4, Hh), device=dev, dtype=bf), torch.empty((2, B, Hh), **f32), torch.empty((2, B, Hh), **f32)
     rows = 2.0 * R * B                     # (step, batch row, direction) units
-    calls['lstm_fwd'] = (lambda: L.dic_lstm_fwd(P(gxl), int(B % 64 == 0), P(whh), None, None, R, B, Hh, P(lout), None, P(lhn), P(lcn), P(lgates), P(lcs), 0, 0, st),
+    calls['lstm_fwd'] = (lambda: L.dic_lstm_fwd(P(gxl), 2 * int(B % 64 == 0), P(whh), None, None, R, B, Hh, P(lout), None, P(lhn), P(lcn), P(lgates), P(lcs), 0, 0, st),
                          rows * (4 * Hh * 2 + Hh * 2 + 4 * Hh * 2 + Hh * 2))      # gx in; h, gates, c (bf16 copy) out
     xenc = (torch.randn((R, B, 32), **f32)).to(bf)
     wih = (torch.randn((2, 4 * Hh, 32), **f32) * 0.1).to(bf)
@@ -598,7 +598,7 @@ def main():
         # which kernel dominates the STEP: launches x duration from a trace of the timed step itself
         trace_name = {'sci_cci_fwd': 'dic::sci_cci_fwd_kernel', 'sci_cci_bwd': 'dic::sci_cci_bwd_kernel', 'rbf_fwd': 'dic::rbf_fwd_kernel',
                       'rbf_bwd': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'), 'masked_sse_fwd': 'dic::masked_sse_kernel', 'masked_sse_bwd': 'dic::masked_sse_bwd_kernel',
-                      'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': 'dic::lstm_fwd_kernel',
+                      'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': ('dic::lstm_fwd8_gxn_kernel', 'dic::lstm_fwd_kernel'),
                       'lstm_fwd_proj': ('dic::lstm_fwd8_proj_kernel', 'dic::lstm_fwd_kernel'), 'lstm_bwd': 'dic::lstm_bwd_kernel', 'lstm_dw': 'dic::lstm_dw_kernel',
                       'row_proj': 'dic::row_proj_kernel', 'row_proj_stats': 'dic::row_proj_kernel', 'fc_bwd': 'dic::fc_bwd_kernel',
                       'lstm_dw_wide': 'dic::lstm_dw_wide_kernel'}
@@ -620,10 +620,10 @@ def main():
             if kernels is not None:
                 hits = [v for k, v in kernels.items() if k.startswith(trace_name[name])]        # (str.startswith takes a tuple of prefixes too)
                 launches = sum(v['launches_per_step'] for v in hits)
-                eight = any(k.startswith('dic::lstm_fwd8') for k in kernels)          # the encoder's recurrence has a kernel name of its own then
-                if name == 'lstm_fwd_proj' and eight:
-                    launches = sum(v['launches_per_step'] for k, v in kernels.items() if k.startswith('dic::lstm_fwd8'))
-                elif name in ('row_proj', 'row_proj_stats') or (name in ('lstm_fwd', 'lstm_fwd_proj') and not eight):
+                own = {'lstm_fwd': 'dic::lstm_fwd8_gxn_kernel', 'lstm_fwd_proj': 'dic::lstm_fwd8_proj_kernel'}.get(name)
+                if own is not None and any(k.startswith(own) for k in kernels):          # the eight-wave kernels have names of their own
+                    launches = sum(v['launches_per_step'] for k, v in kernels.items() if k.startswith(own))
+                elif name in ('row_proj', 'row_proj_stats', 'lstm_fwd', 'lstm_fwd_proj'):
                     launches = launches / 2            # one template, two instantiations (decoder / encoder, gx / CompressFC), one launch each
             per_step[name] = launches * row['ms']
         dom = max(per_step, key=per_step.get)

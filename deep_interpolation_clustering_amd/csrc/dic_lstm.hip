@@ -568,6 +568,181 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
 }
 
 
+// The same eight-wave layout for the decoder's forward on lane-native gx (FWD_GXN): a piece of that layout (unit half qp of wave w) is
+// exactly the 16 units of eight-wave wave 2 w + qp, so every wave stages 4 pieces per 32-row half and step.
+__global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
+    static_assert(LNB == 2, "two 32-row halves per workgroup");
+    extern __shared__ __align__(16) __bf16 fsm[];
+    __bf16 (*hbuf)[LBM * HSTR] = reinterpret_cast<__bf16 (*)[LBM * HSTR]>(fsm);      // [2][LBM*HSTR]
+    __bf16* gst = fsm + 2 * LBM * HSTR;                                               // [8 waves][LNB][4 gates][512]: the wave's own lane-native gx pieces
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                           // 0..7
+    const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
+    const int nbt = gridDim.x * LNB;
+    const int wq = w >> 1, qb = 2 * (w & 1);              // wave / first unit group of the 4-wave kernel's layout these 16 units belong to
+
+    bf16x8 wf[2][8];
+    {
+        const int grow = (dir * 4 + (r >> 4)) * LH + 16 * w + (r & 15);               // block 0: gates 0 / 1 (rows 0-15 / 16-31); block 1: + 2 gates
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                wf[bk][ks] = *reinterpret_cast<const bf16x8*>(a.whh + ((size_t)grow + 2 * bk * LH) * LH + ks * 16 + 8 * hh);
+        }
+    }
+    // lane owns batch row (nb*32 + r) and hidden units 16 w + 8 q + 4 hh + {0..3}, q = 0..1: element 4 q + j
+    float c[LNB][8];
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) {
+        const int b = b0 + nb * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int u = 16 * w + 8 * q + 4 * hh;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+                if (a.h0) hv = *reinterpret_cast<const f32x4*>(a.h0 + state_off(a.bm, dir, b, B) + u);
+                if (a.c0) cv = *reinterpret_cast<const f32x4*>(a.c0 + state_off(a.bm, dir, b, B) + u);
+            }
+            bf16x4 hb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hb[j] = (__bf16)hv[j]; c[nb][4 * q + j] = cv[j]; }
+            *reinterpret_cast<bf16x4*>(&hbuf[0][(nb * 32 + r) * HSTR + u]) = hb;
+            if (a.boundary && b < B) {
+                __bf16* slot = dir ? a.out + (size_t)R * B * 2 * LH : a.out - (size_t)B * 2 * LH;
+                *reinterpret_cast<bf16x4*>(slot + (size_t)b * 2 * LH + dir * LH + u) = hb;
+            }
+        }
+    }
+    // A operands that drop a lane-native piece (B operand: lane (row r, hh) holds the 8 values of units 8 (e / 4) + 4 hh + e % 4 of the
+    // wave's 16) into rows 0-15 (first gate of the block) or 16-31 (second gate) of the accumulator block: 0/1 matrices, exact
+    bf16x8 perm[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) perm[half][e] = (__bf16)((r == 16 * half + 8 * (e >> 2) + 4 * hh + (e & 3)) ? 1.0f : 0.0f);
+    __bf16* const gwave = gst + w * (LNB * 4 * 512);
+    auto request_gxn = [&](int nb, int step) {          // this wave's 4 pieces (gates) of one 32-row half: unit half w & 1 of the 4-wave kernel's wave w / 2
+        const int t = dir ? R - 1 - step : step;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const __bf16* src = a.gx + gxn_off(t, nbt, blockIdx.x * LNB + nb, dir, wq, g, w & 1, hh, r);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(gwave + (nb * 4 + g) * 512), 16, 0, 0);
+        }
+    };
+    // the pieces of a half have landed once at most the operations issued after them remain in flight: the other half's 4 pieces and one
+    // step's stores of this wave (6 per unit group x 4 groups; the batch is a multiple of 64: no row is masked)
+    auto gxn_landed = [&](bool other_half_behind) {
+        if (a.gates && !a.out_relu) {
+            if (other_half_behind) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    request_gxn(0, 0);
+    request_gxn(1, 0);
+    __syncthreads();
+    auto store_relu_rows = [&](int t_of_rows, int buf) {
+        if (!a.out_relu) return;
+#pragma unroll
+        for (int k = 0; k < LBM * 16 / 512; ++k) {
+            const int i = k * 512 + tid, row = i >> 4, pc = i & 15;
+            if (b0 + row < B) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&hbuf[buf][row * HSTR + pc * 8]);
+                auto rl = [](unsigned x) { return x & ~(((x & 0x80008000u) >> 15) * 0xffffu); };
+                *reinterpret_cast<uint4*>(a.out_relu + ((size_t)t_of_rows * B + b0 + row) * 2 * LH + dir * LH + pc * 8) =
+                    make_uint4(rl(v.x), rl(v.y), rl(v.z), rl(v.w));
+            }
+        }
+    };
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? R - 1 - step : step;
+        const int cur = step & 1;
+        f32x16 acc[2][LNB];
+        if (step > 0) store_relu_rows(dir ? R - step : step - 1, cur);
+        const bool last = step == R - 1;
+        auto x_part = [&](int nb) {                // accumulators of a half <- its staged pre-activations (exact: 1.0 x bf16 in f32); the region refills
+            if (step > 0) gxn_landed(nb == 0 || step + 1 < R);
+#pragma unroll
+            for (int bk = 0; bk < 2; ++bk) {
+                const __bf16* gp = gwave + (nb * 4 + 2 * bk) * 512 + lane * 8;
+                f32x16 z;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) z[k] = 0.f;
+                z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(perm[0], *reinterpret_cast<const bf16x8*>(gp), z, 0, 0, 0);
+                acc[bk][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(perm[1], *reinterpret_cast<const bf16x8*>(gp + 512), z, 0, 0, 0);
+            }
+            if (step + 1 < R) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads above have returned: the region may be overwritten
+                request_gxn(nb, step + 1);
+            }
+        };
+        auto h_part = [&](int nb, int ks) {        // G += W_hh . h_{t-1}^T, one k-step
+            const bf16x8 hb = *reinterpret_cast<const bf16x8*>(&hbuf[cur][(nb * 32 + r) * HSTR + ks * 16 + 8 * hh]);
+#pragma unroll
+            for (int bk = 0; bk < 2; ++bk) acc[bk][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[bk][ks], hb, acc[bk][nb], 0, 0, 0);
+        };
+        auto gate_math = [&](int nb, int q) {
+            const int b = b0 + nb * 32 + r;
+            const bool ok = true;               // (lane-native gx: the batch tiles by 64 rows)
+            const int u = 16 * w + 8 * q + 4 * hh;
+            bf16x4 hb, ib, fb, gb, ob;
+            f32x4 cv, hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * q + j;
+                const float ig = sigmoid_fast(acc[0][nb][e]);
+                const float fg = sigmoid_fast(acc[0][nb][8 + e]);
+                const float gg = tanh_fast(acc[1][nb][e]);
+                const float og = sigmoid_fast(acc[1][nb][8 + e]);
+                const float cn = fmaf(fg, c[nb][e], ig * gg);
+                const float hn = og * tanh_fast(cn);
+                c[nb][e] = cn;
+                cv[j] = cn; hv[j] = hn;
+                hb[j] = (__bf16)hn; ib[j] = (__bf16)ig; fb[j] = (__bf16)fg; gb[j] = (__bf16)gg; ob[j] = (__bf16)og;
+            }
+            *reinterpret_cast<bf16x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + u]) = hb;
+            if (a.gates) {
+                const int bt = blockIdx.x * LNB + nb;
+                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 0, qb + q, hh, r)) = ib;
+                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 1, qb + q, hh, r)) = fb;
+                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 2, qb + q, hh, r)) = gb;
+                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 3, qb + q, hh, r)) = ob;
+                bf16x4 cb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cb[j] = (__bf16)cv[j];
+                *reinterpret_cast<bf16x4*>(a.cs + native_off(t, nbt, bt, dir, wq, 1, 0, qb + q, hh, r)) = cb;
+            }
+            if (ok) {
+                const size_t row = (size_t)t * B + b;
+                *reinterpret_cast<bf16x4*>(a.out + row * 2 * LH + dir * LH + u) = hb;
+                if (last) {
+                    *reinterpret_cast<f32x4*>(a.hn + state_off(a.bm, dir, b, B) + u) = hv;
+                    *reinterpret_cast<f32x4*>(a.cn + state_off(a.bm, dir, b, B) + u) = cv;
+                }
+            }
+        };
+        x_part(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) h_part(0, ks);
+        x_part(1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            gate_math(0, q);
+#pragma unroll
+            for (int ks = 4 * q; ks < 4 * q + 4; ++ks) h_part(1, ks);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) gate_math(1, q);
+        lds_barrier();
+    }
+    store_relu_rows(dir ? 0 : R - 1, R & 1);
+}
+
+
+
 struct LstmBwdArgs {
     const __bf16* whh_t;   // (2,H,4H): whh_t[d][u][n] = whh[d][n][u]
     const __bf16* gates;   // lane-native, as written by lstm_fwd_kernel
@@ -818,6 +993,17 @@ int dic_lstm_fwd(const void* gx, int gx_lane_native, const void* whh, const floa
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd: gates and cs go together");
     DIC_REQUIRE(!gx_lane_native || B % LBM == 0, DIC_ERR_INVALID_ARG, "lstm_fwd: lane-native gx needs a batch that is a multiple of %d (got %d)", LBM, B);
     LstmFwdArgs a{(const __bf16*)gx, nullptr, nullptr, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0, write_boundary != 0};
+    if (gx_lane_native == 2) {          // eight waves per workgroup (see lstm_fwd8_gxn_kernel)
+        const size_t lds = (size_t)(2 * LBM * HSTR + LBM * 4 * LH) * sizeof(__bf16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd8_gxn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(lstm_fwd8_gxn_kernel, dim3(B / LBM, 2), dim3(512), lds, (hipStream_t)stream, a);
+        return check_launch("lstm_fwd");
+    }
     return lstm_fwd_launch(gx_lane_native ? FWD_GXN : FWD_GX, a, (hipStream_t)stream);
 }
 

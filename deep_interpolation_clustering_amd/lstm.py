@@ -187,7 +187,7 @@ class _BiLstm(torch.autograd.Function):
                     N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), native, int(relu_kernel), st), 'dic_row_proj')
                 else:
                     gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
-                N.check(L.dic_lstm_fwd(N.ptr(gx), int(native > 0), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
+                N.check(L.dic_lstm_fwd(N.ptr(gx), (2 if FWD_EIGHT_WAVES else 1) if native > 0 else 0, N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
                                        N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), st), 'dic_lstm_fwd')
         ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32), bool(relu))
         ctx.x_relu_in_kernel = relu_kernel

@@ -247,7 +247,8 @@ int dic_kmeans_pp_candidates_rows(const float* X, int N, int D, int row_lo, int 
 int dic_lstm_fwd(const void* gx, int gx_lane_native, const void* whh, const float* h0, const float* c0, int R, int B, int H,
                  void* out, void* out_relu, float* hn, float* cn, void* gates, void* cs, int state_batch_major, int write_boundary,
                  dic_stream_t stream);
-/* gx_lane_native != 0 (B a multiple of 64): gx is not row-major but in the opaque form dic_row_proj(..., lane_native_batch = B) writes --
+/* gx_lane_native == 2: the same with eight waves per workgroup (two per SIMD, 16 hidden units each; bit-identical results).
+ * gx_lane_native != 0 (B a multiple of 64): gx is not row-major but in the opaque form dic_row_proj(..., lane_native_batch = B) writes --
  * the order of the recurrence kernel's MFMA accumulators, 1-KiB pieces per wave access -- and is read straight into registers a step
  * ahead (no LDS staging of the gx tile, one barrier per step). */
 /* write_boundary != 0: `out` points at time slot 1 of an (R+2,B,2H) buffer (dic_lstm_dw's out_ext); the kernel also writes h0 (bf16;

@@ -32,7 +32,7 @@ def timed(fn, it=20):
 
 
 for rep in range(2):
-    t1 = timed(lambda: N.check(L.dic_lstm_fwd(P(gx), 1, P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st), 'fwd'))
+    t1 = timed(lambda: N.check(L.dic_lstm_fwd(P(gx), 1 + int(os.environ.get('DIC_FWD8', '1')), P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st), 'fwd'))
     t0 = timed(lambda: N.check(L.dic_lstm_fwd(P(gx), 0, P(whh), None, None, R, B, H, P(out), None, P(hn), P(cn), P(gates), P(cs), 0, 0, st), 'fwd'))
     t2 = timed(lambda: N.check(L.dic_lstm_fwd_proj(P(x), P(wih), P(whh), None, None, R, B, H, 32, P(out), P(outr), P(hn), P(cn), P(gates), P(cs), 0, 0, int(os.environ.get('DIC_FWD8', '1')), st), 'proj'))
     t3 = timed(lambda: N.check(L.dic_lstm_bwd(P(whh_t), P(gates), P(cs), None, P(dout), None, None, R, B, H, P(dgx), P(dh0), P(dc0), P(db), P(ws), ws.numel(), 0, 0, st), 'bwd'))

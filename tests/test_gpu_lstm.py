@@ -938,3 +938,30 @@ def test_eight_wave_encoder_recurrence_equals_the_four_wave_kernel(R, B, init, r
         m = live.view(1, Bp // 32, 1, 1, 1, 1, 1, 32, 1).expand_as(a)
         assert torch.equal(a[m], b[m])
     assert torch.isfinite(res[0][0].float()).all()
+
+
+@pytest.mark.parametrize('R,B,init', [(24, 128, True), (5, 64, False), (3, 320, True)])
+def test_eight_wave_decoder_recurrence_equals_the_four_wave_kernel(R, B, init):
+    """dic_lstm_fwd(gx_lane_native=2): eight waves per workgroup on the lane-native gx (every wave stages the 4 pieces of its 16 units per
+    32-row half; two permutation MFMAs per accumulator block) == gx_lane_native=1: out, h_n, c_n, saved gates and cell states bit-equal."""
+    from deep_interpolation_clustering_amd import _native as N
+    L = N.lib()
+    dev, bf = torch.device('cuda'), torch.bfloat16
+    torch.manual_seed(R * 100 + B)
+    gx = (torch.randn(R * B, 8 * H, device=dev) * 0.5).to(bf)
+    whh = (torch.randn(2, 4 * H, H, device=dev) * 0.08).to(bf)
+    h0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    c0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    res = []
+    for mode in (1, 2):
+        ext = torch.full((R + 2, B, 2 * H), float('nan'), device=dev, dtype=bf)
+        out = ext[1:R + 1]
+        gates = torch.zeros(R, B, 2, 4, H, device=dev, dtype=bf)
+        cs = torch.zeros(R, B, 2, H, device=dev, dtype=bf)
+        hn, cn = torch.empty(2, B, H, device=dev), torch.empty(2, B, H, device=dev)
+        N.check(L.dic_lstm_fwd(N.ptr(gx), mode, N.ptr(whh), N.ptr(h0), N.ptr(c0), R, B, H, N.ptr(out), None, N.ptr(hn), N.ptr(cn), N.ptr(gates),
+                               N.ptr(cs), 0, 1, N.stream_of(gx)), 'dic_lstm_fwd')
+        res.append([out.clone(), ext[0, :, :H].clone(), ext[R + 1, :, H:].clone(), hn, cn, gates, cs])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[0][0].float()).all() and float(res[0][0].float().abs().mean()) > 0.01
