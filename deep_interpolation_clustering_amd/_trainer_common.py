@@ -202,10 +202,18 @@ class TrainerBase(object):
         dl = dl if dl is not None else getattr(self, '_last_eval_dl', None)
         sharded = getattr(dl, 'world', 1) > 1
         merged = {}
+        n_local = dl.shard_rows().numel() if sharded else None
         for k in (ob_pred_lst[0].keys() if ob_pred_lst else ()):
             vals = [d[k] for d in ob_pred_lst]
             if torch.is_tensor(vals[0]):
                 t = torch.cat([v.float() for v in vals], dim=0)
+                if sharded and t.shape[0] != n_local:
+                    # not one row per encounter: 'fake_det' holds 2 x batch rows in each batch's own random order (real and corrupted
+                    # samples shuffled by fake_perm_idx, clustering_trainer.py:330-332) -- there is no dataset order to assemble it in
+                    if k not in self.__dict__.setdefault('_skipped_dump_keys', set()):
+                        self._skipped_dump_keys.add(k)
+                        logger.warning('sharded feature pass: key {!r} ({} rows for {} encounters) is left out of the merged record'.format(k, t.shape[0], n_local))
+                    continue
                 merged[k] = (self._all_rows(t, dl) if sharded else t).cpu().numpy()
             elif sharded and k == 'encounter_id':
                 merged[k] = np.asarray(dl.ids)                   # the unshuffled pass covers the cohort in dataset order

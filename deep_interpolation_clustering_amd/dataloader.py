@@ -131,9 +131,10 @@ class DataSet(Dataset):
                 sample[task] = self.auxiliary_dict[task][index]
                 if task == 'future_vital':
                     sample['future_vital_mask'] = self.auxiliary_dict['future_vital_mask'][index]
-        fake_is_sample = fake_sample is sample
+        # dataloader.py:147-148 transforms BOTH dicts -- without fake detection they are the same object, so the augmentation noise
+        # is drawn and added twice on it (kept: it is what upstream's augmented pretraining sees)
         sample = self.transform(sample)
-        fake_sample = sample if fake_is_sample else self.transform(fake_sample)
+        fake_sample = self.transform(fake_sample)
         return sample, fake_sample
 
     def __len__(self):
@@ -236,7 +237,11 @@ class DeviceLoader:
             rows = self.data.index_select(0, idx)
             ob, mask, ts, ae = rows[:, 0:C], rows[:, C:2 * C], rows[:, 2 * C:3 * C], rows[:, 3 * C:4 * C]
             lengths = None if self.lengths is None else self.lengths.index_select(0, idx)
-            if self.ds.transform.aug:
+            aug = self.ds.transform.aug
+            raw_ob, raw_ts = ob, ts
+            # the per-sample Transform of DataSet.__getitem__, batched: the real and the fake sample get independent noise; without
+            # fake detection both names are ONE dict upstream, which therefore receives the noise twice (dataloader.py:147-148)
+            for _ in range(0 if not aug else (1 if self.ds.fake_detection else 2)):
                 ob = self._noise(ob, mask, self.ds.aug_std)
                 ts = self._noise(ts, mask, 0.01)
             sample = {'encounter_id': self.ids[idx_h], 'ob': ob, 'padding_mask': mask, 'timestamp': ts,
@@ -245,7 +250,11 @@ class DeviceLoader:
                 sample[k] = v.index_select(0, idx)
             if self.ds.fake_detection:
                 fake = dict(sample)
-                fake['ob'] = self._fake_ob(ob, mask, lengths)
+                fake['ob'] = self._fake_ob(raw_ob, mask, lengths)         # corrupted copy of the un-augmented values (dataloader.py:131-132)
+                fake['timestamp'] = raw_ts
+                if aug:
+                    fake['ob'] = self._noise(fake['ob'], mask, self.ds.aug_std)
+                    fake['timestamp'] = self._noise(raw_ts, mask, 0.01)
             else:
                 fake = sample
             yield sample, fake

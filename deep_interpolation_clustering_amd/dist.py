@@ -154,6 +154,9 @@ class FlatParams:
             o += n
 
     def zero_grad(self):
+        if self._tail_work is not None:      # a backward that raised after the early all-reduce started: finish it before the bucket is reused
+            self._tail_work.wait()
+            self._tail_work = None
         self.grad.zero_()
         self._attach()          # re-attach in case something replaced .data / .grad
         self._reached = [False] * len(self.params)
@@ -179,11 +182,19 @@ class FlatParams:
         if not is_sharded() or self._split is None or self._tail_work is not None:
             return
         from . import lstm, ops
-        if lstm.side_work_pending():    # the decoder's weight gradients are still being formed on the side stream: one all-reduce at the end instead
-            return
         ops.flush_grad_sinks()          # gradients queued by the decoder-side kernels go into the bucket before its tail leaves
         done = all(r or getattr(p, '_dic_grad_written', False) for r, p in zip(self._reached[self._split_index:], self.params[self._split_index:]))
-        if done and self._split < self.grad.numel():
+        if not (done and self._split < self.grad.numel()):
+            return
+        # the decoder's weight gradients may still be forming on the side stream (bf16 step, lstm.DW_SIDE_STREAM): the collective is then
+        # enqueued BEHIND that stream (which first catches up with everything the main stream has launched so far), so the encoder backward
+        # on the main stream overlaps both the weight-gradient kernel and the all-reduce
+        side = lstm.pending_side_stream(self.grad.device) if self.grad.is_cuda else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(self.grad.device))
+            with torch.cuda.stream(side):
+                self._tail_work = td.all_reduce(self.grad[self._split:], op=td.ReduceOp.SUM, async_op=True)
+        else:
             self._tail_work = td.all_reduce(self.grad[self._split:], op=td.ReduceOp.SUM, async_op=True)
 
     def all_reduce_grads(self):

@@ -83,6 +83,14 @@ def side_work_pending():
     return bool(_SIDE['pending'])
 
 
+def pending_side_stream(dev):
+    """The side stream of ``dev`` if work of the current session is still queued on it, else None."""
+    for s in _SIDE['pending']:
+        if s.device == dev:
+            return s
+    return None
+
+
 def join_side_streams():
     pending, _SIDE['pending'] = _SIDE['pending'], []
     for s in pending:
@@ -101,7 +109,10 @@ def _grad_sinks(params, needs):
     """The tensors the kernels write the parameter gradients into, and whether they ACCUMULATE there.
     When every parameter already owns a dense f32 ``.grad`` (the views of the flat bucket, zeroed at the start of the step) the
     kernels add into it and autograd is handed ``None``; otherwise fresh tensors are returned through autograd."""
-    if all(needs) and all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params):
+    from . import ops
+    # (only inside step.Stepper's own backward -- ops.grad_sink_session: any other caller with populated .grad, e.g. torch.autograd.grad or
+    #  a backward with hooks of its own, gets ordinary gradient tensors through autograd and an untouched .grad)
+    if ops.sink_session_active() and all(needs) and all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params):
         for p in params:
             p._dic_grad_written = True         # dist.FlatParams.active_mask: autograd's accumulate hook will not fire for these
         return [p.grad for p in params], True

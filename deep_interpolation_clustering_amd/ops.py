@@ -68,6 +68,11 @@ def _sink(param, grad):
     return None
 
 
+def sink_session_active():
+    """True inside step.Stepper's backward (grad_sink_session): kernels may then add parameter gradients straight into ``.grad``."""
+    return _SINK['on']
+
+
 def flush_grad_sinks():
     pairs, _SINK['pairs'] = _SINK['pairs'], []
     if not pairs:
@@ -591,6 +596,22 @@ def _dropout_rng(device):
         st = _DROP_STATE[key] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
     st[1:] += 1
     return st.clone()
+
+
+def dropout_state_snapshot(device):
+    """(for step.Stepper's hipGraph warm-up) the dropout call counter of ``device``; ``dropout_state_restore`` puts it back, so the warm-up
+    runs leave no trace in the mask sequence."""
+    st = _DROP_STATE.get((device.type, device.index))
+    return None if st is None else st.clone()
+
+
+def dropout_state_restore(device, snap):
+    key = (device.type, device.index)
+    if snap is None:
+        if key in _DROP_STATE:
+            _DROP_STATE[key][1:] = 0          # created during the warm-up: back to the state a first call expects
+    else:
+        _DROP_STATE[key].copy_(snap)
 
 
 def bn_relu_head(z, bn, linear, relu=True, dropout=None, col_sums=None):

@@ -20,6 +20,9 @@ class Trainer(TrainerBase):
                 train_metrics = self.train_one_epoch(self.train_dl, denoise=self.args.denoise)
                 logger.info('==> Epoch: {}, Train, {}'.format(epoch, format_metric_dict(train_metrics)))
                 valid_metrics, _ = self.eval_one_epoch('valid', self._eval_dl('validation'), denoise=self.args.denoise)
+                # (upstream formats the dict for a debug line here, pretrain_trainer.py:77 -- which ROUNDS it in place to 4 decimals: the
+                #  best-checkpoint comparisons of aly_pred see the rounded values, so ties between epochs resolve as they do upstream)
+                logger.debug('{}'.format(format_metric_dict(valid_metrics)))
                 verdict = self.aly_pred('valid', valid_metrics)
                 self.epoch += 1
                 if verdict['early_stop']:

@@ -72,6 +72,8 @@ class Stepper:
 
     def forward_loss(self, x, ob, padding_mask, lengths=None, fake_x=None, fake_perm_idx=None, positive_x=None,
                      aux_label_dict=None, future_vital_mask=None, fake_det_label=None):
+        if lengths is not None:
+            padding_mask = None           # prefix lengths SAY what the mask is (the trainers hand over both): the kernels never read the plane
         with self._ctx():
             hidden, rec_ob, aux_pred = self.model(x, fake_x, fake_perm_idx, positive_x, lengths=lengths)
         losses = compute_losses(self.model, self.args, hidden, rec_ob, aux_pred, ob, padding_mask, lengths,
@@ -102,6 +104,7 @@ class Stepper:
             snap_buf = [b.clone() for b in self.model.buffers()]
             snap_opt = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.optimizer.state.items()}
             snap_rng = torch.cuda.get_rng_state(static['x'].device)      # dropout / randperm draws of the warm-up must not shift the stream
+            snap_drop = ops.dropout_state_snapshot(static['x'].device)   # ... nor the in-kernel dropout's own call counter (not CUDA RNG state)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -117,6 +120,7 @@ class Stepper:
                         if torch.is_tensor(v):
                             v.copy_(snap_opt[p_][k]) if p_ in snap_opt and k in snap_opt[p_] else v.zero_()
             torch.cuda.set_rng_state(snap_rng, static['x'].device)
+            ops.dropout_state_restore(static['x'].device, snap_drop)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = run()
@@ -137,6 +141,12 @@ class Stepper:
     AUTO_GRAPH_BATCH = 8192
 
     def step(self, x, ob, padding_mask, lengths=None, **kw):
+        """One optimisation step.  Returns (loss terms, gradient norm, latents): device tensors, valid until the next call (a replayed
+        hipGraph writes them in place; a graph evicted from the small cache frees their memory -- clone what must outlive the step).
+        With ``lengths`` (prefix masks, all the loaders produce) ``padding_mask`` is redundant and dropped: the de-interpolation kernels
+        then emit the reconstruction loss themselves."""
+        if lengths is not None:
+            padding_mask = None
         if self.use_graphs and x.is_cuda and (not self.auto_graphs or x.shape[0] <= self.AUTO_GRAPH_BATCH):
             tensors = {'x': x, 'ob': ob}
             if padding_mask is not None:

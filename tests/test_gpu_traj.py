@@ -1,0 +1,286 @@
+"""The trainers, the input pipeline and the feature dump on the GPU against what the REFERENCE's own trainers did on the cfg1 cohort
+(tests/golden/{traj_cfg1,featdump_cfg1,netstep_cfg_K4,netstep_cfg_K8}.npz, written by oracle/make_golden_traj.py running
+pretrain_trainer.Trainer.train(), clustering_trainer.TrainerCluster.train() / .eval() and one joint step of clustering_interp.Net).
+
+  * joint step at the configured shape (C,T,R,H) = (6,96,24,24), pretrained weights, k-means centroids, K = 4 and K = 8:
+    loss / ae_mse / kl at rtol 1e-5 with NO absolute floor (north_star's bar; KL is ~0.1 here);
+  * p1: 16 optimiser steps over 2 epochs with the learning-rate schedule acting in between, both loaders (HBM-resident DeviceLoader
+    and upstream-style torch DataLoader over the DataSet);
+  * p3: k-means initialisation from the reference's checkpoint (centres, validation labels), 24 joint steps, per-epoch label delta,
+    for K = 4 (cfg1) and K = 6 (labels keep moving);
+  * feature dump: the .npy dictionary eval() writes from the reference's checkpoint -- keys, dtypes, shapes, values.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def trainer_args(**over):
+    """The namespace oracle/make_golden_traj.py gave the reference's trainers (+ this package's own switches at their defaults)."""
+    a = dict(log_level='WARNING', seed=7529, num_gpus=1, mode='train', restore=False, restore_metric='ae_mse', log_train_freq=1000,
+             log_valid_freq=1000, hours_from_admission=24, num_workers=0, batch_size=100, norm_method='minmax', aug_input=False,
+             aug_std=0.1, scale=5.0, denoise=False, num_variables=6, num_timestamps=96, data_filter=False, evaluate_interpolation=False,
+             ref_points=24, dropout=0.0, fake_detection=False, triple_margin=0.0, triple_pos_std=0.1, loss='ae_mse', aux_tasks={},
+             unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.}, aux_pos_weights={}, optimizer='Adam', init_lr=0.003,
+             min_lr=1e-6, lr_decay_mode='step', lr_decay_step_or_patience=1, lr_decay_rate=0.5, max_epochs=3, grad_clip=15.0,
+             weight_decay_rate=0.0004, early_stopping=50, amp_bf16=False, hip_graph=None, no_hip_graph=True, host_loader=False)
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+@pytest.fixture(scope='module')
+def run_dir(tmp_path_factory):
+    from deep_interpolation_clustering_amd import dataloader, synthetic
+    base = tmp_path_factory.mktemp('dic_traj')
+    synthetic.write_split(str(base), 1000, C=6, T=96, H=24.0, lam=50.0, G=4)      # the cohort the fixtures were generated on
+    run = base / 'run'
+    run.mkdir()
+    old_cwd, old_base = os.getcwd(), dataloader.BASE_PATH
+    os.chdir(run)
+    dataloader.BASE_PATH = str(base)
+    yield run
+    os.chdir(old_cwd)
+    dataloader.BASE_PATH = old_base
+
+
+def make_loaders(args, dev, kind):
+    from deep_interpolation_clustering_amd.dataloader import DataSet, DeviceLoader
+    out = {}
+    for cohort in ('training', 'validation', 'testing'):
+        ds = DataSet(args, cohort)
+        if kind == 'device':
+            out[cohort] = DeviceLoader(ds, args.batch_size, False, dev, seed=1, shard=False)       # fixed batch order, as in the fixture run
+        else:
+            out[cohort] = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, num_workers=0, shuffle=False)
+    return out
+
+
+def spy_steps(trainer, keys):
+    """Record the loss terms of every optimisation step the trainer takes (they stay device tensors inside the trainer)."""
+    rec, inner = [], trainer.stepper.step
+
+    def step(*a, **k):
+        out = inner(*a, **k)
+        rec.append([out[0][key].detach().clone() for key in keys])
+        return out
+    trainer.stepper.step = step
+    return rec
+
+
+def p1_state():
+    t = load('traj_cfg1.npz')
+    return t, {k[5:]: torch.tensor(v) for k, v in t.items() if k.startswith('p1sd/')}
+
+
+def write_checkpoint(path, state, epoch, optimizer):
+    """Upstream's layout (utils.py:141-145): {'epoch','state_dict','optimizer'} at <exp>/weight/<metric>/model.pth.tar."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({'epoch': epoch, 'state_dict': state, 'optimizer': optimizer.state_dict()}, path)
+
+
+# ---------------------------------------------------------------------------------------------------------------- joint step, cfg shape
+@pytest.mark.parametrize('K', [4, 8])
+@pytest.mark.parametrize('use_lengths', [False, True])
+def test_joint_step_cfg_shape_kmeans_centroids(K, use_lengths):
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    g = load(f'netstep_cfg_K{K}.npz')
+    _, sd = p1_state()
+    sd['cluster_assignment.cluster_centers'] = torch.tensor(g['centers'])
+    args = trainer_args(loss='ae_mse_kl', cluster_number=K)
+    dev = torch.device('cuda')
+    net = Net(args, dev).to(dev)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args)
+    x, ob = torch.tensor(g['x'], device=dev), torch.tensor(g['ob'], device=dev)
+    mask = x[:, 6:12].contiguous()
+    losses, gnorm, z = st.step(x, ob, mask, mask.sum(-1).to(torch.int32) if use_lengths else None)
+    assert float(g['loss_kl']) > 0.05                                   # the p3 regime: KL is O(0.1), not the 1e-4 of Xavier centroids
+    for k in ('loss', 'ae_mse', 'kl'):
+        np.testing.assert_allclose(float(losses[k]), float(g['loss_' + k]), rtol=1e-5, atol=0, err_msg=k)
+    np.testing.assert_allclose(float(gnorm), float(g['gnorm']), rtol=1e-4)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g['z'], rtol=1e-4, atol=2e-6)
+    q = net.cluster_assignment(z.detach())
+    assert (q.argmax(1).cpu().numpy() == g['q'].argmax(1)).all()
+    for k, v in net.state_dict().items():
+        got = v.detach().cpu().numpy()
+        if 'sd1/' + k in g:
+            ref = g['sd1/' + k]
+            if 'g/' + k in g:
+                live = np.abs(g['g/' + k]) >= 1e-4 * float(g['gnorm'])
+                got, ref = got[live], ref[live]
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5, err_msg=k)
+        elif 'sd1n/' + k in g:
+            np.testing.assert_allclose(np.linalg.norm(got.astype(np.float64)), float(g['sd1n/' + k]), rtol=2e-5, err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------------------------- p1 trajectory
+@pytest.mark.parametrize('kind', ['device', 'host'])
+def test_pretrain_trainer_follows_reference(run_dir, kind, tmp_path):
+    from deep_interpolation_clustering_amd.pretrain_interp import Net
+    from deep_interpolation_clustering_amd.pretrain_trainer import Trainer
+    t, sd_end = p1_state()
+    plain = load('netstep_plain.npz')
+    args = trainer_args(host_loader=(kind == 'host'))
+    dev = torch.device('cuda')
+    net = Net(args, dev)
+    net.load_state_dict({k[4:]: torch.tensor(v) for k, v in plain.items() if k.startswith('sd0/') and 'cluster' not in k}, strict=True)
+    exp = str(tmp_path / 'Pretrain')
+    tr = Trainer(args, net, make_loaders(args, dev, kind), exp, dev)
+    rec = spy_steps(tr, ['ae_mse'])
+    valid, lrs, inner = [], [], tr.aly_pred
+
+    def aly(scope, md):
+        valid.append(float(md['ae_mse']))
+        r = inner(scope, md)
+        lrs.append(tr.optimizer.param_groups[0]['lr'])
+        return r
+    tr.aly_pred = aly
+    tr.train()
+    got = np.array([[float(v) for v in row] for row in rec])[:, 0]
+    ref = t['p1/train_ae_mse']
+    assert got.shape == ref.shape == (16,)
+    # two f32 implementations of one Adam(amsgrad) loop separate step by step (rounding noise on near-zero gradients becomes O(lr)
+    # moves); the oracle itself is 3e-5 from the reference by step 5 (tests/test_oracle_golden.py)
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-5)
+    np.testing.assert_allclose(got[:8], ref[:8], rtol=1e-4)
+    np.testing.assert_allclose(got, ref, rtol=1e-3)
+    np.testing.assert_allclose(valid, t['p1/valid_batch_ae_mse'][:, 0], rtol=2e-3)          # eval mode: BatchNorm running statistics in use
+    np.testing.assert_allclose(lrs, t['p1/lr_after_epoch'], rtol=1e-12)
+    for k, v in net.state_dict().items():
+        if v.dtype.is_floating_point and v.numel() > 1:
+            a, b = v.detach().cpu().numpy().astype(np.float64), sd_end[k].numpy().astype(np.float64)
+            assert np.linalg.norm(a - b) <= 3e-3 * np.linalg.norm(b) + 1e-6, k
+    bn = 'rbf.compress_fc.module.model.1.'
+    np.testing.assert_allclose(net.state_dict()[bn + 'running_var'].cpu().numpy(), sd_end[bn + 'running_var'].numpy(), rtol=2e-3)
+    assert int(net.state_dict()[bn + 'num_batches_tracked']) == int(sd_end[bn + 'num_batches_tracked']) == 16
+    # amsgrad running maximum, step count
+    for name, p in net.named_parameters():
+        got_n = float(torch.linalg.vector_norm(tr.optimizer.state[p]['max_exp_avg_sq'].double()))
+        np.testing.assert_allclose(got_n, float(t[f'p1opt/max_exp_avg_sq/{name}']), rtol=1e-2, atol=1e-12, err_msg=name)
+    assert float(next(iter(tr.optimizer.state.values()))['step']) == float(t['p1opt/step'])
+    # the checkpoint: upstream's file layout and key names
+    ck = torch.load(os.path.join(exp, 'weight', 'ae_mse', 'model.pth.tar'), map_location='cpu', weights_only=False)
+    assert set(ck) == {'epoch', 'state_dict', 'optimizer'} and int(ck['epoch']) == int(t['p1/ckpt_epoch'])
+    assert sorted(ck['state_dict'].keys()) == list(t['p1/ckpt_keys'])
+
+
+# ---------------------------------------------------------------------------------------------------------------- p3 trajectory
+@pytest.mark.parametrize('K,tag', [(4, 'p3'), (6, 'p3k6')])
+def test_cluster_trainer_follows_reference(run_dir, K, tag, tmp_path):
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.clustering_trainer import TrainerCluster
+    from deep_interpolation_clustering_amd.utils import set_seed
+    t, sd_p1 = p1_state()
+    args = trainer_args(loss='ae_mse_kl', cluster_number=K, dc_restore_metric='ae_mse', init_cluster_center='kmeans',
+                        stopping_delta=None, update_interval=1, max_epochs=4)
+    dev = torch.device('cuda')
+    set_seed(args.seed)                                            # np.random.seed(7529): the k-means++ draws (p3:110)
+    torch.manual_seed(7529)
+    net = Net(args, dev)
+    pre, exp = str(tmp_path / 'Pretrain'), str(tmp_path / 'Clustering')
+    tr = TrainerCluster(args, net, make_loaders(args, dev, 'device'), exp, pre, dev)
+    write_checkpoint(os.path.join(pre, 'weight', 'ae_mse', 'model.pth.tar'), sd_p1, 2, torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]))
+    rec = spy_steps(tr, ['loss', 'ae_mse', 'kl'])
+    seen = {}
+    inner_init, inner_gpc = tr.init_cluster_center, tr.generate_pred_cluster
+
+    def init_spy(c):
+        seen['centers'] = c.detach().cpu().numpy().copy()
+        return inner_init(c)
+
+    def gpc_spy(scope, dl, prev, denoise=False):
+        seen.setdefault('prev', np.asarray(prev).copy())
+        r = inner_gpc(scope, dl, prev, denoise)
+        seen.setdefault('delta', []).append(r[0])
+        seen.setdefault('labels', []).append(np.asarray(r[1]).copy())
+        return r
+    tr.init_cluster_center, tr.generate_pred_cluster = init_spy, gpc_spy
+    tr.train()
+    # k-means initialisation (clustering_trainer.py:72-82): same restart wins, same cluster order, centres to f32 rounding
+    np.testing.assert_allclose(seen['centers'], t[f'{tag}/kmeans_centers'], rtol=2e-4, atol=2e-5)
+    assert (seen['prev'] == t[f'{tag}/valid_prev_labels']).all()
+    got = np.array([[float(v) for v in row] for row in rec])
+    ref = t[f'{tag}/train_losses']
+    assert got.shape == ref.shape == (24, 3)
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-5, atol=0)                # loss, ae_mse AND kl: no absolute floor
+    np.testing.assert_allclose(got[:8], ref[:8], rtol=2e-4)
+    np.testing.assert_allclose(got, ref, rtol=3e-3)
+    delta, ref_delta = np.array(seen['delta']), t[f'{tag}/delta']
+    if K == 4:
+        assert (delta == ref_delta).all() and all((a == b).all() for a, b in zip(seen['labels'], t[f'{tag}/valid_labels']))
+    else:
+        assert delta[0] == ref_delta[0] and (seen['labels'][0] == t[f'{tag}/valid_labels'][0]).all()
+        assert ref_delta[1] > 0 and np.abs(delta - ref_delta).max() <= 0.03       # over-segmented: a few of 100 labels sit on a boundary
+    assert tr.optimizer.param_groups[0]['lr'] == pytest.approx(float(t[f'{tag}/lr_end']), rel=1e-12)
+    sd = net.state_dict()
+    for key in ('sci.kernel', 'cci.kernel', 'rbf.kernel', 'cluster_assignment.cluster_centers'):
+        np.testing.assert_allclose(sd[key].cpu().numpy(), t[f'{tag}sd/{key}'], rtol=5e-3, atol=5e-4, err_msg=key)
+    for key in (k for k in t if k.startswith(f'{tag}sdn/')):
+        np.testing.assert_allclose(float(torch.linalg.vector_norm(sd[key.split('/', 1)[1]].double())), float(t[key]), rtol=2e-3, err_msg=key)
+
+
+# ---------------------------------------------------------------------------------------------------------------- feature dump
+@pytest.mark.parametrize('kind', ['device', 'host'])
+def test_feature_dump_equals_reference(run_dir, kind, tmp_path):
+    """TrainerCluster.eval('validation', generate_feat=True) from the reference's own p3 checkpoint: the dictionary np.save writes."""
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.clustering_trainer import TrainerCluster
+    f = load('featdump_cfg1.npz')
+    args = trainer_args(loss='ae_mse_kl', cluster_number=4, dc_restore_metric='ae_mse', init_cluster_center='kmeans', mode='eval',
+                        stopping_delta=None, update_interval=1, host_loader=(kind == 'host'))
+    dev = torch.device('cuda')
+    net = Net(args, dev)
+    exp = str(tmp_path / 'Clustering')
+    tr = TrainerCluster(args, net, make_loaders(args, dev, kind), exp, str(tmp_path / 'Pretrain'), dev)
+    state = {k[3:]: torch.tensor(v) for k, v in f.items() if k.startswith('sd/')}
+    assert set(state) == set(net.state_dict())                                        # a reference checkpoint loads key for key
+    write_checkpoint(os.path.join(exp, 'weight', 'ae_mse', 'model.pth.tar'), state, int(f['ckpt_epoch']), tr.optimizer)
+    tr.eval('validation', generate_feat=True, viz_feat=False, denoise=False)
+    dump = np.load(os.path.join(exp, 'out_feat', 'ae_mse', 'validation.npy'), allow_pickle=True).item()
+    assert sorted(dump.keys()) == list(f['keys'])
+    assert tr.epoch == int(f['ckpt_epoch'])
+    for k in f['keys']:
+        got, ref = np.asarray(dump[k]), f[f'dump/{k}']
+        assert got.shape == tuple(f[f'shape/{k}']), k
+        assert str(got.dtype) == str(f[f'dtype/{k}']), (k, got.dtype)
+        if k in ('encounter_id', 'padding_mask', 'timestamp', 'ae_mask'):
+            np.testing.assert_array_equal(got, ref, err_msg=k)
+        elif k == 'ob':                                                               # re_norm_data: back in physiologic units (f32 arithmetic)
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-4, err_msg=k)
+        elif k == 'rec_ob':
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-3, err_msg=k)          # units of mmHg / bpm: values are O(100)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6, err_msg=k)
+    assert (dump['cluster_pred'].argmax(1) == f['dump/cluster_pred'].argmax(1)).all()
+
+
+def test_trainer_takes_the_fused_reconstruction_path(run_dir, tmp_path, monkeypatch):
+    """the trainers hand Stepper BOTH the padding mask and the prefix lengths; the step must still run the de-interpolation
+    kernels that emit the reconstruction loss themselves (ops.rbf_rec_loss) -- what bench.py times -- not the masked-MSE pass."""
+    from deep_interpolation_clustering_amd import ops
+    from deep_interpolation_clustering_amd.pretrain_interp import Net
+    from deep_interpolation_clustering_amd.pretrain_trainer import Trainer
+    args = trainer_args(max_epochs=2)
+    dev = torch.device('cuda')
+    torch.manual_seed(1)
+    net = Net(args, dev)
+    tr = Trainer(args, net, make_loaders(args, dev, 'device'), str(tmp_path / 'P'), dev)
+    calls = {'fused': 0, 'mse': 0}
+    inner_f, inner_m = ops.rbf_rec_loss, ops.masked_mse
+    monkeypatch.setattr(ops, 'rbf_rec_loss', lambda *a, **k: (calls.__setitem__('fused', calls['fused'] + 1), inner_f(*a, **k))[1])
+    monkeypatch.setattr(ops, 'masked_mse', lambda *a, **k: (calls.__setitem__('mse', calls['mse'] + 1), inner_m(*a, **k))[1])
+    tr.train_one_epoch(tr.train_dl, denoise=False)
+    assert calls == {'fused': 8, 'mse': 0}, calls

@@ -184,3 +184,78 @@ def test_kmeans_fixture_matches_installed_sklearn():
         assert (km.labels_ == g['labels']).all()
         np.testing.assert_allclose(km.cluster_centers_, g['centers'], rtol=1e-5, atol=1e-6)
         assert km.n_iter_ == int(g['n_iter'])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# round 3: the configured shape (C,T,R,H) = (6,96,24,24) in the p3 regime (pretrained weights, k-means centroids: KL ~ 0.1),
+# and what the reference's trainers do over several steps (oracle/make_golden_traj.py)
+def _p1_state():
+    t = load('traj_cfg1.npz')
+    return t, {k[5:]: torch.tensor(v) for k, v in t.items() if k.startswith('p1sd/')}
+
+
+@pytest.mark.parametrize('K', [4, 8])
+def test_net_step_cfg_shape_kmeans_centroids(K):
+    """One joint step from the reference's own pretrained state with scikit-learn centroids: every loss term at rtol 1e-5 with
+    NO absolute floor (KL is 0.10 / 0.12 here, well conditioned)."""
+    g = load(f'netstep_cfg_K{K}.npz')
+    _, sd = _p1_state()
+    net = O.OracleNet(6, 24, 24.0, K, 0.0)
+    sd['cluster_assignment.cluster_centers'] = torch.tensor(g['centers'])
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    opt = O.make_optimizer(net)
+    x = T(g['x'])
+    terms, gnorm, z = O.train_step(net, opt, x, T(g['ob']), x[:, 6:12], 10.0, 15.0)
+    assert float(g['loss_kl']) > 0.05
+    for k in ('loss', 'ae_mse', 'kl'):
+        np.testing.assert_allclose(terms[k], float(g['loss_' + k]), rtol=1e-5, atol=0, err_msg=k)
+    np.testing.assert_allclose(gnorm, float(g['gnorm']), rtol=1e-4)
+    np.testing.assert_allclose(z.numpy(), g['z'], rtol=1e-4, atol=1e-6)
+    for k, v in net.state_dict().items():
+        if 'sd1n/' + k in g:
+            np.testing.assert_allclose(np.linalg.norm(v.numpy().astype(np.float64)), float(g['sd1n/' + k]), rtol=1e-5, err_msg=k)
+
+
+def _cohort_batches(tmp_path, cohort='training'):
+    """The cfg1 cohort exactly as oracle/make_golden_traj.py wrote it, as stacked (x, ob) batches of 100 in file order."""
+    from deep_interpolation_clustering_amd import synthetic
+    import pickle
+    synthetic.write_split(str(tmp_path), 1000, C=6, T=96, H=24.0, lam=50.0, G=4)
+    with open(tmp_path / 'Data' / 'model_data' / 'split_processed' / f'{cohort}.pickle', 'rb') as f:
+        d = pickle.load(f)
+    x, ob, _ = synthetic.stacked_batch(d)
+    return [(T(x[i:i + 100]), T(ob[i:i + 100])) for i in range(0, len(x), 100)]
+
+
+def test_oracle_follows_reference_pretrain_trajectory(tmp_path):
+    """pretrain_trainer.Trainer.train_one_epoch x 2 epochs (16 optimiser steps, StepLR halving the rate between them): per-step
+    ae_mse of the oracle's train_step loop against the reference's own loop; amsgrad state norms and parameters at the end."""
+    t, sd_end = _p1_state()
+    plain = load('netstep_plain.npz')
+    net = O.OracleNet(6, 24, 24.0, 4, 0.0, clustering=False)
+    net.load_state_dict({k[4:]: torch.tensor(v) for k, v in plain.items() if k.startswith('sd0/') and 'cluster' not in k}, strict=True)
+    net.train()
+    opt = O.make_optimizer(net)
+    batches = _cohort_batches(tmp_path)
+    got = []
+    for epoch in range(2):
+        for x, ob in batches:
+            terms, _, _ = O.train_step(net, opt, x, ob, x[:, 6:12], 0.0, 15.0)
+            got.append(terms['ae_mse'])
+        opt.param_groups[0]['lr'] *= 0.5                       # StepLR(step_size=1, gamma=0.5) after each epoch (aly_pred)
+    ref = t['p1/train_ae_mse']
+    # Adam(amsgrad) turns f32 rounding noise on (near-)zero-gradient parameters into O(lr) moves, so two f32 implementations of the
+    # same loop separate step by step (the reference's unfused ops against the oracle's closed forms: 3e-5 by step 5)
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-5)
+    np.testing.assert_allclose(got[:8], ref[:8], rtol=1e-4)
+    np.testing.assert_allclose(got, ref, rtol=1e-3)
+    for k, v in net.state_dict().items():
+        if v.dtype.is_floating_point and v.numel() > 1:
+            a, b = v.numpy().astype(np.float64), sd_end[k].numpy().astype(np.float64)
+            assert np.linalg.norm(a - b) <= 2e-3 * np.linalg.norm(b) + 1e-6, k
+    for name, p in net.named_parameters():
+        np.testing.assert_allclose(np.linalg.norm(opt.state[p]['max_exp_avg_sq'].numpy().astype(np.float64)),
+                                   float(t[f'p1opt/max_exp_avg_sq/{name}']), rtol=5e-3, atol=1e-12, err_msg=name)
+    assert float(t['p1opt/step']) == 16 and int(t['p1/ckpt_epoch']) == 2
+    np.testing.assert_allclose(t['p1/lr_after_epoch'], [0.0015, 0.00075])
