@@ -206,7 +206,7 @@ class TrainerBase(object):
         for k in (ob_pred_lst[0].keys() if ob_pred_lst else ()):
             vals = [d[k] for d in ob_pred_lst]
             if torch.is_tensor(vals[0]):
-                t = torch.cat([v.float() for v in vals], dim=0)
+                t = torch.cat([v.float() if v.dtype.is_floating_point else v for v in vals], dim=0)     # (ids keep their integer type)
                 if sharded and t.shape[0] != n_local:
                     # not one row per encounter: 'fake_det' holds 2 x batch rows in each batch's own random order (real and corrupted
                     # samples shuffled by fake_perm_idx, clustering_trainer.py:330-332) -- there is no dataset order to assemble it in

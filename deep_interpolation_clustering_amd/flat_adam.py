@@ -55,9 +55,10 @@ class FlatAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         sd = super().state_dict()
-        for st in sd['state'].values():          # one independent step tensor per parameter, as optim.Adam keeps them (a shared
-            if 'step' in st:                     # one would be incremented once per parameter by its foreach path after loading)
-                st['step'] = st['step'].clone()
+        # one independent step tensor per parameter, as optim.Adam keeps them (a shared one would be incremented once per parameter by
+        # its foreach path after loading).  The per-parameter dicts super() returns ARE the live ones: they are copied, not edited --
+        # editing them left a frozen step count in self.state, and every later checkpoint carried that stale count
+        sd['state'] = {k: ({**st, 'step': st['step'].clone()} if 'step' in st else dict(st)) for k, st in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):

@@ -160,7 +160,9 @@ def test_pretrain_trainer_follows_reference(run_dir, kind, tmp_path):
     np.testing.assert_allclose(valid, t['p1/valid_batch_ae_mse'][:, 0], rtol=2e-3)          # eval mode: BatchNorm running statistics in use
     np.testing.assert_allclose(lrs, t['p1/lr_after_epoch'], rtol=1e-12)
     for k, v in net.state_dict().items():
-        if v.dtype.is_floating_point and v.numel() > 1:
+        # (a bias in front of a training-mode BatchNorm has an exactly-zero true gradient and no effect on the function: what Adam
+        #  makes of it is a random walk driven by rounding noise, in the reference too)
+        if v.dtype.is_floating_point and v.numel() > 1 and k != 'rbf.compress_fc.module.model.0.bias':
             a, b = v.detach().cpu().numpy().astype(np.float64), sd_end[k].numpy().astype(np.float64)
             assert np.linalg.norm(a - b) <= 3e-3 * np.linalg.norm(b) + 1e-6, k
     bn = 'rbf.compress_fc.module.model.1.'
@@ -168,6 +170,8 @@ def test_pretrain_trainer_follows_reference(run_dir, kind, tmp_path):
     assert int(net.state_dict()[bn + 'num_batches_tracked']) == int(sd_end[bn + 'num_batches_tracked']) == 16
     # amsgrad running maximum, step count
     for name, p in net.named_parameters():
+        if name == 'rbf.compress_fc.module.model.0.bias':
+            continue
         got_n = float(torch.linalg.vector_norm(tr.optimizer.state[p]['max_exp_avg_sq'].double()))
         np.testing.assert_allclose(got_n, float(t[f'p1opt/max_exp_avg_sq/{name}']), rtol=1e-2, atol=1e-12, err_msg=name)
     assert float(next(iter(tr.optimizer.state.values()))['step']) == float(t['p1opt/step'])
@@ -259,7 +263,16 @@ def test_feature_dump_equals_reference(run_dir, kind, tmp_path):
         if k in ('encounter_id', 'padding_mask', 'timestamp', 'ae_mask'):
             np.testing.assert_array_equal(got, ref, err_msg=k)
         elif k == 'ob':                                                               # re_norm_data: back in physiologic units (f32 arithmetic)
-            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-4, err_msg=k)
+            m = f['dump/padding_mask'] > 0
+            np.testing.assert_allclose(got[m], ref[m], rtol=1e-6, atol=1e-4, err_msg=k)
+            # padded slots: upstream dumps batch_sample['ob'] AFTER `ob *= padding_mask` (clustering_trainer.py:299-303), which edits the
+            # loader's tensor in place only when `.to(device)` is the identity, i.e. on a CPU run like the one that wrote the fixture
+            # (0 -> mid-range after re_norm_data); on the GPU runs upstream is made for the dump keeps the loader's -scale/2 (-> range minimum),
+            # which is what this package writes
+            lo = np.array([20, 5, 0, 24, 0, 0], np.float32)[None, :, None]              # info.MIN_MAX_VALUES minima
+            mid = np.array([160, 115, 150, 34.5, 50, 30], np.float32)[None, :, None]
+            np.testing.assert_allclose(ref[~m], np.broadcast_to(mid, ref.shape)[~m], rtol=1e-6)
+            np.testing.assert_allclose(got[~m], np.broadcast_to(lo, got.shape)[~m], rtol=1e-6)
         elif k == 'rec_ob':
             np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-3, err_msg=k)          # units of mmHg / bpm: values are O(100)
         else:

