@@ -85,3 +85,24 @@ def test_full_size_properties(cs):
     np.testing.assert_allclose(st.own_max[pick].cpu().numpy(), own.cpu().numpy(), rtol=2e-6)
     s = cs.silhouette_score(xd, lab, st)
     assert -1.0 <= s <= 1.0
+
+
+def test_gap_table_equals_reference(tmp_path):
+    """KM.compute_gap_internal_metric against the table the REFERENCE's own method produced (oracle/make_golden_gap.py; p2:353-410):
+    every column at rtol 1e-5 AND the position of NumPy's global stream afterwards -- i.e. the draw order reference set -> that fit's
+    k-means++ seeds -> next reference set (which this package overlaps with the GPU work on a worker thread) is upstream's."""
+    from deep_interpolation_clustering_amd import p2_clustering_optK as p2
+    from oracle.synth import latent_blobs
+    g = np.load(os.path.join(GOLDEN, 'gap_table_blobs.npz'))
+    X, _ = latent_blobs(int(g['seed']), int(g['N']), int(g['D']), int(g['G']))
+    assert str(X.dtype) == str(g['x_dtype'])
+    cols = [str(c) for c in g['columns']]
+    km = p2.KM(int(g['k_max']), str(tmp_path), cols[5:], int(g['n_init']), int(g['gap_b']))
+    np.random.seed(int(g['np_seed']))
+    df = km.compute_gap_internal_metric(X, int(g['k_max']), n_references=int(g['gap_b']), version=1).astype(float)
+    pos = np.random.random()
+    assert list(df.columns) == cols
+    ref = g['table']
+    assert pos == float(g['stream_pos']), 'the global stream was consumed differently'
+    for j, c in enumerate(cols):
+        np.testing.assert_allclose(df[c].to_numpy(), ref[:, j], rtol=1e-5, atol=1e-5 if c == 'gap' else 0, err_msg=c)   # gap = ref - act
