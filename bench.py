@@ -52,7 +52,11 @@ def parse():
     p.add_argument('--cpu-seconds', type=float, default=15.0)
     p.add_argument('--no-secondary', action='store_true', help='skip the secondary records (cfg4, cfg5, batch256, f32, loss deviation)')
     p.add_argument('--no-sweep', action='store_true', help='skip the p2 K=2..20 sweep inside the cfg5 record')
-    p.add_argument('--kernel-iters', type=int, default=20)
+    p.add_argument('--kernel-iters', type=int, default=5, help='stand-alone launches per kernel of the kernel table (kept few: a rocprofv3 '
+                   'average over this command should be dominated by the launches of the timed steps)')
+    p.add_argument('--scaling', choices=['weak', 'strong'], default=os.environ.get('DIC_BENCH_SCALING', 'weak'),
+                   help='weak (default): --encounters resident and --batch per step PER GPU.  strong: ONE cohort of --encounters sharded over the '
+                        'ranks and a fixed GLOBAL batch of --batch per step (BASELINE configs[2]: 75k encounters, K=8, on 8 GPUs)')
     return p.parse_args()
 
 
@@ -370,6 +374,9 @@ def record_loss_deviation(K, dev):
     for mode, dt in (('f32', None), ('bf16', torch.bfloat16)):
         torch.manual_seed(0)
         ref = O.OracleNet(C, R, H, K, 0.0)
+        with torch.no_grad():       # the p3 regime: centroids sit on the latents' clusters (here: phenotype means), KL is O(0.1) and well conditioned
+            zs, gl = ref.encode(x)[3], torch.tensor(coh['phenotype'].astype(np.int64))
+            ref.cluster_assignment.cluster_centers.copy_(torch.stack([zs[gl == j].mean(0) for j in range(K)]))
         ref.train()
         net = Net(args, dev).to(dev)
         net.load_state_dict(ref.state_dict(), strict=True)
@@ -379,6 +386,7 @@ def record_loss_deviation(K, dev):
         losses, _, _ = st.step(x.to(dev), ob.to(dev), None, torch.tensor(n, device=dev))
         torch.cuda.synchronize()
         out[mode] = {k: float(abs(float(losses[k].detach()) - rterms[k]) / max(abs(rterms[k]), 1e-30)) for k in ('loss', 'ae_mse', 'kl')}
+        out[mode]['oracle_kl'] = rterms['kl']
     return out
 
 
@@ -419,11 +427,39 @@ def record_cfg5(dev, sweep=True):
         status[:, 7] = 1e9
         ws = torch.empty(L.dic_kmeans_workspace(n, 256, Kk, runs), dtype=torch.uint8, device=dev)
         st = N.stream_of(Xc)
-        ms = time_kernel(lambda: L.dic_kmeans_lloyd_iter(N.ptr(Xc), N.ptr(xn), n, 256, Kk, runs, N.ptr(cent), N.ptr(labels), N.ptr(status),
-                                                         N.ptr(ws), ws.numel(), st), 20)
-        nbytes = runs * n * (4 * 256 + 4)
+        cent0 = cent.clone()
+
+        def reset():
+            # every timed launch starts from the same state: fresh random-point centres, no labels, status cleared -- a restart that has
+            # converged sets its done flag and later launches skip it, which would bill bytes for work that is not done (round 2's 1.67)
+            cent.copy_(cent0)
+            labels.fill_(-1)
+            status.zero_()
+            status[:, 7] = 1e9
+
+        def launch():
+            return L.dic_kmeans_lloyd_iter(N.ptr(Xc), N.ptr(xn), n, 256, Kk, runs, N.ptr(cent), N.ptr(labels), N.ptr(status), N.ptr(ws), ws.numel(), st)
+        iters, tot, active = 20, 0.0, []
+        for it in range(3 + iters):
+            reset()
+            launch()                                     # iteration 1 from the random-point centres (every point changes label)
+            n_act = int((status[:, 0] == 0).sum())       # (host sync) restarts that will do a full iteration in the timed launch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch()                                     # iteration 2: the timed one -- all restarts still active (checked below)
+            e1.record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                tot += e0.elapsed_time(e1)
+                active.append(n_act)
+        ms = tot / iters
+        n_active = min(active)
+        nbytes = n_active * n * (4 * 256 + 4)           # billed for the restarts that were still running when the timed launch began
         out['lloyd_iter'][f'K{Kk}_x{runs}_restarts'] = {'ms': round(ms, 5), 'algorithmic_bytes': nbytes, 'GBps': round(nbytes / ms / 1e6, 1),
-                                                       'frac_hbm_peak': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                                                       'frac_hbm_peak': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), 'active_restarts': n_active,
+                                                       'note': 'second Lloyd iteration from fresh random-point centres, state reset before every timed '
+                                                               'launch; X (77 MB) is re-read by every restart from the 256 MB Infinity Cache / L2, not '
+                                                               'from HBM: a fraction of the HBM peak above ~0.8 here is cache bandwidth'}
     from sklearn.cluster import KMeans as SK
     from threadpoolctl import threadpool_limits
     cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get('DIC_CPU_THREADS', 16))))
@@ -475,6 +511,17 @@ def guarded(fn, *a, **kw):
         return {'error': repr(e)[:300]}
 
 
+def cpu_model():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.lower().startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or 'unknown'
+
+
 def cpu_baseline(K, seconds, B=256, threads=None, max_steps=200):
     """The CPU oracle (a port of the reference's PyTorch path: oracle/dic_oracle.py) timed on this host.
     B = 256 is the reference's own batch size (p1_pretrain_main.py:43); SURVEY.md 8d also asks for B = 2048 and for 8 threads."""
@@ -504,7 +551,12 @@ def cpu_baseline(K, seconds, B=256, threads=None, max_steps=200):
         el = time.perf_counter() - t0
         if el >= seconds or n >= max_steps:
             break
-    return {'value': round(B * n / el, 1), 'unit': 'encounters/s', 'cores': cores, 'kind': 'port',
+    try:
+        host_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        host_cores = os.cpu_count() or 1
+    return {'value': round(B * n / el, 1), 'unit': 'encounters/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
+            'cores_available': host_cores,
             'sample': f'{n} joint steps of B={B} (C={C}, T={T}, R={R}, K={K}, f32) on torch-CPU, {el:.1f} s',
             'ms_per_step': round(1e3 * el / n, 2)}
 
@@ -538,13 +590,25 @@ def main():
     gemm_table = (not a.no_tuned_gemm) and a.dtype == 'bf16' and tuned.enable()      # read-only: pre-tuned hipBLASLt / rocBLAS picks
 
     # ---- cohort shard, resident in HBM before anything is timed
-    n_enc = max(a.encounters, a.batch)
-    coh = synthetic.make_cohort(n_enc, C=C, T=T, H=H, lam=LAM, G=K, seed=synthetic.SEED + rank)
-    x_np, ob_np, len_np = synthetic.stacked_batch(coh)
+    strong = a.scaling == 'strong'
+    if strong:
+        # ONE cohort (BASELINE configs[2]: 75k encounters) sharded over the ranks as DeviceLoader shards it -- contiguous row ranges --
+        # and a fixed GLOBAL batch: every rank takes global_batch / world rows of its shard per step
+        n_total = max(a.encounters, a.batch)
+        coh = synthetic.make_cohort(n_total, C=C, T=T, H=H, lam=LAM, G=K, seed=synthetic.SEED)       # same seed on every rank: one cohort
+        x_np, ob_np, len_np = synthetic.stacked_batch(coh)
+        lo_r, hi_r = dist.shard_bounds(n_total, rank % world, world)
+        x_np, ob_np, len_np = x_np[lo_r:hi_r], ob_np[lo_r:hi_r], len_np[lo_r:hi_r]
+        a.batch = max(1, a.batch // world)                     # per-rank share of the global batch from here on
+        n_enc = hi_r - lo_r
+    else:
+        n_enc = max(a.encounters, a.batch)
+        coh = synthetic.make_cohort(n_enc, C=C, T=T, H=H, lam=LAM, G=K, seed=synthetic.SEED + rank)
+        x_np, ob_np, len_np = synthetic.stacked_batch(coh)
     X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(len_np, device=dev)
     del coh, x_np, ob_np
-    nb = n_enc // a.batch
-    log(f'rank {rank}: cohort of {n_enc} encounters resident after {time.perf_counter() - t_start:.1f}s')
+    nb = max(1, n_enc // a.batch)
+    log(f'rank {rank}: {n_enc} encounters resident after {time.perf_counter() - t_start:.1f}s ({a.scaling} scaling, {a.batch} per step and rank)')
 
     torch.manual_seed(1234)
     net = Net(args, dev).to(dev)
@@ -626,7 +690,27 @@ def main():
                 elif name in ('row_proj', 'row_proj_stats', 'lstm_fwd', 'lstm_fwd_proj'):
                     launches = launches / 2            # one template, two instantiations (decoder / encoder, gx / CompressFC), one launch each
             per_step[name] = launches * row['ms']
+        # duration of each table kernel INSIDE the timed step (per-dispatch GPU timestamps of the trace: what rocprofv3 --kernel-trace
+        # reports for those launches), where it shares the chip with whatever runs beside it (the decoder's weight-gradient kernel on
+        # the side stream); the stand-alone HIP-event figure stays in the table
+        in_step_ms = {}
+        for name in table:
+            if kernels is None:
+                break
+            own = {'lstm_fwd': 'dic::lstm_fwd8_gxn_kernel', 'lstm_fwd_proj': 'dic::lstm_fwd8_proj_kernel'}.get(name)
+            pref = own if (own is not None and any(k.startswith(own) for k in kernels)) else trace_name[name]
+            hits = [v for k, v in kernels.items() if k.startswith(pref)]
+            if name in ('row_proj', 'row_proj_stats') or (own is None and name in ('lstm_fwd', 'lstm_fwd_proj')):
+                continue                               # one kernel name, two shapes: the trace cannot tell their durations apart
+            n_l = sum(v['launches_per_step'] for v in hits)
+            if n_l > 0:
+                in_step_ms[name] = sum(v['ms_per_step'] for v in hits) / n_l
+                per_step[name] = n_l * in_step_ms[name]
+                table[name]['ms_in_step'] = round(in_step_ms[name], 5)
+                table[name]['frac_hbm_peak_in_step'] = round(table[name]['algorithmic_bytes'] / in_step_ms[name] / 1e6 / HBM_PEAK_GBS, 4)
         dom = max(per_step, key=per_step.get)
+        dom_ms = in_step_ms.get(dom, table[dom]['ms'])
+        dom_gbps = table[dom]['algorithmic_bytes'] / dom_ms / 1e6
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')      # PMC-derived HBM bytes per launch (see its _note)
         if os.path.exists(tf):
@@ -640,22 +724,27 @@ def main():
         out = {
             'metric': 'encounters/sec per joint interp+DEC step', 'value': round(value, 1), 'unit': 'encounters/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
             'dtype': a.dtype, 'dtype_note': 'HIP kernels compute in f32; bf16 = torch.autocast for the bi-LSTMs / FC heads only '
                                             '(outside the 1e-5 parity configuration: see loss_rel_dev_vs_oracle)',
             'data': 'synthetic',
-            'config': {'workload': f'{n_enc} synthetic encounters/GPU, 6 vitals, ~50 irregular samples per channel per 24h '
+            'config': {'workload': (f'{n_enc} of ONE {max(a.encounters, a.batch * world)}-encounter synthetic cohort per GPU' if strong else f'{n_enc} synthetic encounters/GPU') +
+                                   ', 6 vitals, ~50 irregular samples per channel per 24h '
                                    f'(T={T}), R={R}, K={K}, loss ' + ('ae_mse+fake_detect+10*kl' if a.fake_detection else 'ae_mse+10*kl'), 'per_gpu_batch': a.batch,
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single',
                        'tuned_gemm_table': bool(gemm_table)},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': table[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': table[dom]['frac_hbm_peak'], 'traffic': traffic, 'traffic_source': traffic_src,
-                         'ms_per_launch': table[dom]['ms'], 'ms_per_step': round(per_step[dom], 4),
-                         'chosen_by': 'launches per step (trace of the timed step) x HIP-event duration',
-                         'note': 'ms_per_launch is the stand-alone duration (HIP events around back-to-back launches on one stream).  Inside the step the '
-                                 'encoder-side launch of this kernel shares the chip with lstm_dw_wide on a side stream (DIC_DW_SIDE_STREAM=0 turns that '
-                                 'off): a rocprofv3 average over the whole bench command mixes both; its Min column and '
-                                 'profiles/*single_stream_kernel_stats.csv are the stand-alone figure'},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(dom_gbps, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(dom_gbps / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                         'ms_per_launch': round(dom_ms, 5), 'ms_per_step': round(per_step[dom], 4),
+                         'algorithmic_bytes_per_launch': table[dom]['algorithmic_bytes'],
+                         'duration_source': 'in-step: per-dispatch durations of this kernel in a trace of the timed step' if dom in in_step_ms
+                                            else 'stand-alone HIP events (no step trace available)',
+                         'frac_standalone': table[dom]['frac_hbm_peak'], 'ms_per_launch_standalone': table[dom]['ms'],
+                         'chosen_by': 'launches per step x in-step duration (trace of the timed step)',
+                         'note': 'frac = algorithmic bytes per launch / the duration this kernel has INSIDE the timed step, where its encoder-side '
+                                 'launch shares the chip with lstm_dw_wide on a side stream (DIC_DW_SIDE_STREAM=0 turns that off); frac_standalone = '
+                                 'HIP events around back-to-back launches on an otherwise idle chip.  The rocprofv3 average of this command '
+                                 '(profiles/) mixes the two in the proportion of their launch counts'},
             'kernels': table,
             'whole_step': {'gflop_per_step_dense(lstm+fc, fwd+bwd)': round(gflop, 1), 'tflops': round(gflop / ms, 1),
                            'frac_bf16_mfma_peak(2500 TF)': round(gflop / ms / 2500.0, 4),

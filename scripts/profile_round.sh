@@ -3,7 +3,7 @@
 #   bash scripts/profile_round.sh 2
 # Counters are collected in passes of their own (--pmc with --kernel-trace only), as gpurun requires.
 set -e
-R=${1:-2}
+R=${1:-3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_r$R
 mkdir -p $OUT
@@ -35,4 +35,18 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU 
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/sq2 -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
 python3 $ROOT/scripts/pmc_sq.py $OUT/kernels_pmc_sq.json /tmp/sq1/p_counter_collection.csv /tmp/sq2/p_counter_collection.csv > $OUT/kernels_pmc_sq.txt
 echo "[profile] SQ counters done"
+# 5. the k-means kernels on cfg5's own data: kernel statistics + HBM traffic (the Lloyd record of bench.py's cfg5)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/km_stats -o k -- python3 $ROOT/scripts/kmeans_prof.py 5 > $OUT/kmeans_prof.txt 2>&1
+cp /tmp/km_stats/k_kernel_stats.csv $OUT/kmeans_cfg5_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/km_fetch -o p -- python3 $ROOT/scripts/kmeans_prof.py 3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/km_write -o p -- python3 $ROOT/scripts/kmeans_prof.py 3 > /dev/null 2>&1
+python3 $ROOT/scripts/pmc_generic.py /tmp/km_fetch/p_counter_collection.csv /tmp/km_write/p_counter_collection.csv kmeans > $OUT/kmeans_cfg5_pmc_traffic.json
+echo "[profile] cfg5 k-means done"
+# 6. cfg4 (C=12, T=288, ~200 obs/channel, K=16): k1 / k2 / k3 kernel statistics + HBM traffic at its batch of 8192
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c4_stats -o k -- python3 $ROOT/scripts/kbench.py 8192 5 16 12 288 200 nolstm > $OUT/cfg4_kbench.txt 2>&1
+cp /tmp/c4_stats/k_kernel_stats.csv $OUT/cfg4_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/c4_fetch -o p -- python3 $ROOT/scripts/kbench.py 8192 3 16 12 288 200 nolstm > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/c4_write -o p -- python3 $ROOT/scripts/kbench.py 8192 3 16 12 288 200 nolstm > /dev/null 2>&1
+python3 $ROOT/scripts/pmc_generic.py /tmp/c4_fetch/p_counter_collection.csv /tmp/c4_write/p_counter_collection.csv 'sci_cci|rbf_|masked_sse|dec_' > $OUT/cfg4_pmc_traffic.json
+echo "[profile] cfg4 done"
 ls -la $OUT
