@@ -54,6 +54,8 @@ def parse():
     p.add_argument('--no-sweep', action='store_true', help='skip the p2 K=2..20 sweep inside the cfg5 record')
     p.add_argument('--kernel-iters', type=int, default=5, help='stand-alone launches per kernel of the kernel table (kept few: a rocprofv3 '
                    'average over this command should be dominated by the launches of the timed steps)')
+    p.add_argument('--dense-input', action='store_true', help='feed the step padded (B,4C,T) batches instead of reading the ragged encounter '
+                   'store in place (A/B of the input path; the default is what the trainers run on a DeviceLoader)')
     p.add_argument('--scaling', choices=['weak', 'strong'], default=os.environ.get('DIC_BENCH_SCALING', 'weak'),
                    help='weak (default): --encounters resident and --batch per step PER GPU.  strong: ONE cohort of --encounters sharded over the '
                         'ranks and a fixed GLOBAL batch of --batch per step (BASELINE configs[2]: 75k encounters, K=8, on 8 GPUs)')
@@ -606,6 +608,10 @@ def main():
         coh = synthetic.make_cohort(n_enc, C=C, T=T, H=H, lam=LAM, G=K, seed=synthetic.SEED + rank)
         x_np, ob_np, len_np = synthetic.stacked_batch(coh)
     X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(len_np, device=dev)
+    # the cohort as the trainers' DeviceLoader keeps it: a ragged store (observed samples only, packed); a batch = an index range into it
+    from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore
+    store = None if a.dense_input else RaggedStore(x_np, C, dev)
+    IDX = torch.arange(n_enc, device=dev, dtype=torch.int32)
     del coh, x_np, ob_np
     nb = max(1, n_enc // a.batch)
     log(f'rank {rank}: {n_enc} encounters resident after {time.perf_counter() - t_start:.1f}s ({a.scaling} scaling, {a.batch} per step and rank)')
@@ -627,10 +633,14 @@ def main():
 
     def one_step(i):
         lo = (i % nb) * a.batch
+        if store is not None:
+            xb, obb = RaggedBatch(store, IDX[lo:lo + a.batch], LEN[lo:lo + a.batch]), None
+        else:
+            xb, obb = X[lo:lo + a.batch], OB[lo:lo + a.batch]
         if XF is None:
-            return stepper.step(X[lo:lo + a.batch], OB[lo:lo + a.batch], None, LEN[lo:lo + a.batch])
+            return stepper.step(xb, obb, None, LEN[lo:lo + a.batch])
         perm = torch.randperm(2 * a.batch, device=dev)                       # as the trainers draw it (pretrain_trainer.py:156-160)
-        return stepper.step(X[lo:lo + a.batch], OB[lo:lo + a.batch], None, LEN[lo:lo + a.batch], fake_x=XF[lo:lo + a.batch],
+        return stepper.step(xb, obb, None, LEN[lo:lo + a.batch], fake_x=XF[lo:lo + a.batch],
                             fake_perm_idx=perm, fake_det_label=label2[perm].to(torch.int64))
 
     def barrier():
@@ -732,7 +742,9 @@ def main():
                                    ', 6 vitals, ~50 irregular samples per channel per 24h '
                                    f'(T={T}), R={R}, K={K}, loss ' + ('ae_mse+fake_detect+10*kl' if a.fake_detection else 'ae_mse+10*kl'), 'per_gpu_batch': a.batch,
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single',
-                       'tuned_gemm_table': bool(gemm_table)},
+                       'tuned_gemm_table': bool(gemm_table),
+                       'input': 'padded (B,4C,T) batches' if store is None else
+                                f'ragged encounter store read in place ({store.nbytes() / 1e6:.0f} MB resident; the padded array would be {n_enc * 4 * C * T * 4 / 1e6:.0f} MB)'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(dom_gbps, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(dom_gbps / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                          'ms_per_launch': round(dom_ms, 5), 'ms_per_step': round(per_step[dom], 4),

@@ -20,6 +20,7 @@ from . import dist, ops
 from . import lstm as fused_lstm
 from .dec import ClusterAssignment, target_distribution
 from .interpolation_layer import CrossChannelInterp, SingleChannelInterp, fused_forward
+from .ragged import is_ragged
 from .rbf import RBF, basis_func_dict
 from .utils import logger
 
@@ -159,9 +160,13 @@ class NetBase(nn.Module):
 
     def forward(self, x, fake_x=None, fake_perm_idx=None, positive_x=None, lengths=None):
         """x (B,4C,T) -> (cat_hidden (B,256), rec (B,C,T), aux_pred_dict); clustering_interp.py:134-189.
-        ``lengths`` (B,C) int32 is an optional side channel: prefix lengths of the padding mask."""
+        ``lengths`` (B,C) int32 is an optional side channel: prefix lengths of the padding mask.
+        ``x`` may be a ``ragged.RaggedBatch``: the interpolation / de-interpolation kernels then read the encounters' observed samples
+        in place from the device-resident ragged store (no padded (B,4C,T) tensor exists on that path)."""
         args = self.args
         B = x.size(0)
+        if is_ragged(x):
+            lengths = x.lengths
         packed = self._packed_path(x)
         feats = [self._interp(x, lengths, packed)]
         want_fake = bool(args.fake_detection)
@@ -230,6 +235,8 @@ class NetBase(nn.Module):
         fused, self._fused_rec = self._fused_rec, None
         if fused is not None and fused[0] is rec_ob and padding_mask is None and org_ob is self.rec_target:
             return {'loss': fused[1], 'ae_mse': fused[1]}          # came out of the de-interpolation kernel (forward)
+        if is_ragged(org_ob):                                      # (evaluation passes: the observations as a padded tensor after all)
+            lengths, org_ob = org_ob.lengths, org_ob.ob_dense()
         mse = ops.masked_mse(org_ob, rec_ob, padding_mask, lengths, prefix_only=self.internal_step and padding_mask is None)
         return {'loss': mse, 'ae_mse': mse}
 

@@ -98,6 +98,15 @@ class TrainerBase(object):
         dist.all_reduce_sum_(full)
         return full.to(kind)
 
+    @staticmethod
+    def _densify(s):
+        """A ragged-only sample + the padded per-batch tensors upstream's loader yields, rebuilt from the store."""
+        rb = s['ragged']
+        rows, C = rb.store.dense_rows(rb.idx), rb.store.C
+        s = dict(s)
+        s.update(ob=rows[:, 0:C], padding_mask=rows[:, C:2 * C], timestamp=rows[:, 2 * C:3 * C], ae_mask=rows[:, 3 * C:4 * C])
+        return s
+
     def _to_device(self, sample):
         return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in sample.items()}
 
@@ -115,10 +124,23 @@ class TrainerBase(object):
         """Everything the model and the loss switch need for one batch, on the device."""
         args = self.args
         s = self._to_device(batch_sample)
-        ob, x = self._stack(s, denoise)
-        out = dict(x=x, ob=ob, padding_mask=s['padding_mask'], lengths=s.get('lengths'), sample=s,
-                   fake_x=None, fake_perm_idx=None, positive_x=None, fake_det_label=None,
-                   aux_label_dict={}, future_vital_mask=None)
+        rb = s.get('ragged')
+        if rb is not None and 'ob' not in s and not train:
+            s = self._densify(s)                       # evaluation records dump the padded tensors (clustering_trainer.py:409-416)
+        if rb is not None and 'ob' not in s:
+            # ragged-only sample (DeviceLoader on a ragged store, training pass of a plain objective): the kernels read the store in
+            # place through the batch handle; no padded tensor is built.  `ob=None`: the observations are the batch itself
+            out = dict(x=rb.with_denoise(denoise), ob=None, padding_mask=None, lengths=rb.lengths, sample=s,
+                       fake_x=None, fake_perm_idx=None, positive_x=None, fake_det_label=None, aux_label_dict={}, future_vital_mask=None)
+        else:
+            ob, x = self._stack(s, denoise)
+            if rb is not None:
+                x = rb.with_denoise(denoise)           # same samples, read from the store instead of from the padded copy
+                if train:
+                    ob = None                          # (the training step takes its observations from the store too)
+            out = dict(x=x, ob=ob, padding_mask=s['padding_mask'], lengths=s.get('lengths'), sample=s,
+                       fake_x=None, fake_perm_idx=None, positive_x=None, fake_det_label=None,
+                       aux_label_dict={}, future_vital_mask=None)
         if args.fake_detection:
             f = self._to_device(fake_batch_sample)
             assert np.array_equal(np.asarray(f['encounter_id']), np.asarray(s['encounter_id'])), 'Encounter_id dose not match.'
@@ -126,13 +148,14 @@ class TrainerBase(object):
             fob = f['ob'] * mask
             first = fob * f['ae_mask'] if denoise else fob
             out['fake_x'] = torch.cat([first, f['padding_mask'], f['timestamp'], f['ae_mask']], dim=1)
-            B = ob.size(0)
+            B = out['x'].size(0)
             label = torch.cat([torch.ones(B, device=self.device), torch.zeros(B, device=self.device)])
             perm = torch.randperm(2 * B, device=self.device)                   # shuffle the real / fake rows
             out['fake_perm_idx'] = perm
             out['fake_det_label'] = label[perm].to(torch.int64)
         if getattr(args, 'triple_margin', 0.) != 0. and args.fake_detection:
             assert args.scale == 20, 'The noise gaussian config should be adjusted.'
+            ob = s['ob'] * s['padding_mask']
             nob = self.add_gaussian_noise(ob, s['padding_mask'], {'std': args.triple_pos_std})
             nts = self.add_gaussian_noise(s['timestamp'], s['padding_mask'], {'std': 0.01})
             out['positive_x'] = torch.cat([nob, s['padding_mask'], nts, s['ae_mask']], dim=1)
@@ -182,7 +205,7 @@ class TrainerBase(object):
                 for k, v in losses.items():
                     sums[k] = sums[k] + v
                 n_batches += 1
-                rec = {k: v for k, v in b['sample'].items() if k != 'lengths'}      # inputs + labels, as upstream dumps them
+                rec = {k: v for k, v in b['sample'].items() if k not in ('lengths', 'ragged')}      # inputs + labels, as upstream dumps them
                 rec.update(aux_pred)
                 rec['hidden'], rec['rec_ob'] = hidden, rec_ob
                 ob_pred_lst.append(rec)

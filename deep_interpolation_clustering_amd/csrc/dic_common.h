@@ -120,6 +120,21 @@ __device__ __forceinline__ float channel_sum_er(const float* buf, int Ev, int C,
     return s;
 }
 
+// A ragged encounter store in HBM (the device-resident form of dataloader.py:54-79's feed_data): for every
+// (encounter, channel) row only the observed samples, packed back to back.  `enc_idx` maps the rows of a batch to store encounters
+// (NULL: the batch is encounters 0..B-1), so a shuffled batch is read in place -- no gather pass, no padded (B,4C,T) copy.
+// The packed arrays carry >= 64 readable elements behind the last row (clamped look-ahead reads stay in bounds).
+struct StoreSrc {
+    const float* t_pk;               // time stamps (h)
+    const float* v_pk;               // values: ob * mask, rescaled
+    const unsigned char* hold_pk;    // optional hold-out flags (plane 3): a denoising step feeds v * hold to the model, the target stays v
+    const int64_t* row_off;          // (N*C + 1)
+    const int32_t* enc_idx;          // (B) or NULL
+};
+__device__ __forceinline__ int64_t store_row_off(const StoreSrc& s, int e, int c, int C) {
+    return s.row_off[(size_t)(s.enc_idx ? s.enc_idx[e] : e) * C + c];
+}
+
 // XCD-aware block remap (8 XCDs, round-robin dispatch): consecutive logical tiles land on the
 // same XCD so neighbouring rows share that XCD's L2.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -23,7 +23,7 @@
 namespace dic {
 
 struct InterpLayout {   // LDS carve-up, identical on host and device
-    int cnt, alpha, refg, kmat, res, mean, lse, amat, obs;   // offsets in 4-byte words
+    int cnt, roff, alpha, refg, kmat, res, mean, lse, amat, obs;   // offsets in 4-byte words
     int stride;                                              // float2 elements per staged row
     int total_words;
 };
@@ -38,6 +38,8 @@ __host__ __device__ inline InterpLayout interp_layout(int E, int C, int R, int T
     InterpLayout L;
     int o = 0;
     L.cnt = o;   o += E * C + 1;   // +1: tile maximum
+    o = (o + 1) & ~1;
+    L.roff = o;  o += 2 * E * C;   // int64 offset of each row in the packed arrays of a ragged store
     L.alpha = o; o += C;
     L.refg = o;  o += R;
     L.kmat = o;  o += C * C;
@@ -54,7 +56,8 @@ __host__ __device__ inline InterpLayout interp_layout(int E, int C, int R, int T
 
 struct InterpArgs {
     const float* x; const int32_t* lengths; int T;                   // dense stacked input
-    const float* t_pk; const float* v_pk; const int64_t* row_off;     // packed ragged input
+    const float* t_pk; const float* v_pk; const int64_t* row_off;     // packed ragged input (with `lengths`: the batch's (B,C) row lengths)
+    const unsigned char* hold_pk; const int32_t* enc_idx;             // ... read in place from an encounter store (StoreSrc, dic_common.h)
     int B, C, R, Tcap, E, S, logS;
     const float* ref_grid; const float* sci_kernel; const float* cci_kernel;
     float* out; float* saved;
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
     const InterpLayout L = interp_layout(E, C, R, Tcap);
     const int stride = L.stride;
     int* cnt = reinterpret_cast<int*>(smem + L.cnt);
+    int64_t* roff = reinterpret_cast<int64_t*>(smem + L.roff);
     float* alpha = smem + L.alpha;
     float* refg = smem + L.refg;
     float* kmat = smem + L.kmat;
@@ -156,8 +160,12 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
     for (int i = tid; i < nrows; i += kBlock) {
         const size_t g = (size_t)e0 * C + i;
         int n;
-        if (RAGGED) n = (int)(a.row_off[g + 1] - a.row_off[g]);
-        else n = a.lengths ? a.lengths[g] : a.T;
+        if (RAGGED) {
+            const int e = i / C, c = i - e * C;
+            const size_t gs = (size_t)(a.enc_idx ? a.enc_idx[e0 + e] : e0 + e) * C + c;
+            roff[i] = a.row_off[gs];
+            n = a.lengths ? a.lengths[g] : (int)(a.row_off[gs + 1] - a.row_off[gs]);
+        } else n = a.lengths ? a.lengths[g] : a.T;
         n = max(0, min(n, Tcap));
         cnt[i] = n;
         atomicMax(tile_max, n);
@@ -178,7 +186,31 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
         const int units = nrows * nchunk;
         const int wave = tid >> 6, lane = tid & 63;
         constexpr int NW = kBlock / kWave, G = 4;
-        if (!RAGGED && a.lengths) {
+        if (RAGGED) {
+            // ragged store: the same shape of loop as for the prefix-masked dense input below -- the loads of a trip go out back to back
+            // from addresses clamped INTO the row (an empty row reads the element behind it: the store keeps a readable tail)
+            for (int u0 = wave * G; u0 < units; u0 += NW * G) {
+                float tt[G], vv[G];
+                int dst[G];
+                bool valid[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const int u = __builtin_amdgcn_readfirstlane(min(u0 + k, units - 1));
+                    const int row = u / nchunk, ch = u - row * nchunk;
+                    const int i = ch * kWave + lane;
+                    const int n = cnt[row];
+                    const int64_t off = roff[row] + min(i, max(n - 1, 0));
+                    tt[k] = a.t_pk[off];
+                    vv[k] = a.v_pk[off];
+                    if (a.hold_pk) vv[k] *= (float)a.hold_pk[off];          // denoising step: held-out samples enter as 0 (pretrain_trainer.py:139-141)
+                    dst[k] = (u0 + k < units && i < npad) ? row * stride + i : -1;
+                    valid[k] = i < n;
+                }
+#pragma unroll
+                for (int k = 0; k < G; ++k)
+                    if (dst[k] >= 0) obs[dst[k]] = valid[k] ? make_float2(tt[k], vv[k]) : make_float2(kMaskedTime, 0.f);
+            }
+        } else if (a.lengths) {
             // dense input with prefix masks (what the trainers produce): every address is known up front, so the 8 loads of a trip go out
             // back to back from clamped (always valid) addresses with wave-uniform row bases, and the padding is selected away afterwards
             for (int u0 = wave * G; u0 < units; u0 += NW * G) {
@@ -217,10 +249,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
                     if (i < npad) {
                         dst[k] = row * stride + i;
                         if (i < cnt[row]) {
-                            if (RAGGED) {
-                                const int64_t off = a.row_off[(size_t)e0 * C + row] + i;
-                                val[k] = make_float2(a.t_pk[off], a.v_pk[off]);
-                            } else {
+                            {
                                 const int e = row / C, c = row - e * C;
                                 const float* base = a.x + (size_t)(e0 + e) * 4 * C * a.T;
                                 const float t = base[(size_t)(2 * C + c) * a.T + i];
@@ -726,6 +755,20 @@ int dic_sci_cci_fwd_ragged(const float* t_pk, const float* v_pk, const int64_t* 
     InterpArgs a{};
     a.t_pk = t_pk; a.v_pk = v_pk; a.row_off = row_off; a.B = B; a.C = C; a.R = R; a.Tcap = max_len;
     a.ref_grid = ref_grid; a.sci_kernel = sci_kernel; a.cci_kernel = cci_kernel; a.out = out; a.saved = saved;
+    return interp_fwd_launch(a, true, (hipStream_t)stream);
+}
+
+int dic_sci_cci_fwd_store(const float* t_pk, const float* v_pk, const uint8_t* hold_pk, const int64_t* row_off, const int32_t* enc_idx,
+                          const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid, const float* sci_kernel,
+                          const float* cci_kernel, float* out, float* saved, void* xenc, int xw, dic_stream_t stream) {
+    DIC_REQUIRE(t_pk && v_pk && row_off, DIC_ERR_INVALID_ARG, "sci_cci_fwd_store: NULL store pointer");
+    DIC_REQUIRE(!xenc || (cci_kernel && xw % 8 == 0 && xw > 3 * C && xw <= 64), DIC_ERR_INVALID_ARG,
+                "sci_cci_fwd_store: packed rows need cci_kernel and a width that is a multiple of 8 above 3C = %d (got %d)", 3 * C, xw);
+    InterpArgs a{};
+    a.t_pk = t_pk; a.v_pk = v_pk; a.hold_pk = hold_pk; a.row_off = row_off; a.enc_idx = enc_idx; a.lengths = lengths;
+    a.B = B; a.C = C; a.R = R; a.Tcap = T; a.T = T;
+    a.ref_grid = ref_grid; a.sci_kernel = sci_kernel; a.cci_kernel = cci_kernel; a.out = out; a.saved = saved;
+    a.xenc = (__bf16*)xenc; a.xw = xw;
     return interp_fwd_launch(a, true, (hipStream_t)stream);
 }
 

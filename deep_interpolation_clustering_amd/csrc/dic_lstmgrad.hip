@@ -422,15 +422,39 @@ __global__ __launch_bounds__(512) void lstm_dw_wide_kernel(DwWideArgs a) {
             }
 }
 
+// One thread per FOUR consecutive outputs (16-B loads: a wave reads 1 KiB of each partial row), fixed-order f64 sums over the nch
+// partial rows with eight loads in flight.  (Round 2 ran this through reduce_partials_32x8 -- 32 outputs x 8 slices per workgroup, made
+// for a handful of outputs over thousands of rows: 100 MB of partials in 128-B pieces took 217 us per step, 0.46 TB/s.)
 __global__ __launch_bounds__(256) void lstm_dw_wide_finalize(const float* partials, int nch, LstmGrads g, float beta) {
-    __shared__ double red[256];
-    const double s = reduce_partials_32x8(partials, nch, WD_OUT, blockIdx.x * 32, red);
-    const int i = blockIdx.x * 32 + threadIdx.x;
-    if (threadIdx.x >= 32 || i >= WD_OUT) return;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= WD_OUT) return;
+    double ch[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ch[k][e] = 0.0;
+    const float* src = partials + i;
+    int b = 0;
+    for (; b + 8 <= nch; b += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(src + (size_t)(b + k) * WD_OUT);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ch[k][0] += (double)v[k].x; ch[k][1] += (double)v[k].y; ch[k][2] += (double)v[k].z; ch[k][3] += (double)v[k].w; }
+    }
+    for (; b < nch; ++b) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)b * WD_OUT);
+        ch[0][0] += (double)v.x; ch[0][1] += (double)v.y; ch[0][2] += (double)v.z; ch[0][3] += (double)v.w;
+    }
     const int part = i / (DMH * DNW), rem = i - part * (DMH * DNW), m = (part & 1) * DMH + rem / DNW, n = rem % DNW, d = part >> 1;
-    float* dst = n < GH ? g.w_hh[d] + (size_t)m * GH + n : g.w_ih[d] + (size_t)m * DXW + (n - GH);
-    *dst = beta != 0.f ? fmaf(beta, *dst, (float)s) : (float)s;
+    float* dst = n < GH ? g.w_hh[d] + (size_t)m * GH + n : g.w_ih[d] + (size_t)m * DXW + (n - GH);      // (n .. n+3 stay on one side: GH % 4 == 0)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double s = ((ch[0][e] + ch[1][e]) + (ch[2][e] + ch[3][e])) + ((ch[4][e] + ch[5][e]) + (ch[6][e] + ch[7][e]));
+        dst[e] = beta != 0.f ? fmaf(beta, dst[e], (float)s) : (float)s;
+    }
 }
+static_assert(WD_OUT % 4 == 0 && DNW % 4 == 0 && GH % 4 == 0, "four outputs per thread");
 
 static int dw_wide_chunks(int R, int B) {
     const int ntiles = (int)(((long)R * B + TR - 1) / TR);
@@ -584,7 +608,7 @@ int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int x_
     hipStream_t st = (hipStream_t)stream;
     DwWideArgs a{(const __bf16*)dgx, (const __bf16*)out_ext, (const __bf16*)x, (float*)workspace, R, B, x_relu != 0};
     hipLaunchKernelGGL(lstm_dw_wide_kernel, dim3(nch, 4), dim3(512), WD_LDS, st, a);
-    hipLaunchKernelGGL(lstm_dw_wide_finalize, dim3((WD_OUT + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, g, accumulate ? 1.0f : 0.0f);
+    hipLaunchKernelGGL(lstm_dw_wide_finalize, dim3((WD_OUT / 4 + 255) / 256), dim3(256), 0, st, (const float*)workspace, nch, g, accumulate ? 1.0f : 0.0f);
     return check_launch("lstm_dw_wide");
 }
 

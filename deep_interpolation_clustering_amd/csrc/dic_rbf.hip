@@ -23,9 +23,11 @@ struct RbfArgs {
     int v_rbc;                                   // v is laid out (R,B,C) -- the row order CompressFC produces it in -- instead of (B,C,R)
     const float* ob;                             // optional (B,C,T) observations: the reconstruction loss rides along (Net.rec_loss,
     double* sse_part;                            //   clustering_interp.py:197-203): per-workgroup [sum (y - ob)^2, #valid] over the valid slots
+    StoreSrc st;                                 // st.row_off != NULL: time stamps (and, with `ob` set, the observations = st.v_pk) are read in
+                                                 //   place from the ragged encounter store instead of x / ob; y and norm stay (B,C,T)
 };
 
-__host__ __device__ inline int rbf_fwd_words(int E, int C, int R) { return E * C * R + R + C + E * C; }
+__host__ __device__ inline int rbf_fwd_words(int E, int C, int R) { return ((E * C * R + R + C + E * C + 1) & ~1) + 2 * E * C; }
 
 // CT / RT: compile-time channel / grid-point counts (0 = run time).  The kernels decode (encounter, channel, grid point, slot) from flat
 // indices everywhere; with the reference's shapes (C = 6 or 12, R = 24) as constants those divisions become multiply-shifts.
@@ -37,6 +39,7 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
     float* refg = vs + E * C * R;      // [R]
     float* nbeta = refg + R;           // [C]  -beta*log2(e)
     int* cnt = reinterpret_cast<int*>(nbeta + C);   // [E*C]
+    int64_t* roff = reinterpret_cast<int64_t*>(smem + ((E * C * R + R + C + E * C + 1) & ~1));      // [E*C] row offsets in a ragged store
     const int tid = threadIdx.x, e0 = blockIdx.x * E, Ev = min(E, a.B - e0), nrows = Ev * C;
 
     if (a.v_rbc) {
@@ -49,8 +52,10 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
     }
     for (int i = tid; i < R; i += kBlock) refg[i] = a.ref_grid[i];
     for (int i = tid; i < C; i += kBlock) nbeta[i] = -softplus_raw(a.rbf_kernel[i]) * kLog2e;
-    for (int i = tid; i < nrows; i += kBlock)
+    for (int i = tid; i < nrows; i += kBlock) {
         cnt[i] = a.lengths ? max(0, min(a.lengths[(size_t)e0 * C + i], T)) : T;
+        if (a.st.row_off) roff[i] = store_row_off(a.st, e0 + i / C, i % C, C);
+    }
     __syncthreads();
 
     const int nchunk = (T + kWave - 1) / kWave, units = nrows * nchunk;
@@ -63,12 +68,20 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
         if (i >= T) continue;
         if (a.prefix_only && (u - row * nchunk) * kWave >= cnt[row]) continue;      // wave-uniform: the whole chunk is padding
         const int e = row / C, c = row - e * C;
-        const float* base = a.x + (size_t)(e0 + e) * 4 * C * T;
         bool valid = i < cnt[row];
         float t = 0.f;
-        if (valid) {
-            t = base[(size_t)(2 * C + c) * T + i];
-            if (!a.lengths) valid = base[(size_t)(C + c) * T + i] != 0.f;
+        const float* obrow;                          // the row's observations (dereferenced on valid slots of the fused loss only)
+        if (a.st.row_off) {
+            const int64_t off = roff[row];
+            if (valid) t = a.st.t_pk[off + i];
+            obrow = a.st.v_pk + off;
+        } else {
+            const float* base = a.x + (size_t)(e0 + e) * 4 * C * T;
+            if (valid) {
+                t = base[(size_t)(2 * C + c) * T + i];
+                if (!a.lengths) valid = base[(size_t)(C + c) * T + i] != 0.f;
+            }
+            obrow = a.ob + ((size_t)(e0 + e) * C + c) * T;
         }
         float N = 0.f, S = 0.f;
         if (valid) {
@@ -87,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
         a.y[o] = valid ? S * inv : 0.f;
         if (a.norm) a.norm[o] = valid ? inv : 0.f;
         if (a.ob && valid) {
-            const float d = S * inv - a.ob[o];
+            const float d = S * inv - obrow[i];
             sse = fmaf(d, d, sse);
             nvalid += 1.f;
         }
@@ -131,6 +144,7 @@ struct RbfBwdArgs {
     int v_rbc;                                   // v and grad_v are laid out (R,B,C) instead of (B,C,R)
     // the fused reconstruction loss (dic_rbf_bwd_loss): grad_y is not materialised, dL/dy = 2 grad_loss (y - ob) / #valid on the valid slots
     const float* ob; const float* sse_count; const float* grad_loss;
+    StoreSrc st;                                 // st.row_off != NULL: time stamps (and the observations of the fused loss) come from the store
 };
 
 struct RbfBwdLayout { int cnt, refg, nbeta, vs, gbeta, obs, stride, total_words; };
@@ -214,8 +228,15 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_kernel(RbfBwdArgs a) {
 #ifdef DIC_K2_EXP_NOSTAGE     // experiment: no global loads in the staging phase
                     tv[k] = (float)ic; gy[k] = 1.f; nm[k] = 0.5f; yv[k] = (float)o;
 #else
-                    tv[k] = a.x[((size_t)(e0 + e) * 4 * C + 2 * C + c) * T + ic];
-                    gy[k] = a.ob ? a.ob[o] : a.grad_y[o]; nm[k] = a.norm[o]; yv[k] = a.y[o];
+                    if (a.st.row_off) {           // (clamped to the row: the store keeps 64 readable elements behind its last row for empty rows)
+                        const int64_t so = store_row_off(a.st, e0 + e, c, C) + min(ic, max(cnt[row] - 1, 0));
+                        tv[k] = a.st.t_pk[so];
+                        gy[k] = a.ob ? a.st.v_pk[so] : a.grad_y[o];
+                    } else {
+                        tv[k] = a.x[((size_t)(e0 + e) * 4 * C + 2 * C + c) * T + ic];
+                        gy[k] = a.ob ? a.ob[o] : a.grad_y[o];
+                    }
+                    nm[k] = a.norm[o]; yv[k] = a.y[o];
 #endif
                 }
 #pragma unroll
@@ -330,7 +351,9 @@ constexpr int WU = DIC_K2_WAVE_U;      // slots per lane and trip of the (slot, 
 // (Packed arithmetic was tried here -- slot planes read in pairs by ds_read2_b32, 7 v_pk_*_f32 + 2 v_exp_f32 per slot pair: 140 us
 //  against 122 us for this scalar loop at the same occupancy.  v_pk_*_f32 saves instruction slots on gfx950, not cycles, and the
 //  pair operands cost registers, i.e. occupancy.)
-template <int C, int R>
+// STORE: time stamps (and the observations of the fused loss) come from the ragged encounter store (a.st) -- a variant of its own, so
+// that the dense variant keeps its scalar-register budget (the kernel lives at the SGPR limit).
+template <int C, int R, bool STORE>
 __global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
     constexpr int S = kRbfWaveSplit, ROUNDS = C * R * S / kWave, QPR = kWave / S;       // QPR (row, grid point) pairs per round
     static_assert(C * R * S % kWave == 0, "an encounter must be a whole number of wave rounds");
@@ -360,15 +383,35 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
 
     float pt[C], pg[C], pn[C], py[C], pv[ROUNDS];
     int plen[C];
+    // store mode: the C rows of an encounter lie back to back in the packed arrays: one 64-bit base + 32-bit deltas per staged encounter;
+    // the encounter index of the NEXT request is fetched one encounter ahead (index -> offsets -> samples is a chain of dependent loads)
+    int64_t pbase = 0;
+    int pdelta[C];
+    int enc_next = 0;
+    constexpr bool from_store = STORE;
+    auto store_enc = [&](int e) { return a.st.enc_idx ? a.st.enc_idx[e] : e; };
     auto request = [&](int e) {
+        if (STORE) {
+            const int64_t* ro = a.st.row_off + (size_t)enc_next * C;
+            pbase = ro[0];
+#pragma unroll
+            for (int c = 0; c < C; ++c) pdelta[c] = (int)(ro[c] - pbase);
+            if (e + nwaves < B) enc_next = store_enc(e + nwaves);
+        }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const size_t o = ((size_t)e * C + c) * T + ic;
 #ifdef DIC_K2_EXP_NOSTAGE
             pt[c] = (float)ic; pg[c] = 1.f; pn[c] = 0.5f; py[c] = (float)o;
 #else
-            pt[c] = a.x[((size_t)e * 4 * C + 2 * C + c) * T + ic];
-            pg[c] = gsrc[o]; pn[c] = a.norm[o]; py[c] = a.y[o];
+            if (STORE) {                   // lane <= 63 slots past the row start: inside the store's padding even for its last row
+                pt[c] = a.st.t_pk[pbase + pdelta[c] + ic];
+                pg[c] = a.ob ? a.st.v_pk[pbase + pdelta[c] + ic] : gsrc[o];
+            } else {
+                pt[c] = a.x[((size_t)e * 4 * C + 2 * C + c) * T + ic];
+                pg[c] = gsrc[o];
+            }
+            pn[c] = a.norm[o]; py[c] = a.y[o];
 #endif
             plen[c] = a.lengths[(size_t)e * C + c];
         }
@@ -376,6 +419,7 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
         for (int k = 0; k < ROUNDS; ++k) pv[k] = a.v[(size_t)e * vstep + voff[k]];
     };
     const int e_first = blockIdx.x * (kBlock / kWave) + wave;
+    if (STORE && e_first < B) enc_next = store_enc(e_first);
     if (e_first < B) request(e_first);
 
     for (int e = e_first; e < B; e += nwaves) {
@@ -403,8 +447,10 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
                     if (i < n[c]) {
                         const size_t o = ((size_t)e * C + c) * T + i;
                         const float yo = a.y[o];
-                        const float w = (a.ob ? gscale * (yo - gsrc[o]) : gsrc[o]) * a.norm[o];
-                        val = make_float4(a.x[((size_t)e * 4 * C + 2 * C + c) * T + i], w, w * yo, 0.f);
+                        const float gsv = (from_store && a.ob) ? a.st.v_pk[pbase + pdelta[c] + i] : gsrc[o];
+                        const float w = (a.ob ? gscale * (yo - gsv) : gsv) * a.norm[o];
+                        const float tt = from_store ? a.st.t_pk[pbase + pdelta[c] + i] : a.x[((size_t)e * 4 * C + 2 * C + c) * T + i];
+                        val = make_float4(tt, w, w * yo, 0.f);
                     }
                     obs[c * stride + i] = val;
                 }
@@ -586,7 +632,7 @@ static int rbf_fwd_launch(RbfArgs a, float* out2, hipStream_t st) {
     const int B = a.B, C = a.C, T = a.T, R = a.R;
     DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_fwd: non-positive size");
     DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_fwd: C=%d R=%d", C, R);
-    DIC_REQUIRE(a.x && a.ref_grid && a.rbf_kernel && a.v && a.y, DIC_ERR_INVALID_ARG, "rbf_fwd: NULL pointer");
+    DIC_REQUIRE((a.x || a.st.row_off) && a.ref_grid && a.rbf_kernel && a.v && a.y, DIC_ERR_INVALID_ARG, "rbf_fwd: NULL pointer");
     const dim3 grid(rbf_fwd_grid(B, C, R, &a.E));
     const size_t lds = (size_t)rbf_fwd_words(a.E, C, R) * 4;
     if (C == 6 && R == 24) hipLaunchKernelGGL((rbf_fwd_kernel<6, 24>), grid, dim3(kBlock), lds, st, a);
@@ -615,6 +661,18 @@ int dic_rbf_fwd_loss(const float* x, const int32_t* lengths, int B, int C, int T
     DIC_REQUIRE(workspace_bytes >= dic_rbf_fwd_loss_workspace(B, C, T, R), DIC_ERR_WORKSPACE, "rbf_fwd_loss: workspace too small");
     RbfArgs a{x, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm, (prefix_only && lengths) ? 1 : 0, v_time_major != 0, ob, (double*)workspace};
     return rbf_fwd_launch(a, out2, (hipStream_t)stream);
+}
+
+int dic_rbf_fwd_store(const float* t_pk, const float* v_pk, const int64_t* row_off, const int32_t* enc_idx, const int32_t* lengths,
+                      int B, int C, int T, int R, const float* ref_grid, const float* rbf_kernel, const float* v, int v_time_major,
+                      int with_loss, float* y, float* norm, int prefix_only, float* out2, void* workspace, size_t workspace_bytes,
+                      dic_stream_t stream) {
+    DIC_REQUIRE(t_pk && v_pk && row_off && lengths, DIC_ERR_INVALID_ARG, "rbf_fwd_store: NULL store pointer / lengths");
+    DIC_REQUIRE(!with_loss || (out2 && workspace), DIC_ERR_INVALID_ARG, "rbf_fwd_store: the fused loss needs out2 and a workspace");
+    DIC_REQUIRE(!with_loss || workspace_bytes >= dic_rbf_fwd_loss_workspace(B, C, T, R), DIC_ERR_WORKSPACE, "rbf_fwd_store: workspace too small");
+    RbfArgs a{nullptr, lengths, B, C, T, R, 1, ref_grid, rbf_kernel, v, y, norm, prefix_only ? 1 : 0, v_time_major != 0,
+              with_loss ? v_pk : nullptr, with_loss ? (double*)workspace : nullptr, StoreSrc{t_pk, v_pk, nullptr, row_off, enc_idx}};
+    return rbf_fwd_launch(a, with_loss ? out2 : nullptr, (hipStream_t)stream);
 }
 
 static void rbf_bwd_geometry(int B, int C, int T, int R, int* E, int* nblk, size_t* lds) {
@@ -649,10 +707,11 @@ size_t dic_rbf_bwd_workspace(int B, int C, int T, int R) {
 static int rbf_bwd_launch(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
                           const float* rbf_kernel, const float* v, int v_time_major, const float* y, const float* norm, const float* grad_y,
                           const float* ob, const float* sse_count, const float* grad_loss,
-                          float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+                          float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream,
+                          const StoreSrc* store = nullptr) {
     DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_bwd: non-positive size");
     DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_bwd: C=%d R=%d", C, R);
-    DIC_REQUIRE(x && ref_grid && rbf_kernel && v && y && norm && (grad_y || ob) && grad_v && grad_rbf_kernel && workspace,
+    DIC_REQUIRE((x || store) && ref_grid && rbf_kernel && v && y && norm && (grad_y || ob) && grad_v && grad_rbf_kernel && workspace,
                 DIC_ERR_INVALID_ARG, "rbf_bwd: NULL pointer");
     DIC_REQUIRE(!ob || (lengths && sse_count && grad_loss), DIC_ERR_INVALID_ARG, "rbf_bwd_loss: needs lengths, sse_count and grad_loss");
     RbfBwdArgs a{};
@@ -660,11 +719,13 @@ static int rbf_bwd_launch(const float* x, const int32_t* lengths, int B, int C, 
     a.ref_grid = ref_grid; a.rbf_kernel = rbf_kernel; a.v = v; a.y = y; a.norm = norm; a.grad_y = grad_y;
     a.grad_v = grad_v; a.partials = (float*)workspace; a.v_rbc = v_time_major != 0;
     a.ob = ob; a.sse_count = sse_count; a.grad_loss = grad_loss;
+    if (store) a.st = *store;
     size_t lds;
     hipStream_t st = (hipStream_t)stream;
     if (lengths && (size_t)B * C * R < ((size_t)1 << 31) && rbf_bwd_wave_geometry(B, C, T, R, &a.nblk, &lds)) {
         DIC_REQUIRE(workspace_bytes >= (size_t)a.nblk * C * sizeof(float), DIC_ERR_WORKSPACE, "rbf_bwd: workspace too small");
-        hipLaunchKernelGGL((rbf_bwd_wave_kernel<6, 24>), dim3(a.nblk), dim3(kBlock), lds, st, a);
+        if (store) hipLaunchKernelGGL((rbf_bwd_wave_kernel<6, 24, true>), dim3(a.nblk), dim3(kBlock), lds, st, a);
+        else hipLaunchKernelGGL((rbf_bwd_wave_kernel<6, 24, false>), dim3(a.nblk), dim3(kBlock), lds, st, a);
         hipLaunchKernelGGL(rbf_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)workspace, a.nblk, C, rbf_kernel,
                            grad_rbf_kernel);
         return check_launch("rbf_bwd");
@@ -716,6 +777,17 @@ int dic_rbf_bwd_loss(const float* x, const int32_t* lengths, int B, int C, int T
     DIC_REQUIRE(ob, DIC_ERR_INVALID_ARG, "rbf_bwd_loss: ob is NULL");
     return rbf_bwd_launch(x, lengths, B, C, T, R, ref_grid, rbf_kernel, v, v_time_major, y, norm, nullptr, ob, sse_count, grad_loss, grad_v,
                           grad_rbf_kernel, workspace, workspace_bytes, stream);
+}
+
+int dic_rbf_bwd_store(const float* t_pk, const float* v_pk, const int64_t* row_off, const int32_t* enc_idx, const int32_t* lengths,
+                      int B, int C, int T, int R, const float* ref_grid, const float* rbf_kernel, const float* v, int v_time_major,
+                      const float* y, const float* norm, const float* grad_y, const float* sse_count, const float* grad_loss,
+                      float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(t_pk && v_pk && row_off && lengths, DIC_ERR_INVALID_ARG, "rbf_bwd_store: NULL store pointer / lengths");
+    const StoreSrc st{t_pk, v_pk, nullptr, row_off, enc_idx};
+    // grad_y == NULL: the fused reconstruction loss -- the observations are the store's values
+    return rbf_bwd_launch(nullptr, lengths, B, C, T, R, ref_grid, rbf_kernel, v, v_time_major, y, norm, grad_y, grad_y ? nullptr : v_pk,
+                          sse_count, grad_loss, grad_v, grad_rbf_kernel, workspace, workspace_bytes, stream, &st);
 }
 
 size_t dic_masked_sse_workspace(int B, int C, int T) {

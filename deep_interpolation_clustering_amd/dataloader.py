@@ -157,11 +157,24 @@ class DeviceLoader:
 
     When the job is sharded (one process per GPU) each rank iterates its contiguous shard of every global batch."""
 
-    def __init__(self, ds: DataSet, batch_size, shuffle, device, drop_last=False, seed=None, shard=True, keep_every_row=False):
+    def __init__(self, ds: DataSet, batch_size, shuffle, device, drop_last=False, seed=None, shard=True, keep_every_row=False,
+                 ragged='auto', dense_samples=None):
+        """``ragged`` ('auto' / True / False): keep the cohort as a ``ragged.RaggedStore`` (observed samples only, packed) instead of the
+        padded (N,4C,T) array -- 'auto': whenever the cohort is prefix-masked with constant padding (what p0 writes).  Every sample dict
+        then carries ``'ragged'``, a ``RaggedBatch`` the kernels read the store through.  ``dense_samples`` (None = automatic): also
+        rebuild the padded per-batch tensors ('ob', 'padding_mask', 'timestamp', 'ae_mask'); automatic = only where something consumes
+        them (unshuffled = evaluation / dump passes, fake-detection copies, augmentation)."""
         from . import dist
+        from .ragged import RaggedStore
         self.ds, self.batch_size, self.shuffle, self.device, self.drop_last = ds, int(batch_size), shuffle, device, drop_last
         self.C = ds.num_features
-        self.data = torch.as_tensor(ds.feed_data, dtype=torch.float32, device=device)        # (N,4C,T)
+        use_store = ragged is True or (ragged == 'auto' and torch.device(device).type == 'cuda' and ds.prefix_masks
+                                       and RaggedStore.fits(ds.feed_data, self.C))
+        if ragged is True and not RaggedStore.fits(ds.feed_data, self.C):
+            raise ValueError('DeviceLoader(ragged=True): the cohort is not prefix-masked with constant padding')
+        self.store = RaggedStore(ds.feed_data, self.C, device) if use_store else None
+        self.data = None if use_store else torch.as_tensor(ds.feed_data, dtype=torch.float32, device=device)        # (N,4C,T)
+        self.dense_samples = dense_samples
         self.lengths = torch.as_tensor(ds.lengths, device=device) if ds.prefix_masks else None
         self.ids = np.asarray(ds.encounter_ids)
         self.aux = {}
@@ -234,10 +247,23 @@ class DeviceLoader:
         for b in range(len(self)):
             _, _, lo, hi = self._bounds(b)
             idx, idx_h = order[lo:hi], order_h[lo:hi].numpy()
-            rows = self.data.index_select(0, idx)
-            ob, mask, ts, ae = rows[:, 0:C], rows[:, C:2 * C], rows[:, 2 * C:3 * C], rows[:, 3 * C:4 * C]
             lengths = None if self.lengths is None else self.lengths.index_select(0, idx)
             aug = self.ds.transform.aug
+            rb = None
+            if self.store is not None:
+                from .ragged import RaggedBatch
+                rb = RaggedBatch(self.store, idx, lengths)
+                dense = self.dense_samples if self.dense_samples is not None else (not self.shuffle or self.ds.fake_detection or aug)
+                if not dense:          # the training pass of the plain objectives: nothing reads the padded tensors
+                    sample = {'encounter_id': self.ids[idx_h], 'lengths': lengths, 'ragged': rb}
+                    for k, v in self.aux.items():
+                        sample[k] = v.index_select(0, idx)
+                    yield sample, sample
+                    continue
+                rows = self.store.dense_rows(idx)
+            else:
+                rows = self.data.index_select(0, idx)
+            ob, mask, ts, ae = rows[:, 0:C], rows[:, C:2 * C], rows[:, 2 * C:3 * C], rows[:, 3 * C:4 * C]
             raw_ob, raw_ts = ob, ts
             # the per-sample Transform of DataSet.__getitem__, batched: the real and the fake sample get independent noise; without
             # fake detection both names are ONE dict upstream, which therefore receives the noise twice (dataloader.py:147-148)
@@ -248,8 +274,11 @@ class DeviceLoader:
                       'ae_mask': ae, 'lengths': lengths}
             for k, v in self.aux.items():
                 sample[k] = v.index_select(0, idx)
+            if rb is not None and not aug:
+                sample['ragged'] = rb             # (augmented values exist as padded tensors only)
             if self.ds.fake_detection:
                 fake = dict(sample)
+                fake.pop('ragged', None)
                 fake['ob'] = self._fake_ob(raw_ob, mask, lengths)         # corrupted copy of the un-augmented values (dataloader.py:131-132)
                 fake['timestamp'] = raw_ts
                 if aug:

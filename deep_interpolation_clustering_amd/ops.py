@@ -24,6 +24,7 @@ import torch
 
 from . import _native as N
 from . import dist
+from .ragged import is_ragged
 
 
 def _ws(nbytes, device):
@@ -38,6 +39,13 @@ def _lengths_arg(lengths, B, C, device):
     if lengths.numel() != B * C:
         raise ValueError(f'lengths must have B*C={B * C} entries, got {tuple(lengths.shape)}')
     return lengths
+
+
+def _store_ptrs(rb, hold=True):
+    """(t_pk, v_pk[, hold_pk], row_off, enc_idx, lengths) pointers of a ragged.RaggedBatch for the dic_*_store entry points."""
+    st = rb.store
+    head = (N.ptr(st.t_pk), N.ptr(st.v_pk)) + ((N.ptr(st.hold_pk) if rb.denoise else None,) if hold else ())
+    return head + (N.ptr(st.row_off), N.ptr(rb.idx), N.ptr(rb.lengths))
 
 
 def ref_grid(hours, ref_points, device):
@@ -113,20 +121,26 @@ class _SciCci(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sci_kernel, cci_kernel, grid, lengths):
         N.require_gpu(x, sci_kernel, grid)
-        x = N.f32c(x)
+        store = is_ragged(x)                      # a ragged.RaggedBatch: the rows are read in place from the encounter store
+        if not store:
+            x = N.f32c(x)
         B, C4, T = x.shape
         C = sci_kernel.numel()
         if C4 != 4 * C:
             raise ValueError(f'stacked input must be (B, 4*{C}, T), got {tuple(x.shape)}')
         R = grid.numel()
-        lengths = _lengths_arg(lengths, B, C, x.device)
+        lengths = None if store else _lengths_arg(lengths, B, C, x.device)
         sk = N.f32c(sci_kernel.detach())
         ck = None if cci_kernel is None else N.f32c(cci_kernel.detach())
         need_grad = any(ctx.needs_input_grad)
         out = torch.empty((B, R, 3 * C), device=x.device, dtype=torch.float32)
         saved = torch.empty((B, 7, C, R), device=x.device, dtype=torch.float32) if need_grad else None
-        N.check(N.lib().dic_sci_cci_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck),
-                                        N.ptr(out), N.ptr(saved), N.stream_of(x)), 'dic_sci_cci_fwd')
+        if store:
+            N.check(N.lib().dic_sci_cci_fwd_store(*_store_ptrs(x), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), N.ptr(out), N.ptr(saved),
+                                                  None, 0, N.stream_of(out)), 'dic_sci_cci_fwd_store')
+        else:
+            N.check(N.lib().dic_sci_cci_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck),
+                                            N.ptr(out), N.ptr(saved), N.stream_of(x)), 'dic_sci_cci_fwd')
         ctx.dims = (B, C, R)
         ctx.has_cci = ck is not None
         ctx.save_for_backward(saved, sk, ck)
@@ -167,7 +181,9 @@ class _SciCciPacked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sci_kernel, cci_kernel, grid, lengths):
         N.require_gpu(x, sci_kernel, cci_kernel, grid)
-        x = N.f32c(x)
+        store = is_ragged(x)
+        if not store:
+            x = N.f32c(x)
         B, C4, T = x.shape
         C = sci_kernel.numel()
         if C4 != 4 * C:
@@ -175,13 +191,17 @@ class _SciCciPacked(torch.autograd.Function):
         if 3 * C >= PACKED_WIDTH:
             raise ValueError(f'packed rows hold at most {PACKED_WIDTH - 1} features, got 3C = {3 * C}')
         R = grid.numel()
-        lengths = _lengths_arg(lengths, B, C, x.device)
+        lengths = None if store else _lengths_arg(lengths, B, C, x.device)
         sk, ck = N.f32c(sci_kernel.detach()), N.f32c(cci_kernel.detach())
         need_grad = any(ctx.needs_input_grad)
         xenc = torch.empty((R, B, PACKED_WIDTH), device=x.device, dtype=torch.bfloat16)
         saved = torch.empty((B, 7, C, R), device=x.device, dtype=torch.float32) if need_grad else None
-        N.check(N.lib().dic_sci_cci_fwd_packed(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), None,
-                                               N.ptr(saved), N.ptr(xenc), PACKED_WIDTH, N.stream_of(x)), 'dic_sci_cci_fwd_packed')
+        if store:
+            N.check(N.lib().dic_sci_cci_fwd_store(*_store_ptrs(x), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), None, N.ptr(saved),
+                                                  N.ptr(xenc), PACKED_WIDTH, N.stream_of(xenc)), 'dic_sci_cci_fwd_store')
+        else:
+            N.check(N.lib().dic_sci_cci_fwd_packed(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), None,
+                                                   N.ptr(saved), N.ptr(xenc), PACKED_WIDTH, N.stream_of(x)), 'dic_sci_cci_fwd_packed')
         ctx.dims = (B, C, R)
         ctx.sink_params = (sci_kernel, cci_kernel)
         ctx.save_for_backward(saved, sk, ck)
@@ -246,7 +266,8 @@ class _Rbf(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, raw_input, rbf_kernel, grid, lengths, prefix_only=False):
         N.require_gpu(v, raw_input, rbf_kernel, grid)
-        x = N.f32c(raw_input)
+        store = is_ragged(raw_input)              # a ragged.RaggedBatch: time stamps read in place from the encounter store
+        x = raw_input if store else N.f32c(raw_input)
         B, C4, T = x.shape
         C = rbf_kernel.numel()
         R = grid.numel()
@@ -255,15 +276,20 @@ class _Rbf(torch.autograd.Function):
         # v usually arrives as a permuted VIEW of the (R,B,C) rows the FC head wrote: the kernels read that layout as it lies
         tm = v.dtype == torch.float32 and not v.is_contiguous() and v.permute(2, 0, 1).is_contiguous()
         vb = v.permute(2, 0, 1) if tm else N.f32c(v)
-        lengths = _lengths_arg(lengths, B, C, x.device)
+        lengths = x.lengths if store else _lengths_arg(lengths, B, C, x.device)
         rk = N.f32c(rbf_kernel.detach())
         need_grad = any(ctx.needs_input_grad)
         y = torch.empty((B, C, T), device=x.device, dtype=torch.float32)
         norm = torch.empty_like(y) if need_grad else None
-        N.check(N.lib().dic_rbf_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y),
-                                    N.ptr(norm), int(bool(prefix_only)), N.stream_of(x)), 'dic_rbf_fwd')
+        if store:
+            N.check(N.lib().dic_rbf_fwd_store(*_store_ptrs(x, hold=False), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), 0, N.ptr(y),
+                                              N.ptr(norm), int(bool(prefix_only)), None, None, 0, N.stream_of(y)), 'dic_rbf_fwd_store')
+        else:
+            N.check(N.lib().dic_rbf_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y),
+                                        N.ptr(norm), int(bool(prefix_only)), N.stream_of(x)), 'dic_rbf_fwd')
         ctx.dims = (B, C, T, R, bool(tm))
-        ctx.save_for_backward(x, lengths, grid, rk, vb, y, norm)
+        ctx.rb = x if store else None
+        ctx.save_for_backward(None if store else x, lengths, grid, rk, vb, y, norm)
         return y
 
     @staticmethod
@@ -275,8 +301,13 @@ class _Rbf(torch.autograd.Function):
         gk = torch.empty(C, device=g.device, dtype=torch.float32)
         L = N.lib()
         ws = _ws(L.dic_rbf_bwd_workspace(B, C, T, R), g.device)
-        N.check(L.dic_rbf_bwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y), N.ptr(norm),
-                              N.ptr(g), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_rbf_bwd')
+        if ctx.rb is not None:
+            N.check(L.dic_rbf_bwd_store(*_store_ptrs(ctx.rb, hold=False), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y),
+                                        N.ptr(norm), N.ptr(g), None, None, N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(g)),
+                    'dic_rbf_bwd_store')
+        else:
+            N.check(L.dic_rbf_bwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y), N.ptr(norm),
+                                  N.ptr(g), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_rbf_bwd')
         return (gv.permute(1, 2, 0) if tm else gv), None, gk, None, None, None
 
 
@@ -294,27 +325,39 @@ class _RbfRecLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, v, raw_input, rbf_kernel, grid, lengths, ob):
-        N.require_gpu(v, raw_input, rbf_kernel, grid, ob)
-        x, obc = N.f32c(raw_input), N.f32c(ob)
+        store = is_ragged(raw_input)              # a ragged.RaggedBatch: time stamps AND observations read in place from the store (ob is it too)
+        if store:
+            if not is_ragged(ob) or ob.store is not raw_input.store:
+                raise ValueError('rbf_rec_loss: with a RaggedBatch input the observations are the batch itself')
+            N.require_gpu(v, rbf_kernel, grid)
+            x, obc = raw_input, None
+        else:
+            N.require_gpu(v, raw_input, rbf_kernel, grid, ob)
+            x, obc = N.f32c(raw_input), N.f32c(ob)
         B, C4, T = x.shape
         C, R = rbf_kernel.numel(), grid.numel()
-        if C4 != 4 * C or tuple(v.shape) != (B, C, R) or tuple(obc.shape) != (B, C, T):
-            raise ValueError(f'rbf_rec_loss: raw_input {tuple(x.shape)} / v {tuple(v.shape)} / ob {tuple(obc.shape)} do not match C={C}, R={R}')
+        if C4 != 4 * C or tuple(v.shape) != (B, C, R) or (obc is not None and tuple(obc.shape) != (B, C, T)):
+            raise ValueError(f'rbf_rec_loss: raw_input {tuple(x.shape)} / v {tuple(v.shape)} / ob do not match C={C}, R={R}')
         tm = v.dtype == torch.float32 and not v.is_contiguous() and v.permute(2, 0, 1).is_contiguous()
         vb = v.permute(2, 0, 1) if tm else N.f32c(v)
-        lengths = _lengths_arg(lengths, B, C, x.device)
+        lengths = x.lengths if store else _lengths_arg(lengths, B, C, x.device)
         rk = N.f32c(rbf_kernel.detach())
         y = torch.empty((B, C, T), device=x.device, dtype=torch.float32)
         norm = torch.empty_like(y)
         out2 = torch.empty(2, device=x.device, dtype=torch.float32)
         L = N.lib()
         ws = _ws(L.dic_rbf_fwd_loss_workspace(B, C, T, R), x.device)
-        N.check(L.dic_rbf_fwd_loss(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(obc), N.ptr(y),
-                                   N.ptr(norm), 1, N.ptr(out2), N.ptr(ws), ws.numel(), N.stream_of(x)), 'dic_rbf_fwd_loss')
+        if store:
+            N.check(L.dic_rbf_fwd_store(*_store_ptrs(x, hold=False), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), 1, N.ptr(y),
+                                        N.ptr(norm), 1, N.ptr(out2), N.ptr(ws), ws.numel(), N.stream_of(y)), 'dic_rbf_fwd_store')
+        else:
+            N.check(L.dic_rbf_fwd_loss(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(obc), N.ptr(y),
+                                       N.ptr(norm), 1, N.ptr(out2), N.ptr(ws), ws.numel(), N.stream_of(x)), 'dic_rbf_fwd_loss')
         dist.all_reduce_sum_(out2)          # global SSE and global #valid slots
         ctx.dims = (B, C, T, R, bool(tm))
         ctx.sink_params = (rbf_kernel,)
-        ctx.save_for_backward(x, lengths, grid, rk, vb, y, norm, obc, out2)
+        ctx.rb = x if store else None
+        ctx.save_for_backward(None if store else x, lengths, grid, rk, vb, y, norm, obc, out2)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(y)
         return y, out2[0] / out2[1]
@@ -326,13 +369,19 @@ class _RbfRecLoss(torch.autograd.Function):
         if grad_mse is None:
             return None, None, None, None, None, None
         gl = N.f32c(grad_mse.reshape(1))
-        gv = torch.empty((R, B, C) if tm else (B, C, R), device=x.device, dtype=torch.float32)
-        gk = torch.empty(C, device=x.device, dtype=torch.float32)
+        dev = y.device
+        gv = torch.empty((R, B, C) if tm else (B, C, R), device=dev, dtype=torch.float32)
+        gk = torch.empty(C, device=dev, dtype=torch.float32)
         L = N.lib()
-        ws = _ws(L.dic_rbf_bwd_workspace(B, C, T, R), x.device)
-        N.check(L.dic_rbf_bwd_loss(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y), N.ptr(norm),
-                                   N.ptr(obc), N.ptr(out2), N.ptr(gl), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(x)),
-                'dic_rbf_bwd_loss')
+        ws = _ws(L.dic_rbf_bwd_workspace(B, C, T, R), dev)
+        if ctx.rb is not None:
+            N.check(L.dic_rbf_bwd_store(*_store_ptrs(ctx.rb, hold=False), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y),
+                                        N.ptr(norm), None, N.ptr(out2), N.ptr(gl), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(y)),
+                    'dic_rbf_bwd_store')
+        else:
+            N.check(L.dic_rbf_bwd_loss(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(y), N.ptr(norm),
+                                       N.ptr(obc), N.ptr(out2), N.ptr(gl), N.ptr(gv), N.ptr(gk), N.ptr(ws), ws.numel(), N.stream_of(x)),
+                    'dic_rbf_bwd_loss')
         return (gv.permute(1, 2, 0) if tm else gv), None, _sink(ctx.sink_params[0], gk), None, None, None
 
 

@@ -1,0 +1,156 @@
+"""The ragged, device-resident encounter store and the batch handle the kernels read it through.
+
+The reference pads every (encounter, channel) row to the cohort's longest one (p0_data_process.py:35-70) and stacks four such planes
+into ``feed_data (N,4C,T)`` (dataloader.py:54-79): at ~50 observations in 96 slots half of every row is padding, and a batch is a
+gathered copy of it.  ``RaggedStore`` keeps, per row, the observed samples only -- packed time stamps, packed (rescaled) values and
+packed hold-out flags behind one ``row_off`` table -- and a batch is just ``RaggedBatch(store, idx)``: the interpolation and
+de-interpolation kernels (``dic_sci_cci_fwd_store``, ``dic_rbf_fwd_store``, ``dic_rbf_bwd_store``) read the rows of a shuffled batch IN
+PLACE through ``idx``; no gather pass and no padded ``(B,4C,T)`` tensor exist on that path.  The dense planes can be rebuilt exactly
+(``dense_rows``) for the consumers that want them (feature dumps, the corrupted / augmented copies, the module-level API).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+PAD_TAIL = 128      # readable elements behind the last row (the kernels' clamped look-ahead reads stay in bounds)
+
+
+class RaggedStore:
+    def __init__(self, feed_data, C, device):
+        """``feed_data`` (N,4C,T) as DataSet builds it (values already rescaled); rows must be PREFIX-masked with constant padding
+        values per plane and channel (what p0 writes) -- ``RaggedStore.fits`` tells."""
+        fd = np.asarray(feed_data)
+        N, C4, T = fd.shape
+        assert C4 == 4 * C
+        mask = fd[:, C:2 * C] != 0
+        lengths = mask.sum(-1).astype(np.int32)                       # (N,C)
+        row_off = np.zeros(N * C + 1, np.int64)
+        np.cumsum(lengths.reshape(-1), out=row_off[1:])
+        total = int(row_off[-1])
+
+        def pack(plane, dtype):
+            out = np.zeros(total + PAD_TAIL, dtype)
+            out[:total] = plane[mask]                                  # row-major (n, c, slot) order = the rows back to back
+            return torch.as_tensor(out, device=device)
+        self.N, self.C, self.T = N, C, T
+        self.t_pk = pack(fd[:, 2 * C:3 * C], np.float32)
+        self.v_pk = pack(fd[:, 0:C] * mask, np.float32)                # the trainers' `ob *= padding_mask` (a no-op on observed slots)
+        self.hold_pk = pack(fd[:, 3 * C:4 * C], np.uint8)
+        self.row_off = torch.as_tensor(row_off, device=device)
+        self.lengths = torch.as_tensor(lengths, device=device)         # (N,C) int32
+        # what the padding of each plane holds (p0 leaves 0 everywhere, then min-max normalises the whole value array: a constant per
+        # channel): kept so that dense_rows() reproduces feed_data bit for bit
+        pad = ~mask
+        self.pad_value = torch.as_tensor(np.array([fd[:, c][pad[:, c]][0] if pad[:, c].any() else 0.0 for c in range(C)], np.float32), device=device)
+        self.device = device
+
+    @staticmethod
+    def fits(feed_data, C):
+        """True when ``feed_data`` can be stored ragged without loss: prefix masks, binary mask values, zero time / hold-out and one
+        constant value per channel in the padding."""
+        fd = np.asarray(feed_data)
+        T = fd.shape[-1]
+        m = fd[:, C:2 * C]
+        if not np.isin(m, (0, 1)).all():
+            return False
+        n = m.sum(-1)
+        if not (m == (np.arange(T)[None, None] < n[..., None])).all():
+            return False
+        pad = m == 0
+        if (fd[:, 2 * C:3 * C][pad] != 0).any() or (fd[:, 3 * C:4 * C][pad] != 0).any():
+            return False
+        hold = fd[:, 3 * C:4 * C]
+        if not np.isin(hold, (0, 1)).all():
+            return False
+        for c in range(C):
+            pv = fd[:, c][pad[:, c]]
+            if pv.size and (pv != pv[0]).any():
+                return False
+        return True
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in (self.t_pk, self.v_pk, self.hold_pk, self.row_off, self.lengths))
+
+    def dense_rows(self, idx, masked_values=False):
+        """feed_data[idx] rebuilt from the packed rows: (b,4C,T) f32 planes [value | mask | time | hold-out].  ``masked_values``: the
+        value plane times the mask (0 in the padding) instead of the stored padding constant."""
+        C, T = self.C, self.T
+        idx = idx.to(self.device, torch.int64)
+        lens = self.lengths.index_select(0, idx)                                    # (b,C)
+        off = self.row_off[:-1].view(self.N, C).index_select(0, idx)                # (b,C)
+        ar = torch.arange(T, device=self.device)
+        m = ar < lens[..., None]                                                    # (b,C,T)
+        pos = (off[..., None] + ar)[m]                                              # packed positions, rows back to back
+        out = torch.zeros((idx.numel(), 4 * C, T), dtype=torch.float32, device=self.device)
+        val = out[:, 0:C]
+        if not masked_values:
+            val += self.pad_value[None, :, None]
+        val[m] = self.v_pk[pos]
+        out[:, C:2 * C] = m.to(torch.float32)
+        out[:, 2 * C:3 * C][m] = self.t_pk[pos]
+        out[:, 3 * C:4 * C][m] = self.hold_pk[pos].to(torch.float32)
+        return out
+
+
+class RaggedBatch:
+    """``B`` encounters of a ``RaggedStore`` named by ``idx`` -- what the model's forward takes in place of the stacked ``(B,4C,T)``
+    tensor (it quacks like one where the callers look: ``size / shape / device / is_cuda / dtype``), and what ``rec_loss`` takes in
+    place of the ``(B,C,T)`` observations.  ``denoise``: the model input is value x hold-out flag (pretrain_trainer.py:139-141)."""
+    is_ragged = True
+
+    def __init__(self, store: RaggedStore, idx, lengths=None, denoise=False):
+        self.store = store
+        self.idx = idx if (idx.dtype == torch.int32 and idx.is_contiguous()) else idx.to(torch.int32).contiguous()
+        self.lengths = lengths if lengths is not None else store.lengths.index_select(0, self.idx.to(torch.int64))
+        if self.lengths.dtype != torch.int32 or not self.lengths.is_contiguous():
+            self.lengths = self.lengths.to(torch.int32).contiguous()
+        self.denoise = bool(denoise)
+
+    # ---- the corner of the tensor interface the model code touches
+    @property
+    def shape(self):
+        return torch.Size((self.idx.numel(), 4 * self.store.C, self.store.T))
+
+    def size(self, k=None):
+        return self.shape if k is None else self.shape[k]
+
+    @property
+    def device(self):
+        return self.store.device
+
+    @property
+    def is_cuda(self):
+        return torch.device(self.store.device).type == 'cuda'
+
+    dtype = torch.float32
+
+    # ---- Stepper's hipGraph path keeps static copies of its inputs
+    def clone(self):
+        return RaggedBatch(self.store, self.idx.clone(), self.lengths.clone(), self.denoise)
+
+    def copy_(self, other, non_blocking=False):
+        assert other.store is self.store and other.denoise == self.denoise
+        self.idx.copy_(other.idx, non_blocking=non_blocking)
+        self.lengths.copy_(other.lengths, non_blocking=non_blocking)
+        return self
+
+    def with_denoise(self, denoise):
+        return self if bool(denoise) == self.denoise else RaggedBatch(self.store, self.idx, self.lengths, denoise)
+
+    # ---- dense views (rebuilt on demand)
+    def dense(self):
+        """The stacked input the trainers build (pretrain_trainer.py:132-143): [ob*mask (x hold-out when denoising) | mask | time | hold-out]."""
+        x = self.store.dense_rows(self.idx, masked_values=True)
+        if self.denoise:
+            C = self.store.C
+            x[:, 0:C] *= x[:, 3 * C:4 * C]
+        return x
+
+    def ob_dense(self):
+        C = self.store.C
+        return self.store.dense_rows(self.idx, masked_values=True)[:, 0:C].contiguous()
+
+
+def is_ragged(x):
+    return getattr(x, 'is_ragged', False)

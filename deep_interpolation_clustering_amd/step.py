@@ -11,6 +11,7 @@ import torch
 
 from . import dist, ops
 from . import lstm as fused_lstm
+from .ragged import is_ragged
 
 LOSS_NAMES = ('ae_mse', 'ae_mse_sup', 'ae_mse_fake_detect', 'ae_mse_fake_detect_triplet', 'ae_mse_sup_fake_detect',
               'ae_mse_kl', 'ae_mse_fake_detect_kl', 'ae_mse_sup_kl', 'ae_mse_sup_fake_detect_kl')
@@ -72,6 +73,8 @@ class Stepper:
 
     def forward_loss(self, x, ob, padding_mask, lengths=None, fake_x=None, fake_perm_idx=None, positive_x=None,
                      aux_label_dict=None, future_vital_mask=None, fake_det_label=None):
+        if is_ragged(x):                  # ragged.RaggedBatch: lengths come with it; the observations are the batch itself unless given
+            lengths, ob, padding_mask = x.lengths, (x if ob is None else ob), None
         if lengths is not None:
             padding_mask = None           # prefix lengths SAY what the mask is (the trainers hand over both): the kernels never read the plane
         with self._ctx():
@@ -145,10 +148,12 @@ class Stepper:
         hipGraph writes them in place; a graph evicted from the small cache frees their memory -- clone what must outlive the step).
         With ``lengths`` (prefix masks, all the loaders produce) ``padding_mask`` is redundant and dropped: the de-interpolation kernels
         then emit the reconstruction loss themselves."""
+        if is_ragged(x):
+            lengths = padding_mask = None                # (both travel inside x)
         if lengths is not None:
             padding_mask = None
         if self.use_graphs and x.is_cuda and (not self.auto_graphs or x.shape[0] <= self.AUTO_GRAPH_BATCH):
-            tensors = {'x': x, 'ob': ob}
+            tensors = {'x': x} if ob is None else {'x': x, 'ob': ob}
             if padding_mask is not None:
                 tensors['padding_mask'] = padding_mask
             if lengths is not None:
@@ -161,6 +166,8 @@ class Stepper:
 
     def _step_eager(self, x, ob, padding_mask, lengths=None, **kw):
         self.flat.zero_grad()
+        if is_ragged(x):
+            lengths, ob = x.lengths, (x if ob is None else ob)
         self.model.internal_step = True          # the reconstruction stays inside this step: its padded slots need not be written
         # ... and with prefix lengths its loss comes out of the de-interpolation kernels themselves (ops.rbf_rec_loss)
         self.model.rec_target = ob if (padding_mask is None and lengths is not None and ob.is_cuda) else None

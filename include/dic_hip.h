@@ -75,6 +75,22 @@ int dic_sci_cci_fwd_ragged(const float* t_pk, const float* v_pk, const int64_t* 
                            const float* sci_kernel, const float* cci_kernel,
                            float* out, float* saved, dic_stream_t stream);
 
+/* The same forward reading a RAGGED ENCOUNTER STORE in place (the device-resident form of the feed_data array
+ * dataloader.py:54-79 builds): for every (encounter, channel) row only the observed samples, packed back to back --
+ *   t_pk, v_pk   packed time stamps (h) and values (ob * mask, rescaled): row g of the store at [row_off[g], row_off[g+1]);
+ *   hold_pk      optional packed hold-out flags (plane 3, p0_data_process.py:95-117): the model input is v * hold (a denoising
+ *                step, pretrain_trainer.py:139-141);
+ *   row_off      (N*C + 1) int64; the packed arrays must keep >= 64 readable elements behind the last row;
+ *   enc_idx      (B) int32 store encounter of each batch row (a shuffled batch is read in place: no gather, no padded copy), or
+ *                NULL: the batch is encounters 0..B-1;
+ *   lengths      (B,C) int32 row lengths of the BATCH rows (= the store's, gathered), or NULL: taken from row_off;
+ *   T            the padded width the dense path would have (bounds every row; sizes the LDS rows).
+ * out (B,R,3C) f32 and / or xenc (R,B,xw) bf16 packed rows as dic_sci_cci_fwd_packed; saved as above.  Same arithmetic, same results
+ * as the dense entry points on the same samples. */
+int dic_sci_cci_fwd_store(const float* t_pk, const float* v_pk, const uint8_t* hold_pk, const int64_t* row_off, const int32_t* enc_idx,
+                          const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid, const float* sci_kernel,
+                          const float* cci_kernel, float* out, float* saved, void* xenc, int xw, dic_stream_t stream);
+
 /* Backward of the above wrt the two parameters only (the inputs carry no gradient upstream).
  *   grad_out (B,R,3C) cotangent of `out`; saved from the forward;
  *   grad_sci_kernel (C), grad_cci_kernel (C,C; ignored when cci_kernel==NULL): OVERWRITTEN.
@@ -140,6 +156,20 @@ int dic_rbf_bwd_loss(const float* x, const int32_t* lengths, int B, int C, int T
                      const float* v, int v_time_major, const float* y, const float* norm, const float* ob, const float* sse_count,
                      const float* grad_loss, float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes,
                      dic_stream_t stream);
+
+/* k2 reading the ragged encounter store in place (see dic_sci_cci_fwd_store for t_pk / v_pk / row_off / enc_idx / lengths; lengths is
+ * required here): the time stamps come from t_pk and -- for the fused reconstruction loss -- the observations from v_pk, so the
+ * padded (B,4C,T) input and the (B,C,T) observation tensor do not exist on this path.  y, norm (and grad_y when given) stay (B,C,T).
+ *   dic_rbf_fwd_store: with_loss != 0 = dic_rbf_fwd_loss (out2, workspace of dic_rbf_fwd_loss_workspace bytes), else dic_rbf_fwd;
+ *   dic_rbf_bwd_store: grad_y == NULL = dic_rbf_bwd_loss (sse_count, grad_loss required), else dic_rbf_bwd. */
+int dic_rbf_fwd_store(const float* t_pk, const float* v_pk, const int64_t* row_off, const int32_t* enc_idx, const int32_t* lengths,
+                      int B, int C, int T, int R, const float* ref_grid, const float* rbf_kernel, const float* v, int v_time_major,
+                      int with_loss, float* y, float* norm, int prefix_only, float* out2, void* workspace, size_t workspace_bytes,
+                      dic_stream_t stream);
+int dic_rbf_bwd_store(const float* t_pk, const float* v_pk, const int64_t* row_off, const int32_t* enc_idx, const int32_t* lengths,
+                      int B, int C, int T, int R, const float* ref_grid, const float* rbf_kernel, const float* v, int v_time_major,
+                      const float* y, const float* norm, const float* grad_y, const float* sse_count, const float* grad_loss,
+                      float* grad_v, float* grad_rbf_kernel, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
 /* Net.rec_loss (clustering_interp.py:197-203): out2[0]=sum((rec*m-ob*m)^2), out2[1]=#{m==1}.
  * mask (B,C,T) may be NULL when lengths is given.  The loss is out2[0]/out2[1]. */

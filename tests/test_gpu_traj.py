@@ -58,8 +58,12 @@ def make_loaders(args, dev, kind):
     out = {}
     for cohort in ('training', 'validation', 'testing'):
         ds = DataSet(args, cohort)
-        if kind == 'device':
+        if kind == 'device':          # the HBM-resident ragged store; padded per-batch tensors rebuilt beside it (unshuffled loaders do)
             out[cohort] = DeviceLoader(ds, args.batch_size, False, dev, seed=1, shard=False)       # fixed batch order, as in the fixture run
+        elif kind == 'ragged':        # ... training batches as bare handles into the store, what a shuffled training loader yields
+            out[cohort] = DeviceLoader(ds, args.batch_size, False, dev, seed=1, shard=False, dense_samples=False if cohort == 'training' else None)
+        elif kind == 'padded':        # the padded (N,4C,T) array resident instead
+            out[cohort] = DeviceLoader(ds, args.batch_size, False, dev, seed=1, shard=False, ragged=False)
         else:
             out[cohort] = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, num_workers=0, shuffle=False)
     return out
@@ -127,7 +131,7 @@ def test_joint_step_cfg_shape_kmeans_centroids(K, use_lengths):
 
 
 # ---------------------------------------------------------------------------------------------------------------- p1 trajectory
-@pytest.mark.parametrize('kind', ['device', 'host'])
+@pytest.mark.parametrize('kind', ['device', 'ragged', 'padded', 'host'])
 def test_pretrain_trainer_follows_reference(run_dir, kind, tmp_path):
     from deep_interpolation_clustering_amd.pretrain_interp import Net
     from deep_interpolation_clustering_amd.pretrain_trainer import Trainer
@@ -182,8 +186,8 @@ def test_pretrain_trainer_follows_reference(run_dir, kind, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------- p3 trajectory
-@pytest.mark.parametrize('K,tag', [(4, 'p3'), (6, 'p3k6')])
-def test_cluster_trainer_follows_reference(run_dir, K, tag, tmp_path):
+@pytest.mark.parametrize('K,tag,kind', [(4, 'p3', 'ragged'), (6, 'p3k6', 'ragged'), (4, 'p3', 'padded')])
+def test_cluster_trainer_follows_reference(run_dir, K, tag, kind, tmp_path):
     from deep_interpolation_clustering_amd.clustering_interp import Net
     from deep_interpolation_clustering_amd.clustering_trainer import TrainerCluster
     from deep_interpolation_clustering_amd.utils import set_seed
@@ -195,7 +199,7 @@ def test_cluster_trainer_follows_reference(run_dir, K, tag, tmp_path):
     torch.manual_seed(7529)
     net = Net(args, dev)
     pre, exp = str(tmp_path / 'Pretrain'), str(tmp_path / 'Clustering')
-    tr = TrainerCluster(args, net, make_loaders(args, dev, 'device'), exp, pre, dev)
+    tr = TrainerCluster(args, net, make_loaders(args, dev, kind), exp, pre, dev)
     write_checkpoint(os.path.join(pre, 'weight', 'ae_mse', 'model.pth.tar'), sd_p1, 2, torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]))
     rec = spy_steps(tr, ['loss', 'ae_mse', 'kl'])
     seen = {}
@@ -280,7 +284,8 @@ def test_feature_dump_equals_reference(run_dir, kind, tmp_path):
     assert (dump['cluster_pred'].argmax(1) == f['dump/cluster_pred'].argmax(1)).all()
 
 
-def test_trainer_takes_the_fused_reconstruction_path(run_dir, tmp_path, monkeypatch):
+@pytest.mark.parametrize('kind', ['ragged', 'device', 'padded'])
+def test_trainer_takes_the_fused_reconstruction_path(run_dir, tmp_path, monkeypatch, kind):
     """the trainers hand Stepper BOTH the padding mask and the prefix lengths; the step must still run the de-interpolation
     kernels that emit the reconstruction loss themselves (ops.rbf_rec_loss) -- what bench.py times -- not the masked-MSE pass."""
     from deep_interpolation_clustering_amd import ops
@@ -290,7 +295,7 @@ def test_trainer_takes_the_fused_reconstruction_path(run_dir, tmp_path, monkeypa
     dev = torch.device('cuda')
     torch.manual_seed(1)
     net = Net(args, dev)
-    tr = Trainer(args, net, make_loaders(args, dev, 'device'), str(tmp_path / 'P'), dev)
+    tr = Trainer(args, net, make_loaders(args, dev, kind), str(tmp_path / 'P'), dev)
     calls = {'fused': 0, 'mse': 0}
     inner_f, inner_m = ops.rbf_rec_loss, ops.masked_mse
     monkeypatch.setattr(ops, 'rbf_rec_loss', lambda *a, **k: (calls.__setitem__('fused', calls['fused'] + 1), inner_f(*a, **k))[1])
