@@ -84,7 +84,7 @@ def time_kernel(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True):
+def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True, input_path='both'):
     """Per hand-written kernel: algorithmic bytes (SURVEY.md 8d formulas, ragged accounting) / HIP-event time.
     Shapes (C, T, R) are read from the tensors / the net, so BASELINE configs[3] (C=12, T=288) reuses it."""
     from deep_interpolation_clustering_amd import _native as N
@@ -141,13 +141,34 @@ def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True):
         'dec_bwd': (lambda: L.dic_dec_bwd(P(z), P(mu), P(q), P(ts), P(gq), B, D, K, 1.0, P(gz), P(gmu), P(ws5), ws5.numel(), st),
                     4.0 * B * (2 * D + 2 * K)),
     }
-    fwd_first = ['sci_cci_fwd', 'rbf_fwd', 'masked_sse_fwd', 'dec_fwd']
+    # the same k1 / k2 kernels reading the ragged encounter store in place through a shuffled encounter index (what the trainers' DeviceLoader
+    # and the timed step above run): packed (t, v) rows, no padded planes
+    from deep_interpolation_clustering_amd.ragged import RaggedStore
+    stor = RaggedStore(x.detach().cpu().numpy(), C, dev)
+    perm = torch.randperm(B, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(torch.int32)
+    lperm = lengths.index_select(0, perm.to(torch.int64)).contiguous()
+    sp = (P(stor.t_pk), P(stor.v_pk))
+    out2s = torch.empty(2, **f32)
+    ws2s = torch.empty(max(16, L.dic_rbf_fwd_loss_workspace(B, C, T, R)), dtype=torch.uint8, device=dev)
+    if 3 * C < 32:
+        calls['sci_cci_fwd_store'] = (lambda: L.dic_sci_cci_fwd_store(*sp, None, P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(sk), P(ck), None,
+                                                                     P(saved), P(xenc_k1), 32, st), 8 * nsum + 4 * B * C + 12 * B * C * R)
+    calls['rbf_fwd_store'] = (lambda: L.dic_rbf_fwd_store(*sp, P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(rk), P(v), 0, 1, P(y), P(norm), 1,
+                                                          P(out2s), P(ws2s), ws2s.numel(), st), 12 * nsum + 4 * B * C * R)
+    calls['rbf_bwd_store'] = (lambda: L.dic_rbf_bwd_store(*sp, P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(rk), P(v), 0, P(y), P(norm), None,
+                                                          P(out2s), P(gl), P(gv), P(gk), P(ws2), ws2.numel(), st), 8 * nsum + 8 * B * C * R)
+    fwd_first = ['sci_cci_fwd', 'rbf_fwd', 'masked_sse_fwd', 'dec_fwd', 'rbf_fwd_store']
     if with_lstm:
         fwd_first.append('lstm_fwd')
         _lstm_calls(calls, L, P, st, B, R, dev)
     # run the forwards once so the backward inputs (saved, y, norm, out2, ts, LSTM state) hold real values
+    # input_path 'store' / 'dense': launch k1 / k2 on one input path only (PMC passes tell kernels apart by name, and both paths share names)
+    twin = {'sci_cci_fwd': 'sci_cci_fwd_store', 'rbf_fwd': 'rbf_fwd_store', 'rbf_bwd': 'rbf_bwd_store'}
+    drop = set(twin.values()) if input_path == 'dense' else (set(twin.keys()) if input_path == 'store' else set())
+    calls = {k: v for k, v in calls.items() if k not in drop}
     for name in fwd_first:
-        assert calls[name][0]() == 0, name
+        if name in calls:
+            assert calls[name][0]() == 0, name
     table = {}
     for name, (fn, nbytes) in calls.items():
         ms = time_kernel(fn, iters)
@@ -672,6 +693,7 @@ def main():
         # which kernel dominates the STEP: launches x duration from a trace of the timed step itself
         trace_name = {'sci_cci_fwd': 'dic::sci_cci_fwd_kernel', 'sci_cci_bwd': 'dic::sci_cci_bwd_kernel', 'rbf_fwd': 'dic::rbf_fwd_kernel',
                       'rbf_bwd': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'), 'masked_sse_fwd': 'dic::masked_sse_kernel', 'masked_sse_bwd': 'dic::masked_sse_bwd_kernel',
+                      'sci_cci_fwd_store': 'dic::sci_cci_fwd_kernel', 'rbf_fwd_store': 'dic::rbf_fwd_kernel', 'rbf_bwd_store': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'),
                       'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': ('dic::lstm_fwd8_gxn_kernel', 'dic::lstm_fwd_kernel'),
                       'lstm_fwd_proj': ('dic::lstm_fwd8_proj_kernel', 'dic::lstm_fwd_kernel'), 'lstm_bwd': 'dic::lstm_bwd_kernel', 'lstm_dw': 'dic::lstm_dw_kernel',
                       'row_proj': 'dic::row_proj_kernel', 'row_proj_stats': 'dic::row_proj_kernel', 'fc_bwd': 'dic::fc_bwd_kernel',
@@ -689,8 +711,14 @@ def main():
         for i in range(ran[0], TRACE_STEPS if sharded else 0):                              # stay in lockstep with the other ranks whatever the tracer did
             one_step(a.warmup + a.steps + i)
         per_step = {}
+        # k1 / k2 appear twice in the table (padded input, ragged store): the step runs ONE of the two
+        twin = {'sci_cci_fwd': 'sci_cci_fwd_store', 'rbf_fwd': 'rbf_fwd_store', 'rbf_bwd': 'rbf_bwd_store'}
+        not_in_step = set(twin.keys() if store is not None else twin.values())
         for name, row in table.items():
             launches = 1.0
+            if name in not_in_step:
+                per_step[name] = 0.0
+                continue
             if kernels is not None:
                 hits = [v for k, v in kernels.items() if k.startswith(trace_name[name])]        # (str.startswith takes a tuple of prefixes too)
                 launches = sum(v['launches_per_step'] for v in hits)
@@ -707,6 +735,8 @@ def main():
         for name in table:
             if kernels is None:
                 break
+            if name in not_in_step:
+                continue
             own = {'lstm_fwd': 'dic::lstm_fwd8_gxn_kernel', 'lstm_fwd_proj': 'dic::lstm_fwd8_proj_kernel'}.get(name)
             pref = own if (own is not None and any(k.startswith(own) for k in kernels)) else trace_name[name]
             hits = [v for k, v in kernels.items() if k.startswith(pref)]

@@ -22,6 +22,8 @@ coh = synthetic.make_cohort(B, C=bench.C, T=bench.T, H=bench.H, lam=bench.LAM, G
 x_np, ob_np, n = synthetic.stacked_batch(coh)
 x, ob, lens = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
 net = Net(bench.make_args(K), dev).to(dev)
-table = bench.kernel_table(net, x, ob, lens, K, iters, with_lstm='nolstm' not in sys.argv)
+table = bench.kernel_table(net, x, ob, lens, K, iters, with_lstm='nolstm' not in sys.argv,
+                           input_path='store' if 'store' in sys.argv else ('dense' if 'dense' in sys.argv else 'both'))
+# ('store' / 'dense' on the command line: the PMC passes cannot tell the two input paths of k1 / k2 apart by kernel name -- launch one of them only)
 for k, v in table.items():
     print(f'{k:16s} {v["ms"] * 1e3:9.1f} us  {v["GBps"]:8.1f} GB/s  {100 * v["frac_hbm_peak"]:5.1f}% of HBM peak')
