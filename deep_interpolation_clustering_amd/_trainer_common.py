@@ -84,18 +84,25 @@ class TrainerBase(object):
 
     def _all_rows(self, local, dl):
         """Rows every rank produced over one pass of the sharded, unshuffled loader ``dl`` -> the full tensor, in dataset order, on
-        every rank.  One sum all-reduce of a zero-filled buffer (disjoint rows: the sum is the concatenation; works on RCCL and on
-        gloo alike)."""
-        if getattr(dl, 'world', 1) <= 1:
+        every rank.  ONE all-gather (shards padded to the longest: every rank knows every rank's row list, the loader's sharding is
+        a pure function of the rank) -- half the bytes of round 2's zero-padded sum all-reduce of the full tensor, and no adds."""
+        world = getattr(dl, 'world', 1)
+        if world <= 1:
             return local
-        rows = dl.shard_rows().to(local.device)
-        if rows.numel() != local.shape[0]:
-            raise RuntimeError(f'sharded pass produced {local.shape[0]} rows, the loader promises {rows.numel()}')
+        rows = [dl.shard_rows(r) for r in range(world)]
+        if rows[dl.rank].numel() != local.shape[0]:
+            raise RuntimeError(f'sharded pass produced {local.shape[0]} rows, the loader promises {rows[dl.rank].numel()}')
         kind = local.dtype
-        work = local.to(torch.int32) if kind in (torch.bool, torch.uint8, torch.int8, torch.int16) else local
-        full = torch.zeros((len(dl.ds),) + tuple(local.shape[1:]), dtype=work.dtype, device=local.device)
-        full[rows] = work
-        dist.all_reduce_sum_(full)
+        work = local.to(torch.int32) if kind in (torch.bool, torch.uint8, torch.int8, torch.int16) else local.contiguous()
+        longest = max(r.numel() for r in rows)
+        mine = work
+        if work.shape[0] < longest:
+            mine = torch.zeros((longest,) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
+            mine[:work.shape[0]] = work
+        gathered = dist.all_gather_rows(mine)                     # (world, longest, ...)
+        full = torch.empty((len(dl.ds),) + tuple(work.shape[1:]), dtype=work.dtype, device=work.device)
+        for r in range(world):
+            full[rows[r].to(work.device)] = gathered[r, :rows[r].numel()]
         return full.to(kind)
 
     @staticmethod

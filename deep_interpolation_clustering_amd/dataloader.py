@@ -205,21 +205,22 @@ class DeviceLoader:
             return 1
         return full + (1 if keep_tail else 0)
 
-    def _bounds(self, b):
-        """[lo, hi) of global batch b in the epoch's order, and this rank's [lo, hi) inside it."""
+    def _bounds(self, b, rank=None):
+        """[lo, hi) of global batch b in the epoch's order, and this rank's (or ``rank``'s) [lo, hi) inside it."""
         n, nb = len(self.ds), len(self)
+        rank = self.rank if rank is None else rank
         lo = b * self.batch_size
         hi = n if (b == nb - 1 and self.keep_every_row) else min((b + 1) * self.batch_size, n)
         if self.world > 1:
             m = hi - lo
-            return lo, hi, lo + (m * self.rank) // self.world, lo + (m * (self.rank + 1)) // self.world
+            return lo, hi, lo + (m * rank) // self.world, lo + (m * (rank + 1)) // self.world
         return lo, hi, lo, hi
 
-    def shard_rows(self):
-        """Dataset rows this rank yields over one UNSHUFFLED pass, in iteration order (the scatter index of trainers' row gather)."""
+    def shard_rows(self, rank=None):
+        """Dataset rows this rank (or ``rank``) yields over one UNSHUFFLED pass, in iteration order (the scatter index of trainers' row gather)."""
         if self.shuffle:
             raise ValueError('shard_rows: the loader shuffles')
-        parts = [torch.arange(*self._bounds(b)[2:]) for b in range(len(self))]
+        parts = [torch.arange(*self._bounds(b, rank)[2:]) for b in range(len(self))]
         return torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64)
 
     def _noise(self, t, mask, std):

@@ -19,6 +19,11 @@ import torch.distributed as td
 _SINGLE_RANK_REHEARSAL = os.environ.get('DIC_DIST_SINGLE_RANK') == '1'
 
 
+def graph_capturable() -> bool:
+    """True when the collectives of a sharded step can be recorded into a hipGraph: RCCL enqueues them on HIP streams (gloo does not)."""
+    return is_sharded() and td.get_backend() == 'nccl'
+
+
 def is_sharded() -> bool:
     return td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or _SINGLE_RANK_REHEARSAL)
 
@@ -38,6 +43,16 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
+    """(world, *t.shape): every rank's ``t`` (equal shapes), one all-gather (RCCL / gloo); ``t[None]`` when not sharded."""
+    if not is_sharded():
+        return t[None]
+    t = t.contiguous()
+    out = torch.empty((world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)      # (the concatenated form: gloo takes no other)
+    td.all_gather_into_tensor(out, t)
+    return out.view((world_size(),) + tuple(t.shape))
+
+
 class _GlobalMean(torch.autograd.Function):
     """sum over ranks of ``local_sum`` / sum over ranks of ``local_count``: the value every rank reports is the global-batch mean,
     and d/d local_sum = 1 / global count, so the SUM of the ranks' gradients (FlatParams.all_reduce_grads) is the gradient of that
@@ -45,7 +60,10 @@ class _GlobalMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, local_sum, local_count):
-        both = torch.stack([local_sum.detach().float().reshape(()), torch.as_tensor(local_count, dtype=torch.float32, device=local_sum.device).reshape(())])
+        # (the count as a device scalar WITHOUT a host-to-device copy: a fill kernel is capturable in a hipGraph, a pageable copy is not)
+        cnt = (local_count.to(device=local_sum.device, dtype=torch.float32).reshape(()) if torch.is_tensor(local_count)
+               else torch.full((), float(local_count), dtype=torch.float32, device=local_sum.device))
+        both = torch.stack([local_sum.detach().float().reshape(()), cnt])
         all_reduce_sum_(both)
         ctx.save_for_backward(both[1])
         return (both[0] / both[1]).to(local_sum.dtype)

@@ -6,6 +6,7 @@ RCCL when sharded] -> clip_grad_norm_(grad_clip) -> optimizer.step.  Loss terms 
 (the reference's per-term ``.item()`` is a host sync per batch); callers read them when they log.
 """
 import contextlib
+import os
 
 import torch
 
@@ -62,8 +63,16 @@ class Stepper:
         # hipGraph capture of the whole step (single-GPU): at the reference's batch size (256) the ~250 launches of a
         # step are launch-bound (2.5 ms); one graph replay runs them back to back.
         # 'auto': graphs for batches up to AUTO_GRAPH_BATCH encounters (0.89 against 1.5 ms per step at the reference's B = 256)
+        # Sharded (one process per GPU): RCCL collectives are stream operations and capture with the kernels around them, so an EXPLICIT
+        # use_graphs=True (or DIC_SHARDED_GRAPHS=1 for 'auto') captures the sharded step too -- what a strong-scaled batch of a few
+        # thousand encounters per rank needs, where the step is launch-bound; rehearsed on RCCL with one rank (tests/test_gpu_dist.py),
+        # off by default until it has run on a multi-GPU node.  gloo (CPU-side collectives) cannot be captured.
         self.auto_graphs = use_graphs == 'auto'
-        self.use_graphs = (self.auto_graphs or bool(use_graphs)) and not dist.is_sharded()
+        want = self.auto_graphs or bool(use_graphs)
+        if dist.is_sharded():
+            explicit = (use_graphs is True) or (self.auto_graphs and os.environ.get('DIC_SHARDED_GRAPHS') == '1')
+            want = want and explicit and dist.graph_capturable()
+        self.use_graphs = want
         self._graphs = {}
 
     def _ctx(self):

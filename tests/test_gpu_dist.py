@@ -378,6 +378,13 @@ def test_bench_runs_sharded_on_two_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['scaling'] == 'weak' and rec['config']['global_batch'] == 1024
     assert abs(rec['value'] - 2 * 512 * 3 / (rec['ms_per_step'] * 3e-3)) <= 0.01 * rec['value']      # whole-job rate over all ranks
+    # strong scaling (BASELINE configs[2]'s shape of run): ONE cohort sharded over the ranks, the GLOBAL batch fixed
+    res = subprocess.run(cmd + ['--scaling', 'strong'], env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][0])
+    assert rec['scaling'] == 'strong' and rec['config']['global_batch'] == 512 and rec['config']['per_gpu_batch'] == 256
+    assert 'of ONE 4096-encounter' in rec['config']['workload']
+    assert abs(rec['value'] - 512 * 3 / (rec['ms_per_step'] * 3e-3)) <= 0.01 * rec['value']
 
 
 def test_sharded_paths_on_rccl_with_one_rank(tmp_path):
@@ -405,6 +412,51 @@ def test_sharded_paths_on_rccl_with_one_rank(tmp_path):
     for case in ('pp', 'empty'):
         assert np.array_equal(a[case][0], b[case][0]) and a[case][3] == b[case][3], case
         np.testing.assert_allclose(a[case][1], b[case][1], rtol=1e-5, atol=1e-6, err_msg=case)
+
+
+def _run_graphed(rank, world, port, out):
+    """The SHARDED step (every collective on RCCL: one rank, DIC_DIST_SINGLE_RANK=1) captured in a hipGraph against the same step
+    launched eagerly."""
+    sys.path.insert(0, ROOT)
+    _env(rank, world, port, True)
+    from deep_interpolation_clustering_amd import dist, synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    dist.init_from_env()
+    _join(True)
+    assert dist.graph_capturable()
+    dev = torch.device('cuda', 0)
+    coh = synthetic.make_cohort(512, seed=31)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = (torch.tensor(a, device=dev) for a in (x_np, ob_np, n))
+    res = {}
+    for graphs in (False, True):
+        torch.manual_seed(5)
+        net = _pretrained(Net(_args(), dev).to(dev))
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), _args(), autocast_dtype=torch.bfloat16, use_graphs=graphs)
+        assert st.use_graphs == graphs
+        traj = []
+        for i in range(6):
+            lo = (i % 2) * 256
+            losses, gnorm, _ = st.step(X[lo:lo + 256], OB[lo:lo + 256], None, LEN[lo:lo + 256])
+            traj.append([float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(losses['kl'].detach()), float(gnorm)])
+        if graphs:
+            assert len(st._graphs) == 1
+        res[graphs] = np.array(traj)
+    torch.save(res, os.path.join(out, 'graphed.pt'))
+    _leave()
+
+
+def test_sharded_step_is_hip_graph_capturable_on_rccl(tmp_path):
+    """a strong-scaled batch of a few thousand encounters per rank is launch-bound, and Stepper refused to capture a
+    sharded step.  With the collectives on RCCL (stream operations) an explicit use_graphs=True records them with the kernels: the
+    replayed trajectory must follow the eager one (bf16 mode; same bar as the single-GPU graph test)."""
+    mp.spawn(_run_graphed, args=(1, 29200 + (os.getpid() % 1000), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(tmp_path / 'graphed.pt', weights_only=False)
+    np.testing.assert_allclose(res[True], res[False], rtol=2e-3)
+    assert np.isfinite(res[True]).all() and not np.allclose(res[True][0], res[True][-1])        # the replays do advance the parameters
 
 
 def test_bench_runs_on_rccl_with_one_rank():
