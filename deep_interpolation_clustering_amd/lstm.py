@@ -64,6 +64,9 @@ def f32_available(x, lstm):
 # The decoder's weight-gradient kernel (MFMA-bound) has no consumer before the optimizer: inside step.Stepper's backward it runs on a
 # side stream next to the bandwidth-bound encoder backward that follows on the main stream (side_stream_session joins at the end).
 DW_SIDE_STREAM = os.environ.get('DIC_DW_SIDE_STREAM', '1') != '0'
+# the decoder's input gradient dX = dG.W_ih on the hand-written resident-weight kernel (csrc/dic_dxproj.hip) instead of the library GEMM:
+# OFF by default -- measured 571 us against the library's 447 us at B = 32 768 (per-CU ingest bound, see the kernel's header)
+DX_KERNEL = os.environ.get('DIC_DX_KERNEL', '0') == '1'
 _SIDE = {'on': False, 'streams': {}, 'pending': [], 'keep': []}
 RECORD_STREAM = os.environ.get('DIC_SIDE_RECORD_STREAM', '0') == '1'      # (experiment switch: the allocator-side alternative)
 
@@ -246,7 +249,12 @@ class _BiLstm(torch.autograd.Function):
         dxp = torch.empty((2, R * B, Ip), device=dev, dtype=T) if (fuse_dx and ctx.needs_input_grad[0]) else None
         dx = None
         if ctx.needs_input_grad[0] and dxp is None:
-            dx = dg2 @ wih                                           # (R*B, Ip)
+            if DX_KERNEL and (not f32) and I == WIDE_INPUT and Ip == I and R * B >= 32:
+                # decoder: dX = dG . W_ih with the weights resident in registers (csrc/dic_dxproj.hip; round 2: a library GEMM)
+                dx = torch.empty((R * B, Ip), device=dev, dtype=T)
+                N.check(Lb.dic_lstm_dx_wide(N.ptr(dg2), N.ptr(wih), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_wide')
+            else:
+                dx = dg2 @ wih                                       # (R*B, Ip)
             if packed:
                 dx = dx.view(R, B, Ip)                               # consumed in this layout by ops._SciCciPacked.backward
             else:

@@ -319,6 +319,12 @@ int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const vo
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
                      void* workspace, size_t workspace_bytes, int state_batch_major, int dout_of_relu, dic_stream_t stream);
 
+/* The decoder LSTM's input gradient dX = dG . W_ih (the backward of nn.LSTM's input projection, clustering_interp.py:29-41) with the
+ * weights resident in registers: dg (N, gate_columns = 1024) bf16 gate gradients of both directions as dic_lstm_bwd writes them,
+ * w_ih (1024, in_features = 256) bf16 (dic_lstm_pack's wih), dx (N, 256) bf16 OVERWRITTEN = the gradient w.r.t. the LSTM's input rows
+ * (with input_rectify upstream of a ReLU: w.r.t. relu(x); the mask is the producer's).  N >= 32.  Replaces round 2's library GEMM. */
+int dic_lstm_dx_wide(const void* dg, const void* w_ih, int64_t N, int gate_columns, int in_features, void* dx, dic_stream_t stream);
+
 /* ------------------------------------------------------------------ bi-LSTM parameters --------
  * The eight f32 parameters of one bidirectional nn.LSTM layer (clustering_interp.py:22,35: weight_ih_l0, weight_hh_l0,
  * bias_ih_l0, bias_hh_l0, then the same four with the _reverse suffix) are passed as a HOST array of 8 device pointers in

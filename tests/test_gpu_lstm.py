@@ -965,3 +965,23 @@ def test_eight_wave_decoder_recurrence_equals_the_four_wave_kernel(R, B, init):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert torch.isfinite(res[0][0].float()).all() and float(res[0][0].float().abs().mean()) > 0.01
+
+
+@pytest.mark.parametrize('rows', [32, 33, 1000, 24 * 4096 + 7])
+def test_decoder_input_gradient_kernel_equals_matmul(rows):
+    """dic_lstm_dx_wide (csrc/dic_dxproj.hip: dX = dG . W_ih, weights resident in registers) against torch's bf16 matmul
+    (f32 accumulation, one rounding to bf16) and against the f64 product: ragged row counts exercise the shifted last tile."""
+    from deep_interpolation_clustering_amd import _native as N
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(rows)
+    dg = (torch.randn(rows, 1024, device=dev, generator=g) * 0.3).to(torch.bfloat16)
+    w = (torch.randn(1024, 256, device=dev, generator=g) * 0.06).to(torch.bfloat16)
+    dx = torch.full((rows, 256), float('nan'), device=dev, dtype=torch.bfloat16)
+    N.check(N.lib().dic_lstm_dx_wide(N.ptr(dg), N.ptr(w), rows, 1024, 256, N.ptr(dx), N.stream_of(dg)), 'dic_lstm_dx_wide')
+    ref64 = dg.double() @ w.double()
+    assert torch.isfinite(dx.float()).all()
+    err = (dx.double() - ref64).abs()
+    assert float(err.max()) <= 2.0 ** -8 * float(ref64.abs().max()) + 1e-6              # one bf16 rounding of an f32-accumulated sum
+    lib = (dg @ w).double()
+    assert float((dx.double() - lib).abs().max()) <= 2.0 ** -7 * float(ref64.abs().max())
+    assert N.lib().dic_lstm_dx_wide(N.ptr(dg), N.ptr(w), 31, 1024, 256, N.ptr(dx), N.stream_of(dg)) == -1      # fewer rows than a tile: rejected
