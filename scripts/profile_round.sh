@@ -19,10 +19,14 @@ unset DIC_DW_SIDE_STREAM
 cp /tmp/p_stats1/b_kernel_stats.csv $OUT/bench_single_stream_kernel_stats.csv
 echo "[profile] kernel stats done"
 # 2. HBM traffic per kernel (micro table at the bench batch)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_fetch -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_write -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
+# (k1 / k2 on the ragged encounter store, the input path of the timed step; the padded-input launches of the same kernels in a pass of their own)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_fetch -o p -- python3 $ROOT/scripts/kbench.py 32768 3 4 store > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_write -o p -- python3 $ROOT/scripts/kbench.py 32768 3 4 store > /dev/null 2>&1
 python3 $ROOT/scripts/pmc_traffic.py /tmp/p_fetch/p_counter_collection.csv /tmp/p_write/p_counter_collection.csv 32768 $R > $OUT/traffic.txt
 cp $ROOT/profiles/traffic.json $OUT/traffic.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/d_fetch -o p -- python3 $ROOT/scripts/kbench.py 32768 3 4 nolstm dense > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/d_write -o p -- python3 $ROOT/scripts/kbench.py 32768 3 4 nolstm dense > /dev/null 2>&1
+python3 $ROOT/scripts/pmc_generic.py /tmp/d_fetch/p_counter_collection.csv /tmp/d_write/p_counter_collection.csv 'sci_cci|rbf_' > $OUT/k1k2_padded_input_pmc_traffic.json
 echo "[profile] kernel traffic done"
 # 3. HBM traffic of the whole step
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/s_fetch -o p -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline --steps 6 --warmup 2 --kernel-iters 1 > /dev/null 2>&1
@@ -31,8 +35,8 @@ python3 $ROOT/scripts/step_traffic.py /tmp/s_fetch/p_counter_collection.csv /tmp
 cp $ROOT/profiles/step_traffic.json $OUT/step_traffic.json
 echo "[profile] step traffic done"
 # 4. SQ counters of the hand-written kernels at the bench batch
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d /tmp/sq1 -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/sq2 -o p -- python3 $ROOT/scripts/kbench.py 32768 3 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d /tmp/sq1 -o p -- python3 $ROOT/scripts/kbench.py 32768 3 4 store > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/sq2 -o p -- python3 $ROOT/scripts/kbench.py 32768 3 4 store > /dev/null 2>&1
 python3 $ROOT/scripts/pmc_sq.py $OUT/kernels_pmc_sq.json /tmp/sq1/p_counter_collection.csv /tmp/sq2/p_counter_collection.csv > $OUT/kernels_pmc_sq.txt
 echo "[profile] SQ counters done"
 # 5. the k-means kernels on cfg5's own data: kernel statistics + HBM traffic (the Lloyd record of bench.py's cfg5)
