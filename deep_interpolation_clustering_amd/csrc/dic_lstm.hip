@@ -851,11 +851,32 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             dc[nb][k] = dct * fg;
             ccar[nb][k] = (float)x.cp[j];                 // this step's c_prev is the next visited step's c
         }
+#ifdef DIC_LSTM_BWD_B64_WRITES       // round 2's form: four 8-B stores per lane, 16 consecutive rows per LDS pass -> rows r and r + 8 share banks
         __bf16* lp = dgt + (nb * 32 + r) * GSTR + u;
         *reinterpret_cast<bf16x4*>(lp) = di;
         *reinterpret_cast<bf16x4*>(lp + LH) = df;
         *reinterpret_cast<bf16x4*>(lp + 2 * LH) = dg;
         *reinterpret_cast<bf16x4*>(lp + 3 * LH) = dO;
+#else
+        // The two lane halves hold units u..u+3 (hh = 0) and u+4..u+7 (hh = 1) of the same row: four v_permlane32_swap trade them so that
+        // the lower half ends up with the whole 8-unit (16-B) pieces of gates i and g, the upper half with those of f and o, and each lane
+        // issues TWO 16-B stores.  A ds_write_b128 pass covers 8 consecutive rows: at the 1040-B row pitch they fall on 8 x 4 distinct
+        // banks -- no conflict (the 8-B stores were 2-way: SQ_LDS_BANK_CONFLICT 22 % of the kernel's LDS cycles in round 2).
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x2 I = __builtin_bit_cast(u32x2, di), F = __builtin_bit_cast(u32x2, df), G = __builtin_bit_cast(u32x2, dg), O = __builtin_bit_cast(u32x2, dO);
+        {   // permlane32_swap(x, y): x of lanes 32..63 <-> y of lanes 0..31
+            auto s0 = __builtin_amdgcn_permlane32_swap(I[0], F[0], false, false); I[0] = s0[0]; F[0] = s0[1];
+            auto s1 = __builtin_amdgcn_permlane32_swap(I[1], F[1], false, false); I[1] = s1[0]; F[1] = s1[1];
+            auto s2 = __builtin_amdgcn_permlane32_swap(G[0], O[0], false, false); G[0] = s2[0]; O[0] = s2[1];
+            auto s3 = __builtin_amdgcn_permlane32_swap(G[1], O[1], false, false); G[1] = s3[0]; O[1] = s3[1];
+        }
+        // lower half: (I, F) = gate i of units u..u+7 (this lane's four, then the partner's), (G, O) = gate g; upper half: gates f and o
+        __bf16* lp = dgt + (nb * 32 + r) * GSTR + (32 * w + 8 * q) + hh * LH;
+        const u32x4 c0 = {I[0], I[1], F[0], F[1]}, c1 = {G[0], G[1], O[0], O[1]};
+        *reinterpret_cast<u32x4*>(lp) = c0;
+        *reinterpret_cast<u32x4*>(lp + 2 * LH) = c1;
+#endif
     };
     // one of this wave's 8 rows of half nb: dG row LDS -> global (whole 1-KiB row per wave instruction, row-major for the
     // weight-gradient GEMMs) + bias column sums, then four k-steps of dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n]
