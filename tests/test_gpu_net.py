@@ -430,3 +430,43 @@ def test_fast_path_switches_leave_the_step_unchanged(module, switch, loss, fake,
         res[on] = (np.array(out), st.flat.flat.detach().clone())
     np.testing.assert_array_equal(res[True][0], res[False][0])
     assert torch.equal(res[True][1], res[False][1])
+
+
+def test_joint_step_K8_large_batch_bf16_tracks_f32():
+    """BASELINE configs[2]'s model (K = 8) at a batch that takes every large-batch kernel (64-row recurrences, one-pass weight gradients,
+    resident-weight projections, fused CompressFC, ragged store input): three steps of the bf16 fast mode follow the f32 parity mode, whose
+    single step is pinned against the reference at this K by tests/test_gpu_traj.py::test_joint_step_cfg_shape_kmeans_centroids[8]."""
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    args = SimpleNamespace(num_variables=6, num_timestamps=96, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=8, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    B = 8192
+    coh = synthetic.make_cohort(B, G=8, seed=33)
+    x_np, _, n = synthetic.stacked_batch(coh)
+    store = RaggedStore(x_np, 6, dev)
+    rb = RaggedBatch(store, torch.arange(B, device=dev))
+    g = torch.tensor(coh['phenotype'].astype(np.int64), device=dev)
+    traj = {}
+    for mode in ('bf16', 'f32'):
+        torch.manual_seed(4)
+        net = Net(args, dev).to(dev)
+        net.eval()
+        with torch.no_grad():            # centroids on the latents' clusters: the p3 regime
+            z = net(rb)[0]
+            net.init_cluster_center(torch.stack([z[g == j].mean(0) for j in range(8)]))
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16 if mode == 'bf16' else None,
+                     use_graphs=False)
+        out = []
+        for _ in range(3):
+            losses, gnorm, _ = st.step(rb, None, None)
+            out.append([float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(losses['kl'].detach())])
+        traj[mode] = np.array(out)
+    assert traj['f32'][0, 2] > 0.01
+    np.testing.assert_allclose(traj['bf16'], traj['f32'], rtol=2e-2)
+    assert traj['f32'][2, 1] < traj['f32'][0, 1]
