@@ -783,10 +783,9 @@ def main():
                                             else 'stand-alone HIP events (no step trace available)',
                          'frac_standalone': table[dom]['frac_hbm_peak'], 'ms_per_launch_standalone': table[dom]['ms'],
                          'chosen_by': 'launches per step x in-step duration (trace of the timed step)',
-                         'note': 'frac = algorithmic bytes per launch / the duration this kernel has INSIDE the timed step, where its encoder-side '
-                                 'launch shares the chip with lstm_dw_wide on a side stream (DIC_DW_SIDE_STREAM=0 turns that off); frac_standalone = '
-                                 'HIP events around back-to-back launches on an otherwise idle chip.  The rocprofv3 average of this command '
-                                 '(profiles/) mixes the two in the proportion of their launch counts'},
+                         'note': 'frac = algorithmic bytes per launch / the duration this kernel has INSIDE the timed step (per-dispatch GPU timestamps); '
+                                 'frac_standalone = HIP events around back-to-back launches on an otherwise idle chip.  With DIC_DW_SIDE_STREAM=1 '
+                                 '(round 2 default, now off: measured slower) the encoder-side launch shares the chip with lstm_dw_wide and the in-step figure drops'},
             'kernels': table,
             'whole_step': {'gflop_per_step_dense(lstm+fc, fwd+bwd)': round(gflop, 1), 'tflops': round(gflop / ms, 1),
                            'frac_bf16_mfma_peak(2500 TF)': round(gflop / ms / 2500.0, 4),

@@ -61,9 +61,11 @@ def f32_available(x, lstm):
             and all(p.dtype == torch.float32 for p in lstm.parameters()))
 
 
-# The decoder's weight-gradient kernel (MFMA-bound) has no consumer before the optimizer: inside step.Stepper's backward it runs on a
-# side stream next to the bandwidth-bound encoder backward that follows on the main stream (side_stream_session joins at the end).
-DW_SIDE_STREAM = os.environ.get('DIC_DW_SIDE_STREAM', '1') != '0'
+# The decoder's weight-gradient kernel has no consumer before the optimizer: inside step.Stepper's backward it CAN run on a side stream next
+# to the encoder backward that follows on the main stream (side_stream_session joins at the end).  Round 2 measured that as a win (6.56 ->
+# 6.46 ms); round 3's same-box A/B (3 x 60 steps each) has it LOSING by 0.03-0.07 ms (6.505 vs 6.44-6.48 ms): both kernels are bound by the
+# same HBM, the encoder's lstm_bwd stretches from 0.85 to 1.77 ms while they share the chip, and nothing is hidden.  Off by default.
+DW_SIDE_STREAM = os.environ.get('DIC_DW_SIDE_STREAM', '0') == '1'
 # the decoder's input gradient dX = dG.W_ih on the hand-written resident-weight kernel (csrc/dic_dxproj.hip) instead of the library GEMM:
 # OFF by default -- measured 571 us against the library's 447 us at B = 32 768 (per-CU ingest bound, see the kernel's header)
 DX_KERNEL = os.environ.get('DIC_DX_KERNEL', '0') == '1'

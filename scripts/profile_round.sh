@@ -11,12 +11,12 @@ cd /tmp && export TMPDIR=/tmp
 # 1. kernel statistics of the bench command itself
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 cp /tmp/p_stats/b_kernel_stats.csv $OUT/bench_kernel_stats.csv
-# 1b. the same with the decoder's weight-gradient kernel on the main stream (DIC_DW_SIDE_STREAM=0): no two kernels share the chip, so
-#     every average is a stand-alone duration (in the default run the encoder's lstm_bwd launches of the step overlap with lstm_dw_wide)
-export DIC_DW_SIDE_STREAM=0
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats1 -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/bench_single_stream_under_rocprof.json 2> /dev/null
+# 1b. the same with the decoder's weight-gradient kernel on a side stream next to the encoder backward (DIC_DW_SIDE_STREAM=1, round 2's default):
+#     the encoder's lstm_bwd launches of the step then share the chip with lstm_dw_wide and stretch
+export DIC_DW_SIDE_STREAM=1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats1 -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/bench_side_stream_under_rocprof.json 2> /dev/null
 unset DIC_DW_SIDE_STREAM
-cp /tmp/p_stats1/b_kernel_stats.csv $OUT/bench_single_stream_kernel_stats.csv
+cp /tmp/p_stats1/b_kernel_stats.csv $OUT/bench_side_stream_kernel_stats.csv
 echo "[profile] kernel stats done"
 # 2. HBM traffic per kernel (micro table at the bench batch)
 # (k1 / k2 on the ragged encounter store, the input path of the timed step; the padded-input launches of the same kernels in a pass of their own)
