@@ -531,10 +531,12 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
             *reinterpret_cast<bf16x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + u]) = hb;
             if (a.gates) {
                 const int bt = blockIdx.x * LNB + nb;
+#ifndef DIC_LSTM_EXP_RECOMPUTE   // experiment (scripts/lstm_recompute_ab.sh, timing only): the backward recomputes the gates, the forward does not save them
                 *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 0, qb + q, hh, r)) = ib;
                 *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 1, qb + q, hh, r)) = fb;
                 *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 2, qb + q, hh, r)) = gb;
                 *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 3, qb + q, hh, r)) = ob;
+#endif
                 bf16x4 cb;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cb[j] = (__bf16)cv[j];
@@ -706,10 +708,12 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
             *reinterpret_cast<bf16x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + u]) = hb;
             if (a.gates) {
                 const int bt = blockIdx.x * LNB + nb;
+#ifndef DIC_LSTM_EXP_RECOMPUTE   // experiment (scripts/lstm_recompute_ab.sh, timing only): the backward recomputes the gates, the forward does not save them
                 *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 0, qb + q, hh, r)) = ib;
                 *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 1, qb + q, hh, r)) = fb;
                 *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 2, qb + q, hh, r)) = gb;
                 *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 3, qb + q, hh, r)) = ob;
+#endif
                 bf16x4 cb;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cb[j] = (__bf16)cv[j];
@@ -770,6 +774,11 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
     for (int ks = 0; ks < 32; ++ks)
         wt[ks] = *reinterpret_cast<const bf16x8*>(a.whh_t + ((size_t)dir * LH + 32 * w + r) * 4 * LH + ks * 16 + 8 * hh);
 
+#ifdef DIC_LSTM_EXP_RECOMPUTE
+    f32x16 exp_acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) exp_acc[k] = 0.f;
+#endif
     f32x16 dh[LNB];        // recurrent dL/dh arriving at the current step
     float dc[LNB][16];
     float ccar[LNB][16];   // c of the step processed next (= this step's c_prev): each cell state is read once
@@ -814,9 +823,13 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             const int u = 32 * w + 8 * q + 4 * hh;
             StepIn& d = in[nb][q];
             d.ib = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
+#ifdef DIC_LSTM_EXP_RECOMPUTE    // experiment (timing only, wrong results): ONE 2-B-per-unit plane stands in for the h_prev row a recomputing backward reads
+            d.fb = d.ib; d.gb = d.ib; d.ob = d.ib;
+#else
             d.fb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
             d.gb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
             d.ob = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
+#endif
             bf16x4 cp = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
             else if (a.c0) {
@@ -841,7 +854,11 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 4 * q + j;
+#ifdef DIC_LSTM_EXP_RECOMPUTE    // ... and the four activations of the recomputed pre-activations (3 sigmoids + 1 tanh = 8 transcendentals per unit)
+            const float ig = sigmoid_fast((float)x.ib[j]), fg = sigmoid_fast((float)x.fb[j] + 0.1f), gg = tanh_fast((float)x.gb[j]), og = sigmoid_fast((float)x.ob[j] - 0.1f);
+#else
             const float ig = (float)x.ib[j], fg = (float)x.fb[j], gg = (float)x.gb[j], og = (float)x.ob[j];
+#endif
             const float tc = tanh_fast(ccar[nb][k]);
             const float dht = dh[nb][k] + ((a.relu && !(tc > 0.f)) ? 0.f : (float)x.go[j]);
             const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
@@ -893,6 +910,11 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         for (int ks = 4 * k; ks < 4 * k + 4; ++ks) {
             const bf16x8 gbv = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + r) * GSTR + ks * 16 + 8 * hh);
             dh[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, dh[nb], 0, 0, 0);
+#ifdef DIC_LSTM_EXP_RECOMPUTE    // ... and the 80 MFMAs per wave and step of W_hh.h_prev + W_ih.x (5 per 4 of the backward's own; OPTIMISTIC: they reuse the
+            // resident W_hh^T fragments and the dG tile as operands, so the 128 extra weight registers and the h / x tiles in LDS cost nothing here)
+            exp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, exp_acc, 0, 0, 0);
+            if ((ks & 3) == 3) exp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks ^ 1], gbv, exp_acc, 0, 0, 0);
+#endif
         }
     };
     {   // prologue: c of the first visited step, the inputs of both halves, and half 0's first gate gradients
@@ -950,6 +972,9 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         DIC_STAMP(1, step, 4);
         DIC_STAMP(1, step, 5);
     }
+#ifdef DIC_LSTM_EXP_RECOMPUTE
+    asm volatile("" :: "v"(exp_acc));                      // (keeps the experiment's products alive)
+#endif
     __syncthreads();                                       // the dG tile is free for the bias reduction below
     if (a.dbias_part) {     // add the 4 waves' column sums through LDS (the dG tile is free now): one partial per workgroup
         float* red = reinterpret_cast<float*>(dgt);
