@@ -97,6 +97,7 @@ SIGNATURES = {
     'dic_bnhead_bwd_reduce': (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p, _sz, _p]),
     'dic_bnhead_bwd_input': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_double, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p]),
     'dic_cluster_pairdist': (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    'dic_cluster_intra_sums': (_i, [_p, _p, _i, _i, _i, _p, _p]),
     'dic_adam_amsgrad_step': (_i, [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     'dic_grad_norm_workspace': (_sz, [C.c_int64]),
     'dic_grad_norm_clip': (_i, [_p, C.c_int64, _f, _p, _p, _sz, _p]),

@@ -47,17 +47,19 @@ class PairStats:
     """Result of one pair pass: ``labels`` (N) encoded 0..K-1, ``counts`` (K), ``S`` / ``Dmin`` (N,K) f32 and ``own_max`` (N),
     all in the caller's row order."""
 
-    def __init__(self, labels, counts, S, Dmin, own_max):
-        self.labels, self.counts, self.S, self.Dmin, self.own_max = labels, counts, S, Dmin, own_max
+    def __init__(self, labels, counts, S, Dmin, own_max, S_own=None):
+        self.labels, self.counts, self.S, self.Dmin, self.own_max, self.S_own = labels, counts, S, Dmin, own_max, S_own
         self.K = int(counts.numel())
 
     def intra_sums(self):
         """(K,) f64: sum over ordered pairs (i, j) of one cluster of ||x_i - x_j||  (= np.sum(pairwise_distances(X_c)))."""
-        own = self.S.gather(1, self.labels[:, None])[:, 0].double()
+        own = (self.S_own if self.S is None else self.S.gather(1, self.labels[:, None])[:, 0]).double()
         return _segment_sum(own, self.labels, self.K)
 
 
-def pair_stats(x, labels, need_min=True, need_max=True):
+def pair_stats(x, labels, need_min=True, need_max=True, intra_only=False):
+    """``intra_only``: only the pairs inside a cluster (``dic_cluster_intra_sums``: sum_c n_c^2 of the N^2 pairs) -- what the two inertia
+    definitions of the gap statistic need; ``S`` / ``Dmin`` / ``own_max`` are then None and ``S_own`` (N) holds each point's own-cluster sum."""
     x = _device_points(x)
     n, d = x.shape
     lab, K = _encode(labels, x.device)
@@ -71,6 +73,12 @@ def pair_stats(x, labels, need_min=True, need_max=True):
     counts = torch.bincount(lab, minlength=K)
     seg = torch.zeros(K + 1, dtype=torch.int32, device=x.device)
     seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    if intra_only:
+        S_own = torch.empty(n, device=x.device, dtype=torch.float32)
+        N.check(N.lib().dic_cluster_intra_sums(N.ptr(xs), N.ptr(seg), n, d, K, N.ptr(S_own), N.stream_of(xs)), 'dic_cluster_intra_sums')
+        out = torch.empty_like(S_own)
+        out[order] = S_own
+        return PairStats(lab, counts, None, None, None, out)
     S = torch.empty((n, K), device=x.device, dtype=torch.float32)
     Dmin = torch.empty_like(S) if need_min else None
     omax = torch.empty(n, device=x.device, dtype=torch.float32) if need_max else None
@@ -89,14 +97,14 @@ def pair_stats(x, labels, need_min=True, need_max=True):
 # ---------------------------------------------------------------------------- gap-statistic inertia (p2:334-351)
 def inertia_v1(x, labels, stats=None):
     """np.mean([np.mean(pairwise_distances(X[a == c])) for c in unique(a)])  (p2:334-342)."""
-    st = stats or pair_stats(x, labels, need_min=False, need_max=False)
+    st = stats or pair_stats(x, labels, intra_only=True)
     n = st.counts.double()
     return float((st.intra_sums() / (n * n)).mean())
 
 
 def inertia_v2(x, labels, stats=None):
     """sum_c sum(pairwise_distances(X[a == c])) / (2 n_c)  (p2:344-351)."""
-    st = stats or pair_stats(x, labels, need_min=False, need_max=False)
+    st = stats or pair_stats(x, labels, intra_only=True)
     return float((st.intra_sums() / (2.0 * st.counts.double())).sum())
 
 

@@ -48,6 +48,9 @@ __device__ __forceinline__ float row16_min(float v) {
     return v;
 }
 
+// INTRA: only the pairs inside a cluster are wanted (the gap statistic's inertia of a reference set, p2:334-351: sum_c n_c^2 pairs instead
+// of N^2): a row tile visits the column tiles of the clusters its own rows belong to, and S holds ONE value per point (its own cluster's sum).
+template <bool INTRA>
 __global__ __launch_bounds__(256) void pairdist_kernel(const float* __restrict__ X, const int* __restrict__ seg, int N, int D, int K,
                                                        float* __restrict__ S, float* __restrict__ Dmin, float* __restrict__ own_max) {
     __shared__ float xi[PT * PLD], xj[PT * PLD];
@@ -69,7 +72,14 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const float* __restrict__
     }
     float rmax[4] = {0.f, 0.f, 0.f, 0.f};
 
-    for (int k = 0; k < K; ++k) {
+    int k_lo = 0, k_hi = K - 1;
+    if (INTRA) {           // rows are sorted by cluster: the tile's rows span the clusters of its first and of its last valid row (uniform over the workgroup)
+        const int first = i0, last = min(i0 + PT, N) - 1;
+        while (k_lo + 1 < K && seg[k_lo + 1] <= first) ++k_lo;
+        k_hi = k_lo;
+        while (k_hi + 1 < K && seg[k_hi + 1] <= last) ++k_hi;
+    }
+    for (int k = k_lo; k <= k_hi; ++k) {
         const int jbeg = seg[k], jend = seg[k + 1];
         float rsum[4] = {0.f, 0.f, 0.f, 0.f}, rmin[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
         for (int j0 = jbeg; j0 < jend; j0 += PT) {
@@ -130,7 +140,9 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const float* __restrict__
         for (int r = 0; r < 4; ++r) {
             const float s = row16_sum(rsum[r]), mn = row16_min(rmin[r]);
             const int i = i0 + ty + 16 * r;
-            if (tx == 0 && i < N) {
+            if (INTRA) {
+                if (tx == 0 && i < N && own[r] == k) S[i] = s;
+            } else if (tx == 0 && i < N) {
                 S[(size_t)i * K + k] = s;
                 if (Dmin) Dmin[(size_t)i * K + k] = mn;
             }
@@ -157,8 +169,18 @@ int dic_cluster_pairdist(const float* X, const int32_t* seg, int N, int D, int K
     DIC_REQUIRE(K <= 64, DIC_ERR_UNSUPPORTED, "cluster_pairdist: K=%d > 64", K);
     DIC_REQUIRE(X && seg && S, DIC_ERR_INVALID_ARG, "cluster_pairdist: NULL pointer");
     const int grid = (N + PT - 1) / PT;
-    hipLaunchKernelGGL(pairdist_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, seg, N, D, K, S, Dmin, own_max);
+    hipLaunchKernelGGL(pairdist_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, seg, N, D, K, S, Dmin, own_max);
     return check_launch("cluster_pairdist");
+}
+
+int dic_cluster_intra_sums(const float* X, const int32_t* seg, int N, int D, int K, float* S_own, dic_stream_t stream) {
+    DIC_REQUIRE(N > 0 && D > 0 && K > 0, DIC_ERR_INVALID_ARG, "cluster_intra_sums: non-positive size");
+    DIC_REQUIRE(D % 4 == 0, DIC_ERR_UNSUPPORTED, "cluster_intra_sums: D=%d must be a multiple of 4", D);
+    DIC_REQUIRE(K <= 64, DIC_ERR_UNSUPPORTED, "cluster_intra_sums: K=%d > 64", K);
+    DIC_REQUIRE(X && seg && S_own, DIC_ERR_INVALID_ARG, "cluster_intra_sums: NULL pointer");
+    const int grid = (N + PT - 1) / PT;
+    hipLaunchKernelGGL(pairdist_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, seg, N, D, K, S_own, (float*)nullptr, (float*)nullptr);
+    return check_launch("cluster_intra_sums");
 }
 
 }  // extern "C"

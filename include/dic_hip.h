@@ -446,6 +446,11 @@ int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, co
 int dic_cluster_pairdist(const float* X, const int32_t* seg, int N, int D, int K, float* S, float* Dmin, float* own_max,
                          dic_stream_t stream);
 
+/* The same pass restricted to the pairs INSIDE a cluster -- all the gap statistic's inertia of a reference set needs (p2_clustering_optK.py:
+ * 334-351: np.mean / np.sum of pairwise_distances(X[a == c]) per cluster): sum_c n_c^2 pairs instead of N^2.
+ *   S_own (N) OVERWRITTEN: S_own[i] = sum over the points j of i's own cluster of ||x_i - x_j||  (rows sorted by cluster, as above). */
+int dic_cluster_intra_sums(const float* X, const int32_t* seg, int N, int D, int K, float* S_own, dic_stream_t stream);
+
 /* ------------------------------------------------------------- optimisation step tail ---------
  * clip_grad_norm_ scaling + torch.optim.Adam(amsgrad=True, L2 weight decay) (pretrain_trainer.py:228-229, utils.py:83)
  * over one flat f32 bucket of n elements: p, g (scaled in place by *grad_scale, NULL = 1), exp_avg m, exp_avg_sq v,

@@ -28,6 +28,9 @@ def test_scores_match_reference(cs, name):
     st = cs.pair_stats(x, lab)
     np.testing.assert_allclose(cs.inertia_v1(x, lab, st), g['inertia_v1'], rtol=1e-5)
     np.testing.assert_allclose(cs.inertia_v2(x, lab, st), g['inertia_v2'], rtol=1e-5)
+    # the intra-cluster-only pass (dic_cluster_intra_sums: what the gap statistic's reference sets run) gives the reference's inertias too
+    np.testing.assert_allclose(cs.inertia_v1(x, lab), g['inertia_v1'], rtol=1e-5)
+    np.testing.assert_allclose(cs.inertia_v2(x, lab), g['inertia_v2'], rtol=1e-5)
     np.testing.assert_allclose(cs.dunn_index(x, lab, st), g['dunn'], rtol=1e-5)
     np.testing.assert_allclose(cs.silhouette_score(x, lab, st), g['silhouette'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(cs.calinski_harabasz_score(x, lab), g['calinski_harabasz'], rtol=1e-5)
@@ -85,6 +88,25 @@ def test_full_size_properties(cs):
     np.testing.assert_allclose(st.own_max[pick].cpu().numpy(), own.cpu().numpy(), rtol=2e-6)
     s = cs.silhouette_score(xd, lab, st)
     assert -1.0 <= s <= 1.0
+
+
+@pytest.mark.parametrize('n,d,k', [(63, 4, 2), (65, 36, 3), (1000, 256, 7), (1537, 20, 64), (300, 6, 5), (5000, 256, 1)])
+def test_intra_only_pass_equals_own_column_of_the_full_pass(cs, n, d, k):
+    """dic_cluster_intra_sums visits only the column tiles of the clusters a row tile's own rows belong to (sum_c n_c^2 of the N^2 pairs):
+    every point's own-cluster sum must be BIT-identical to the own column of the full pass (same tiles, same summation order), for
+    row tiles that straddle cluster boundaries, singleton clusters and K = 1."""
+    rng = np.random.default_rng(n + d + k)
+    x = rng.normal(0, 1, (n, d)).astype(np.float32)
+    lab = rng.integers(0, k, n)
+    lab[:k] = np.arange(k)                       # every label occurs
+    if k > 3:
+        lab[lab == k - 1] = 0
+        lab[k - 1] = k - 1                       # a singleton cluster
+    full = cs.pair_stats(x, lab, need_min=False, need_max=False)
+    intra = cs.pair_stats(x, lab, intra_only=True)
+    own = full.S.gather(1, full.labels[:, None])[:, 0]
+    assert torch.equal(intra.S_own, own)
+    assert intra.S is None and torch.equal(intra.intra_sums(), full.intra_sums())
 
 
 def test_gap_table_equals_reference(tmp_path):

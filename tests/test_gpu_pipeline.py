@@ -57,7 +57,9 @@ def test_p1_to_p4(run_dir):
     a2.internal_metrics = ['Calinski-Harabasz', 'Davies-Bouldin_Index']
     res = p2.main(a2)['ae_mse']
     assert list(res['gap_sts']['k']) == [2.0, 3.0, 4.0] and np.isfinite(res['gap_sts'][['gap', 'ref', 'act']].to_numpy()).all()
-    assert (np.diff(res['elbow']['train']) < 0).all()          # distortion falls as k grows
+    el = res['elbow']['train'].to_numpy()
+    assert np.isfinite(el).all() and el[-1] < el[0]            # distortion falls from k = 2 to k_max (single k-means++ inits, as upstream's
+                                                               # KMeans(k) with n_init='auto': a local optimum may make one step non-monotone)
 
     # ---- p4: final labels, both branches
     for method in ('kmeans', 'dl'):
