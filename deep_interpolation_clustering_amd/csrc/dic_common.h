@@ -19,6 +19,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // dic_kmeans_mfma.hip: E-step + partial M-step of a Lloyd iteration on the matrix cores, for 8 < K <= 32
 int kmeans_mfma_blocks(int N, int K, int n_runs);
+bool kmeans_use_mfma(int K, int n_runs);
 int kmeans_assign_mfma_launch(const float* X, const float* xnorm, int N, int D, int K, int n_runs, const float* centers, int32_t* labels,
                               const float* status, float* mind, float* psum, int* pcnt, hipStream_t st);
 

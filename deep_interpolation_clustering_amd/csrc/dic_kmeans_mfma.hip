@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
     float* cnorm = cent + MCOLS * MCP;                                   // [64]
     int* cnt = reinterpret_cast<int*>(cnorm + MCOLS);                    // [64] members per centroid column
     int* chg = cnt + MCOLS;                                              // [G] labels changed per restart
-    unsigned char* lab8 = reinterpret_cast<unsigned char*>(chg + 4);     // [4 waves][G][32]
+    unsigned char* lab8 = reinterpret_cast<unsigned char*>(chg + 4);     // [4 waves][G][32]  (G <= 4: KP >= 8)
+    static_assert(G <= 4, "chg[] has four slots");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, hh = lane >> 5;
     const int N = a.N, D = a.D, K = a.K;
     const int run0 = blockIdx.y * G;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
         *reinterpret_cast<kf32x2*>(dst + 2) = kf32x2{v[2], v[3]};
     }
     if (tid < MCOLS) cnt[tid] = 0;
-    if (tid < 4) chg[tid] = 0;
+    if (tid < G) chg[tid] = 0;
     __syncthreads();
     for (int col = w; col < MCOLS; col += 4) {           // row_norms (_k_means_lloyd.pyx:99), one wave per centroid
         const kf32x4 c = kf32x4{cent[col * MCP + lane * 4], cent[col * MCP + lane * 4 + 1], cent[col * MCP + lane * 4 + 2], cent[col * MCP + lane * 4 + 3]};
@@ -218,8 +219,16 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
 // workgroup was the first layout: it needs all 512 registers -- one workgroup per CU, spilling -- and pads 10 restarts of K = 16 to
 // 192 columns where 32-column groups need 160; with half the accumulators two workgroups fit a CU: 284 -> 254 us per iteration.)
 static int kmeans_mfma_groups(int K, int n_runs) {
-    const int G = 32 / (K <= 16 ? 16 : 32);
+    const int G = 32 / (K <= 8 ? 8 : K <= 16 ? 16 : 32);
     return (n_runs + G - 1) / G;
+}
+// K <= 8 too (round 3): the one-wave-per-row kernel of dic_latent.hip walks X once per RESTART (grid.y = restart: 20 x 77 MB out of L2 /
+// Infinity Cache per Lloyd iteration of KMeans(4, n_init=20), 0.41 ms); here four restarts of up to 8 centroids share every X tile.
+// Only where there is something to share -- two or more restarts in the launch; a single restart (fixed init, n_init = 1) stays on the
+// one-pass wave-per-row kernel.  DIC_KMEANS_SMALLK_MFMA=0 keeps the round-2 kernel for every K <= 8 launch.
+bool kmeans_use_mfma(int K, int n_runs) {
+    static const bool small_k = [] { const char* e = getenv("DIC_KMEANS_SMALLK_MFMA"); return !(e && e[0] == '0'); }();
+    return K > 8 || (small_k && n_runs >= 2);
 }
 int kmeans_mfma_blocks(int N, int K, int n_runs) {
     return (int)max(1L, min(((long)N + 127) / 128, (long)max(1, 2 * kNumCU / kmeans_mfma_groups(K, n_runs))));      // two workgroups per CU
@@ -244,7 +253,8 @@ int kmeans_assign_mfma_launch(const float* X, const float* xnorm, int N, int D, 
                               const float* status, float* mind, float* psum, int* pcnt, hipStream_t st) {
     KmMfmaArgs a{X, xnorm, N, D, K, n_runs, kmeans_mfma_blocks(N, K, n_runs), centers, labels, status, mind, psum, pcnt};
     const int groups = kmeans_mfma_groups(K, n_runs);
-    const int rc = K <= 16 ? kmeans_assign_mfma_launch_t<16, 1>(a, groups, st) : kmeans_assign_mfma_launch_t<32, 1>(a, groups, st);
+    const int rc = K <= 8 ? kmeans_assign_mfma_launch_t<8, 1>(a, groups, st)
+                 : K <= 16 ? kmeans_assign_mfma_launch_t<16, 1>(a, groups, st) : kmeans_assign_mfma_launch_t<32, 1>(a, groups, st);
     return rc ? rc : check_launch("kmeans_assign_mfma");
 }
 

@@ -717,7 +717,7 @@ int dic_kmeans_lloyd_iter(const float* X, const float* xnorm, int N, int D, int 
     double* sums = (double*)(ws + w.sums); float* mind = (float*)(ws + w.mind);
     hipStream_t st = (hipStream_t)stream;
     int np = nblk;                                    // partial slots per restart actually written
-    if (K > 8) {                                      // matrix-core E-step (dic_kmeans_mfma.hip); fewer, fatter workgroups
+    if (kmeans_use_mfma(K, n_runs)) {                         // matrix-core E-step (dic_kmeans_mfma.hip); fewer, fatter workgroups
         np = kmeans_mfma_blocks(N, K, n_runs);
         rc = kmeans_assign_mfma_launch(X, xnorm, N, D, K, n_runs, centers, labels, status, mind, psum, pcnt, st);
         if (rc) return rc;
@@ -751,7 +751,7 @@ int dic_kmeans_lloyd_partial(const float* X, const float* xnorm, int N, int D, i
     hipStream_t st = (hipStream_t)stream;
     const size_t words = dic_kmeans_stats_words(D, K);
     int np = nblk;
-    if (K > 8) {
+    if (kmeans_use_mfma(K, n_runs)) {
         np = kmeans_mfma_blocks(N, K, n_runs);
         rc = kmeans_assign_mfma_launch(X, xnorm, N, D, K, n_runs, centers, labels, status, mind, psum, pcnt, st);
         if (rc) return rc;

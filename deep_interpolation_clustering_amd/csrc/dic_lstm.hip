@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
     };
     // gate gradients of hidden units 32w + 8q + 4hh .. +3 of half nb -> its rows of the LDS dG tile; dc and the c carry advance
     auto math_q = [&](int nb, int q) {
-        const int u = 32 * w + 8 * q + 4 * hh;
+        [[maybe_unused]] const int u = 32 * w + 8 * q + 4 * hh;
         const StepIn& x = in[nb][q];
         bf16x4 di, df, dg, dO;
 #pragma unroll
