@@ -12,20 +12,25 @@
 //       LDS transposed (ds_read_b64_tr_b16): the reduction index (row) is the slow index of dZ and X in memory.
 // Tiles go global -> registers -> LDS (one 16-B piece of dZ and two of X per thread and tile, requested one tile ahead), two LDS
 // images so that a single barrier per tile suffices; the dX block leaves through an LDS staging tile as whole 512-B rows.
-// Row pitches of 256 + 48 / 512 + 48 B keep the straight 16-B reads (32 rows, same piece) and the transposed reads (4 rows x 32 B)
-// both free of bank conflicts.  Deterministic: per-workgroup dW partials, fixed-order f64 second stage.
+// Row pitches of 256 + 80 / 512 + 80 B (= 20 dwords mod 64) serve both kinds of read without bank conflicts: the straight 16-B reads
+// (the 16 rows of a ds_read_b128 lane group land on 16 different 4-bank slots: slot = 5 row mod 16) and the transposed reads, whose
+// 32-lane half takes 4 rows x 64 B -- with rows FOUR apart (4 x 20 dwords = 16 mod 64: four disjoint 16-bank groups), which is
+// free to choose because the tile row is the reduction index of dW: dZ and X fragments only have to agree on the order.  (Round 2's
+// 256 + 48 / 512 + 48 with rows 0..3 of a transposed read side by side overlapped by 4 banks per row: SQ_LDS_BANK_CONFLICT 23 %.)
+// The dX block reaches the staging tile as packed bf16 pairs (one DPP swap per pair of accumulator rows) instead of 2-byte stores.
+// Deterministic: per-workgroup dW partials, fixed-order f64 second stage.
 #include "dic_bnhead.h"
 
 namespace dic {
 
 constexpr int FO = 128, FI = 256;                    // out / in features of the layer
 constexpr int FT = 32;                               // rows per tile
-constexpr int FZ_PITCH = FO * 2 + 48;                // 304 B
-constexpr int FX_PITCH = FI * 2 + 48;                // 560 B
-constexpr int FS_PITCH = FI * 2 + 16;                // 528 B: dX staging rows
-constexpr int F_TILE = FT * (FZ_PITCH + FX_PITCH);   // 27 648 B per tile image
-constexpr int F_STAGE = FT * FS_PITCH;               // 16 896 B
-constexpr int F_LDS = 2 * F_TILE + 2 * F_STAGE;      // 89 088 B
+constexpr int FZ_PITCH = FO * 2 + 80;                // 336 B
+constexpr int FX_PITCH = FI * 2 + 80;                // 592 B
+constexpr int FS_PITCH = FI * 2 + 64;                // 576 B: dX staging rows (rows m, m + 1 written by one store: 16 banks apart)
+constexpr int F_TILE = FT * (FZ_PITCH + FX_PITCH);   // 29 696 B per tile image
+constexpr int F_STAGE = FT * FS_PITCH;               // 18 432 B
+constexpr int F_LDS = 2 * F_TILE + 2 * F_STAGE;      // 96 256 B
 constexpr int F_W2_MAX = 12;                         // FUSED: 128-float rows kept behind the staging tiles: the head weight W2 (C rows) + 6 rows of column constants
 constexpr int F_LDS_FUSED = F_LDS + F_W2_MAX * FO * 4;
 
@@ -171,12 +176,13 @@ __global__ __launch_bounds__(512) void fc_bwd_kernel(FcBwdArgs a) {
         *reinterpret_cast<uint4*>(base + FT * FZ_PITCH + (xrow + 16) * FX_PITCH + xpc * 16) = px1;
     };
 
-    // transposed-read addressing (see lstm_dw_kernel): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3; lane l of the
-    // 32x32x16 operand needs column (l & 31) and rows 8 (l >> 5) + 0..7 of the k-step
+    // transposed-read addressing (see lstm_dw_kernel): lane 4q+p of a 16-lane group supplies "row" q, columns 4p..4p+3; lane l of the
+    // 32x32x16 operand takes column (l & 31) and 8 reduction terms.  Which tile rows those are is free (the same for dZ and X): the q-th
+    // row of a read is tile row 16 ks + 4 q + 2 (l >> 5) (+ 1 for the second read), see the note on the pitches
     const int kq = (lane & 15) >> 2, kp = lane & 3, cb = (lane >> 4) & 1, hh = lane >> 5;
-    const int rowoff = 8 * hh + kq;
+    const int rowoff = 4 * kq + 2 * hh;
     auto frag = [&](const unsigned char* p, int pitch) {
-        const fs16x4 lo = f_lds_tr16(p), hi = f_lds_tr16(p + 4 * pitch);
+        const fs16x4 lo = f_lds_tr16(p), hi = f_lds_tr16(p + pitch);
         fs16x8 f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
@@ -227,11 +233,23 @@ __global__ __launch_bounds__(512) void fc_bwd_kernel(FcBwdArgs a) {
         if (tile + nwg < ntiles) land(slot ^ 1);
         if (tile + 2 * nwg < ntiles) request(tile + 2 * nwg);
         if (a.dx) {
+            // accumulators 2p, 2p + 1 of a lane are rows m, m + 1 of its column: the even lane of a pair takes both columns of row m, the odd
+            // lane those of row m + 1 (one quad_perm [1,0,3,2] swap), each stores ONE packed dword
             unsigned char* sb = stage + slot * F_STAGE;
+            const int odd = lane & 1;
+            unsigned char* sdst = sb + odd * FS_PITCH + (32 * w + ((lane & 31) & ~1)) * 2;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int m = (k & 3) + 8 * (k >> 2) + 4 * hh;
-                *reinterpret_cast<__bf16*>(sb + m * FS_PITCH + (32 * w + (lane & 31)) * 2) = (__bf16)acc[k];
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k0 = 2 * kk, m = (k0 & 3) + 8 * (k0 >> 2) + 4 * hh;
+                // (both candidates are formed and ONE select picks: a select between acc[k0] and acc[k0 + 1] themselves becomes a dynamic
+                // vector index, i.e. a 16-way select chain)
+                const float a0 = acc[k0], a1 = acc[k0 + 1];       // (locals: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0)
+                const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a0), 0xB1, 0xF, 0xF, true));
+                const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a1), 0xB1, 0xF, 0xF, true));
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const bf16x2_t pe = {(__bf16)a0, (__bf16)n0}, po = {(__bf16)n1, (__bf16)a1};
+                const unsigned pk = odd ? __builtin_bit_cast(unsigned, po) : __builtin_bit_cast(unsigned, pe);
+                *reinterpret_cast<unsigned*>(sdst + m * FS_PITCH) = pk;
             }
         }
         __syncthreads();

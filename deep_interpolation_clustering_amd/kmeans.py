@@ -136,7 +136,13 @@ def lloyd_sharded(X, xnorm, centers, tol, max_iter):
     return labels, inertia, status
 
 
-def _pp_init(X, K, n_runs, rs, after_draws=None, shard=False):
+def seed_draw_count(K, n_init):
+    """Doubles a k-means++ fit takes from its random stream (``_pp_init``: per restart one ``choice`` = one double, then K-1 times
+    ``uniform(size=trials)``) -- independent of the data, so a caller can advance a stream past a fit it does not run (p2's sharded sweep)."""
+    return int(n_init) * (1 + (int(K) - 1) * (2 + int(np.log(K))))
+
+
+def _pp_init(X, K, n_runs, rs, shard=False):
     """k-means++ (greedy, 2+log K local trials) for n_runs restarts at once.  Every random number is
     drawn from ``rs`` up front in scikit-learn's order (per restart: one ``choice`` then K-1
     ``uniform(size=trials)``), which is possible because the Lloyd runs consume no randomness."""
@@ -151,8 +157,6 @@ def _pp_init(X, K, n_runs, rs, after_draws=None, shard=False):
         first[r] = rs.choice(Nn, p=p_uniform)
         for c in range(K - 1):
             u[r, c] = rs.uniform(size=trials)
-    if after_draws is not None:          # the fit consumes no randomness past this point (see KMeans._after_seeding)
-        after_draws()
     u = torch.as_tensor(u, device=dev)
     st = N.stream_of(X)
     centers_idx = torch.empty((n_runs, K), dtype=torch.int64, device=dev)
@@ -214,9 +218,6 @@ class KMeans:
         # shard with one all-reduce of centroid partial sums per iteration (lloyd_sharded), and the k-means++ candidate distances
         # are evaluated per row shard too (the random draws stay replicated: same stream on every rank).
         self.shard_points = shard_points
-        # (private) called once the fit has drawn its last random number (k-means++ draws everything up front): p2 uses it to start
-        # drawing the next gap-statistic reference set on a worker thread while this fit's GPU work runs, in the same stream order
-        self._after_seeding = None
 
     # -- helpers ------------------------------------------------------------------------------
     def _random_state(self):
@@ -265,7 +266,7 @@ class KMeans:
                 raise ValueError(f'The shape of the initial centers {tuple(c0.shape)} does not match (n_clusters, n_features)')
             centers = _pad_features(c0 - mean)[None].contiguous()
         elif self.init == 'k-means++':
-            centers = _pp_init(Xc, K, n_init, rs, self._after_seeding, shard=self.shard_points and dist.is_sharded() and Nn >= dist.world_size()).contiguous()
+            centers = _pp_init(Xc, K, n_init, rs, shard=self.shard_points and dist.is_sharded() and Nn >= dist.world_size()).contiguous()
         elif self.init == 'random':
             p = np.full(Nn, 1.0 / Nn)
             seeds = np.stack([rs.choice(Nn, size=K, replace=False, p=p) for _ in range(n_init)])

@@ -10,18 +10,19 @@ Results/Pretrain/out_feat/<metric>_kmeans_aligned/plot/{elbow.csv, gap_sts_v1.cs
 upstream script are alternative algorithms / presentation and are not provided.
 """
 import argparse
-import concurrent.futures
 import os
+import queue
+import threading
 import os.path as osp
 
 import numpy as np
 import pandas as pd
 import torch
 
-from . import cluster_stats
+from . import cluster_stats, dist
 from .info import COHORTS
 from .internal_eval import CHIndex, DBIndex, DunnIndex, Sihouette
-from .kmeans import KMeans
+from .kmeans import KMeans, seed_draw_count
 from .utils import logger, print_dict_byline
 
 np.random.seed(123)        # p2_clustering_optK.py:23
@@ -59,6 +60,68 @@ def global_uniform_into(out):
     return out
 
 
+def _random_state_at(state):
+    rs = np.random.RandomState()
+    rs.set_state(state)
+    return rs
+
+
+class _StreamWalker:
+    """Walks NumPy's global stream through the gap statistic's draws in upstream's order on a worker thread (see
+    ``KM.compute_gap_internal_metric``).  Iterating yields, for the problems of this rank only and in stream order,
+    ``(k index, i, buffer, state)``: ``i < n_references`` is a reference fit (``buffer`` = its uniform draws, to be handed back with
+    ``release``), ``i == n_references`` the fit on the data (``buffer`` None); ``state`` is the global stream's state where that fit's
+    seeding starts.  Problems of other ranks only advance the stream (their uniform draws go to a scratch buffer)."""
+
+    def __init__(self, shape, ks, n_references, n_init, rank=0, world=1, n_buffers=2):
+        self.free = queue.Queue()
+        for _ in range(n_buffers):
+            self.free.put(torch.empty(shape, dtype=torch.float64, pin_memory=torch.cuda.is_available()).numpy())
+        self.out = queue.Queue()
+        self.shape, self.ks, self.n_ref, self.n_init, self.rank, self.world = tuple(shape), ks, n_references, n_init, rank, world
+        self.thread = threading.Thread(target=self._walk, daemon=True)
+        self.thread.start()
+
+    def _walk(self):
+        try:
+            scratch = None
+            j = 0
+            for ki, k in enumerate(self.ks):
+                n_seed = seed_draw_count(k, self.n_init)
+                for i in range(self.n_ref + 1):
+                    mine = j % self.world == self.rank
+                    j += 1
+                    buf = None
+                    if i < self.n_ref:
+                        if mine:
+                            buf = self.free.get()
+                        else:
+                            buf = scratch = np.empty(self.shape, np.float64) if scratch is None else scratch
+                        global_uniform_into(buf)
+                    state = np.random.get_state()
+                    np.random.random_sample(n_seed)               # what the fit's k-means++ seeding consumes
+                    if mine:
+                        self.out.put((ki, i, buf, state))
+            self.out.put(None)
+        except BaseException as e:                                # surfaced by the consumer
+            self.out.put(e)
+
+    def __iter__(self):
+        while True:
+            item = self.out.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def release(self, buf):
+        self.free.put(buf)
+
+    def join(self):
+        self.thread.join()
+
+
 class KM(object):
     def __init__(self, k_max, out_path, internal_metrics, n_init, gap_b, metric_sample=0):
         self.k_max, self.n_init, self.gap_b, self.metric_sample = k_max, n_init, gap_b, metric_sample
@@ -86,50 +149,64 @@ class KM(object):
             rows.append(dict(k=k, train=float(torch.cdist(tr, c).min(1).values.mean()),
                              valid=float(torch.cdist(va, c).min(1).values.mean())))
         df = pd.DataFrame(rows)
-        df.to_csv(osp.join(self.out_path, 'elbow.csv'), index=False)
+        if dist.rank() == 0:
+            df.to_csv(osp.join(self.out_path, 'elbow.csv'), index=False)
         return df
 
     def compute_gap_internal_metric(self, data, k_max=5, n_references=5, version=1):
-        """Gap statistic (p2:353-410): uniform reference sets over the data's bounding range, NumPy global RNG."""
+        """Gap statistic (p2:353-410): uniform reference sets over the data's bounding range, NumPy global RNG.
+
+        Upstream's draw order on the global stream is  draw(ref_1) seeds(fit_1) draw(ref_2) ... seeds(fit on the data)  for K = 2, 3, ...
+        A fit draws all its k-means++ randomness before its first distance (``kmeans.seed_draw_count`` doubles: data-independent), so
+        the stream can be walked without doing any fit: ``_StreamWalker`` does that on a worker thread, handing each fit the stream state
+        its seeding starts from (the fit then draws from a private ``RandomState`` in that state) and each reference fit its uniform
+        draws in a pinned buffer.  The walk therefore runs ahead of the GPU work (0.03 s of host time per 75 k x 256 set), and with
+        one process per GPU every rank walks the SAME stream but fits only the (K, reference set) problems it owns
+        (problem j -> rank j mod world; SURVEY.md 8e: no data-path collective, one all-reduce of the result table at the end)."""
         data = np.asarray(data)
         lo, rng_ = float(data.min()), float(data.max() - data.min())
         logger.info('Data max: {}, min: {}, rng: {}'.format(data.max(), data.min(), rng_))
-        dev = torch.device('cuda')
+        dev = torch.device('cuda', torch.cuda.current_device())
         Xd = torch.as_tensor(data, dtype=torch.float32, device=dev)
         inertia = self.compute_inertia_v1 if version == 1 else self.computer_intertia_v2
-        rows = []
-        bufs = [torch.empty(data.shape, dtype=torch.float64, pin_memory=True).numpy() for _ in range(2)]      # reference draws (double-buffered)
-        for k in range(2, k_max + 1):
-            local = []
-            # Reference sets come from NumPy's global stream in upstream's order: draw(ref_1), seeds(fit_1), draw(ref_2), ...  A fit
-            # draws all its k-means++ randomness before its GPU work starts, so draw(ref_{i+1}) runs on a worker thread during the
-            # GPU work of fit_i / its pair pass (0.15 s of host time per 75 k x 256 set, about a third of the sweep otherwise)
-            pending = None
-            with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
-                for i in range(n_references):
-                    u = pending.result() if pending is not None else global_uniform_into(bufs[i & 1])
-                    pending = None
-                    refd = torch.as_tensor(u).to(dev).mul_(rng_).add_(lo).float()         # scale / shift / f32 cast on the device (f64 math as upstream)
-                    torch.cuda.current_stream().synchronize()                              # the host buffer is refilled two draws later
-                    km = KMeans(n_clusters=k, n_init=self.n_init)
-                    if i + 1 < n_references and km.init == 'k-means++':
-                        def start_next_draw(nxt=bufs[(i + 1) & 1]):
-                            nonlocal pending
-                            pending = pool.submit(global_uniform_into, nxt)
-                        km._after_seeding = start_next_draw
-                    local.append(inertia(km.fit_predict(refd), refd))
-            ref_mean, ref_std = np.mean(np.log(local)), np.std(np.log(local))
-            ref_s = np.sqrt(1 + 1 / n_references) * ref_std
-            assignments = KMeans(n_clusters=k, n_init=self.n_init).fit_predict(Xd)
-            need_minmax = any(isinstance(m, DunnIndex) for m in self.internal_metrics)
+        world, rank = (dist.world_size(), dist.rank()) if dist.is_sharded() else (1, 0)
+        ks = list(range(2, k_max + 1))
+        n_met = len(self.internal_metrics)
+        # per K: [log-inertia of every reference fit | act | validity indices]; a rank fills the entries of its own problems only
+        table = np.zeros((len(ks), n_references + 1 + n_met), np.float64)
+        need_minmax = any(isinstance(m, DunnIndex) for m in self.internal_metrics)
+        walker = _StreamWalker(data.shape, ks, n_references, KMeans(n_init=self.n_init)._resolve_n_init(False), rank, world)
+        for ki, i, buf, state in walker:
+            k = ks[ki]
+            km = KMeans(n_clusters=k, n_init=self.n_init, random_state=_random_state_at(state))
+            if i < n_references:
+                refd = torch.as_tensor(buf).to(dev).mul_(rng_).add_(lo).float()         # scale / shift / f32 cast on the device (f64 math as upstream)
+                torch.cuda.current_stream().synchronize()
+                walker.release(buf)                                                      # the walker refills it for a later set
+                table[ki, i] = np.log(inertia(km.fit_predict(refd), refd))
+                continue
+            assignments = km.fit_predict(Xd)
             stats = cluster_stats.pair_stats(Xd, assignments, need_min=need_minmax, need_max=need_minmax)
-            act = np.log(inertia(assignments, Xd, stats))      # the same pair pass feeds the gap term and every index
-            gap = ref_mean - act
+            table[ki, n_references] = np.log(inertia(assignments, Xd, stats))      # the same pair pass feeds the gap term and every index
             if self.metric_sample and self.metric_sample < len(data):
                 pick = np.random.RandomState(0).choice(len(data), self.metric_sample, replace=False)
                 vals = [m(Xd[torch.as_tensor(pick, device=dev)], assignments[pick]) for m in self.internal_metrics]
             else:
                 vals = [m(Xd, assignments, stats=stats) for m in self.internal_metrics]
+            table[ki, n_references + 1:] = vals
+        walker.join()
+        if world > 1 or dist.is_sharded():
+            t = torch.as_tensor(table, device=dev)
+            dist.all_reduce_sum_(t)                 # disjoint entries, zeros elsewhere: the sum is the assembled table (x + 0.0 is exact)
+            table = t.cpu().numpy()
+        rows = []
+        for ki, k in enumerate(ks):
+            local = table[ki, :n_references]
+            ref_mean, ref_std = np.mean(local), np.std(local)
+            ref_s = np.sqrt(1 + 1 / n_references) * ref_std
+            act = table[ki, n_references]
+            gap = ref_mean - act
+            vals = list(table[ki, n_references + 1:])
             logger.info('k: {}, gap: {:.4f}, ref: {:.4f}, act: {:.4f}, ref_s: {:.4f} '.format(k, gap, ref_mean, act, ref_s)
                         + ' '.join('{}: {:.4f}'.format(n, v) for n, v in zip(self.internal_metrics_names, vals)))
             rows.append([k, gap, ref_mean, act, ref_s] + vals)
@@ -149,7 +226,8 @@ class KM(object):
                 else:
                     df = self.compute_gap_internal_metric(train_data['hidden'], self.k_max, n_references=self.gap_b, version=1)
                     df = df.astype(float)
-                    df.to_csv(csv, index=False)
+                    if dist.rank() == 0:
+                        df.to_csv(csv, index=False)
                     out['gap_sts'] = df
         return out
 
@@ -184,7 +262,10 @@ class Cluster(object):
 
 
 def main(args):
-    return Cluster(args).select_opt_k()
+    dist.init_from_env()            # one process per GPU: the gap statistic's (K, reference set) problems are dealt over the ranks
+    out = Cluster(args).select_opt_k()
+    dist.barrier()
+    return out
 
 
 if __name__ == '__main__':

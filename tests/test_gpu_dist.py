@@ -357,6 +357,51 @@ def test_sharded_kmeans_equals_single_device(tmp_path):
     assert len(np.unique(one['empty'][0])) == 4               # the empty cluster was relocated, as scikit-learn does
 
 
+def _run_gap(rank, world, port, out, rccl=False):
+    sys.path.insert(0, ROOT)
+    _env(rank, world, port, rccl)
+    from deep_interpolation_clustering_amd import dist
+    from deep_interpolation_clustering_amd import p2_clustering_optK as p2
+    from oracle.synth import latent_blobs
+    dist.init_from_env()
+    _join(rccl)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'gap_table_blobs.npz'))
+    X, _ = latent_blobs(int(g['seed']), int(g['N']), int(g['D']), int(g['G']))
+    cols = [str(c) for c in g['columns']]
+    km = p2.KM(int(g['k_max']), os.path.join(out, f'r{rank}'), cols[5:], int(g['n_init']), int(g['gap_b']))
+    np.random.seed(int(g['np_seed']))
+    fits = []
+    fit0 = p2.KMeans.fit
+    p2.KMeans.fit = lambda self, X, *a, **k: (fits.append(self.n_clusters), fit0(self, X, *a, **k))[1]
+    df = km.compute_gap_internal_metric(X, int(g['k_max']), n_references=int(g['gap_b']), version=1).astype(float)
+    torch.save(dict(table=df.to_numpy(), cols=list(df.columns), pos=np.random.random(), fits=fits),
+               os.path.join(out, f'gap_w{world}{"x" if rccl else ""}_r{rank}.pt'))
+    _leave()
+
+
+def test_two_rank_gap_table_equals_reference(tmp_path):
+    """The gap statistic's (K, reference set) problems dealt over two ranks (they shard with no data-path collective):
+    every rank walks upstream's global NumPy stream in full but fits only its own problems; the assembled table on EVERY rank is the
+    one the reference's own KM.compute_gap_internal_metric produced (oracle/make_golden_gap.py) and the stream ends where upstream's does."""
+    port = 29400 + (os.getpid() % 1000)
+    mp.spawn(_run_gap, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_run_gap, args=(1, port + 1, str(tmp_path), True), nprocs=1, join=True)       # and one rank with the table's all-reduce on RCCL
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'gap_table_blobs.npz'))
+    cols = [str(c) for c in g['columns']]
+    n_fits = (int(g['k_max']) - 1) * (int(g['gap_b']) + 1)
+    res = [torch.load(tmp_path / f'gap_w2_r{r}.pt', weights_only=False) for r in range(2)]
+    assert len(res[0]['fits']) + len(res[1]['fits']) == n_fits and abs(len(res[0]['fits']) - len(res[1]['fits'])) <= 1     # the work IS split
+    for r in res:
+        assert r['cols'] == cols
+        assert r['pos'] == float(g['stream_pos']), 'the global stream was consumed differently'
+        for j, c in enumerate(cols):
+            np.testing.assert_allclose(r['table'][:, j], g['table'][:, j], rtol=1e-5, atol=1e-5 if c == 'gap' else 0, err_msg=c)
+    assert np.array_equal(res[0]['table'], res[1]['table'])
+    one = torch.load(tmp_path / 'gap_w1x_r0.pt', weights_only=False)
+    assert len(one['fits']) == n_fits and one['pos'] == float(g['stream_pos'])
+    np.testing.assert_allclose(one['table'], g['table'], rtol=1e-5, atol=1e-5)
+
+
 def test_bench_runs_sharded_on_two_ranks(tmp_path):
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), two ranks sharing the
     test GPU over gloo: it must finish (every rank runs the traced steps rank 0 profiles -- a sharded step is full of collectives)
