@@ -15,7 +15,13 @@
 
 namespace dic {
 
-constexpr int MCP = 256 + 2;         // LDS pitch of a centroid row (floats): == 2 (mod 64) words -> conflict-free b64 reads over 32 rows
+constexpr int MCP = 256 + 4;         // LDS pitch of a centroid row (floats): 65 16-B slots -> the 16 rows of a ds_read_b128 lane group fall on 16 different slots
+constexpr int XCH = 64;              // features per staged X chunk
+constexpr int XP = XCH + 4;          // LDS pitch of a staged X row (floats): 17 16-B slots, the same property
+// Both LDS images keep every aligned group of 8 features in the order [0 1 4 5 | 2 3 6 7]: one 16-B read at 8 m + 4 hh then hands the
+// lower half-wave (hh = 0) features {0 1 4 5} and the upper one {2 3 6 7}, i.e. the MFMA k pairs (0|2) (1|3) (4|6) (5|7) -- the order
+// in which round 2's kernel (8-B reads at 4 m + 2 hh) accumulated, so the scores are bit-identical to it.
+__device__ __forceinline__ int km_perm8(int d4) { return (d4 >> 3) * 8 + ((d4 >> 2) & 1) * 2; }      // position of the LOW pair of the float4 at feature d4; the high pair sits 4 further
 
 typedef float kf32x16 __attribute__((ext_vector_type(16)));
 typedef float kf32x2 __attribute__((ext_vector_type(2)));
@@ -42,6 +48,7 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
     int* cnt = reinterpret_cast<int*>(cnorm + MCOLS);                    // [64] members per centroid column
     int* chg = cnt + MCOLS;                                              // [G] labels changed per restart
     unsigned char* lab8 = reinterpret_cast<unsigned char*>(chg + 4);     // [4 waves][G][32]  (G <= 4: KP >= 8)
+    float* xbuf = reinterpret_cast<float*>(lab8 + 4 * G * 32);           // [4 waves][32 rows][XP]: the wave's X tile, one 64-feature chunk at a time
     static_assert(G <= 4, "chg[] has four slots");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, hh = lane >> 5;
     const int N = a.N, D = a.D, K = a.K;
@@ -57,15 +64,16 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
         const int g = col / KP, k = col - g * KP, run = run0 + g;
         kf32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (run < a.n_runs && k < K && d4 < D) v = *reinterpret_cast<const kf32x4*>(a.centers + ((size_t)run * K + k) * D + d4);
-        float* dst = cent + col * MCP + d4;              // (pitch 258: 8-byte aligned rows)
+        float* dst = cent + col * MCP + km_perm8(d4);
         *reinterpret_cast<kf32x2*>(dst) = kf32x2{v[0], v[1]};
-        *reinterpret_cast<kf32x2*>(dst + 2) = kf32x2{v[2], v[3]};
+        *reinterpret_cast<kf32x2*>(dst + 4) = kf32x2{v[2], v[3]};
     }
     if (tid < MCOLS) cnt[tid] = 0;
     if (tid < G) chg[tid] = 0;
     __syncthreads();
     for (int col = w; col < MCOLS; col += 4) {           // row_norms (_k_means_lloyd.pyx:99), one wave per centroid
-        const kf32x4 c = kf32x4{cent[col * MCP + lane * 4], cent[col * MCP + lane * 4 + 1], cent[col * MCP + lane * 4 + 2], cent[col * MCP + lane * 4 + 3]};
+        const float* cp = cent + col * MCP + km_perm8(4 * lane);     // features 4 lane .. 4 lane + 3, in that order
+        const kf32x4 c = kf32x4{cp[0], cp[1], cp[4], cp[5]};
         const float s = wave_sum(fmaf(c[3], c[3], fmaf(c[2], c[2], fmaf(c[1], c[1], c[0] * c[0]))));
         const int g = col / KP, k = col - g * KP;
         if (lane == 0) cnorm[col] = (k < K) ? s : INFINITY;          // padding columns can never win the argmin
@@ -87,28 +95,66 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
             for (int k = 0; k < 16; ++k) S[mb][nb][k] = 0.f;
 
     const int ntiles = (N + 31) / 32;
+    // staging of X chunks (scores phase): lane -> (16-B piece, row of 4) such that a 16-lane group is 2 rows x 128 B
+    float* xb = xbuf + w * 32 * XP;
+    const int lq = (lane & 7) | (((lane >> 4) & 1) << 3), lrow = ((lane >> 3) & 1) | (((lane >> 5) & 1) << 1);
+    const float* xsrc = a.X + 4 * lq;
+    float* xdst = xb + lrow * XP + km_perm8(4 * lq);
+    kf32x4 v[8];
+    auto load_chunk = [&](int r0_, int c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = kf32x4{0.f, 0.f, 0.f, 0.f};
+            if (XCH * c + 4 * lq < D) v[i] = *reinterpret_cast<const kf32x4*>(xsrc + (size_t)min(r0_ + 4 * i + lrow, N - 1) * D + XCH * c);
+        }
+    };
     for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += a.nblk * 4) {
         const int r0 = tile * 32, row = r0 + j;
         const bool valid = row < N;
-        const float* xr = a.X + (size_t)min(row, N - 1) * D;
-        // ---- scores: D'[centroid][row] = sum_k C[centroid][k] X[row][k]; MFMA 2m + e multiplies k = 4m + 2hh + e
+        // ---- scores: D'[centroid][row] = sum_k C[centroid][k] X[row][k].  The tile's rows come in as whole 128-B lines (a load instruction
+        // = 4 rows x 256 B), go through the wave's own LDS chunk and come back as the B operand (lane = row): round 2's per-lane 8-B loads
+        // straight from the row (32 rows x 16 B per instruction, 64 instructions per tile) kept the texture path busier than the matrix
+        // cores (rocprofv3: SQ_VALU_MFMA_BUSY_CYCLES 35 % of the kernel's time).  The next chunk's loads fly during this chunk's MFMAs.
         kf32x16 dacc[NMB];
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
             for (int k = 0; k < 16; ++k) dacc[mb][k] = 0.f;
-#pragma unroll 8
-        for (int m = 0; m < 64; ++m) {
-            const int kk = 4 * m + 2 * hh;
-            kf32x2 x2 = {0.f, 0.f};
-            if (kk < D) x2 = *reinterpret_cast<const kf32x2*>(xr + kk);
+        {
+            load_chunk(r0, 0);
 #pragma unroll
-            for (int mb = 0; mb < NMB; ++mb) {
-                const kf32x2 c2 = *reinterpret_cast<const kf32x2*>(cent + (32 * mb + j) * MCP + kk);
-                dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[0], x2[0], dacc[mb], 0, 0, 0);
-                dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[1], x2[1], dacc[mb], 0, 0, 0);
+            for (int c = 0; c < 256 / XCH; ++c) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {        // (this wave's previous reads of the chunk were issued before: the LDS queue keeps the order)
+                    *reinterpret_cast<kf32x2*>(xdst + 4 * i * XP) = kf32x2{v[i][0], v[i][1]};
+                    *reinterpret_cast<kf32x2*>(xdst + 4 * i * XP + 4) = kf32x2{v[i][2], v[i][3]};
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (c + 1 < 256 / XCH) load_chunk(r0, c + 1);
+#pragma unroll
+                for (int mm = 0; mm < XCH / 8; ++mm) {
+                    const kf32x4 x4 = *reinterpret_cast<const kf32x4*>(xb + j * XP + 8 * mm + 4 * hh);
+#pragma unroll
+                    for (int mb = 0; mb < NMB; ++mb) {
+                        const kf32x4 c4 = *reinterpret_cast<const kf32x4*>(cent + (32 * mb + j) * MCP + XCH * c + 8 * mm + 4 * hh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dacc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(c4[e], x4[e], dacc[mb], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
+        // the sums phase's B operand (rows 2n + hh as they lie: whole 512-B half rows per half-wave) in a ring of four row pairs that
+        // reuses the staging registers: the first four pairs are requested here, before the argmin, pair n + 4 once pair n is consumed
+        auto load_rows = [&](int n) {
+            const float* xrow = a.X + (size_t)min(r0 + 2 * n + hh, N - 1) * D;
+            v[n & 3] = kf32x4{0.f, 0.f, 0.f, 0.f};
+            v[4 + (n & 3)] = kf32x4{0.f, 0.f, 0.f, 0.f};
+            if (4 * j < D) v[n & 3] = *reinterpret_cast<const kf32x4*>(xrow + 4 * j);
+            if (128 + 4 * j < D) v[4 + (n & 3)] = *reinterpret_cast<const kf32x4*>(xrow + 128 + 4 * j);
+        };
+#pragma unroll
+        for (int n = 0; n < 4; ++n) load_rows(n);
         // ---- argmin per restart: in-lane over this half's centroids (ascending index, strict <: first minimum wins), then across halves
         const float xn = valid && a.xnorm ? a.xnorm[row] : 0.f;
 #pragma unroll
@@ -158,11 +204,7 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
         for (int mb = 0; mb < NMB; ++mb) kc[mb] = (32 * mb + j) % KP;
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
-            const int rr = 2 * n + hh;
-            const float* xrow = a.X + (size_t)min(r0 + rr, N - 1) * D;
-            kf32x4 xlo = {0.f, 0.f, 0.f, 0.f}, xhi = {0.f, 0.f, 0.f, 0.f};
-            if (4 * j < D) xlo = *reinterpret_cast<const kf32x4*>(xrow + 4 * j);
-            if (128 + 4 * j < D) xhi = *reinterpret_cast<const kf32x4*>(xrow + 128 + 4 * j);
+            const kf32x4 xlo = v[n & 3], xhi = v[4 + (n & 3)];
             // byte rr of the packed labels: dword rr >> 2, byte rr & 3 (rr = 2n + hh)
             float onehot[NMB];
 #pragma unroll
@@ -177,6 +219,7 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
                     S[mb][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(onehot[mb], xlo[e], S[mb][e], 0, 0, 0);
                     S[mb][4 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(onehot[mb], xhi[e], S[mb][4 + e], 0, 0, 0);
                 }
+            if (n + 4 < 16) load_rows(n + 4);
         }
     }
     // ---- the 4 waves' sums -> one partial per workgroup (through the centroid area), counts, #changed
@@ -187,13 +230,13 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
 #pragma unroll
             for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 8; ++nb)
+                for (int half = 0; half < 2; ++half)
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
+                    for (int reg = 0; reg < 16; ++reg) {          // d = 128 half + 4 j + (nb & 3): the lane's four d-blocks of a half are one 16-B piece
                         const int col = 32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                        const int d = 128 * (nb >> 2) + 4 * j + (nb & 3);
-                        float* p = red + col * 256 + d;
-                        *p = (ww == 0) ? S[mb][nb][reg] : *p + S[mb][nb][reg];
+                        kf32x4* p = reinterpret_cast<kf32x4*>(red + col * 256 + 128 * half + 4 * j);
+                        const kf32x4 sv = {S[mb][4 * half][reg], S[mb][4 * half + 1][reg], S[mb][4 * half + 2][reg], S[mb][4 * half + 3][reg]};
+                        *p = (ww == 0) ? sv : *p + sv;
                     }
         }
         __syncthreads();
@@ -212,7 +255,7 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
     }
 }
 
-// Row-chunk workgroups per restart group: one workgroup per CU over ALL groups (67 KB of LDS, ~500 registers: one resident workgroup
+// Row-chunk workgroups per restart group: one workgroup per CU over ALL groups (69 KB of LDS, ~500 registers: one resident workgroup
 // per CU), so that each pays its centroid staging and its cross-wave reduction once and walks several tiles per wave
 // (0.34 -> 0.2 ms per iteration of 10 restarts at K = 16 against three rounds of 256 workgroups).
 // One MFMA row block (32 centroid columns) per workgroup: 32 / KP restarts share its X tiles.  (Two row blocks = 64 columns per
@@ -237,7 +280,7 @@ int kmeans_mfma_blocks(int N, int K, int n_runs) {
 template <int KP, int NMB>
 static int kmeans_assign_mfma_launch_t(const KmMfmaArgs& a, int groups, hipStream_t st) {
     constexpr int MCOLS = 32 * NMB, G = MCOLS / KP;
-    const size_t lds = (size_t)MCOLS * MCP * 4 + MCOLS * 4 + MCOLS * 4 + 16 + 4 * G * 32;
+    const size_t lds = (size_t)MCOLS * MCP * 4 + MCOLS * 4 + MCOLS * 4 + 16 + 4 * G * 32 + 4 * 32 * XP * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kmeans_assign_mfma_kernel<KP, NMB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
