@@ -368,6 +368,21 @@ __global__ __launch_bounds__(256) void kmeans_reduce_kernel(const float* psum_al
     if (threadIdx.x < 32 && i < n) sums_all[(size_t)run * n + i] = s;
 }
 
+// K sums over the block's 256 threads (terms[k * 256 + tid] in LDS) -> out[k], bit for bit what the fold-down tree
+// `for (st = 128; st; st >>= 1) v[tid] += v[tid + st]` gives (the first two levels by hand, the other six ARE the xor butterfly of
+// wave_sum: the same pairs are added at every level) -- but with two barriers in all instead of nine per centre (K = 20: 21 -> 8 us
+// per Lloyd iteration of the update kernel, 1.2 s of the p2 sweep).
+__device__ __forceinline__ void block_sums_256(int K, const float* terms, float* out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    for (int k = w; k < K; k += 4) {
+        const float* t = terms + k * 256 + lane;
+        const float v = wave_sum((t[0] + t[128]) + (t[64] + t[192]));
+        if (lane == 0) out[k] = v;
+    }
+    __syncthreads();
+}
+
 // stage B: counts, empty-cluster relocation, averaging, centre shift, convergence; one block per run
 __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* X, int N, int D, int K, int nblk,
                                                            const int* pcnt_all, const int* pchg_all, double* sums_all,
@@ -379,6 +394,7 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* X, int 
     __shared__ float redv[256];
     __shared__ int redi[256];
     __shared__ float shift2[DIC_MAX_CLUSTERS];
+    __shared__ float shk[DIC_MAX_CLUSTERS * 256];
     const int run = blockIdx.x, tid = threadIdx.x;
     float* status = status_all + run * DIC_KM_STATUS_WORDS;
     if (status[0] != 0.f) return;
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* X, int 
     // _average_centers (:274-295) incl. its in-place quirk for a still-empty cluster, then _center_shift
     int amax = 0;
     for (int k = 1; k < K; ++k) if (cntf[k] > cntf[amax]) amax = k;
-    float ss_local[DIC_MAX_CLUSTERS];
+    float* ss_local = shk + tid;                  // [k][256]: this thread's term of centre k's squared shift
     if (tid < D) {
         float newc[DIC_MAX_CLUSTERS];
         for (int k = 0; k < K; ++k) newc[k] = (float)sums[(size_t)k * D + tid];
@@ -448,22 +464,13 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* X, int 
         }
         for (int k = 0; k < K; ++k) {
             const float dlt = newc[k] - centers[(size_t)k * D + tid];
-            ss_local[k] = dlt * dlt;
+            ss_local[k * 256] = dlt * dlt;
             centers[(size_t)k * D + tid] = newc[k];
         }
     } else {
-        for (int k = 0; k < K; ++k) ss_local[k] = 0.f;
+        for (int k = 0; k < K; ++k) ss_local[k * 256] = 0.f;
     }
-    for (int k = 0; k < K; ++k) {
-        redv[tid] = ss_local[k];
-        __syncthreads();
-        for (int st = 128; st >= 1; st >>= 1) {
-            if (tid < st) redv[tid] += redv[tid + st];
-            __syncthreads();
-        }
-        if (tid == 0) shift2[k] = redv[0];
-        __syncthreads();
-    }
+    block_sums_256(K, shk, shift2);
     if (tid == 0) {
         float tot = 0.f;
         for (int k = 0; k < K; ++k) { const float sh = sqrtf(shift2[k]); tot += sh * sh; }   // (center_shift**2).sum()
@@ -497,8 +504,8 @@ __global__ __launch_bounds__(256) void kmeans_pack_counts_kernel(const int* pcnt
 // may live on another rank): the run is halted with status[0] = 2 and the caller re-runs it unsharded.
 __global__ __launch_bounds__(256) void kmeans_finish_kernel(int D, int K, const double* stats_all, float* centers_all, float* status_all) {
     __shared__ float cntf[DIC_MAX_CLUSTERS];
-    __shared__ float redv[256];
     __shared__ float shift2[DIC_MAX_CLUSTERS];
+    __shared__ float shk[DIC_MAX_CLUSTERS * 256];
     __shared__ int s_empty;
     const int run = blockIdx.x, tid = threadIdx.x;
     float* status = status_all + run * DIC_KM_STATUS_WORDS;
@@ -518,27 +525,18 @@ __global__ __launch_bounds__(256) void kmeans_finish_kernel(int D, int K, const 
         return;
     }
     const int changed = (int)stats[(size_t)K * D + K];
-    float ss_local[DIC_MAX_CLUSTERS];
+    float* ss_local = shk + tid;                  // [k][256]: this thread's term of centre k's squared shift
     if (tid < D) {
         for (int k = 0; k < K; ++k) {
             const float nc = (float)sums[(size_t)k * D + tid] * (1.0f / cntf[k]);
             const float dlt = nc - centers[(size_t)k * D + tid];
-            ss_local[k] = dlt * dlt;
+            ss_local[k * 256] = dlt * dlt;
             centers[(size_t)k * D + tid] = nc;
         }
     } else {
-        for (int k = 0; k < K; ++k) ss_local[k] = 0.f;
+        for (int k = 0; k < K; ++k) ss_local[k * 256] = 0.f;
     }
-    for (int k = 0; k < K; ++k) {
-        redv[tid] = ss_local[k];
-        __syncthreads();
-        for (int st = 128; st >= 1; st >>= 1) {
-            if (tid < st) redv[tid] += redv[tid + st];
-            __syncthreads();
-        }
-        if (tid == 0) shift2[k] = redv[0];
-        __syncthreads();
-    }
+    block_sums_256(K, shk, shift2);
     if (tid == 0) {
         float tot = 0.f;
         for (int k = 0; k < K; ++k) { const float sh = sqrtf(shift2[k]); tot += sh * sh; }
