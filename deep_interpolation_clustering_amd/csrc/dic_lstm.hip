@@ -764,7 +764,7 @@ struct LstmBwdArgs {
 
 __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwdArgs a) {
     extern __shared__ __align__(16) __bf16 dgt[];      // [LBM][GSTR]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
     const int nbt = gridDim.x * LNB;
 
@@ -822,16 +822,20 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         {
             const int u = 32 * w + 8 * q + 4 * hh;
             StepIn& d = in[nb][q];
-            d.ib = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, hh, r));
+            // (uniform base + this lane's 8 bytes: the base is scalar arithmetic, the loads take it as an SGPR pair)
+            const unsigned lane_b = (unsigned)lane * 8u;                       // bytes
+            const char* gbase = reinterpret_cast<const char*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, 0, 0));
+            constexpr unsigned GATE_STRIDE = 4 * 2 * 32 * 4 * 2;               // bytes between the planes of two gates
+            d.ib = *reinterpret_cast<const bf16x4*>(gbase + lane_b);
 #ifdef DIC_LSTM_EXP_RECOMPUTE    // experiment (timing only, wrong results): ONE 2-B-per-unit plane stands in for the h_prev row a recomputing backward reads
             d.fb = d.ib; d.gb = d.ib; d.ob = d.ib;
 #else
-            d.fb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 1, q, hh, r));
-            d.gb = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 2, q, hh, r));
-            d.ob = *reinterpret_cast<const bf16x4*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 3, q, hh, r));
+            d.fb = *reinterpret_cast<const bf16x4*>(gbase + (GATE_STRIDE + lane_b));
+            d.gb = *reinterpret_cast<const bf16x4*>(gbase + (2 * GATE_STRIDE + lane_b));
+            d.ob = *reinterpret_cast<const bf16x4*>(gbase + (3 * GATE_STRIDE + lane_b));
 #endif
             bf16x4 cp = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-            if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, hh, r));
+            if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const char*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, 0, 0)) + lane_b);
             else if (a.c0) {
                 const f32x4 c0v = *reinterpret_cast<const f32x4*>(a.c0 + state_off(a.bm, dir, b, B) + u);
 #pragma unroll
@@ -896,26 +900,50 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 #endif
     };
     // one of this wave's 8 rows of half nb: dG row LDS -> global (whole 1-KiB row per wave instruction, row-major for the
-    // weight-gradient GEMMs) + bias column sums, then four k-steps of dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n]
+    // weight-gradient GEMMs) + bias column sums, and four k-steps of dh_{t-1}[u][b] = sum_n W_hh[n][u] dG_t[b][n].
+    // The B fragments of a group of four k-steps are requested ONE GROUP AHEAD into a two-slot ring (`fetch_b`), so that the MFMAs never
+    // wait on an LDS read issued right in front of them (round 2's form read each fragment immediately before its MFMA: hipcc put an
+    // `s_waitcnt lgkmcnt(0)` in front of all 64 MFMAs of a step, an exposed LDS round trip each -- the wave is alone on its SIMD).
+    bf16x8 gring[2][4];
+    auto fetch_b = [&](int nb, int k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            gring[k & 1][i] = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + r) * GSTR + (4 * k + i) * 16 + 8 * hh);
+    };
     auto row_and_mfma = [&](int nb, int k, int t) {
         const int rowl = nb * 32 + k * 4 + w;
         const int b = b0 + rowl;
-        if (b < B) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(dgt + rowl * GSTR + lane * 8);
-            *reinterpret_cast<bf16x8*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8) = v;
+        bf16x8 v;
+        if (b < B) v = *reinterpret_cast<const bf16x8*>(dgt + rowl * GSTR + lane * 8);
+        if (k + 1 < 8) fetch_b(nb, k + 1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
-        }
-#pragma unroll
-        for (int ks = 4 * k; ks < 4 * k + 4; ++ks) {
-            const bf16x8 gbv = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + r) * GSTR + ks * 16 + 8 * hh);
+        for (int i = 0; i < 4; ++i) {
+            const int ks = 4 * k + i;
+            const bf16x8 gbv = gring[k & 1][i];
+#ifndef DIC_LSTM_BWD_ASM_MFMA
             dh[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, dh[nb], 0, 0, 0);
+#else
+            // (experiment, bit-identical, no gain: 0.827 -> 0.831 ms)  The MFMA as asm with its A operand constrained to the accumulation
+            // registers: W_hh^T (128 registers) then LIVES there and is read in place -- through the builtin hipcc parks the weights in
+            // AGPRs as spill space and copies four of them back with v_accvgpr_read in front of every MFMA (256 copies per step).  Wait
+            // states by hand (cdna_hip_programming.md 5.7 item 2): `s_nop 1` covers a v_accvgpr_write of the zeroed accumulator just
+            // before; the accumulate chain itself needs none; the readers of D are held off by the `s_nop 11` after the phase's last MFMA.
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dh[nb]) : "a"(wt[ks]), "v"(gbv));
+#endif
 #ifdef DIC_LSTM_EXP_RECOMPUTE    // ... and the 80 MFMAs per wave and step of W_hh.h_prev + W_ih.x (5 per 4 of the backward's own; OPTIMISTIC: they reuse the
             // resident W_hh^T fragments and the dG tile as operands, so the 128 extra weight registers and the h / x tiles in LDS cost nothing here)
             exp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks], gbv, exp_acc, 0, 0, 0);
             if ((ks & 3) == 3) exp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[ks ^ 1], gbv, exp_acc, 0, 0, 0);
 #endif
         }
+        if (b < B) {
+            *reinterpret_cast<bf16x8*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
+        }
+#ifdef DIC_LSTM_BWD_ASM_MFMA
+        if (k == 7) asm volatile("s_nop 11" : "+a"(dh[nb]));      // D of the phase's last MFMA -> its first reader: 12 wait states (8-pass XDL)
+#endif
     };
     {   // prologue: c of the first visited step, the inputs of both halves, and half 0's first gate gradients
         const int t0 = dir ? 0 : R - 1;
@@ -944,6 +972,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         for (int k = 0; k < 16; ++k) dh[0][k] = 0.f;
         // (each unit group's registers are refilled as soon as its math has consumed them: a full step of lead time, and the
         // requests spread over the step instead of one burst per phase)
+        fetch_b(0, 0);
 #define DIC_BWD_X(Q)                                                   \
         math_q(1, Q);                                                  \
         if (step + 1 < R) load_q(IC<1>{}, IC<Q>{}, step + 1);          \
@@ -957,6 +986,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         // ---- phase Y: MFMA + stores of half 1  ||  math of half 0 for the next step
 #pragma unroll
         for (int k = 0; k < 16; ++k) dh[1][k] = 0.f;
+        fetch_b(1, 0);
         if (step + 1 < R) {
 #define DIC_BWD_Y(Q)                                                   \
             math_q(0, Q);                                              \
