@@ -763,9 +763,10 @@ struct LstmBwdArgs {
 };
 
 __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwdArgs a) {
-    extern __shared__ __align__(16) __bf16 dgt[];      // [LBM][GSTR]
+    extern __shared__ __align__(16) __bf16 dgt[];      // [LBM][GSTR], then the staged rows of dL/dout: [LNB][32][LH]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
+    __bf16* dob = dgt + LBM * GSTR;
     const int nbt = gridDim.x * LNB;
 
     // A operand: W_hh^T rows for this wave's 32 hidden units, all 32 k-steps over the 4H gate columns
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
     // 96 VGPRs the one-deep pipeline used.  One barrier per phase: it publishes the half just written to LDS and retires the
     // reads of the half about to be overwritten.
     static_assert(LNB == 2, "the half-step software pipeline is written for two 32-row halves");
-    struct StepIn { bf16x4 ib, fb, gb, ob, go, cp; };
+    struct StepIn { bf16x4 ib, fb, gb, ob, cp; };
     StepIn in[LNB][4];
     // (half and unit group are compile-time constants: a run-time index into the register arrays sends them to scratch memory)
     auto load_q = [&](auto nbc, auto qc, int step) {
@@ -842,9 +843,33 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
                 for (int j = 0; j < 4; ++j) cp[j] = (__bf16)c0v[j];
             }
             d.cp = cp;
-            bf16x4 go = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-            if (a.dout) go = *reinterpret_cast<const bf16x4*>(a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + u);
-            d.go = go;
+        }
+    };
+    // dL/dout of a 32-row half and step: WHOLE 256-B row pieces (16 lanes x 16 B; a load instruction = 4 rows) one step ahead into
+    // registers, then into LDS with the 16-B pieces of row r rotated by r, where the gate math picks up its 8 bytes (2-way conflict at
+    // worst).  Round 2 let every lane fetch its own 8 bytes straight from its row: 32 rows x 16 B per instruction, eight instructions per
+    // wave and step -- 1 024 cache-line requests per workgroup and step for 16 KB, more than all its other loads together (640).
+    bf16x8 dstage[LNB][2];
+    auto dout_load = [&](auto nbc, int step) {
+        constexpr int nb = decltype(nbc)::value;
+        const int t = dir ? step : R - 1 - step;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * w + 4 * i + (lane >> 4);
+            const int b = min(b0 + nb * 32 + row, B - 1);
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+            if (a.dout) v = *reinterpret_cast<const bf16x8*>(a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + 8 * (lane & 15));
+            dstage[nb][i] = v;
+        }
+    };
+    auto dout_store = [&](auto nbc) {
+        constexpr int nb = decltype(nbc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * w + 4 * i + (lane >> 4);
+            *reinterpret_cast<bf16x8*>(dob + (nb * 32 + row) * LH + (((lane & 15) + row) & 15) * 8) = dstage[nb][i];
         }
     };
     auto load_half = [&](auto nbc, int step) {
@@ -854,6 +879,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
     auto math_q = [&](int nb, int q) {
         [[maybe_unused]] const int u = 32 * w + 8 * q + 4 * hh;
         const StepIn& x = in[nb][q];
+        const bf16x4 go = *reinterpret_cast<const bf16x4*>(dob + (nb * 32 + r) * LH + (((4 * w + q) + r) & 15) * 8 + 4 * hh);
         bf16x4 di, df, dg, dO;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -864,7 +890,7 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
             const float ig = (float)x.ib[j], fg = (float)x.fb[j], gg = (float)x.gb[j], og = (float)x.ob[j];
 #endif
             const float tc = tanh_fast(ccar[nb][k]);
-            const float dht = dh[nb][k] + ((a.relu && !(tc > 0.f)) ? 0.f : (float)x.go[j]);
+            const float dht = dh[nb][k] + ((a.relu && !(tc > 0.f)) ? 0.f : (float)go[j]);
             const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
             const float vi = dct * gg * ig * (1.0f - ig), vf = dct * (float)x.cp[j] * fg * (1.0f - fg);
             const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
@@ -955,8 +981,14 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ccar[nb][4 * q + j] = (float)ct[j];
             }
+        dout_load(IC<0>{}, 0);
+        dout_load(IC<1>{}, 0);
         load_half(IC<0>{}, 0);
         load_half(IC<1>{}, 0);
+        dout_store(IC<0>{});
+        dout_store(IC<1>{});
+        if (R > 1) { dout_load(IC<0>{}, 1); dout_load(IC<1>{}, 1); }
+        lds_barrier();                                     // both halves' first rows of dL/dout are in LDS
 #pragma unroll
         for (int q = 0; q < 4; ++q) math_q(0, q);
         if (R > 1) load_half(IC<0>{}, 1);
@@ -980,6 +1012,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
         row_and_mfma(0, 2 * Q + 1, t);
         DIC_BWD_X(0) DIC_BWD_X(1) DIC_BWD_X(2) DIC_BWD_X(3)
 #undef DIC_BWD_X
+        if (step + 1 < R) dout_store(IC<0>{});            // half 0's dL/dout of step + 1: read by phase Y's math (its last readers left before this phase's barrier)
+        if (step + 2 < R) dout_load(IC<0>{}, step + 2);
         DIC_STAMP(1, step, 2);
         lds_barrier();                                     // half 1 of dG_t is complete; the reads of half 0 have retired
         DIC_STAMP(1, step, 3);
@@ -999,6 +1033,8 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
 #pragma unroll
             for (int k = 0; k < 8; ++k) row_and_mfma(1, k, t);
         }
+        if (step + 1 < R) dout_store(IC<1>{});            // half 1's dL/dout of step + 1: read by the next phase X
+        if (step + 2 < R) dout_load(IC<1>{}, step + 2);
         DIC_STAMP(1, step, 4);
         DIC_STAMP(1, step, 5);
     }
@@ -1120,7 +1156,7 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_bwd: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_bwd: hidden size %d (compiled for %d)", H, LH);
     DIC_REQUIRE(whh_t && gates && cs && dgx && dh0 && dc0, DIC_ERR_INVALID_ARG, "lstm_bwd: NULL pointer");
-    static const size_t lds = (size_t)LBM * GSTR * sizeof(__bf16);
+    static const size_t lds = (size_t)(LBM * GSTR + LBM * LH) * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
