@@ -695,7 +695,8 @@ def splitk_tn(a, b, chunks=(8192, 4096, 2048)):
 
 
 FC_BWD_SHAPE = (128, 256)      # dic_fc_bwd's compiled Linear(256, 128)
-FC_BWD_MIN_ROWS = int(os.environ.get('DIC_FC_BWD_MIN_ROWS', 8192))          # below this the two library GEMMs are launch-bound anyway
+FC_BWD_MIN_ROWS = int(os.environ.get('DIC_FC_BWD_MIN_ROWS', 1024))          # (8192 until round 3: the one-node path also wins where the step is launch-bound --
+                                                                            # B = 256, 6144 rows: 73 -> 63 launches, 0.708 -> 0.677 ms from the hipGraph; 0.66 -> 0.63 at B = 64)
 
 
 class _RowsLinear(torch.autograd.Function):
