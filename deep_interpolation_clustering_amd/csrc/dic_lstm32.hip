@@ -99,10 +99,18 @@ template <> struct Rec<__bf16> {
             }
         }
     }
+    // B fragments are requested DEPTH k-steps ahead into a register ring: read right in front of its MFMA, each fragment cost the wave
+    // -- alone on its SIMD -- an exposed LDS round trip (hipcc put `s_waitcnt lgkmcnt(0)` before 31 of the backward's 32 MFMAs per step)
     template <int K> __device__ static sf32x16 mma(const Frag<K>& a, const __bf16* brow, int hh, sf32x16 acc) {
+        constexpr int NK = K / 16, DEPTH = NK < 8 ? NK : 8;
+        sbf16x8 ring[DEPTH];
 #pragma unroll
-        for (int ks = 0; ks < K / 16; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[ks], *reinterpret_cast<const sbf16x8*>(brow + ks * 16 + 8 * hh), acc, 0, 0, 0);
+        for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(brow + i * 16 + 8 * hh);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[ks], ring[ks % DEPTH], acc, 0, 0, 0);
+            if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(brow + (ks + DEPTH) * 16 + 8 * hh);
+        }
         return acc;
     }
 };
@@ -403,12 +411,310 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Eight waves per 32-row tile (bf16; round 3).  At the reference's own batch size (256: p1_pretrain_main.py:43) a recurrence launch is
+// 16 workgroups x 24 dependent steps, and a step of the four-wave kernels above is a chain of phases that each keep one unit busy: 16
+// elements of gate math per lane (~1 us of transcendentals alone in the forward), 32 MFMAs, 8 row copies.  Here a wave owns 16 hidden
+// units instead of 32: half the math, half the MFMA time and half the copies per wave and step, two waves per SIMD to fill each other's
+// stalls.  Same arithmetic per element, same saved-state layout (unit 16 w8 + 8 qq + 4 hh + j = group q = 2 (w8 & 1) + qq of wave
+// w8 >> 1 in `snative_off`), so either forward pairs with either backward.
+//   forward : the wave's 64 gate rows are two 32-row MFMA blocks with the gates stacked in pairs -- block 0 = [i | f], block 1 = [g | o],
+//             16 units each -- so that accumulator registers k and 8 + k of a lane are two gates of the same unit (register-local math).
+//   backward: dh[unit][batch] on v_mfma_f32_16x16x32_bf16 (16 units x 16 batch rows per MFMA, two batch blocks).  The A rows are
+//             ordered so that lane (n, g) -- batch n or 16 + n, units 4 g .. 4 g + 3 of the permuted order -- holds what math lane
+//             n + 16 g needs, up to one v_permlane16_swap per register between the two batch blocks.
+typedef float sf32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 1) void lstm_rec_fwd8_kernel(RecFwdArgs<__bf16> a) {
+    typedef __bf16 T;
+    typedef sbf16x4 V4;
+    constexpr int HP = Rec<T>::PITCH(SH);
+    constexpr int GXP = S4 + 16 / sizeof(T);
+    extern __shared__ __align__(16) unsigned char fsm32[];
+    T* hbuf0 = reinterpret_cast<T*>(fsm32);               // [2][SROWS*HP]
+    T* gst = hbuf0 + 2 * SROWS * HP;                       // [SROWS][GXP]
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = w8 >> 1, qh = w8 & 1;
+    const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
+    const int nbt = gridDim.x, bt = blockIdx.x;
+    const int b = b0 + r;
+    const bool ok = b < B;
+    const int bc = min(b, B - 1);
+
+    sbf16x8 wf[2][SH / 16];          // A rows of block blk: m = lane & 31 -> gate 2 blk + (m >> 4), unit 16 w8 + (m & 15)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < SH / 16; ++ks)
+            wf[blk][ks] = *reinterpret_cast<const sbf16x8*>(a.whh + ((size_t)(dir * 4 + 2 * blk + (r >> 4)) * SH + 16 * w8 + (r & 15)) * SH + ks * 16 + 8 * hh);
+
+    float c[8];                      // element e = 4 qq + j: unit 16 w8 + 8 qq + 4 hh + j
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
+        sf32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            if (a.h0) hv = *reinterpret_cast<const sf32x4*>(a.h0 + sstate_off(a.bm, dir, b, B) + u);
+            if (a.c0) cv = *reinterpret_cast<const sf32x4*>(a.c0 + sstate_off(a.bm, dir, b, B) + u);
+        }
+        V4 hb, cb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; cb[j] = (T)cv[j]; c[4 * qq + j] = cv[j]; }
+        *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
+        if (a.cs) *reinterpret_cast<V4*>(a.cs + snative_off(R, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cb;
+    }
+    auto request_gx = [&](int step) {                      // 32 whole 1-KiB rows by LDS-DMA, four per wave
+        const int t = dir ? R - 1 - step : step;
+#pragma unroll
+        for (int k = 0; k < SROWS / 8; ++k) {
+            const int rowl = k * 8 + w8;
+            const int bb = min(b0 + rowl, B - 1);
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(a.gx + (((size_t)t * B + bb) * 2 + dir) * S4) + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(gst + rowl * GXP)), 16, 0, 0);
+        }
+    };
+    request_gx(0);
+    __syncthreads();
+
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? R - 1 - step : step;
+        const int cur = step & 1;
+        const T* hcur = hbuf0 + cur * SROWS * HP;
+        T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
+        sf32x16 acc[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const V4 gv = *reinterpret_cast<const V4*>(gst + r * GXP + g * SH + 16 * w8 + 8 * qq + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g >> 1][8 * (g & 1) + 4 * qq + j] = (float)gv[j];
+            }
+        sbf16x8 hf[SH / 16];                              // the step's B fragments, all requested before the first MFMA
+#pragma unroll
+        for (int ks = 0; ks < SH / 16; ++ks) hf[ks] = *reinterpret_cast<const sbf16x8*>(hcur + r * HP + ks * 16 + 8 * hh);
+        lds_barrier();                                     // every wave has read its part of the staged tile
+        if (step + 1 < R) request_gx(step + 1);
+#pragma unroll
+        for (int ks = 0; ks < SH / 16; ++ks) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], hf[ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], hf[ks], acc[1], 0, 0, 0);
+        }
+        const bool last = step == R - 1;
+        const size_t row = (size_t)t * B + bc;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
+            V4 hb, ib, fb, gb, ob, cb;
+            sf32x4 cv, hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * qq + j;
+                const float ig = sigmoid_acc<T>(acc[0][k]), fg = sigmoid_acc<T>(acc[0][8 + k]), gg = tanh_acc<T>(acc[1][k]), og = sigmoid_acc<T>(acc[1][8 + k]);
+                const float cn = fmaf(fg, c[k], ig * gg);
+                const float hn = og * tanh_acc<T>(cn);
+                c[k] = cn;
+                cv[j] = cn; hv[j] = hn;
+                hb[j] = (T)hn; ib[j] = (T)ig; fb[j] = (T)fg; gb[j] = (T)gg; ob[j] = (T)og; cb[j] = (T)cn;
+            }
+            *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
+            if (a.gates) {
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 0, q, hh, r)) = ib;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 1, q, hh, r)) = fb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 2, q, hh, r)) = gb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 3, q, hh, r)) = ob;
+                *reinterpret_cast<V4*>(a.cs + snative_off(t, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cb;
+            }
+            if (ok) {
+                *reinterpret_cast<V4*>(a.out + row * 2 * SH + dir * SH + u) = hb;
+                if (last) {
+                    *reinterpret_cast<sf32x4*>(a.hn + sstate_off(a.bm, dir, b, B) + u) = hv;
+                    *reinterpret_cast<sf32x4*>(a.cn + sstate_off(a.bm, dir, b, B) + u) = cv;
+                }
+            }
+        }
+        // (as in the four-wave kernel: the DMA of the next tile has landed once only the stores issued after it are in flight --
+        // 10 saved-state stores per wave; the 2 `out` stores may have been branched over)
+        if (a.gates) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void lstm_rec_bwd8_kernel(RecBwdArgs<__bf16> a) {
+    typedef __bf16 T;
+    typedef sbf16x4 V4;
+    constexpr int GP = Rec<T>::PITCH(S4);
+    extern __shared__ __align__(16) unsigned char rsm[];
+    T* dgt = reinterpret_cast<T*>(rsm);                 // [32][GP] gate gradients of the current step
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5, n16 = lane & 15, g4 = lane >> 4;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = w8 >> 1, qh = w8 & 1;
+    const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
+    const int b = b0 + r;
+    const bool ok = b < B;
+    const int bc = min(b, B - 1);
+
+    // A operand of the 16x16x32 MFMA: lane (m = lane & 15, kg = lane >> 4) holds W_hh^T[unit s(m)][32 ks + 8 kg .. + 7], s(m) = 8 ((m >> 2) & 1) +
+    // 4 (m >> 3) + (m & 3): D row 4 g + e of lane (n, g) is then unit 8 (g & 1) + 4 (g >> 1) + e -- the units math lane n + 16 g owns (its hh = g >> 1),
+    // group qq = g & 1
+    sbf16x8 wt[S4 / 32];
+    {
+        const int m = n16, unit = 16 * w8 + 8 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+#pragma unroll
+        for (int ks = 0; ks < S4 / 32; ++ks) {
+            if (a.transposed) {
+                wt[ks] = *reinterpret_cast<const sbf16x8*>(a.whh + ((size_t)dir * SH + unit) * S4 + ks * 32 + 8 * g4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wt[ks][j] = a.whh[((size_t)dir * S4 + ks * 32 + 8 * g4 + j) * SH + unit];
+            }
+        }
+    }
+    float dh[8], dc[8], ccar[8];     // element e = 4 qq + j: unit 16 w8 + 8 qq + 4 hh + j of batch row r
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    {
+        const int t0 = dir ? 0 : R - 1;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
+            sf32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                if (a.dhn) hv = *reinterpret_cast<const sf32x4*>(a.dhn + sstate_off(a.bm, dir, b, B) + u);
+                if (a.dcn) cv = *reinterpret_cast<const sf32x4*>(a.dcn + sstate_off(a.bm, dir, b, B) + u);
+            }
+            const V4 ct = *reinterpret_cast<const V4*>(a.cs + snative_off(t0, gridDim.x, blockIdx.x, dir, w4, 1, 0, q, hh, r));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dh[4 * qq + j] = hv[j]; dc[4 * qq + j] = cv[j]; ccar[4 * qq + j] = (float)ct[j]; }
+        }
+    }
+    struct StepQ { V4 ib, fb, gb, ob, cp, go; };
+    auto load_q = [&](int step, int qq, StepQ& d) {
+        const int t = dir ? step : R - 1 - step;
+        const int tp = step == R - 1 ? R : (dir ? t + 1 : t - 1);
+        const size_t row = (size_t)t * B + bc;
+        const int nbt = gridDim.x, bt = blockIdx.x, q = 2 * qh + qq;
+        const int u = 16 * w8 + 8 * qq + 4 * hh;
+        d.ib = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 0, q, hh, r));
+        d.fb = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 1, q, hh, r));
+        d.gb = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 2, q, hh, r));
+        d.ob = *reinterpret_cast<const V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 3, q, hh, r));
+        d.cp = *reinterpret_cast<const V4*>(a.cs + snative_off(tp, nbt, bt, dir, w4, 1, 0, q, hh, r));
+        if (a.dout) d.go = *reinterpret_cast<const V4*>(a.dout + row * 2 * SH + dir * SH + u);
+    };
+    StepQ in0, in1, nx0, nx1;
+    load_q(0, 0, in0); load_q(0, 1, in1);
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? step : R - 1 - step;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh;
+            const StepQ cur = qq == 0 ? in0 : in1;
+            V4 di, df, dg, dO;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * qq + j;
+                const float ig = (float)cur.ib[j], fg = (float)cur.fb[j], gg = (float)cur.gb[j], og = (float)cur.ob[j], cp = (float)cur.cp[j];
+                const float go = a.dout ? (float)cur.go[j] : 0.f;
+                const float tc = tanh_acc<T>(ccar[k]);
+                const float dht = dh[k] + ((a.relu && !(tc > 0.f)) ? 0.f : go);
+                const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[k]);
+                const float vi = dct * gg * ig * (1.0f - ig), vf = dct * cp * fg * (1.0f - fg);
+                const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
+                di[j] = (T)(ok ? vi : 0.f); df[j] = (T)(ok ? vf : 0.f); dg[j] = (T)(ok ? vg : 0.f); dO[j] = (T)(ok ? vo : 0.f);
+                dc[k] = dct * fg;
+                ccar[k] = cp;
+            }
+            T* lp = dgt + r * GP + u;
+            *reinterpret_cast<V4*>(lp) = di;
+            *reinterpret_cast<V4*>(lp + SH) = df;
+            *reinterpret_cast<V4*>(lp + 2 * SH) = dg;
+            *reinterpret_cast<V4*>(lp + 3 * SH) = dO;
+        }
+        if (step + 1 < R) { load_q(step + 1, 0, nx0); load_q(step + 1, 1, nx1); }
+        lds_barrier();                                     // the dG tile of this step is complete
+        // dh_prev[unit][batch] = sum_n W_hh[n][unit] dG[batch][n]: two batch blocks (rows n16, 16 + n16) x 16 k-steps of 32 gate columns;
+        // the B fragments of four k-steps are requested ahead (ring), the four row copies of this wave ride between the MFMA groups
+        sf32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        constexpr int NKS = S4 / 32, DEPTH = 4;
+        sbf16x8 ring0[DEPTH], ring1[DEPTH];
+        const T* brow0 = dgt + n16 * GP + 8 * g4;
+        const T* brow1 = dgt + (16 + n16) * GP + 8 * g4;
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            ring0[i] = *reinterpret_cast<const sbf16x8*>(brow0 + i * 32);
+            ring1[i] = *reinterpret_cast<const sbf16x8*>(brow1 + i * 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks], ring0[ks % DEPTH], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks], ring1[ks % DEPTH], acc1, 0, 0, 0);
+            if (ks + DEPTH < NKS) {
+                ring0[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(brow0 + (ks + DEPTH) * 32);
+                ring1[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(brow1 + (ks + DEPTH) * 32);
+            }
+            if ((ks & 3) == 3) {                           // one of this wave's four dG rows: LDS -> global (a whole 1-KiB row) + bias column sums
+                const int rowl = (ks >> 2) * 8 + w8;
+                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(dgt + rowl * GP) + lane * 16);
+                if (b0 + rowl < B)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.dgx + (((size_t)t * B + b0 + rowl) * 2 + dir) * S4) + lane * 16) = v;
+                const sbf16x8 x = __builtin_bit_cast(sbf16x8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[e] += (float)x[e];
+            }
+        }
+        // lane (n, g) holds units 4 (g >> 1) + 8 (g & 1) + e of batch n (acc0) and 16 + n (acc1); math lane n + 16 g wants batch n + 16 (g & 1),
+        // units 8 qq + 4 (g >> 1) + e for qq = 0, 1: the even 16-lane rows keep acc0 and take the odd partner's acc0, the odd rows keep acc1 and
+        // take the even partner's acc1 -- v_permlane16_swap(acc0, acc1) trades exactly those (odd rows of the first <-> even rows of the second)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, (float)acc0[e]), __builtin_bit_cast(unsigned, (float)acc1[e]), false, false);
+            dh[e] = __builtin_bit_cast(float, (unsigned)s[0]);
+            dh[4 + e] = __builtin_bit_cast(float, (unsigned)s[1]);
+        }
+        lds_barrier();                                     // every wave is done reading the tile
+        in0 = nx0; in1 = nx1;
+    }
+    if (a.dbias_part) {      // add the 8 waves' column sums through LDS (the dG tile is free now): one partial per workgroup
+        float* red = reinterpret_cast<float*>(rsm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w8 * S4 + lane * 8 + e] = bsum[e];
+        __syncthreads();
+        float* o = a.dbias_part + ((size_t)blockIdx.x * 2 + dir) * S4;
+        for (int i = tid; i < S4; i += 512) {
+            float sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) sum += red[ww * S4 + i];
+            o[i] = sum;
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh;
+            sf32x4 hv, cv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hv[j] = dh[4 * qq + j]; cv[j] = dc[4 * qq + j]; }
+            *reinterpret_cast<sf32x4*>(a.dh0 + sstate_off(a.bm, dir, b, B) + u) = hv;
+            *reinterpret_cast<sf32x4*>(a.dc0 + sstate_off(a.bm, dir, b, B) + u) = cv;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void lstm_rec_dbias_finalize(const float* partials, int nblk, float* dbias) {
     __shared__ double red[256];
     const int n = 2 * S4;
     const double s = reduce_partials_32x8(partials, nblk, n, blockIdx.x * 32, red);
     const int i = blockIdx.x * 32 + threadIdx.x;
     if (threadIdx.x < 32 && i < n) dbias[i] = (float)s;
+}
+
+// DIC_REC_EIGHT_WAVES=0 keeps the four-wave bf16 kernels (A/B switch)
+static bool rec_eight_waves() {
+    static const bool on = [] { const char* e = getenv("DIC_REC_EIGHT_WAVES"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 template <typename T>
@@ -421,6 +727,18 @@ static int rec_fwd(const void* gx, const void* whh, const float* h0, const float
         hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         attr_set = true;
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (rec_eight_waves()) {
+            static bool attr8_set = false;
+            if (!attr8_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_fwd8: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+                attr8_set = true;
+            }
+            hipLaunchKernelGGL(lstm_rec_fwd8_kernel, dim3((B + SROWS - 1) / SROWS, 2), dim3(512), lds, st, a);
+            return check_launch("lstm_rec_fwd8");
+        }
     }
     hipLaunchKernelGGL(lstm_rec_fwd_kernel<T>, dim3((B + SROWS - 1) / SROWS, 2), dim3(256), lds, st, a);
     return check_launch("lstm_rec_fwd");
@@ -439,7 +757,20 @@ static int rec_bwd(const void* whh, int transposed, const void* gates, const voi
     const int nwg = (B + SROWS - 1) / SROWS;
     RecBwdArgs<T> a{(const T*)whh, (const T*)gates, (const T*)cs, (const T*)dout, dhn, dcn, (T*)dgx, dh0, dc0,
                     dbias ? (float*)workspace : nullptr, R, B, bm != 0, transposed, relu != 0};
-    hipLaunchKernelGGL(lstm_rec_bwd_kernel<T>, dim3(nwg, 2), dim3(256), lds, st, a);
+    bool eight = false;
+    if constexpr (sizeof(T) == 2) {
+        if (rec_eight_waves()) {
+            static bool attr8_set = false;
+            if (!attr8_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_bwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_bwd8: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+                attr8_set = true;
+            }
+            hipLaunchKernelGGL(lstm_rec_bwd8_kernel, dim3(nwg, 2), dim3(512), lds, st, a);
+            eight = true;
+        }
+    }
+    if (!eight) hipLaunchKernelGGL(lstm_rec_bwd_kernel<T>, dim3(nwg, 2), dim3(256), lds, st, a);
     if (dbias) hipLaunchKernelGGL(lstm_rec_dbias_finalize, dim3(2 * S4 / 32), dim3(256), 0, st, (const float*)workspace, nwg, dbias);
     return check_launch("lstm_rec_bwd");
 }

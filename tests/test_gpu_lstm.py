@@ -985,3 +985,25 @@ def test_decoder_input_gradient_kernel_equals_matmul(rows):
     lib = (dg @ w).double()
     assert float((dx.double() - lib).abs().max()) <= 2.0 ** -7 * float(ref64.abs().max())
     assert N.lib().dic_lstm_dx_wide(N.ptr(dg), N.ptr(w), 31, 1024, 256, N.ptr(dx), N.stream_of(dg)) == -1      # fewer rows than a tile: rejected
+
+
+def test_eight_wave_small_batch_recurrence_equals_four_wave(tmp_path):
+    """The eight-waves-per-tile bf16 recurrence kernels of csrc/dic_lstm32.hip (a wave owns 16 hidden units; the backward's dh on
+    16x16x32 MFMAs with a permlane16 swap between the two batch blocks) against the four-wave kernels on the same inputs, batch sizes
+    with and without a ragged last tile: outputs, saved state and every gradient bit for bit; the bias gradient (a sum over eight
+    waves instead of four) to f32 rounding.  One process per variant: the switch DIC_REC_EIGHT_WAVES is read once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ('0', '1'):
+        f = str(tmp_path / f'rec{mode}.pt')
+        res = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'rec8_ab.py'), 'run', f], env=dict(os.environ, DIC_REC_EIGHT_WAVES=mode),
+                             capture_output=True, text=True, timeout=280, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(torch.load(f))
+    four, eight = outs
+    for B in four:
+        for k in ('out', 'hn', 'cn', 'gates', 'cs', 'dgx', 'dh0', 'dc0'):
+            assert torch.equal(four[B][k], eight[B][k]), (B, k)
+        torch.testing.assert_close(eight[B]['db'], four[B]['db'], rtol=1e-5, atol=1e-5)
