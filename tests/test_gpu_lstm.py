@@ -1,6 +1,8 @@
 """Fused bi-LSTM recurrence (csrc/dic_lstm.hip + lstm.py, the bf16 fast path) against
 (1) an f32 emulation that rounds to bf16 at exactly the kernel's rounding points, and
 (2) torch.nn.LSTM in f32 (loose: bf16 operands)."""
+import os
+
 import numpy as np
 import pytest
 import torch
