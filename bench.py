@@ -695,7 +695,7 @@ def main():
                       'rbf_bwd': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'), 'masked_sse_fwd': 'dic::masked_sse_kernel', 'masked_sse_bwd': 'dic::masked_sse_bwd_kernel',
                       'sci_cci_fwd_store': 'dic::sci_cci_fwd_kernel', 'rbf_fwd_store': 'dic::rbf_fwd_kernel', 'rbf_bwd_store': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'),
                       'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': ('dic::lstm_fwd8_gxn_kernel', 'dic::lstm_fwd_kernel'),
-                      'lstm_fwd_proj': ('dic::lstm_fwd8_proj_kernel', 'dic::lstm_fwd_kernel'), 'lstm_bwd': 'dic::lstm_bwd_kernel', 'lstm_dw': 'dic::lstm_dw_kernel',
+                      'lstm_fwd_proj': ('dic::lstm_fwd8_proj_kernel', 'dic::lstm_fwd_kernel'), 'lstm_bwd': ('dic::lstm_bwd8_kernel', 'dic::lstm_bwd_kernel'), 'lstm_dw': 'dic::lstm_dw_kernel',
                       'row_proj': 'dic::row_proj_kernel', 'row_proj_stats': 'dic::row_proj_kernel', 'fc_bwd': 'dic::fc_bwd_kernel',
                       'lstm_dw_wide': 'dic::lstm_dw_wide_kernel'}
         kernels = groups = None

@@ -1066,6 +1066,260 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_bwd_kernel(LstmBwd
     }
 }
 
+// ---- the same backward with EIGHT waves per workgroup (round 3): a wave owns 16 hidden units (unit group pair q = 2 (w8 & 1) + {0, 1} of
+// unit block w8 >> 1 in the saved-state layout), i.e. half the gate math, half the MFMA time and half the row copies of a four-wave wave,
+// and two waves per SIMD fill each other's stalls.  dh[unit][batch] runs on v_mfma_f32_16x16x32_bf16 -- 16 units x 16 batch rows per
+// MFMA, two batch blocks per 32-row half -- with the A rows ordered so that D lane (n, g) holds what math lane n + 16 g needs, up to one
+// v_permlane16_swap per register between the two batch blocks (the recipe of dic_lstm32.hip's lstm_rec_bwd8_kernel, where it is
+// bit-identical to the 32x32x16 form).  Same half-step software pipeline, same LDS images, same results.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 1) void lstm_bwd8_kernel(LstmBwdArgs a) {
+    extern __shared__ __align__(16) __bf16 dgt[];      // [LBM][GSTR], then the staged rows of dL/dout: [LNB][32][LH]
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5, n16 = lane & 15, g4 = lane >> 4;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w = w8 >> 1, qh = w8 & 1;      // w: the 32-unit block of the saved-state layout
+    const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
+    __bf16* dob = dgt + LBM * GSTR;
+    const int nbt = gridDim.x * LNB;
+    static_assert(LNB == 2, "the half-step software pipeline is written for two 32-row halves");
+
+    // A operand (16x16x32): lane (m = lane & 15, kg = lane >> 4) holds W_hh^T[unit s(m)][32 ks + 8 kg .. + 7], s(m) = 8 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3)
+    bf16x8 wt[16];
+    {
+        const int unit = 16 * w8 + 8 * ((n16 >> 2) & 1) + 4 * (n16 >> 3) + (n16 & 3);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            wt[ks] = *reinterpret_cast<const bf16x8*>(a.whh_t + ((size_t)dir * LH + unit) * 4 * LH + ks * 32 + 8 * g4);
+    }
+    float dh[LNB][8];      // element e = 4 qq + j: unit 16 w8 + 8 qq + 4 hh + j of batch row r
+    float dc[LNB][8];
+    float ccar[LNB][8];
+    float bsum[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) {
+        const int b = b0 + nb * 32 + r;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) {
+                if (a.dhn) hv = *reinterpret_cast<const f32x4*>(a.dhn + state_off(a.bm, dir, b, B) + u);
+                if (a.dcn) cv = *reinterpret_cast<const f32x4*>(a.dcn + state_off(a.bm, dir, b, B) + u);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dh[nb][4 * qq + j] = hv[j]; dc[nb][4 * qq + j] = cv[j]; }
+        }
+    }
+    struct StepIn { bf16x4 ib, fb, gb, ob, cp; };
+    StepIn in[LNB][2];
+    auto load_q = [&](auto nbc, auto qc, int step) {
+        constexpr int nb = decltype(nbc)::value, qq = decltype(qc)::value;
+        const int q = 2 * qh + qq;
+        const int t = dir ? step : R - 1 - step;
+        const bool first_fwd = step == R - 1;
+        const int tp = dir ? t + 1 : t - 1;
+        const int b = min(b0 + nb * 32 + r, B - 1);
+        const int bt = blockIdx.x * LNB + nb;
+        const int u = 16 * w8 + 8 * qq + 4 * hh;
+        StepIn& d = in[nb][qq];
+        const unsigned lane_b = (unsigned)lane * 8u;
+        const char* gbase = reinterpret_cast<const char*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, 0, 0));
+        constexpr unsigned GATE_STRIDE = 4 * 2 * 32 * 4 * 2;
+        d.ib = *reinterpret_cast<const bf16x4*>(gbase + lane_b);
+        d.fb = *reinterpret_cast<const bf16x4*>(gbase + (GATE_STRIDE + lane_b));
+        d.gb = *reinterpret_cast<const bf16x4*>(gbase + (2 * GATE_STRIDE + lane_b));
+        d.ob = *reinterpret_cast<const bf16x4*>(gbase + (3 * GATE_STRIDE + lane_b));
+        bf16x4 cp = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const char*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, 0, 0)) + lane_b);
+        else if (a.c0) {
+            const f32x4 c0v = *reinterpret_cast<const f32x4*>(a.c0 + state_off(a.bm, dir, b, B) + u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cp[j] = (__bf16)c0v[j];
+        }
+        d.cp = cp;
+    };
+    auto load_half = [&](auto nbc, int step) { load_q(nbc, IC<0>{}, step); load_q(nbc, IC<1>{}, step); };
+    // dL/dout of a 32-row half and step through LDS (see lstm_bwd_kernel): eight waves x one instruction of 4 rows x 256 B
+    bf16x8 dstage[LNB];
+    auto dout_load = [&](auto nbc, int step) {
+        constexpr int nb = decltype(nbc)::value;
+        const int t = dir ? step : R - 1 - step;
+        const int row = 4 * w8 + (lane >> 4);
+        const int b = min(b0 + nb * 32 + row, B - 1);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+        if (a.dout) v = *reinterpret_cast<const bf16x8*>(a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + 8 * (lane & 15));
+        dstage[nb] = v;
+    };
+    auto dout_store = [&](auto nbc) {
+        constexpr int nb = decltype(nbc)::value;
+        const int row = 4 * w8 + (lane >> 4);
+        *reinterpret_cast<bf16x8*>(dob + (nb * 32 + row) * LH + (((lane & 15) + row) & 15) * 8) = dstage[nb];
+    };
+    auto math_q = [&](int nb, int qq) {
+        const int q = 2 * qh + qq;
+        const StepIn& x = in[nb][qq];
+        const bf16x4 go = *reinterpret_cast<const bf16x4*>(dob + (nb * 32 + r) * LH + (((4 * w + q) + r) & 15) * 8 + 4 * hh);
+        bf16x4 di, df, dg, dO;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * qq + j;
+            const float ig = (float)x.ib[j], fg = (float)x.fb[j], gg = (float)x.gb[j], og = (float)x.ob[j];
+            const float tc = tanh_fast(ccar[nb][k]);
+            const float dht = dh[nb][k] + ((a.relu && !(tc > 0.f)) ? 0.f : (float)go[j]);
+            const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
+            const float vi = dct * gg * ig * (1.0f - ig), vf = dct * (float)x.cp[j] * fg * (1.0f - fg);
+            const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
+            di[j] = (__bf16)vi; df[j] = (__bf16)vf; dg[j] = (__bf16)vg; dO[j] = (__bf16)vo;
+            dc[nb][k] = dct * fg;
+            ccar[nb][k] = (float)x.cp[j];
+        }
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x2 I = __builtin_bit_cast(u32x2, di), F = __builtin_bit_cast(u32x2, df), G = __builtin_bit_cast(u32x2, dg), O = __builtin_bit_cast(u32x2, dO);
+        {
+            auto s0 = __builtin_amdgcn_permlane32_swap(I[0], F[0], false, false); I[0] = s0[0]; F[0] = s0[1];
+            auto s1 = __builtin_amdgcn_permlane32_swap(I[1], F[1], false, false); I[1] = s1[0]; F[1] = s1[1];
+            auto s2 = __builtin_amdgcn_permlane32_swap(G[0], O[0], false, false); G[0] = s2[0]; O[0] = s2[1];
+            auto s3 = __builtin_amdgcn_permlane32_swap(G[1], O[1], false, false); G[1] = s3[0]; O[1] = s3[1];
+        }
+        __bf16* lp = dgt + (nb * 32 + r) * GSTR + (32 * w + 8 * q) + hh * LH;
+        const u32x4 c0 = {I[0], I[1], F[0], F[1]}, c1 = {G[0], G[1], O[0], O[1]};
+        *reinterpret_cast<u32x4*>(lp) = c0;
+        *reinterpret_cast<u32x4*>(lp + 2 * LH) = c1;
+    };
+    // the recurrent product of half nb in four groups of (4 k-steps x 2 batch blocks), B fragments one group ahead; one of this wave's four
+    // dG rows of the half leaves for global memory with every group
+    f32x4v acc0, acc1;
+    bf16x8 gring[4];                // one group of B fragments (2 k-steps x 2 batch blocks): the MFMAs read their operands at issue, so the next
+                                    // group's reads may overwrite the registers right behind them; the wave's partner on the SIMD covers the round trip
+    auto fetch_b = [&](int nb, int sg) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            gring[i] = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + n16) * GSTR + (2 * sg + i) * 32 + 8 * g4);
+            gring[2 + i] = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + 16 + n16) * GSTR + (2 * sg + i) * 32 + 8 * g4);
+        }
+    };
+    auto mfma_sub = [&](int nb, int sg) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[2 * sg + i], gring[i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[2 * sg + i], gring[2 + i], acc1, 0, 0, 0);
+        }
+        if (sg + 1 < 8) fetch_b(nb, sg + 1);
+    };
+    auto row_and_mfma = [&](int nb, int k, int t) {
+        const int rowl = nb * 32 + k * 8 + w8;
+        const int b = b0 + rowl;
+        bf16x8 v;
+        if (b < B) v = *reinterpret_cast<const bf16x8*>(dgt + rowl * GSTR + lane * 8);
+        mfma_sub(nb, 2 * k);
+        mfma_sub(nb, 2 * k + 1);
+        if (b < B) {
+            *reinterpret_cast<bf16x8*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
+        }
+    };
+    auto finish_dh = [&](int nb) {     // even 16-lane rows keep acc0 and take the odd partner's acc0 (batch n), odd rows keep acc1 and take the even partner's (batch 16 + n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, (float)acc0[e]), __builtin_bit_cast(unsigned, (float)acc1[e]), false, false);
+            dh[nb][e] = __builtin_bit_cast(float, (unsigned)s[0]);
+            dh[nb][4 + e] = __builtin_bit_cast(float, (unsigned)s[1]);
+        }
+    };
+    {   // prologue
+        const int t0 = dir ? 0 : R - 1;
+#pragma unroll
+        for (int nb = 0; nb < LNB; ++nb)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const bf16x4 ct = *reinterpret_cast<const bf16x4*>(a.cs + native_off(t0, nbt, blockIdx.x * LNB + nb, dir, w, 1, 0, 2 * qh + qq, hh, r));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ccar[nb][4 * qq + j] = (float)ct[j];
+            }
+        dout_load(IC<0>{}, 0);
+        dout_load(IC<1>{}, 0);
+        load_half(IC<0>{}, 0);
+        load_half(IC<1>{}, 0);
+        dout_store(IC<0>{});
+        dout_store(IC<1>{});
+        if (R > 1) { dout_load(IC<0>{}, 1); dout_load(IC<1>{}, 1); }
+        lds_barrier();
+        math_q(0, 0); math_q(0, 1);
+        if (R > 1) load_half(IC<0>{}, 1);
+    }
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? step : R - 1 - step;
+        lds_barrier();                                     // half 0 of dG_t is complete; nobody reads half 1 of the previous step any more
+        // ---- phase X: MFMA + stores of half 0  ||  math of half 1
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        fetch_b(0, 0);
+#define DIC_BWD8_X(Q)                                                  \
+        math_q(1, Q);                                                  \
+        if (step + 1 < R) load_q(IC<1>{}, IC<Q>{}, step + 1);          \
+        row_and_mfma(0, 2 * Q, t);                                     \
+        row_and_mfma(0, 2 * Q + 1, t);
+        DIC_BWD8_X(0) DIC_BWD8_X(1)
+#undef DIC_BWD8_X
+        finish_dh(0);
+        if (step + 1 < R) dout_store(IC<0>{});
+        if (step + 2 < R) dout_load(IC<0>{}, step + 2);
+        lds_barrier();                                     // half 1 of dG_t is complete; the reads of half 0 have retired
+        // ---- phase Y: MFMA + stores of half 1  ||  math of half 0 for the next step
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        fetch_b(1, 0);
+        if (step + 1 < R) {
+#define DIC_BWD8_Y(Q)                                                  \
+            math_q(0, Q);                                              \
+            if (step + 2 < R) load_q(IC<0>{}, IC<Q>{}, step + 2);      \
+            row_and_mfma(1, 2 * Q, t);                                 \
+            row_and_mfma(1, 2 * Q + 1, t);
+            DIC_BWD8_Y(0) DIC_BWD8_Y(1)
+#undef DIC_BWD8_Y
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) row_and_mfma(1, k, t);
+        }
+        finish_dh(1);
+        if (step + 1 < R) dout_store(IC<1>{});
+        if (step + 2 < R) dout_load(IC<1>{}, step + 2);
+    }
+    __syncthreads();                                       // the dG tile is free for the bias reduction below
+    if (a.dbias_part) {
+        float* red = reinterpret_cast<float*>(dgt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w8 * 4 * LH + lane * 8 + e] = bsum[e];
+        __syncthreads();
+        for (int i = tid; i < 4 * LH; i += 512) {
+            float sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) sum += red[ww * 4 * LH + i];
+            a.dbias_part[((size_t)blockIdx.x * 2 + dir) * 4 * LH + i] = sum;
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < LNB; ++nb) {
+        const int b = b0 + nb * 32 + r;
+        if (b >= B) continue;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh;
+            f32x4 hv, cv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hv[j] = dh[nb][4 * qq + j]; cv[j] = dc[nb][4 * qq + j]; }
+            *reinterpret_cast<f32x4*>(a.dh0 + state_off(a.bm, dir, b, B) + u) = hv;
+            *reinterpret_cast<f32x4*>(a.dc0 + state_off(a.bm, dir, b, B) + u) = cv;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void lstm_dbias_finalize(const float* partials, int nblk, float* dbias) {
     __shared__ double red[256];
     const int n = 2 * 4 * LH;
@@ -1168,7 +1422,18 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
                 "lstm_bwd: dbias needs %zu B of workspace", dic_lstm_bwd_workspace(B));
     LstmBwdArgs a{(const __bf16*)whh_t, (const __bf16*)gates, (const __bf16*)cs, c0, (const __bf16*)dout, dhn, dcn, (__bf16*)dgx, dh0, dc0,
                   dbias ? (float*)workspace : nullptr, R, B, state_batch_major != 0, dout_of_relu != 0};
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nwg, 2), dim3(256), lds, (hipStream_t)stream, a);
+    static const bool eight = [] { const char* e = getenv("DIC_BWD_EIGHT_WAVES"); return !(e && e[0] == '0'); }();
+    if (eight) {
+        static bool attr8_set = false;
+        if (!attr8_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_bwd8: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            attr8_set = true;
+        }
+        hipLaunchKernelGGL(lstm_bwd8_kernel, dim3(nwg, 2), dim3(512), lds, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(lstm_bwd_kernel, dim3(nwg, 2), dim3(256), lds, (hipStream_t)stream, a);
+    }
     if (dbias)
         hipLaunchKernelGGL(lstm_dbias_finalize, dim3(2 * 4 * LH / 32), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nwg,
                            dbias);
