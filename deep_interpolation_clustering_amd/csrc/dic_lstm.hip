@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd8_kernel(LstmBwdArgs a) {
     }
     float dh[LNB][8];      // element e = 4 qq + j: unit 16 w8 + 8 qq + 4 hh + j of batch row r
     float dc[LNB][8];
-    float ccar[LNB][8];
+    bf16x4 ccar[LNB][2];   // c of the step processed next, as the bf16 it was saved in (packed: the wave has 256 registers)
     float bsum[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) bsum[k] = 0.f;
@@ -1168,15 +1168,15 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd8_kernel(LstmBwdArgs a) {
         for (int j = 0; j < 4; ++j) {
             const int k = 4 * qq + j;
             const float ig = (float)x.ib[j], fg = (float)x.fb[j], gg = (float)x.gb[j], og = (float)x.ob[j];
-            const float tc = tanh_fast(ccar[nb][k]);
+            const float tc = tanh_fast((float)ccar[nb][qq][j]);
             const float dht = dh[nb][k] + ((a.relu && !(tc > 0.f)) ? 0.f : (float)go[j]);
             const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[nb][k]);
             const float vi = dct * gg * ig * (1.0f - ig), vf = dct * (float)x.cp[j] * fg * (1.0f - fg);
             const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
             di[j] = (__bf16)vi; df[j] = (__bf16)vf; dg[j] = (__bf16)vg; dO[j] = (__bf16)vo;
             dc[nb][k] = dct * fg;
-            ccar[nb][k] = (float)x.cp[j];
         }
+        ccar[nb][qq] = x.cp;
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x2 I = __builtin_bit_cast(u32x2, di), F = __builtin_bit_cast(u32x2, df), G = __builtin_bit_cast(u32x2, dg), O = __builtin_bit_cast(u32x2, dO);
@@ -1238,9 +1238,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd8_kernel(LstmBwdArgs a) {
         for (int nb = 0; nb < LNB; ++nb)
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
-                const bf16x4 ct = *reinterpret_cast<const bf16x4*>(a.cs + native_off(t0, nbt, blockIdx.x * LNB + nb, dir, w, 1, 0, 2 * qh + qq, hh, r));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ccar[nb][4 * qq + j] = (float)ct[j];
+                ccar[nb][qq] = *reinterpret_cast<const bf16x4*>(a.cs + native_off(t0, nbt, blockIdx.x * LNB + nb, dir, w, 1, 0, 2 * qh + qq, hh, r));
             }
         dout_load(IC<0>{}, 0);
         dout_load(IC<1>{}, 0);
