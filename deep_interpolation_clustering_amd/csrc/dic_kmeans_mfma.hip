@@ -79,13 +79,8 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
         if (lane == 0) cnorm[col] = (k < K) ? s : INFINITY;          // padding columns can never win the argmin
     }
     __syncthreads();
-    // the centroid of accumulator register `reg` of M-block mb in this lane: m = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 hh
-    float cn[NMB][16];
-#pragma unroll
-    for (int mb = 0; mb < NMB; ++mb)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) cn[mb][reg] = cnorm[32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * hh];
-
+    // the centroid of accumulator register `reg` of M-block mb in this lane: m = 32 mb + (reg & 3) + 8 (reg >> 2) + 4 hh; its squared norm is read
+    // from LDS where the argmin needs it (two addresses per wave: broadcast reads) -- held in 16 registers it made the kernel spill
     kf32x16 S[NMB][8];                                   // sums[centroid column block][d block]: column jj of d-block nb is d = 128 (nb >> 2) + 4 jj + (nb & 3)
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
@@ -98,14 +93,13 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
     // staging of X chunks (scores phase): lane -> (16-B piece, row of 4) such that a 16-lane group is 2 rows x 128 B
     float* xb = xbuf + w * 32 * XP;
     const int lq = (lane & 7) | (((lane >> 4) & 1) << 3), lrow = ((lane >> 3) & 1) | (((lane >> 5) & 1) << 1);
-    const float* xsrc = a.X + 4 * lq;
     float* xdst = xb + lrow * XP + km_perm8(4 * lq);
     kf32x4 v[8];
     auto load_chunk = [&](int r0_, int c) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             v[i] = kf32x4{0.f, 0.f, 0.f, 0.f};
-            if (XCH * c + 4 * lq < D) v[i] = *reinterpret_cast<const kf32x4*>(xsrc + (size_t)min(r0_ + 4 * i + lrow, N - 1) * D + XCH * c);
+            if (XCH * c + 4 * lq < D) v[i] = *reinterpret_cast<const kf32x4*>(a.X + ((size_t)min(r0_ + 4 * i + lrow, N - 1) * D + (unsigned)(XCH * c + 4 * lq)));
         }
     };
     for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += a.nblk * 4) {
@@ -168,7 +162,7 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
                 for (int reg = 0; reg < 16; ++reg) {
                     const int mcol = 32 * mb + (reg & 3) + 8 * (reg >> 2);      // + 4 hh
                     if (mcol / KP != g) continue;                               // compile-time: (mcol + 4 hh) / KP == mcol / KP for KP >= 8
-                    const float s = fmaf(-2.0f, dacc[mb][reg], cn[mb][reg]);
+                    const float s = fmaf(-2.0f, dacc[mb][reg], cnorm[32 * mb + (reg & 3) + 8 * (reg >> 2) + 4 * hh]);
                     const int kidx = mcol + 4 * hh - g * KP;
                     if (s < best) { best = s; bi = kidx; }
                 }
@@ -191,14 +185,9 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
         }
         // (lab8 of this wave is written and read by this wave only: wave-local ordering through the LDS queue)
         // ---- sums: S[col][d] += sum_rows onehot[col][row] X[row][d]; MFMA n multiplies rows 2n + hh
-        unsigned lw[NMB][8];                                 // labels of the 32 rows for the restarts of this lane's centroid column(s)
-#pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) {
-            const int g = (32 * mb + j) / KP;
-            const unsigned* lp = reinterpret_cast<const unsigned*>(lab8 + (w * G + g) * 32);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) lw[mb][q] = lp[q];
-        }
+        const unsigned* lwp[NMB];                            // packed labels of the 32 rows for the restart of this lane's centroid column(s): read from LDS
+#pragma unroll                                              // per row pair below (broadcast reads) -- eight registers of them made the K <= 32 kernel spill
+        for (int mb = 0; mb < NMB; ++mb) lwp[mb] = reinterpret_cast<const unsigned*>(lab8 + (w * G + (32 * mb + j) / KP) * 32);
         int kc[NMB];
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb) kc[mb] = (32 * mb + j) % KP;
@@ -209,7 +198,8 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
             float onehot[NMB];
 #pragma unroll
             for (int mb = 0; mb < NMB; ++mb) {
-                const unsigned b = (hh ? (lw[mb][n >> 1] >> (16 * (n & 1) + 8)) : (lw[mb][n >> 1] >> (16 * (n & 1)))) & 255u;
+                const unsigned lwv = lwp[mb][n >> 1];
+                const unsigned b = (hh ? (lwv >> (16 * (n & 1) + 8)) : (lwv >> (16 * (n & 1)))) & 255u;
                 onehot[mb] = b == (unsigned)kc[mb] ? 1.0f : 0.0f;
             }
 #pragma unroll

@@ -1194,22 +1194,21 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd8_kernel(LstmBwdArgs a) {
     // the recurrent product of half nb in four groups of (4 k-steps x 2 batch blocks), B fragments one group ahead; one of this wave's four
     // dG rows of the half leaves for global memory with every group
     f32x4v acc0, acc1;
-    bf16x8 gring[4];                // one group of B fragments (2 k-steps x 2 batch blocks): the MFMAs read their operands at issue, so the next
-                                    // group's reads may overwrite the registers right behind them; the wave's partner on the SIMD covers the round trip
-    auto fetch_b = [&](int nb, int sg) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            gring[i] = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + n16) * GSTR + (2 * sg + i) * 32 + 8 * g4);
-            gring[2 + i] = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + 16 + n16) * GSTR + (2 * sg + i) * 32 + 8 * g4);
-        }
+    bf16x8 gring[2];                // the B fragments of ONE k-step (two batch blocks): the MFMAs read their operands at issue, so the next k-step's
+                                    // reads may overwrite the registers right behind them; the wave's partner on the SIMD covers the round trip
+                                    // (a wave has 256 registers here: a deeper ring spills)
+    auto fetch_b = [&](int nb, int ks) {
+        gring[0] = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + n16) * GSTR + ks * 32 + 8 * g4);
+        gring[1] = *reinterpret_cast<const bf16x8*>(dgt + (nb * 32 + 16 + n16) * GSTR + ks * 32 + 8 * g4);
     };
-    auto mfma_sub = [&](int nb, int sg) {
+    auto mfma_sub = [&](int nb, int sg) {      // two k-steps
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[2 * sg + i], gring[i], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[2 * sg + i], gring[2 + i], acc1, 0, 0, 0);
+            const int ks = 2 * sg + i;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks], gring[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks], gring[1], acc1, 0, 0, 0);
+            if (ks + 1 < 16) fetch_b(nb, ks + 1);
         }
-        if (sg + 1 < 8) fetch_b(nb, sg + 1);
     };
     auto row_and_mfma = [&](int nb, int k, int t) {
         const int rowl = nb * 32 + k * 8 + w8;
