@@ -15,7 +15,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdic_hip.so')
+LIB_PATH = os.environ.get('DIC_LIB_PATH') or os.path.join(_HERE, 'libdic_hip.so')      # (DIC_LIB_PATH: another build of the library, for A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dic_hip.h')
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 

@@ -4,7 +4,19 @@
 #include <stdint.h>
 #include "dic_hip.h"
 
+// Streaming (nontemporal) accesses for data a launch touches exactly once in whole cache lines (16 B per lane, or 8 B per lane over a
+// contiguous 512-B piece): they would only push each other out of L2.  Partial-line stores must NOT use it (measured 2x slower).
+// -DDIC_NO_NT: plain accesses everywhere (A/B builds).
+#ifndef DIC_NO_NT
+#define DIC_NT_LOAD(T, p) __builtin_nontemporal_load(reinterpret_cast<const T*>(p))
+#define DIC_NT_STORE(T, p, v) __builtin_nontemporal_store((v), reinterpret_cast<T*>(p))
+#else
+#define DIC_NT_LOAD(T, p) (*reinterpret_cast<const T*>(p))
+#define DIC_NT_STORE(T, p, v) (*reinterpret_cast<T*>(p) = (v))
+#endif
+
 namespace dic {
+
 
 constexpr int kWave = 64;            // CDNA4 wavefront
 constexpr int kBlock = 256;          // default workgroup: 4 waves, one per SIMD

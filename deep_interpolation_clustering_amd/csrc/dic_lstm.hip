@@ -36,6 +36,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int V> struct IC { static constexpr int value = V; };      // compile-time index passed through a generic lambda
 
+// (DIC_NT_LOAD / DIC_NT_STORE, dic_common.h: same-box A/B of lstm_bwd8 at B = 32 768 with its saved-state loads and 16-B dG row stores
+// nontemporal: 794 -> 763 us.  Tried and dropped elsewhere -- the forward kernels' 8-B-per-lane saved-state stores: nothing; their `out`
+// stores, 16 B of each of 32 rows per instruction, i.e. partial lines: TWICE as long; the decoder forward's gx LDS-DMA: +6 %; row_proj's x
+// loads (each tile is read by four column stripes): +15 %; fc_bwd, the weight-gradient kernels' DMA: nothing.)
+
+
 #ifdef DIC_LSTM_EXP_NOMATH      // experiment: gate non-linearities replaced by one FMA each (timing only, wrong results)
 __device__ __forceinline__ float sigmoid_fast(float x) { return fmaf(x, 0.01f, 0.5f); }
 __device__ __forceinline__ float tanh_fast(float x) { return x * 0.01f; }
@@ -1127,10 +1133,10 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd8_kernel(LstmBwdArgs a) {
         const unsigned lane_b = (unsigned)lane * 8u;
         const char* gbase = reinterpret_cast<const char*>(a.gates + native_off(t, nbt, bt, dir, w, 4, 0, q, 0, 0));
         constexpr unsigned GATE_STRIDE = 4 * 2 * 32 * 4 * 2;
-        d.ib = *reinterpret_cast<const bf16x4*>(gbase + lane_b);
-        d.fb = *reinterpret_cast<const bf16x4*>(gbase + (GATE_STRIDE + lane_b));
-        d.gb = *reinterpret_cast<const bf16x4*>(gbase + (2 * GATE_STRIDE + lane_b));
-        d.ob = *reinterpret_cast<const bf16x4*>(gbase + (3 * GATE_STRIDE + lane_b));
+        d.ib = DIC_NT_LOAD(bf16x4, gbase + lane_b);
+        d.fb = DIC_NT_LOAD(bf16x4, gbase + (GATE_STRIDE + lane_b));
+        d.gb = DIC_NT_LOAD(bf16x4, gbase + (2 * GATE_STRIDE + lane_b));
+        d.ob = DIC_NT_LOAD(bf16x4, gbase + (3 * GATE_STRIDE + lane_b));
         bf16x4 cp = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
         if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const char*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, 0, 0)) + lane_b);
         else if (a.c0) {
@@ -1218,7 +1224,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd8_kernel(LstmBwdArgs a) {
         mfma_sub(nb, 2 * k);
         mfma_sub(nb, 2 * k + 1);
         if (b < B) {
-            *reinterpret_cast<bf16x8*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8) = v;
+            DIC_NT_STORE(bf16x8, a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * LH + lane * 8, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) bsum[e] += (float)v[e];
         }

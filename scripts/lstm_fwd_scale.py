@@ -4,6 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 from deep_interpolation_clustering_amd import _native as N
+if len(sys.argv) > 1:                 # A/B: another build of the library
+    N.LIB_PATH = os.path.abspath(sys.argv[1])
 L = N.lib()
 R, H = 24, 128
 dev, bf = torch.device('cuda'), torch.bfloat16
