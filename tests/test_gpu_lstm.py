@@ -1009,3 +1009,25 @@ def test_eight_wave_small_batch_recurrence_equals_four_wave(tmp_path):
         for k in ('out', 'hn', 'cn', 'gates', 'cs', 'dgx', 'dh0', 'dc0'):
             assert torch.equal(four[B][k], eight[B][k]), (B, k)
         torch.testing.assert_close(eight[B]['db'], four[B]['db'], rtol=1e-5, atol=1e-5)
+
+
+def test_eight_wave_backward_equals_four_wave_on_odd_shapes(tmp_path):
+    """lstm_bwd8_kernel (eight waves per 64-row workgroup, dh on 16x16x32 MFMAs) against lstm_bwd_kernel on R = 1, 2, 3, 5, 24, batches with a
+    ragged last tile, with / without c0 and the ReLU mask: dG, dh0, dc0 bit for bit; the bias gradient (summed over eight waves instead of
+    four) to f32 rounding.  scripts/bwd8_ab.py, one process per variant (DIC_BWD_EIGHT_WAVES is read once)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for mode in ('0', '1'):
+        f = str(tmp_path / f'bwd{mode}.pt')
+        res = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'bwd8_ab.py'), 'run', f], env=dict(os.environ, DIC_BWD_EIGHT_WAVES=mode),
+                             capture_output=True, text=True, timeout=280, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        files.append(f)
+    four, eight = torch.load(files[0]), torch.load(files[1])
+    assert set(four) == set(eight) and len(four) == 5
+    for key in four:
+        for k in ('dgx', 'dh0', 'dc0'):
+            assert torch.equal(four[key][k], eight[key][k]), (key, k)
+        torch.testing.assert_close(eight[key]['db'], four[key]['db'], rtol=1e-5, atol=1e-5)
