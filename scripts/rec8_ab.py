@@ -12,17 +12,17 @@ if sys.argv[1] == 'cmp':
                 continue
             x, y = a[B][k].float(), b[B][k].float()
             d = (x - y).abs().max().item()
-            print('B %5d %-6s max|a-b| %.3e  max|a| %.3e  equal %s' % (B, k, d, x.abs().max().item(), bool(torch.equal(a[B][k], b[B][k]))))
-        print('B %5d  fwd %.1f vs %.1f us   bwd %.1f vs %.1f us' % (B, a[B]['t_fwd'], b[B]['t_fwd'], a[B]['t_bwd'], b[B]['t_bwd']))
+            print('%-10s %-6s max|a-b| %.3e  max|a| %.3e  equal %s' % (B, k, d, x.abs().max().item(), bool(torch.equal(a[B][k], b[B][k]))))
+        print('%-10s  fwd %.1f vs %.1f us   bwd %.1f vs %.1f us' % (B, a[B]['t_fwd'], b[B]['t_fwd'], a[B]['t_bwd'], b[B]['t_bwd']))
     sys.exit(0)
 
 from deep_interpolation_clustering_amd import _native as N
 L = N.lib()
-R, H = 24, 128
+H = 128
 dev, bf = torch.device('cuda'), torch.bfloat16
 P = N.ptr
 res = {}
-for B in (256, 300, 1024, 4096):
+for R, B in ((24, 256), (24, 300), (24, 1024), (24, 4096), (1, 40), (2, 96)):
     torch.manual_seed(B)
     gx = (torch.randn(R, B, 2, 4, H, device=dev) * 0.5).to(bf)
     whh = (torch.randn(2, 4 * H, H, device=dev) * 0.08).to(bf); whh_t = whh.transpose(1, 2).contiguous()
@@ -48,5 +48,5 @@ for B in (256, 300, 1024, 4096):
         b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / it * 1e3
     tf = timed(fwd); tb = timed(bwd)
-    res[B] = dict(out=out.cpu(), hn=hn.cpu(), cn=cn.cpu(), gates=gates.cpu(), cs=cs.cpu(), dgx=dgx.cpu(), dh0=dh0.cpu(), dc0=dc0.cpu(), db=db.cpu(), t_fwd=tf, t_bwd=tb)
+    res['R%d_B%d' % (R, B)] = dict(out=out.cpu(), hn=hn.cpu(), cn=cn.cpu(), gates=gates.cpu(), cs=cs.cpu(), dgx=dgx.cpu(), dh0=dh0.cpu(), dc0=dc0.cpu(), db=db.cpu(), t_fwd=tf, t_bwd=tb)
 torch.save(res, sys.argv[2])
