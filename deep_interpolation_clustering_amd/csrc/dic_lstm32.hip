@@ -129,6 +129,7 @@ struct RecFwdArgs {
     T* gates;              // lane-native (R,Bp,2,4,H) post-activation i,f,g,o or NULL (Bp = B rounded up to 32)
     T* cs;                 // lane-native (R+1,Bp,2,H) cell states or NULL; time slot R receives c0 (zeros without one): the backward's c_prev of the first step
     int R, B, bm;
+    int boundary;          // out is time slots 1..R of an (R+2,B,2H) buffer: also write h0 (zeros without one) into slot 0 [:, :H] / slot R+1 [:, H:]
 };
 
 template <typename T>
@@ -164,6 +165,10 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; cb[j] = (T)cv[j]; c[4 * q + j] = cv[j]; }
         *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
+        if (a.boundary && ok) {
+            T* slot = dir ? a.out + (size_t)R * B * 2 * SH : a.out - (size_t)B * 2 * SH;
+            *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
+        }
         if (a.cs) *reinterpret_cast<V4*>(a.cs + snative_off(R, nbt, bt, dir, w, 1, 0, q, hh, r)) = cb;
     }
     // gx tile of a step -> LDS by LDS-DMA: one instruction moves 1 KiB of a row (a whole bf16 row, half an f32 row)
@@ -461,6 +466,10 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_fwd8_kernel(RecFwdArgs<__bf16
 #pragma unroll
         for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; cb[j] = (T)cv[j]; c[4 * qq + j] = cv[j]; }
         *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
+        if (a.boundary && ok) {
+            T* slot = dir ? a.out + (size_t)R * B * 2 * SH : a.out - (size_t)B * 2 * SH;
+            *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
+        }
         if (a.cs) *reinterpret_cast<V4*>(a.cs + snative_off(R, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cb;
     }
     auto request_gx = [&](int step) {                      // 32 whole 1-KiB rows by LDS-DMA, four per wave
@@ -720,7 +729,7 @@ static bool rec_eight_waves() {
 template <typename T>
 static int rec_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, void* out, float* hn, float* cn,
                    void* gates, void* cs, int bm, hipStream_t st) {
-    RecFwdArgs<T> a{(const T*)gx, (const T*)whh, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B, bm != 0};
+    RecFwdArgs<T> a{(const T*)gx, (const T*)whh, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B, (bm & 1) != 0, (bm & 2) != 0};
     const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)SROWS * (S4 + 16 / sizeof(T))) * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
@@ -782,7 +791,8 @@ using namespace dic;
 extern "C" {
 
 int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H, void* out,
-                     float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream) {
+                     float* hn, float* cn, void* gates, void* cs, int state_flags, dic_stream_t stream) {
+    const int state_batch_major = state_flags;      // (bit 0: batch-major states; bit 1: boundary slots -- see dic_hip.h)
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_rec_fwd: non-positive size");
     DIC_REQUIRE(H == SH, DIC_ERR_UNSUPPORTED, "lstm_rec_fwd: hidden size %d (compiled for %d)", H, SH);
     DIC_REQUIRE(dtype == DIC_DTYPE_F32 || dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "lstm_rec_fwd: dtype %d", dtype);

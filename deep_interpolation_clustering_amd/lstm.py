@@ -163,14 +163,8 @@ class _BiLstm(torch.autograd.Function):
             xb = torch.relu(xb)
         out_ext = torch.empty((R + 2, B, 2 * H), device=dev, dtype=T)       # [h0 | h_1..h_R | h0]: every step's h_prev is a row above / below
         out = out_ext[1:R + 1]
-        kernel_boundary = need and not small                       # the 64-row kernels write the boundary rows of the dW_hh products themselves
-        if need and small:                                         # (h0 into time slot 0 [:H] / slot R+1 [H:]; the other halves are never read)
-            if h0 is None:
-                out_ext[0, :, :H].zero_()
-                out_ext[R + 1, :, H:].zero_()
-            else:
-                out_ext[0, :, :H].copy_(h0[:, 0] if bm else h0[0])
-                out_ext[R + 1, :, H:].copy_(h0[:, 1] if bm else h0[1])
+        kernel_boundary = need                                     # the kernels write the boundary rows of the dW_hh products themselves (h0 into time
+                                                                   # slot 0 [:H] / slot R+1 [H:]; the other halves are never read): no fill / copy launches
         hn = torch.empty((B, 2, H) if bm else (2, B, H), device=dev, dtype=torch.float32)
         cn = torch.empty_like(hn)
         h0c = None if h0 is None else N.f32c(h0)
@@ -184,7 +178,7 @@ class _BiLstm(torch.autograd.Function):
                 cs = torch.empty((R + 1, Bp, 2, H), device=dev, dtype=T)     # (time slot R: c0, written by the forward)
             gx = torch.mm(xb.view(R * B, Ip), wih.t()) if narrow else torch.addmm(bias, xb.view(R * B, Ip), wih.t())     # (R*B, 2*4*H)
             N.check(L.dic_lstm_rec_fwd(code, N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
-                                       N.ptr(gates), N.ptr(cs), int(bm), st), 'dic_lstm_rec_fwd')
+                                       N.ptr(gates), N.ptr(cs), int(bm) | (2 if kernel_boundary else 0), st), 'dic_lstm_rec_fwd')
         else:
             if need:
                 Bp = (B + 63) // 64 * 64                           # kernel-native saved state is tiled by 64 rows

@@ -309,11 +309,14 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
  * B = 256: one 32-row tile per workgroup instead of two).  Element type T of gx, whh, out, gates, cs, dout, dgx follows dtype;
  * gates (R,Bp,2,4,H) and cs (R+1,Bp,2,H), Bp = B rounded up to 32, are an opaque lane-native layout exchanged between the two
  * calls (time slot R of cs carries c0, so the backward takes no c0).  whh (2,4H,H); the backward takes either that (read transposed
- * once at start-up) or the transposed copy (2,H,4H) with whh_is_transposed != 0. */
+ * once at start-up) or the transposed copy (2,H,4H) with whh_is_transposed != 0.
+ * state_flags of the forward: bit 0 = the state tensors (h0, c0, hn, cn) are batch-major (B,2,H); bit 1 (round 3) = `out` is time slots
+ * 1..R of an (R+2,B,2H) buffer and the kernel also writes h0 (zeros without one) into slot 0 [:, :H] / slot R+1 [:, H:] -- every step's
+ * recurrent input for the weight-gradient kernels, as dic_lstm_fwd's `boundary` does (two fill / copy launches per LSTM less). */
 #define DIC_DTYPE_F32 0
 #define DIC_DTYPE_BF16 1
 int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H, void* out,
-                     float* hn, float* cn, void* gates, void* cs, int state_batch_major, dic_stream_t stream);
+                     float* hn, float* cn, void* gates, void* cs, int state_flags, dic_stream_t stream);
 size_t dic_lstm_rec_bwd_workspace(int B);
 int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const void* dout,
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
