@@ -435,7 +435,7 @@ def record_cfg5(dev, sweep=True):
     import tempfile
     from deep_interpolation_clustering_amd import _native as N
     from deep_interpolation_clustering_amd.kmeans import KMeans
-    from oracle.synth import latent_blobs
+    from deep_interpolation_clustering_amd.synthetic import latent_blobs
     n = 75000
     X, _ = latent_blobs(2024, n, 256, 4, spread=0.35, noise=0.3)
     Xd = torch.tensor(X, device=dev)

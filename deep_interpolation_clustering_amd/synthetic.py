@@ -77,3 +77,15 @@ def stacked_batch(cohort, scale=5.0, denoise=False):
     first = ob * drop if denoise else ob
     x = np.concatenate([first, mask, cohort['time_step'].astype(np.float32), drop], axis=1)
     return x, ob, cohort['lengths'].astype(np.int32)
+
+
+def latent_blobs(seed, N, D, K, centers_seed=None, spread=0.35, noise=0.25):
+    """(N,D) f32 Gaussian-mixture 'latents' with K components; returns (X, component) -- the inputs of the k-means / K-sweep
+    measurements (bench.py cfg5, scripts/).  Same draws as the test suite's generator (oracle/synth.py keeps its own copy: nothing
+    outside tests / the CPU baseline touches oracle/)."""
+    crng = np.random.default_rng(seed if centers_seed is None else centers_seed)
+    cent = crng.normal(0, spread, (K, D)).astype(np.float32)
+    rng = np.random.default_rng([seed, 17])
+    comp = rng.integers(0, K, N)
+    X = (cent[comp] + rng.normal(0, noise, (N, D))).astype(np.float32)
+    return X, comp

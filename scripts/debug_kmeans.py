@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 warnings.filterwarnings('ignore')
 from sklearn.cluster import KMeans as SK
 from deep_interpolation_clustering_amd.kmeans import KMeans
-from oracle.synth import latent_blobs
+from deep_interpolation_clustering_amd.synthetic import latent_blobs
 N, D, K = 20000, 256, 8
 X, _ = latent_blobs(N + K, N, D, max(2, K // 2), spread=0.3, noise=0.3)
 init = X[np.random.default_rng(K).choice(N, K, replace=False)].copy()

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 from deep_interpolation_clustering_amd import _native as N  # noqa: E402
 from deep_interpolation_clustering_amd.kmeans import KMeans, lloyd  # noqa: E402
-from oracle.synth import latent_blobs  # noqa: E402
+from deep_interpolation_clustering_amd.synthetic import latent_blobs  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 75000
 X, _ = latent_blobs(2024, n, 256, 4, spread=0.35, noise=0.3)

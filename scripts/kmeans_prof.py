@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch  # noqa: E402
 
 from deep_interpolation_clustering_amd import _native as N  # noqa: E402
-from oracle.synth import latent_blobs  # noqa: E402
+from deep_interpolation_clustering_amd.synthetic import latent_blobs  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device('cuda', 0)

@@ -3,7 +3,7 @@ gap_b = 10 reference sets, silhouette / Davies-Bouldin / Calinski-Harabasz per K
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
-from oracle.synth import latent_blobs
+from deep_interpolation_clustering_amd.synthetic import latent_blobs
 from deep_interpolation_clustering_amd import p2_clustering_optK as p2
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 75000

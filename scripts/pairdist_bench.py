@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
-from oracle.synth import latent_blobs
+from deep_interpolation_clustering_amd.synthetic import latent_blobs
 from deep_interpolation_clustering_amd import cluster_stats as cs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 75000
 for K in (2, 4, 16):
