@@ -822,6 +822,10 @@ def main():
                 return Stepper(n2, opt_f, args, autocast_dtype=dtype, use_graphs=graphs)
             out['batch256'] = guarded(record_small_batch, lambda g: fresh(torch.bfloat16, g), X, OB, LEN)
             log('batch256 done', out['batch256'])
+            # SURVEY.md 8d's throughput sweep (B = 256, 2 048, 16 384 per GPU; 256 is the record above, the headline is 32 768)
+            out['batch_sweep'] = {str(bs): guarded(record_small_batch, lambda g: fresh(torch.bfloat16, g), X, OB, LEN, bs, st_)
+                                  for bs, st_ in ((2048, 60), (16384, 20))}
+            log('batch sweep done', out['batch_sweep'])
             out['f32'] = guarded(record_f32, lambda: fresh(None, False), X, OB, LEN)
             log('f32 done', out['f32'])
             out['fake_detection_objective'] = guarded(record_fake_detection, K, dev, X, OB, LEN, a.batch)
