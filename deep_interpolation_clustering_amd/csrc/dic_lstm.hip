@@ -37,9 +37,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int V> struct IC { static constexpr int value = V; };      // compile-time index passed through a generic lambda
 
 // (DIC_NT_LOAD / DIC_NT_STORE, dic_common.h: same-box A/B of lstm_bwd8 at B = 32 768 with its saved-state loads and 16-B dG row stores
-// nontemporal: 794 -> 763 us.  Tried and dropped elsewhere -- the forward kernels' 8-B-per-lane saved-state stores: nothing; their `out`
-// stores, 16 B of each of 32 rows per instruction, i.e. partial lines: TWICE as long; the decoder forward's gx LDS-DMA: +6 %; row_proj's x
-// loads (each tile is read by four column stripes): +15 %; fc_bwd, the weight-gradient kernels' DMA: nothing.)
+// nontemporal: 794 -> 763 us; its c_prev and dL/dout loads too: another -1.5 %.  The ENCODER forward (98 % writes) gains 3 % from nontemporal
+// saved-state stores (538 -> 522 us, three alternating same-box runs); the decoder forward does not (772 vs 777 us) and keeps plain stores.
+// Tried and dropped elsewhere -- the forward kernels' `out` stores, 16 B of each of 32 rows per instruction, i.e. partial lines: TWICE as
+// long; the decoder forward's gx LDS-DMA: +6 %; row_proj's x loads (each tile is read by four column stripes): +15 %; fc_bwd, the
+// weight-gradient kernels' DMA: nothing.)
 
 
 #ifdef DIC_LSTM_EXP_NOMATH      // experiment: gate non-linearities replaced by one FMA each (timing only, wrong results)
@@ -538,15 +540,15 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
             if (a.gates) {
                 const int bt = blockIdx.x * LNB + nb;
 #ifndef DIC_LSTM_EXP_RECOMPUTE   // experiment (scripts/lstm_recompute_ab.sh, timing only): the backward recomputes the gates, the forward does not save them
-                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 0, qb + q, hh, r)) = ib;
-                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 1, qb + q, hh, r)) = fb;
-                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 2, qb + q, hh, r)) = gb;
-                *reinterpret_cast<bf16x4*>(a.gates + native_off(t, nbt, bt, dir, wq, 4, 3, qb + q, hh, r)) = ob;
+                DIC_NT_STORE(bf16x4, a.gates + native_off(t, nbt, bt, dir, wq, 4, 0, qb + q, hh, r), ib);
+                DIC_NT_STORE(bf16x4, a.gates + native_off(t, nbt, bt, dir, wq, 4, 1, qb + q, hh, r), fb);
+                DIC_NT_STORE(bf16x4, a.gates + native_off(t, nbt, bt, dir, wq, 4, 2, qb + q, hh, r), gb);
+                DIC_NT_STORE(bf16x4, a.gates + native_off(t, nbt, bt, dir, wq, 4, 3, qb + q, hh, r), ob);
 #endif
                 bf16x4 cb;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cb[j] = (__bf16)cv[j];
-                *reinterpret_cast<bf16x4*>(a.cs + native_off(t, nbt, bt, dir, wq, 1, 0, qb + q, hh, r)) = cb;
+                DIC_NT_STORE(bf16x4, a.cs + native_off(t, nbt, bt, dir, wq, 1, 0, qb + q, hh, r), cb);
             }
             if (ok) {
                 const size_t row = (size_t)t * B + b;
@@ -1138,7 +1140,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd8_kernel(LstmBwdArgs a) {
         d.gb = DIC_NT_LOAD(bf16x4, gbase + (2 * GATE_STRIDE + lane_b));
         d.ob = DIC_NT_LOAD(bf16x4, gbase + (3 * GATE_STRIDE + lane_b));
         bf16x4 cp = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-        if (!first_fwd) cp = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const char*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, 0, 0)) + lane_b);
+        if (!first_fwd) cp = DIC_NT_LOAD(bf16x4, reinterpret_cast<const char*>(a.cs + native_off(tp, nbt, bt, dir, w, 1, 0, q, 0, 0)) + lane_b);
         else if (a.c0) {
             const f32x4 c0v = *reinterpret_cast<const f32x4*>(a.c0 + state_off(a.bm, dir, b, B) + u);
 #pragma unroll
@@ -1157,7 +1159,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd8_kernel(LstmBwdArgs a) {
         bf16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-        if (a.dout) v = *reinterpret_cast<const bf16x8*>(a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + 8 * (lane & 15));
+        if (a.dout) v = DIC_NT_LOAD(bf16x8, a.dout + ((size_t)t * B + b) * 2 * LH + dir * LH + 8 * (lane & 15));
         dstage[nb] = v;
     };
     auto dout_store = [&](auto nbc) {
