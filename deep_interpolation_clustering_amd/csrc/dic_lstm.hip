@@ -493,12 +493,23 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
             }
         }
     };
+    // the step's h rows LDS -> global as whole 256-B pieces, one step late (see lstm_fwd8_gxn_kernel; same-box A/B 501 -> 482 us here)
+    auto store_out_rows = [&](int t_of_rows, int buf) {
+#pragma unroll
+        for (int k = 0; k < LBM * 16 / 512; ++k) {
+            const int i = k * 512 + tid, row = i >> 4, pc = i & 15;
+            if (b0 + row < B)
+                *reinterpret_cast<uint4*>(a.out + ((size_t)t_of_rows * B + b0 + row) * 2 * LH + dir * LH + pc * 8) =
+                    *reinterpret_cast<const uint4*>(&hbuf[buf][row * HSTR + pc * 8]);
+        }
+    };
     for (int step = 0; step < R; ++step) {
         const int t = dir ? R - 1 - step : step;
         const int cur = step & 1;
         f32x16 acc[2][LNB];
         if (xloader && step + 1 < R) xnext = load_x(step + 1);
         if (step > 0) store_relu_rows(dir ? R - step : step - 1, cur);
+        if (step > 0) store_out_rows(dir ? R - step : step - 1, cur);
         const bool last = step == R - 1;
         auto x_part = [&](int nb) {                // G = W_ih . x_t^T (bias included: constant-one input column)
 #pragma unroll
@@ -551,8 +562,6 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
                 DIC_NT_STORE(bf16x4, a.cs + native_off(t, nbt, bt, dir, wq, 1, 0, qb + q, hh, r), cb);
             }
             if (ok) {
-                const size_t row = (size_t)t * B + b;
-                *reinterpret_cast<bf16x4*>(a.out + row * 2 * LH + dir * LH + u) = hb;
                 if (last) {
                     *reinterpret_cast<f32x4*>(a.hn + state_off(a.bm, dir, b, B) + u) = hv;
                     *reinterpret_cast<f32x4*>(a.cn + state_off(a.bm, dir, b, B) + u) = cv;
@@ -575,6 +584,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
         lds_barrier();
     }
     store_relu_rows(dir ? 0 : R - 1, R & 1);
+    store_out_rows(dir ? 0 : R - 1, R & 1);
 }
 
 
@@ -642,11 +652,12 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
         }
     };
     // the pieces of a half have landed once at most the operations issued after them remain in flight: the other half's 4 pieces and one
-    // step's stores of this wave (6 per unit group x 4 groups; the batch is a multiple of 64: no row is masked)
+    // step's stores of this wave (5 saved-state stores per unit group x 4 groups + the 2 row stores of `store_out_rows` at the step's top; the
+    // batch is a multiple of 64: no row is masked)
     auto gxn_landed = [&](bool other_half_behind) {
         if (a.gates && !a.out_relu) {
-            if (other_half_behind) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            if (other_half_behind) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -667,11 +678,22 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
             }
         }
     };
+    // the step's h rows LDS -> global as whole 256-B pieces, one step late (round 2 let every lane store its own 8 bytes: 32 rows x 16 B per
+    // instruction, 1 024 partial-line writes per workgroup and step instead of 128 line-sized ones; same-box A/B 701.7 -> 688.6 us)
+    auto store_out_rows = [&](int t_of_rows, int buf) {
+#pragma unroll
+        for (int k = 0; k < LBM * 16 / 512; ++k) {
+            const int i = k * 512 + tid, row = i >> 4, pc = i & 15;
+            const uint4 v = *reinterpret_cast<const uint4*>(&hbuf[buf][row * HSTR + pc * 8]);
+            *reinterpret_cast<uint4*>(a.out + ((size_t)t_of_rows * B + b0 + row) * 2 * LH + dir * LH + pc * 8) = v;
+        }
+    };
     for (int step = 0; step < R; ++step) {
         const int t = dir ? R - 1 - step : step;
         const int cur = step & 1;
         f32x16 acc[2][LNB];
         if (step > 0) store_relu_rows(dir ? R - step : step - 1, cur);
+        if (step > 0) store_out_rows(dir ? R - step : step - 1, cur);
         const bool last = step == R - 1;
         auto x_part = [&](int nb) {                // accumulators of a half <- its staged pre-activations (exact: 1.0 x bf16 in f32); the region refills
             if (step > 0) gxn_landed(nb == 0 || step + 1 < R);
@@ -728,8 +750,6 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
                 *reinterpret_cast<bf16x4*>(a.cs + native_off(t, nbt, bt, dir, wq, 1, 0, qb + q, hh, r)) = cb;
             }
             if (ok) {
-                const size_t row = (size_t)t * B + b;
-                *reinterpret_cast<bf16x4*>(a.out + row * 2 * LH + dir * LH + u) = hb;
                 if (last) {
                     *reinterpret_cast<f32x4*>(a.hn + state_off(a.bm, dir, b, B) + u) = hv;
                     *reinterpret_cast<f32x4*>(a.cn + state_off(a.bm, dir, b, B) + u) = cv;
@@ -751,6 +771,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
         lds_barrier();
     }
     store_relu_rows(dir ? 0 : R - 1, R & 1);
+    store_out_rows(dir ? 0 : R - 1, R & 1);
 }
 
 
