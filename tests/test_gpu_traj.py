@@ -130,6 +130,84 @@ def test_joint_step_cfg_shape_kmeans_centroids(K, use_lengths):
             np.testing.assert_allclose(np.linalg.norm(got.astype(np.float64)), float(g['sd1n/' + k]), rtol=2e-5, err_msg=k)
 
 
+# ---------------------------------------------------------------------------------------------------------------- joint step, cfg4 shape
+def _wide_net(g, dev):
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    args = trainer_args(loss='ae_mse_kl', cluster_number=16, num_variables=12, num_timestamps=288)
+    net = Net(args, dev).to(dev)
+    net.load_state_dict({k[4:]: torch.tensor(v) for k, v in g.items() if k.startswith('sd0/')}, strict=True)
+    net.train()
+    return args, net
+
+
+@pytest.mark.parametrize('inp', ['padded', 'lengths', 'store'])
+def test_joint_step_wide_shape_K16(inp):
+    """BASELINE configs[3]'s shape: C = 12 (the encoder LSTM takes 3C = 36 features, clustering_interp.py:102-111), T = 288, R = 24,
+    K = 16 -- one joint step against the reference's own (tests/golden/netstep_wide_K16.npz, oracle/make_golden_wide.py): loss / ae_mse /
+    kl at rtol 1e-5 with no floor, argmax of q exact, gradient norm, latents, the state after the step."""
+    from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    g = load('netstep_wide_K16.npz')
+    dev = torch.device('cuda')
+    args, net = _wide_net(g, dev)
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args)
+    x, ob = torch.tensor(g['x'], device=dev), torch.tensor(g['ob'], device=dev)
+    mask = x[:, 12:24].contiguous()
+    if inp == 'store':
+        rb = RaggedBatch(RaggedStore(g['x'], 12, dev), torch.arange(x.shape[0], device=dev))
+        losses, gnorm, z = st.step(rb, None, None)
+    else:
+        losses, gnorm, z = st.step(x, ob, mask, mask.sum(-1).to(torch.int32) if inp == 'lengths' else None)
+    assert float(g['loss_kl']) > 0.02                                   # k-means centroids: KL is well conditioned
+    for k in ('loss', 'ae_mse', 'kl'):
+        np.testing.assert_allclose(float(losses[k]), float(g['loss_' + k]), rtol=1e-5, atol=0, err_msg=k)
+    np.testing.assert_allclose(float(gnorm), float(g['gnorm']), rtol=1e-4)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g['z'], rtol=1e-4, atol=2e-6)
+    q = net.cluster_assignment(z.detach())
+    assert (q.argmax(1).cpu().numpy() == g['q'].argmax(1)).all()
+    for k, v in net.state_dict().items():
+        got = v.detach().cpu().numpy()
+        if 'sd1/' + k in g:
+            ref = g['sd1/' + k]
+            if 'g/' + k in g:
+                live = np.abs(g['g/' + k]) >= 1e-4 * float(g['gnorm'])
+                got, ref = got[live], ref[live]
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5, err_msg=k)
+        elif 'sd1n/' + k in g:
+            np.testing.assert_allclose(np.linalg.norm(got.astype(np.float64)), float(g['sd1n/' + k]), rtol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('B', [64, 4160])
+def test_joint_step_wide_shape_bf16_tracks_f32(B):
+    """The bf16 mode at C = 12: packed 64-wide encoder rows (36 features + the bias column), the fused-projection recurrence and the one-pass
+    weight-gradient kernel at that width (B = 4160: the 64-row kernels, not a multiple of the tile sizes; B = 64: the 32-row ones) -- three
+    steps follow the f32 mode, whose first step is pinned against the reference above."""
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    g = load('netstep_wide_K16.npz')
+    dev = torch.device('cuda')
+    if B == 64:
+        x = torch.tensor(g['x'], device=dev)
+    else:
+        coh = synthetic.make_cohort(B, C=12, T=288, H=24.0, lam=200.0, G=16, seed=45)
+        x = torch.tensor(synthetic.stacked_batch(coh)[0], device=dev)
+    ob, ln = x[:, :12].contiguous(), x[:, 12:24].sum(-1).to(torch.int32)
+    traj = {}
+    for mode in ('bf16', 'f32'):
+        args, net = _wide_net(g, dev)
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16 if mode == 'bf16' else None)
+        out = []
+        for _ in range(3):
+            losses, gnorm, _ = st.step(x, ob, None, ln)
+            out.append([float(losses[k].detach()) for k in ('loss', 'ae_mse', 'kl')] + [float(gnorm)])
+        traj[mode] = np.array(out)
+    np.testing.assert_allclose(traj['bf16'][:, :3], traj['f32'][:, :3], rtol=2e-2)
+    np.testing.assert_allclose(traj['bf16'][:, 3], traj['f32'][:, 3], rtol=5e-2)
+    assert traj['f32'][2, 1] < traj['f32'][0, 1]
+
+
 # ---------------------------------------------------------------------------------------------------------------- p1 trajectory
 @pytest.mark.parametrize('kind', ['device', 'ragged', 'padded', 'host'])
 def test_pretrain_trainer_follows_reference(run_dir, kind, tmp_path):

@@ -217,6 +217,27 @@ def test_net_step_cfg_shape_kmeans_centroids(K):
             np.testing.assert_allclose(np.linalg.norm(v.numpy().astype(np.float64)), float(g['sd1n/' + k]), rtol=1e-5, err_msg=k)
 
 
+def test_net_step_wide_shape_K16():
+    """BASELINE configs[3]'s shape -- C = 12 (encoder input 3C = 36, clustering_interp.py:102-111), T = 288, R = 24, K = 16: one joint
+    step of the reference's Net from a state six optimisation steps away from the initial one, scikit-learn centroids
+    (oracle/make_golden_wide.py)."""
+    g = load('netstep_wide_K16.npz')
+    net = O.OracleNet(12, 24, 24.0, 16, 0.0)
+    net.load_state_dict({k[4:]: torch.tensor(v) for k, v in g.items() if k.startswith('sd0/')}, strict=True)
+    net.train()
+    opt = O.make_optimizer(net)
+    x = T(g['x'])
+    terms, gnorm, z = O.train_step(net, opt, x, T(g['ob']), x[:, 12:24], 10.0, 15.0)
+    assert float(g['loss_kl']) > 0.02
+    for k in ('loss', 'ae_mse', 'kl'):
+        np.testing.assert_allclose(terms[k], float(g['loss_' + k]), rtol=1e-5, atol=0, err_msg=k)
+    np.testing.assert_allclose(gnorm, float(g['gnorm']), rtol=1e-4)
+    np.testing.assert_allclose(z.numpy(), g['z'], rtol=1e-4, atol=1e-6)
+    for k, v in net.state_dict().items():
+        if 'sd1n/' + k in g:
+            np.testing.assert_allclose(np.linalg.norm(v.numpy().astype(np.float64)), float(g['sd1n/' + k]), rtol=1e-5, err_msg=k)
+
+
 def _cohort_batches(tmp_path, cohort='training'):
     """The cfg1 cohort exactly as oracle/make_golden_traj.py wrote it, as stacked (x, ob) batches of 100 in file order."""
     from deep_interpolation_clustering_amd import synthetic
