@@ -149,8 +149,8 @@ class NetBase(nn.Module):
         return hidden.reshape(hidden.size(0), -1) if batch_major else torch.cat([h for h in hidden], dim=-1)
 
     def _packed_path(self, x):
-        """bf16 step on the GPU with 3C < 32 features: the interpolation kernel writes the encoder LSTM's input rows itself."""
-        return 3 * self.num_variables < ops.PACKED_WIDTH and fused_lstm.fused_available(x, self.encoder.lstm)
+        """bf16 step on the GPU with 3C < 64 features: the interpolation kernel writes the encoder LSTM's input rows itself."""
+        return ops.packed_width(3 * self.num_variables) > 0 and fused_lstm.fused_available(x, self.encoder.lstm)
 
     def _interp(self, x, lengths=None, packed=False):
         """Time-major interpolated features: (R,B,3C) f32 (a permuted view of upstream's (B,R,3C)), or the packed (R,B,32) bf16 rows."""

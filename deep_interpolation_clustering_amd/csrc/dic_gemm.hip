@@ -1,0 +1,428 @@
+// Row-streaming MFMA products for the dense layers of the step in the shapes no specialised kernel covers -- and for the f32 step, whose
+// arithmetic is the reference's (clustering_interp.py:14-41: nn.LSTM / nn.Linear in f32, dataloader.py:204):
+//
+//   gemm_nt   Y[m][n] = sum_k act(A[m][k]) W[n][k] (+ bias[n])      M = (time step, encounter) rows in the hundreds of thousands, N, K <= 1024:
+//             the LSTM input projections gx = X.W_ih^T + b, CompressFC's Linear(256,128), and -- with W handed over transposed -- the input
+//             gradients dX = dG.W_ih, dX = dZ.W1
+//   gemm_tn   D[n][k] (+)= sum_m A[m][n] X[m][k]                      the weight gradients dW = dG^T.X: the reduction runs over the rows, the slow
+//             index of both operands -> both MFMA operands leave LDS transposed (ds_read_b64_tr_b16); split over row chunks, f32 partials,
+//             fixed-order f64 second stage (deterministic, like every cross-workgroup reduction of this library)
+//
+// Operand types:  bf16 -> one v_mfma_f32_32x32x16_bf16 per product (the bf16 step's small-batch / odd-shape fallbacks: no library GEMM);
+//                 f32  -> THREE: x = hi + lo with hi = bf16(x), lo = bf16(x - hi) on the way into LDS, x.w ~ hi.hi + lo.hi + hi.lo in
+//                         f32 accumulators ("bf16x3").  The dropped lo.lo term and the rounding of lo are O(2^-17) per product: the joint step's
+//                         losses stay within 1e-6 of the f32 reference (tests/test_gpu_traj.py, oracle emulation in DESIGN.md) at 5x the
+//                         exact-f32 MFMA rate (v_mfma_f32_32x32x2_f32: 157 TF/s peak against 2.5 PF/s / 3).
+// Tiling: 256 threads = 4 waves in 2 x 2, wave tile 64 x 64 (or 64 x 32) = 32x32 blocks; one LDS tile image, the next tile's global loads
+// in flight in registers while the matrix cores work on the current one; 16-B fragment reads at an 80-B row pitch (conflict-free).  Workgroup
+// ids are remapped so that the tiles that share an A row block (gemm_nt) / a row chunk (gemm_tn) sit on one XCD and meet in its L2.
+#include "dic_common.h"
+
+namespace dic {
+
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gbf16x4 __attribute__((ext_vector_type(4)));
+typedef short gs16x4 __attribute__((ext_vector_type(4)));
+typedef short gs16x8 __attribute__((ext_vector_type(8)));
+typedef float gf32x16 __attribute__((ext_vector_type(16)));
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GBM = 128;           // rows of A per workgroup (gemm_nt) / output rows n per workgroup (gemm_tn)
+constexpr int GBK = 32;            // reduction elements per LDS tile = 2 MFMA k-steps
+constexpr int GP = GBK + 8;        // bf16 elements per LDS row of a k-contiguous tile (80 B: conflict-free ds_read_b128)
+
+// 16 consecutive reduction elements of one tile row, as they come out of global memory
+template <typename T> struct Chunk16;
+template <> struct Chunk16<float> { gf32x4 v[4]; };
+template <> struct Chunk16<__bf16> { gbf16x8 v[2]; };
+
+template <typename T> __device__ __forceinline__ void chunk_zero(Chunk16<T>& c);
+template <> __device__ __forceinline__ void chunk_zero<float>(Chunk16<float>& c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.v[i] = gf32x4{0.f, 0.f, 0.f, 0.f};
+}
+template <> __device__ __forceinline__ void chunk_zero<__bf16>(Chunk16<__bf16>& c) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c.v[i][j] = (__bf16)0.f;
+}
+// elements [k0, k0 + 16) of a row whose valid length is `klen` (klen % 4 == 0 for f32, % 8 == 0 for bf16: vector pieces are all-in or all-out)
+__device__ __forceinline__ void chunk_load(Chunk16<float>& c, const float* row, int k0, int klen) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.v[i] = (k0 + 4 * i < klen) ? *reinterpret_cast<const gf32x4*>(row + k0 + 4 * i) : gf32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void chunk_load(Chunk16<__bf16>& c, const __bf16* row, int k0, int klen) {
+    gbf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c.v[i] = (k0 + 8 * i < klen) ? *reinterpret_cast<const gbf16x8*>(row + k0 + 8 * i) : z;
+}
+// -> LDS: hi (and lo) images, 16 elements at `dst`
+__device__ __forceinline__ void chunk_store(const Chunk16<float>& c, __bf16* hi, __bf16* lo, bool relu) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        gbf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = c.v[2 * h + (j >> 2)][j & 3];
+            if (relu) x = fmaxf(x, 0.f);
+            const __bf16 xh = (__bf16)x;
+            vh[j] = xh;
+            vl[j] = (__bf16)(x - (float)xh);
+        }
+        *reinterpret_cast<gbf16x8*>(hi + 8 * h) = vh;
+        *reinterpret_cast<gbf16x8*>(lo + 8 * h) = vl;
+    }
+}
+__device__ __forceinline__ void chunk_store(const Chunk16<__bf16>& c, __bf16* hi, __bf16*, bool relu) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        gbf16x8 v = c.v[h];
+        if (relu) {
+            const gs16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            v = __builtin_bit_cast(gbf16x8, __builtin_elementwise_max(__builtin_bit_cast(gs16x8, v), zero));      // bf16 relu on the int16 images
+        }
+        *reinterpret_cast<gbf16x8*>(hi + 8 * h) = v;
+    }
+}
+
+// the first 8 elements only (gemm_tn's 64-column X tiles: 8 columns per thread)
+__device__ __forceinline__ void chunk_store8(const Chunk16<float>& c, __bf16* hi, __bf16* lo) {
+    gbf16x8 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = c.v[j >> 2][j & 3];
+        const __bf16 xh = (__bf16)x;
+        vh[j] = xh;
+        vl[j] = (__bf16)(x - (float)xh);
+    }
+    *reinterpret_cast<gbf16x8*>(hi) = vh;
+    *reinterpret_cast<gbf16x8*>(lo) = vl;
+}
+__device__ __forceinline__ void chunk_store8(const Chunk16<__bf16>& c, __bf16* hi, __bf16*) { *reinterpret_cast<gbf16x8*>(hi) = c.v[0]; }
+
+template <typename T> struct OutCvt;
+template <> struct OutCvt<float> { __device__ static float of(float v) { return v; } };
+template <> struct OutCvt<__bf16> { __device__ static __bf16 of(float v) { return (__bf16)v; } };
+
+// ------------------------------------------------------------------------------------------------------------------------ gemm_nt
+struct GemmNtArgs {
+    const void* A; long lda;       // (M, K) rows, element stride lda
+    const void* W; long ldw;       // (N, K) rows
+    const float* bias;             // (N) or NULL
+    void* Y; long ldy;             // (M, N)
+    long M; int N, K;
+    int relu_a;                    // the product runs on max(A, 0)
+    int tiles_n;
+};
+
+template <typename TIN, typename TOUT, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs a) {
+    constexpr bool SPLIT = sizeof(TIN) == 4;
+    constexpr int NB = BN / 64;                              // 32-column blocks per wave
+    constexpr int IMG = SPLIT ? 2 : 1;
+    __shared__ __align__(16) __bf16 sa[IMG][GBM * GP];
+    __shared__ __align__(16) __bf16 sw[IMG][BN * GP];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w & 1, wn = w >> 1;
+    const int lt = xcd_remap(blockIdx.x, gridDim.x);        // consecutive logical tiles (the n-tiles of one row block) share an XCD
+    const long m0 = (long)(lt / a.tiles_n) * GBM;
+    const int n0 = (lt % a.tiles_n) * BN;
+    const TIN* A = reinterpret_cast<const TIN*>(a.A);
+    const TIN* W = reinterpret_cast<const TIN*>(a.W);
+    const int lrow = tid >> 1, lk = 16 * (tid & 1);         // this thread's tile row / first reduction element of its 16
+    const TIN* arow = A + (size_t)min(m0 + lrow, a.M - 1) * a.lda;
+    const bool wload = lrow < BN;
+    const bool wvalid = wload && n0 + lrow < a.N;
+    const TIN* wrow = W + (size_t)min(n0 + lrow, a.N - 1) * a.ldw;
+
+    gf32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[mb][nb][k] = 0.f;
+
+    Chunk16<TIN> ca, cw;
+    const int nkt = (a.K + GBK - 1) / GBK;
+    chunk_load(ca, arow, lk, a.K);
+    if (wvalid) chunk_load(cw, wrow, lk, a.K); else chunk_zero(cw);
+    for (int kt = 0; kt < nkt; ++kt) {
+        chunk_store(ca, &sa[0][lrow * GP + lk], &sa[IMG - 1][lrow * GP + lk], a.relu_a != 0);
+        if (wload) chunk_store(cw, &sw[0][lrow * GP + lk], &sw[IMG - 1][lrow * GP + lk], false);
+        __syncthreads();
+        if (kt + 1 < nkt) {                                  // in flight while the matrix cores work on this tile
+            chunk_load(ca, arow, (kt + 1) * GBK + lk, a.K);
+            if (wvalid) chunk_load(cw, wrow, (kt + 1) * GBK + lk, a.K);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GBK / 16; ++ks) {
+            gbf16x8 ah[2], al[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int o = (64 * wm + 32 * mb + r) * GP + ks * 16 + 8 * hh;
+                ah[mb] = *reinterpret_cast<const gbf16x8*>(&sa[0][o]);
+                if (SPLIT) al[mb] = *reinterpret_cast<const gbf16x8*>(&sa[IMG - 1][o]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int o = ((BN / 2) * wn + 32 * nb + r) * GP + ks * 16 + 8 * hh;
+                const gbf16x8 bh = *reinterpret_cast<const gbf16x8*>(&sw[0][o]);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb][nb], 0, 0, 0);
+                if (SPLIT) {
+                    const gbf16x8 bl = *reinterpret_cast<const gbf16x8*>(&sw[IMG - 1][o]);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb][nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // C/D layout of a 32x32 block: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    TOUT* Y = reinterpret_cast<TOUT*>(a.Y);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + (BN / 2) * wn + 32 * nb + r;
+        if (n >= a.N) continue;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const long m = m0 + 64 * wm + 32 * mb + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                if (m < a.M) Y[(size_t)m * a.ldy + n] = OutCvt<TOUT>::of(acc[mb][nb][k] + bv);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------ gemm_tn
+// Tile images hold 32 rows (reduction index m) x 128 / 64 columns, row pitch 256 + 64 / 128 + 64 B: the 4 rows x 64 B a half-wave takes per
+// transposed read (ds_read_b64_tr_b16) fall on disjoint 16-bank groups (pitch = 64 B mod 256 B).
+constexpr int TROWS = 32;
+struct GemmTnArgs {
+    const void* A; long lda;       // (M, N) rows
+    const void* X; long ldx;       // (M, K) rows
+    float* part;                   // (S, N, K) partial sums
+    long M; int N, K;
+    long rows_per_chunk;           // multiple of TROWS
+    int tiles_n, tiles_k;
+};
+
+__device__ __forceinline__ gs16x4 glds_tr16(const __bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs16x4*)(p));
+}
+
+template <typename TIN, int BKO>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
+    constexpr bool SPLIT = sizeof(TIN) == 4;
+    constexpr int IMG = SPLIT ? 2 : 1;
+    constexpr int PA = 128 + 32, PX = BKO + 32;              // row pitches in bf16 elements (320 B / 320 or 192 B)
+    constexpr int NBK = BKO / 64;                            // 32-column blocks of X per wave
+    __shared__ __align__(16) __bf16 sa[IMG][TROWS * PA];
+    __shared__ __align__(16) __bf16 sx[IMG][TROWS * PX];
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wn = w & 1, wk = w >> 1;
+    const int lt = xcd_remap(blockIdx.x, gridDim.x);        // consecutive logical ids = the output tiles of one row chunk: one XCD
+    const int ntile = a.tiles_n * a.tiles_k;
+    const int s = lt / ntile, ot = lt % ntile;
+    const int n0 = (ot / a.tiles_k) * 128, k0 = (ot % a.tiles_k) * BKO;
+    const long mbeg = (long)s * a.rows_per_chunk, mend = min(a.M, mbeg + a.rows_per_chunk);
+    const TIN* A = reinterpret_cast<const TIN*>(a.A);
+    const TIN* X = reinterpret_cast<const TIN*>(a.X);
+    // loads: row = tid >> 3 of the 32; A: 16 columns [16 seg, +16); X: BKO / 8 columns
+    const int lrow = tid >> 3, seg = tid & 7;
+    constexpr int XC = BKO / 8;                              // 16 or 8 columns of X per thread
+    const int nvalid_a = a.N - n0, kvalid = a.K - k0;        // valid columns of this tile (vector pieces all-in or all-out)
+
+    gf32x16 acc[2][NBK];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[nb][kb][k] = 0.f;
+
+    Chunk16<TIN> ca, cx;
+    auto load = [&](long m) {
+        const long row = m + lrow;
+        if (row < mend) {
+            chunk_load(ca, A + (size_t)row * a.lda + n0, 16 * seg, nvalid_a);
+            if (XC == 16) chunk_load(cx, X + (size_t)row * a.ldx + k0, 16 * seg, kvalid);
+            else chunk_load(cx, X + (size_t)row * a.ldx + k0, 8 * seg, min(kvalid, 8 * seg + 8));      // 8 columns: the second half stays zero
+        } else {
+            chunk_zero(ca);
+            chunk_zero(cx);
+        }
+    };
+    // transposed-read addressing: within each 16-lane group lane 4q+p supplies row q, columns 4p..4p+3 of a 4-row x 16-column block and
+    // lane i receives column i of those rows; the 32x32x16 operand of lane l is column (l & 31), rows 8 (l >> 5) + 0..7 of the k-step
+    const int kq = (lane & 15) >> 2, kp = lane & 3, cb = (lane >> 4) & 1;
+    const int rowoff = 8 * hh + kq;
+    auto frag = [&](const __bf16* img, int pitch, int col0, int ks) {
+        const __bf16* p = img + (ks * 16 + rowoff) * pitch + col0 + 16 * cb + 4 * kp;
+        const gs16x4 lo = glds_tr16(p), hi = glds_tr16(p + 4 * pitch);
+        gs16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+        return __builtin_bit_cast(gbf16x8, f);
+    };
+    if (mbeg < mend) load(mbeg);
+    for (long m = mbeg; m < mend; m += TROWS) {
+        chunk_store(ca, &sa[0][lrow * PA + 16 * seg], &sa[IMG - 1][lrow * PA + 16 * seg], false);
+        if (XC == 16) {
+            chunk_store(cx, &sx[0][lrow * PX + 16 * seg], &sx[IMG - 1][lrow * PX + 16 * seg], false);
+        } else {                                             // 8 columns per thread: the first half of the chunk
+            chunk_store8(cx, &sx[0][lrow * PX + 8 * seg], &sx[IMG - 1][lrow * PX + 8 * seg]);
+        }
+        __syncthreads();
+        if (m + TROWS < mend) load(m + TROWS);
+#pragma unroll
+        for (int ks = 0; ks < TROWS / 16; ++ks) {
+            gbf16x8 ah[2], al[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                ah[nb] = frag(sa[0], PA, 64 * wn + 32 * nb, ks);
+                if (SPLIT) al[nb] = frag(sa[IMG - 1], PA, 64 * wn + 32 * nb, ks);
+            }
+#pragma unroll
+            for (int kb = 0; kb < NBK; ++kb) {
+                const gbf16x8 bh = frag(sx[0], PX, (BKO / 2) * wk + 32 * kb, ks);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[nb], bh, acc[nb][kb], 0, 0, 0);
+                if (SPLIT) {
+                    const gbf16x8 bl = frag(sx[IMG - 1], PX, (BKO / 2) * wk + 32 * kb, ks);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[nb], bh, acc[nb][kb], 0, 0, 0);
+                        acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[nb], bl, acc[nb][kb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D block: rows = output row n (the A operand's columns), columns = output column k: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 hh
+    float* o = a.part + (size_t)s * a.N * a.K;
+#pragma unroll
+    for (int kb = 0; kb < NBK; ++kb) {
+        const int k = k0 + (BKO / 2) * wk + 32 * kb + (lane & 31);
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + 64 * wn + 32 * nb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (n < a.N) o[(size_t)n * a.K + k] = acc[nb][kb][e];
+            }
+    }
+}
+
+// D[n][k] (+)= sum over the S chunks, fixed order, f64; k < kcols only (the padding columns of a packed operand are dropped)
+__global__ __launch_bounds__(256) void gemm_tn_finalize(const float* part, int S, int N, int K, float* D, long ldd, int kcols, float beta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * K) return;
+    const int n = i / K, k = i - n * K;
+    if (k >= kcols) return;
+    double ch[4] = {0.0, 0.0, 0.0, 0.0};
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = part[(size_t)(s + j) * N * K + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ch[j] += (double)v[j];
+    }
+    for (; s < S; ++s) ch[0] += (double)part[(size_t)s * N * K + i];
+    const float r = (float)((ch[0] + ch[1]) + (ch[2] + ch[3]));
+    float* dst = D + (size_t)n * ldd + k;
+    *dst = beta != 0.f ? fmaf(beta, *dst, r) : r;
+}
+
+static int tn_chunks(long M, int N, int K, long* rows_per_chunk, int* bko) {
+    *bko = K > 64 ? 128 : 64;
+    const int tiles = ((N + 127) / 128) * ((K + *bko - 1) / *bko);
+    const long row_tiles = (M + TROWS - 1) / TROWS;
+    long S = max(1L, min(row_tiles, (long)(4 * kNumCU + tiles - 1) / tiles));        // ~4 workgroups per CU
+    S = min(S, 256L);
+    long rpc = (row_tiles + S - 1) / S * TROWS;
+    *rows_per_chunk = rpc;
+    return (int)((M + rpc - 1) / rpc);
+}
+
+}  // namespace dic
+
+using namespace dic;
+
+extern "C" {
+
+int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void* W, long ldw, const float* bias, long M, int N, int K,
+                void* Y, long ldy, int relu_a, dic_stream_t stream) {
+    DIC_REQUIRE(in_dtype == DIC_DTYPE_F32 || in_dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "gemm_nt: input dtype %d", in_dtype);
+    DIC_REQUIRE(out_dtype == DIC_DTYPE_F32 || out_dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "gemm_nt: output dtype %d", out_dtype);
+    DIC_REQUIRE(A && W && Y, DIC_ERR_INVALID_ARG, "gemm_nt: NULL pointer");
+    DIC_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, DIC_ERR_INVALID_ARG, "gemm_nt: M=%ld N=%d K=%d lda=%ld ldw=%ld ldy=%ld", M, N, K, lda, ldw, ldy);
+    const int vec = in_dtype == DIC_DTYPE_F32 ? 4 : 8;       // 16-B vector loads
+    DIC_REQUIRE(K % vec == 0 && lda % vec == 0 && ldw % vec == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, DIC_ERR_UNSUPPORTED,
+                "gemm_nt: K, lda, ldw must be multiples of %d elements and the operands 16-B aligned (K=%d lda=%ld ldw=%ld): pad the rows", vec, K, lda, ldw);
+    const int bn = N > 64 ? 128 : 64;
+    GemmNtArgs a{A, lda, W, ldw, bias, Y, ldy, M, N, K, relu_a, (N + bn - 1) / bn};
+    const long tiles = ((M + GBM - 1) / GBM) * a.tiles_n;
+    DIC_REQUIRE(tiles < (1L << 31), DIC_ERR_UNSUPPORTED, "gemm_nt: %ld tiles", tiles);
+    const dim3 grid((unsigned)tiles), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bool f32in = in_dtype == DIC_DTYPE_F32, f32out = out_dtype == DIC_DTYPE_F32;
+#define DIC_NT(TI, TO, BN) hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, BN>), grid, blk, 0, st, a)
+    if (bn == 128) {
+        if (f32in) { if (f32out) DIC_NT(float, float, 128); else DIC_NT(float, __bf16, 128); }
+        else { if (f32out) DIC_NT(__bf16, float, 128); else DIC_NT(__bf16, __bf16, 128); }
+    } else {
+        if (f32in) { if (f32out) DIC_NT(float, float, 64); else DIC_NT(float, __bf16, 64); }
+        else { if (f32out) DIC_NT(__bf16, float, 64); else DIC_NT(__bf16, __bf16, 64); }
+    }
+#undef DIC_NT
+    return check_launch("gemm_nt");
+}
+
+size_t dic_gemm_tn_workspace(long M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    long rpc; int bko;
+    const int S = tn_chunks(M, N, K, &rpc, &bko);
+    return (size_t)S * N * K * sizeof(float);
+}
+
+int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
+                int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(in_dtype == DIC_DTYPE_F32 || in_dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "gemm_tn: input dtype %d", in_dtype);
+    DIC_REQUIRE(A && X && D && workspace, DIC_ERR_INVALID_ARG, "gemm_tn: NULL pointer");
+    DIC_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= N && ldx >= K && kcols > 0 && kcols <= K && ldd >= kcols, DIC_ERR_INVALID_ARG,
+                "gemm_tn: M=%ld N=%d K=%d lda=%ld ldx=%ld ldd=%ld kcols=%d", M, N, K, lda, ldx, ldd, kcols);
+    const int vec = in_dtype == DIC_DTYPE_F32 ? 4 : 8;
+    DIC_REQUIRE(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldx % vec == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)X & 15) == 0, DIC_ERR_UNSUPPORTED,
+                "gemm_tn: N, K, lda, ldx must be multiples of %d elements and the operands 16-B aligned (N=%d K=%d lda=%ld ldx=%ld): pad the rows", vec, N, K, lda, ldx);
+    long rpc; int bko;
+    const int S = tn_chunks(M, N, K, &rpc, &bko);
+    DIC_REQUIRE(workspace_bytes >= (size_t)S * N * K * sizeof(float), DIC_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", workspace_bytes,
+                (size_t)S * N * K * sizeof(float));
+    GemmTnArgs a{A, lda, X, ldx, (float*)workspace, M, N, K, rpc, (N + 127) / 128, (K + bko - 1) / bko};
+    const dim3 grid((unsigned)(S * a.tiles_n * a.tiles_k)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (in_dtype == DIC_DTYPE_F32) {
+        if (bko == 128) hipLaunchKernelGGL((gemm_tn_kernel<float, 128>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((gemm_tn_kernel<float, 64>), grid, blk, 0, st, a);
+    } else {
+        if (bko == 128) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, 128>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((gemm_tn_kernel<__bf16, 64>), grid, blk, 0, st, a);
+    }
+    hipLaunchKernelGGL(gemm_tn_finalize, dim3((N * K + 255) / 256), dim3(256), 0, st, (const float*)workspace, S, N, K, D, ldd, kcols,
+                       accumulate ? 1.0f : 0.0f);
+    return check_launch("gemm_tn");
+}
+
+}  // extern "C"

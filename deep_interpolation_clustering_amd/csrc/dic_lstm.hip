@@ -424,18 +424,22 @@ __global__ __launch_bounds__(256, LNB == 1 ? 2 : 1) void lstm_fwd_kernel(LstmFwd
 // 8 + k the second gate of the same unit -- the four gates of a unit still meet in one lane, and the unit <-> (lane, register) map
 // is the one of the 4-wave kernel (its wave w / 2, unit group 2 (w & 1) + q), so the saved gates / cell states land where lstm_bwd
 // expects them and every number is bit-identical (same MFMA k order).
+// XK = packed input width: 32 (3C < 32: the reference's six vitals) or 64 (3C < 64: BASELINE configs[3]'s twelve channels, 36 features + bias).
+template <int XK>
 __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
     static_assert(LNB == 2, "two 32-row halves per workgroup");
+    static_assert(XK == 32 || XK == 64, "packed input rows are 32 or 64 wide");
+    constexpr int XS = XK + 8;                // bf16 elements per LDS row of the x tile (80 / 144 B: conflict-free ds_read_b128)
     extern __shared__ __align__(16) __bf16 fsm[];
     __bf16 (*hbuf)[LBM * HSTR] = reinterpret_cast<__bf16 (*)[LBM * HSTR]>(fsm);      // [2][LBM*HSTR]
-    __bf16* gst = fsm + 2 * LBM * HSTR;                                               // [2][LBM][XSTR] x tiles
+    __bf16* gst = fsm + 2 * LBM * HSTR;                                               // [2][LBM][XS] x tiles
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                           // 0..7
     const int dir = blockIdx.y, b0 = blockIdx.x * LBM, B = a.B, R = a.R;
     const int nbt = gridDim.x * LNB;
     const int wq = w >> 1, qb = 2 * (w & 1);              // wave / first unit group of the 4-wave kernel's layout these 16 units belong to
 
-    bf16x8 wf[2][8], wx[2][LXK / 16];
+    bf16x8 wf[2][8], wx[2][XK / 16];
     {
         const int grow = (dir * 4 + (r >> 4)) * LH + 16 * w + (r & 15);               // block 0: gates 0 / 1 (rows 0-15 / 16-31); block 1: + 2 gates
 #pragma unroll
@@ -444,8 +448,8 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
             for (int ks = 0; ks < 8; ++ks)
                 wf[bk][ks] = *reinterpret_cast<const bf16x8*>(a.whh + ((size_t)grow + 2 * bk * LH) * LH + ks * 16 + 8 * hh);
 #pragma unroll
-            for (int ks = 0; ks < LXK / 16; ++ks)
-                wx[bk][ks] = *reinterpret_cast<const bf16x8*>(a.wih + ((size_t)grow + 2 * bk * LH) * LXK + ks * 16 + 8 * hh);
+            for (int ks = 0; ks < XK / 16; ++ks)
+                wx[bk][ks] = *reinterpret_cast<const bf16x8*>(a.wih + ((size_t)grow + 2 * bk * LH) * XK + ks * 16 + 8 * hh);
         }
     }
     // lane owns batch row (nb*32 + r) and hidden units 16 w + 8 q + 4 hh + {0..3}, q = 0..1: element 4 q + j
@@ -471,14 +475,15 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
             }
         }
     }
-    const bool xloader = tid < 256;                       // 64 rows x 4 pieces of 16 B
-    const int xrow = (tid & 255) >> 2, xpc = tid & 3;
+    constexpr int XPC = XK / 8;                           // 16-B pieces per row: 64 rows x 4 (first 256 threads) or x 8 (all 512)
+    const bool xloader = tid < LBM * XPC;
+    const int xrow = (tid & (LBM * XPC - 1)) / XPC, xpc = tid & (XPC - 1);
     auto load_x = [&](int step) {
         const int t = dir ? R - 1 - step : step;
-        return *reinterpret_cast<const bf16x8*>(a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * LXK + xpc * 8);
+        return *reinterpret_cast<const bf16x8*>(a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * XK + xpc * 8);
     };
     bf16x8 xnext = {};
-    if (xloader) *reinterpret_cast<bf16x8*>(gst + xrow * XSTR + xpc * 8) = load_x(0);
+    if (xloader) *reinterpret_cast<bf16x8*>(gst + xrow * XS + xpc * 8) = load_x(0);
     __syncthreads();
     auto store_relu_rows = [&](int t_of_rows, int buf) {
         if (!a.out_relu) return;
@@ -517,8 +522,8 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[bk][nb][k] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < LXK / 16; ++ks) {
-                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(gst + cur * LBM * XSTR + (nb * 32 + r) * XSTR + ks * 16 + 8 * hh);
+            for (int ks = 0; ks < XK / 16; ++ks) {
+                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(gst + cur * LBM * XS + (nb * 32 + r) * XS + ks * 16 + 8 * hh);
 #pragma unroll
                 for (int bk = 0; bk < 2; ++bk) acc[bk][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[bk][ks], xb, acc[bk][nb], 0, 0, 0);
             }
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) gate_math(1, q);
-        if (xloader && step + 1 < R) *reinterpret_cast<bf16x8*>(gst + (cur ^ 1) * LBM * XSTR + xrow * XSTR + xpc * 8) = xnext;
+        if (xloader && step + 1 < R) *reinterpret_cast<bf16x8*>(gst + (cur ^ 1) * LBM * XS + xrow * XS + xpc * 8) = xnext;
         lds_barrier();
     }
     store_relu_rows(dir ? 0 : R - 1, R & 1);
@@ -1404,19 +1409,23 @@ int dic_lstm_fwd_proj(const void* x, const void* wih, const void* whh, const flo
                       int eight_waves, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: non-positive size");
     DIC_REQUIRE(H == LH, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: hidden size %d (compiled for %d)", H, LH);
-    DIC_REQUIRE(I == LXK, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: input width %d (compiled for %d: zero-pad narrower inputs)", I, LXK);
+    DIC_REQUIRE(I == LXK || I == 64, DIC_ERR_UNSUPPORTED, "lstm_fwd_proj: input width %d (compiled for %d and 64: zero-pad narrower inputs)", I, LXK);
+    if (I == 64) eight_waves = 1;                  // (the 64-wide rows exist in the eight-wave kernel only)
     DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd_proj: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd_proj: gates and cs go together");
     LstmFwdArgs a{nullptr, (const __bf16*)x, (const __bf16*)wih, (const __bf16*)whh, h0, c0, (__bf16*)out, (__bf16*)out_relu, hn, cn, (__bf16*)gates, (__bf16*)cs, R, B, state_batch_major != 0, write_boundary != 0};
     if (eight_waves) {
-        const size_t lds = (size_t)(2 * LBM * HSTR + 2 * LBM * XSTR) * sizeof(__bf16);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd8_proj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int wide = I == 64;
+        const size_t lds = (size_t)(2 * LBM * HSTR + 2 * LBM * (I + 8)) * sizeof(__bf16);
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[wide]) {
+            hipError_t e = hipFuncSetAttribute(wide ? (const void*)lstm_fwd8_proj_kernel<64> : (const void*)lstm_fwd8_proj_kernel<32>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd_proj: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-            attr_set = true;
+            attr_set[wide] = true;
         }
-        hipLaunchKernelGGL(lstm_fwd8_proj_kernel, dim3((B + LBM - 1) / LBM, 2), dim3(512), lds, (hipStream_t)stream, a);
+        if (wide) hipLaunchKernelGGL(lstm_fwd8_proj_kernel<64>, dim3((B + LBM - 1) / LBM, 2), dim3(512), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(lstm_fwd8_proj_kernel<32>, dim3((B + LBM - 1) / LBM, 2), dim3(512), lds, (hipStream_t)stream, a);
         return check_launch("lstm_fwd_proj");
     }
     return lstm_fwd_launch(FWD_PROJ, a, (hipStream_t)stream);

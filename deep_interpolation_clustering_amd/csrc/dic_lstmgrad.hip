@@ -19,7 +19,6 @@ namespace dic {
 constexpr int GH = 128;            // hidden size
 constexpr int G4 = 4 * GH;         // gate rows per direction
 constexpr int XW = 32;             // packed encoder input width (MFMA k-step multiple; column I carries the constant one)
-constexpr int NW = GH + XW;        // B-operand columns of the fused product: [h_prev | x]
 constexpr int TR = 32;             // (t, b) rows per tile = 2 MFMA k-steps
 constexpr int NBUF = 3;            // LDS ring: one tile being read, two in flight
 // LDS image of a tile.  A transposed read (ds_read_b64_tr_b16) takes 4 rows x 64 contiguous bytes per 32-lane half:
@@ -41,7 +40,6 @@ constexpr int WT_COLS = 19, WT_PITCH = 2 * G4 + 16;  // 1040 B rows: 16 lanes x 
 constexpr int LDS_WT = WT_COLS * WT_PITCH;           // 19 760 B
 constexpr int LDS_RED = 2 * 4 * 1024;                // two parities x four 1-KiB partial tiles (k-halves are summed across wave pairs)
 constexpr int DW_LDS = NBUF * SLOT + LDS_WT + LDS_RED;   // 163 120 B of the CU's 163 840: one workgroup per CU
-constexpr int DW_OUT = 2 * G4 * NW;                 // outputs per partial: [dir][gate row][h cols | x cols]
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -123,7 +121,17 @@ __device__ __forceinline__ void dma4(const void* sbase, unsigned voff, unsigned 
 // buffer.  Every byte comes in by LDS-DMA into a ring of three tile images; per tile ONE raw s_barrier and a COUNTED
 // s_waitcnt vmcnt, so two tiles (90 KB per CU) stay in flight across the barrier while the matrix cores work on the third
 // (a __syncthreads() here drains the DMA queue: measured 0.55 ms instead of the 0.4 ms HBM floor).
+// XWT = packed input width: 32 (3C < 32, the reference's six vitals: 5 n-blocks, the input gradient dX rides along) or 64 (3C < 64,
+// BASELINE configs[3]'s twelve channels: 6 n-blocks = 192 accumulator registers like lstm_dw_wide's waves, x rows of 128 B with their 64-B
+// halves XOR-swizzled by (row >> 1) & 1 through the DMA source addresses so that the 4 rows of a transposed read stay on disjoint
+// bank groups; no fused dX -- its W_ih^T image does not fit next to the three tile slots -- dic_gemm_nt forms it)
+template <int XWT>
 __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
+    static_assert(XWT == 32 || XWT == 64, "packed input rows are 32 or 64 wide");
+    constexpr int NBX = XWT / 32, NBN = 4 + NBX;          // n-blocks of x / in total
+    constexpr int NWT = GH + XWT;                          // output columns [h_prev | x]
+    constexpr int XP = 2 * XWT, L_X = TR * XP;             // x row pitch / tile bytes
+    constexpr int SLOTT = LDS_DG + LDS_H + L_X;
     extern __shared__ __align__(16) unsigned char dwsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,11 +140,11 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
     const int ntiles = (int)((nrows + TR - 1) / TR), nch = gridDim.x;
     const __bf16* hsrc = a.hext + (dir ? (size_t)2 * a.B * 2 * GH + GH : 0);        // row i of this view = h_prev of row i
 
-    f32x16 acc[2][5];
+    f32x16 acc[2][NBN];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 5; ++nb)
+        for (int nb = 0; nb < NBN; ++nb)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[mb][nb][k] = 0.f;
 
@@ -145,10 +153,13 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)dwsm);
     const unsigned v_dg = lane * 16;                                                     // per-lane byte offsets of the three streams
     const unsigned v_h = (lane >> 4) * (2 * GH * 2) + (((lane & 15) ^ ((lane >> 4) << 2)) * 16);
+    // x: 64-B rows, four per 4-B-per-lane instruction as they lie; 128-B rows, two per instruction, half j of row r stored at j ^ ((r >> 1) & 1)
     const unsigned v_x = lane * 4;
+    const unsigned v_x64[2] = {(unsigned)((lane >> 5) * 128 + (((lane >> 4) & 1) * 64) + (lane & 15) * 4),
+                               (unsigned)((lane >> 5) * 128 + ((((lane >> 4) & 1) ^ 1) * 64) + (lane & 15) * 4)};
     auto request = [&](int tile, int slot) {
         const long r0 = min((long)tile * TR, nrows - TR);
-        const unsigned base = lds0 + slot * SLOT;
+        const unsigned base = lds0 + slot * SLOTT;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {              // dG: one row (1 KiB of this direction) per instruction
             const int row = p * 8 + w;
@@ -157,7 +168,13 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
         // h: four 256-B rows per instruction, 16-B pieces XOR-swizzled through the source address
         dma16(hsrc + (size_t)(r0 + w * 4) * 2 * GH, v_h, base + LDS_DG + w * 4 * H_PITCH);
         // x: four 64-B rows per 4-B-per-lane instruction (every wave issues the same number of instructions: one counted wait fits all)
-        dma4(a.x + (size_t)r0 * XW + w * 128, v_x, base + LDS_DG + LDS_H + w * 256);
+        if constexpr (XWT == 32) {
+            dma4(a.x + (size_t)r0 * XWT + w * 128, v_x, base + LDS_DG + LDS_H + w * 256);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)            // rows 4 w + 2 i + {0, 1}: (row >> 1) & 1 == i
+                dma4(a.x + (size_t)(r0 + 4 * w + 2 * i) * XWT, v_x64[i], base + LDS_DG + LDS_H + (4 * w + 2 * i) * XP);
+        }
     };
 
     // transposed-read addressing (ds_read_b64_tr_b16): within each 16-lane group, lane 4q+p supplies row q, columns 4p..4p+3 of a
@@ -166,7 +183,10 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
     const int kq = (lane & 15) >> 2, kp = lane & 3, cb = (lane >> 4) & 1, hh = lane >> 5;
     const int rowoff = 8 * hh + kq;                                    // (rowoff & 3) == kq for both reads (+4 rows)
     const int pa_off = rowoff * DG_PITCH + (64 * w + 16 * cb + 4 * kp) * 2;
-    const int px_off = LDS_DG + LDS_H + rowoff * X_PITCH + (16 * cb + 4 * kp) * 2;
+    int px_off[NBX];
+#pragma unroll
+    for (int nbx = 0; nbx < NBX; ++nbx)
+        px_off[nbx] = LDS_DG + LDS_H + rowoff * XP + (XWT == 64 ? ((nbx ^ ((rowoff >> 1) & 1)) * 64) : 0) + (16 * cb + 4 * kp) * 2;
     int ph_off[4];                                                      // 16-B piece (4 nb + 2 cb + (kp >> 1)) ^ (kq << 2), 8-B half kp & 1
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) ph_off[nb] = LDS_DG + rowoff * H_PITCH + (((4 * nb + 2 * cb + (kp >> 1)) ^ (kq << 2)) * 16) + (kp & 1) * 8;
@@ -180,13 +200,13 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
 
     // ---- dX: this direction's W_ih^T -> LDS once; per tile, wave w multiplies quadrant (rows 16 (q >> 1).., input columns 16 (q & 1)..),
     // q = w & 3, over half of the 512 gate columns (w >> 2); the two halves meet through LDS one tile later (no extra barrier)
-    unsigned char* wt = dwsm + NBUF * SLOT;
+    unsigned char* wt = dwsm + NBUF * SLOTT;
     float* red = reinterpret_cast<float*>(wt + LDS_WT);
-    const bool want_dx = a.wih != nullptr;
+    const bool want_dx = XWT == 32 && a.wih != nullptr;
     if (want_dx) {
         for (int i = tid; i < WT_COLS * G4; i += 512) {
             const int xc = i / G4, k = i - xc * G4;
-            *reinterpret_cast<__bf16*>(wt + xc * WT_PITCH + k * 2) = a.wih[((size_t)dir * G4 + k) * XW + xc];
+            *reinterpret_cast<__bf16*>(wt + xc * WT_PITCH + k * 2) = a.wih[((size_t)dir * G4 + k) * XWT + xc];
         }
     }
     const int q4 = w & 3, rw = q4 >> 1, xcb = q4 & 1, khalf = w >> 2, li = lane & 15, kq4 = lane >> 4;
@@ -198,9 +218,9 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
     auto finish_dx = [&](int par, long r0p) {          // waves 0-3: add the other k-half (parked in LDS by waves 4-7), round, store the 16x16 tile
         if (want_dx && khalf == 0 && r0p >= 0) {
             const f32x4_t o = *reinterpret_cast<const f32x4_t*>(red + (par * 4 + q4) * 256 + lane * 4);
-            __bf16* dst = a.dxp + ((size_t)dir * nrows + r0p + 16 * rw + 4 * kq4) * XW + 16 * xcb + li;
+            __bf16* dst = a.dxp + ((size_t)dir * nrows + r0p + 16 * rw + 4 * kq4) * XWT + 16 * xcb + li;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[(size_t)e * XW] = (__bf16)(o[e] + own_prev[e]);
+            for (int e = 0; e < 4; ++e) dst[(size_t)e * XWT] = (__bf16)(o[e] + own_prev[e]);
         }
     };
 
@@ -210,15 +230,19 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
     for (; tile < ntiles; tile += nch) {
         // this wave's DMA of the current tile has landed once at most the next tile's instructions are outstanding
         // (the dX stores of waves 0-3 are ordinary global stores issued after the DMAs they must not be confused with: up to 4 per tile)
-        if (tile + nch < ntiles) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");       // 6 = LDS-DMA instructions per wave and tile: 4 dG + 1 h + 1 x
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (tile + nch < ntiles) {                 // 6 / 7 = LDS-DMA instructions per wave and tile: 4 dG + 1 h + 1 / 2 x
+            if constexpr (XWT == 32) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();              // ... and every other wave's; all waves are done reading the slot refilled next
         finish_dx(parity ^ 1, prev_r0);            // the previous tile's input gradients (its partials were parked before this barrier)
         if (tile + 2 * nch < ntiles) request(tile + 2 * nch, slot == 0 ? 2 : slot - 1);
-        unsigned char* base = dwsm + slot * SLOT;
+        unsigned char* base = dwsm + slot * SLOTT;
         if ((long)tile * TR + TR > nrows) {        // the shifted last tile: its first rows were summed by the previous tile already
             const int dup = (int)((long)tile * TR + TR - nrows);
-            for (int i = tid; i < dup * (H_PITCH + X_PITCH) / 16; i += 512) {
+            for (int i = tid; i < dup * (H_PITCH + XP) / 16; i += 512) {
                 const int nh = dup * H_PITCH / 16;
                 unsigned char* dst = i < nh ? base + LDS_DG + i * 16 : base + LDS_DG + LDS_H + (i - nh) * 16;
                 *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
@@ -233,9 +257,9 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) af[mb] = frag(kb + pa_off + mb * 64, DG_PITCH);
 #pragma unroll
-            for (int nb = 0; nb < 5; ++nb) {
+            for (int nb = 0; nb < NBN; ++nb) {
                 const bf16x8 bfg = nb < 4 ? frag(base + ks * 16 * H_PITCH + ph_off[nb < 4 ? nb : 0], H_PITCH)
-                                          : frag(base + ks * 16 * X_PITCH + px_off, X_PITCH);
+                                          : frag(base + ks * 16 * XP + px_off[nb < 4 ? 0 : nb - 4], XP);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfg, acc[mb][nb], 0, 0, 0);
             }
@@ -261,15 +285,15 @@ __global__ __launch_bounds__(512) void lstm_dw_kernel(DwArgs a) {
         finish_dx(parity ^ 1, prev_r0);
     }
     // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    float* o = a.partials + ((size_t)blockIdx.x * 2 + dir) * G4 * NW;
+    float* o = a.partials + ((size_t)blockIdx.x * 2 + dir) * G4 * NWT;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 5; ++nb)
+        for (int nb = 0; nb < NBN; ++nb)
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int m = 64 * w + 32 * mb + (k & 3) + 8 * (k >> 2) + 4 * hh;
-                o[(size_t)m * NW + 32 * nb + (lane & 31)] = acc[mb][nb][k];
+                o[(size_t)m * NWT + 32 * nb + (lane & 31)] = acc[mb][nb][k];
             }
 }
 
@@ -465,12 +489,13 @@ static int dw_wide_chunks(int R, int B) {
 // out_i = sum over workgroups of partial_i (fixed order, f64), scattered into the nn.LSTM gradients: h columns -> weight_hh,
 // x columns [0, I) -> weight_ih (column I of the packed input is the constant one: its sum is the bias gradient, which the
 // recurrence backward already delivers in f32).  beta = 0 overwrites, 1 accumulates.
-__global__ __launch_bounds__(256) void lstm_dw_finalize(const float* partials, int nch, int I, LstmGrads g, float beta) {
+__global__ __launch_bounds__(256) void lstm_dw_finalize(const float* partials, int nch, int I, int nw, LstmGrads g, float beta) {
     __shared__ double red[256];
-    const double s = reduce_partials_32x8(partials, nch, DW_OUT, blockIdx.x * 32, red);
+    const int n_out = 2 * G4 * nw;
+    const double s = reduce_partials_32x8(partials, nch, n_out, blockIdx.x * 32, red);
     const int i = blockIdx.x * 32 + threadIdx.x;
-    if (threadIdx.x >= 32 || i >= DW_OUT) return;
-    const int d = i / (G4 * NW), rem = i - d * (G4 * NW), m = rem / NW, n = rem - m * NW;
+    if (threadIdx.x >= 32 || i >= n_out) return;
+    const int d = i / (G4 * nw), rem = i - d * (G4 * nw), m = rem / nw, n = rem - m * nw;
     float* dst;
     if (n < GH) dst = g.w_hh[d] + (size_t)m * GH + n;
     else if (n - GH < I) dst = g.w_ih[d] + (size_t)m * I + (n - GH);
@@ -547,36 +572,39 @@ static int grads_from(float* const* grads, LstmGrads* g, bool need_w, bool need_
     return DIC_OK;
 }
 
-size_t dic_lstm_dw_workspace(int R, int B) {
+size_t dic_lstm_dw_workspace(int R, int B) {        // (sized for the 64-wide packed rows: 2 x 4H x (H + 64) sums per workgroup)
     if (R <= 0 || B <= 0) return 0;
-    return (size_t)dw_chunks(R, B) * DW_OUT * sizeof(float);
+    return (size_t)dw_chunks(R, B) * 2 * G4 * (GH + 64) * sizeof(float);
 }
 
 int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, const void* wih, void* dx_parts, int R, int B, int H, int I, int Ip,
                 float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_dw: non-positive size");
     DIC_REQUIRE(H == GH, DIC_ERR_UNSUPPORTED, "lstm_dw: hidden size %d (compiled for %d)", H, GH);
-    DIC_REQUIRE(Ip == XW && I > 0 && I <= XW, DIC_ERR_UNSUPPORTED, "lstm_dw: packed input width %d / %d (compiled for %d)", I, Ip, XW);
+    DIC_REQUIRE((Ip == XW || Ip == 64) && I > 0 && I <= Ip, DIC_ERR_UNSUPPORTED, "lstm_dw: packed input width %d / %d (compiled for %d and 64)", I, Ip, XW);
     DIC_REQUIRE(dgx && out_ext && x && workspace, DIC_ERR_INVALID_ARG, "lstm_dw: NULL pointer");
     DIC_REQUIRE((long)R * B >= TR, DIC_ERR_UNSUPPORTED, "lstm_dw: R*B = %ld rows < one %d-row tile (use the GEMM path)", (long)R * B, TR);
     LstmGrads g;
     int rc = grads_from(grads, &g, true, false, "lstm_dw");
     if (rc) return rc;
     const int nch = dw_chunks(R, B);
-    DIC_REQUIRE(workspace_bytes >= (size_t)nch * DW_OUT * sizeof(float), DIC_ERR_WORKSPACE, "lstm_dw: workspace %zu < %zu", workspace_bytes,
-                (size_t)nch * DW_OUT * sizeof(float));
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
-        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_dw: cannot reserve %d B of LDS: %s", DW_LDS, hipGetErrorString(e));
-        attr_set = true;
+    const int wide = Ip == 64, nw = GH + Ip, n_out = 2 * G4 * nw;
+    DIC_REQUIRE(workspace_bytes >= (size_t)nch * n_out * sizeof(float), DIC_ERR_WORKSPACE, "lstm_dw: workspace %zu < %zu", workspace_bytes,
+                (size_t)nch * n_out * sizeof(float));
+    const int lds = wide ? NBUF * (LDS_DG + LDS_H + TR * 2 * 64) : DW_LDS;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[wide]) {
+        hipError_t e = hipFuncSetAttribute(wide ? (const void*)lstm_dw_kernel<64> : (const void*)lstm_dw_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_dw: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set[wide] = true;
     }
     hipStream_t st = (hipStream_t)stream;
     DIC_REQUIRE((wih == nullptr) == (dx_parts == nullptr), DIC_ERR_INVALID_ARG, "lstm_dw: wih and dx_parts go together");
-    DIC_REQUIRE(!wih || I <= WT_COLS, DIC_ERR_UNSUPPORTED, "lstm_dw: the fused input gradient covers %d input columns, got %d", WT_COLS, I);
+    DIC_REQUIRE(!wih || (!wide && I <= WT_COLS), DIC_ERR_UNSUPPORTED, "lstm_dw: the fused input gradient covers %d input columns of 32-wide rows, got %d of %d", WT_COLS, I, Ip);
     DwArgs a{(const __bf16*)dgx, (const __bf16*)out_ext, (const __bf16*)x, (float*)workspace, (const __bf16*)wih, (__bf16*)dx_parts, R, B};
-    hipLaunchKernelGGL(lstm_dw_kernel, dim3(nch, 2), dim3(512), DW_LDS, st, a);
-    hipLaunchKernelGGL(lstm_dw_finalize, dim3((DW_OUT + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, I, g,
+    if (wide) hipLaunchKernelGGL(lstm_dw_kernel<64>, dim3(nch, 2), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(lstm_dw_kernel<32>, dim3(nch, 2), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(lstm_dw_finalize, dim3((n_out + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, I, nw, g,
                        accumulate ? 1.0f : 0.0f);
     return check_launch("lstm_dw");
 }

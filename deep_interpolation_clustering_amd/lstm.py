@@ -28,10 +28,11 @@ import os
 import torch
 
 from . import _native as N
-from .ops import PACKED_WIDTH, splitk_tn
+from . import ops as _ops
+from .ops import packed_width, splitk_tn
 
 H = 128
-PROJ_WIDTH = PACKED_WIDTH      # dic_lstm_fwd_proj's compiled input width
+PROJ_WIDTHS = (32, 64)         # dic_lstm_fwd_proj's / dic_lstm_dw's compiled packed input widths (3C = 18 / 36 features + the bias column)
 PARAM_NAMES = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0',
                'weight_ih_l0_reverse', 'weight_hh_l0_reverse', 'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
 
@@ -133,9 +134,11 @@ class _BiLstm(torch.autograd.Function):
         dev = x.device
         I = params[0].shape[1]
         small = f32 or B <= SMALL_BATCH                           # one 32-row tile per workgroup (csrc/dic_lstm32.hip)
-        narrow = (not f32) and I < PROJ_WIDTH                      # bf16, narrow input (encoder): rows packed to 32 with the bias as a constant-one column
+        x3 = f32 and _ops.f32_products() == 'x3'                  # f32 tensors, products as three bf16 MFMAs (csrc/dic_gemm.hip)
+        narrow = (not f32) and packed_width(I) > 0                 # bf16, narrow input (encoder): rows packed to 32 / 64 with the bias as a constant-one column
         proj = narrow and not small                                # ... and projected inside the 64-row recurrence kernel
-        Ip = I if f32 else (PROJ_WIDTH if narrow else (I + 15) // 16 * 16)      # K of the projection (bf16: padded to the MFMA step)
+        # K of the projection (bf16: padded to the MFMA step; f32 'x3': to the 16-B vector loads of dic_gemm_nt)
+        Ip = ((I + 3) // 4 * 4 if x3 else I) if f32 else (packed_width(I) if narrow else (I + 15) // 16 * 16)
         need = any(ctx.needs_input_grad)
         pf = [N.f32c(p.detach()) for p in params]
         wih = torch.empty((8 * H, Ip), device=dev, dtype=T)
@@ -146,7 +149,7 @@ class _BiLstm(torch.autograd.Function):
         N.check(L.dic_lstm_pack(code, N.ptr_array(pf), H, I, Ip, int(narrow), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), st), 'dic_lstm_pack')
         if packed:                                                 # (R,B,32) bf16 rows [features | 1 | 0...] from ops.sci_cci_packed
             if not narrow or I_in != Ip or x.dtype != T:
-                raise ValueError(f'packed input must be (R,B,{PROJ_WIDTH}) bf16 for an LSTM of input size < {PROJ_WIDTH}')
+                raise ValueError(f'packed input must be (R,B,{Ip}) bf16 for an LSTM of input size {I}')
             xb = x if x.is_contiguous() else x.contiguous()
         else:
             if I_in != I:
@@ -176,7 +179,16 @@ class _BiLstm(torch.autograd.Function):
                 Bp = (B + 31) // 32 * 32                           # kernel-native saved state is tiled by 32 rows
                 gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=T)
                 cs = torch.empty((R + 1, Bp, 2, H), device=dev, dtype=T)     # (time slot R: c0, written by the forward)
-            gx = torch.mm(xb.view(R * B, Ip), wih.t()) if narrow else torch.addmm(bias, xb.view(R * B, Ip), wih.t())     # (R*B, 2*4*H)
+            # input projection gx (R*B, 2*4*H) of all steps: hand-written MFMA kernels (no library GEMM) except in the exact-f32 parity mode
+            if narrow:
+                gx = _ops.gemm_nt(xb.view(R * B, Ip), wih)                       # (the bias rides in the constant-one column)
+            elif (not f32) and Ip == WIDE_INPUT and ROW_PROJ:
+                gx = torch.empty((R * B, 8 * H), device=dev, dtype=T)           # decoder: weights resident in registers (csrc/dic_rowproj.hip)
+                N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), 0, 0, st), 'dic_row_proj')
+            elif x3 or not f32:
+                gx = _ops.gemm_nt(xb.view(R * B, Ip), wih, bias.float())
+            else:
+                gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
             N.check(L.dic_lstm_rec_fwd(code, N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
                                        N.ptr(gates), N.ptr(cs), int(bm) | (2 if kernel_boundary else 0), st), 'dic_lstm_rec_fwd')
         else:
@@ -196,10 +208,11 @@ class _BiLstm(torch.autograd.Function):
                     gx = torch.empty((R * B, 8 * H), device=dev, dtype=T)
                     N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), native, int(relu_kernel), st), 'dic_row_proj')
                 else:
-                    gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
+                    gx = _ops.gemm_nt(xb.view(R * B, Ip), wih, bias.float())
                 N.check(L.dic_lstm_fwd(N.ptr(gx), (2 if FWD_EIGHT_WAVES else 1) if native > 0 else 0, N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
                                        N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), st), 'dic_lstm_fwd')
         ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32), bool(relu))
+        ctx.x3 = x3
         ctx.x_relu_in_kernel = relu_kernel
         ctx.x_dtype = x.dtype
         ctx.has_init = h0 is not None
@@ -241,7 +254,8 @@ class _BiLstm(torch.autograd.Function):
                                     R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), int(relu), st), 'dic_lstm_bwd')
         dg2 = dgx.view(R * B, 8 * H)
         use_dw = narrow and R * B >= 32                              # one-pass weight-gradient kernel (csrc/dic_lstmgrad.hip; it tiles the R*B rows by 32)
-        fuse_dx = use_dw and I <= 19 and any(ctx.needs_input_grad[8:])       # ... which then also forms dX = dG.W_ih per direction
+        fuse_dx = use_dw and Ip == 32 and I <= 19 and any(ctx.needs_input_grad[8:])       # ... which then also forms dX = dG.W_ih per direction (32-wide rows)
+        x3 = ctx.x3
         dxp = torch.empty((2, R * B, Ip), device=dev, dtype=T) if (fuse_dx and ctx.needs_input_grad[0]) else None
         dx = None
         if ctx.needs_input_grad[0] and dxp is None:
@@ -249,8 +263,12 @@ class _BiLstm(torch.autograd.Function):
                 # decoder: dX = dG . W_ih with the weights resident in registers (csrc/dic_dxproj.hip; round 2: a library GEMM)
                 dx = torch.empty((R * B, Ip), device=dev, dtype=T)
                 N.check(Lb.dic_lstm_dx_wide(N.ptr(dg2), N.ptr(wih), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_wide')
+            elif f32 and not x3:
+                dx = dg2 @ wih                                       # (R*B, Ip): the exact-f32 parity mode
+            elif (not f32) and I == WIDE_INPUT and not small:
+                dx = dg2 @ wih                                       # the decoder's large-batch dX: the one library GEMM left (see DX_KERNEL)
             else:
-                dx = dg2 @ wih                                       # (R*B, Ip)
+                dx = _ops.gemm_nt(dg2, wih.t().contiguous())         # dX = dG . W_ih on dic_gemm_nt (W_ih^T: a (Ip, 8H) copy of the packed weights)
             if packed:
                 dx = dx.view(R, B, Ip)                               # consumed in this layout by ops._SciCciPacked.backward
             else:
@@ -291,6 +309,16 @@ class _BiLstm(torch.autograd.Function):
                     _SIDE['keep'].append((dgx, out_ext, xb, dbias, wih, sinks))
                 else:
                     weight_grads(st)
+            elif x3 or not f32:
+                # dic_gemm_tn: dW_ih[d] = dG[d]^T . x and dW_hh[d] = dG[d]^T . h_prev[d] straight into the parameter gradients; h_prev = row-shifted
+                # views of the extended output buffer (see below)
+                oe = out_ext.view((R + 2) * B, 2 * H)
+                xv = xb.view(R * B, Ip)
+                for d in range(2):
+                    _ops.gemm_tn_into(dg2[:, 4 * H * d:4 * H * (d + 1)], xv, sinks[4 * d], kcols=I, accumulate=accumulate)
+                    hp = oe[:R * B, :H] if d == 0 else oe[2 * B:, H:]
+                    _ops.gemm_tn_into(dg2[:, 4 * H * d:4 * H * (d + 1)], hp, sinks[4 * d + 1], accumulate=accumulate)
+                N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             else:
                 # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split-K bmm (ops.splitk_tn).
                 # dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d], h_prev = h_{t-1} (forward) / h_{t+1} (reverse): row-shifted views of the
@@ -339,7 +367,7 @@ def _relu_mode(rectified_out):
 
 def bilstm_packed(xenc, lstm, h0=None, c0=None, batch_major_state=False, rectified_out=False):
     """The same for an input already in the recurrence kernel's layout: xenc (R,B,32) bf16 rows [features | 1 | 0...]
-    (``ops.sci_cci_packed``); its gradient comes back in that layout too."""
+    (``ops.sci_cci_packed``; 64-wide rows for 32 <= 3C < 64); its gradient comes back in that layout too."""
     with torch.autocast('cuda', enabled=False):
         out, hn, cn = _BiLstm.apply(xenc, h0, c0, True, batch_major_state, False, _relu_mode(rectified_out), False, *_params(lstm))
     return out, (hn, cn)

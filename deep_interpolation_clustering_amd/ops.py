@@ -170,7 +170,13 @@ def sci_only(x, sci_kernel, grid, lengths=None):
     return _SciCci.apply(x, sci_kernel, None, grid, lengths)
 
 
-PACKED_WIDTH = 32      # width of the encoder LSTM's packed input rows (dic_lstm_fwd_proj / dic_lstm_dw: one MFMA k-step pair)
+PACKED_WIDTH = 32      # width of the encoder LSTM's packed input rows for the reference's six vitals (dic_lstm_fwd_proj / dic_lstm_dw: one MFMA k-step pair)
+
+
+def packed_width(features):
+    """Width of the packed bf16 rows [features | 1 | 0...] for an LSTM of ``features`` inputs: 32 (3C = 18: the reference's six vitals) or 64
+    (3C = 36: BASELINE configs[3]'s twelve channels; clustering_interp.py:102-111 sizes the encoder as 3 * num_variables); 0 = not packed."""
+    return 32 if features < 32 else (64 if features < 64 else 0)
 
 
 class _SciCciPacked(torch.autograd.Function):
@@ -188,21 +194,23 @@ class _SciCciPacked(torch.autograd.Function):
         C = sci_kernel.numel()
         if C4 != 4 * C:
             raise ValueError(f'stacked input must be (B, 4*{C}, T), got {tuple(x.shape)}')
-        if 3 * C >= PACKED_WIDTH:
-            raise ValueError(f'packed rows hold at most {PACKED_WIDTH - 1} features, got 3C = {3 * C}')
+        xw = packed_width(3 * C)
+        if not xw:
+            raise ValueError(f'packed rows hold at most 63 features, got 3C = {3 * C}')
         R = grid.numel()
         lengths = None if store else _lengths_arg(lengths, B, C, x.device)
         sk, ck = N.f32c(sci_kernel.detach()), N.f32c(cci_kernel.detach())
         need_grad = any(ctx.needs_input_grad)
-        xenc = torch.empty((R, B, PACKED_WIDTH), device=x.device, dtype=torch.bfloat16)
+        xenc = torch.empty((R, B, xw), device=x.device, dtype=torch.bfloat16)
         saved = torch.empty((B, 7, C, R), device=x.device, dtype=torch.float32) if need_grad else None
         if store:
             N.check(N.lib().dic_sci_cci_fwd_store(*_store_ptrs(x), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), None, N.ptr(saved),
-                                                  N.ptr(xenc), PACKED_WIDTH, N.stream_of(xenc)), 'dic_sci_cci_fwd_store')
+                                                  N.ptr(xenc), xw, N.stream_of(xenc)), 'dic_sci_cci_fwd_store')
         else:
             N.check(N.lib().dic_sci_cci_fwd_packed(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), None,
-                                                   N.ptr(saved), N.ptr(xenc), PACKED_WIDTH, N.stream_of(x)), 'dic_sci_cci_fwd_packed')
+                                                   N.ptr(saved), N.ptr(xenc), xw, N.stream_of(x)), 'dic_sci_cci_fwd_packed')
         ctx.dims = (B, C, R)
+        ctx.xw = xw
         ctx.sink_params = (sci_kernel, cci_kernel)
         ctx.save_for_backward(saved, sk, ck)
         return xenc
@@ -217,13 +225,13 @@ class _SciCciPacked(torch.autograd.Function):
         gc = torch.empty((C, C), device=g.device, dtype=torch.float32)
         L = N.lib()
         ws = _ws(L.dic_sci_cci_bwd_workspace(B, C, R), g.device)
-        N.check(L.dic_sci_cci_bwd_packed(N.ptr(g), PACKED_WIDTH, N.ptr(saved), N.ptr(sk), N.ptr(ck), B, C, R, N.ptr(gs), N.ptr(gc),
+        N.check(L.dic_sci_cci_bwd_packed(N.ptr(g), ctx.xw, N.ptr(saved), N.ptr(sk), N.ptr(ck), B, C, R, N.ptr(gs), N.ptr(gc),
                                          N.ptr(ws), ws.numel(), N.stream_of(g)), 'dic_sci_cci_bwd_packed')
         return None, _sink(ctx.sink_params[0], gs), _sink(ctx.sink_params[1], gc), None, None
 
 
 def sci_cci_packed(x, sci_kernel, cci_kernel, grid, lengths=None):
-    """Fused SCI + CCI: x (B,4C,T) -> (R,B,32) bf16 = [smooth | intensity | transient | 1 | 0...], time-major (3C < 32)."""
+    """Fused SCI + CCI: x (B,4C,T) -> (R,B,32 or 64) bf16 = [smooth | intensity | transient | 1 | 0...], time-major (3C < 64)."""
     return _SciCciPacked.apply(x, sci_kernel, cci_kernel, grid, lengths)
 
 
@@ -692,6 +700,114 @@ def splitk_tn(a, b, chunks=(8192, 4096, 2048)):
         body = torch.sum(torch.bmm(a[:m].unflatten(0, (m // c, c)).transpose(1, 2), b[:m].unflatten(0, (m // c, c))), dim=0, dtype=torch.float32)
         return body + (a[m:].t() @ b[m:]).float()
     return (a.t() @ b).float()
+
+
+# ----------------------------------------------------------------------------------------- row-streaming MFMA products (csrc/dic_gemm.hip)
+# How the f32 step (no autocast) forms its dense products -- nn.LSTM's input projections and recurrent products, nn.Linear, and their gradients
+# (clustering_interp.py:14-41, rbf.py:111-125):
+#   'exact'  the exact-f32 MFMA recurrence (csrc/dic_lstm32.hip, v_mfma_f32_32x32x2_f32) and f32 library GEMMs: the 1e-5 parity configuration
+#            of the test suite, every shape;
+#   'x3'     operands split on the fly into bf16 hi + lo pieces, products as hi.hi + lo.hi + hi.lo on the bf16 matrix cores with f32
+#            accumulation (dic_gemm_nt / dic_gemm_tn, the split recurrence kernels): every tensor stays f32, no library GEMM, the step's losses
+#            within ~1e-6 of the reference (tests/test_gpu_traj.py) at several times the exact mode's throughput.
+_F32_PRODUCTS = [os.environ.get('DIC_F32_PRODUCTS', 'exact')]
+
+
+def f32_products():
+    return _F32_PRODUCTS[0]
+
+
+class f32_products_mode:
+    """``with f32_products_mode('x3'): ...`` -- see above; step.Stepper(precision=...) wraps its forward and backward in it."""
+
+    def __init__(self, mode):
+        if mode not in ('exact', 'x3'):
+            raise ValueError(f"f32 products mode must be 'exact' or 'x3', got {mode!r}")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev, _F32_PRODUCTS[0] = _F32_PRODUCTS[0], self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _F32_PRODUCTS[0] = self.prev
+        return False
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return N.DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return N.DTYPE_BF16
+    raise TypeError(f'dic_gemm: f32 or bf16 operands, got {t.dtype}')
+
+
+def _rows(t):
+    """(rows, columns) matrix view whose rows are contiguous (row stride arbitrary)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f'dic_gemm: need a 2-D operand with contiguous rows, got shape {tuple(t.shape)} strides {t.stride()}')
+    return t
+
+
+def gemm_nt(a, w, bias=None, out_dtype=None, relu_a=False, out=None):
+    """y (M,N) = act(a (M,K)) . w (N,K)^T (+ bias (N) f32) on the matrix cores (dic_gemm_nt): bf16 operands -> one MFMA per product; f32
+    operands -> the three-term bf16 split with f32 accumulation.  Rows may be strided views (16-B aligned, strides multiples of 4 / 8)."""
+    N.require_gpu(a, w)
+    a, w = _rows(a), _rows(w)
+    if a.dtype != w.dtype or a.shape[1] != w.shape[1]:
+        raise ValueError(f'gemm_nt: a {tuple(a.shape)} {a.dtype} vs w {tuple(w.shape)} {w.dtype}')
+    M, K = a.shape
+    n = w.shape[0]
+    y = torch.empty((M, n), device=a.device, dtype=out_dtype or a.dtype) if out is None else _rows(out)
+    b = None if bias is None else N.f32c(bias)
+    N.check(N.lib().dic_gemm_nt(_dt(a), _dt(y), N.ptr(a), a.stride(0), N.ptr(w), w.stride(0), N.ptr(b), M, n, K, N.ptr(y), y.stride(0), int(bool(relu_a)),
+                                N.stream_of(a)), 'dic_gemm_nt')
+    return y
+
+
+def gemm_tn_into(a, x, dst, kcols=None, accumulate=False):
+    """dst (N,kcols) f32 (+)= a (M,N)^T . x (M,K)[:, :kcols] (dic_gemm_tn): the weight-gradient shape -- a reduction over hundreds of thousands of
+    rows into a small matrix; row chunks in parallel, fixed-order f64 second stage (deterministic)."""
+    N.require_gpu(a, x, dst)
+    a, x, dst = _rows(a), _rows(x), _rows(dst)
+    if a.dtype != x.dtype or a.shape[0] != x.shape[0] or dst.dtype != torch.float32:
+        raise ValueError(f'gemm_tn: a {tuple(a.shape)} {a.dtype}, x {tuple(x.shape)} {x.dtype}, dst {dst.dtype}')
+    M, n = a.shape
+    K = x.shape[1]
+    kcols = K if kcols is None else int(kcols)
+    if tuple(dst.shape) != (n, kcols):
+        raise ValueError(f'gemm_tn: dst {tuple(dst.shape)} != ({n}, {kcols})')
+    L = N.lib()
+    ws = _ws(L.dic_gemm_tn_workspace(M, n, K), a.device)
+    N.check(L.dic_gemm_tn(_dt(a), N.ptr(a), a.stride(0), N.ptr(x), x.stride(0), M, n, K, N.ptr(dst), dst.stride(0), kcols, int(bool(accumulate)),
+                          N.ptr(ws), ws.numel(), N.stream_of(a)), 'dic_gemm_tn')
+    return dst
+
+
+class _MfmaLinear(torch.autograd.Function):
+    """y = x W^T + b over (N, in) rows on dic_gemm_nt / dic_gemm_tn -- nn.Linear (rbf.py:111-125's first layer, the heads' first layers) without a
+    library GEMM: f32 operands in the 'x3' mode of the f32 step, bf16 operands in the bf16 step's small-batch path."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bias_grad_is_zero):
+        xc = x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
+        wc = weight.detach().to(xc.dtype).contiguous()
+        ctx.save_for_backward(xc, wc)
+        ctx.zero_db, ctx.sink_params = bool(bias_grad_is_zero), (weight, bias)
+        return gemm_nt(xc, wc, bias.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        dyc = dy.to(xc.dtype).contiguous()
+        dx = gemm_nt(dyc, wc.t().contiguous()) if ctx.needs_input_grad[0] else None
+        dw = gemm_tn_into(dyc, xc, torch.empty(wc.shape, device=xc.device, dtype=torch.float32))
+        db = torch.zeros(wc.shape[0], device=xc.device, dtype=torch.float32) if ctx.zero_db else torch.sum(dyc, dim=0, dtype=torch.float32)
+        return dx, _sink(ctx.sink_params[0], dw), _sink(ctx.sink_params[1], db), None
+
+
+def mfma_linear(x, weight, bias, bias_grad_is_zero=False):
+    return _MfmaLinear.apply(x, weight, bias, bias_grad_is_zero)
 
 
 FC_BWD_SHAPE = (128, 256)      # dic_fc_bwd's compiled Linear(256, 128)

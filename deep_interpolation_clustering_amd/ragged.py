@@ -22,7 +22,8 @@ class RaggedStore:
         values per plane and channel (what p0 writes) -- ``RaggedStore.fits`` tells."""
         fd = np.asarray(feed_data)
         N, C4, T = fd.shape
-        assert C4 == 4 * C
+        if C4 != 4 * C:
+            raise ValueError(f"stacked planes must be (N, 4*{C}, T), got {tuple(fd.shape)}")
         mask = fd[:, C:2 * C] != 0
         lengths = mask.sum(-1).astype(np.int32)                       # (N,C)
         row_off = np.zeros(N * C + 1, np.int64)
@@ -130,7 +131,8 @@ class RaggedBatch:
         return RaggedBatch(self.store, self.idx.clone(), self.lengths.clone(), self.denoise)
 
     def copy_(self, other, non_blocking=False):
-        assert other.store is self.store and other.denoise == self.denoise
+        if other.store is not self.store or other.denoise != self.denoise:      # (a captured step replays against ONE store / denoise setting)
+            raise ValueError('RaggedBatch.copy_: the source batch belongs to another store or has another denoise setting')
         self.idx.copy_(other.idx, non_blocking=non_blocking)
         self.lengths.copy_(other.lengths, non_blocking=non_blocking)
         return self

@@ -23,6 +23,12 @@ class CompressFC(nn.Module):
         fast = (rec_input.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
                 and last.in_features == ops.HEAD_IN and last.out_features in ops.HEAD_OUT and rec_input.dim() == 2)
         if not fast:
+            if (rec_input.is_cuda and rec_input.dim() == 2 and rec_input.dtype == torch.float32 and not torch.is_autocast_enabled()
+                    and ops.f32_products() == 'x3' and rec_input.shape[1] % 4 == 0):
+                # f32 step, products as three-term bf16 splits on the matrix cores (csrc/dic_gemm.hip): the 256 -> 128 layer without a library GEMM
+                first, bn = self.model[0], self.model[1]
+                z = ops.mfma_linear(rec_input, first.weight, first.bias, bias_grad_is_zero=bn.training)
+                return self.model[4](self.model[3](self.model[2](bn(z))))
             return self.model(rec_input)
         # bf16 step: the C-wide output layer over all B*R rows is a 100 MB stream, not a GEMM (csrc/dic_head.hip)
         first = self.model[0]

@@ -48,8 +48,14 @@ class Stepper:
     ``autocast_dtype`` (e.g. torch.bfloat16) wraps the forward in torch.autocast so the bi-LSTMs and the
     FC heads run on bf16 MFMA; the HIP kernels always compute in f32."""
 
-    def __init__(self, model, optimizer_factory, args, autocast_dtype=None, use_graphs=False):
+    def __init__(self, model, optimizer_factory, args, autocast_dtype=None, use_graphs=False, precision=None):
+        """``precision`` (f32 step only, i.e. ``autocast_dtype=None``): how the dense products are formed -- 'exact' (exact-f32 MFMA recurrence +
+        f32 library GEMMs) or 'x3' (every product as a three-term bf16 split on the matrix cores with f32 accumulation, all tensors f32:
+        csrc/dic_gemm.hip; no library GEMM).  None = the process default (ops.f32_products(), env DIC_F32_PRODUCTS, 'exact')."""
         self.model, self.args = model, args
+        if precision is not None and autocast_dtype is not None:
+            raise ValueError('precision= selects the f32 step\'s products; it does not combine with autocast_dtype')
+        self.precision = precision
         self.flat = dist.FlatParams(model)          # must precede the optimizer: it re-homes parameter storage
         self.flat.broadcast_(0)
         self.optimizer = optimizer_factory(model)
@@ -77,7 +83,7 @@ class Stepper:
 
     def _ctx(self):
         if self.autocast_dtype is None:
-            return contextlib.nullcontext()
+            return contextlib.nullcontext() if self.precision is None else ops.f32_products_mode(self.precision)
         return torch.autocast('cuda', dtype=self.autocast_dtype)
 
     def forward_loss(self, x, ob, padding_mask, lengths=None, fake_x=None, fake_perm_idx=None, positive_x=None,
@@ -98,7 +104,9 @@ class Stepper:
     def _graph_key(self, tensors):
         # (the fused optimiser reads lr / betas / eps / weight decay from device memory: they are not part of the key)
         lrs = () if self._fused_tail else tuple(float(g['lr']) for g in self.optimizer.param_groups)
-        return tuple((k, tuple(v.shape), v.dtype) for k, v in tensors.items()) + (lrs, self.model.training)
+        # (a ragged batch is a handle into ONE store, read in place by the captured launches, with its denoise flag baked in: both belong to the key)
+        ragged = tuple((k, id(v.store), bool(v.denoise)) for k, v in tensors.items() if is_ragged(v))
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in tensors.items()) + (lrs, self.model.training, ragged)
 
     def _step_graphed(self, tensors):
         key = self._graph_key(tensors)

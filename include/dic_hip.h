@@ -474,6 +474,22 @@ int dic_grad_norm_clip(const float* g, int64_t n, float max_norm, float* out2, v
  * with one launch each between loss.backward() and the optimizer, pretrain_trainer.py:223-231). */
 int dic_accumulate_many(const float* const* src, float* const* dst, const int* n, int count, dic_stream_t stream);
 
+/* ---- row-streaming MFMA products (csrc/dic_gemm.hip) for the dense layers in the shapes no specialised kernel covers, and for the f32 step.
+ * Replaces the library GEMMs behind nn.LSTM's input projections / nn.Linear (clustering_interp.py:14-41, rbf.py:111-125) and their
+ * autograd gradients.  in_dtype DIC_DTYPE_BF16: one bf16 MFMA per product.  DIC_DTYPE_F32: operands split on the fly into bf16 hi + lo
+ * pieces and multiplied as hi.hi + lo.hi + hi.lo in f32 accumulators ("bf16x3": products good to ~2^-17, at 5x the exact-f32 MFMA rate).
+ *   dic_gemm_nt:  Y[m][n] = sum_k act(A[m][k]) W[n][k] (+ bias[n]);  A (M,K) rows at stride lda, W (N,K) rows at stride ldw (both of
+ *                 in_dtype), Y (M,N) of out_dtype at stride ldy; relu_a != 0: act = max(., 0).  K, lda, ldw multiples of 4 (f32) / 8 (bf16)
+ *                 elements, operands 16-B aligned.  An input gradient dX = dY.W is the same call with W handed over transposed.
+ *   dic_gemm_tn:  D[n][k] (+)= sum_m A[m][n] X[m][k] for k < kcols;  A (M,N) at stride lda, X (M,K) at stride ldx (both in_dtype), D f32
+ *                 (N,kcols) at stride ldd; the M rows are cut into chunks whose f32 partial products go through `workspace`
+ *                 (dic_gemm_tn_workspace bytes) and are summed in a fixed order in f64: deterministic.  accumulate != 0: added to D. */
+int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void* W, long ldw, const float* bias, long M, int N, int K,
+                void* Y, long ldy, int relu_a, dic_stream_t stream);
+size_t dic_gemm_tn_workspace(long M, int N, int K);
+int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
+                int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,123 @@
+"""Row-streaming MFMA products (csrc/dic_gemm.hip: dic_gemm_nt / dic_gemm_tn) against f64 products of the same operands: bf16 inputs (one
+MFMA per product) and f32 inputs (the three-term bf16 split, 'x3'), tile tails in every dimension, strided row views, bias, the ReLU on load,
+written and accumulated weight gradients -- and the f32 step in the 'x3' mode against the reference's own joint step."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _tol(dtype):
+    # bf16 operands are exact inputs (the products are exact, f32 accumulation): only the accumulation order differs from f64.
+    # f32 operands: the split drops lo.lo and rounds lo: ~2^-17 per product, a random walk over K
+    return 2e-6 if dtype == torch.bfloat16 else 2e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('M,N,K,bias,relu', [(24 * 200, 1024, 256, True, False), (33, 128, 256, True, True), (70001, 64, 1024, False, False),
+                                               (1, 1024, 40, True, False), (5000, 36, 1024, False, False), (129, 200, 72, True, True),
+                                               (4096, 1024, 64, False, False)])
+def test_gemm_nt_matches_f64(dtype, M, N, K, bias, relu):
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(M + N + K)
+    dev = torch.device('cuda')
+    a = (torch.randn(M, K + 8, device=dev) * 0.7).to(dtype)[:, :K]                 # a strided row view
+    w = (torch.randn(N, K, device=dev) * 0.1).to(dtype)
+    b = torch.randn(N, device=dev) if bias else None
+    for out_dtype in (torch.float32, torch.bfloat16):
+        y = ops.gemm_nt(a, w, b, out_dtype=out_dtype, relu_a=relu)
+        assert y.dtype == out_dtype and tuple(y.shape) == (M, N)
+        ad = a.double().clamp_min(0) if relu else a.double()
+        want = ad @ w.double().t() + (b.double() if bias else 0.0)
+        err = float((y.double() - want).abs().max()) / float(want.abs().max())
+        assert err <= (_tol(dtype) if out_dtype == torch.float32 else 5e-3), (dtype, out_dtype, err)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('M,N,K,kcols,accumulate', [(24 * 200, 512, 256, 256, False), (70001, 512, 128, 128, True), (31, 128, 256, 256, False),
+                                                      (5000, 512, 40, 36, True), (4099, 1024, 64, 37, False), (24 * 4096, 128, 256, 256, False),
+                                                      (1, 512, 24, 18, False)])
+def test_gemm_tn_matches_f64(dtype, M, N, K, kcols, accumulate):
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(M + N + K)
+    dev = torch.device('cuda')
+    a = (torch.randn(M, 2 * N, device=dev) * 0.3).to(dtype)[:, N:]                 # the second direction's gate columns: a strided view
+    x = (torch.randn(M + 7, K, device=dev) * 0.5).to(dtype)[7:]                     # row-shifted view (h_prev of the reverse direction)
+    dst = torch.randn(N, kcols, device=dev)
+    before = dst.clone()
+    ops.gemm_tn_into(a, x, dst, kcols=kcols, accumulate=accumulate)
+    want = a.double().t() @ x.double()[:, :kcols] + (before.double() if accumulate else 0.0)
+    err = float((dst.double() - want).abs().max()) / float(want.abs().max())
+    assert err <= 10 * _tol(dtype), (dtype, err)                                    # (f32 partial sums over up to 100 k rows before the f64 stage)
+    again = torch.randn(N, kcols, device=dev) if not accumulate else before.clone()
+    ops.gemm_tn_into(a, x, again, kcols=kcols, accumulate=accumulate)
+    assert torch.equal(again, dst)                                                  # fixed-order reductions: run-to-run identical
+
+
+def test_split_products_are_f32_grade_where_bf16_is_not():
+    """The point of the three-term split: f32 operands with a full mantissa -- bf16 rounding of the same operands is off by ~1e-3."""
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(0)
+    dev = torch.device('cuda')
+    a, w = torch.randn(4096, 256, device=dev), torch.randn(512, 256, device=dev) * 0.1
+    want = a.double() @ w.double().t()
+    scale = float(want.abs().max())
+    e3 = float((ops.gemm_nt(a, w).double() - want).abs().max()) / scale
+    e1 = float((ops.gemm_nt(a.bfloat16(), w.bfloat16(), out_dtype=torch.float32).double() - want).abs().max()) / scale
+    ef = float(((a @ w.t()).double() - want).abs().max()) / scale
+    assert e3 < 1e-5 and e1 > 20 * e3, (e3, e1, ef)
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def _args(C, T, K):
+    return SimpleNamespace(num_variables=C, num_timestamps=T, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=K, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.}, aux_pos_weights={})
+
+
+@pytest.mark.parametrize('case', ['cfg_K4', 'cfg_K8', 'wide_K16'])
+def test_f32_step_on_split_products_matches_reference_step(case):
+    """The f32 step with every dense product on the bf16 matrix cores as a three-term split (Stepper(precision='x3'): dic_gemm_nt / dic_gemm_tn,
+    the split recurrence): loss / ae_mse / kl of the reference's own joint step at rtol 1e-5 with no floor at the configured shape (K = 4, 8;
+    measured ~1e-6), 2e-5 at BASELINE configs[3]'s (the oracle's emulation of the split: kl 7e-6 there); argmax of q exact."""
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    dev = torch.device('cuda')
+    if case == 'wide_K16':
+        g = _load('netstep_wide_K16.npz')
+        sd = {k[4:]: torch.tensor(v) for k, v in g.items() if k.startswith('sd0/')}
+        C, T, K, rtol = 12, 288, 16, 2e-5
+    else:
+        g = _load(f'netstep_{case}.npz')
+        t = _load('traj_cfg1.npz')
+        sd = {k[5:]: torch.tensor(v) for k, v in t.items() if k.startswith('p1sd/')}
+        sd['cluster_assignment.cluster_centers'] = torch.tensor(g['centers'])
+        C, T, K, rtol = 6, 96, int(g['K']), 1e-5
+    args = _args(C, T, K)
+    net = Net(args, dev).to(dev)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, precision='x3')
+    x, ob = torch.tensor(g['x'], device=dev), torch.tensor(g['ob'], device=dev)
+    lens = x[:, C:2 * C].sum(-1).to(torch.int32)
+    losses, gnorm, z = st.step(x, ob, None, lens)
+    dev_rel = {k: abs(float(losses[k]) - float(g['loss_' + k])) / abs(float(g['loss_' + k])) for k in ('loss', 'ae_mse', 'kl')}
+    print('x3 deviation', case, dev_rel)
+    for k in ('loss', 'ae_mse', 'kl'):
+        np.testing.assert_allclose(float(losses[k]), float(g['loss_' + k]), rtol=rtol, atol=0, err_msg=k)
+    np.testing.assert_allclose(float(gnorm), float(g['gnorm']), rtol=1e-4)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g['z'], rtol=1e-3, atol=2e-4 if case == 'wide_K16' else 3e-5)
+    q = net.cluster_assignment(z.detach())
+    assert (q.argmax(1).cpu().numpy() == g['q'].argmax(1)).all()
+    for k, v in net.state_dict().items():
+        if 'sd1n/' + k in g:
+            np.testing.assert_allclose(np.linalg.norm(v.detach().cpu().numpy().astype(np.float64)), float(g['sd1n/' + k]), rtol=1e-4, err_msg=k)

@@ -23,7 +23,7 @@ def emulate(x, lstm, h0=None, c0=None, gx_bf16=False):
         w_ih, w_hh = getattr(lstm, 'weight_ih_l0' + sfx), getattr(lstm, 'weight_hh_l0' + sfx)
         bias = getattr(lstm, 'bias_ih_l0' + sfx) + getattr(lstm, 'bias_hh_l0' + sfx)
         gx = (rb(x).reshape(R * B, I) @ rb(w_ih).t() + rb(bias)).reshape(R, B, 4 * H)
-        if I >= 32 or gx_bf16:      # library-GEMM projection: gx itself is stored in bf16; I < 32 is projected in-kernel (f32) by the 64-row kernels
+        if I >= 64 or gx_bf16:      # separate projection kernel: gx itself is stored in bf16; I < 64 is projected in-kernel (f32) by the 64-row kernels
             gx = rb(gx)
         h = torch.zeros(B, H, device=x.device) if h0 is None else h0[d]
         c = torch.zeros(B, H, device=x.device) if c0 is None else c0[d]
@@ -50,7 +50,8 @@ def kernel_family(request, monkeypatch):
 
 
 @pytest.mark.parametrize('R,B,I,init', [(24, 200, 18, False), (24, 96, 256, True), (6, 64, 18, False), (5, 1, 256, True), (3, 130, 40, True),
-                                          (7, 70, 31, True), (4, 33, 32, False), (2, 5, 1, False)])
+                                          (7, 70, 31, True), (4, 33, 32, False), (2, 5, 1, False), (24, 200, 36, True), (4, 130, 63, False),
+                                          (3, 70, 80, True)])
 def test_fused_bilstm_matches_emulation(R, B, I, init, kernel_family):
     from deep_interpolation_clustering_amd import lstm as L
     torch.manual_seed(R * 1000 + B)
@@ -333,7 +334,7 @@ def _lstm_params(net):
     return [getattr(net, n) for n in L.PARAM_NAMES]
 
 
-@pytest.mark.parametrize('I', [18, 256, 40, 1])
+@pytest.mark.parametrize('I', [18, 256, 40, 1, 36, 80])
 def test_lstm_pack_matches_torch(I):
     """dic_lstm_pack: the eight nn.LSTM parameters -> the bf16 operands, against the torch stack / add / cast / pad sequence."""
     from deep_interpolation_clustering_amd import _native as N
@@ -341,8 +342,8 @@ def test_lstm_pack_matches_torch(I):
     torch.manual_seed(I)
     dev = torch.device('cuda')
     net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
-    proj = I < L.PROJ_WIDTH
-    Ip = L.PROJ_WIDTH if proj else (I + 15) // 16 * 16
+    proj = L.packed_width(I) > 0
+    Ip = L.packed_width(I) if proj else (I + 15) // 16 * 16
     bf = torch.bfloat16
     wih = torch.full((8 * H, Ip), 7.0, device=dev, dtype=bf)
     whh, whh_t = torch.empty((2, 4 * H, H), device=dev, dtype=bf), torch.empty((2, H, 4 * H), device=dev, dtype=bf)
@@ -369,7 +370,9 @@ def test_lstm_pack_matches_torch(I):
 
 
 @pytest.mark.parametrize('R,B,I,init,accumulate', [(24, 200, 18, False, False), (3, 64, 18, True, True), (5, 130, 31, True, False),
-                                                     (1, 37, 6, False, True), (2, 4099, 18, True, False), (3, 11, 18, True, True)])
+                                                     (1, 37, 6, False, True), (2, 4099, 18, True, False), (3, 11, 18, True, True),
+                                                     (24, 200, 36, True, False), (2, 4099, 36, False, True), (3, 11, 63, True, False),
+                                                     (5, 130, 32, False, False)])
 def test_lstm_dw_matches_matmul(R, B, I, init, accumulate):
     """dic_lstm_dw (one pass over dG, MFMA with transposed LDS reads) against f64 products of the same bf16 operands:
     dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d], dW_ih[d] = sum_t dG_t[d]^T x_t; written or accumulated into the eight gradients."""
@@ -379,7 +382,8 @@ def test_lstm_dw_matches_matmul(R, B, I, init, accumulate):
     bf = torch.bfloat16
     dg = (torch.randn(R, B, 2, 4 * H, device=dev) * 0.3).to(bf)
     out = (torch.randn(R, B, 2 * H, device=dev) * 0.5).to(bf)
-    x = torch.zeros(R, B, 32, device=dev)
+    XW = 32 if I < 32 else 64                                        # packed row width: 3C = 18 -> 32, 3C = 36 (BASELINE configs[3]) -> 64
+    x = torch.zeros(R, B, XW, device=dev)
     x[..., :I] = torch.randn(R, B, I, device=dev)
     x[..., I] = 1.0
     x = x.to(bf)
@@ -394,9 +398,9 @@ def test_lstm_dw_matches_matmul(R, B, I, init, accumulate):
     out_ext[0, :, :H] = h0[0] if init else 0.0
     out_ext[R + 1, :, H:] = h0[1] if init else 0.0
     fuse_dx = I <= 19
-    wih = (torch.randn(2 * 4 * H, 32, device=dev) * 0.2).to(bf)
-    dxp = torch.full((2, R * B, 32), float('nan'), device=dev, dtype=bf) if fuse_dx else None
-    N.check(L.dic_lstm_dw(N.ptr(dg), N.ptr(out_ext), N.ptr(x), N.ptr(wih) if fuse_dx else None, N.ptr(dxp), R, B, H, I, 32, N.ptr_array(grads),
+    wih = (torch.randn(2 * 4 * H, XW, device=dev) * 0.2).to(bf)
+    dxp = torch.full((2, R * B, XW), float('nan'), device=dev, dtype=bf) if fuse_dx else None
+    N.check(L.dic_lstm_dw(N.ptr(dg), N.ptr(out_ext), N.ptr(x), N.ptr(wih) if fuse_dx else None, N.ptr(dxp), R, B, H, I, XW, N.ptr_array(grads),
                           int(accumulate), N.ptr(ws), ws.numel(), N.stream_of(dg)), 'dic_lstm_dw')
     if fuse_dx:      # per-direction input gradients dG[d] . W_ih[d], columns [0, 19)
         for d in range(2):

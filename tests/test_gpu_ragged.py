@@ -72,7 +72,7 @@ def test_store_path_equals_dense_path_bit_for_bit(C, T, R, lam, denoise):
     (os_ * cot).sum().backward()
     assert torch.equal(pd[0].grad, ps[0].grad) and torch.equal(pd[1].grad, ps[1].grad)
     # k1, packed bf16 rows for the encoder LSTM
-    if 3 * C < ops.PACKED_WIDTH:
+    if ops.packed_width(3 * C):
         assert torch.equal(ops.sci_cci_packed(X, pd[0], pd[1], grid, LEN), ops.sci_cci_packed(rb, ps[0], ps[1], grid))
     # k2 with the reconstruction loss riding along (training step) -- the store supplies time stamps AND observations
     plain = RaggedBatch(store, idx)                                  # (the target is never the denoised input)
