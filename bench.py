@@ -35,13 +35,14 @@ C, T, H, LAM, R, D = 6, 96, 24.0, 50.0, 24, 256
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=30)
-    p.add_argument('--warmup', type=int, default=10)
+    p.add_argument('--steps', type=int, default=100, help='timed steps (SURVEY.md 8d: >= 100)')
+    p.add_argument('--warmup', type=int, default=20, help='untimed warm-up steps (SURVEY.md 8d: >= 20)')
     p.add_argument('--batch', type=int, default=int(os.environ.get('DIC_BENCH_BATCH', 32768)), help='encounters per GPU per step')
     p.add_argument('--encounters', type=int, default=75000, help='cohort size resident per GPU')
     p.add_argument('--clusters', type=int, default=None, help='K (default 4; 8 for the 8-GPU config)')
-    p.add_argument('--dtype', choices=['bf16', 'f32'], default=os.environ.get('DIC_BENCH_DTYPE', 'bf16'),
-                   help='bf16: autocast for the bi-LSTMs / FC heads (HIP kernels stay f32)')
+    p.add_argument('--dtype', choices=['bf16', 'f32', 'f32x3'], default=os.environ.get('DIC_BENCH_DTYPE', 'bf16'),
+                   help='bf16: autocast for the bi-LSTMs / FC heads (HIP kernels stay f32); f32: every tensor and product f32 (exact-f32 MFMA recurrence, '
+                        'f32 library GEMMs); f32x3: every tensor f32, every dense product a three-term bf16 split on the matrix cores (no library GEMM)')
     p.add_argument('--graph', action='store_true', help='capture the step in a hipGraph (pays off for small --batch)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--fake-detection', action='store_true',
@@ -60,6 +61,23 @@ def parse():
                    help='weak (default): --encounters resident and --batch per step PER GPU.  strong: ONE cohort of --encounters sharded over the '
                         'ranks and a fixed GLOBAL batch of --batch per step (BASELINE configs[2]: 75k encounters, K=8, on 8 GPUs)')
     return p.parse_args()
+
+
+def launch_ranks(a):
+    """``python bench.py --gpus N`` without a launcher around it (the reference's multi-GPU entry is a plain ``python p1...py --num_gpus N``,
+    pretrain_trainer.py:21): start the N ranks through torch.distributed.run as CHILD processes -- this process never initialises the GPU
+    (no HIP call, no torch.cuda query) -- and relay rank 0's JSON line and the children's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    log(f'--gpus {a.gpus} without a launcher: starting {a.gpus} ranks through torch.distributed.run (port {port})')
+    return subprocess.run(cmd, env=env).returncode
 
 
 def make_args(K, fake_detection=False, dropout=0.0):
@@ -590,6 +608,8 @@ def log(*msg):
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(a))          # (before anything touches the GPU in this process)
     t_start = time.perf_counter()
     from deep_interpolation_clustering_amd import dist, synthetic
     from deep_interpolation_clustering_amd.clustering_interp import Net
@@ -601,7 +621,7 @@ def main():
     sharded = dist.is_sharded()         # world > 1 (or the one-rank RCCL rehearsal of tests/test_gpu_dist.py)
     if sharded and rank == 0:
         log(f'process group: {td.get_backend()}, world {world}')
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU implementation')

@@ -20,7 +20,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dic_hip.h')
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 KM_STATUS_WORDS = 8
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F32X3 = 0, 1, 2
 MAX_CHANNELS, MAX_REFPOINTS, MAX_CLUSTERS, LATENT_MAX_DIM = 16, 64, 32, 256
 
 _lib = None

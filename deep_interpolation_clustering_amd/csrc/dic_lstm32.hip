@@ -17,6 +17,7 @@
 // address-coalescer bound): the saved gates / cell states use the lane-native layout (every wave instruction one contiguous
 // 512-B / 1-KiB piece; opaque, exchanged only between these two kernels), gx rows enter through LDS by whole-row LDS-DMA, and
 // dG rows leave from the LDS tile as whole rows.
+#include <type_traits>
 #include "dic_common.h"
 
 namespace dic {
@@ -115,6 +116,55 @@ template <> struct Rec<__bf16> {
     }
 };
 
+// ---- f32 tensors, products as THREE bf16 MFMAs ("x3": DIC_DTYPE_F32X3): every operand x is split into hi = bf16(x) and lo = bf16(x - hi) --
+// the weights once at start-up (the same 256 registers the f32 fragments take), h / dG on their way into LDS (two bf16 images instead of
+// one f32 image) -- and W.x ~ hi.hi + lo.hi + hi.lo accumulates in f32: 96 v_mfma_f32_32x32x16_bf16 per step and wave instead of 256
+// v_mfma_f32_32x32x2_f32 at twice the cycles each (5.3x less matrix-core time); products good to ~2^-17, the joint step's losses within ~1e-6
+// of the exact-f32 kernels (tests/test_gpu_gemm.py).  Everything else -- gx, saved gates / cell states, dG, the gate math -- is the f32 path.
+struct RecX3 {
+    static constexpr int PITCH(int K) { return K + 8; }       // bf16 images: 272-B / 1040-B rows
+    template <int K> struct Frag { sbf16x8 hi[K / 16], lo[K / 16]; };
+    __device__ static void split(float x, __bf16& hi, __bf16& lo) { hi = (__bf16)x; lo = (__bf16)(x - (float)hi); }
+    template <int K> __device__ static void load_a(Frag<K>& f, const float* row, int hh, int stride) {
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __bf16 h, l;
+                split(row[(size_t)(ks * 16 + 8 * hh + j) * stride], h, l);
+                f.hi[ks][j] = h; f.lo[ks][j] = l;
+            }
+    }
+    template <int K> __device__ static sf32x16 mma(const Frag<K>& a, const __bf16* bhi, const __bf16* blo, int hh, sf32x16 acc) {
+        constexpr int NK = K / 16, DEPTH = NK < 4 ? NK : 4;
+        sbf16x8 rh[DEPTH], rl[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            rh[i] = *reinterpret_cast<const sbf16x8*>(bhi + i * 16 + 8 * hh);
+            rl[i] = *reinterpret_cast<const sbf16x8*>(blo + i * 16 + 8 * hh);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi[ks], rh[ks % DEPTH], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo[ks], rh[ks % DEPTH], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi[ks], rl[ks % DEPTH], acc, 0, 0, 0);
+            if (ks + DEPTH < NK) {
+                rh[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(bhi + (ks + DEPTH) * 16 + 8 * hh);
+                rl[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(blo + (ks + DEPTH) * 16 + 8 * hh);
+            }
+        }
+        return acc;
+    }
+    // four f32 values -> the two images of an LDS tile
+    __device__ static void store4(__bf16* hi, __bf16* lo, sf32x4 v) {
+        sbf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { __bf16 a, b; split(v[j], a, b); h[j] = a; l[j] = b; }
+        *reinterpret_cast<sbf16x4*>(hi) = h;
+        *reinterpret_cast<sbf16x4*>(lo) = l;
+    }
+};
+
 template <typename T> struct Vec4;
 template <> struct Vec4<float> { typedef sf32x4 type; };
 template <> struct Vec4<__bf16> { typedef sbf16x4 type; };
@@ -132,14 +182,18 @@ struct RecFwdArgs {
     int boundary;          // out is time slots 1..R of an (R+2,B,2H) buffer: also write h0 (zeros without one) into slot 0 [:, :H] / slot R+1 [:, H:]
 };
 
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
+    static_assert(!X3 || sizeof(T) == 4, "the split products run on f32 tensors");
     typedef typename Vec4<T>::type V4;
-    constexpr int HP = Rec<T>::PITCH(SH);
+    typedef typename std::conditional<X3, __bf16, T>::type HT;      // element type of the h tile images
+    typedef typename std::conditional<X3, RecX3, Rec<T>>::type P;   // product policy
+    constexpr int HP = P::PITCH(SH);
+    constexpr int HBUF = (X3 ? 2 : 1) * SROWS * HP;        // elements per h buffer (x3: hi image, then lo image)
     constexpr int GXP = S4 + 16 / sizeof(T);               // staged gx row pitch (elements): whole rows + 16 B
     extern __shared__ __align__(16) unsigned char fsm32[];
-    T* hbuf0 = reinterpret_cast<T*>(fsm32);               // [2][SROWS*HP]
-    T* gst = hbuf0 + 2 * SROWS * HP;                       // [SROWS][GXP]
+    HT* hbuf0 = reinterpret_cast<HT*>(fsm32);             // [2][HBUF]
+    T* gst = reinterpret_cast<T*>(hbuf0 + 2 * HBUF);       // [SROWS][GXP]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
     const int nbt = gridDim.x, bt = blockIdx.x;
@@ -147,9 +201,9 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
     const bool ok = b < B;
     const int bc = min(b, B - 1);
 
-    typename Rec<T>::template Frag<SH> wf[4];            // this wave's W_hh rows: gate g, hidden units 32w + (lane & 31)
+    typename P::template Frag<SH> wf[4];                 // this wave's W_hh rows: gate g, hidden units 32w + (lane & 31)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) Rec<T>::template load_a<SH>(wf[g], a.whh + ((size_t)(dir * 4 + g) * SH + 32 * w + r) * SH, hh, 1);
+    for (int g = 0; g < 4; ++g) P::template load_a<SH>(wf[g], a.whh + ((size_t)(dir * 4 + g) * SH + 32 * w + r) * SH, hh, 1);
 
     // lane owns batch row b and hidden units u(q) = 32w + 8q + 4hh + {0..3}, q = 0..3 (accumulator register k = 4q + j)
     float c[16];
@@ -164,7 +218,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
         V4 hb, cb;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; cb[j] = (T)cv[j]; c[4 * q + j] = cv[j]; }
-        *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
+        if constexpr (X3) RecX3::store4(hbuf0 + r * HP + u, hbuf0 + SROWS * HP + r * HP + u, hv);
+        else *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
         if (a.boundary && ok) {
             T* slot = dir ? a.out + (size_t)R * B * 2 * SH : a.out - (size_t)B * 2 * SH;
             *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
@@ -190,8 +245,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
     for (int step = 0; step < R; ++step) {
         const int t = dir ? R - 1 - step : step;
         const int cur = step & 1;
-        const T* hcur = hbuf0 + cur * SROWS * HP;
-        T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
+        const HT* hcur = hbuf0 + cur * HBUF;
+        HT* hnxt = hbuf0 + (cur ^ 1) * HBUF;
         sf32x16 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -204,7 +259,10 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
         lds_barrier();                                     // every wave has read its part of the staged tile
         if (step + 1 < R) request_gx(step + 1);            // lands during the MFMAs / gate math (the closing barrier waits for it)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = Rec<T>::template mma<SH>(wf[g], hcur + r * HP, hh, acc[g]);
+        for (int g = 0; g < 4; ++g) {
+            if constexpr (X3) acc[g] = RecX3::template mma<SH>(wf[g], hcur + r * HP, hcur + SROWS * HP + r * HP, hh, acc[g]);
+            else acc[g] = P::template mma<SH>(wf[g], hcur + r * HP, hh, acc[g]);
+        }
         const bool last = step == R - 1;
         const size_t row = (size_t)t * B + bc;
 #pragma unroll
@@ -222,7 +280,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
                 cv[j] = cn; hv[j] = hn;
                 hb[j] = (T)hn; ib[j] = (T)ig; fb[j] = (T)fg; gb[j] = (T)gg; ob[j] = (T)og; cb[j] = (T)cn;
             }
-            *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
+            if constexpr (X3) RecX3::store4(hnxt + r * HP + u, hnxt + SROWS * HP + r * HP + u, hv);
+            else *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
             if (a.gates) {
                 *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 0, q, hh, r)) = ib;
                 *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 1, q, hh, r)) = fb;
@@ -260,12 +319,17 @@ struct RecBwdArgs {
     int relu;              // dout is the gradient of relu(out): it passes where h_t > 0, i.e. where tanh(c_t) > 0
 };
 
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
+    static_assert(!X3 || sizeof(T) == 4, "the split products run on f32 tensors");
     typedef typename Vec4<T>::type V4;
+    typedef typename std::conditional<X3, RecX3, Rec<T>>::type P;
     constexpr int GP = Rec<T>::PITCH(S4);
+    constexpr int GPB = RecX3::PITCH(S4);               // x3: row pitch of the two bf16 images behind the f32 tile
     extern __shared__ __align__(16) unsigned char rsm[];
-    T* dgt = reinterpret_cast<T*>(rsm);                 // [32][GP] gate gradients of the current step
+    T* dgt = reinterpret_cast<T*>(rsm);                 // [32][GP] gate gradients of the current step (the rows that leave for global memory)
+    __bf16* dgh = reinterpret_cast<__bf16*>(rsm + (size_t)SROWS * GP * sizeof(T));      // x3: [32][GPB] hi image, [32][GPB] lo image: the MFMA operands
+    __bf16* dgl = dgh + SROWS * GPB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
     const int b = b0 + r;
@@ -273,9 +337,9 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
     const int bc = min(b, B - 1);
 
     // A operand: row u = 32w + (lane & 31) of W_hh^T over all 4H gate columns
-    typename Rec<T>::template Frag<S4> wt;
-    if (a.transposed) Rec<T>::template load_a<S4>(wt, a.whh + ((size_t)dir * SH + 32 * w + r) * S4, hh, 1);
-    else Rec<T>::template load_a<S4>(wt, a.whh + (size_t)dir * S4 * SH + 32 * w + r, hh, SH);
+    typename P::template Frag<S4> wt;
+    if (a.transposed) P::template load_a<S4>(wt, a.whh + ((size_t)dir * SH + 32 * w + r) * S4, hh, 1);
+    else P::template load_a<S4>(wt, a.whh + (size_t)dir * S4 * SH + 32 * w + r, hh, SH);
 
     sf32x16 dh;
     float dc[16], ccar[16];
@@ -351,6 +415,13 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
             *reinterpret_cast<V4*>(lp + SH) = df;
             *reinterpret_cast<V4*>(lp + 2 * SH) = dg;
             *reinterpret_cast<V4*>(lp + 3 * SH) = dO;
+            if constexpr (X3) {
+                const int o = r * GPB + u;
+                RecX3::store4(dgh + o, dgl + o, di);
+                RecX3::store4(dgh + o + SH, dgl + o + SH, df);
+                RecX3::store4(dgh + o + 2 * SH, dgl + o + 2 * SH, dg);
+                RecX3::store4(dgh + o + 3 * SH, dgl + o + 3 * SH, dO);
+            }
         }
         if (PREFETCH && step + 1 < R) { load_q(step + 1, 0, nx0); load_q(step + 1, 1, nx1); load_q(step + 1, 2, nx2); load_q(step + 1, 3, nx3); }
         lds_barrier();                                     // the dG tile of this step is complete
@@ -388,7 +459,8 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) dh[k] = 0.f;
-        dh = Rec<T>::template mma<S4>(wt, dgt + r * GP, hh, dh);          // dh_{prev}[u][b] = sum_n W_hh[n][u] dG[b][n]
+        if constexpr (X3) dh = RecX3::template mma<S4>(wt, dgh + r * GPB, dgl + r * GPB, hh, dh);
+        else dh = P::template mma<S4>(wt, dgt + r * GP, hh, dh);          // dh_{prev}[u][b] = sum_n W_hh[n][u] dG[b][n]
         lds_barrier();                                     // every wave is done reading the tile
         if (PREFETCH) { in0 = nx0; in1 = nx1; in2 = nx2; in3 = nx3; }
     }
@@ -726,14 +798,15 @@ static bool rec_eight_waves() {
     return on;
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int rec_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, void* out, float* hn, float* cn,
                    void* gates, void* cs, int bm, hipStream_t st) {
     RecFwdArgs<T> a{(const T*)gx, (const T*)whh, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B, (bm & 1) != 0, (bm & 2) != 0};
-    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)SROWS * (S4 + 16 / sizeof(T))) * sizeof(T);
+    const size_t lds = X3 ? (size_t)2 * 2 * SROWS * RecX3::PITCH(SH) * sizeof(__bf16) + (size_t)SROWS * (S4 + 16 / sizeof(T)) * sizeof(T)
+                          : ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)SROWS * (S4 + 16 / sizeof(T))) * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd_kernel<T, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
@@ -749,17 +822,17 @@ static int rec_fwd(const void* gx, const void* whh, const float* h0, const float
             return check_launch("lstm_rec_fwd8");
         }
     }
-    hipLaunchKernelGGL(lstm_rec_fwd_kernel<T>, dim3((B + SROWS - 1) / SROWS, 2), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((lstm_rec_fwd_kernel<T, X3>), dim3((B + SROWS - 1) / SROWS, 2), dim3(256), lds, st, a);
     return check_launch("lstm_rec_fwd");
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int rec_bwd(const void* whh, int transposed, const void* gates, const void* cs, const void* dout, const float* dhn,
                    const float* dcn, int R, int B, void* dgx, float* dh0, float* dc0, float* dbias, void* workspace, int bm, int relu, hipStream_t st) {
-    const size_t lds = (size_t)SROWS * Rec<T>::PITCH(S4) * sizeof(T);
+    const size_t lds = (size_t)SROWS * Rec<T>::PITCH(S4) * sizeof(T) + (X3 ? (size_t)2 * SROWS * RecX3::PITCH(S4) * sizeof(__bf16) : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_bwd_kernel<T, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
@@ -779,7 +852,7 @@ static int rec_bwd(const void* whh, int transposed, const void* gates, const voi
             eight = true;
         }
     }
-    if (!eight) hipLaunchKernelGGL(lstm_rec_bwd_kernel<T>, dim3(nwg, 2), dim3(256), lds, st, a);
+    if (!eight) hipLaunchKernelGGL((lstm_rec_bwd_kernel<T, X3>), dim3(nwg, 2), dim3(256), lds, st, a);
     if (dbias) hipLaunchKernelGGL(lstm_rec_dbias_finalize, dim3(2 * S4 / 32), dim3(256), 0, st, (const float*)workspace, nwg, dbias);
     return check_launch("lstm_rec_bwd");
 }
@@ -795,9 +868,10 @@ int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0
     const int state_batch_major = state_flags;      // (bit 0: batch-major states; bit 1: boundary slots -- see dic_hip.h)
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_rec_fwd: non-positive size");
     DIC_REQUIRE(H == SH, DIC_ERR_UNSUPPORTED, "lstm_rec_fwd: hidden size %d (compiled for %d)", H, SH);
-    DIC_REQUIRE(dtype == DIC_DTYPE_F32 || dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "lstm_rec_fwd: dtype %d", dtype);
+    DIC_REQUIRE(dtype == DIC_DTYPE_F32 || dtype == DIC_DTYPE_BF16 || dtype == DIC_DTYPE_F32X3, DIC_ERR_INVALID_ARG, "lstm_rec_fwd: dtype %d", dtype);
     DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_rec_fwd: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_rec_fwd: gates and cs go together");
+    if (dtype == DIC_DTYPE_F32X3) return rec_fwd<float, true>(gx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_batch_major, (hipStream_t)stream);
     if (dtype == DIC_DTYPE_F32) return rec_fwd<float>(gx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_batch_major, (hipStream_t)stream);
     return rec_fwd<__bf16>(gx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_batch_major, (hipStream_t)stream);
 }
@@ -809,10 +883,12 @@ int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const vo
                      void* workspace, size_t workspace_bytes, int state_batch_major, int dout_of_relu, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_rec_bwd: non-positive size");
     DIC_REQUIRE(H == SH, DIC_ERR_UNSUPPORTED, "lstm_rec_bwd: hidden size %d (compiled for %d)", H, SH);
-    DIC_REQUIRE(dtype == DIC_DTYPE_F32 || dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "lstm_rec_bwd: dtype %d", dtype);
+    DIC_REQUIRE(dtype == DIC_DTYPE_F32 || dtype == DIC_DTYPE_BF16 || dtype == DIC_DTYPE_F32X3, DIC_ERR_INVALID_ARG, "lstm_rec_bwd: dtype %d", dtype);
     DIC_REQUIRE(whh && gates && cs && dgx && dh0 && dc0, DIC_ERR_INVALID_ARG, "lstm_rec_bwd: NULL pointer");
     DIC_REQUIRE(!dbias || (workspace && workspace_bytes >= dic_lstm_rec_bwd_workspace(B)), DIC_ERR_WORKSPACE,
                 "lstm_rec_bwd: dbias needs %zu B of workspace", dic_lstm_rec_bwd_workspace(B));
+    if (dtype == DIC_DTYPE_F32X3)
+        return rec_bwd<float, true>(whh, whh_is_transposed, gates, cs, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, dout_of_relu, (hipStream_t)stream);
     if (dtype == DIC_DTYPE_F32)
         return rec_bwd<float>(whh, whh_is_transposed, gates, cs, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, dout_of_relu, (hipStream_t)stream);
     return rec_bwd<__bf16>(whh, whh_is_transposed, gates, cs, dout, dhn, dcn, R, B, dgx, dh0, dc0, dbias, workspace, state_batch_major, dout_of_relu, (hipStream_t)stream);

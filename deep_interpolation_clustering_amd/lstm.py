@@ -189,7 +189,7 @@ class _BiLstm(torch.autograd.Function):
                 gx = _ops.gemm_nt(xb.view(R * B, Ip), wih, bias.float())
             else:
                 gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
-            N.check(L.dic_lstm_rec_fwd(code, N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
+            N.check(L.dic_lstm_rec_fwd(N.DTYPE_F32X3 if x3 else code, N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
                                        N.ptr(gates), N.ptr(cs), int(bm) | (2 if kernel_boundary else 0), st), 'dic_lstm_rec_fwd')
         else:
             if need:
@@ -246,7 +246,7 @@ class _BiLstm(torch.autograd.Function):
         dbias = torch.empty((2, 4 * H), device=dev, dtype=torch.float32)         # summed inside the kernel, f32
         if small:
             ws = torch.empty(max(16, Lb.dic_lstm_rec_bwd_workspace(B)), device=dev, dtype=torch.uint8)
-            N.check(Lb.dic_lstm_rec_bwd(code, N.ptr(whh_b), int(not f32), N.ptr(gates), N.ptr(cs), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
+            N.check(Lb.dic_lstm_rec_bwd(N.DTYPE_F32X3 if ctx.x3 else code, N.ptr(whh_b), int(not f32), N.ptr(gates), N.ptr(cs), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
                                         R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), int(relu), st), 'dic_lstm_rec_bwd')
         else:
             ws = torch.empty(max(16, Lb.dic_lstm_bwd_workspace(B)), device=dev, dtype=torch.uint8)

@@ -315,6 +315,7 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
  * recurrent input for the weight-gradient kernels, as dic_lstm_fwd's `boundary` does (two fill / copy launches per LSTM less). */
 #define DIC_DTYPE_F32 0
 #define DIC_DTYPE_BF16 1
+#define DIC_DTYPE_F32X3 2   /* dic_lstm_rec_fwd / _bwd only: f32 tensors, the recurrent products as three-term bf16 splits (hi.hi + lo.hi + hi.lo) on the bf16 matrix cores */
 int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H, void* out,
                      float* hn, float* cn, void* gates, void* cs, int state_flags, dic_stream_t stream);
 size_t dic_lstm_rec_bwd_workspace(int B);

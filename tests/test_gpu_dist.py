@@ -432,6 +432,29 @@ def test_bench_runs_sharded_on_two_ranks(tmp_path):
     assert abs(rec['value'] - 512 * 3 / (rec['ms_per_step'] * 3e-3)) <= 0.01 * rec['value']
 
 
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with NO launcher around it (the shape of the driver's single-GPU command with another N; the reference's
+    multi-GPU entry is a plain ``python p1...py --num_gpus N``, pretrain_trainer.py:21): the parent starts the ranks through
+    torch.distributed.run without touching the GPU itself and relays rank 0's line; a WORLD_SIZE that contradicts --gpus still fails."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIC_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '512',
+           '--encounters', '4096', '--no-secondary', '--no-cpu-baseline', '--kernel-iters', '1']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['global_batch'] == 1024
+    bad = subprocess.run(cmd, env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=280, cwd=root)
+    assert bad.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in bad.stderr
+
+
 def test_sharded_paths_on_rccl_with_one_rank(tmp_path):
     """The box has one GPU, and RCCL wants one GPU per rank: so ONE rank joins a `nccl` process group (dist.init_from_env as on a real
     node: device_id, current device) with DIC_DIST_SINGLE_RANK=1, which makes that world count as sharded.  Every collective of the

@@ -203,7 +203,8 @@ def test_joint_step_wide_shape_bf16_tracks_f32(B):
             losses, gnorm, _ = st.step(x, ob, None, ln)
             out.append([float(losses[k].detach()) for k in ('loss', 'ae_mse', 'kl')] + [float(gnorm)])
         traj[mode] = np.array(out)
-    np.testing.assert_allclose(traj['bf16'][:, :3], traj['f32'][:, :3], rtol=2e-2, atol=1e-4)      # (atol: KL falls to 1e-3 within three steps here)
+    np.testing.assert_allclose(traj['bf16'][:, :2], traj['f32'][:, :2], rtol=2e-2)
+    np.testing.assert_allclose(traj['bf16'][:, 2], traj['f32'][:, 2], rtol=2e-2, atol=5e-4)      # (KL falls from 0.04 to ~2e-3 within three steps here)
     np.testing.assert_allclose(traj['bf16'][:, 3], traj['f32'][:, 3], rtol=5e-2)
     assert traj['f32'][2, 1] < traj['f32'][0, 1]
 
