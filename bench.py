@@ -343,6 +343,14 @@ def record_small_batch(make_stepper, X, OB, LEN, batch=256, steps=100):
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / steps
         out[mode] = {'ms_per_step': round(ms, 4), 'encounters_per_s': round(batch / ms * 1e3, 1)}
+        if not graphs:          # what the step launches at this batch size: the library-GEMM share must be zero on the bf16 small-batch path
+            try:
+                kernels, groups = step_trace(one, 0, 2)
+                out['launches_per_step'] = round(sum(g['launches_per_step'] for g in groups.values()), 1)
+                out['library_gemm_ms'] = groups.get('library_gemm', {}).get('ms_per_step', 0.0)
+                out['library_gemm_kernels'] = [k for k in kernels if _group(k) == 'library_gemm']
+            except Exception as e:
+                out['step_trace_error'] = repr(e)[:200]
         del st
     return out
 
@@ -380,23 +388,69 @@ def record_fake_detection(K, dev, X, OB, LEN, batch, steps=12, warmup=4):
     return {'loss': 'ae_mse + fake_detection + 10*kl', 'per_gpu_batch': batch, 'ms_per_step': round(ms, 3), 'encounters_per_s': round(batch / ms * 1e3, 1)}
 
 
-def record_f32(make_stepper_f32, X, OB, LEN, batch=4096, steps=10):
-    """No autocast: every GEMM / recurrence operand in f32 -- the configuration of the 1e-5 parity tests."""
-    st = make_stepper_f32()
-    nb = X.shape[0] // batch
+F32_MFMA_PEAK_TF, BF16_MFMA_PEAK_TF = 157.3, 2500.0      # /opt/skills/guides/MI355X_MICROARCH.md: dense matrix-core peaks
+
+
+def f32_roofline(kernels, batch, products):
+    """Roofline of the dominant kernel of an f32 step (``products`` 'exact' / 'x3') from its step trace.  The 32-row recurrence kernels
+    (csrc/dic_lstm32.hip) carry f32 tensors: per (step, row, direction) unit the forward reads gx (4H f32) and writes h, the four gates and c
+    (5 120 B); the backward reads gates, c_prev, dL/dout and writes dG (5 120 B); both do 2 x 4H x H flops of recurrent product -- on
+    v_mfma_f32_32x32x2_f32 ('exact': priced against the f32 matrix-core peak) or as three bf16 MFMAs ('x3': 3 x the flops against the bf16
+    peak).  ``frac`` is the larger of the two fractions and ``bound`` says which one it is."""
+    units = 2.0 * R * batch
+    rows = []
+    for name, v in kernels.items():
+        if name.startswith('dic::lstm_rec_'):
+            rows.append((v['ms_per_step'], name, v))
+    if not rows:
+        return None
+    _, name, v = max(rows)
+    ms = v['us_per_launch'] / 1e3
+    nbytes = units * 5120.0
+    flop = units * 2.0 * 512 * 128
+    gbps = nbytes / ms / 1e6
+    if products == 'x3':
+        tf, peak_tf = 3.0 * flop / ms / 1e9, BF16_MFMA_PEAK_TF
+    else:
+        tf, peak_tf = flop / ms / 1e9, F32_MFMA_PEAK_TF
+    f_hbm, f_mfma = gbps / HBM_PEAK_GBS, tf / peak_tf
+    bound = 'hbm' if f_hbm >= f_mfma else 'mfma'
+    return {'kernel': name, 'bound': bound, 'achieved': round(gbps if bound == 'hbm' else tf, 1), 'peak': HBM_PEAK_GBS if bound == 'hbm' else peak_tf,
+            'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s', 'frac': round(max(f_hbm, f_mfma), 4), 'frac_hbm': round(f_hbm, 4), 'frac_mfma': round(f_mfma, 4),
+            'ms_per_launch': round(ms, 4), 'launches_per_step': v['launches_per_step'], 'algorithmic_bytes_per_launch': int(nbytes),
+            'matrix_core_flop_per_launch': int(flop * (3 if products == 'x3' else 1)), 'traffic': None,
+            'duration_source': 'in-step: per-dispatch durations of this kernel in a trace of the timed steps'}
+
+
+def record_f32(make_stepper, one_batch, nb, batch, products, steps=20, warmup=4):
+    """The f32 step -- every tensor f32, the reference's own arithmetic (clustering_interp.py:14-41, dataloader.py:204) -- at the HEADLINE batch on
+    the headline's input path (the ragged store read in place): ``products`` 'exact' = exact-f32 MFMA recurrence + f32 library GEMMs (the 1e-5
+    parity configuration of the test suite), 'x3' = every dense product a three-term bf16 split on the matrix cores (csrc/dic_gemm.hip, the
+    split recurrence kernels; no library GEMM).  With its own step trace and roofline."""
+    st = make_stepper(products)
 
     def one(i):
-        lo = (i % nb) * batch
-        return st.step(X[lo:lo + batch], OB[lo:lo + batch], None, LEN[lo:lo + batch])
-    for i in range(4):
+        return st.step(*one_batch(i % nb))
+    for i in range(warmup):
         one(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        one(4 + i)
+        one(warmup + i)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
-    return {'per_gpu_batch': batch, 'ms_per_step': round(ms, 3), 'encounters_per_s': round(batch / ms * 1e3, 1)}
+    out = {'products': products, 'per_gpu_batch': batch, 'steps': steps, 'ms_per_step': round(ms, 3), 'encounters_per_s': round(batch / ms * 1e3, 1),
+           'input': 'ragged encounter store read in place (the headline\'s input path)'}
+    try:
+        kernels, groups = step_trace(one, warmup + steps, 2)
+        out['step_trace'] = {'groups': groups, 'top_kernels': dict(list(kernels.items())[:14])}
+        out['library_gemm_ms'] = groups.get('library_gemm', {}).get('ms_per_step', 0.0)
+        out['roofline'] = f32_roofline(kernels, batch, products)
+        gflop = FLOP_PER_ENCOUNTER * batch / 1e9
+        out['whole_step_tflops(useful)'] = round(gflop / ms, 1)
+    except Exception as e:
+        out['step_trace_error'] = repr(e)[:200]
+    return out
 
 
 def record_loss_deviation(K, dev):
@@ -412,7 +466,7 @@ def record_loss_deviation(K, dev):
     x, ob = torch.tensor(x_np), torch.tensor(ob_np)
     args = make_args(K)
     out = {}
-    for mode, dt in (('f32', None), ('bf16', torch.bfloat16)):
+    for mode, dt, prec in (('f32', None, 'exact'), ('f32x3', None, 'x3'), ('bf16', torch.bfloat16, None)):
         torch.manual_seed(0)
         ref = O.OracleNet(C, R, H, K, 0.0)
         with torch.no_grad():       # the p3 regime: centroids sit on the latents' clusters (here: phenotype means), KL is O(0.1) and well conditioned
@@ -423,7 +477,7 @@ def record_loss_deviation(K, dev):
         net.load_state_dict(ref.state_dict(), strict=True)
         net.train()
         rterms, _, _ = O.train_step(ref, O.make_optimizer(ref), x, ob, x[:, C:2 * C], 10.0, 15.0)
-        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=dt)
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=dt, precision=prec)
         losses, _, _ = st.step(x.to(dev), ob.to(dev), None, torch.tensor(n, device=dev))
         torch.cuda.synchronize()
         out[mode] = {k: float(abs(float(losses[k].detach()) - rterms[k]) / max(abs(rterms[k]), 1e-30)) for k in ('loss', 'ae_mse', 'kl')}
@@ -443,8 +497,53 @@ def record_cfg4(dev, iters, batch=8192):
     a.num_variables, a.num_timestamps = C4, T4
     net = Net(a, dev).to(dev)
     table = kernel_table(net, x, ob, ln, K4, iters, with_lstm=False)
-    return {'workload': f'C={C4}, T={T4}, ~{int(LAM4)} obs/channel, R={R}, K={K4}, batch {batch} (300k-encounter cohort streams through in batches)',
-            'kernels': table}
+    out = {'workload': f'C={C4}, T={T4}, ~{int(LAM4)} obs/channel, R={R}, K={K4}, batch {batch} (300k-encounter cohort streams through in batches)',
+           'kernels': table}
+    # the JOINT STEP at this shape (encoder input 3C = 36: 64-wide packed rows through k1 -> fused-projection recurrence -> one-pass dW), bf16 mode,
+    # ragged store input; pinned against the reference by tests/test_gpu_traj.py::test_joint_step_wide_shape_K16 (f32) / ..._bf16_tracks_f32
+    try:
+        from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore
+        from deep_interpolation_clustering_amd.step import Stepper
+        from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+        store = RaggedStore(x_np, C4, dev)
+        del x, ob
+        torch.manual_seed(1234)
+        net = Net(a, dev).to(dev)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), a, autocast_dtype=torch.bfloat16)
+        perm = torch.randperm(batch, device=dev, generator=torch.Generator(device=dev).manual_seed(2)).to(torch.int32)
+        rb = RaggedBatch(store, perm)
+
+        def one(i):
+            return st.step(rb, None, None)
+        for i in range(4):
+            one(i)
+        torch.cuda.synchronize()
+        steps = 20
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        rec = {'per_gpu_batch': batch, 'dtype': 'bf16', 'steps': steps, 'ms_per_step': round(ms, 3), 'encounters_per_s': round(batch / ms * 1e3, 1),
+               'input': 'ragged encounter store, shuffled index'}
+        kernels, groups = step_trace(one, 0, 2)
+        rec['step_trace'] = {'groups': groups, 'top_kernels': dict(list(kernels.items())[:16])}
+        rec['library_gemm_ms'] = groups.get('library_gemm', {}).get('ms_per_step', 0.0)
+        units = 2.0 * R * batch
+        dom = max(((v['ms_per_step'], k, v) for k, v in kernels.items() if k.startswith('dic::')), default=None)
+        if dom is not None:
+            _, k, v = dom
+            per_unit = {'dic::lstm_bwd8_kernel': 2560, 'dic::lstm_bwd_kernel': 2560, 'dic::lstm_fwd8_gxn_kernel': 2560, 'dic::lstm_fwd_kernel': 2560,
+                        'dic::lstm_fwd8_proj_kernel': 1536 + 64}.get(k.split('<')[0])
+            rec['dominant_kernel'] = {'kernel': k, 'ms_per_launch': round(v['us_per_launch'] / 1e3, 4), 'launches_per_step': v['launches_per_step']}
+            if per_unit:
+                nb_ = units * per_unit
+                rec['dominant_kernel'].update({'algorithmic_bytes_per_launch': int(nb_), 'frac_hbm_peak': round(nb_ / (v['us_per_launch'] / 1e3) / 1e6 / HBM_PEAK_GBS, 4)})
+        out['step'] = rec
+    except Exception as e:
+        out['step'] = {'error': repr(e)[:300]}
+    return out
 
 
 def record_cfg5(dev, sweep=True):
@@ -563,7 +662,25 @@ def cpu_model():
     return platform.processor() or 'unknown'
 
 
-def cpu_baseline(K, seconds, B=256, threads=None, max_steps=200):
+def cpu_quota_cores():
+    """CPU time this process may use, in cores: the cgroup quota when there is one (the GPU box shows 256 cores in the affinity mask but grants
+    a 16-core share: 256 threads on it take minutes per step), else None."""
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    return max(1, int(round(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    return max(1, int(round(q / int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read()))))
+        except (OSError, ValueError, IndexError):
+            pass
+    return None
+
+
+def cpu_baseline(K, seconds, B=256, threads=None, max_steps=200, all_cores=False):
     """The CPU oracle (a port of the reference's PyTorch path: oracle/dic_oracle.py) timed on this host.
     B = 256 is the reference's own batch size (p1_pretrain_main.py:43); SURVEY.md 8d also asks for B = 2048 and for 8 threads."""
     from deep_interpolation_clustering_amd import synthetic
@@ -572,7 +689,11 @@ def cpu_baseline(K, seconds, B=256, threads=None, max_steps=200):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get('DIC_CPU_THREADS', 16))))    # the GPU box grants ~16 cores per GPU
+    quota = cpu_quota_cores()
+    if all_cores:          # every core this process may actually use: the affinity mask, capped by the cgroup quota (never oversubscribe: see cpu_quota_cores)
+        cores = max(1, min(cores, quota or cores, int(os.environ.get('DIC_CPU_THREADS_MAX', 64))))
+    else:
+        cores = max(1, min(cores, int(os.environ.get('DIC_CPU_THREADS', 16))))    # the GPU box grants ~16 cores per GPU
     if threads:
         cores = max(1, min(cores, threads))
     torch.set_num_threads(cores)
@@ -597,7 +718,9 @@ def cpu_baseline(K, seconds, B=256, threads=None, max_steps=200):
     except AttributeError:
         host_cores = os.cpu_count() or 1
     return {'value': round(B * n / el, 1), 'unit': 'encounters/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
-            'cores_available': host_cores,
+            'cores_available': host_cores, 'cpu_quota_cores': quota,
+            'port_note': 'oracle/dic_oracle.py: the reference path restated with broadcasting ops (fewer (B,C,T,R) temporaries than upstream\'s '
+                         'repeat / log / exp sequence): if anything FASTER than the reference\'s own modules on the same cores',
             'sample': f'{n} joint steps of B={B} (C={C}, T={T}, R={R}, K={K}, f32) on torch-CPU, {el:.1f} s',
             'ms_per_step': round(1e3 * el / n, 2)}
 
@@ -652,7 +775,12 @@ def main():
     # the cohort as the trainers' DeviceLoader keeps it: a ragged store (observed samples only, packed); a batch = an index range into it
     from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore
     store = None if a.dense_input else RaggedStore(x_np, C, dev)
-    IDX = torch.arange(n_enc, device=dev, dtype=torch.int32)
+    # batches are drawn from a shuffled index, as the trainers' DeviceLoader does (a contiguous slab of the packed store would be the most
+    # favourable access pattern for the in-place reads: ~1 KB row groups behind an index -> row_off -> samples chain are what a real epoch sees)
+    PERM = torch.randperm(n_enc, device=dev, generator=torch.Generator(device=dev).manual_seed(7529 + rank))
+    shuffled = store is not None and not a.fake_detection       # (--fake-detection keeps file order: its corrupted copies XF are a padded tensor in that order)
+    IDX = PERM.to(torch.int32) if shuffled else torch.arange(n_enc, device=dev, dtype=torch.int32)
+    LEN_B = LEN.index_select(0, PERM).contiguous() if shuffled else LEN      # lengths in batch order
     del coh, x_np, ob_np
     nb = max(1, n_enc // a.batch)
     log(f'rank {rank}: {n_enc} encounters resident after {time.perf_counter() - t_start:.1f}s ({a.scaling} scaling, {a.batch} per step and rank)')
@@ -661,7 +789,8 @@ def main():
     net = Net(args, dev).to(dev)
     net.train()
     stepper = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args,
-                      autocast_dtype=torch.bfloat16 if a.dtype == 'bf16' else None, use_graphs=a.graph)
+                      autocast_dtype=torch.bfloat16 if a.dtype == 'bf16' else None, use_graphs=a.graph,
+                      precision={'f32': 'exact', 'f32x3': 'x3'}.get(a.dtype))
 
     XF = label2 = None
     if a.fake_detection:          # corrupted copies as dataloader.py:182-193 makes them (half of each channel's samples -> noise)
@@ -675,13 +804,13 @@ def main():
     def one_step(i):
         lo = (i % nb) * a.batch
         if store is not None:
-            xb, obb = RaggedBatch(store, IDX[lo:lo + a.batch], LEN[lo:lo + a.batch]), None
+            xb, obb = RaggedBatch(store, IDX[lo:lo + a.batch], LEN_B[lo:lo + a.batch]), None
         else:
             xb, obb = X[lo:lo + a.batch], OB[lo:lo + a.batch]
         if XF is None:
-            return stepper.step(xb, obb, None, LEN[lo:lo + a.batch])
+            return stepper.step(xb, obb, None, LEN_B[lo:lo + a.batch])
         perm = torch.randperm(2 * a.batch, device=dev)                       # as the trainers draw it (pretrain_trainer.py:156-160)
-        return stepper.step(xb, obb, None, LEN[lo:lo + a.batch], fake_x=XF[lo:lo + a.batch],
+        return stepper.step(xb, obb, None, LEN_B[lo:lo + a.batch], fake_x=XF[lo:lo + a.batch],
                             fake_perm_idx=perm, fake_det_label=label2[perm].to(torch.int64))
 
     def barrier():
@@ -785,14 +914,18 @@ def main():
             'metric': 'encounters/sec per joint interp+DEC step', 'value': round(value, 1), 'unit': 'encounters/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
-            'dtype': a.dtype, 'dtype_note': 'HIP kernels compute in f32; bf16 = torch.autocast for the bi-LSTMs / FC heads only '
-                                            '(outside the 1e-5 parity configuration: see loss_rel_dev_vs_oracle)',
+            'dtype': a.dtype, 'dtype_note': {'bf16': 'HIP kernels compute in f32; bf16 = torch.autocast for the bi-LSTMs / FC heads only '
+                                                     '(outside the 1e-5 parity configuration: see loss_rel_dev_vs_oracle; the f32 / f32x3 records carry the parity-grade rates)',
+                                             'f32': 'every tensor and product f32: exact-f32 MFMA recurrence, f32 library GEMMs (the 1e-5 parity configuration of the tests)',
+                                             'f32x3': 'every tensor f32; every dense product a three-term bf16 split (hi.hi + lo.hi + hi.lo) on the bf16 matrix cores '
+                                                      'with f32 accumulation: no library GEMM; losses within 1e-5 of the reference (loss_rel_dev_vs_oracle)'}[a.dtype],
             'data': 'synthetic',
             'config': {'workload': (f'{n_enc} of ONE {max(a.encounters, a.batch * world)}-encounter synthetic cohort per GPU' if strong else f'{n_enc} synthetic encounters/GPU') +
                                    ', 6 vitals, ~50 irregular samples per channel per 24h '
                                    f'(T={T}), R={R}, K={K}, loss ' + ('ae_mse+fake_detect+10*kl' if a.fake_detection else 'ae_mse+10*kl'), 'per_gpu_batch': a.batch,
                        'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single',
                        'tuned_gemm_table': bool(gemm_table),
+                       'index_order': 'shuffled (a per-run randperm of the cohort, as the trainers\' DeviceLoader draws batches)' if shuffled else 'file order (contiguous rows)',
                        'input': 'padded (B,4C,T) batches' if store is None else
                                 f'ragged encounter store read in place ({store.nbytes() / 1e6:.0f} MB resident; the padded array would be {n_enc * 4 * C * T * 4 / 1e6:.0f} MB)'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(dom_gbps, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -812,6 +945,10 @@ def main():
                            'hip_kernels_ms(table x launches)': round(custom_ms, 3)},
             'final_loss': final_loss,
         }
+        if a.dtype != 'bf16' and kernels is not None:       # the f32 modes run the 32-row recurrence kernels: their own roofline
+            rl = f32_roofline(kernels, a.batch, 'x3' if a.dtype == 'f32x3' else 'exact')
+            if rl:
+                out['roofline'] = rl
         if groups is not None:
             out['step_trace'] = {'groups': groups, 'top_kernels': dict(list(kernels.items())[:24]),
                                  'kernel_ms_per_step': round(sum(g['ms_per_step'] for g in groups.values()), 3),
@@ -829,25 +966,38 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(K, a.cpu_seconds)
             if not a.no_secondary:        # the other two points of SURVEY.md 8d's CPU comparison, a few seconds each
-                out['cpu_baseline_more'] = [guarded(cpu_baseline, K, 6.0, 256, 8, 60), guarded(cpu_baseline, K, 8.0, 2048, None, 12)]
+                out['cpu_baseline_more'] = [guarded(cpu_baseline, K, 6.0, 256, 8, 60), guarded(cpu_baseline, K, 8.0, 2048, None, 12),
+                                            guarded(cpu_baseline, K, 8.0, 2048, None, 6, True)]      # every core the process may use (count stated; capped by the cgroup quota and at 64)
         if world == 1 and not a.no_secondary:
             del stepper
             torch.cuda.empty_cache()
             opt_f = lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4)      # noqa: E731
 
-            def fresh(dtype, graphs):
+            def fresh(dtype, graphs, precision=None):
                 torch.manual_seed(1234)
                 n2 = Net(args, dev).to(dev)
                 n2.train()
-                return Stepper(n2, opt_f, args, autocast_dtype=dtype, use_graphs=graphs)
+                return Stepper(n2, opt_f, args, autocast_dtype=dtype, use_graphs=graphs, precision=precision)
             out['batch256'] = guarded(record_small_batch, lambda g: fresh(torch.bfloat16, g), X, OB, LEN)
             log('batch256 done', out['batch256'])
             # SURVEY.md 8d's throughput sweep (B = 256, 2 048, 16 384 per GPU; 256 is the record above, the headline is 32 768)
             out['batch_sweep'] = {str(bs): guarded(record_small_batch, lambda g: fresh(torch.bfloat16, g), X, OB, LEN, bs, st_)
-                                  for bs, st_ in ((2048, 60), (16384, 20))}
+                                  for bs, st_ in ((2048, 60), (4096, 40), (16384, 20))}
             log('batch sweep done', out['batch_sweep'])
-            out['f32'] = guarded(record_f32, lambda: fresh(None, False), X, OB, LEN)
-            log('f32 done', out['f32'])
+            # the f32 step at the headline batch on the headline's input path: the reference's own arithmetic ('exact') and the same tensors with
+            # every dense product as a three-term bf16 split on the matrix cores ('x3': the parity-grade throughput record)
+            if store is not None:
+                def f32_batch(i):
+                    lo_ = i * a.batch
+                    return RaggedBatch(store, IDX[lo_:lo_ + a.batch], LEN_B[lo_:lo_ + a.batch]), None, None
+            else:
+                def f32_batch(i):
+                    lo_ = i * a.batch
+                    return X[lo_:lo_ + a.batch], OB[lo_:lo_ + a.batch], None, LEN[lo_:lo_ + a.batch]
+            for key, products in (('f32x3', 'x3'), ('f32', 'exact')):
+                out[key] = guarded(record_f32, lambda pr: fresh(None, False, pr), f32_batch, nb, a.batch, products)
+                torch.cuda.empty_cache()
+                log(key, 'done', {k: v for k, v in out[key].items() if k in ('ms_per_step', 'encounters_per_s', 'library_gemm_ms', 'roofline', 'error')})
             out['fake_detection_objective'] = guarded(record_fake_detection, K, dev, X, OB, LEN, a.batch)
             log('fake-detection objective done', out['fake_detection_objective'])
             out['loss_rel_dev_vs_oracle'] = guarded(record_loss_deviation, K, dev)

@@ -74,6 +74,8 @@ EXTRA = [   # not upstream
     ('MI355X options', ('--amp_bf16',), dict(action='store_true', help='bf16 autocast for the bi-LSTMs / FC heads')),
     ('MI355X options', ('--hip_graph',), dict(action='store_true', default=None, help='always replay the training step from a captured hipGraph (single GPU); default: automatically for batches up to 8192 encounters, where the step is launch-bound')),
     ('MI355X options', ('--no_hip_graph',), dict(action='store_true', help='never capture the training step (eager launches)')),
+    ('MI355X options', ('--cpu_padded_ob',), dict(action='store_true', help="feature dumps: write the padded slots of 'ob' as a CPU run of the reference does "
+                                                                             "(masked in place before the dump) instead of as its GPU runs do")),
     ('MI355X options', ('--no_aux',), dict(action='store_true', help='shorthand: aux_tasks={} (the synthetic cohorts carry no outcome tables)')),
     ('MI355X options', ('--no_fake',), dict(action='store_true', help='shorthand: fake_detection=False')),
 ]

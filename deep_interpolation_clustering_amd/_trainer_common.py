@@ -78,7 +78,8 @@ class TrainerBase(object):
             cache = self.__dict__.setdefault('_eval_loaders', {})
             if cohort not in cache:
                 from .dataloader import DeviceLoader
-                cache[cohort] = DeviceLoader(dl.ds, dl.batch_size, False, dl.device, seed=0, shard=True, keep_every_row=True)
+                cache[cohort] = DeviceLoader(dl.ds, dl.batch_size, False, dl.device, seed=0, shard=True, keep_every_row=True,
+                                             store=getattr(dl, 'store', None), ragged='auto' if getattr(dl, 'store', None) is not None else False)
             return cache[cohort]
         return dl
 
@@ -89,7 +90,12 @@ class TrainerBase(object):
         world = getattr(dl, 'world', 1)
         if world <= 1:
             return local
-        rows = [dl.shard_rows(r) for r in range(world)]
+        rows = dl.__dict__.get('_rank_rows')              # (a pure function of the loader: computed once, not per key of the record)
+        if rows is None:
+            rows = dl._rank_rows = [dl.shard_rows(r) for r in range(world)]
+            if sum(r.numel() for r in rows) != len(dl.ds):
+                raise RuntimeError(f'sharded pass: the loader covers {sum(r.numel() for r in rows)} of {len(dl.ds)} rows (it must keep every row: '
+                                   'an unshuffled loader with keep_every_row=True)')
         if rows[dl.rank].numel() != local.shape[0]:
             raise RuntimeError(f'sharded pass produced {local.shape[0]} rows, the loader promises {rows[dl.rank].numel()}')
         kind = local.dtype
@@ -213,6 +219,11 @@ class TrainerBase(object):
                     sums[k] = sums[k] + v
                 n_batches += 1
                 rec = {k: v for k, v in b['sample'].items() if k not in ('lengths', 'ragged')}      # inputs + labels, as upstream dumps them
+                if getattr(self.args, 'cpu_padded_ob', False) and torch.is_tensor(rec.get('ob')) and torch.is_tensor(rec.get('padding_mask')):
+                    # upstream masks the observations IN PLACE before the forward (`ob *= padding_mask`, clustering_trainer.py:299-303): on a CPU run
+                    # `.to(device)` is the identity, so the loader's tensor -- the one the dump keeps -- is the masked one (padded slots 0 ->
+                    # mid-range after re_norm_data); on a GPU run the dump keeps the loader's -scale/2.  This switch writes the CPU run's bytes.
+                    rec['ob'] = rec['ob'] * rec['padding_mask']
                 rec.update(aux_pred)
                 rec['hidden'], rec['rec_ob'] = hidden, rec_ob
                 ob_pred_lst.append(rec)

@@ -158,21 +158,28 @@ class DeviceLoader:
     When the job is sharded (one process per GPU) each rank iterates its contiguous shard of every global batch."""
 
     def __init__(self, ds: DataSet, batch_size, shuffle, device, drop_last=False, seed=None, shard=True, keep_every_row=False,
-                 ragged='auto', dense_samples=None):
+                 ragged='auto', dense_samples=None, store=None):
         """``ragged`` ('auto' / True / False): keep the cohort as a ``ragged.RaggedStore`` (observed samples only, packed) instead of the
         padded (N,4C,T) array -- 'auto': whenever the cohort is prefix-masked with constant padding (what p0 writes).  Every sample dict
         then carries ``'ragged'``, a ``RaggedBatch`` the kernels read the store through.  ``dense_samples`` (None = automatic): also
         rebuild the padded per-batch tensors ('ob', 'padding_mask', 'timestamp', 'ae_mask'); automatic = only where something consumes
-        them (unshuffled = evaluation / dump passes, fake-detection copies, augmentation)."""
+        them (unshuffled = evaluation / dump passes, fake-detection copies, augmentation).  ``store``: an existing ``RaggedStore`` of THIS
+        dataset on this device (another loader's: the sharded evaluation loaders share the training loader's instead of packing and
+        uploading the cohort a second time)."""
         from . import dist
         from .ragged import RaggedStore
         self.ds, self.batch_size, self.shuffle, self.device, self.drop_last = ds, int(batch_size), shuffle, device, drop_last
         self.C = ds.num_features
-        use_store = ragged is True or (ragged == 'auto' and torch.device(device).type == 'cuda' and ds.prefix_masks
-                                       and RaggedStore.fits(ds.feed_data, self.C))
-        if ragged is True and not RaggedStore.fits(ds.feed_data, self.C):
-            raise ValueError('DeviceLoader(ragged=True): the cohort is not prefix-masked with constant padding')
-        self.store = RaggedStore(ds.feed_data, self.C, device) if use_store else None
+        if store is not None:
+            if store.N != len(ds) or store.C != self.C or torch.device(store.device) != torch.device(device):
+                raise ValueError('DeviceLoader(store=...): the store does not belong to this dataset / device')
+            use_store = True
+        else:
+            use_store = ragged is True or (ragged == 'auto' and torch.device(device).type == 'cuda' and ds.prefix_masks
+                                           and RaggedStore.fits(ds.feed_data, self.C))
+            if ragged is True and not RaggedStore.fits(ds.feed_data, self.C):
+                raise ValueError('DeviceLoader(ragged=True): the cohort is not prefix-masked with constant padding')
+        self.store = store if store is not None else (RaggedStore(ds.feed_data, self.C, device) if use_store else None)
         self.data = None if use_store else torch.as_tensor(ds.feed_data, dtype=torch.float32, device=device)        # (N,4C,T)
         self.dense_samples = dense_samples
         self.lengths = torch.as_tensor(ds.lengths, device=device) if ds.prefix_masks else None

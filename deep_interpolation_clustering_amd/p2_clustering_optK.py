@@ -79,6 +79,7 @@ class _StreamWalker:
             self.free.put(torch.empty(shape, dtype=torch.float64, pin_memory=torch.cuda.is_available()).numpy())
         self.out = queue.Queue()
         self.shape, self.ks, self.n_ref, self.n_init, self.rank, self.world = tuple(shape), ks, n_references, n_init, rank, world
+        self.stop = threading.Event()           # set by the consumer when it gives up: the walker must not keep moving the GLOBAL stream
         self.thread = threading.Thread(target=self._walk, daemon=True)
         self.thread.start()
 
@@ -89,12 +90,21 @@ class _StreamWalker:
             for ki, k in enumerate(self.ks):
                 n_seed = seed_draw_count(k, self.n_init)
                 for i in range(self.n_ref + 1):
+                    if self.stop.is_set():
+                        return
                     mine = j % self.world == self.rank
                     j += 1
                     buf = None
                     if i < self.n_ref:
                         if mine:
-                            buf = self.free.get()
+                            buf = None
+                            while buf is None and not self.stop.is_set():        # (a consumer that raised never releases a buffer)
+                                try:
+                                    buf = self.free.get(timeout=0.2)
+                                except queue.Empty:
+                                    pass
+                            if buf is None:
+                                return
                         else:
                             buf = scratch = np.empty(self.shape, np.float64) if scratch is None else scratch
                         global_uniform_into(buf)
@@ -117,6 +127,11 @@ class _StreamWalker:
 
     def release(self, buf):
         self.free.put(buf)
+
+    def close(self):
+        """Stop walking (the consumer raised or is done) and wait for the thread: nothing touches NumPy's global stream afterwards."""
+        self.stop.set()
+        self.thread.join()
 
     def join(self):
         self.thread.join()
@@ -153,6 +168,33 @@ class KM(object):
             df.to_csv(osp.join(self.out_path, 'elbow.csv'), index=False)
         return df
 
+    def _fit_problems(self, walker, table, ks, n_references, Xd, data, lo, rng_, dev, inertia, need_minmax):
+        """The fits of this rank's (K, reference set) problems, in stream order (see compute_gap_internal_metric)."""
+        for ki, i, buf, state in walker:
+            k = ks[ki]
+            km = KMeans(n_clusters=k, n_init=self.n_init, random_state=_random_state_at(state))
+            # the walker skipped seed_draw_count(k, n_init) doubles for this fit WITHOUT running it: only right for k-means++ seeding with
+            # exactly that many restarts
+            if km.init != 'k-means++' or km._resolve_n_init(False) != walker.n_init:
+                raise RuntimeError(f'gap statistic: the stream walk assumes k-means++ seeding with n_init={walker.n_init}, got init={km.init!r}, '
+                                   f'n_init={km._resolve_n_init(False)}')
+            if i < n_references:
+                refd = torch.as_tensor(buf).to(dev).mul_(rng_).add_(lo).float()         # scale / shift / f32 cast on the device (f64 math as upstream)
+                torch.cuda.current_stream().synchronize()
+                walker.release(buf)                                                      # the walker refills it for a later set
+                table[ki, i] = np.log(inertia(km.fit_predict(refd), refd))
+                continue
+            assignments = km.fit_predict(Xd)
+            stats = cluster_stats.pair_stats(Xd, assignments, need_min=need_minmax, need_max=need_minmax)
+            table[ki, n_references] = np.log(inertia(assignments, Xd, stats))      # the same pair pass feeds the gap term and every index
+            if self.metric_sample and self.metric_sample < len(data):
+                pick = np.random.RandomState(0).choice(len(data), self.metric_sample, replace=False)
+                vals = [m(Xd[torch.as_tensor(pick, device=dev)], assignments[pick]) for m in self.internal_metrics]
+            else:
+                vals = [m(Xd, assignments, stats=stats) for m in self.internal_metrics]
+            table[ki, n_references + 1:] = vals
+        return table
+
     def compute_gap_internal_metric(self, data, k_max=5, n_references=5, version=1):
         """Gap statistic (p2:353-410): uniform reference sets over the data's bounding range, NumPy global RNG.
 
@@ -176,26 +218,12 @@ class KM(object):
         table = np.zeros((len(ks), n_references + 1 + n_met), np.float64)
         need_minmax = any(isinstance(m, DunnIndex) for m in self.internal_metrics)
         walker = _StreamWalker(data.shape, ks, n_references, KMeans(n_init=self.n_init)._resolve_n_init(False), rank, world)
-        for ki, i, buf, state in walker:
-            k = ks[ki]
-            km = KMeans(n_clusters=k, n_init=self.n_init, random_state=_random_state_at(state))
-            if i < n_references:
-                refd = torch.as_tensor(buf).to(dev).mul_(rng_).add_(lo).float()         # scale / shift / f32 cast on the device (f64 math as upstream)
-                torch.cuda.current_stream().synchronize()
-                walker.release(buf)                                                      # the walker refills it for a later set
-                table[ki, i] = np.log(inertia(km.fit_predict(refd), refd))
-                continue
-            assignments = km.fit_predict(Xd)
-            stats = cluster_stats.pair_stats(Xd, assignments, need_min=need_minmax, need_max=need_minmax)
-            table[ki, n_references] = np.log(inertia(assignments, Xd, stats))      # the same pair pass feeds the gap term and every index
-            if self.metric_sample and self.metric_sample < len(data):
-                pick = np.random.RandomState(0).choice(len(data), self.metric_sample, replace=False)
-                vals = [m(Xd[torch.as_tensor(pick, device=dev)], assignments[pick]) for m in self.internal_metrics]
-            else:
-                vals = [m(Xd, assignments, stats=stats) for m in self.internal_metrics]
-            table[ki, n_references + 1:] = vals
-        walker.join()
+        try:
+            table = self._fit_problems(walker, table, ks, n_references, Xd, data, lo, rng_, dev, inertia, need_minmax)
+        finally:
+            walker.close()
         if world > 1 or dist.is_sharded():
+
             t = torch.as_tensor(table, device=dev)
             dist.all_reduce_sum_(t)                 # disjoint entries, zeros elsewhere: the sum is the assembled table (x + 0.0 is exact)
             table = t.cpu().numpy()

@@ -25,6 +25,41 @@ def load(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 
 
+DEV_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'traj_deviation.jsonl')
+
+
+def log_deviation(test, **measured):
+    """The measured distance of this run from the reference's trajectory, one JSON line per test (gpurun_out/traj_deviation.jsonl: the
+    directory gpurun merges back; also on stdout with -s).  The tolerances below are <= 3 x the larger of these numbers (last measured
+    values: profiles/r4_traj_deviation.json) and of the reference's own run-to-run spread (tests/golden/ref_spread.json: the same trainers
+    on 8 and on 3 CPU threads)."""
+    import json
+    rec = {'test': test}
+    rec.update({k: (v.tolist() if hasattr(v, 'tolist') else v) for k, v in measured.items()})
+    line = json.dumps(rec)
+    print('[traj-deviation]', line)
+    try:
+        os.makedirs(os.path.dirname(DEV_LOG), exist_ok=True)
+        with open(DEV_LOG, 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.abs(b))) if a.size else 0.0
+
+
+# Tolerances of the trajectory tests: <= 3 x max(measured distance of the GPU run from the reference's trajectory, the reference's own
+# run-to-run spread between 8 and 3 CPU threads).  Measured values: profiles/r4_traj_deviation.json / tests/golden/ref_spread.json; both are
+# restated in DESIGN.md section 2.
+TOL = {
+    'p1_first2': 1e-5, 'p1_first8': 1e-4, 'p1_all': 1e-3, 'p1_valid': 2e-3, 'p1_state': 3e-3, 'p1_moments': 1e-2,
+    'p3_first2': 1e-5, 'p3_first8': 2e-4, 'p3_all': 3e-3, 'p3_param_norms': 2e-3,
+}
+
+
 def trainer_args(**over):
     """The namespace oracle/make_golden_traj.py gave the reference's trainers (+ this package's own switches at their defaults)."""
     a = dict(log_level='WARNING', seed=7529, num_gpus=1, mode='train', restore=False, restore_metric='ae_mse', log_train_freq=1000,
@@ -237,17 +272,20 @@ def test_pretrain_trainer_follows_reference(run_dir, kind, tmp_path):
     assert got.shape == ref.shape == (16,)
     # two f32 implementations of one Adam(amsgrad) loop separate step by step (rounding noise on near-zero gradients becomes O(lr)
     # moves); the oracle itself is 3e-5 from the reference by step 5 (tests/test_oracle_golden.py)
-    np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-5)
-    np.testing.assert_allclose(got[:8], ref[:8], rtol=1e-4)
-    np.testing.assert_allclose(got, ref, rtol=1e-3)
-    np.testing.assert_allclose(valid, t['p1/valid_batch_ae_mse'][:, 0], rtol=2e-3)          # eval mode: BatchNorm running statistics in use
+    dev_state, dev_mom = {}, {}
+    log_deviation(f'p1[{kind}]', step_loss_rel=np.abs(got - ref) / np.abs(ref), valid_rel=relmax(valid, t['p1/valid_batch_ae_mse'][:, 0]))
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=TOL['p1_first2'])
+    np.testing.assert_allclose(got[:8], ref[:8], rtol=TOL['p1_first8'])
+    np.testing.assert_allclose(got, ref, rtol=TOL['p1_all'])
+    np.testing.assert_allclose(valid, t['p1/valid_batch_ae_mse'][:, 0], rtol=TOL['p1_valid'])          # eval mode: BatchNorm running statistics in use
     np.testing.assert_allclose(lrs, t['p1/lr_after_epoch'], rtol=1e-12)
     for k, v in net.state_dict().items():
         # (a bias in front of a training-mode BatchNorm has an exactly-zero true gradient and no effect on the function: what Adam
         #  makes of it is a random walk driven by rounding noise, in the reference too)
         if v.dtype.is_floating_point and v.numel() > 1 and k != 'rbf.compress_fc.module.model.0.bias':
             a, b = v.detach().cpu().numpy().astype(np.float64), sd_end[k].numpy().astype(np.float64)
-            assert np.linalg.norm(a - b) <= 3e-3 * np.linalg.norm(b) + 1e-6, k
+            dev_state[k] = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+            assert np.linalg.norm(a - b) <= TOL['p1_state'] * np.linalg.norm(b) + 1e-6, k
     bn = 'rbf.compress_fc.module.model.1.'
     np.testing.assert_allclose(net.state_dict()[bn + 'running_var'].cpu().numpy(), sd_end[bn + 'running_var'].numpy(), rtol=2e-3)
     assert int(net.state_dict()[bn + 'num_batches_tracked']) == int(sd_end[bn + 'num_batches_tracked']) == 16
@@ -256,7 +294,9 @@ def test_pretrain_trainer_follows_reference(run_dir, kind, tmp_path):
         if name == 'rbf.compress_fc.module.model.0.bias':
             continue
         got_n = float(torch.linalg.vector_norm(tr.optimizer.state[p]['max_exp_avg_sq'].double()))
-        np.testing.assert_allclose(got_n, float(t[f'p1opt/max_exp_avg_sq/{name}']), rtol=1e-2, atol=1e-12, err_msg=name)
+        dev_mom[name] = abs(got_n - float(t[f'p1opt/max_exp_avg_sq/{name}'])) / max(float(t[f'p1opt/max_exp_avg_sq/{name}']), 1e-30)
+        np.testing.assert_allclose(got_n, float(t[f'p1opt/max_exp_avg_sq/{name}']), rtol=TOL['p1_moments'], atol=1e-12, err_msg=name)
+    log_deviation(f'p1[{kind}]/end', state_rel_max=max(dev_state.values()), max_exp_avg_sq_rel_max=max(dev_mom.values()))
     assert float(next(iter(tr.optimizer.state.values()))['step']) == float(t['p1opt/step'])
     # the checkpoint: upstream's file layout and key names
     ck = torch.load(os.path.join(exp, 'weight', 'ae_mse', 'model.pth.tar'), map_location='cpu', weights_only=False)
@@ -302,9 +342,11 @@ def test_cluster_trainer_follows_reference(run_dir, K, tag, kind, tmp_path):
     got = np.array([[float(v) for v in row] for row in rec])
     ref = t[f'{tag}/train_losses']
     assert got.shape == ref.shape == (24, 3)
-    np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-5, atol=0)                # loss, ae_mse AND kl: no absolute floor
-    np.testing.assert_allclose(got[:8], ref[:8], rtol=2e-4)
-    np.testing.assert_allclose(got, ref, rtol=3e-3)
+    log_deviation(f'p3[{tag},{kind}]', step_loss_rel=(np.abs(got - ref) / np.abs(ref)).max(axis=1), kl_rel=np.abs(got[:, 2] - ref[:, 2]) / np.abs(ref[:, 2]),
+                  centers_rel=float(np.abs(seen['centers'] - t[f'{tag}/kmeans_centers']).max() / np.abs(t[f'{tag}/kmeans_centers']).max()))
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=TOL['p3_first2'], atol=0)                # loss, ae_mse AND kl: no absolute floor
+    np.testing.assert_allclose(got[:8], ref[:8], rtol=TOL['p3_first8'])
+    np.testing.assert_allclose(got, ref, rtol=TOL['p3_all'])
     delta, ref_delta = np.array(seen['delta']), t[f'{tag}/delta']
     if K == 4:
         assert (delta == ref_delta).all() and all((a == b).all() for a, b in zip(seen['labels'], t[f'{tag}/valid_labels']))
@@ -315,19 +357,25 @@ def test_cluster_trainer_follows_reference(run_dir, K, tag, kind, tmp_path):
     sd = net.state_dict()
     for key in ('sci.kernel', 'cci.kernel', 'rbf.kernel', 'cluster_assignment.cluster_centers'):
         np.testing.assert_allclose(sd[key].cpu().numpy(), t[f'{tag}sd/{key}'], rtol=5e-3, atol=5e-4, err_msg=key)
+    norm_dev = {}
     for key in (k for k in t if k.startswith(f'{tag}sdn/')):
-        np.testing.assert_allclose(float(torch.linalg.vector_norm(sd[key.split('/', 1)[1]].double())), float(t[key]), rtol=2e-3, err_msg=key)
+        gn = float(torch.linalg.vector_norm(sd[key.split('/', 1)[1]].double()))
+        norm_dev[key] = abs(gn - float(t[key])) / float(t[key])
+        np.testing.assert_allclose(gn, float(t[key]), rtol=TOL['p3_param_norms'], err_msg=key)
+    log_deviation(f'p3[{tag},{kind}]/end', param_norm_rel_max=max(norm_dev.values()))
 
 
 # ---------------------------------------------------------------------------------------------------------------- feature dump
-@pytest.mark.parametrize('kind', ['device', 'host'])
+@pytest.mark.parametrize('kind', ['device', 'host', 'device-cpu_padded_ob', 'host-cpu_padded_ob'])
 def test_feature_dump_equals_reference(run_dir, kind, tmp_path):
     """TrainerCluster.eval('validation', generate_feat=True) from the reference's own p3 checkpoint: the dictionary np.save writes."""
     from deep_interpolation_clustering_amd.clustering_interp import Net
     from deep_interpolation_clustering_amd.clustering_trainer import TrainerCluster
     f = load('featdump_cfg1.npz')
+    cpu_ob = kind.endswith('cpu_padded_ob')            # --cpu_padded_ob: the padded 'ob' slots as the reference's CPU run (the fixture) dumps them
+    kind = kind.split('-')[0]
     args = trainer_args(loss='ae_mse_kl', cluster_number=4, dc_restore_metric='ae_mse', init_cluster_center='kmeans', mode='eval',
-                        stopping_delta=None, update_interval=1, host_loader=(kind == 'host'))
+                        stopping_delta=None, update_interval=1, host_loader=(kind == 'host'), cpu_padded_ob=cpu_ob)
     dev = torch.device('cuda')
     net = Net(args, dev)
     exp = str(tmp_path / 'Clustering')
@@ -345,6 +393,8 @@ def test_feature_dump_equals_reference(run_dir, kind, tmp_path):
         assert str(got.dtype) == str(f[f'dtype/{k}']), (k, got.dtype)
         if k in ('encounter_id', 'padding_mask', 'timestamp', 'ae_mask'):
             np.testing.assert_array_equal(got, ref, err_msg=k)
+        elif k == 'ob' and cpu_ob:                                                    # the whole array, padded slots included, as the fixture has it
+            np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-4, err_msg=k)
         elif k == 'ob':                                                               # re_norm_data: back in physiologic units (f32 arithmetic)
             m = f['dump/padding_mask'] > 0
             np.testing.assert_allclose(got[m], ref[m], rtol=1e-6, atol=1e-4, err_msg=k)
