@@ -96,6 +96,10 @@ SIGNATURES = {
     'dic_bnhead_bwd_workspace': (_sz, [C.c_int64, _i, _i]),
     'dic_bnhead_bwd_reduce': (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p, _sz, _p]),
     'dic_bnhead_bwd_input': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_double, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p]),
+    'dic_bn_colstats_f32': (_i, [_p, C.c_int64, _i, _p, _p, _sz, _p]),
+    'dic_bnhead_fwd_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p]),
+    'dic_bnhead_bwd_reduce_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p, _sz, _p]),
+    'dic_bnhead_bwd_input_f32': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_double, _p, C.c_int64, _i, _i, _i, _f, _p, _p, _p]),
     'dic_cluster_pairdist': (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
     'dic_cluster_intra_sums': (_i, [_p, _p, _i, _i, _i, _p, _p]),
     'dic_adam_amsgrad_step': (_i, [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
@@ -103,8 +107,8 @@ SIGNATURES = {
     'dic_grad_norm_clip': (_i, [_p, C.c_int64, _f, _p, _p, _sz, _p]),
     'dic_accumulate_many': (_i, [_p, _p, _p, _i, _p]),
     'dic_gemm_nt': (_i, [_i, _i, _p, C.c_int64, _p, C.c_int64, _p, C.c_int64, _i, _i, _p, C.c_int64, _i, _p]),
-    'dic_gemm_tn_workspace': (_sz, [C.c_int64, _i, _i]),
-    'dic_gemm_tn': (_i, [_i, _p, C.c_int64, _p, C.c_int64, C.c_int64, _i, _i, _p, C.c_int64, _i, _i, _p, _sz, _p]),
+    'dic_gemm_tn_workspace': (_sz, [C.c_int64, _i, _i, _i]),
+    'dic_gemm_tn': (_i, [_i, _p, C.c_int64, _p, C.c_int64, C.c_int64, _i, _i, _p, C.c_int64, _i, _p, C.c_int64, _i, _p, C.c_int64, _i, _p, _sz, _p]),
     'dic_kmeans_pp_workspace': (_sz, [_i, _i]),
     'dic_kmeans_pp_candidates': (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _sz, _p]),
     'dic_kmeans_pp_candidates_rows': (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _sz, _p]),

@@ -15,8 +15,37 @@
 
 namespace dic {
 
+// 8 consecutive columns of a row of z as floats: one 16-B load of bf16 (the bf16 step) or two of f32 (the f32 step: the `_f32` entry points)
+typedef float bnf32x4 __attribute__((ext_vector_type(4)));
+struct Row8 { float v[8]; };
+__device__ __forceinline__ Row8 load_row8(const __bf16* p) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+    Row8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.v[e] = (float)x[e];
+    return r;
+}
+__device__ __forceinline__ Row8 load_row8(const float* p) {
+    const bnf32x4 a = *reinterpret_cast<const bnf32x4*>(p), b = *reinterpret_cast<const bnf32x4*>(p + 4);
+    Row8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r.v[e] = a[e]; r.v[4 + e] = b[e]; }
+    return r;
+}
+__device__ __forceinline__ void store_row8(__bf16* p, const float (&o)[8]) {
+    bf16x8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (__bf16)o[e];
+    *reinterpret_cast<bf16x8*>(p) = x;
+}
+__device__ __forceinline__ void store_row8(float* p, const float (&o)[8]) {
+    *reinterpret_cast<bnf32x4*>(p) = bnf32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<bnf32x4*>(p + 4) = bnf32x4{o[4], o[5], o[6], o[7]};
+}
+
 // partials[blk][2][BK]: sum z, sum z^2
-__global__ __launch_bounds__(256) void bn_colstats_kernel(const __bf16* z, long N, float* partials) {
+template <typename ZT>
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const ZT* z, long N, float* partials) {
     __shared__ float red[4][2][BK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
     float s1[8], s2[8];
@@ -24,10 +53,10 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const __bf16* z, long 
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     const long stride = (long)gridDim.x * 16;
     for (long row = ((long)blockIdx.x * 4 + wave) * 4 + slot; row < N; row += stride) {
-        const bf16x8 x = *reinterpret_cast<const bf16x8*>(z + row * BK + kc * 8);
+        const Row8 x = load_row8(z + row * BK + kc * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float xe = (float)x[e];
+            const float xe = x.v[e];
             s1[e] += xe;
             s2[e] = fmaf(xe, xe, s2[e]);
         }
@@ -82,8 +111,8 @@ __global__ __launch_bounds__(BK) void bn_moments_kernel(const double* sums, floa
     }
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
+template <int C, typename ZT>
+__global__ __launch_bounds__(256) void bnhead_fwd_kernel(const ZT* z, const float* mean, const float* rstd, const float* gamma,
                                                          const float* beta, const float* W, const float* b, long N, float floor_, float drop_p,
                                                          const unsigned long long* rng, float* v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
@@ -108,20 +137,20 @@ __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const 
         return a;
     };
     long row0 = ((long)blockIdx.x * 4 + wave) * 4;
-    bf16x8 xn = {};
-    if (row0 + slot < N) xn = *reinterpret_cast<const bf16x8*>(z + (row0 + slot) * BK + kc * 8);
+    Row8 xn = {};
+    if (row0 + slot < N) xn = load_row8(z + (row0 + slot) * BK + kc * 8);
     for (; row0 < N; row0 += stride) {       // wave-uniform trip count; the next row is in flight while this one is reduced
         const long row = row0 + slot;
         const bool live = row < N;
-        const bf16x8 x = xn;
-        if (row + stride < N) xn = *reinterpret_cast<const bf16x8*>(z + (row + stride) * BK + kc * 8);
+        const Row8 x = xn;
+        if (row + stride < N) xn = load_row8(z + (row + stride) * BK + kc * 8);
         float acc[C], keep[8];
         drop_factors(drop, row, kc, keep);
 #pragma unroll
         for (int j = 0; j < C; ++j) acc[j] = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float h = fmaxf(fmaf((float)x[e], p.scale[e], p.shift[e]), floor_) * keep[e];      // floor_ = 0 (ReLU) or -inf (none)
+            const float h = fmaxf(fmaf(x.v[e], p.scale[e], p.shift[e]), floor_) * keep[e];      // floor_ = 0 (ReLU) or -inf (none)
 #pragma unroll
             for (int j = 0; j < C; ++j) acc[j] = fmaf(h, w[j][e], acc[j]);
         }
@@ -137,11 +166,11 @@ __global__ __launch_bounds__(256) void bnhead_fwd_kernel(const __bf16* z, const 
 
 // recompute the post-ReLU activation h, x-hat and da = (dv W) 1[h > 0] for this lane's 8 columns of one row
 template <int C>
-__device__ __forceinline__ void recompute_row(const bf16x8 x, const ColParams& p, const float (&w)[C][8], const float (&g)[C],
+__device__ __forceinline__ void recompute_row(const Row8& x, const ColParams& p, const float (&w)[C][8], const float (&g)[C],
                                               float floor_, const float (&keep)[8], float (&h)[8], float (&xhat)[8], float (&da)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float xe = (float)x[e];
+        const float xe = x.v[e];
         const float act = fmaxf(fmaf(xe, p.scale[e], p.shift[e]), floor_);
         h[e] = act * keep[e];                      // what the Linear saw (dropout applied): multiplies dv in dW
         xhat[e] = (xe - p.mean[e]) * p.rstd[e];
@@ -153,8 +182,8 @@ __device__ __forceinline__ void recompute_row(const bf16x8 x, const ColParams& p
 }
 
 // partials[blk][(2 + C) * BK + C]: sum da | sum da*xhat | dW[C][BK] | db[C]
-template <int C>
-__global__ __launch_bounds__(256) void bnhead_bwd_reduce_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
+template <int C, typename ZT>
+__global__ __launch_bounds__(256) void bnhead_bwd_reduce_kernel(const ZT* z, const float* mean, const float* rstd, const float* gamma,
                                                                 const float* beta, const float* W, const float* dv, long N, float floor_, float drop_p,
                                                                 const unsigned long long* rng, float* partials) {
     constexpr int NOUT = (2 + C) * BK + C;
@@ -178,20 +207,20 @@ __global__ __launch_bounds__(256) void bnhead_bwd_reduce_kernel(const __bf16* z,
     }
     const long stride = (long)gridDim.x * 16;
     long row = ((long)blockIdx.x * 4 + wave) * 4 + slot;
-    bf16x8 xn = {};
+    Row8 xn = {};
     float gn[C] = {};
     if (row < N) {
-        xn = *reinterpret_cast<const bf16x8*>(z + row * BK + kc * 8);
+        xn = load_row8(z + row * BK + kc * 8);
 #pragma unroll
         for (int j = 0; j < C; ++j) gn[j] = dv[row * C + j];
     }
     for (; row < N; row += stride) {
-        const bf16x8 x = xn;
+        const Row8 x = xn;
         float g[C];
 #pragma unroll
         for (int j = 0; j < C; ++j) g[j] = gn[j];
         if (row + stride < N) {              // next row in flight while this one is reduced
-            xn = *reinterpret_cast<const bf16x8*>(z + (row + stride) * BK + kc * 8);
+            xn = load_row8(z + (row + stride) * BK + kc * 8);
 #pragma unroll
             for (int j = 0; j < C; ++j) gn[j] = dv[(row + stride) * C + j];
         }
@@ -253,11 +282,11 @@ __global__ __launch_bounds__(256) void bnhead_bwd_finalize(const float* partials
     if (threadIdx.x < 32 && i < nout) sums[i] = (float)s;
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void bnhead_bwd_input_kernel(const __bf16* z, const float* mean, const float* rstd, const float* gamma,
+template <int C, typename ZT>
+__global__ __launch_bounds__(256) void bnhead_bwd_input_kernel(const ZT* z, const float* mean, const float* rstd, const float* gamma,
                                                                const float* beta, const float* W, const float* dv, const float* sum_da,
                                                                const float* sum_dax, float inv_n, const float* count, long N, float floor_, float drop_p,
-                                                               const unsigned long long* rng, __bf16* dz) {
+                                                               const unsigned long long* rng, ZT* dz) {
     if (count) inv_n = 1.0f / count[0];                      // global row count of the batch moments, on the device
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane >> 4, kc = lane & 15;
     const ColParams p = load_cols(mean, rstd, gamma, beta, kc);
@@ -274,7 +303,7 @@ __global__ __launch_bounds__(256) void bnhead_bwd_input_kernel(const __bf16* z, 
     }
     const long stride = (long)gridDim.x * 16;
     for (long row = ((long)blockIdx.x * 4 + wave) * 4 + slot; row < N; row += stride) {
-        const bf16x8 x = *reinterpret_cast<const bf16x8*>(z + row * BK + kc * 8);
+        const Row8 x = load_row8(z + row * BK + kc * 8);
         float g[C];
 #pragma unroll
         for (int j = 0; j < C; ++j) g[j] = dv[row * C + j];
@@ -282,10 +311,10 @@ __global__ __launch_bounds__(256) void bnhead_bwd_input_kernel(const __bf16* z, 
         float keep[8];
         drop_factors(drop, row, kc, keep);
         recompute_row<C>(x, p, w, g, floor_, keep, h, xhat, da);
-        bf16x8 o;
+        float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(p.scale[e] * (da[e] - c1[e] - xhat[e] * c2[e]));
-        *reinterpret_cast<bf16x8*>(dz + row * BK + kc * 8) = o;
+        for (int e = 0; e < 8; ++e) o[e] = p.scale[e] * (da[e] - c1[e] - xhat[e] * c2[e]);
+        store_row8(dz + row * BK + kc * 8, o);
     }
 }
 
@@ -303,7 +332,8 @@ static int bnhead_reduce_blocks(long N) { return (int)max(1L, min((N + 127) / 12
         case 6: { constexpr int C = 6; __VA_ARGS__; } break;     \
         case 7: { constexpr int C = 7; __VA_ARGS__; } break;     \
         case 8: { constexpr int C = 8; __VA_ARGS__; } break;     \
-        default: set_error("bnhead: out_features=%d not compiled (1..8)", CV); return DIC_ERR_UNSUPPORTED; \
+        case 12: { constexpr int C = 12; __VA_ARGS__; } break;   \
+        default: set_error("bnhead: out_features=%d not compiled (1..8, 12)", CV); return DIC_ERR_UNSUPPORTED; \
     }
 
 }  // namespace dic
@@ -317,16 +347,27 @@ size_t dic_bn_colstats_workspace(int64_t N, int K) {
     return (size_t)bnhead_blocks(N) * 2 * BK * sizeof(float);
 }
 
-int dic_bn_colstats(const void* z, int64_t N, int K, double* sums, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+}  // extern "C"
+
+template <typename ZT>
+static int bn_colstats_t(const void* z, int64_t N, int K, double* sums, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(N > 0, DIC_ERR_INVALID_ARG, "bn_colstats: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bn_colstats: width %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && sums && workspace, DIC_ERR_INVALID_ARG, "bn_colstats: NULL pointer");
     const int nblk = bnhead_blocks(N);
     DIC_REQUIRE(workspace_bytes >= (size_t)nblk * 2 * BK * sizeof(float), DIC_ERR_WORKSPACE, "bn_colstats: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_colstats_kernel, dim3(nblk), dim3(256), 0, st, (const __bf16*)z, (long)N, (float*)workspace);
+    hipLaunchKernelGGL(bn_colstats_kernel<ZT>, dim3(nblk), dim3(256), 0, st, (const ZT*)z, (long)N, (float*)workspace);
     hipLaunchKernelGGL(bn_colstats_finalize, dim3(2 * BK / 32), dim3(256), 0, st, (const float*)workspace, nblk, (double)N, sums);
     return check_launch("bn_colstats");
+}
+
+extern "C" {
+int dic_bn_colstats(const void* z, int64_t N, int K, double* sums, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    return bn_colstats_t<__bf16>(z, N, K, sums, workspace, workspace_bytes, stream);
+}
+int dic_bn_colstats_f32(const float* z, int64_t N, int K, double* sums, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    return bn_colstats_t<float>(z, N, K, sums, workspace, workspace_bytes, stream);
 }
 
 int dic_bn_moments(const double* sums, int K, float eps, float momentum, float* running_mean, float* running_var,
@@ -339,16 +380,29 @@ int dic_bn_moments(const double* sums, int K, float eps, float momentum, float* 
     return check_launch("bn_moments");
 }
 
-int dic_bnhead_fwd(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                   const float* b, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* v, dic_stream_t stream) {
+}  // extern "C"
+
+template <typename ZT>
+static int bnhead_fwd_t(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                        const float* b, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* v, dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_fwd: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_fwd: in_features %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && mean && rstd && gamma && beta && W && b && v, DIC_ERR_INVALID_ARG, "bnhead_fwd: NULL pointer");
     DIC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng), DIC_ERR_INVALID_ARG, "bnhead_fwd: dropout p=%g needs 0 <= p < 1 and an rng state", (double)drop_p);
     const int grid = bnhead_blocks(N);
-    DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_fwd_kernel<C>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)z, mean,
+    DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL((bnhead_fwd_kernel<C, ZT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const ZT*)z, mean,
                                                 rstd, gamma, beta, W, b, (long)N, relu ? 0.f : -INFINITY, drop_p, (const unsigned long long*)rng, v));
     return check_launch("bnhead_fwd");
+}
+
+extern "C" {
+int dic_bnhead_fwd(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                   const float* b, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* v, dic_stream_t stream) {
+    return bnhead_fwd_t<__bf16>(z, mean, rstd, gamma, beta, W, b, N, K, C, relu, drop_p, rng, v, stream);
+}
+int dic_bnhead_fwd_f32(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                       const float* b, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* v, dic_stream_t stream) {
+    return bnhead_fwd_t<float>(z, mean, rstd, gamma, beta, W, b, N, K, C, relu, drop_p, rng, v, stream);
 }
 
 size_t dic_bnhead_bwd_workspace(int64_t N, int K, int C) {
@@ -356,32 +410,62 @@ size_t dic_bnhead_bwd_workspace(int64_t N, int K, int C) {
     return (size_t)bnhead_reduce_blocks(N) * ((2 + C) * BK + C) * sizeof(float);
 }
 
-int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                          const float* dv, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* sums,
-                          void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+}  // extern "C"
+
+template <typename ZT>
+static int bnhead_bwd_reduce_t(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                               const float* dv, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* sums,
+                               void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_bwd_reduce: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_bwd_reduce: in_features %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && mean && rstd && gamma && beta && W && dv && sums && workspace, DIC_ERR_INVALID_ARG, "bnhead_bwd_reduce: NULL pointer");
     const int nblk = bnhead_reduce_blocks(N), nout = (2 + C) * BK + C;
     DIC_REQUIRE(workspace_bytes >= (size_t)nblk * nout * sizeof(float), DIC_ERR_WORKSPACE, "bnhead_bwd_reduce: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_bwd_reduce_kernel<C>, dim3(nblk), dim3(256), 0, st, (const __bf16*)z, mean, rstd, gamma,
+    DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL((bnhead_bwd_reduce_kernel<C, ZT>), dim3(nblk), dim3(256), 0, st, (const ZT*)z, mean, rstd, gamma,
                                                 beta, W, dv, (long)N, relu ? 0.f : -INFINITY, drop_p, (const unsigned long long*)rng, (float*)workspace));
     hipLaunchKernelGGL(bnhead_bwd_finalize, dim3((nout + 31) / 32), dim3(256), 0, st, (const float*)workspace, nblk, nout, sums);
     return check_launch("bnhead_bwd_reduce");
 }
 
-int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
-                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, const float* count, int64_t N, int K, int C, int relu,
-                         float drop_p, const uint64_t* rng, void* dz, dic_stream_t stream) {
+extern "C" {
+int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                          const float* dv, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* sums,
+                          void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    return bnhead_bwd_reduce_t<__bf16>(z, mean, rstd, gamma, beta, W, dv, N, K, C, relu, drop_p, rng, sums, workspace, workspace_bytes, stream);
+}
+int dic_bnhead_bwd_reduce_f32(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                              const float* dv, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* sums,
+                              void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    return bnhead_bwd_reduce_t<float>(z, mean, rstd, gamma, beta, W, dv, N, K, C, relu, drop_p, rng, sums, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+template <typename ZT>
+static int bnhead_bwd_input_t(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                              const float* dv, const float* sum_da, const float* sum_dax, double inv_n, const float* count, int64_t N, int K, int C, int relu,
+                              float drop_p, const uint64_t* rng, void* dz, dic_stream_t stream) {
     DIC_REQUIRE(N > 0 && C > 0, DIC_ERR_INVALID_ARG, "bnhead_bwd_input: non-positive size");
     DIC_REQUIRE(K == BK, DIC_ERR_UNSUPPORTED, "bnhead_bwd_input: in_features %d (compiled for %d)", K, BK);
     DIC_REQUIRE(z && mean && rstd && gamma && beta && W && dv && sum_da && sum_dax && dz, DIC_ERR_INVALID_ARG, "bnhead_bwd_input: NULL pointer");
     const int grid = bnhead_blocks(N);
-    DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL(bnhead_bwd_input_kernel<C>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)z, mean,
+    DIC_BNHEAD_DISPATCH_C(C, hipLaunchKernelGGL((bnhead_bwd_input_kernel<C, ZT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const ZT*)z, mean,
                                                 rstd, gamma, beta, W, dv, sum_da, sum_dax, (float)inv_n, count, (long)N, relu ? 0.f : -INFINITY, drop_p,
-                                                (const unsigned long long*)rng, (__bf16*)dz));
+                                                (const unsigned long long*)rng, (ZT*)dz));
     return check_launch("bnhead_bwd_input");
+}
+
+extern "C" {
+int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                         const float* dv, const float* sum_da, const float* sum_dax, double inv_n, const float* count, int64_t N, int K, int C, int relu,
+                         float drop_p, const uint64_t* rng, void* dz, dic_stream_t stream) {
+    return bnhead_bwd_input_t<__bf16>(z, mean, rstd, gamma, beta, W, dv, sum_da, sum_dax, inv_n, count, N, K, C, relu, drop_p, rng, dz, stream);
+}
+int dic_bnhead_bwd_input_f32(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                             const float* dv, const float* sum_da, const float* sum_dax, double inv_n, const float* count, int64_t N, int K, int C, int relu,
+                             float drop_p, const uint64_t* rng, float* dz, dic_stream_t stream) {
+    return bnhead_bwd_input_t<float>(z, mean, rstd, gamma, beta, W, dv, sum_da, sum_dax, inv_n, count, N, K, C, relu, drop_p, rng, dz, stream);
 }
 
 }  // extern "C"

@@ -209,10 +209,12 @@ constexpr int TROWS = 32;
 struct GemmTnArgs {
     const void* A; long lda;       // (M, N) rows
     const void* X; long ldx;       // (M, K) rows
-    float* part;                   // (S, N, K) partial sums
+    const void* X2; long ldx2;     // optional second right-hand operand (M, K2) rows: its product leaves in columns [K, K + K2) of the partials --
+    int K2;                        //   dW_ih = dG^T.x and dW_hh = dG^T.h_prev from ONE pass over the gate gradients
+    float* part;                   // (S, N, K + K2) partial sums
     long M; int N, K;
     long rows_per_chunk;           // multiple of TROWS
-    int tiles_n, tiles_k;
+    int tiles_n, tiles_k, tiles_k1;      // tiles_k = tiles_k1 (of X) + those of X2
 };
 
 __device__ __forceinline__ gs16x4 glds_tr16(const __bf16* p) {
@@ -232,14 +234,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     const int lt = xcd_remap(blockIdx.x, gridDim.x);        // consecutive logical ids = the output tiles of one row chunk: one XCD
     const int ntile = a.tiles_n * a.tiles_k;
     const int s = lt / ntile, ot = lt % ntile;
-    const int n0 = (ot / a.tiles_k) * 128, k0 = (ot % a.tiles_k) * BKO;
+    const int kt = ot % a.tiles_k;
+    const bool second = kt >= a.tiles_k1;                   // this tile multiplies the second right-hand operand
+    const int n0 = (ot / a.tiles_k) * 128, k0 = (second ? kt - a.tiles_k1 : kt) * BKO;
     const long mbeg = (long)s * a.rows_per_chunk, mend = min(a.M, mbeg + a.rows_per_chunk);
     const TIN* A = reinterpret_cast<const TIN*>(a.A);
-    const TIN* X = reinterpret_cast<const TIN*>(a.X);
+    const TIN* X = reinterpret_cast<const TIN*>(second ? a.X2 : a.X);
+    const long ldx = second ? a.ldx2 : a.ldx;
+    const int KX = second ? a.K2 : a.K, KT = a.K + a.K2;
     // loads: row = tid >> 3 of the 32; A: 16 columns [16 seg, +16); X: BKO / 8 columns
     const int lrow = tid >> 3, seg = tid & 7;
     constexpr int XC = BKO / 8;                              // 16 or 8 columns of X per thread
-    const int nvalid_a = a.N - n0, kvalid = a.K - k0;        // valid columns of this tile (vector pieces all-in or all-out)
+    const int nvalid_a = a.N - n0, kvalid = KX - k0;         // valid columns of this tile (vector pieces all-in or all-out)
 
     gf32x16 acc[2][NBK];
 #pragma unroll
@@ -254,8 +260,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
         const long row = m + lrow;
         if (row < mend) {
             chunk_load(ca, A + (size_t)row * a.lda + n0, 16 * seg, nvalid_a);
-            if (XC == 16) chunk_load(cx, X + (size_t)row * a.ldx + k0, 16 * seg, kvalid);
-            else chunk_load(cx, X + (size_t)row * a.ldx + k0, 8 * seg, min(kvalid, 8 * seg + 8));      // 8 columns: the second half stays zero
+            if (XC == 16) chunk_load(cx, X + (size_t)row * ldx + k0, 16 * seg, kvalid);
+            else chunk_load(cx, X + (size_t)row * ldx + k0, 8 * seg, min(kvalid, 8 * seg + 8));      // 8 columns: the second half stays zero
         } else {
             chunk_zero(ca);
             chunk_zero(cx);
@@ -309,27 +315,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
         __syncthreads();
     }
     // D block: rows = output row n (the A operand's columns), columns = output column k: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 hh
-    float* o = a.part + (size_t)s * a.N * a.K;
+    float* o = a.part + (size_t)s * a.N * KT + (second ? a.K : 0);
 #pragma unroll
     for (int kb = 0; kb < NBK; ++kb) {
         const int k = k0 + (BKO / 2) * wk + 32 * kb + (lane & 31);
-        if (k >= a.K) continue;
+        if (k >= KX) continue;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + 64 * wn + 32 * nb + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (n < a.N) o[(size_t)n * a.K + k] = acc[nb][kb][e];
+                if (n < a.N) o[(size_t)n * KT + k] = acc[nb][kb][e];
             }
     }
 }
 
-// D[n][k] (+)= sum over the S chunks, fixed order, f64; k < kcols only (the padding columns of a packed operand are dropped)
-__global__ __launch_bounds__(256) void gemm_tn_finalize(const float* part, int S, int N, int K, float* D, long ldd, int kcols, float beta) {
+// D[n][k] (+)= sum over the S chunks, fixed order, f64; k < kcols only (the padding columns of a packed operand are dropped); columns
+// [K1, K) of the partials belong to the second product and go to D2
+__global__ __launch_bounds__(256) void gemm_tn_finalize(const float* part, int S, int N, int K, int K1, float* D, long ldd, int kcols, float* D2, long ldd2,
+                                                        float beta) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * K) return;
     const int n = i / K, k = i - n * K;
-    if (k >= kcols) return;
+    if (k < K1 && k >= kcols) return;
     double ch[4] = {0.0, 0.0, 0.0, 0.0};
     int s = 0;
     for (; s + 4 <= S; s += 4) {
@@ -341,13 +349,13 @@ __global__ __launch_bounds__(256) void gemm_tn_finalize(const float* part, int S
     }
     for (; s < S; ++s) ch[0] += (double)part[(size_t)s * N * K + i];
     const float r = (float)((ch[0] + ch[1]) + (ch[2] + ch[3]));
-    float* dst = D + (size_t)n * ldd + k;
+    float* dst = k < K1 ? D + (size_t)n * ldd + k : D2 + (size_t)n * ldd2 + (k - K1);
     *dst = beta != 0.f ? fmaf(beta, *dst, r) : r;
 }
 
-static int tn_chunks(long M, int N, int K, long* rows_per_chunk, int* bko) {
-    *bko = K > 64 ? 128 : 64;
-    const int tiles = ((N + 127) / 128) * ((K + *bko - 1) / *bko);
+static int tn_chunks(long M, int N, int K, int K2, long* rows_per_chunk, int* bko) {
+    *bko = (K > 64 || K2 > 64) ? 128 : 64;
+    const int tiles = ((N + 127) / 128) * ((K + *bko - 1) / *bko + (K2 + *bko - 1) / *bko);
     const long row_tiles = (M + TROWS - 1) / TROWS;
     long S = max(1L, min(row_tiles, (long)(4 * kNumCU + tiles - 1) / tiles));        // ~4 workgroups per CU
     S = min(S, 256L);
@@ -390,27 +398,33 @@ int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void
     return check_launch("gemm_nt");
 }
 
-size_t dic_gemm_tn_workspace(long M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
+size_t dic_gemm_tn_workspace(long M, int N, int K, int K2) {
+    if (M <= 0 || N <= 0 || K <= 0 || K2 < 0) return 0;
     long rpc; int bko;
-    const int S = tn_chunks(M, N, K, &rpc, &bko);
-    return (size_t)S * N * K * sizeof(float);
+    const int S = tn_chunks(M, N, K, K2, &rpc, &bko);
+    return (size_t)S * N * (K + K2) * sizeof(float);
 }
 
 int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
-                int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+                const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(in_dtype == DIC_DTYPE_F32 || in_dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "gemm_tn: input dtype %d", in_dtype);
     DIC_REQUIRE(A && X && D && workspace, DIC_ERR_INVALID_ARG, "gemm_tn: NULL pointer");
     DIC_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= N && ldx >= K && kcols > 0 && kcols <= K && ldd >= kcols, DIC_ERR_INVALID_ARG,
                 "gemm_tn: M=%ld N=%d K=%d lda=%ld ldx=%ld ldd=%ld kcols=%d", M, N, K, lda, ldx, ldd, kcols);
+    if (!X2) K2 = 0;
+    DIC_REQUIRE(!X2 || (K2 > 0 && D2 && ldx2 >= K2 && ldd2 >= K2), DIC_ERR_INVALID_ARG, "gemm_tn: second operand K2=%d ldx2=%ld ldd2=%ld", K2, ldx2, ldd2);
     const int vec = in_dtype == DIC_DTYPE_F32 ? 4 : 8;
     DIC_REQUIRE(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldx % vec == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)X & 15) == 0, DIC_ERR_UNSUPPORTED,
                 "gemm_tn: N, K, lda, ldx must be multiples of %d elements and the operands 16-B aligned (N=%d K=%d lda=%ld ldx=%ld): pad the rows", vec, N, K, lda, ldx);
+    DIC_REQUIRE(!X2 || (K2 % vec == 0 && ldx2 % vec == 0 && ((uintptr_t)X2 & 15) == 0), DIC_ERR_UNSUPPORTED,
+                "gemm_tn: K2, ldx2 must be multiples of %d elements and X2 16-B aligned (K2=%d ldx2=%ld)", vec, K2, ldx2);
     long rpc; int bko;
-    const int S = tn_chunks(M, N, K, &rpc, &bko);
-    DIC_REQUIRE(workspace_bytes >= (size_t)S * N * K * sizeof(float), DIC_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", workspace_bytes,
-                (size_t)S * N * K * sizeof(float));
-    GemmTnArgs a{A, lda, X, ldx, (float*)workspace, M, N, K, rpc, (N + 127) / 128, (K + bko - 1) / bko};
+    const int S = tn_chunks(M, N, K, K2, &rpc, &bko);
+    const int KT = K + K2;
+    DIC_REQUIRE(workspace_bytes >= (size_t)S * N * KT * sizeof(float), DIC_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", workspace_bytes,
+                (size_t)S * N * KT * sizeof(float));
+    const int tk1 = (K + bko - 1) / bko, tk2 = (K2 + bko - 1) / bko;
+    GemmTnArgs a{A, lda, X, ldx, X2, ldx2, K2, (float*)workspace, M, N, K, rpc, (N + 127) / 128, tk1 + tk2, tk1};
     const dim3 grid((unsigned)(S * a.tiles_n * a.tiles_k)), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == DIC_DTYPE_F32) {
@@ -420,7 +434,7 @@ int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, 
         if (bko == 128) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, 128>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((gemm_tn_kernel<__bf16, 64>), grid, blk, 0, st, a);
     }
-    hipLaunchKernelGGL(gemm_tn_finalize, dim3((N * K + 255) / 256), dim3(256), 0, st, (const float*)workspace, S, N, K, D, ldd, kcols,
+    hipLaunchKernelGGL(gemm_tn_finalize, dim3((N * KT + 255) / 256), dim3(256), 0, st, (const float*)workspace, S, N, KT, K, D, ldd, kcols, D2, ldd2,
                        accumulate ? 1.0f : 0.0f);
     return check_launch("gemm_tn");
 }

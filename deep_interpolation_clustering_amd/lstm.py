@@ -314,10 +314,9 @@ class _BiLstm(torch.autograd.Function):
                 # views of the extended output buffer (see below)
                 oe = out_ext.view((R + 2) * B, 2 * H)
                 xv = xb.view(R * B, Ip)
-                for d in range(2):
-                    _ops.gemm_tn_into(dg2[:, 4 * H * d:4 * H * (d + 1)], xv, sinks[4 * d], kcols=I, accumulate=accumulate)
+                for d in range(2):              # (both products of a direction from ONE pass over its gate gradients)
                     hp = oe[:R * B, :H] if d == 0 else oe[2 * B:, H:]
-                    _ops.gemm_tn_into(dg2[:, 4 * H * d:4 * H * (d + 1)], hp, sinks[4 * d + 1], accumulate=accumulate)
+                    _ops.gemm_tn_into(dg2[:, 4 * H * d:4 * H * (d + 1)], xv, sinks[4 * d], kcols=I, accumulate=accumulate, x2=hp, dst2=sinks[4 * d + 1])
                 N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             else:
                 # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split-K bmm (ops.splitk_tn).

@@ -578,7 +578,10 @@ class _BnReluHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, gamma, beta, weight, bias, eps, running_mean, running_var, nbt, momentum, training, relu, drop_p=0.0, col_sums=None):
         N.require_gpu(z, gamma, beta, weight, bias)
-        zb = z.to(torch.bfloat16).contiguous()
+        # bf16 rows (the bf16 step) or, for an f32 pre-activation outside autocast, f32 rows through the `_f32` twins of the same kernels
+        f32z = z.dtype == torch.float32 and not torch.is_autocast_enabled() and f32_products() == 'x3'
+        zb = z.contiguous() if f32z else z.to(torch.bfloat16).contiguous()
+        sfx = '_f32' if f32z else ''
         n, k = zb.shape
         c = weight.shape[0]
         L, dev, st = N.lib(), zb.device, N.stream_of(zb)
@@ -588,7 +591,7 @@ class _BnReluHead(torch.autograd.Function):
             else:
                 sums = torch.empty(2 * k + 1, device=dev, dtype=torch.float64)
                 ws = _ws(L.dic_bn_colstats_workspace(n, k), dev)
-                N.check(L.dic_bn_colstats(N.ptr(zb), n, k, N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bn_colstats')      # [sum z | sum z^2 | rows]
+                N.check(getattr(L, 'dic_bn_colstats' + sfx)(N.ptr(zb), n, k, N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bn_colstats')      # [sum z | sum z^2 | rows]
             dist.all_reduce_sum_(sums)            # the moments of the GLOBAL batch
             mean = torch.empty(k, device=dev, dtype=torch.float32)
             rstd, cnt = torch.empty_like(mean), torch.empty(1, device=dev, dtype=torch.float32)
@@ -603,10 +606,10 @@ class _BnReluHead(torch.autograd.Function):
         g, bt, w, b = N.f32c(gamma.detach()), N.f32c(beta.detach()), N.f32c(weight.detach()), N.f32c(bias.detach())
         v = torch.empty((n, c), device=dev, dtype=torch.float32)
         rng = _dropout_rng(dev) if drop_p > 0 else None
-        N.check(L.dic_bnhead_fwd(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(b), n, k, c, int(relu), float(drop_p), N.ptr(rng), N.ptr(v), st),
+        N.check(getattr(L, 'dic_bnhead_fwd' + sfx)(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(b), n, k, c, int(relu), float(drop_p), N.ptr(rng), N.ptr(v), st),
                 'dic_bnhead_fwd')
         ctx.save_for_backward(zb, mean, rstd, g, bt, w, cnt, rng)
-        ctx.z_dtype, ctx.training, ctx.relu, ctx.drop_p = z.dtype, bool(training), int(relu), float(drop_p)
+        ctx.z_dtype, ctx.training, ctx.relu, ctx.drop_p, ctx.sfx = z.dtype, bool(training), int(relu), float(drop_p), sfx
         return v
 
     @staticmethod
@@ -618,8 +621,8 @@ class _BnReluHead(torch.autograd.Function):
         gv = N.f32c(dv)
         sums = torch.empty((2 + c) * k + c, device=dev, dtype=torch.float32)
         ws = _ws(L.dic_bnhead_bwd_workspace(n, k, c), dev)
-        N.check(L.dic_bnhead_bwd_reduce(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), n, k, c, ctx.relu, ctx.drop_p, N.ptr(rng),
-                                        N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bnhead_bwd_reduce')
+        N.check(getattr(L, 'dic_bnhead_bwd_reduce' + ctx.sfx)(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), n, k, c, ctx.relu, ctx.drop_p, N.ptr(rng),
+                                                              N.ptr(sums), N.ptr(ws), ws.numel(), st), 'dic_bnhead_bwd_reduce')
         dbeta, dgamma = sums[:k], sums[k:2 * k]                 # this rank's share; the gradient all-reduce sums them
         dw, db = sums[2 * k:(2 + c) * k].view(c, k), sums[(2 + c) * k:]
         dz = None
@@ -634,13 +637,13 @@ class _BnReluHead(torch.autograd.Function):
                 red = torch.zeros(2 * k, device=dev, dtype=torch.float32)
                 count = None
             dz = torch.empty_like(zb)
-            N.check(L.dic_bnhead_bwd_input(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), N.ptr(red),
-                                           N.ptr(red[k:]), 1.0, N.ptr(count), n, k, c, ctx.relu, ctx.drop_p, N.ptr(rng), N.ptr(dz), st), 'dic_bnhead_bwd_input')
+            N.check(getattr(L, 'dic_bnhead_bwd_input' + ctx.sfx)(N.ptr(zb), N.ptr(mean), N.ptr(rstd), N.ptr(g), N.ptr(bt), N.ptr(w), N.ptr(gv), N.ptr(red),
+                                                                 N.ptr(red[k:]), 1.0, N.ptr(count), n, k, c, ctx.relu, ctx.drop_p, N.ptr(rng), N.ptr(dz), st), 'dic_bnhead_bwd_input')
             dz = dz.to(ctx.z_dtype)
         return dz, dgamma, dbeta, dw, db, None, None, None, None, None, None, None, None, None
 
 
-BNHEAD_OUT = (1, 2, 3, 4, 5, 6, 7, 8)
+BNHEAD_OUT = (1, 2, 3, 4, 5, 6, 7, 8, 12)      # head widths dic_bnhead_* is compiled for (12: BASELINE configs[3]'s twelve channels)
 _DROP_STATE = {}
 
 
@@ -765,9 +768,10 @@ def gemm_nt(a, w, bias=None, out_dtype=None, relu_a=False, out=None):
     return y
 
 
-def gemm_tn_into(a, x, dst, kcols=None, accumulate=False):
+def gemm_tn_into(a, x, dst, kcols=None, accumulate=False, x2=None, dst2=None):
     """dst (N,kcols) f32 (+)= a (M,N)^T . x (M,K)[:, :kcols] (dic_gemm_tn): the weight-gradient shape -- a reduction over hundreds of thousands of
-    rows into a small matrix; row chunks in parallel, fixed-order f64 second stage (deterministic)."""
+    rows into a small matrix; row chunks in parallel, fixed-order f64 second stage (deterministic).  ``x2`` (M,K2), ``dst2`` (N,K2): a second
+    product a^T . x2 from the same pass over ``a`` (dW_ih and dW_hh of one LSTM direction read the gate gradients once)."""
     N.require_gpu(a, x, dst)
     a, x, dst = _rows(a), _rows(x), _rows(dst)
     if a.dtype != x.dtype or a.shape[0] != x.shape[0] or dst.dtype != torch.float32:
@@ -777,10 +781,17 @@ def gemm_tn_into(a, x, dst, kcols=None, accumulate=False):
     kcols = K if kcols is None else int(kcols)
     if tuple(dst.shape) != (n, kcols):
         raise ValueError(f'gemm_tn: dst {tuple(dst.shape)} != ({n}, {kcols})')
+    K2 = 0
+    if x2 is not None:
+        x2, dst2 = _rows(x2), _rows(dst2)
+        K2 = x2.shape[1]
+        if x2.dtype != a.dtype or x2.shape[0] != M or tuple(dst2.shape) != (n, K2) or dst2.dtype != torch.float32:
+            raise ValueError(f'gemm_tn: x2 {tuple(x2.shape)} {x2.dtype}, dst2 {tuple(dst2.shape)} {dst2.dtype}')
     L = N.lib()
-    ws = _ws(L.dic_gemm_tn_workspace(M, n, K), a.device)
-    N.check(L.dic_gemm_tn(_dt(a), N.ptr(a), a.stride(0), N.ptr(x), x.stride(0), M, n, K, N.ptr(dst), dst.stride(0), kcols, int(bool(accumulate)),
-                          N.ptr(ws), ws.numel(), N.stream_of(a)), 'dic_gemm_tn')
+    ws = _ws(L.dic_gemm_tn_workspace(M, n, K, K2), a.device)
+    N.check(L.dic_gemm_tn(_dt(a), N.ptr(a), a.stride(0), N.ptr(x), x.stride(0), M, n, K, N.ptr(dst), dst.stride(0), kcols,
+                          N.ptr(x2), x2.stride(0) if x2 is not None else 0, K2, N.ptr(dst2), dst2.stride(0) if dst2 is not None else 0,
+                          int(bool(accumulate)), N.ptr(ws), ws.numel(), N.stream_of(a)), 'dic_gemm_tn')
     return dst
 
 

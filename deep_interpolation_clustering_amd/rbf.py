@@ -28,6 +28,9 @@ class CompressFC(nn.Module):
                 # f32 step, products as three-term bf16 splits on the matrix cores (csrc/dic_gemm.hip): the 256 -> 128 layer without a library GEMM
                 first, bn = self.model[0], self.model[1]
                 z = ops.mfma_linear(rec_input, first.weight, first.bias, bias_grad_is_zero=bn.training)
+                if last.in_features == ops.HEAD_IN and last.out_features in ops.BNHEAD_OUT:
+                    # BatchNorm -> ReLU -> Dropout -> Linear(128, C) as the streaming kernels of csrc/dic_bnhead.hip on f32 rows
+                    return ops.bn_relu_head(z, bn, last, dropout=self.model[3])
                 return self.model[4](self.model[3](self.model[2](bn(z))))
             return self.model(rec_input)
         # bf16 step: the C-wide output layer over all B*R rows is a 100 MB stream, not a GEMM (csrc/dic_head.hip)

@@ -437,6 +437,18 @@ int dic_bnhead_bwd_reduce(const void* z, const float* mean, const float* rstd, c
 int dic_bnhead_bwd_input(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
                          const float* dv, const float* sum_da, const float* sum_dax, double inv_n, const float* count, int64_t N, int K, int C, int relu,
                          float drop_p, const uint64_t* rng, void* dz, dic_stream_t stream);
+/* The same four kernels on an f32 (N,128) pre-activation -- the f32 step ('x3' products: ops.mfma_linear writes z in f32): every value of the
+ * BatchNorm -> ReLU -> Dropout -> Linear tail stays f32, no torch BatchNorm kernels, no library GEMM for the C-wide head. */
+int dic_bn_colstats_f32(const float* z, int64_t N, int K, double* sums, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+int dic_bnhead_fwd_f32(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                       const float* b, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* v, dic_stream_t stream);
+int dic_bnhead_bwd_reduce_f32(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                              const float* dv, int64_t N, int K, int C, int relu, float drop_p, const uint64_t* rng, float* sums,
+                              void* workspace, size_t workspace_bytes, dic_stream_t stream);
+int dic_bnhead_bwd_input_f32(const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* W,
+                             const float* dv, const float* sum_da, const float* sum_dax, double inv_n, const float* count, int64_t N, int K, int C, int relu,
+                             float drop_p, const uint64_t* rng, float* dz, dic_stream_t stream);
+
 
 /* ------------------------------------------------- K-sweep statistics (p2, internal_eval) ------
  * One pass over all N^2 point pairs, nothing n x n materialised.  Replaces sklearn pairwise_distances per
@@ -487,9 +499,11 @@ int dic_accumulate_many(const float* const* src, float* const* dst, const int* n
  *                 (dic_gemm_tn_workspace bytes) and are summed in a fixed order in f64: deterministic.  accumulate != 0: added to D. */
 int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void* W, long ldw, const float* bias, long M, int N, int K,
                 void* Y, long ldy, int relu_a, dic_stream_t stream);
-size_t dic_gemm_tn_workspace(long M, int N, int K);
+size_t dic_gemm_tn_workspace(long M, int N, int K, int K2);
+/* X2 (M,K2) at stride ldx2 (or NULL, K2 = 0): a second right-hand operand multiplied in the SAME pass over A, D2 (N,K2) f32 at stride ldd2 (+)= A^T.X2
+ * -- dW_ih = dG^T.x and dW_hh = dG^T.h_prev read the gate gradients once. */
 int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
-                int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+                const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
 #ifdef __cplusplus
 }

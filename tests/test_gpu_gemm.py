@@ -59,6 +59,26 @@ def test_gemm_tn_matches_f64(dtype, M, N, K, kcols, accumulate):
     assert torch.equal(again, dst)                                                  # fixed-order reductions: run-to-run identical
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('M,K,kcols,K2,accumulate', [(24 * 200, 40, 36, 128, False), (70001, 256, 256, 128, True), (33, 24, 18, 128, False)])
+def test_gemm_tn_two_products_from_one_pass(dtype, M, K, kcols, K2, accumulate):
+    """dW_ih = dG^T.x and dW_hh = dG^T.h_prev of one LSTM direction from ONE pass over the gate gradients (dic_gemm_tn's second operand)."""
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(M + K)
+    dev = torch.device('cuda')
+    N = 512
+    a = (torch.randn(M, 2 * N, device=dev) * 0.3).to(dtype)[:, :N]
+    x = (torch.randn(M, K, device=dev) * 0.5).to(dtype)
+    h = (torch.randn(M + 3, 2 * K2, device=dev) * 0.5).to(dtype)[3:, K2:]          # a row-shifted half-row view, as h_prev of the reverse direction
+    d1, d2 = torch.randn(N, kcols, device=dev), torch.randn(N, K2, device=dev)
+    b1, b2 = d1.clone(), d2.clone()
+    ops.gemm_tn_into(a, x, d1, kcols=kcols, accumulate=accumulate, x2=h, dst2=d2)
+    w1 = a.double().t() @ x.double()[:, :kcols] + (b1.double() if accumulate else 0.0)
+    w2 = a.double().t() @ h.double() + (b2.double() if accumulate else 0.0)
+    for got, want in ((d1, w1), (d2, w2)):
+        assert float((got.double() - want).abs().max()) / float(want.abs().max()) <= 10 * _tol(dtype)
+
+
 def test_split_products_are_f32_grade_where_bf16_is_not():
     """The point of the three-term split: f32 operands with a full mantissa -- bf16 rounding of the same operands is off by ~1e-3."""
     from deep_interpolation_clustering_amd import ops
