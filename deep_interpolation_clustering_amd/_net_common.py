@@ -195,6 +195,16 @@ class NetBase(nn.Module):
                 context = context[:, :B]
                 hidden, cell = (hidden[:B], cell[:B]) if bm else (hidden[:, :B].contiguous(), cell[:, :B].contiguous())
         cat_hidden = z_all if z_all.size(0) == B else z_all[:B]        # (no slice node -- and no zero-filled slice_backward -- without extra branches)
+        q = colsum = None
+        if self.clustering:
+            # the soft assignment needs the latent only: computed here, its column sums f_j (a batch-level statistic: one exchange when the batch
+            # is sharded over ranks) ride on the next small all-reduce -- CompressFC's BatchNorm moments -- instead of paying their own
+            q = self.cluster_assignment(cat_hidden)
+            _, colsum = self.cluster_assignment.last_colsum
+            if dist.is_sharded():
+                colsum = colsum.clone()
+                colsum._dic_deferred_sum = True
+                dist.deferred_sum_(colsum)
         if self.on_decoder_side_grads is not None and context.requires_grad:
             cb = self.on_decoder_side_grads
             context.register_hook(lambda g: cb())           # fires when the backward has passed the decoder, its head and the latent heads
@@ -223,8 +233,6 @@ class NetBase(nn.Module):
             aux['positive'] = z_all[2 * B:3 * B]
             aux['negative'] = z_all[B:2 * B]
         if self.clustering:
-            q = self.cluster_assignment(cat_hidden)
-            _, colsum = self.cluster_assignment.last_colsum
             aux['cluster_pred'] = q
             aux['cluster_label'] = target_distribution(q, colsum).detach()
         return cat_hidden, y, aux

@@ -36,11 +36,58 @@ def rank() -> int:
     return td.get_rank() if (td.is_available() and td.is_initialized()) else 0
 
 
+# Small statistics that are not needed at once ride on the NEXT small sum all-reduce of the step instead of paying a latency-bound exchange of
+# their own ("pack all small statistics into one buffer per step"): the DEC column sums f_j are known right after the encoder
+# but consumed only by the target distribution at the end of the forward -- they travel with the BatchNorm moments of CompressFC.
+_RIDERS = []
+RIDER_MAX_CARRIER = 4096          # elements: only small exchanges carry riders (never the gradient bucket: the concatenation would copy it)
+
+
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
-    """In-place sum all-reduce; a no-op when not sharded."""
-    if is_sharded():
+    """In-place sum all-reduce; a no-op when not sharded.  Pending riders (``deferred_sum_``) of a dtype this buffer can carry exactly are
+    appended, reduced in the same collective and written back in place."""
+    if not is_sharded():
+        return t
+    riders = []
+    if _RIDERS and t.numel() <= RIDER_MAX_CARRIER and t.is_contiguous():
+        for r in list(_RIDERS):
+            if r.device == t.device and (r.dtype == t.dtype or (t.dtype == torch.float64 and r.dtype == torch.float32)):
+                riders.append(r)
+                _RIDERS.remove(r)
+    if not riders:
         td.all_reduce(t, op=td.ReduceOp.SUM)
+        return t
+    buf = torch.cat([t.reshape(-1)] + [r.reshape(-1).to(t.dtype) for r in riders])
+    td.all_reduce(buf, op=td.ReduceOp.SUM)
+    o = t.numel()
+    t.copy_(buf[:o].view_as(t))
+    for r in riders:
+        r.copy_(buf[o:o + r.numel()].view_as(r))          # (f32 riders on an f64 carrier: summed in f64, rounded once)
+        o += r.numel()
     return t
+
+
+def deferred_sum_(t: torch.Tensor) -> torch.Tensor:
+    """Queue ``t`` for an in-place sum all-reduce that rides on the next small ``all_reduce_sum_``; ``resolve_sum_(t)`` before reading it."""
+    if is_sharded() and not any(r is t for r in _RIDERS):
+        _RIDERS.append(t)
+    return t
+
+
+def resolve_sum_(t: torch.Tensor) -> torch.Tensor:
+    """``t`` holds its global sum after this call: a rider that found no carrier gets a collective of its own."""
+    for i, r in enumerate(_RIDERS):
+        if r is t:
+            del _RIDERS[i]
+            if is_sharded():
+                td.all_reduce(t, op=td.ReduceOp.SUM)
+            break
+    return t
+
+
+def drop_riders():
+    """(step.Stepper, after a forward that raised: nothing may ride into the next step)"""
+    del _RIDERS[:]
 
 
 def all_gather_rows(t: torch.Tensor) -> torch.Tensor:

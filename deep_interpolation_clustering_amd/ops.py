@@ -491,8 +491,11 @@ def dec_target(q, colsum=None):
     B, K = qd.shape
     if colsum is None:
         colsum = qd.sum(dim=0)      # K floats of host-side plumbing; hot callers pass the kernel's colsum
-    colsum = colsum.clone() if dist.is_sharded() else colsum
-    dist.all_reduce_sum_(colsum)
+    if getattr(colsum, '_dic_deferred_sum', False):
+        dist.resolve_sum_(colsum)         # queued by the caller right after the soft assignment (dist.deferred_sum_): it has usually travelled already
+    else:
+        colsum = colsum.clone() if dist.is_sharded() else colsum
+        dist.all_reduce_sum_(colsum)
     p = torch.empty_like(qd)
     N.check(N.lib().dic_dec_target(N.ptr(qd), N.ptr(N.f32c(colsum)), B, K, N.ptr(p), N.stream_of(qd)), 'dic_dec_target')
     return p

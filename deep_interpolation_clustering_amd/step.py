@@ -194,6 +194,7 @@ class Stepper:
             with ops.grad_sink_session(), fused_lstm.side_stream_session():
                 losses['loss'].backward()
         finally:
+            dist.drop_riders()
             self.model.internal_step = False
             self.model.rec_target = None
             self.model._fused_rec = None

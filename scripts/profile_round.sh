@@ -3,20 +3,14 @@
 #   bash scripts/profile_round.sh 2
 # Counters are collected in passes of their own (--pmc with --kernel-trace only), as gpurun requires.
 set -e
-R=${1:-3}
+R=${1:-4}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_r$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel statistics of the bench command itself
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline --steps 30 --warmup 10 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 cp /tmp/p_stats/b_kernel_stats.csv $OUT/bench_kernel_stats.csv
-# 1b. the same with the decoder's weight-gradient kernel on a side stream next to the encoder backward (DIC_DW_SIDE_STREAM=1, round 2's default):
-#     the encoder's lstm_bwd launches of the step then share the chip with lstm_dw_wide and stretch
-export DIC_DW_SIDE_STREAM=1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats1 -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline > $OUT/bench_side_stream_under_rocprof.json 2> /dev/null
-unset DIC_DW_SIDE_STREAM
-cp /tmp/p_stats1/b_kernel_stats.csv $OUT/bench_side_stream_kernel_stats.csv
 echo "[profile] kernel stats done"
 # 2. HBM traffic per kernel (micro table at the bench batch)
 # (k1 / k2 on the ragged encounter store, the input path of the timed step; the padded-input launches of the same kernels in a pass of their own)
@@ -53,4 +47,16 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/c4_fetch -
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/c4_write -o p -- python3 $ROOT/scripts/kbench.py 8192 3 16 12 288 200 nolstm > /dev/null 2>&1
 python3 $ROOT/scripts/pmc_generic.py /tmp/c4_fetch/p_counter_collection.csv /tmp/c4_write/p_counter_collection.csv 'sci_cci|rbf_|masked_sse|dec_' > $OUT/cfg4_pmc_traffic.json
 echo "[profile] cfg4 done"
+# 7. the joint step at cfg4's shape (C=12 -> 64-wide packed encoder rows): kernel statistics
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c4s_stats -o k -- python3 $ROOT/scripts/cfg4_step.py 20 > $OUT/cfg4_step.txt 2>&1
+cp /tmp/c4s_stats/k_kernel_stats.csv $OUT/cfg4_step_kernel_stats.csv
+echo "[profile] cfg4 step done"
+# 8. the f32 step with every dense product as a three-term bf16 split (--dtype f32x3) at the headline batch: kernel statistics + HBM traffic of its
+#    recurrence / product kernels
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/x3_stats -o k -- python3 $ROOT/bench.py --dtype f32x3 --no-secondary --no-cpu-baseline --steps 10 --warmup 3 --kernel-iters 1 > $OUT/bench_f32x3_under_rocprof.json 2> /dev/null
+cp /tmp/x3_stats/k_kernel_stats.csv $OUT/step_f32x3_B32768_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/x3_fetch -o p -- python3 $ROOT/bench.py --dtype f32x3 --no-secondary --no-cpu-baseline --steps 4 --warmup 2 --kernel-iters 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/x3_write -o p -- python3 $ROOT/bench.py --dtype f32x3 --no-secondary --no-cpu-baseline --steps 4 --warmup 2 --kernel-iters 1 > /dev/null 2>&1
+python3 $ROOT/scripts/pmc_generic.py /tmp/x3_fetch/p_counter_collection.csv /tmp/x3_write/p_counter_collection.csv 'lstm_rec_|gemm_|bnhead|bn_colstats' > $OUT/step_f32x3_pmc_traffic.json
+echo "[profile] f32x3 done"
 ls -la $OUT

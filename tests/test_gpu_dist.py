@@ -136,11 +136,22 @@ def _run(rank, world, port, out, rccl=False):
     net = _pretrained(Net(_args(), dev).to(dev))
     net.train()
     st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), _args())
-    res = []
+    import torch.distributed as td
+    calls, inner = [], td.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls.append(int(t.numel()))
+        return inner(t, *a, **k)
+    td.all_reduce = counting_all_reduce          # every collective of the step goes through it (dist.all_reduce_sum_, the gradient bucket's async pieces)
+    res, per_step = [], []
     for _ in range(3):
+        n0 = len(calls)
         losses, gnorm, _ = st.step(x, ob, None, lens)
+        per_step.append(calls[n0:])
         res.append([float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(losses['kl'].detach()), float(gnorm)])
-    torch.save({'traj': np.array(res), 'flat': st.flat.flat.detach().cpu(), 'bn_mean': net.rbf.compress_fc.module.model[1].running_mean.cpu()},
+    td.all_reduce = inner
+    torch.save({'traj': np.array(res), 'flat': st.flat.flat.detach().cpu(), 'bn_mean': net.rbf.compress_fc.module.model[1].running_mean.cpu(),
+                'collectives': per_step},
                os.path.join(out, f'w{world}{"x" if rccl else ""}_r{rank}.pt'))
     _leave()
 
@@ -161,6 +172,16 @@ def test_two_rank_step_equals_single_device(tmp_path):
     np.testing.assert_allclose(r0['bn_mean'].numpy(), one['bn_mean'].numpy(), rtol=1e-3, atol=1e-4)   # global-batch BatchNorm moments
     d = (r0['flat'] - one['flat']).abs()
     assert float(d.max()) < 2e-2 and float((d > 1e-4).float().mean()) < 0.01        # Adam amplifies noise only where grad ~ 0
+    # the exchanges of a sharded joint step, bounded by what the data dependencies force (at 4 096 rows per GPU every extra
+    # latency-bound exchange is 1-2 % of the step): forward -- BatchNorm moments of CompressFC carrying the DEC column sums f_j (they are
+    # known earlier and needed later: dist.deferred_sum_), the reconstruction SSE + mask count (needs the BatchNorm output), the KL sum +
+    # batch rows (needs f_j); backward -- BatchNorm's two column sums, the gradient bucket in two pieces (the decoder-side piece overlaps
+    # the encoder backward)
+    assert one['collectives'] == [[], [], []]
+    for step in r0['collectives']:
+        assert len(step) <= 6, step
+        assert sorted(step)[-2:] == sorted(step)[-2:] and sum(1 for n in step if n > 10000) == 2      # two big pieces, the rest small statistics
+        assert any(n == 2 * 128 + 1 + 4 for n in step), step                                            # f_j (K = 4) rode with the 257 BatchNorm sums
 
 
 def _run_cfg3(rank, world, port, out):

@@ -54,9 +54,17 @@ def relmax(a, b):
 # Tolerances of the trajectory tests: <= 3 x max(measured distance of the GPU run from the reference's trajectory, the reference's own
 # run-to-run spread between 8 and 3 CPU threads).  Measured values: profiles/r4_traj_deviation.json / tests/golden/ref_spread.json; both are
 # restated in DESIGN.md section 2.
-TOL = {
-    'p1_first2': 1e-5, 'p1_first8': 1e-4, 'p1_all': 1e-3, 'p1_valid': 2e-3, 'p1_state': 3e-3, 'p1_moments': 1e-2,
-    'p3_first2': 1e-5, 'p3_first8': 2e-4, 'p3_all': 3e-3, 'p3_param_norms': 2e-3,
+TOL = {       # tolerance (measured on the GPU, round 4 / the reference's own spread): profiles/r4_traj_deviation.json
+    'p1_first2': 2.5e-6,        # 1.5e-7 / 8.2e-7
+    'p1_first8': 1.1e-4,        # 3.4e-5 / 2.8e-5
+    'p1_all': 2.7e-4,           # 8.9e-5 / 4.2e-5
+    'p1_valid': 3.3e-4,         # 1.1e-4 / 1.7e-5
+    'p1_state': 4.3e-3,         # 1.4e-3 (relative L2 distance of the worst parameter tensor after 16 steps)
+    'p1_moments': 3.5e-4,       # 5.8e-5 / 1.1e-4
+    'p3_first2': 1e-6,          # 2.3e-7  (p3 starts from the fixture's p1 state: no reference spread is comparable -- see ref_spread.json's note)
+    'p3_first8': 8.1e-5,        # 2.7e-5  (K = 6, the over-segmented run; K = 4: 2.7e-6)
+    'p3_all': 8.1e-5,           # 2.7e-5
+    'p3_param_norms': 5.4e-6,   # 1.8e-6
 }
 
 
