@@ -170,7 +170,7 @@ def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True, input_path='both
     ws2s = torch.empty(max(16, L.dic_rbf_fwd_loss_workspace(B, C, T, R)), dtype=torch.uint8, device=dev)
     if 3 * C < 32:
         calls['sci_cci_fwd_store'] = (lambda: L.dic_sci_cci_fwd_store(*sp, None, P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(sk), P(ck), None,
-                                                                     P(saved), P(xenc_k1), 32, st), 8 * nsum + 4 * B * C + 12 * B * C * R)
+                                                                     P(saved), P(xenc_k1), 32, int(stor.times_sorted), st), 8 * nsum + 4 * B * C + 12 * B * C * R)
     calls['rbf_fwd_store'] = (lambda: L.dic_rbf_fwd_store(*sp, P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(rk), P(v), 0, 1, P(y), P(norm), 1,
                                                           P(out2s), P(ws2s), ws2s.numel(), st), 12 * nsum + 4 * B * C * R)
     calls['rbf_bwd_store'] = (lambda: L.dic_rbf_bwd_store(*sp, P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(rk), P(v), 0, P(y), P(norm), None,

@@ -34,7 +34,7 @@ SIGNATURES = {
     'dic_last_error_string': (C.c_char_p, []),
     'dic_sci_cci_fwd': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     'dic_sci_cci_fwd_ragged': (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
-    'dic_sci_cci_fwd_store': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p]),
+    'dic_sci_cci_fwd_store': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     'dic_rbf_fwd_store': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _sz, _p]),
     'dic_rbf_bwd_store': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'dic_sci_cci_bwd_workspace': (_sz, [_i, _i, _i]),

@@ -454,6 +454,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
     }
     // lane owns batch row (nb*32 + r) and hidden units 16 w + 8 q + 4 hh + {0..3}, q = 0..1: element 4 q + j
     float c[LNB][8];
+    bf16x4 hkeep[LNB];     // unit group 0's h of each half, until group 1's is there (see gate_math)
 #pragma unroll
     for (int nb = 0; nb < LNB; ++nb) {
         const int b = b0 + nb * 32 + r;
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
         if (!a.out_relu) return;
 #pragma unroll
         for (int k = 0; k < LBM * 16 / 512; ++k) {
-            const int i = k * 512 + tid, row = i >> 4, pc = i & 15;
+            const int i = k * 512 + tid, row = i >> 4, pc = ((i & 15) - (row & 1)) & 15;      // odd rows rotated by one 16-B piece (LDS banks, see below)
             if (b0 + row < B) {
                 const uint4 v = *reinterpret_cast<const uint4*>(&hbuf[buf][row * HSTR + pc * 8]);
                 auto rl = [](unsigned x) { return x & ~(((x & 0x80008000u) >> 15) * 0xffffu); };
@@ -499,10 +500,13 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
         }
     };
     // the step's h rows LDS -> global as whole 256-B pieces, one step late (see lstm_fwd8_gxn_kernel; same-box A/B 501 -> 482 us here)
+    // (round 4: a ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27}, ... -- eight pieces of an even row and the OTHER eight of the odd row
+    //  behind it; at the 272-B pitch piece p of row r sits on slot (r + p) mod 16, so piece 12 of the even row met piece 11 of the odd one: a
+    //  doubled slot in every group.  Lane i of an odd row now copies piece (i - 1) & 15 -- the 16 lanes still cover the row, conflict-free.)
     auto store_out_rows = [&](int t_of_rows, int buf) {
 #pragma unroll
         for (int k = 0; k < LBM * 16 / 512; ++k) {
-            const int i = k * 512 + tid, row = i >> 4, pc = i & 15;
+            const int i = k * 512 + tid, row = i >> 4, pc = ((i & 15) - (row & 1)) & 15;      // odd rows rotated by one 16-B piece (LDS banks, see below)
             if (b0 + row < B)
                 *reinterpret_cast<uint4*>(a.out + ((size_t)t_of_rows * B + b0 + row) * 2 * LH + dir * LH + pc * 8) =
                     *reinterpret_cast<const uint4*>(&hbuf[buf][row * HSTR + pc * 8]);
@@ -552,7 +556,20 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_proj_kernel(LstmFwdArgs a) {
                 cv[j] = cn; hv[j] = hn;
                 hb[j] = (__bf16)hn; ib[j] = (__bf16)ig; fb[j] = (__bf16)fg; gb[j] = (__bf16)gg; ob[j] = (__bf16)og;
             }
-            *reinterpret_cast<bf16x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + u]) = hb;
+            // h_t -> the LDS tile as ONE 16-B store per lane and unit-group pair (round 4; was two 8-B stores: ds_write_b64 is served in groups
+            // of 16 consecutive lanes with banks mod 32, and at the 272-B pitch rows r and r + 8 share their banks -- 2-way): the lane halves
+            // trade group 1 of the lower half for group 0 of the upper one, so that lane (r, hh) holds units 16 w + 8 hh .. + 7 of its row
+            if (q == 0) {
+                hkeep[nb] = hb;
+            } else {
+                typedef unsigned hu32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
+                hu32x2 A = __builtin_bit_cast(hu32x2, hkeep[nb]), Bv = __builtin_bit_cast(hu32x2, hb);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(A[0], Bv[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(A[1], Bv[1], false, false);
+                const hu32x4 v16 = {s0[0], s1[0], s0[1], s1[1]};
+                *reinterpret_cast<hu32x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + 16 * w + 8 * hh]) = v16;
+            }
             if (a.gates) {
                 const int bt = blockIdx.x * LNB + nb;
 #ifndef DIC_LSTM_EXP_RECOMPUTE   // experiment (scripts/lstm_recompute_ab.sh, timing only): the backward recomputes the gates, the forward does not save them
@@ -618,6 +635,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
     }
     // lane owns batch row (nb*32 + r) and hidden units 16 w + 8 q + 4 hh + {0..3}, q = 0..1: element 4 q + j
     float c[LNB][8];
+    bf16x4 hkeep[LNB];     // unit group 0's h of each half, until group 1's is there (see gate_math)
 #pragma unroll
     for (int nb = 0; nb < LNB; ++nb) {
         const int b = b0 + nb * 32 + r;
@@ -674,7 +692,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
         if (!a.out_relu) return;
 #pragma unroll
         for (int k = 0; k < LBM * 16 / 512; ++k) {
-            const int i = k * 512 + tid, row = i >> 4, pc = i & 15;
+            const int i = k * 512 + tid, row = i >> 4, pc = ((i & 15) - (row & 1)) & 15;      // odd rows rotated by one 16-B piece (LDS banks, see below)
             if (b0 + row < B) {
                 const uint4 v = *reinterpret_cast<const uint4*>(&hbuf[buf][row * HSTR + pc * 8]);
                 auto rl = [](unsigned x) { return x & ~(((x & 0x80008000u) >> 15) * 0xffffu); };
@@ -688,7 +706,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
     auto store_out_rows = [&](int t_of_rows, int buf) {
 #pragma unroll
         for (int k = 0; k < LBM * 16 / 512; ++k) {
-            const int i = k * 512 + tid, row = i >> 4, pc = i & 15;
+            const int i = k * 512 + tid, row = i >> 4, pc = ((i & 15) - (row & 1)) & 15;      // odd rows rotated by one 16-B piece (LDS banks, see below)
             const uint4 v = *reinterpret_cast<const uint4*>(&hbuf[buf][row * HSTR + pc * 8]);
             *reinterpret_cast<uint4*>(a.out + ((size_t)t_of_rows * B + b0 + row) * 2 * LH + dir * LH + pc * 8) = v;
         }
@@ -740,7 +758,20 @@ __global__ __launch_bounds__(512, 1) void lstm_fwd8_gxn_kernel(LstmFwdArgs a) {
                 cv[j] = cn; hv[j] = hn;
                 hb[j] = (__bf16)hn; ib[j] = (__bf16)ig; fb[j] = (__bf16)fg; gb[j] = (__bf16)gg; ob[j] = (__bf16)og;
             }
-            *reinterpret_cast<bf16x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + u]) = hb;
+            // h_t -> the LDS tile as ONE 16-B store per lane and unit-group pair (round 4; was two 8-B stores: ds_write_b64 is served in groups
+            // of 16 consecutive lanes with banks mod 32, and at the 272-B pitch rows r and r + 8 share their banks -- 2-way): the lane halves
+            // trade group 1 of the lower half for group 0 of the upper one, so that lane (r, hh) holds units 16 w + 8 hh .. + 7 of its row
+            if (q == 0) {
+                hkeep[nb] = hb;
+            } else {
+                typedef unsigned hu32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned hu32x4 __attribute__((ext_vector_type(4)));
+                hu32x2 A = __builtin_bit_cast(hu32x2, hkeep[nb]), Bv = __builtin_bit_cast(hu32x2, hb);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(A[0], Bv[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(A[1], Bv[1], false, false);
+                const hu32x4 v16 = {s0[0], s1[0], s0[1], s1[1]};
+                *reinterpret_cast<hu32x4*>(&hbuf[cur ^ 1][(nb * 32 + r) * HSTR + 16 * w + 8 * hh]) = v16;
+            }
             if (a.gates) {
                 const int bt = blockIdx.x * LNB + nb;
 #ifndef DIC_LSTM_EXP_RECOMPUTE   // experiment (scripts/lstm_recompute_ab.sh, timing only): the backward recomputes the gates, the forward does not save them

@@ -137,7 +137,7 @@ class _SciCci(torch.autograd.Function):
         saved = torch.empty((B, 7, C, R), device=x.device, dtype=torch.float32) if need_grad else None
         if store:
             N.check(N.lib().dic_sci_cci_fwd_store(*_store_ptrs(x), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), N.ptr(out), N.ptr(saved),
-                                                  None, 0, N.stream_of(out)), 'dic_sci_cci_fwd_store')
+                                                  None, 0, int(x.store.times_sorted), N.stream_of(out)), 'dic_sci_cci_fwd_store')
         else:
             N.check(N.lib().dic_sci_cci_fwd(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck),
                                             N.ptr(out), N.ptr(saved), N.stream_of(x)), 'dic_sci_cci_fwd')
@@ -205,7 +205,7 @@ class _SciCciPacked(torch.autograd.Function):
         saved = torch.empty((B, 7, C, R), device=x.device, dtype=torch.float32) if need_grad else None
         if store:
             N.check(N.lib().dic_sci_cci_fwd_store(*_store_ptrs(x), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), None, N.ptr(saved),
-                                                  N.ptr(xenc), xw, N.stream_of(xenc)), 'dic_sci_cci_fwd_store')
+                                                  N.ptr(xenc), xw, int(x.store.times_sorted), N.stream_of(xenc)), 'dic_sci_cci_fwd_store')
         else:
             N.check(N.lib().dic_sci_cci_fwd_packed(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(sk), N.ptr(ck), None,
                                                    N.ptr(saved), N.ptr(xenc), xw, N.stream_of(x)), 'dic_sci_cci_fwd_packed')

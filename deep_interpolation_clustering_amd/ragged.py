@@ -29,6 +29,10 @@ class RaggedStore:
         row_off = np.zeros(N * C + 1, np.int64)
         np.cumsum(lengths.reshape(-1), out=row_off[1:])
         total = int(row_off[-1])
+        # are the time stamps of every row non-decreasing?  (p0 writes them in charting order; the synthetic cohorts sort them.)  One host pass
+        # here lets k1 find each grid point's nearest sample by bisection instead of a pass over the row (dic_sci_cci_fwd_store(times_sorted=1))
+        tpl = fd[:, 2 * C:3 * C]
+        self.times_sorted = bool(np.all((np.diff(tpl, axis=-1) >= 0) | ~mask[..., 1:]))
 
         def pack(plane, dtype):
             out = np.zeros(total + PAD_TAIL, dtype)

@@ -85,11 +85,13 @@ int dic_sci_cci_fwd_ragged(const float* t_pk, const float* v_pk, const int64_t* 
  *                NULL: the batch is encounters 0..B-1;
  *   lengths      (B,C) int32 row lengths of the BATCH rows (= the store's, gathered), or NULL: taken from row_off;
  *   T            the padded width the dense path would have (bounds every row; sizes the LDS rows).
+ * times_sorted != 0: the caller certifies that every row's time stamps are non-decreasing (ragged.RaggedStore checks it once when the cohort is packed):
+ * the soft-max shift min_t (t - ref)^2 is then found by bisection instead of a pass over the row -- the same value, bit for bit.
  * out (B,R,3C) f32 and / or xenc (R,B,xw) bf16 packed rows as dic_sci_cci_fwd_packed; saved as above.  Same arithmetic, same results
  * as the dense entry points on the same samples. */
 int dic_sci_cci_fwd_store(const float* t_pk, const float* v_pk, const uint8_t* hold_pk, const int64_t* row_off, const int32_t* enc_idx,
                           const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid, const float* sci_kernel,
-                          const float* cci_kernel, float* out, float* saved, void* xenc, int xw, dic_stream_t stream);
+                          const float* cci_kernel, float* out, float* saved, void* xenc, int xw, int times_sorted, dic_stream_t stream);
 
 /* Backward of the above wrt the two parameters only (the inputs carry no gradient upstream).
  *   grad_out (B,R,3C) cotangent of `out`; saved from the forward;
