@@ -121,8 +121,9 @@ def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True, input_path='both
     out = torch.empty((B, R, 3 * C), **f32)
     saved = torch.empty((B, 7, C, R), **f32)
     gout = torch.randn((B, R, 3 * C), **f32)
-    xenc_k1 = torch.empty((R, B, 32), device=dev, dtype=torch.bfloat16)
-    gx_k1 = torch.randn((R, B, 32), **f32).to(torch.bfloat16)
+    XW = ops.packed_width(3 * C)               # packed encoder rows: 32 wide for the six vitals, 64 for cfg4's twelve channels (0: not packed)
+    xenc_k1 = torch.empty((R, B, max(XW, 8)), device=dev, dtype=torch.bfloat16)
+    gx_k1 = torch.randn((R, B, max(XW, 8)), **f32).to(torch.bfloat16)
     gs, gc = torch.empty(C, **f32), torch.empty((C, C), **f32)
     ws1 = torch.empty(max(16, L.dic_sci_cci_bwd_workspace(B, C, R)), dtype=torch.uint8, device=dev)
     v = torch.randn((B, C, R), **f32)
@@ -140,11 +141,11 @@ def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True, input_path='both
     calls = {
         # (the entry points the bf16 step uses when 3C < 32: the forward writes the encoder LSTM's packed bf16 input rows, the backward
         #  reads the input gradient in that layout; algorithmic bytes as SURVEY.md 8d counts them, for the f32 (B,R,3C) tensors)
-        'sci_cci_fwd': ((lambda: L.dic_sci_cci_fwd_packed(P(x), P(lengths), B, C, T, R, P(grid), P(sk), P(ck), None, P(saved), P(xenc_k1), 32, st))
-                        if 3 * C < 32 else (lambda: L.dic_sci_cci_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(sk), P(ck), P(out), P(saved), st)),
+        'sci_cci_fwd': ((lambda: L.dic_sci_cci_fwd_packed(P(x), P(lengths), B, C, T, R, P(grid), P(sk), P(ck), None, P(saved), P(xenc_k1), XW, st))
+                        if XW else (lambda: L.dic_sci_cci_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(sk), P(ck), P(out), P(saved), st)),
                         8 * nsum + 4 * B * C + 12 * B * C * R),
-        'sci_cci_bwd': ((lambda: L.dic_sci_cci_bwd_packed(P(gx_k1), 32, P(saved), P(sk), P(ck), B, C, R, P(gs), P(gc), P(ws1), ws1.numel(), st))
-                        if 3 * C < 32 else (lambda: L.dic_sci_cci_bwd(P(gout), P(saved), P(sk), P(ck), B, C, R, P(gs), P(gc), P(ws1), ws1.numel(), st)),
+        'sci_cci_bwd': ((lambda: L.dic_sci_cci_bwd_packed(P(gx_k1), XW, P(saved), P(sk), P(ck), B, C, R, P(gs), P(gc), P(ws1), ws1.numel(), st))
+                        if XW else (lambda: L.dic_sci_cci_bwd(P(gout), P(saved), P(sk), P(ck), B, C, R, P(gs), P(gc), P(ws1), ws1.numel(), st)),
                         8 * nsum + 24 * B * C * R),
         'rbf_fwd': (lambda: L.dic_rbf_fwd(P(x), P(lengths), B, C, T, R, P(grid), P(rk), P(v), 0, P(y), P(norm), 1, st),
                     12 * nsum + 4 * B * C * R),
@@ -168,9 +169,9 @@ def kernel_table(net, x, ob, lengths, K, iters, with_lstm=True, input_path='both
     sp = (P(stor.t_pk), P(stor.v_pk))
     out2s = torch.empty(2, **f32)
     ws2s = torch.empty(max(16, L.dic_rbf_fwd_loss_workspace(B, C, T, R)), dtype=torch.uint8, device=dev)
-    if 3 * C < 32:
+    if XW:
         calls['sci_cci_fwd_store'] = (lambda: L.dic_sci_cci_fwd_store(*sp, None, P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(sk), P(ck), None,
-                                                                     P(saved), P(xenc_k1), 32, int(stor.times_sorted), st), 8 * nsum + 4 * B * C + 12 * B * C * R)
+                                                                     P(saved), P(xenc_k1), XW, int(stor.times_sorted), st), 8 * nsum + 4 * B * C + 12 * B * C * R)
     calls['rbf_fwd_store'] = (lambda: L.dic_rbf_fwd_store(*sp, P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(rk), P(v), 0, 1, P(y), P(norm), 1,
                                                           P(out2s), P(ws2s), ws2s.numel(), st), 12 * nsum + 4 * B * C * R)
     calls['rbf_bwd_store'] = (lambda: L.dic_rbf_bwd_store(*sp, P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(rk), P(v), 0, P(y), P(norm), None,

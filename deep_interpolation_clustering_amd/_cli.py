@@ -72,6 +72,10 @@ P3_ONLY = [
 EXTRA = [   # not upstream
     ('MI355X options', ('--host_loader',), dict(action='store_true', help='use torch DataLoader workers like upstream instead of the HBM-resident loader')),
     ('MI355X options', ('--amp_bf16',), dict(action='store_true', help='bf16 autocast for the bi-LSTMs / FC heads')),
+    ('MI355X options', ('--f32_products',), dict(type=str, default=None, choices=['exact', 'x3'],
+                                                  help="f32 step (no --amp_bf16): 'exact' = exact-f32 MFMA recurrence + f32 library GEMMs (the default); 'x3' = every "
+                                                       "tensor f32, every dense product a three-term bf16 split on the matrix cores (losses within ~1e-6 of the reference at "
+                                                       "1.6x the exact mode's throughput, no library GEMM)")),
     ('MI355X options', ('--hip_graph',), dict(action='store_true', default=None, help='always replay the training step from a captured hipGraph (single GPU); default: automatically for batches up to 8192 encounters, where the step is launch-bound')),
     ('MI355X options', ('--no_hip_graph',), dict(action='store_true', help='never capture the training step (eager launches)')),
     ('MI355X options', ('--cpu_padded_ob',), dict(action='store_true', help="feature dumps: write the padded slots of 'ob' as a CPU run of the reference does "

@@ -38,7 +38,7 @@ class TrainerBase(object):
             from . import tuned
             tuned.enable()                       # pre-tuned library GEMM picks for the step's shapes (read-only; tuned.py)
         self.stepper = Stepper(self.model, lambda m: pytorch_optimizer(m, args.optimizer, args.init_lr, args.weight_decay_rate),
-                               args, autocast_dtype=autocast,
+                               args, autocast_dtype=autocast, precision=(getattr(args, 'f32_products', None) if autocast is None else None),
                                use_graphs=False if getattr(args, 'no_hip_graph', False) else (True if getattr(args, 'hip_graph', None) else 'auto'))
         self.optimizer = self.stepper.optimizer
         self.lr_scheduler = pytorch_lr_scheduler(self.optimizer, args.lr_decay_mode, args.lr_decay_step_or_patience,
