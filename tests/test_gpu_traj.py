@@ -61,6 +61,7 @@ TOL = {       # tolerance (measured on the GPU, round 4 / the reference's own sp
     'p1_valid': 3.3e-4,         # 1.1e-4 / 1.7e-5
     'p1_state': 4.3e-3,         # 1.4e-3 (relative L2 distance of the worst parameter tensor after 16 steps)
     'p1_moments': 3.5e-4,       # 5.8e-5 / 1.1e-4
+    'p1x3_first2': 1.2e-5, 'p1x3_all': 7.5e-4,  # 4.0e-6 / 2.5e-4: the same 16 steps with the products as three-term bf16 splits (--f32_products x3)
     'p3_first2': 1e-6,          # 2.3e-7  (p3 starts from the fixture's p1 state: no reference spread is comparable -- see ref_spread.json's note)
     'p3_first8': 8.1e-5,        # 2.7e-5  (K = 6, the over-segmented run; K = 4: 2.7e-6)
     'p3_all': 8.1e-5,           # 2.7e-5
@@ -310,6 +311,29 @@ def test_pretrain_trainer_follows_reference(run_dir, kind, tmp_path):
     ck = torch.load(os.path.join(exp, 'weight', 'ae_mse', 'model.pth.tar'), map_location='cpu', weights_only=False)
     assert set(ck) == {'epoch', 'state_dict', 'optimizer'} and int(ck['epoch']) == int(t['p1/ckpt_epoch'])
     assert sorted(ck['state_dict'].keys()) == list(t['p1/ckpt_keys'])
+
+
+def test_pretrain_trainer_on_split_products_follows_reference(run_dir, tmp_path):
+    """The same 16 pretrain steps with the f32 step's products as three-term bf16 splits (--f32_products x3): products good to ~2^-17 instead of
+    2^-24, so the trajectory separates from the reference's a little earlier than the exact mode's -- measured (profiles/r4_traj_deviation.json,
+    key p1[x3]) and bounded at 3 x that."""
+    from deep_interpolation_clustering_amd.pretrain_interp import Net
+    from deep_interpolation_clustering_amd.pretrain_trainer import Trainer
+    t, sd_end = p1_state()
+    plain = load('netstep_plain.npz')
+    args = trainer_args(f32_products='x3')
+    dev = torch.device('cuda')
+    net = Net(args, dev)
+    net.load_state_dict({k[4:]: torch.tensor(v) for k, v in plain.items() if k.startswith('sd0/') and 'cluster' not in k}, strict=True)
+    tr = Trainer(args, net, make_loaders(args, dev, 'ragged'), str(tmp_path / 'Pretrain'), dev)
+    assert tr.stepper.precision == 'x3'
+    rec = spy_steps(tr, ['ae_mse'])
+    tr.train()
+    got = np.array([[float(v) for v in row] for row in rec])[:, 0]
+    ref = t['p1/train_ae_mse']
+    log_deviation('p1[x3]', step_loss_rel=np.abs(got - ref) / np.abs(ref))
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=TOL['p1x3_first2'])
+    np.testing.assert_allclose(got, ref, rtol=TOL['p1x3_all'])
 
 
 # ---------------------------------------------------------------------------------------------------------------- p3 trajectory
