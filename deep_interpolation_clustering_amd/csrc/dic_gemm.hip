@@ -353,6 +353,115 @@ __global__ __launch_bounds__(256) void gemm_tn_finalize(const float* part, int S
     *dst = beta != 0.f ? fmaf(beta, *dst, r) : r;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------ x3_row_proj
+// The 256-input projections of the x3 f32 step over all (time step, encounter) rows -- the decoder LSTM's gx = act(x).W_ih^T + b (Nout = 1024) and
+// CompressFC's Linear(256, 128) -- in dic_rowproj.hip's form: the weights never move.  Wave w keeps W[n][0..255] of its 32 output columns as hi / lo
+// bf16 fragments (split ONCE at start-up: 128 registers), the workgroup streams 32-row tiles of f32 x (global -> registers one tile ahead -> split ->
+// two bf16 images in LDS, 560-B pitch: conflict-free straight 16-B reads), 48 MFMAs per tile and wave (hi.hi + lo.hi + hi.lo), f32 outputs straight from
+// the accumulators as 128-B row segments.  Against gemm_nt on the same shapes: no weight traffic and no weight conversion inside the loop, a tile's x
+// split once per 256 output columns instead of once per 128, one barrier per tile.  grid (row chunks, Nout / (32 NW)): the stripes of a chunk share an XCD.
+constexpr int XK = 256, XT = 32;
+constexpr int XPITCH = XK * 2 + 48;                  // bytes per LDS row of a bf16 image
+constexpr int XIMG = XT * XPITCH;                    // 17 920 B
+struct X3ProjArgs {
+    const float* x; const float* w; const float* bias; float* out;
+    long N; int Nout; int relu_in;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
+    constexpr int NT = NW * 64, NCOLS = 32 * NW, PPT = XT * 32 / NT;       // PPT: 8-float pieces of x per thread and tile
+    extern __shared__ __align__(16) unsigned char xsm[];                    // [2 slots][hi image | lo image]
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long N = a.N;
+    const int ntiles = (int)((N + XT - 1) / XT), nch = gridDim.x;
+    const int n0 = blockIdx.y * NCOLS, ncol = n0 + 32 * w + (lane & 31);
+
+    gbf16x8 whi[XK / 16], wlo[XK / 16];              // B operand: W[ncol][16 ks + 8 hh .. + 7] as hi + lo
+    {
+        const float* wr = a.w + (size_t)min(ncol, a.Nout - 1) * XK;
+#pragma unroll
+        for (int ks = 0; ks < XK / 16; ++ks) {
+            const gf32x4 p0 = *reinterpret_cast<const gf32x4*>(wr + 16 * ks + 8 * hh), p1 = *reinterpret_cast<const gf32x4*>(wr + 16 * ks + 8 * hh + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = j < 4 ? p0[j & 3] : p1[j & 3];
+                const __bf16 h = (__bf16)v;
+                whi[ks][j] = h;
+                wlo[ks][j] = (__bf16)(v - (float)h);
+            }
+        }
+    }
+    const float bn = (a.bias && ncol < a.Nout) ? a.bias[ncol] : 0.f;
+
+    // x pieces: piece p = tid + NT j of a tile: row p / 32, floats 8 (p % 32) .. + 7
+    gf32x4 px[PPT][2];
+    auto request = [&](int tile) {
+        const long r0 = (long)tile * XT;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int p = tid + NT * j;
+            const float* src = a.x + (size_t)min(r0 + (p >> 5), N - 1) * XK + (p & 31) * 8;
+            px[j][0] = *reinterpret_cast<const gf32x4*>(src);
+            px[j][1] = *reinterpret_cast<const gf32x4*>(src + 4);
+        }
+    };
+    auto land = [&](int slot) {
+        unsigned char* base = xsm + slot * 2 * XIMG;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int p = tid + NT * j;
+            gbf16x8 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = px[j][e >> 2][e & 3];
+                if (a.relu_in) v = fmaxf(v, 0.f);
+                const __bf16 h = (__bf16)v;
+                vh[e] = h;
+                vl[e] = (__bf16)(v - (float)h);
+            }
+            unsigned char* dst = base + (p >> 5) * XPITCH + (p & 31) * 16;
+            *reinterpret_cast<gbf16x8*>(dst) = vh;
+            *reinterpret_cast<gbf16x8*>(dst + XIMG) = vl;
+        }
+    };
+    const int a_off = (lane & 31) * XPITCH + hh * 16;          // A operand: row (lane & 31), 16-B piece 2 ks + hh
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) { request(tile); land(0); }
+    if (tile + nch < ntiles) request(tile + nch);
+    __syncthreads();
+    int slot = 0;
+    for (; tile < ntiles; tile += nch) {
+        const unsigned char* base = xsm + slot * 2 * XIMG;
+        gf32x16 acc;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = bn;
+#pragma unroll
+        for (int ks = 0; ks < XK / 16; ++ks) {
+            const gbf16x8 ah = *reinterpret_cast<const gbf16x8*>(base + a_off + ks * 32);
+            const gbf16x8 al = *reinterpret_cast<const gbf16x8*>(base + XIMG + a_off + ks * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, whi[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, whi[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wlo[ks], acc, 0, 0, 0);
+        }
+        if (tile + nch < ntiles) land(slot ^ 1);               // (the other slot was read in the previous iteration: everybody is past its barrier)
+        if (tile + 2 * nch < ntiles) request(tile + 2 * nch);
+        // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        const long r0 = (long)tile * XT;
+        if (ncol < a.Nout) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const long m = r0 + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                if (m < N) a.out[(size_t)m * a.Nout + ncol] = acc[k];
+            }
+        }
+        __syncthreads();
+        slot ^= 1;
+    }
+}
+
 static int tn_chunks(long M, int N, int K, int K2, long* rows_per_chunk, int* bko) {
     *bko = (K > 64 || K2 > 64) ? 128 : 64;
     const int tiles = ((N + 127) / 128) * ((K + *bko - 1) / *bko + (K2 + *bko - 1) / *bko);
@@ -437,6 +546,41 @@ int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, 
     hipLaunchKernelGGL(gemm_tn_finalize, dim3((N * KT + 255) / 256), dim3(256), 0, st, (const float*)workspace, S, N, KT, K, D, ldd, kcols, D2, ldd2,
                        accumulate ? 1.0f : 0.0f);
     return check_launch("gemm_tn");
+}
+
+int dic_x3_row_proj(const float* x, const float* w, const float* bias, int64_t N, int in_features, int out_features, float* out, int relu_input,
+                    dic_stream_t stream) {
+    DIC_REQUIRE(N > 0, DIC_ERR_INVALID_ARG, "x3_row_proj: non-positive row count");
+    DIC_REQUIRE(in_features == XK && out_features > 0 && (out_features % 256 == 0 || out_features == 128), DIC_ERR_UNSUPPORTED,
+                "x3_row_proj: (%d -> %d) (compiled for 256 -> 128 or a multiple of 256)", in_features, out_features);
+    DIC_REQUIRE(x && w && out, DIC_ERR_INVALID_ARG, "x3_row_proj: NULL pointer");
+    DIC_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, DIC_ERR_UNSUPPORTED, "x3_row_proj: x and w must be 16-B aligned");
+    X3ProjArgs a{x, w, bias, out, (long)N, out_features, relu_input != 0};
+    const int lds = 2 * 2 * XIMG;
+    const int ntiles = (int)((N + XT - 1) / XT);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_features == 128) {
+        static bool attr4 = false;
+        if (!attr4) {
+            hipError_t e = hipFuncSetAttribute((const void*)x3_row_proj_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "x3_row_proj: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+            attr4 = true;
+        }
+        const int nch = max(1, min(ntiles, 2 * kNumCU));
+        hipLaunchKernelGGL(x3_row_proj_kernel<4>, dim3(nch, 1), dim3(256), lds, st, a);
+    } else {
+        static bool attr8 = false;
+        if (!attr8) {
+            hipError_t e = hipFuncSetAttribute((const void*)x3_row_proj_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "x3_row_proj: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+            attr8 = true;
+        }
+        const int stripes = out_features / 256;
+        int nch = max(1, min(ntiles, kNumCU / stripes * 1));
+        nch = nch >= 8 ? nch / 8 * 8 : nch;                          // a multiple of 8: the stripes of a row chunk share an XCD
+        hipLaunchKernelGGL(x3_row_proj_kernel<8>, dim3(nch, stripes), dim3(512), lds, st, a);
+    }
+    return check_launch("x3_row_proj");
 }
 
 }  // extern "C"

@@ -185,6 +185,8 @@ class _BiLstm(torch.autograd.Function):
             elif (not f32) and Ip == WIDE_INPUT and ROW_PROJ:
                 gx = torch.empty((R * B, 8 * H), device=dev, dtype=T)           # decoder: weights resident in registers (csrc/dic_rowproj.hip)
                 N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), 0, 0, st), 'dic_row_proj')
+            elif x3 and _ops.x3_row_proj_ok(xb.view(R * B, Ip), wih):
+                gx = _ops.x3_row_proj(xb.view(R * B, Ip), wih, bias)              # decoder, x3: weights split once, resident in registers
             elif x3 or not f32:
                 gx = _ops.gemm_nt(xb.view(R * B, Ip), wih, bias.float())
             else:

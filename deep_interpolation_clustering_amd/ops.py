@@ -771,6 +771,24 @@ def gemm_nt(a, w, bias=None, out_dtype=None, relu_a=False, out=None):
     return y
 
 
+X3_ROW_PROJ = os.environ.get('DIC_X3_ROW_PROJ', '1') != '0'      # (A/B switch: 0 = dic_gemm_nt for the 256-input projections of the x3 step too)
+
+
+def x3_row_proj_ok(x, w):
+    """f32 (N,256) contiguous rows times f32 (128 | k*256, 256): the resident-weight form of the three-term-split product (dic_x3_row_proj)."""
+    return (X3_ROW_PROJ and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 256 and x.is_contiguous()
+            and w.dim() == 2 and w.shape[1] == 256 and w.is_contiguous() and (w.shape[0] == 128 or w.shape[0] % 256 == 0))
+
+
+def x3_row_proj(x, w, bias=None, relu_a=False):
+    """y (N, Nout) f32 = act(x (N,256)) . w (Nout,256)^T + bias with every product a three-term bf16 split, the weights resident in registers."""
+    N.require_gpu(x, w)
+    y = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32)
+    b = None if bias is None else N.f32c(bias)
+    N.check(N.lib().dic_x3_row_proj(N.ptr(x), N.ptr(w), N.ptr(b), x.shape[0], 256, w.shape[0], N.ptr(y), int(bool(relu_a)), N.stream_of(x)), 'dic_x3_row_proj')
+    return y
+
+
 def gemm_tn_into(a, x, dst, kcols=None, accumulate=False, x2=None, dst2=None):
     """dst (N,kcols) f32 (+)= a (M,N)^T . x (M,K)[:, :kcols] (dic_gemm_tn): the weight-gradient shape -- a reduction over hundreds of thousands of
     rows into a small matrix; row chunks in parallel, fixed-order f64 second stage (deterministic).  ``x2`` (M,K2), ``dst2`` (N,K2): a second
@@ -808,6 +826,8 @@ class _MfmaLinear(torch.autograd.Function):
         wc = weight.detach().to(xc.dtype).contiguous()
         ctx.save_for_backward(xc, wc)
         ctx.zero_db, ctx.sink_params = bool(bias_grad_is_zero), (weight, bias)
+        if x3_row_proj_ok(xc, wc):
+            return x3_row_proj(xc, wc, bias.detach())
         return gemm_nt(xc, wc, bias.detach())
 
     @staticmethod

@@ -501,6 +501,11 @@ int dic_accumulate_many(const float* const* src, float* const* dst, const int* n
  *                 (dic_gemm_tn_workspace bytes) and are summed in a fixed order in f64: deterministic.  accumulate != 0: added to D. */
 int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void* W, long ldw, const float* bias, long M, int N, int K,
                 void* Y, long ldy, int relu_a, dic_stream_t stream);
+/* dic_x3_row_proj: out (N, out_features) f32 = act(x (N,256) f32) . w (out_features,256)^T + bias, every product a three-term bf16 split, for the
+ * 256-input projections of the x3 f32 step (the decoder LSTM's input projection, out_features = 1024; CompressFC's Linear(256,128)): weights split once and
+ * resident in registers, x tiles streamed through LDS (csrc/dic_gemm.hip).  out_features: 128 or a multiple of 256; relu_input != 0: act = max(., 0). */
+int dic_x3_row_proj(const float* x, const float* w, const float* bias, int64_t N, int in_features, int out_features, float* out, int relu_input,
+                    dic_stream_t stream);
 size_t dic_gemm_tn_workspace(long M, int N, int K, int K2);
 /* X2 (M,K2) at stride ldx2 (or NULL, K2 = 0): a second right-hand operand multiplied in the SAME pass over A, D2 (N,K2) f32 at stride ldd2 (+)= A^T.X2
  * -- dW_ih = dG^T.x and dW_hh = dG^T.h_prev read the gate gradients once. */

@@ -37,6 +37,13 @@ for name, K, N in (('gx enc (x.W_ih^T)', 20, 1024), ('gx dec', 256, 1024), ('fc 
     fl, by = 2.0 * M * K * N, 4.0 * (M * K + M * N)
     print(f'gemm_nt {name:20s} K={K:5d} N={N:5d}: {ms:7.3f} ms  {3 * fl / ms / 1e9:7.1f} TF bf16 ({3 * fl / ms / 1e9 / 2500:.3f} of peak)  {by / ms / 1e6:7.1f} GB/s min-traffic')
     del a, w, y
+for name, N in (('gx dec (x3_row_proj)', 1024), ('fc fwd (x3_row_proj)', 128)):
+    a = torch.randn(M, 256, device=dev)
+    w = torch.randn(N, 256, device=dev) * 0.1
+    ms = timeit(lambda: ops.x3_row_proj(a, w))
+    fl, by = 2.0 * M * 256 * N, 4.0 * (M * 256 + M * N)
+    print(f'x3_row_proj {name:20s} N={N:5d}: {ms:7.3f} ms  {3 * fl / ms / 1e9:7.1f} TF bf16 ({3 * fl / ms / 1e9 / 2500:.3f} of peak)  {by / ms / 1e6:7.1f} GB/s min-traffic')
+    del a, w
 for name, N, K, K2 in (('dW enc dir', 512, 20, 128), ('dW dec dir', 512, 256, 128), ('dW fc', 128, 256, 0)):
     a = torch.randn(M, 2 * N if N == 512 else N, device=dev)[:, :N]
     x = torch.randn(M, K, device=dev)

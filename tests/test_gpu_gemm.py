@@ -79,6 +79,26 @@ def test_gemm_tn_two_products_from_one_pass(dtype, M, K, kcols, K2, accumulate):
         assert float((got.double() - want).abs().max()) / float(want.abs().max()) <= 10 * _tol(dtype)
 
 
+@pytest.mark.parametrize('n,nout,bias,relu', [(24 * 200, 1024, True, False), (33, 128, True, True), (70001, 1024, False, True), (1, 256, True, False),
+                                             (4097, 128, False, False)])
+def test_x3_row_proj_matches_f64(n, nout, bias, relu):
+    """dic_x3_row_proj (resident split weights, 256-input projections of the x3 step) against the f64 product, and against dic_gemm_nt."""
+    from deep_interpolation_clustering_amd import ops
+    torch.manual_seed(n + nout)
+    dev = torch.device('cuda')
+    x = torch.randn(n, 256, device=dev) * 0.7
+    w = torch.randn(nout, 256, device=dev) * 0.1
+    b = torch.randn(nout, device=dev) if bias else None
+    assert ops.x3_row_proj_ok(x, w)
+    y = ops.x3_row_proj(x, w, b, relu_a=relu)
+    xd = x.double().clamp_min(0) if relu else x.double()
+    want = xd @ w.double().t() + (b.double() if bias else 0.0)
+    scale = float(want.abs().max())
+    assert float((y.double() - want).abs().max()) / scale <= 2e-5
+    y2 = ops.gemm_nt(x, w, b, relu_a=relu)
+    assert float((y - y2).abs().max()) / scale <= 4e-6              # the same three products per term, another accumulation order
+
+
 def test_split_products_are_f32_grade_where_bf16_is_not():
     """The point of the three-term split: f32 operands with a full mantissa -- bf16 rounding of the same operands is off by ~1e-3."""
     from deep_interpolation_clustering_amd import ops
