@@ -126,3 +126,60 @@ def test_global_mean_with_uneven_shards(tmp_path):
     np.testing.assert_allclose(r0['loss'], float(ref.detach()), rtol=1e-6)
     np.testing.assert_allclose(r0['grad'].numpy(), w.grad.numpy(), rtol=1e-5, atol=1e-7)
     assert torch.equal(r0['grad'], r1['grad'])
+
+
+def _rider_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as td
+    from deep_interpolation_clustering_amd import dist
+    dist.init_from_env('gloo')
+    try:
+        calls, inner = [], td.all_reduce
+
+        def counting(t, *a, **k):
+            calls.append(int(t.numel()))
+            return inner(t, *a, **k)
+        td.all_reduce = counting
+        res = {}
+        # an f32 rider on an f64 carrier: one collective, both reduced in place (the DEC column sums on CompressFC's BatchNorm moments)
+        colsum = torch.tensor([1.0 + rank, 2.0, 0.5 * rank, 4.0])
+        dist.deferred_sum_(colsum)
+        sums = torch.arange(257, dtype=torch.float64) * (rank + 1)
+        dist.all_reduce_sum_(sums)
+        n_after_carrier = len(calls)
+        dist.resolve_sum_(colsum)                                        # already reduced: no second collective
+        res['colsum'], res['sums_tail'], res['calls_a'] = colsum.clone(), sums[-3:].clone(), (n_after_carrier, len(calls), calls[:])
+        # a rider that meets no carrier gets a collective of its own when it is resolved
+        lone = torch.tensor([float(rank)])
+        dist.deferred_sum_(lone)
+        dist.resolve_sum_(lone)
+        res['lone'], res['calls_b'] = lone.clone(), len(calls)
+        # the gradient bucket (large) never carries riders; an f64 rider does not ride on an f32 carrier
+        r64 = torch.tensor([1.5 * (rank + 1)], dtype=torch.float64)
+        dist.deferred_sum_(r64)
+        big = torch.ones(10000)
+        dist.all_reduce_sum_(big)
+        small32 = torch.ones(4)
+        dist.all_reduce_sum_(small32)
+        res['still_pending'] = float(r64)                                # untouched so far
+        dist.resolve_sum_(r64)
+        res['r64'], res['calls_c'] = float(r64), calls[len(calls) - 3:]
+        td.all_reduce = inner
+        torch.save(res, os.path.join(out, f'rider{rank}.pt'))
+    finally:
+        td.destroy_process_group()
+
+
+def test_deferred_sums_ride_on_the_next_small_all_reduce(tmp_path):
+    """dist.deferred_sum_ / resolve_sum_: small statistics that are needed later travel with the next small exchange (one
+    packed buffer per dependency level), exactly, and never with the gradient bucket."""
+    port = 29800 + (os.getpid() % 1000)
+    mp.spawn(_rider_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'rider{r}.pt', weights_only=False) for r in (0, 1))
+    for r in (r0, r1):
+        assert torch.equal(r['colsum'], torch.tensor([3.0, 4.0, 0.5, 8.0]))
+        assert torch.equal(r['sums_tail'], torch.tensor([254.0, 255.0, 256.0], dtype=torch.float64) * 3)
+        assert r['calls_a'][0] == 1 and r['calls_a'][1] == 1 and r['calls_a'][2] == [261]          # 257 + 4 in ONE collective, none at resolve
+        assert float(r['lone']) == 1.0 and r['calls_b'] == 2
+        assert r['still_pending'] in (1.5, 3.0) and r['r64'] == 4.5 and r['calls_c'] == [10000, 4, 1]
