@@ -89,11 +89,12 @@ __device__ __forceinline__ void chunk_store(const Chunk16<__bf16>& c, __bf16* hi
 }
 
 // the first 8 elements only (gemm_tn's 64-column X tiles: 8 columns per thread)
-__device__ __forceinline__ void chunk_store8(const Chunk16<float>& c, __bf16* hi, __bf16* lo) {
+__device__ __forceinline__ void chunk_store8(const Chunk16<float>& c, __bf16* hi, __bf16* lo, bool relu) {
     gbf16x8 vh, vl;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float x = c.v[j >> 2][j & 3];
+        float x = c.v[j >> 2][j & 3];
+        if (relu) x = fmaxf(x, 0.f);
         const __bf16 xh = (__bf16)x;
         vh[j] = xh;
         vl[j] = (__bf16)(x - (float)xh);
@@ -101,7 +102,14 @@ __device__ __forceinline__ void chunk_store8(const Chunk16<float>& c, __bf16* hi
     *reinterpret_cast<gbf16x8*>(hi) = vh;
     *reinterpret_cast<gbf16x8*>(lo) = vl;
 }
-__device__ __forceinline__ void chunk_store8(const Chunk16<__bf16>& c, __bf16* hi, __bf16*) { *reinterpret_cast<gbf16x8*>(hi) = c.v[0]; }
+__device__ __forceinline__ void chunk_store8(const Chunk16<__bf16>& c, __bf16* hi, __bf16*, bool relu) {
+    gbf16x8 v = c.v[0];
+    if (relu) {
+        const gs16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        v = __builtin_bit_cast(gbf16x8, __builtin_elementwise_max(__builtin_bit_cast(gs16x8, v), zero));
+    }
+    *reinterpret_cast<gbf16x8*>(hi) = v;
+}
 
 template <typename T> struct OutCvt;
 template <> struct OutCvt<float> { __device__ static float of(float v) { return v; } };
@@ -215,6 +223,7 @@ struct GemmTnArgs {
     long M; int N, K;
     long rows_per_chunk;           // multiple of TROWS
     int tiles_n, tiles_k, tiles_k1;      // tiles_k = tiles_k1 (of X) + those of X2
+    int relu_x;                          // the product runs on max(X, 0) (X only, not X2): the decoder LSTM's input is relu(encoder output), rectified on load
 };
 
 __device__ __forceinline__ gs16x4 glds_tr16(const __bf16* p) {
@@ -282,10 +291,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     if (mbeg < mend) load(mbeg);
     for (long m = mbeg; m < mend; m += TROWS) {
         chunk_store(ca, &sa[0][lrow * PA + 16 * seg], &sa[IMG - 1][lrow * PA + 16 * seg], false);
+        const bool rx = a.relu_x != 0 && !second;
         if (XC == 16) {
-            chunk_store(cx, &sx[0][lrow * PX + 16 * seg], &sx[IMG - 1][lrow * PX + 16 * seg], false);
+            chunk_store(cx, &sx[0][lrow * PX + 16 * seg], &sx[IMG - 1][lrow * PX + 16 * seg], rx);
         } else {                                             // 8 columns per thread: the first half of the chunk
-            chunk_store8(cx, &sx[0][lrow * PX + 8 * seg], &sx[IMG - 1][lrow * PX + 8 * seg]);
+            chunk_store8(cx, &sx[0][lrow * PX + 8 * seg], &sx[IMG - 1][lrow * PX + 8 * seg], rx);
         }
         __syncthreads();
         if (m + TROWS < mend) load(m + TROWS);
@@ -515,7 +525,7 @@ size_t dic_gemm_tn_workspace(long M, int N, int K, int K2) {
 }
 
 int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
-                const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+                const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, int relu_x, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(in_dtype == DIC_DTYPE_F32 || in_dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "gemm_tn: input dtype %d", in_dtype);
     DIC_REQUIRE(A && X && D && workspace, DIC_ERR_INVALID_ARG, "gemm_tn: NULL pointer");
     DIC_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= N && ldx >= K && kcols > 0 && kcols <= K && ldd >= kcols, DIC_ERR_INVALID_ARG,
@@ -533,7 +543,7 @@ int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, 
     DIC_REQUIRE(workspace_bytes >= (size_t)S * N * KT * sizeof(float), DIC_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", workspace_bytes,
                 (size_t)S * N * KT * sizeof(float));
     const int tk1 = (K + bko - 1) / bko, tk2 = (K2 + bko - 1) / bko;
-    GemmTnArgs a{A, lda, X, ldx, X2, ldx2, K2, (float*)workspace, M, N, K, rpc, (N + 127) / 128, tk1 + tk2, tk1};
+    GemmTnArgs a{A, lda, X, ldx, X2, ldx2, K2, (float*)workspace, M, N, K, rpc, (N + 127) / 128, tk1 + tk2, tk1, relu_x};
     const dim3 grid((unsigned)(S * a.tiles_n * a.tiles_k)), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == DIC_DTYPE_F32) {

@@ -161,7 +161,8 @@ class _BiLstm(torch.autograd.Function):
             if narrow:
                 xb[..., I].fill_(1.0)                              # the bias rides along as a constant-one input column
         # input_rectify: relu(x) is applied by the projection / weight-gradient kernels on the raw x (large decoder path), else here
-        relu_kernel = bool(relu_in) and (not small) and (not proj) and Ip == WIDE_INPUT and ROW_PROJ
+        relu_kernel = bool(relu_in) and (((not small) and (not proj) and Ip == WIDE_INPUT and ROW_PROJ)
+                                         or (x3 and Ip == WIDE_INPUT and _ops.X3_ROW_PROJ))          # (x3: dic_x3_row_proj / dic_gemm_tn rectify on load)
         if relu_in and not relu_kernel:
             xb = torch.relu(xb)
         out_ext = torch.empty((R + 2, B, 2 * H), device=dev, dtype=T)       # [h0 | h_1..h_R | h0]: every step's h_prev is a row above / below
@@ -186,9 +187,9 @@ class _BiLstm(torch.autograd.Function):
                 gx = torch.empty((R * B, 8 * H), device=dev, dtype=T)           # decoder: weights resident in registers (csrc/dic_rowproj.hip)
                 N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), 0, 0, st), 'dic_row_proj')
             elif x3 and _ops.x3_row_proj_ok(xb.view(R * B, Ip), wih):
-                gx = _ops.x3_row_proj(xb.view(R * B, Ip), wih, bias)              # decoder, x3: weights split once, resident in registers
+                gx = _ops.x3_row_proj(xb.view(R * B, Ip), wih, bias, relu_a=relu_kernel)      # decoder, x3: weights split once, resident in registers
             elif x3 or not f32:
-                gx = _ops.gemm_nt(xb.view(R * B, Ip), wih, bias.float())
+                gx = _ops.gemm_nt(xb.view(R * B, Ip), wih, bias.float(), relu_a=relu_kernel)
             else:
                 gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
             N.check(L.dic_lstm_rec_fwd(N.DTYPE_F32X3 if x3 else code, N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
@@ -318,7 +319,8 @@ class _BiLstm(torch.autograd.Function):
                 xv = xb.view(R * B, Ip)
                 for d in range(2):              # (both products of a direction from ONE pass over its gate gradients)
                     hp = oe[:R * B, :H] if d == 0 else oe[2 * B:, H:]
-                    _ops.gemm_tn_into(dg2[:, 4 * H * d:4 * H * (d + 1)], xv, sinks[4 * d], kcols=I, accumulate=accumulate, x2=hp, dst2=sinks[4 * d + 1])
+                    _ops.gemm_tn_into(dg2[:, 4 * H * d:4 * H * (d + 1)], xv, sinks[4 * d], kcols=I, accumulate=accumulate, x2=hp, dst2=sinks[4 * d + 1],
+                                      relu_x=ctx.x_relu_in_kernel)
                 N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             else:
                 # dW = dG^T.X has K = R*B (hundreds of thousands) and a tiny output: split-K bmm (ops.splitk_tn).
@@ -344,7 +346,9 @@ def deferred_relu_ok(x_or_batch):
     """The F.relu between encoder and decoder (clustering_interp.py:38-41) can be left to the decoder's kernels -- its input projection and
     its weight-gradient kernel rectify the raw encoder output on load -- on the large-batch bf16 path: no rectified copy is written."""
     B = x_or_batch if isinstance(x_or_batch, int) else x_or_batch.shape[1]
-    return DEFER_RELU and ROW_PROJ and RELU_IN_KERNEL and B > SMALL_BATCH and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+    if not torch.is_autocast_enabled():          # f32 step: only the x3 products rectify on load (dic_x3_row_proj, dic_gemm_tn)
+        return DEFER_RELU and RELU_IN_KERNEL and _ops.f32_products() == 'x3' and _ops.X3_ROW_PROJ
+    return DEFER_RELU and ROW_PROJ and RELU_IN_KERNEL and B > SMALL_BATCH and torch.get_autocast_dtype('cuda') == torch.bfloat16
 
 
 def bilstm(x, lstm, h0=None, c0=None, batch_major_state=False, rectified_out=False, input_rectify=False):

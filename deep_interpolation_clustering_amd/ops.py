@@ -789,10 +789,11 @@ def x3_row_proj(x, w, bias=None, relu_a=False):
     return y
 
 
-def gemm_tn_into(a, x, dst, kcols=None, accumulate=False, x2=None, dst2=None):
+def gemm_tn_into(a, x, dst, kcols=None, accumulate=False, x2=None, dst2=None, relu_x=False):
     """dst (N,kcols) f32 (+)= a (M,N)^T . x (M,K)[:, :kcols] (dic_gemm_tn): the weight-gradient shape -- a reduction over hundreds of thousands of
     rows into a small matrix; row chunks in parallel, fixed-order f64 second stage (deterministic).  ``x2`` (M,K2), ``dst2`` (N,K2): a second
-    product a^T . x2 from the same pass over ``a`` (dW_ih and dW_hh of one LSTM direction read the gate gradients once)."""
+    product a^T . x2 from the same pass over ``a`` (dW_ih and dW_hh of one LSTM direction read the gate gradients once).  ``relu_x``: the first product
+    runs on relu(x)."""
     N.require_gpu(a, x, dst)
     a, x, dst = _rows(a), _rows(x), _rows(dst)
     if a.dtype != x.dtype or a.shape[0] != x.shape[0] or dst.dtype != torch.float32:
@@ -812,7 +813,7 @@ def gemm_tn_into(a, x, dst, kcols=None, accumulate=False, x2=None, dst2=None):
     ws = _ws(L.dic_gemm_tn_workspace(M, n, K, K2), a.device)
     N.check(L.dic_gemm_tn(_dt(a), N.ptr(a), a.stride(0), N.ptr(x), x.stride(0), M, n, K, N.ptr(dst), dst.stride(0), kcols,
                           N.ptr(x2), x2.stride(0) if x2 is not None else 0, K2, N.ptr(dst2), dst2.stride(0) if dst2 is not None else 0,
-                          int(bool(accumulate)), N.ptr(ws), ws.numel(), N.stream_of(a)), 'dic_gemm_tn')
+                          int(bool(accumulate)), int(bool(relu_x)), N.ptr(ws), ws.numel(), N.stream_of(a)), 'dic_gemm_tn')
     return dst
 
 

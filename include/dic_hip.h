@@ -508,9 +508,9 @@ int dic_x3_row_proj(const float* x, const float* w, const float* bias, int64_t N
                     dic_stream_t stream);
 size_t dic_gemm_tn_workspace(long M, int N, int K, int K2);
 /* X2 (M,K2) at stride ldx2 (or NULL, K2 = 0): a second right-hand operand multiplied in the SAME pass over A, D2 (N,K2) f32 at stride ldd2 (+)= A^T.X2
- * -- dW_ih = dG^T.x and dW_hh = dG^T.h_prev read the gate gradients once. */
+ * -- dW_ih = dG^T.x and dW_hh = dG^T.h_prev read the gate gradients once.  relu_x != 0: the first product runs on max(X, 0). */
 int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
-                const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+                const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, int relu_x, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
 #ifdef __cplusplus
 }
