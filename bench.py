@@ -416,10 +416,19 @@ def f32_roofline(kernels, batch, products):
         tf, peak_tf = flop / ms / 1e9, F32_MFMA_PEAK_TF
     f_hbm, f_mfma = gbps / HBM_PEAK_GBS, tf / peak_tf
     bound = 'hbm' if f_hbm >= f_mfma else 'mfma'
+    traffic = traffic_src = None
+    tf_file = os.path.join(ROOT, 'profiles', 'r4_step_f32x3_pmc_traffic.json')      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `--dtype f32x3` at B = 32768
+    if products == 'x3' and os.path.exists(tf_file):
+        tj = json.load(open(tf_file))
+        key = name.split('dic::')[-1].split('<')[0]
+        if key in tj:
+            traffic = int(tj[key]['hbm_bytes'] * batch / 32768)
+            traffic_src = {'from_profile': 'profiles/r4_step_f32x3_pmc_traffic.json', 'profile_batch': 32768,
+                           'note': 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of a separate run, scaled by batch; not measured in this run'}
     return {'kernel': name, 'bound': bound, 'achieved': round(gbps if bound == 'hbm' else tf, 1), 'peak': HBM_PEAK_GBS if bound == 'hbm' else peak_tf,
             'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s', 'frac': round(max(f_hbm, f_mfma), 4), 'frac_hbm': round(f_hbm, 4), 'frac_mfma': round(f_mfma, 4),
             'ms_per_launch': round(ms, 4), 'launches_per_step': v['launches_per_step'], 'algorithmic_bytes_per_launch': int(nbytes),
-            'matrix_core_flop_per_launch': int(flop * (3 if products == 'x3' else 1)), 'traffic': None,
+            'matrix_core_flop_per_launch': int(flop * (3 if products == 'x3' else 1)), 'traffic': traffic, 'traffic_source': traffic_src,
             'duration_source': 'in-step: per-dispatch durations of this kernel in a trace of the timed steps'}
 
 
