@@ -180,6 +180,8 @@ struct RecFwdArgs {
     T* cs;                 // lane-native (R+1,Bp,2,H) cell states or NULL; time slot R receives c0 (zeros without one): the backward's c_prev of the first step
     int R, B, bm;
     int boundary;          // out is time slots 1..R of an (R+2,B,2H) buffer: also write h0 (zeros without one) into slot 0 [:, :H] / slot R+1 [:, H:]
+    const T* x = nullptr;  // lstm_rec_fwd8_kernel<XK>: (R,B,XK) packed inputs [features | 1 | 0...] and wih (2*4H, XK): the input projection runs in-kernel
+    const T* wih = nullptr;
 };
 
 template <typename T, bool X3 = false>
@@ -502,14 +504,20 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
 //             n + 16 g needs, up to one v_permlane16_swap per register between the two batch blocks.
 typedef float sf32x4_t __attribute__((ext_vector_type(4)));
 
+// XK = 0: gx comes in from a projection kernel.  XK = 32 / 64 (round 4): the narrow encoder input -- packed rows [3C features | 1 | 0...] -- is projected
+// IN the kernel, as in dic_lstm.hip's lstm_fwd8_proj: W_ih for the wave's 64 gate rows in 16 / 32 more registers, the 32 x XK x tile of a step one step
+// ahead through a register into the other LDS buffer; gx (1 KiB written and read per row and step) and its launch do not exist.
+template <int XK>
 __global__ __launch_bounds__(512, 1) void lstm_rec_fwd8_kernel(RecFwdArgs<__bf16> a) {
     typedef __bf16 T;
     typedef sbf16x4 V4;
+    constexpr bool PROJ = XK > 0;
     constexpr int HP = Rec<T>::PITCH(SH);
     constexpr int GXP = S4 + 16 / sizeof(T);
+    constexpr int XS = XK + 8;                             // bf16 elements per LDS row of the x tile
     extern __shared__ __align__(16) unsigned char fsm32[];
     T* hbuf0 = reinterpret_cast<T*>(fsm32);               // [2][SROWS*HP]
-    T* gst = hbuf0 + 2 * SROWS * HP;                       // [SROWS][GXP]
+    T* gst = hbuf0 + 2 * SROWS * HP;                       // [SROWS][GXP] staged gx tile, or (PROJ) [2][SROWS][XS] x tiles
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = w8 >> 1, qh = w8 & 1;
     const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
@@ -524,6 +532,14 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_fwd8_kernel(RecFwdArgs<__bf16
 #pragma unroll
         for (int ks = 0; ks < SH / 16; ++ks)
             wf[blk][ks] = *reinterpret_cast<const sbf16x8*>(a.whh + ((size_t)(dir * 4 + 2 * blk + (r >> 4)) * SH + 16 * w8 + (r & 15)) * SH + ks * 16 + 8 * hh);
+    sbf16x8 wx[2][PROJ ? XK / 16 : 1];
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int ks = 0; ks < XK / 16; ++ks)
+                wx[blk][ks] = *reinterpret_cast<const sbf16x8*>(a.wih + ((size_t)(dir * 4 + 2 * blk + (r >> 4)) * SH + 16 * w8 + (r & 15)) * XK + ks * 16 + 8 * hh);
+    }
 
     float c[8];                      // element e = 4 qq + j: unit 16 w8 + 8 qq + 4 hh + j
 #pragma unroll
@@ -555,7 +571,20 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_fwd8_kernel(RecFwdArgs<__bf16
                                              (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(gst + rowl * GXP)), 16, 0, 0);
         }
     };
-    request_gx(0);
+    // PROJ: 32 rows x XK / 8 pieces of 16 B per step
+    constexpr int XPC = PROJ ? XK / 8 : 1;
+    const bool xloader = PROJ && tid < SROWS * XPC;
+    const int xrow = tid / XPC, xpc = tid % XPC;
+    auto load_x = [&](int step) {
+        const int t = dir ? R - 1 - step : step;
+        return *reinterpret_cast<const sbf16x8*>(a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * XK + xpc * 8);
+    };
+    sbf16x8 xnext = {};
+    if constexpr (PROJ) {
+        if (xloader) *reinterpret_cast<sbf16x8*>(gst + xrow * XS + xpc * 8) = load_x(0);
+    } else {
+        request_gx(0);
+    }
     __syncthreads();
 
     for (int step = 0; step < R; ++step) {
@@ -564,19 +593,35 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_fwd8_kernel(RecFwdArgs<__bf16
         const T* hcur = hbuf0 + cur * SROWS * HP;
         T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
         sf32x16 acc[2];
+        if constexpr (PROJ) {
+            if (xloader && step + 1 < R) xnext = load_x(step + 1);       // in flight across the MFMA and gate-math phases
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const V4 gv = *reinterpret_cast<const V4*>(gst + r * GXP + g * SH + 16 * w8 + 8 * qq + 4 * hh);
+                for (int k = 0; k < 16; ++k) acc[blk][k] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g >> 1][8 * (g & 1) + 4 * qq + j] = (float)gv[j];
+            for (int ks = 0; ks < XK / 16; ++ks) {          // G = W_ih . x_t^T (bias included: constant-one input column)
+                const sbf16x8 xb = *reinterpret_cast<const sbf16x8*>(gst + cur * SROWS * XS + r * XS + ks * 16 + 8 * hh);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[0][ks], xb, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[1][ks], xb, acc[1], 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const V4 gv = *reinterpret_cast<const V4*>(gst + r * GXP + g * SH + 16 * w8 + 8 * qq + 4 * hh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[g >> 1][8 * (g & 1) + 4 * qq + j] = (float)gv[j];
+                }
+        }
         sbf16x8 hf[SH / 16];                              // the step's B fragments, all requested before the first MFMA
 #pragma unroll
         for (int ks = 0; ks < SH / 16; ++ks) hf[ks] = *reinterpret_cast<const sbf16x8*>(hcur + r * HP + ks * 16 + 8 * hh);
-        lds_barrier();                                     // every wave has read its part of the staged tile
-        if (step + 1 < R) request_gx(step + 1);
+        if constexpr (!PROJ) {
+            lds_barrier();                                 // every wave has read its part of the staged tile
+            if (step + 1 < R) request_gx(step + 1);
+        }
 #pragma unroll
         for (int ks = 0; ks < SH / 16; ++ks) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], hf[ks], acc[0], 0, 0, 0);
@@ -615,10 +660,14 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_fwd8_kernel(RecFwdArgs<__bf16
                 }
             }
         }
-        // (as in the four-wave kernel: the DMA of the next tile has landed once only the stores issued after it are in flight --
-        // 10 saved-state stores per wave; the 2 `out` stores may have been branched over)
-        if (a.gates) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PROJ) {
+            if (xloader && step + 1 < R) *reinterpret_cast<sbf16x8*>(gst + (cur ^ 1) * SROWS * XS + xrow * XS + xpc * 8) = xnext;
+        } else {
+            // (as in the four-wave kernel: the DMA of the next tile has landed once only the stores issued after it are in flight --
+            // 10 saved-state stores per wave; the 2 `out` stores may have been branched over)
+            if (a.gates) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         lds_barrier();
     }
 }
@@ -814,11 +863,11 @@ static int rec_fwd(const void* gx, const void* whh, const float* h0, const float
         if (rec_eight_waves()) {
             static bool attr8_set = false;
             if (!attr8_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_fwd8: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
                 attr8_set = true;
             }
-            hipLaunchKernelGGL(lstm_rec_fwd8_kernel, dim3((B + SROWS - 1) / SROWS, 2), dim3(512), lds, st, a);
+            hipLaunchKernelGGL(lstm_rec_fwd8_kernel<0>, dim3((B + SROWS - 1) / SROWS, 2), dim3(512), lds, st, a);
             return check_launch("lstm_rec_fwd8");
         }
     }
@@ -874,6 +923,23 @@ int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0
     if (dtype == DIC_DTYPE_F32X3) return rec_fwd<float, true>(gx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_batch_major, (hipStream_t)stream);
     if (dtype == DIC_DTYPE_F32) return rec_fwd<float>(gx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_batch_major, (hipStream_t)stream);
     return rec_fwd<__bf16>(gx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_batch_major, (hipStream_t)stream);
+}
+
+int dic_lstm_rec_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H, int I, void* out,
+                          float* hn, float* cn, void* gates, void* cs, int state_flags, dic_stream_t stream) {
+    DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_rec_fwd_proj: non-positive size");
+    DIC_REQUIRE(H == SH, DIC_ERR_UNSUPPORTED, "lstm_rec_fwd_proj: hidden size %d (compiled for %d)", H, SH);
+    DIC_REQUIRE(I == 32 || I == 64, DIC_ERR_UNSUPPORTED, "lstm_rec_fwd_proj: packed input width %d (compiled for 32 and 64)", I);
+    DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_rec_fwd_proj: NULL pointer");
+    DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_rec_fwd_proj: gates and cs go together");
+    typedef __bf16 T;
+    RecFwdArgs<T> a{nullptr, (const T*)whh, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B, (state_flags & 1) != 0, (state_flags & 2) != 0};
+    a.x = (const T*)x; a.wih = (const T*)wih;
+    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)2 * SROWS * (I + 8)) * sizeof(T);
+    const dim3 grid((B + SROWS - 1) / SROWS, 2);
+    if (I == 32) hipLaunchKernelGGL(lstm_rec_fwd8_kernel<32>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(lstm_rec_fwd8_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, a);
+    return check_launch("lstm_rec_fwd_proj");
 }
 
 size_t dic_lstm_rec_bwd_workspace(int B) { return B > 0 ? (size_t)((B + SROWS - 1) / SROWS) * 2 * S4 * sizeof(float) : 0; }

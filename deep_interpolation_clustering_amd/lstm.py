@@ -43,6 +43,7 @@ GX_LANE_NATIVE = os.environ.get('DIC_GX_LANE_NATIVE', '1') != '0'     # (A/B swi
 ROW_PROJ = os.environ.get('DIC_ROW_PROJ', '1') != '0'                  # (A/B switch: 0 = library GEMM for the decoder's input projection)
 RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B switch: 0 = rectify the encoder output with a torch pass)
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
+REC_PROJ = os.environ.get('DIC_REC_PROJ', '1') != '0'                  # (A/B switch: 0 = dic_gemm_nt + dic_lstm_rec_fwd for the encoder's small-batch forward)
 SMALL_BATCH = 4096             # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
 
 
@@ -181,7 +182,10 @@ class _BiLstm(torch.autograd.Function):
                 gates = torch.empty((R, Bp, 2, 4, H), device=dev, dtype=T)
                 cs = torch.empty((R + 1, Bp, 2, H), device=dev, dtype=T)     # (time slot R: c0, written by the forward)
             # input projection gx (R*B, 2*4*H) of all steps: hand-written MFMA kernels (no library GEMM) except in the exact-f32 parity mode
-            if narrow:
+            gx = None
+            if narrow and REC_PROJ:
+                pass                                                             # (projected inside the recurrence kernel below: no gx)
+            elif narrow:
                 gx = _ops.gemm_nt(xb.view(R * B, Ip), wih)                       # (the bias rides in the constant-one column)
             elif (not f32) and Ip == WIDE_INPUT and ROW_PROJ:
                 gx = torch.empty((R * B, 8 * H), device=dev, dtype=T)           # decoder: weights resident in registers (csrc/dic_rowproj.hip)
@@ -192,8 +196,12 @@ class _BiLstm(torch.autograd.Function):
                 gx = _ops.gemm_nt(xb.view(R * B, Ip), wih, bias.float(), relu_a=relu_kernel)
             else:
                 gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
-            N.check(L.dic_lstm_rec_fwd(N.DTYPE_F32X3 if x3 else code, N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
-                                       N.ptr(gates), N.ptr(cs), int(bm) | (2 if kernel_boundary else 0), st), 'dic_lstm_rec_fwd')
+            if gx is None:
+                N.check(L.dic_lstm_rec_fwd_proj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out), N.ptr(hn), N.ptr(cn),
+                                                N.ptr(gates), N.ptr(cs), int(bm) | (2 if kernel_boundary else 0), st), 'dic_lstm_rec_fwd_proj')
+            else:
+                N.check(L.dic_lstm_rec_fwd(N.DTYPE_F32X3 if x3 else code, N.ptr(gx), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
+                                           N.ptr(gates), N.ptr(cs), int(bm) | (2 if kernel_boundary else 0), st), 'dic_lstm_rec_fwd')
         else:
             if need:
                 Bp = (B + 63) // 64 * 64                           # kernel-native saved state is tiled by 64 rows

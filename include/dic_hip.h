@@ -320,6 +320,12 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
 #define DIC_DTYPE_F32X3 2   /* dic_lstm_rec_fwd / _bwd only: f32 tensors, the recurrent products as three-term bf16 splits (hi.hi + lo.hi + hi.lo) on the bf16 matrix cores */
 int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, int H, void* out,
                      float* hn, float* cn, void* gates, void* cs, int state_flags, dic_stream_t stream);
+/* dic_lstm_rec_fwd_proj (bf16, batches up to 4096): the same 32-row forward recurrence with the encoder's input projection inside the kernel -- x (R,B,I)
+ * bf16 packed rows [3C features | 1 | 0...] as dic_sci_cci_fwd_packed writes them (I = 32 or 64), wih (2*4H, I) bf16 from dic_lstm_pack(bias_col = 1):
+ * the (R,B,8H) gx tensor and the projection launch of nn.LSTM (clustering_interp.py:22) do not exist.  Other arguments as dic_lstm_rec_fwd. */
+int dic_lstm_rec_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H, int I, void* out,
+                          float* hn, float* cn, void* gates, void* cs, int state_flags, dic_stream_t stream);
+
 size_t dic_lstm_rec_bwd_workspace(int B);
 int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const void* dout,
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
