@@ -161,3 +161,41 @@ def test_f32_step_on_split_products_matches_reference_step(case):
     for k, v in net.state_dict().items():
         if 'sd1n/' + k in g:
             np.testing.assert_allclose(np.linalg.norm(v.detach().cpu().numpy().astype(np.float64)), float(g['sd1n/' + k]), rtol=1e-4, err_msg=k)
+
+
+def test_x3_step_tracks_the_exact_f32_step_at_a_large_batch():
+    """The x3 mode where its kernels run many tiles (B = 8192: 196 608 rows through dic_x3_row_proj / dic_gemm_nt / dic_gemm_tn's row chunks, 256 tiles of
+    the x3 recurrence, the ReLU between the LSTMs applied on load, ragged store input): three optimisation steps against the exact-f32 mode from the
+    same state -- first-step losses to 2e-6, the trajectories to 1e-4 (two f32-grade implementations of one Adam loop)."""
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    dev = torch.device('cuda')
+    B = 8192
+    coh = synthetic.make_cohort(B, G=4, seed=35)
+    x_np, _, _ = synthetic.stacked_batch(coh)
+    store = RaggedStore(x_np, 6, dev)
+    rb = RaggedBatch(store, torch.randperm(B, device=dev, generator=torch.Generator(device=dev).manual_seed(3)))
+    g = torch.tensor(coh['phenotype'].astype(np.int64), device=dev)[rb.idx.long()]
+    args = _args(6, 96, 4)
+    traj = {}
+    for mode in ('exact', 'x3'):
+        torch.manual_seed(4)
+        net = Net(args, dev).to(dev)
+        net.eval()
+        with torch.no_grad():            # centroids on the latents' clusters: the p3 regime
+            z = net(rb)[0]
+            net.init_cluster_center(torch.stack([z[g == j].mean(0) for j in range(4)]))
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, precision=mode)
+        out = []
+        for _ in range(3):
+            losses, gnorm, _ = st.step(rb, None, None)
+            out.append([float(losses[k].detach()) for k in ('loss', 'ae_mse', 'kl')] + [float(gnorm)])
+        traj[mode] = np.array(out)
+    assert traj['exact'][0, 2] > 0.01
+    np.testing.assert_allclose(traj['x3'][0, :3], traj['exact'][0, :3], rtol=2e-6)
+    np.testing.assert_allclose(traj['x3'][0, 3], traj['exact'][0, 3], rtol=2e-5)
+    np.testing.assert_allclose(traj['x3'], traj['exact'], rtol=1e-4)
