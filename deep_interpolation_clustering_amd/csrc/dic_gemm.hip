@@ -210,6 +210,112 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs a) {
     }
 }
 
+// The same 128 x 128 tile on EIGHT waves (2 x 4, wave tile 64 x 32): half the conversions, LDS stores and MFMAs per wave and twice the waves per CU for the
+// same LDS -- the A/Bs of section 5 say this kernel lives on occupancy.  A thread brings in 8 elements of an A row and 8 of a W row per tile.
+template <typename T> struct Chunk8;
+template <> struct Chunk8<float> { gf32x4 v[2]; };
+template <> struct Chunk8<__bf16> { gbf16x8 v; };
+__device__ __forceinline__ void chunk8_load(Chunk8<float>& c, const float* row, int k0, int klen, bool valid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c.v[i] = (valid && k0 + 4 * i < klen) ? *reinterpret_cast<const gf32x4*>(row + k0 + 4 * i) : gf32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void chunk8_load(Chunk8<__bf16>& c, const __bf16* row, int k0, int klen, bool valid) {
+    gbf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+    c.v = (valid && k0 < klen) ? *reinterpret_cast<const gbf16x8*>(row + k0) : z;
+}
+__device__ __forceinline__ void chunk8_store(const Chunk8<float>& c, __bf16* hi, __bf16* lo, bool relu) {
+    gbf16x8 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float x = c.v[j >> 2][j & 3];
+        if (relu) x = fmaxf(x, 0.f);
+        const __bf16 xh = (__bf16)x;
+        vh[j] = xh;
+        vl[j] = (__bf16)(x - (float)xh);
+    }
+    *reinterpret_cast<gbf16x8*>(hi) = vh;
+    *reinterpret_cast<gbf16x8*>(lo) = vl;
+}
+__device__ __forceinline__ void chunk8_store(const Chunk8<__bf16>& c, __bf16* hi, __bf16*, bool relu) {
+    gbf16x8 v = c.v;
+    if (relu) {
+        const gs16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        v = __builtin_bit_cast(gbf16x8, __builtin_elementwise_max(__builtin_bit_cast(gs16x8, v), zero));
+    }
+    *reinterpret_cast<gbf16x8*>(hi) = v;
+}
+
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
+    constexpr bool SPLIT = sizeof(TIN) == 4;
+    constexpr int IMG = SPLIT ? 2 : 1, BN = 128;
+    __shared__ __align__(16) __bf16 sa[IMG][GBM * GP];
+    __shared__ __align__(16) __bf16 sw[IMG][BN * GP];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w & 1, wn = w >> 1;      // wave tile: rows 64 wm.., columns 32 wn..
+    const int lt = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(lt / a.tiles_n) * GBM;
+    const int n0 = (lt % a.tiles_n) * BN;
+    const TIN* A = reinterpret_cast<const TIN*>(a.A);
+    const TIN* W = reinterpret_cast<const TIN*>(a.W);
+    const int lrow = tid >> 2, lk = 8 * (tid & 3);
+    const TIN* arow = A + (size_t)min(m0 + lrow, a.M - 1) * a.lda;
+    const bool wvalid = n0 + lrow < a.N;
+    const TIN* wrow = W + (size_t)min(n0 + lrow, a.N - 1) * a.ldw;
+
+    gf32x16 acc[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[mb][k] = 0.f;
+    Chunk8<TIN> ca, cw;
+    const int nkt = (a.K + GBK - 1) / GBK;
+    chunk8_load(ca, arow, lk, a.K, true);
+    chunk8_load(cw, wrow, lk, a.K, wvalid);
+    for (int kt = 0; kt < nkt; ++kt) {
+        chunk8_store(ca, &sa[0][lrow * GP + lk], &sa[IMG - 1][lrow * GP + lk], a.relu_a != 0);
+        chunk8_store(cw, &sw[0][lrow * GP + lk], &sw[IMG - 1][lrow * GP + lk], false);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            chunk8_load(ca, arow, (kt + 1) * GBK + lk, a.K, true);
+            chunk8_load(cw, wrow, (kt + 1) * GBK + lk, a.K, wvalid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GBK / 16; ++ks) {
+            const int ob = (32 * wn + r) * GP + ks * 16 + 8 * hh;
+            const gbf16x8 bh = *reinterpret_cast<const gbf16x8*>(&sw[0][ob]);
+            gbf16x8 bl;
+            if (SPLIT) bl = *reinterpret_cast<const gbf16x8*>(&sw[IMG - 1][ob]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int o = (64 * wm + 32 * mb + r) * GP + ks * 16 + 8 * hh;
+                const gbf16x8 ah = *reinterpret_cast<const gbf16x8*>(&sa[0][o]);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+                if (SPLIT) {
+                    const gbf16x8 al = *reinterpret_cast<const gbf16x8*>(&sa[IMG - 1][o]);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    TOUT* Y = reinterpret_cast<TOUT*>(a.Y);
+    const int n = n0 + 32 * wn + r;
+    if (n < a.N) {
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const long m = m0 + 64 * wm + 32 * mb + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                if (m < a.M) Y[(size_t)m * a.ldy + n] = OutCvt<TOUT>::of(acc[mb][k] + bv);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------ gemm_tn
 // Tile images hold 32 rows (reduction index m) x 128 / 64 columns, row pitch 256 + 64 / 128 + 64 B: the 4 rows x 64 B a half-wave takes per
 // transposed read (ds_read_b64_tr_b16) fall on disjoint 16-bank groups (pitch = 64 B mod 256 B).
@@ -506,7 +612,13 @@ int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void
     hipStream_t st = (hipStream_t)stream;
     const bool f32in = in_dtype == DIC_DTYPE_F32, f32out = out_dtype == DIC_DTYPE_F32;
 #define DIC_NT(TI, TO, BN) hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, BN>), grid, blk, 0, st, a)
-    if (bn == 128) {
+    static const bool eight = [] { const char* e = getenv("DIC_GEMM_NT8"); return !(e && e[0] == '0'); }();      // (A/B switch: 0 = four waves per 128 x 128 tile)
+    if (bn == 128 && eight) {
+#define DIC_NT8(TI, TO) hipLaunchKernelGGL((gemm_nt8_kernel<TI, TO>), grid, dim3(512), 0, st, a)
+        if (f32in) { if (f32out) DIC_NT8(float, float); else DIC_NT8(float, __bf16); }
+        else { if (f32out) DIC_NT8(__bf16, float); else DIC_NT8(__bf16, __bf16); }
+#undef DIC_NT8
+    } else if (bn == 128) {
         if (f32in) { if (f32out) DIC_NT(float, float, 128); else DIC_NT(float, __bf16, 128); }
         else { if (f32out) DIC_NT(__bf16, float, 128); else DIC_NT(__bf16, __bf16, 128); }
     } else {
