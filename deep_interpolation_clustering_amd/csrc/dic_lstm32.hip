@@ -8,7 +8,7 @@
 //               resident for all R steps -- no per-step weight traffic, no per-step launches.
 //   T = bf16    small batches (the reference's own B = 256, p1_pretrain_main.py:43): the 64-row kernels put B/64 x 2 workgroups on
 //               256 CUs and walk two 32-row halves per step; these take ONE 32-row tile per workgroup, so twice the workgroups
-//               each finish a step in about half the time.
+//               each finish a step in about half the time -- and, up to 2048 rows, one 16-row tile (lstm_rec_fwd16 / bwd16 below).
 //
 // One 256-thread workgroup owns 32 batch rows of one direction for the whole sequence.  The MFMA is issued transposed, as in
 // dic_lstm.hip: D[gate unit][batch] = W[gate unit][k] . h^T[k][batch], so wave w's A operand is the W_hh slice of hidden units
@@ -833,6 +833,306 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_bwd8_kernel(RecBwdArgs<__bf16
     }
 }
 
+// ---- 16-row tiles (round 4): batches up to REC16_MAX_BATCH.  At the reference's own B = 256 the 32-row kernels above put 16 workgroups on 256 CUs and
+// every recurrence step costs 2.4 (forward) / 3.2 us (backward) of serial MFMA + gate math per workgroup; half the rows per workgroup is half of both on
+// twice the CUs.  The product runs on v_mfma_f32_16x16x32_bf16 in the same transposed form (A = weights, B = h^T / dG^T of the 16 batch rows): lane
+// (n = lane & 15, g = lane >> 4) of wave w8 ends up with batch row n, units 16 w8 + 4 g + {0..3} of all four gates -- no lane exchange in either direction.
+// The saved state has its own lane-native layout (one contiguous 512-B piece per wave instruction), exchanged only between these two kernels.
+constexpr int TROWS = 16;
+constexpr int REC16_MAX_BATCH = 2048;     // 2 x 128 workgroups: up to here the 16-row grid still fits the chip in one round
+
+__device__ __forceinline__ size_t snative16_off(int t, int nbt, int bt, int dir, int G, int g, int w8, int lane) {
+    size_t o = ((size_t)t * nbt + bt) * 2 + dir;
+    o = (o * G + g) * 8 + w8;
+    return (o * 64 + lane) * 4;
+}
+
+template <int XK>
+__global__ __launch_bounds__(512, 1) void lstm_rec_fwd16_kernel(RecFwdArgs<__bf16> a) {
+    typedef __bf16 T;
+    typedef sbf16x4 V4;
+    constexpr bool PROJ = XK > 0;
+    constexpr int HP = Rec<T>::PITCH(SH);
+    constexpr int GXP = S4 + 8;
+    constexpr int XS = XK + 8;
+    extern __shared__ __align__(16) unsigned char fsm32[];
+    T* hbuf0 = reinterpret_cast<T*>(fsm32);               // [2][TROWS*HP]
+    T* gst = hbuf0 + 2 * TROWS * HP;                       // [TROWS][GXP] staged gx tile, or (PROJ) [2][TROWS][XS] x tiles
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, b0 = blockIdx.x * TROWS, B = a.B, R = a.R;
+    const int nbt = gridDim.x, bt = blockIdx.x;
+    const int b = b0 + n;
+    const bool ok = b < B;
+    const int bc = min(b, B - 1);
+    const int u = 16 * w8 + 4 * g4;                        // this lane's four hidden units
+
+    sbf16x8 wf[4][SH / 32];          // A rows of block blk (= gate): m = lane & 15 -> unit 16 w8 + m; k = 32 ks + 8 g4 + j
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < SH / 32; ++ks)
+            wf[blk][ks] = *reinterpret_cast<const sbf16x8*>(a.whh + ((size_t)(dir * 4 + blk) * SH + 16 * w8 + n) * SH + ks * 32 + 8 * g4);
+    sbf16x8 wx[4][PROJ ? XK / 32 : 1];
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int ks = 0; ks < XK / 32; ++ks)
+                wx[blk][ks] = *reinterpret_cast<const sbf16x8*>(a.wih + ((size_t)(dir * 4 + blk) * SH + 16 * w8 + n) * XK + ks * 32 + 8 * g4);
+    }
+
+    float c[4];
+    {
+        sf32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            if (a.h0) hv = *reinterpret_cast<const sf32x4*>(a.h0 + sstate_off(a.bm, dir, b, B) + u);
+            if (a.c0) cv = *reinterpret_cast<const sf32x4*>(a.c0 + sstate_off(a.bm, dir, b, B) + u);
+        }
+        V4 hb, cb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; cb[j] = (T)cv[j]; c[j] = cv[j]; }
+        *reinterpret_cast<V4*>(hbuf0 + n * HP + u) = hb;
+        if (a.boundary && ok) {
+            T* slot = dir ? a.out + (size_t)R * B * 2 * SH : a.out - (size_t)B * 2 * SH;
+            *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
+        }
+        if (a.cs) *reinterpret_cast<V4*>(a.cs + snative16_off(R, nbt, bt, dir, 1, 0, w8, lane)) = cb;
+    }
+    auto request_gx = [&](int step) {                      // 16 whole 1-KiB rows by LDS-DMA, two per wave
+        const int t = dir ? R - 1 - step : step;
+#pragma unroll
+        for (int k = 0; k < TROWS / 8; ++k) {
+            const int rowl = k * 8 + w8;
+            const int bb = min(b0 + rowl, B - 1);
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(a.gx + (((size_t)t * B + bb) * 2 + dir) * S4) + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(gst + rowl * GXP)), 16, 0, 0);
+        }
+    };
+    constexpr int XPC = PROJ ? XK / 8 : 1;                 // PROJ: 16 rows x XK / 8 pieces of 16 B per step
+    const bool xloader = PROJ && tid < TROWS * XPC;
+    const int xrow = tid / XPC, xpc = tid % XPC;
+    auto load_x = [&](int step) {
+        const int t = dir ? R - 1 - step : step;
+        return *reinterpret_cast<const sbf16x8*>(a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * XK + xpc * 8);
+    };
+    sbf16x8 xnext = {};
+    if constexpr (PROJ) {
+        if (xloader) *reinterpret_cast<sbf16x8*>(gst + xrow * XS + xpc * 8) = load_x(0);
+    } else {
+        request_gx(0);
+    }
+    __syncthreads();
+
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? R - 1 - step : step;
+        const int cur = step & 1;
+        const T* hcur = hbuf0 + cur * TROWS * HP;
+        T* hnxt = hbuf0 + (cur ^ 1) * TROWS * HP;
+        sf32x4_t acc[4];
+        if constexpr (PROJ) {
+            if (xloader && step + 1 < R) xnext = load_x(step + 1);       // in flight across the MFMA and gate-math phases
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) acc[blk] = sf32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < XK / 32; ++ks) {          // G = W_ih . x_t^T (bias included: constant-one input column)
+                const sbf16x8 xb = *reinterpret_cast<const sbf16x8*>(gst + cur * TROWS * XS + n * XS + ks * 32 + 8 * g4);
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wx[blk][ks], xb, acc[blk], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const V4 gv = *reinterpret_cast<const V4*>(gst + n * GXP + blk * SH + u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[blk][j] = (float)gv[j];
+            }
+        }
+        sbf16x8 hf[SH / 32];                              // the step's B fragments, all requested before the first MFMA
+#pragma unroll
+        for (int ks = 0; ks < SH / 32; ++ks) hf[ks] = *reinterpret_cast<const sbf16x8*>(hcur + n * HP + ks * 32 + 8 * g4);
+        if constexpr (!PROJ) {
+            lds_barrier();                                 // every wave has read its part of the staged tile
+            if (step + 1 < R) request_gx(step + 1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < SH / 32; ++ks)
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[blk][ks], hf[ks], acc[blk], 0, 0, 0);
+        const bool last = step == R - 1;
+        const size_t row = (size_t)t * B + bc;
+        V4 hb, ib, fb, gb, ob, cb;
+        sf32x4 cv, hv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ig = sigmoid_acc<T>(acc[0][j]), fg = sigmoid_acc<T>(acc[1][j]), gg = tanh_acc<T>(acc[2][j]), og = sigmoid_acc<T>(acc[3][j]);
+            const float cn = fmaf(fg, c[j], ig * gg);
+            const float hn = og * tanh_acc<T>(cn);
+            c[j] = cn;
+            cv[j] = cn; hv[j] = hn;
+            hb[j] = (T)hn; ib[j] = (T)ig; fb[j] = (T)fg; gb[j] = (T)gg; ob[j] = (T)og; cb[j] = (T)cn;
+        }
+        *reinterpret_cast<V4*>(hnxt + n * HP + u) = hb;
+        if (a.gates) {
+            *reinterpret_cast<V4*>(a.gates + snative16_off(t, nbt, bt, dir, 4, 0, w8, lane)) = ib;
+            *reinterpret_cast<V4*>(a.gates + snative16_off(t, nbt, bt, dir, 4, 1, w8, lane)) = fb;
+            *reinterpret_cast<V4*>(a.gates + snative16_off(t, nbt, bt, dir, 4, 2, w8, lane)) = gb;
+            *reinterpret_cast<V4*>(a.gates + snative16_off(t, nbt, bt, dir, 4, 3, w8, lane)) = ob;
+            *reinterpret_cast<V4*>(a.cs + snative16_off(t, nbt, bt, dir, 1, 0, w8, lane)) = cb;
+        }
+        if (ok) {
+            *reinterpret_cast<V4*>(a.out + row * 2 * SH + dir * SH + u) = hb;
+            if (last) {
+                *reinterpret_cast<sf32x4*>(a.hn + sstate_off(a.bm, dir, b, B) + u) = hv;
+                *reinterpret_cast<sf32x4*>(a.cn + sstate_off(a.bm, dir, b, B) + u) = cv;
+            }
+        }
+        if constexpr (PROJ) {
+            if (xloader && step + 1 < R) *reinterpret_cast<sbf16x8*>(gst + (cur ^ 1) * TROWS * XS + xrow * XS + xpc * 8) = xnext;
+        } else {
+            // the DMA of the next tile has landed once only the stores issued after it are in flight: 5 saved-state stores per wave
+            // (the `out` store may have been branched over)
+            if (a.gates) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        lds_barrier();
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void lstm_rec_bwd16_kernel(RecBwdArgs<__bf16> a) {
+    typedef __bf16 T;
+    typedef sbf16x4 V4;
+    constexpr int GP = Rec<T>::PITCH(S4);
+    extern __shared__ __align__(16) unsigned char rsm[];
+    T* dgt = reinterpret_cast<T*>(rsm);                 // [16][GP] gate gradients of the current step
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g4 = lane >> 4;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, b0 = blockIdx.x * TROWS, B = a.B, R = a.R;
+    const int nbt = gridDim.x, bt = blockIdx.x;
+    const int b = b0 + n;
+    const bool ok = b < B;
+    const int bc = min(b, B - 1);
+    const int u = 16 * w8 + 4 * g4;
+
+    // A operand: lane (m = lane & 15, kg = lane >> 4) holds W_hh^T[unit 16 w8 + m][32 ks + 8 kg .. + 7]; D row 4 g + e of lane (n, g) is unit
+    // 16 w8 + 4 g + e of batch row n -- what the gate math of that lane owns
+    sbf16x8 wt[S4 / 32];
+    {
+        const int unit = 16 * w8 + n;
+#pragma unroll
+        for (int ks = 0; ks < S4 / 32; ++ks) {
+            if (a.transposed) {
+                wt[ks] = *reinterpret_cast<const sbf16x8*>(a.whh + ((size_t)dir * SH + unit) * S4 + ks * 32 + 8 * g4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wt[ks][j] = a.whh[((size_t)dir * S4 + ks * 32 + 8 * g4 + j) * SH + unit];
+            }
+        }
+    }
+    float dh[4], dc[4], ccar[4];
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    {
+        const int t0 = dir ? 0 : R - 1;
+        sf32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            if (a.dhn) hv = *reinterpret_cast<const sf32x4*>(a.dhn + sstate_off(a.bm, dir, b, B) + u);
+            if (a.dcn) cv = *reinterpret_cast<const sf32x4*>(a.dcn + sstate_off(a.bm, dir, b, B) + u);
+        }
+        const V4 ct = *reinterpret_cast<const V4*>(a.cs + snative16_off(t0, nbt, bt, dir, 1, 0, w8, lane));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dh[j] = hv[j]; dc[j] = cv[j]; ccar[j] = (float)ct[j]; }
+    }
+    struct StepQ { V4 ib, fb, gb, ob, cp, go; };
+    auto load_q = [&](int step, StepQ& d) {
+        const int t = dir ? step : R - 1 - step;
+        const int tp = step == R - 1 ? R : (dir ? t + 1 : t - 1);
+        const size_t row = (size_t)t * B + bc;
+        d.ib = *reinterpret_cast<const V4*>(a.gates + snative16_off(t, nbt, bt, dir, 4, 0, w8, lane));
+        d.fb = *reinterpret_cast<const V4*>(a.gates + snative16_off(t, nbt, bt, dir, 4, 1, w8, lane));
+        d.gb = *reinterpret_cast<const V4*>(a.gates + snative16_off(t, nbt, bt, dir, 4, 2, w8, lane));
+        d.ob = *reinterpret_cast<const V4*>(a.gates + snative16_off(t, nbt, bt, dir, 4, 3, w8, lane));
+        d.cp = *reinterpret_cast<const V4*>(a.cs + snative16_off(tp, nbt, bt, dir, 1, 0, w8, lane));
+        if (a.dout) d.go = *reinterpret_cast<const V4*>(a.dout + row * 2 * SH + dir * SH + u);
+    };
+    StepQ in, nx;
+    load_q(0, in);
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? step : R - 1 - step;
+        {
+            V4 di, df, dg, dO;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ig = (float)in.ib[j], fg = (float)in.fb[j], gg = (float)in.gb[j], og = (float)in.ob[j], cp = (float)in.cp[j];
+                const float go = a.dout ? (float)in.go[j] : 0.f;
+                const float tc = tanh_acc<T>(ccar[j]);
+                const float dht = dh[j] + ((a.relu && !(tc > 0.f)) ? 0.f : go);
+                const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[j]);
+                const float vi = dct * gg * ig * (1.0f - ig), vf = dct * cp * fg * (1.0f - fg);
+                const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
+                di[j] = (T)(ok ? vi : 0.f); df[j] = (T)(ok ? vf : 0.f); dg[j] = (T)(ok ? vg : 0.f); dO[j] = (T)(ok ? vo : 0.f);
+                dc[j] = dct * fg;
+                ccar[j] = cp;
+            }
+            T* lp = dgt + n * GP + u;
+            *reinterpret_cast<V4*>(lp) = di;
+            *reinterpret_cast<V4*>(lp + SH) = df;
+            *reinterpret_cast<V4*>(lp + 2 * SH) = dg;
+            *reinterpret_cast<V4*>(lp + 3 * SH) = dO;
+        }
+        if (step + 1 < R) load_q(step + 1, nx);
+        lds_barrier();                                     // the dG tile of this step is complete
+        // dh_prev[unit][batch] = sum_n W_hh[n][unit] dG[batch][n]: 16 k-steps of 32 gate columns; B fragments four k-steps ahead (ring), this
+        // wave's two row copies ride between the MFMA groups
+        sf32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        constexpr int NKS = S4 / 32, DEPTH = 4;
+        sbf16x8 ring[DEPTH];
+        const T* brow = dgt + n * GP + 8 * g4;
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(brow + i * 32);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[ks], ring[ks % DEPTH], acc, 0, 0, 0);
+            if (ks + DEPTH < NKS) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(brow + (ks + DEPTH) * 32);
+            if ((ks & 7) == 7) {                           // one of this wave's two dG rows: LDS -> global (a whole 1-KiB row) + bias column sums
+                const int rowl = (ks >> 3) * 8 + w8;
+                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(dgt + rowl * GP) + lane * 16);
+                if (b0 + rowl < B)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.dgx + (((size_t)t * B + b0 + rowl) * 2 + dir) * S4) + lane * 16) = v;
+                const sbf16x8 x = __builtin_bit_cast(sbf16x8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[e] += (float)x[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dh[e] = acc[e];
+        lds_barrier();                                     // every wave is done reading the tile
+        in = nx;
+    }
+    if (a.dbias_part) {      // add the 8 waves' column sums through LDS (the dG tile is free now): one partial per workgroup
+        float* red = reinterpret_cast<float*>(rsm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w8 * S4 + lane * 8 + e] = bsum[e];
+        __syncthreads();
+        float* o = a.dbias_part + ((size_t)blockIdx.x * 2 + dir) * S4;
+        for (int i = tid; i < S4; i += 512) {
+            float sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) sum += red[ww * S4 + i];
+            o[i] = sum;
+        }
+    }
+    if (ok) {
+        sf32x4 hv, cv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hv[j] = dh[j]; cv[j] = dc[j]; }
+        *reinterpret_cast<sf32x4*>(a.dh0 + sstate_off(a.bm, dir, b, B) + u) = hv;
+        *reinterpret_cast<sf32x4*>(a.dc0 + sstate_off(a.bm, dir, b, B) + u) = cv;
+    }
+}
+
 __global__ __launch_bounds__(256) void lstm_rec_dbias_finalize(const float* partials, int nblk, float* dbias) {
     __shared__ double red[256];
     const int n = 2 * S4;
@@ -845,6 +1145,20 @@ __global__ __launch_bounds__(256) void lstm_rec_dbias_finalize(const float* part
 static bool rec_eight_waves() {
     static const bool on = [] { const char* e = getenv("DIC_REC_EIGHT_WAVES"); return !(e && e[0] == '0'); }();
     return on;
+}
+
+// batches up to REC16_MAX_BATCH run on the 16-row kernels (bf16; DIC_REC_SIXTEEN=0 keeps the 32-row ones: A/B switch, read per call so that a test can
+// flip it -- forward and backward of one LSTM call must see the same value, the saved-state layouts differ)
+static int rec16_max_batch() {
+    const char* e = getenv("DIC_REC16_MAX");
+    return e ? atoi(e) : REC16_MAX_BATCH;
+}
+static bool rec_sixteen(int B) {
+    const char* e = getenv("DIC_REC_SIXTEEN");
+    return rec_eight_waves() && B <= rec16_max_batch() && !(e && e[0] == '0');
+}
+static size_t rec16_fwd_lds(int xk) {
+    return ((size_t)2 * TROWS * Rec<__bf16>::PITCH(SH) + (xk ? (size_t)2 * TROWS * (xk + 8) : (size_t)TROWS * (S4 + 8))) * sizeof(__bf16);
 }
 
 template <typename T, bool X3 = false>
@@ -860,6 +1174,10 @@ static int rec_fwd(const void* gx, const void* whh, const float* h0, const float
         attr_set = true;
     }
     if constexpr (sizeof(T) == 2) {
+        if (rec_sixteen(B)) {
+            hipLaunchKernelGGL(lstm_rec_fwd16_kernel<0>, dim3((B + TROWS - 1) / TROWS, 2), dim3(512), rec16_fwd_lds(0), st, a);
+            return check_launch("lstm_rec_fwd16");
+        }
         if (rec_eight_waves()) {
             static bool attr8_set = false;
             if (!attr8_set) {
@@ -885,12 +1203,16 @@ static int rec_bwd(const void* whh, int transposed, const void* gates, const voi
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
-    const int nwg = (B + SROWS - 1) / SROWS;
+    const bool sixteen = sizeof(T) == 2 && rec_sixteen(B);
+    const int nwg = sixteen ? (B + TROWS - 1) / TROWS : (B + SROWS - 1) / SROWS;
     RecBwdArgs<T> a{(const T*)whh, (const T*)gates, (const T*)cs, (const T*)dout, dhn, dcn, (T*)dgx, dh0, dc0,
                     dbias ? (float*)workspace : nullptr, R, B, bm != 0, transposed, relu != 0};
     bool eight = false;
     if constexpr (sizeof(T) == 2) {
-        if (rec_eight_waves()) {
+        if (sixteen) {
+            hipLaunchKernelGGL(lstm_rec_bwd16_kernel, dim3(nwg, 2), dim3(512), (size_t)TROWS * Rec<T>::PITCH(S4) * sizeof(T), st, a);
+            eight = true;
+        } else if (rec_eight_waves()) {
             static bool attr8_set = false;
             if (!attr8_set) {
                 hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_bwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -936,13 +1258,24 @@ int dic_lstm_rec_fwd_proj(const void* x, const void* wih, const void* whh, const
     RecFwdArgs<T> a{nullptr, (const T*)whh, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B, (state_flags & 1) != 0, (state_flags & 2) != 0};
     a.x = (const T*)x; a.wih = (const T*)wih;
     const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)2 * SROWS * (I + 8)) * sizeof(T);
+    if (rec_sixteen(B)) {
+        const dim3 grid16((B + TROWS - 1) / TROWS, 2);
+        if (I == 32) hipLaunchKernelGGL(lstm_rec_fwd16_kernel<32>, grid16, dim3(512), rec16_fwd_lds(32), (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(lstm_rec_fwd16_kernel<64>, grid16, dim3(512), rec16_fwd_lds(64), (hipStream_t)stream, a);
+        return check_launch("lstm_rec_fwd16_proj");
+    }
     const dim3 grid((B + SROWS - 1) / SROWS, 2);
     if (I == 32) hipLaunchKernelGGL(lstm_rec_fwd8_kernel<32>, grid, dim3(512), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(lstm_rec_fwd8_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, a);
     return check_launch("lstm_rec_fwd_proj");
 }
 
-size_t dic_lstm_rec_bwd_workspace(int B) { return B > 0 ? (size_t)((B + SROWS - 1) / SROWS) * 2 * S4 * sizeof(float) : 0; }
+// (sized for the 16-row kernels' one partial per 16 rows where they may run)
+size_t dic_lstm_rec_bwd_workspace(int B) {
+    if (B <= 0) return 0;
+    const int rows = B <= rec16_max_batch() ? TROWS : SROWS;
+    return (size_t)((B + rows - 1) / rows) * 2 * S4 * sizeof(float);
+}
 
 int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const void* dout,
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,

@@ -308,9 +308,11 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
 /* The same recurrence for the two regimes the 64-row bf16 kernels above do not serve (csrc/dic_lstm32.hip): dtype =
  * DIC_DTYPE_F32 -- every tensor f32, the recurrent product on v_mfma_f32_32x32x2_f32 (exact f32: the configuration of the 1e-5
  * parity tests, which round 1 left on MIOpen's nn.LSTM) -- and dtype = DIC_DTYPE_BF16 for small batches (the reference's own
- * B = 256: one 32-row tile per workgroup instead of two).  Element type T of gx, whh, out, gates, cs, dout, dgx follows dtype;
+ * B = 256: one 32-row tile per workgroup instead of two; round 4: one 16-row tile up to 2048 rows, v_mfma_f32_16x16x32_bf16, same results bit
+ * for bit).  Element type T of gx, whh, out, gates, cs, dout, dgx follows dtype;
  * gates (R,Bp,2,4,H) and cs (R+1,Bp,2,H), Bp = B rounded up to 32, are an opaque lane-native layout exchanged between the two
- * calls (time slot R of cs carries c0, so the backward takes no c0).  whh (2,4H,H); the backward takes either that (read transposed
+ * calls of one (dtype, B) -- the 16- and 32-row kernels order it differently, and which pair runs is a function of B and the process environment
+ * (DIC_REC_SIXTEEN, DIC_REC16_MAX) alone -- (time slot R of cs carries c0, so the backward takes no c0).  whh (2,4H,H); the backward takes either that (read transposed
  * once at start-up) or the transposed copy (2,H,4H) with whh_is_transposed != 0.
  * state_flags of the forward: bit 0 = the state tensors (h0, c0, hn, cn) are batch-major (B,2,H); bit 1 (round 3) = `out` is time slots
  * 1..R of an (R+2,B,2H) buffer and the kernel also writes h0 (zeros without one) into slot 0 [:, :H] / slot R+1 [:, H:] -- every step's

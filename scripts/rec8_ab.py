@@ -22,7 +22,8 @@ H = 128
 dev, bf = torch.device('cuda'), torch.bfloat16
 P = N.ptr
 res = {}
-for R, B in ((24, 256), (24, 300), (24, 1024), (24, 4096), (1, 40), (2, 96)):
+SHAPES = [tuple(int(v) for v in t.split('x')) for t in os.environ['REC_AB_SHAPES'].split(',')] if os.environ.get('REC_AB_SHAPES') else ((24, 256), (24, 300), (24, 1024), (24, 4096), (1, 40), (2, 96))
+for R, B in SHAPES:
     torch.manual_seed(B)
     gx = (torch.randn(R, B, 2, 4, H, device=dev) * 0.5).to(bf)
     whh = (torch.randn(2, 4 * H, H, device=dev) * 0.08).to(bf); whh_t = whh.transpose(1, 2).contiguous()

@@ -95,11 +95,14 @@ def test_fused_bilstm_matches_emulation(R, B, I, init, kernel_family):
         close(gh0[1], c0.grad, 'dc0')
 
 
+@pytest.mark.parametrize('sixteen', ['0', '1'])
 @pytest.mark.parametrize('R,B,I,init', [(24, 256, 18, False), (5, 70, 36, True), (3, 33, 63, True)])
-def test_small_batch_in_kernel_projection_equals_the_64_row_kernel(R, B, I, init, monkeypatch):
+def test_small_batch_in_kernel_projection_equals_the_64_row_kernel(R, B, I, init, sixteen, monkeypatch):
     """dic_lstm_rec_fwd_proj (32-row tiles, the encoder's input projection inside the recurrence kernel: round 4) against dic_lstm_fwd_proj (the 64-row
-    pipelined kernel): the same products in the same order, the same gate math -- outputs, final states and saved-state-driven gradients bit for bit."""
+    pipelined kernel): the same products in the same order, the same gate math -- outputs, final states and saved-state-driven gradients bit for bit.
+    Both small-batch tilings: 32 rows per workgroup (DIC_REC_SIXTEEN=0) and the 16-row kernels that serve batches up to 2048."""
     from deep_interpolation_clustering_amd import lstm as L
+    monkeypatch.setenv('DIC_REC_SIXTEEN', sixteen)
     torch.manual_seed(R * 1000 + B + I)
     dev = torch.device('cuda')
     net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
@@ -1032,7 +1035,7 @@ def test_eight_wave_small_batch_recurrence_equals_four_wave(tmp_path):
     outs = []
     for mode in ('0', '1'):
         f = str(tmp_path / f'rec{mode}.pt')
-        res = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'rec8_ab.py'), 'run', f], env=dict(os.environ, DIC_REC_EIGHT_WAVES=mode),
+        res = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'rec8_ab.py'), 'run', f], env=dict(os.environ, DIC_REC_EIGHT_WAVES=mode, DIC_REC_SIXTEEN='0'),
                              capture_output=True, text=True, timeout=280, cwd=root)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(torch.load(f))
@@ -1041,6 +1044,31 @@ def test_eight_wave_small_batch_recurrence_equals_four_wave(tmp_path):
         for k in ('out', 'hn', 'cn', 'gates', 'cs', 'dgx', 'dh0', 'dc0'):
             assert torch.equal(four[B][k], eight[B][k]), (B, k)
         torch.testing.assert_close(eight[B]['db'], four[B]['db'], rtol=1e-5, atol=1e-5)
+
+
+def test_sixteen_row_small_batch_recurrence_equals_the_32_row_kernels(tmp_path):
+    """The 16-row-tile kernels of csrc/dic_lstm32.hip (batches up to 2048: v_mfma_f32_16x16x32_bf16, twice the workgroups at half the work per step)
+    against the 32-row eight-wave kernels (DIC_REC_SIXTEEN=0) on the same inputs, batches with and without a ragged last tile and R = 1, 2, 24: the two MFMA
+    shapes add a gate's products in the same k order, so outputs, final states, dG, dh0 and dc0 agree bit for bit; the bias gradient (one partial per 16
+    rows instead of 32) to f32 rounding.  The saved gates / cell states are layout-private to each pair of kernels and not compared."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ('0', '1'):
+        f = str(tmp_path / f'rec16_{mode}.pt')
+        res = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'rec8_ab.py'), 'run', f],
+                             env=dict(os.environ, DIC_REC_SIXTEEN=mode, REC_AB_SHAPES='24x256,24x300,24x1024,24x2048,1x40,2x96,5x7'),
+                             capture_output=True, text=True, timeout=280, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(torch.load(f))
+    wide, narrow = outs
+    assert len(wide) == 7
+    for key in wide:
+        for k in ('out', 'hn', 'cn', 'dgx', 'dh0', 'dc0'):
+            assert torch.equal(wide[key][k], narrow[key][k]), (key, k)
+        torch.testing.assert_close(narrow[key]['db'], wide[key]['db'], rtol=1e-5, atol=1e-5)
+        assert not torch.equal(wide[key]['gates'], narrow[key]['gates'])         # (the two runs did take different kernels)
 
 
 def test_eight_wave_backward_equals_four_wave_on_odd_shapes(tmp_path):
