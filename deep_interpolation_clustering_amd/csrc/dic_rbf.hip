@@ -521,6 +521,114 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_wave_kernel(RbfBwdArgs a) {
     if (tid < C) a.partials[(size_t)blockIdx.x * C + tid] = (red[tid] + red[C + tid]) + (red[2 * C + tid] + red[3 * C + tid]);
 }
 
+// ---- the backward with the SLOTS on the lanes (round 4; prefix masks, any C, R <= 4 RQ).  The two kernels above put (row, grid point[, split]) items on the
+// lanes and stream the row's slots from an LDS copy: a staging phase under a barrier, 16 B of LDS read per (slot, grid point), whole rows of T + 16 slots
+// resident (58 KB per encounter at C = 12, T = 288: two workgroups per CU), index decode per item.  At configs[3] (n = 200 slots per row) that is 37
+// vector-instruction slots per (slot, grid point) where the arithmetic needs 11.  Here a wave owns a ROW at a time and nothing is staged: lane (q, s) =
+// (lane >> 4, lane & 15) takes slot 16 k + s of chunk k straight from global memory into registers (four lanes share an address: one request) and grid
+// points RQ q .. RQ q + RQ - 1, whose three sums it keeps in 3 RQ registers for the whole row -- 7 vector operations + 1 exp per (slot, grid point), no LDS,
+// no barrier, no per-item decode; a row's tail wastes at most 15 slots (4 % at n = 200).  At the end of a row the sums of the 16 slot lanes are added by four
+// DPP steps inside the 16-lane row (quad permutes, half mirror, mirror: 12 RQ instructions per row), RQ lanes per quarter store dL/dv, and the row's
+// dL/dbeta term goes to the wave's per-channel accumulator in LDS.  ~60 registers: eight waves per SIMD hide the load latency of the 16-slot chunks.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float x) {      // every lane of a 16-lane row ends up with the row's sum
+    x += dpp_move<0xB1>(x);       // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);       // quad_perm [2,3,0,1]
+    x += dpp_move<0x141>(x);      // row_half_mirror
+    x += dpp_move<0x140>(x);      // row_mirror
+    return x;
+}
+
+template <int RQ, bool STORE>
+__global__ __launch_bounds__(kBlock) void rbf_bwd_slot_kernel(RbfBwdArgs a) {
+    constexpr int NW = kBlock / kWave;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, s = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, T = a.T, B = a.B, R = a.R;
+    float* nbeta = smem;               // [C]
+    float* gb = smem + C;              // [NW][C] dL/dbeta terms of this wave's rows
+    for (int i = tid; i < C; i += kBlock) nbeta[i] = -softplus_raw(a.rbf_kernel[i]) * kLog2e;
+    for (int i = tid; i < NW * C; i += kBlock) gb[i] = 0.f;
+    __syncthreads();
+    float ref[RQ];
+    bool rok[RQ];
+#pragma unroll
+    for (int j = 0; j < RQ; ++j) { rok[j] = RQ * q + j < R; ref[j] = a.ref_grid[min(RQ * q + j, R - 1)]; }
+    const float gscale = a.ob ? 2.0f * a.grad_loss[0] / a.sse_count[1] : 0.f;
+    const int nrows = B * C, nwaves = a.nblk * NW;
+    for (int row = blockIdx.x * NW + wave; row < nrows; row += nwaves) {
+        const int e = row / C, c = row - e * C;
+        const int n = max(0, min(a.lengths[row], T));
+        const float nb = nbeta[c];
+        const size_t o0 = (size_t)row * T;
+        const float* tp;
+        const float* gp;
+        if (STORE) {
+            const int64_t so = store_row_off(a.st, e, c, C);
+            tp = a.st.t_pk + so;
+            gp = a.ob ? a.st.v_pk + so : a.grad_y + o0;
+        } else {
+            tp = a.x + ((size_t)e * 4 * C + 2 * C + c) * T;
+            gp = (a.ob ? a.ob : a.grad_y) + o0;
+        }
+        const float* np = a.norm + o0;
+        const float* yp = a.y + o0;
+        float vr[RQ], gv[RQ], q1[RQ], q2[RQ];
+#pragma unroll
+        for (int j = 0; j < RQ; ++j) {
+            const int r = min(RQ * q + j, R - 1);
+            vr[j] = a.v[a.v_rbc ? ((size_t)r * B + e) * C + c : (size_t)row * R + r];
+            gv[j] = q1[j] = q2[j] = 0.f;
+        }
+        const int last = max(n - 1, 0), nchunks = (n + 15) >> 4;
+        int ic = min(s, last);                       // (clamped into the row: the slots behind it may hold anything -- they get weight 0)
+        float tv = tp[ic], gy = gp[ic], nm = np[ic], yv = yp[ic];
+        for (int k = 0; k < nchunks; ++k) {
+            const int i = 16 * k + s;
+            ic = min(i + 16, last);
+            const float tv2 = tp[ic], gy2 = gp[ic], nm2 = np[ic], yv2 = yp[ic];      // the next chunk, in flight across this one's arithmetic
+            const float g = a.ob ? gscale * (yv - gy) : gy;
+            const float w = i < n ? g * nm : 0.f;      // dL/dS = g/den (the forward saved 1/den)
+            const float wy = w * yv;
+#pragma unroll
+            for (int j = 0; j < RQ; ++j) {
+                const float d = tv - ref[j];
+                const float u = d * d;
+                const float ex = fast_exp2(nb * u);
+                gv[j] = fmaf(w, ex, gv[j]);
+                const float eu = ex * u;
+                q2[j] = fmaf(w, eu, q2[j]);
+                q1[j] = fmaf(wy, eu, q1[j]);
+            }
+            tv = tv2; gy = gy2; nm = nm2; yv = yv2;
+        }
+        float gbt = 0.f, out = 0.f;
+#pragma unroll
+        for (int j = 0; j < RQ; ++j) {
+            gv[j] = row16_sum(gv[j]);
+            const float t1 = row16_sum(q1[j]), t2 = row16_sum(q2[j]);
+            gbt += rok[j] ? fmaf(-vr[j], t2, t1) : 0.f;
+            out = s == j ? gv[j] : out;
+        }
+        gbt += __shfl_xor(gbt, 16);
+        gbt += __shfl_xor(gbt, 32);
+        if (lane == 0) gb[wave * C + c] += gbt;
+        const int r = RQ * q + s;
+        if (s < RQ && r < R) a.grad_v[a.v_rbc ? ((size_t)r * B + e) * C + c : (size_t)row * R + r] = out;
+    }
+    __syncthreads();
+    if (tid < C) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += gb[w * C + tid];
+        a.partials[(size_t)blockIdx.x * C + tid] = sum;
+    }
+}
+
 __global__ __launch_bounds__(256) void rbf_bwd_finalize(const float* partials, int nblk, int C, const float* rbf_kernel,
                                                        float* grad_kernel) {
     __shared__ double red[256];
@@ -696,12 +804,26 @@ static bool rbf_bwd_wave_geometry(int B, int C, int T, int R, int* nblk, size_t*
     return true;
 }
 
+// slots-on-lanes variant (rbf_bwd_slot_kernel): one row per wave at a time; DIC_RBF_BWD_SLOT=0 switches it off, =2 prefers it to the
+// wave-per-encounter kernel where both apply (A/B)
+static int rbf_bwd_slot_mode() {
+    const char* e = getenv("DIC_RBF_BWD_SLOT");
+    return e ? atoi(e) : 1;
+}
+static bool rbf_bwd_slot_geometry(int B, int C, int R, int* nblk) {
+    if (R > 24 || rbf_bwd_slot_mode() == 0) return false;
+    const int wpb = kBlock / kWave;
+    *nblk = (int)min(((long)B * C + wpb - 1) / wpb, (long)5 * kNumCU);      // 84 registers: five waves per SIMD = five workgroups per CU, one round
+    return true;
+}
+
 size_t dic_rbf_bwd_workspace(int B, int C, int T, int R) {
     if (B <= 0 || C <= 0 || T <= 0 || R <= 0) return 0;
-    int E, nblk, nblk2 = 0; size_t lds;
+    int E, nblk, nblk2 = 0, nblk3 = 0; size_t lds;
     rbf_bwd_geometry(B, C, T, R, &E, &nblk, &lds);
     rbf_bwd_wave_geometry(B, C, T, R, &nblk2, &lds);
-    return (size_t)max(nblk, nblk2) * C * sizeof(float);
+    rbf_bwd_slot_geometry(B, C, R, &nblk3);
+    return (size_t)max(max(nblk, nblk2), nblk3) * C * sizeof(float);
 }
 
 static int rbf_bwd_launch(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid,
@@ -722,7 +844,23 @@ static int rbf_bwd_launch(const float* x, const int32_t* lengths, int B, int C, 
     if (store) a.st = *store;
     size_t lds;
     hipStream_t st = (hipStream_t)stream;
-    if (lengths && (size_t)B * C * R < ((size_t)1 << 31) && rbf_bwd_wave_geometry(B, C, T, R, &a.nblk, &lds)) {
+    const bool wave_ok = lengths && (size_t)B * C * R < ((size_t)1 << 31) && rbf_bwd_wave_geometry(B, C, T, R, &a.nblk, &lds);
+    if (lengths && (!wave_ok || rbf_bwd_slot_mode() == 2) && rbf_bwd_slot_geometry(B, C, R, &a.nblk)) {
+        DIC_REQUIRE(workspace_bytes >= (size_t)a.nblk * C * sizeof(float), DIC_ERR_WORKSPACE, "rbf_bwd: workspace too small");
+        const size_t slds = (size_t)(1 + kBlock / kWave) * C * sizeof(float);
+        if (R <= 8) {
+            if (store) hipLaunchKernelGGL((rbf_bwd_slot_kernel<2, true>), dim3(a.nblk), dim3(kBlock), slds, st, a);
+            else hipLaunchKernelGGL((rbf_bwd_slot_kernel<2, false>), dim3(a.nblk), dim3(kBlock), slds, st, a);
+        } else {
+            if (store) hipLaunchKernelGGL((rbf_bwd_slot_kernel<6, true>), dim3(a.nblk), dim3(kBlock), slds, st, a);
+            else hipLaunchKernelGGL((rbf_bwd_slot_kernel<6, false>), dim3(a.nblk), dim3(kBlock), slds, st, a);
+        }
+        hipLaunchKernelGGL(rbf_bwd_finalize, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)workspace, a.nblk, C, rbf_kernel,
+                           grad_rbf_kernel);
+        return check_launch("rbf_bwd");
+    }
+    if (wave_ok) {
+        rbf_bwd_wave_geometry(B, C, T, R, &a.nblk, &lds);
         DIC_REQUIRE(workspace_bytes >= (size_t)a.nblk * C * sizeof(float), DIC_ERR_WORKSPACE, "rbf_bwd: workspace too small");
         if (store) hipLaunchKernelGGL((rbf_bwd_wave_kernel<6, 24, true>), dim3(a.nblk), dim3(kBlock), lds, st, a);
         else hipLaunchKernelGGL((rbf_bwd_wave_kernel<6, 24, false>), dim3(a.nblk), dim3(kBlock), lds, st, a);

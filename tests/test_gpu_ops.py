@@ -196,8 +196,10 @@ def test_rbf_golden(ops, name):
         np.testing.assert_allclose(k2.grad.cpu().numpy(), k.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize('shape', [(64, 6, 96, 24, 24, 50), (130, 6, 354, 6, 6, 60), (9, 12, 288, 24, 24, 200), (1, 6, 30, 11, 6, 9)])
-def test_rbf_vs_oracle(ops, shape):
+@pytest.mark.parametrize('slot_mode', ['0', '2'])
+@pytest.mark.parametrize('shape', [(64, 6, 96, 24, 24, 50), (130, 6, 354, 6, 6, 60), (9, 12, 288, 24, 24, 200), (1, 6, 30, 11, 6, 9), (70, 3, 50, 20, 12, 30)])
+def test_rbf_vs_oracle(ops, shape, slot_mode, monkeypatch):
+    monkeypatch.setenv('DIC_RBF_BWD_SLOT', slot_mode)         # (0: tile / wave-per-encounter kernels; 2: slots-on-lanes)
     B, C, T, R, H, lam = shape
     x, n = vitals_stack(77 + B, B, C, T, H, lam)
     rng = np.random.default_rng(B)
@@ -219,10 +221,12 @@ def test_rbf_vs_oracle(ops, shape):
 
 @pytest.mark.parametrize('B,T,lam,time_major,prefix_only', [(1, 30, 9, False, False), (37, 96, 80, True, True), (1027, 96, 50, True, True),
                                                            (130, 64, 40, False, True), (9, 100, 3, True, False)])
-def test_rbf_backward_reference_shape_kernel(ops, B, T, lam, time_major, prefix_only):
-    """The wave-per-encounter backward (C = 6, R = 24, prefix masks): rows longer than one 64-slot chunk, empty rows, a batch that is
-    not a multiple of the wave count, v / grad_v in CompressFC's (R,B,C) row order, and padding the forward never wrote
-    (prefix_only: poisoned with NaN here) -- against the fp64 oracle."""
+@pytest.mark.parametrize('slot_mode', ['1', '2'])
+def test_rbf_backward_reference_shape_kernel(ops, B, T, lam, time_major, prefix_only, slot_mode, monkeypatch):
+    """The wave-per-encounter backward (C = 6, R = 24, prefix masks; slot_mode 2: the slots-on-lanes kernel that serves every other shape, forced
+    onto this one): rows longer than one 64-slot chunk, empty rows, a batch that is not a multiple of the wave count, v / grad_v in CompressFC's
+    (R,B,C) row order, and padding the forward never wrote (prefix_only: poisoned with NaN here) -- against the fp64 oracle."""
+    monkeypatch.setenv('DIC_RBF_BWD_SLOT', slot_mode)
     C, R, H = 6, 24, 24.0
     x, n = vitals_stack(300 + B, B, C, T, H, lam)
     if B > 8:
@@ -258,9 +262,12 @@ def test_rbf_backward_reference_shape_kernel(ops, B, T, lam, time_major, prefix_
 
 @pytest.mark.parametrize('B,C,T,R,H,lam,time_major', [(1027, 6, 96, 24, 24.0, 50, True), (37, 6, 96, 24, 24.0, 80, False), (33, 12, 288, 24, 24.0, 200, True),
                                                        (5, 3, 40, 9, 12.0, 20, False)])
-def test_rbf_with_fused_reconstruction_loss_matches_separate_kernels(ops, B, C, T, R, H, lam, time_major):
+@pytest.mark.parametrize('slot_mode', ['0', '1', '2'])
+def test_rbf_with_fused_reconstruction_loss_matches_separate_kernels(ops, B, C, T, R, H, lam, time_major, slot_mode, monkeypatch):
     """ops.rbf_rec_loss (k2 forward emitting the masked SSE, k2 backward forming dL/dy from the observations) against
-    rbf_deinterp + masked_mse: same reconstruction on the observed slots, same loss and same gradients (to summation order)."""
+    rbf_deinterp + masked_mse: same reconstruction on the observed slots, same loss and same gradients (to summation order).  slot_mode: which
+    backward kernels serve the shape (DIC_RBF_BWD_SLOT: 0 = tile / wave-per-encounter only, 1 = default, 2 = slots-on-lanes wherever lengths are given)."""
+    monkeypatch.setenv('DIC_RBF_BWD_SLOT', slot_mode)
     x, n = vitals_stack(900 + B, B, C, T, H, lam)
     rng = np.random.default_rng(B)
     v_np = rng.normal(0, 1, (B, C, R)).astype(np.float32)
