@@ -585,20 +585,32 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_slot_kernel(RbfBwdArgs a) {
             gv[j] = q1[j] = q2[j] = 0.f;
         }
         const int last = max(n - 1, 0), nchunks = (n + 15) >> 4;
-        int ic = min(s, last);                       // (clamped into the row: the slots behind it may hold anything -- they get weight 0)
-        float tv = tp[ic], gy = gp[ic], nm = np[ic], yv = yp[ic];
+        // exp(-beta u) = exp2(-(sc d)^2), sc = sqrt(beta log2 e): the bandwidth rides on the time stamps (one multiplication per slot and RQ per row
+        // instead of one per (slot, grid point)); the two u-weighted sums come out scaled by sc^2 and are scaled back once per row
+        const float sc = __builtin_sqrtf(-nb), unscale = __builtin_amdgcn_rcpf(-nb);
+        float refs[RQ];
+#pragma unroll
+        for (int j = 0; j < RQ; ++j) refs[j] = sc * ref[j];
+        // The next chunk's four loads stay in flight across this chunk's arithmetic -- behind a compiler barrier: without one the loop is rotated, the
+        // loads sink to the top of the iteration that uses them and every chunk exposes a load round trip.  Indices are clamped into the row: the slots
+        // behind it may hold anything -- they get weight 0.  (Unsigned byte offsets: scalar base + 32-bit vector offset addressing.)
+        auto at = [](const float* base, unsigned byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+        unsigned off = 4u * (unsigned)min(s, last);
+        float tv = at(tp, off), gy = at(gp, off), nm = at(np, off), yv = at(yp, off);
         for (int k = 0; k < nchunks; ++k) {
             const int i = 16 * k + s;
-            ic = min(i + 16, last);
-            const float tv2 = tp[ic], gy2 = gp[ic], nm2 = np[ic], yv2 = yp[ic];      // the next chunk, in flight across this one's arithmetic
+            off = 4u * (unsigned)min(i + 16, last);
+            const float tv2 = at(tp, off), gy2 = at(gp, off), nm2 = at(np, off), yv2 = at(yp, off);
+            asm volatile("" ::: "memory");
             const float g = a.ob ? gscale * (yv - gy) : gy;
             const float w = i < n ? g * nm : 0.f;      // dL/dS = g/den (the forward saved 1/den)
             const float wy = w * yv;
+            const float ts = sc * tv;
 #pragma unroll
             for (int j = 0; j < RQ; ++j) {
-                const float d = tv - ref[j];
+                const float d = ts - refs[j];
                 const float u = d * d;
-                const float ex = fast_exp2(nb * u);
+                const float ex = fast_exp2(-u);
                 gv[j] = fmaf(w, ex, gv[j]);
                 const float eu = ex * u;
                 q2[j] = fmaf(w, eu, q2[j]);
@@ -611,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_slot_kernel(RbfBwdArgs a) {
         for (int j = 0; j < RQ; ++j) {
             gv[j] = row16_sum(gv[j]);
             const float t1 = row16_sum(q1[j]), t2 = row16_sum(q2[j]);
-            gbt += rok[j] ? fmaf(-vr[j], t2, t1) : 0.f;
+            gbt += rok[j] ? unscale * fmaf(-vr[j], t2, t1) : 0.f;
             out = s == j ? gv[j] : out;
         }
         gbt += __shfl_xor(gbt, 16);
