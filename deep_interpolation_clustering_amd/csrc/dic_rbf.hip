@@ -120,6 +120,97 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_kernel(RbfArgs a) {
     }
 }
 
+// The forward for prefix masks (lengths given), a ROW PER WAVE (round 4).  The tile kernel above decodes (row, chunk) from a flat unit index for every
+// 64-slot chunk, keeps the tile's v in LDS behind a workgroup barrier and spends 13.5 vector instructions per (slot, grid point) wave-pair where the arithmetic
+// is 6 (SQ_INSTS_VALU, profiles/r4_kernels_B32768_pmc_sq.json: its vector pipes are 93 % busy -- with bookkeeping).  Here a wave walks whole rows: the row's
+// grid values go through R words of wave-private LDS (no barrier: a wave's LDS operations execute in order), lane = slot, and the only per-chunk work besides
+// the R-step loop is one clamped load and the stores.  Same expression order per slot as the tile kernel: y and 1/(N + eps) are bit-identical to it.
+template <int RT, bool STORE>
+__global__ __launch_bounds__(kBlock) void rbf_fwd_row_kernel(RbfArgs a) {
+    constexpr int NW = kBlock / kWave, RP = DIC_MAX_REFPOINTS;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, T = a.T, B = a.B, R = RT ? RT : a.R;
+    float* lv = smem + wave * RP;          // [NW][RP] this wave's row of grid values
+    float* refg = smem + NW * RP;          // [RP]
+    float* nbeta = refg + RP;              // [C]  -beta*log2(e)
+    for (int i = tid; i < R; i += kBlock) refg[i] = a.ref_grid[i];
+    for (int i = tid; i < C; i += kBlock) nbeta[i] = -softplus_raw(a.rbf_kernel[i]) * kLog2e;
+    __syncthreads();
+    float sse = 0.f, nvalid = 0.f;
+    const int nrows = B * C, nwaves = gridDim.x * NW;
+    for (int row = blockIdx.x * NW + wave; row < nrows; row += nwaves) {
+        const int e = row / C, c = row - e * C;
+        const int n = max(0, min(a.lengths[row], T));
+        const float nb = nbeta[c];
+        if (lane < R) lv[lane] = a.v[a.v_rbc ? ((size_t)lane * B + e) * C + c : (size_t)row * R + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float* tp;
+        const float* obp;
+        if (STORE) {
+            const int64_t so = store_row_off(a.st, e, c, C);
+            tp = a.st.t_pk + so;
+            obp = a.st.v_pk + so;
+        } else {
+            tp = a.x + ((size_t)e * 4 * C + 2 * C + c) * T;
+            obp = a.ob + (size_t)row * T;
+        }
+        const size_t o0 = (size_t)row * T;
+        const int nslots = a.prefix_only ? n : T;              // prefix_only: the padding stays as the caller allocated it
+        for (int i0 = 0; i0 < nslots; i0 += kWave) {
+            const int i = i0 + lane;
+            const bool valid = i < n;
+            float N = 0.f, S = 0.f;
+            if (i0 < n) {                                      // (wave-uniform)
+                const float t = tp[min(i, n - 1)];
+                if (RT) {
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        const float d = t - refg[r];
+                        const float phi = fast_exp2(nb * (d * d));
+                        N += phi;
+                        S = fmaf(phi, lv[r], S);
+                    }
+                } else {
+                    for (int r = 0; r < R; ++r) {
+                        const float d = t - refg[r];
+                        const float phi = fast_exp2(nb * (d * d));
+                        N += phi;
+                        S = fmaf(phi, lv[r], S);
+                    }
+                }
+            }
+            if (i < nslots) {
+                const float inv = 1.0f / (N + kRbfEps);
+                a.y[o0 + i] = valid ? S * inv : 0.f;
+                if (a.norm) a.norm[o0 + i] = valid ? inv : 0.f;
+                if (a.ob && valid) {
+                    const float d = S * inv - obp[i];
+                    sse = fmaf(d, d, sse);
+                    nvalid += 1.f;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // the next row's grid values overwrite lv only after this row's reads
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (a.ob) {          // fixed-order sums: lanes -> waves -> one pair per workgroup
+        __syncthreads();
+        const double ws = wave_sum((double)sse), wc = wave_sum((double)nvalid);
+        double* red = reinterpret_cast<double*>(smem);
+        if (lane == 0) { red[wave] = ws; red[NW + wave] = wc; }
+        __syncthreads();
+        if (tid == 0) {
+            double s2 = 0, c2 = 0;
+            for (int w2 = 0; w2 < NW; ++w2) { s2 += red[w2]; c2 += red[NW + w2]; }
+            a.sse_part[2 * blockIdx.x] = s2;
+            a.sse_part[2 * blockIdx.x + 1] = c2;
+        }
+    }
+}
+
 // thousands of per-workgroup [sse, count] pairs -> out2: 512 slices x 2 columns, fixed order (f64)
 __global__ __launch_bounds__(1024) void sse_pairs_finalize(const double* partials, int nblk, float* out2) {
     __shared__ double red[1024];
@@ -748,11 +839,35 @@ static int rbf_fwd_grid(int B, int C, int R, int* E) {
     return (B + *E - 1) / *E;
 }
 
+// row-per-wave variant (rbf_fwd_row_kernel; prefix masks): DIC_RBF_FWD_ROW=0 keeps the tile kernel (A/B)
+static int rbf_fwd_row_grid(int B, int C) {
+    const int wpb = kBlock / kWave;
+    return (int)min(((long)B * C + wpb - 1) / wpb, (long)8 * kNumCU);
+}
+static bool rbf_fwd_row_on() {
+    const char* e = getenv("DIC_RBF_FWD_ROW");
+    return !(e && e[0] == '0');
+}
+
 static int rbf_fwd_launch(RbfArgs a, float* out2, hipStream_t st) {
     const int B = a.B, C = a.C, T = a.T, R = a.R;
     DIC_REQUIRE(B > 0 && C > 0 && T > 0 && R > 0, DIC_ERR_INVALID_ARG, "rbf_fwd: non-positive size");
     DIC_REQUIRE(C <= DIC_MAX_CHANNELS && R <= DIC_MAX_REFPOINTS, DIC_ERR_UNSUPPORTED, "rbf_fwd: C=%d R=%d", C, R);
     DIC_REQUIRE((a.x || a.st.row_off) && a.ref_grid && a.rbf_kernel && a.v && a.y, DIC_ERR_INVALID_ARG, "rbf_fwd: NULL pointer");
+    if (a.lengths && rbf_fwd_row_on()) {
+        const dim3 rgrid(rbf_fwd_row_grid(B, C));
+        const size_t rlds = (size_t)((kBlock / kWave + 1) * DIC_MAX_REFPOINTS + C) * sizeof(float);
+        const bool store = a.st.row_off != nullptr;
+        if (R == 24) {
+            if (store) hipLaunchKernelGGL((rbf_fwd_row_kernel<24, true>), rgrid, dim3(kBlock), rlds, st, a);
+            else hipLaunchKernelGGL((rbf_fwd_row_kernel<24, false>), rgrid, dim3(kBlock), rlds, st, a);
+        } else {
+            if (store) hipLaunchKernelGGL((rbf_fwd_row_kernel<0, true>), rgrid, dim3(kBlock), rlds, st, a);
+            else hipLaunchKernelGGL((rbf_fwd_row_kernel<0, false>), rgrid, dim3(kBlock), rlds, st, a);
+        }
+        if (a.ob) hipLaunchKernelGGL(sse_pairs_finalize, dim3(1), dim3(1024), 0, st, (const double*)a.sse_part, (int)rgrid.x, out2);
+        return check_launch("rbf_fwd");
+    }
     const dim3 grid(rbf_fwd_grid(B, C, R, &a.E));
     const size_t lds = (size_t)rbf_fwd_words(a.E, C, R) * 4;
     if (C == 6 && R == 24) hipLaunchKernelGGL((rbf_fwd_kernel<6, 24>), grid, dim3(kBlock), lds, st, a);
@@ -771,7 +886,7 @@ int dic_rbf_fwd(const float* x, const int32_t* lengths, int B, int C, int T, int
 size_t dic_rbf_fwd_loss_workspace(int B, int C, int T, int R) {
     if (B <= 0 || C <= 0 || T <= 0 || R <= 0) return 0;
     int E;
-    return (size_t)rbf_fwd_grid(B, C, R, &E) * 2 * sizeof(double);
+    return (size_t)max(rbf_fwd_grid(B, C, R, &E), rbf_fwd_row_grid(B, C)) * 2 * sizeof(double);
 }
 
 int dic_rbf_fwd_loss(const float* x, const int32_t* lengths, int B, int C, int T, int R, const float* ref_grid, const float* rbf_kernel,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the k2 backward variants (csrc/dic_rbf.hip) on the store path with the fused loss -- what the timed step launches -- at BASELINE configs[1]
+"""A/B of the k2 forward (DIC_RBF_FWD_ROW = 0 tile kernel / 1 row-per-wave kernel) and backward variants (csrc/dic_rbf.hip) on the store path with the fused loss -- what the timed step launches -- at BASELINE configs[1]
 (C=6, T=96, ~50 obs, B=32768) and configs[3] (C=12, T=288, ~200 obs, B=8192): DIC_RBF_BWD_SLOT = 0 (wave-per-encounter kernel where it applies, else the
 tile kernel), 1 (slots-on-lanes kernel where the wave kernel does not apply), 2 (slots-on-lanes everywhere).  Prints time per launch and the largest
 difference of dL/dv and dL/dkernel against mode 0 (the variants add the slots of a row in different orders).  usage: python3 scripts/k2_bwd_ab.py"""
@@ -36,6 +36,17 @@ for name, (C, T, lam, B) in {'cfg2': (6, 96, 50.0, 32768), 'cfg4': (12, 288, 200
     wsf = torch.empty(max(16, L.dic_rbf_fwd_loss_workspace(B, C, T, R)), dtype=torch.uint8, device=dev)
     N.check(L.dic_rbf_fwd_store(P(stor.t_pk), P(stor.v_pk), P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(rk), P(v), 0, 1, P(y), P(norm), 1,
                                 P(out2), P(wsf), wsf.numel(), st), 'fwd')
+    fres = {}
+    for mode in ('0', '1'):
+        os.environ['DIC_RBF_FWD_ROW'] = mode
+        y.fill_(-7.0); norm.fill_(-7.0)
+        ffn = lambda: L.dic_rbf_fwd_store(P(stor.t_pk), P(stor.v_pk), P(stor.row_off), P(perm), P(lperm), B, C, T, R, P(grid), P(rk), P(v), 0, 1, P(y), P(norm), 1,
+                                          P(out2), P(wsf), wsf.numel(), st)
+        assert ffn() == 0
+        fres[mode] = (y.clone(), norm.clone(), out2.clone(), bench.time_kernel(ffn, 20))
+    print('%-8s forward: tile kernel %8.1f us, row-per-wave kernel %8.1f us   y equal %s  norm equal %s  sse rel diff %.2e' % (
+        name, fres['0'][3] * 1e3, fres['1'][3] * 1e3, bool(torch.equal(fres['0'][0], fres['1'][0])), bool(torch.equal(fres['0'][1], fres['1'][1])),
+        float(abs(fres['0'][2][0] - fres['1'][2][0]) / fres['0'][2][0])))
     res = {}
     for mode in ('0', '1', '2'):
         os.environ['DIC_RBF_BWD_SLOT'] = mode

@@ -299,6 +299,39 @@ def test_rbf_with_fused_reconstruction_loss_matches_separate_kernels(ops, B, C, 
         np.testing.assert_allclose(a, b, rtol=tol, atol=tol * np.abs(b).max(), err_msg=key)
 
 
+@pytest.mark.parametrize('B,C,T,R,H,lam,time_major', [(1027, 6, 96, 24, 24.0, 50, True), (37, 6, 354, 6, 6.0, 80, False), (33, 12, 288, 24, 24.0, 200, True),
+                                                       (5, 3, 40, 9, 12.0, 20, False), (70, 6, 64, 24, 24.0, 70, False)])
+def test_rbf_forward_row_kernel_equals_tile_kernel(ops, B, C, T, R, H, lam, time_major, monkeypatch):
+    """rbf_fwd_row_kernel (prefix masks: a row per wave, round 4) against the tile kernel (DIC_RBF_FWD_ROW=0): the reconstruction bit for bit -- written
+    slots, zeros (or, prefix_only, the caller's bytes) in the padding --, an empty row, rows of exactly T slots; the fused loss to summation order."""
+    x, n = vitals_stack(500 + B, B, C, T, H, lam)
+    if B > 8:
+        n[3, 1] = 0
+        x[3, 1, :] = 0.0; x[3, C + 1, :] = 0.0; x[3, 2 * C + 1, :] = 0.0
+        n[4, 0] = T
+        x[4, C, :] = 1.0
+        x[4, 2 * C, :] = np.sort(np.random.default_rng(2).uniform(0, H, T)).astype(np.float32)
+    rng = np.random.default_rng(B)
+    v_np = rng.normal(0, 1, (B, C, R)).astype(np.float32)
+    k = G(rng.uniform(-0.5, 1.5, C).astype(np.float32))
+    ob = G((rng.normal(0, 1, (B, C, T)) * x[:, C:2 * C]).astype(np.float32))
+    v = G(np.ascontiguousarray(v_np.transpose(2, 0, 1))).permute(1, 2, 0) if time_major else G(v_np)
+    grid = ops.ref_grid(H, R, 'cuda')
+    lens, xg = G(n, dtype=torch.int32), G(x)
+    keep = torch.arange(T, device='cuda')[None, None, :] < lens[:, :, None]
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DIC_RBF_FWD_ROW', mode)
+        y_full = ops.rbf_deinterp(v, xg, k, grid, lengths=lens)
+        y_pref = ops.rbf_deinterp(v, xg, k, grid, lengths=lens, prefix_only=True)
+        y_loss, mse = ops.rbf_rec_loss(v, xg, k, grid, lens, ob)
+        res[mode] = (y_full, torch.where(keep, y_pref, torch.zeros_like(y_pref)), torch.where(keep, y_loss, torch.zeros_like(y_loss)), float(mse))
+    for j in range(3):
+        assert torch.equal(res['0'][j], res['1'][j]), j
+    assert float(res['1'][0][~keep].abs().max()) == 0.0
+    np.testing.assert_allclose(res['1'][3], res['0'][3], rtol=2e-6)
+
+
 # ------------------------------------------------------------------------------------ k3 golden
 @pytest.mark.parametrize('name', DEC)
 def test_dec_golden(ops, name):
