@@ -630,6 +630,135 @@ __global__ __launch_bounds__(kBlock) void sci_cci_bwd_kernel(const float* grad_o
     fold_gk_slices(smem, gk_acc, C, o + C);
 }
 
+// The fused backward for the reference shape (C = 6, R <= 32, cross-channel kernel present), GRID POINTS ON THE LANES (round 4).  The tile kernel above
+// walks an encounter tile through nine barrier phases over LDS planes and decodes (e, c, r) from a flat index in each: 440 vector instructions per 64 (c, r)
+// items (SQ_INSTS_VALU, profiles/r4_kernels_B32768_pmc_sq.json), 0.12 ms at B = 32 768 for 4 KB of input per encounter.  Here half a wave owns an
+// encounter: lane (h, r) = (lane >> 5, lane & 31) holds grid point r of encounter 2 p + h for all six channels in registers -- the seven saved planes and
+// the incoming gradient are read straight from global memory, coalesced along r (the packed bf16 rows: three 16-B pieces per lane) -- so that every sum over
+// channels (LSE, K-products, g_w's correction) is a register loop, and only two sums per channel cross lanes (the mean over r and sum_r (gs - ga w^)):
+// four DPP adds inside a 16-lane row and one v_permlane16_swap between the two rows of a half.  dL/dK (36 terms) and dL/dalpha (6) accumulate per lane over
+// all encounters of the wave and are reduced once, at the end.  No LDS until then, no barrier.  Same formulas, term by term, as cci_backward_lds.
+template <int CTRL>
+__device__ __forceinline__ float interp_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half_wave_sum(float x) {      // every lane of a 32-lane half ends up with the half's sum
+    x += interp_dpp<0xB1>(x);        // quad_perm [1,0,3,2]
+    x += interp_dpp<0x4E>(x);        // quad_perm [2,3,0,1]
+    x += interp_dpp<0x141>(x);       // row_half_mirror
+    x += interp_dpp<0x140>(x);       // row_mirror
+    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    return __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);      // rows (0,1) and (2,3) pairwise
+}
+
+template <int C, bool PACKED>
+__global__ __launch_bounds__(kBlock) void sci_cci_bwd_lane_kernel(const float* grad_out, const __bf16* grad_packed, int xw, const float* saved,
+                                                                 const float* cci_kernel, int B, int R, int nblk, float* partials) {
+    constexpr int NW = kBlock / kWave, NOUT = C + C * C;
+    __shared__ float red[NW * NOUT];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rc = min(r, R - 1), CR = C * R;
+    const float invR = 1.0f / (float)R, Rf = (float)R;
+    float kmat[C * C];
+#pragma unroll
+    for (int i = 0; i < C * C; ++i) kmat[i] = cci_kernel[i];
+    float gk[C * C], gal[C];
+#pragma unroll
+    for (int i = 0; i < C * C; ++i) gk[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) gal[c] = 0.f;
+
+    const int npairs = (B + 1) >> 1, nwaves = nblk * NW;
+    for (int p = blockIdx.x * NW + wave; p < npairs; p += nwaves) {
+        const int e = 2 * p + h;
+        const bool act = r < R && e < B;
+        const int ec = min(e, B - 1);
+        float y[C], w[C], yt[C], eu1[C], exu1[C], eu10[C], exu10[C], g1[C], g2[C], g3[C];
+        const float* sv = saved + (size_t)ec * 7 * CR + rc;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            y[c] = sv[c * R]; w[c] = sv[CR + c * R]; yt[c] = sv[2 * CR + c * R];
+            eu1[c] = sv[3 * CR + c * R]; exu1[c] = sv[4 * CR + c * R]; eu10[c] = sv[5 * CR + c * R]; exu10[c] = sv[6 * CR + c * R];
+        }
+        if (PACKED) {              // (R,B,xw) bf16 rows as the encoder's dX product wrote them: [g_y(C) | g_w(C) | g_yt(C) | ...]
+            constexpr int NP = (3 * C + 7) / 8;
+            __bf16 gb[NP * 8];
+            const uint4* src = reinterpret_cast<const uint4*>(grad_packed + ((size_t)rc * B + ec) * xw);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) *reinterpret_cast<uint4*>(gb + 8 * k) = src[k];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { g1[c] = (float)gb[c]; g2[c] = (float)gb[C + c]; g3[c] = (float)gb[2 * C + c]; }
+        } else {                   // (B,R,3C) f32
+            const float* src = grad_out + ((size_t)ec * R + rc) * 3 * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { g1[c] = src[c]; g2[c] = src[C + c]; g3[c] = src[2 * C + c]; }
+        }
+        // ---- cross-channel backward (cci_backward_lds, per grid point)
+        float mean[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) mean[c] = half_wave_sum(act ? y[c] : 0.f) / Rf;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, w[c]);
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) se += fast_exp(w[c] - mx);
+        const float lse = (mx == -INFINITY) ? -INFINITY : mx + fast_log(se);
+        float what[C], gs[C], ga[C], dsum[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            what[c] = fast_exp(w[c] - lse);
+            gs[c] = g1[c] - g3[c];
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const float ai = act ? what[i] * (y[i] - mean[i]) : 0.f;      // dL/dK[i][j] += a[i] gs[j]
+#pragma unroll
+            for (int j = 0; j < C; ++j) gk[i * C + j] = fmaf(ai, gs[j], gk[i * C + j]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < C; ++j) t = fmaf(gs[j], kmat[c * C + j], t);
+            ga[c] = t;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) dsum[c] = half_wave_sum(act ? gs[c] - ga[c] * what[c] : 0.f);      // sum_r gs - sum_r ga w^
+        float gww = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) gww = fmaf(ga[c] * (y[c] - mean[c]), what[c], gww);
+        // ---- single-channel backward: dL/dalpha terms  -gw*Eu1 - gy*(Exu1 - y*Eu1) - 10*gyt*(Exu10 - yt*Eu10)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float gwh = ga[c] * (y[c] - mean[c]);
+            const float gy = ga[c] * what[c] + dsum[c] * invR;
+            const float gw = g2[c] * fast_exp(w[c]) + what[c] * (gwh - gww);
+            const float part = -gw * eu1[c] - gy * (exu1[c] - y[c] * eu1[c]) - 10.0f * g3[c] * (exu10[c] - yt[c] * eu10[c]);
+            gal[c] += act ? part : 0.f;
+        }
+    }
+    // lanes -> wave (fixed butterfly) -> workgroup (wave order): one partial row per workgroup, [dalpha(C) | dK(C*C)]
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float t = wave_sum(gal[c]);
+        if (lane == 0) red[wave * NOUT + c] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < C * C; ++i) {
+        const float t = wave_sum(gk[i]);
+        if (lane == 0) red[wave * NOUT + C + i] = t;
+    }
+    __syncthreads();
+    if (tid < NOUT) {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) t += red[w2 * NOUT + tid];
+        partials[(size_t)blockIdx.x * NOUT + tid] = t;
+    }
+}
+
 // Stand-alone CCI backward: grad wrt s (B,R,3C) and per-block dL/dK partials.
 __global__ __launch_bounds__(kBlock) void cci_bwd_kernel(const float* grad_out, const float* s, const float* cci_kernel,
                                                         int B, int C, int R, int E, int nblk, float* grad_s,
@@ -800,11 +929,24 @@ int dic_sci_cci_fwd_store(const float* t_pk, const float* v_pk, const uint8_t* h
     return interp_fwd_launch(a, true, (hipStream_t)stream);
 }
 
+// grid-points-on-lanes variant (sci_cci_bwd_lane_kernel): C = 6, R <= 32, with the cross-channel kernel; DIC_K1_BWD_LANES=0 keeps the tile kernel (A/B)
+static bool bwd_lane_ok(int C, int R, bool with_cci, bool packed, int xw) {
+    const char* e = getenv("DIC_K1_BWD_LANES");
+    return C == 6 && R <= 32 && with_cci && (!packed || (xw >= 24 && xw % 8 == 0)) && !(e && e[0] == '0');
+}
+static int bwd_lane_blocks(int B, bool packed = true) {
+    const int per_block = 2 * (kBlock / kWave);          // encounters per workgroup and trip
+    const char* e = getenv("DIC_K1_BWD_LANE_WGS");          // workgroups per CU (tuning knob; default: 3 = one round at 123-131 registers)
+    const int per_cu = e ? max(1, atoi(e)) : 3;
+    (void)packed;
+    return max(1, min((B + per_block - 1) / per_block, per_cu * kNumCU));
+}
+
 size_t dic_sci_cci_bwd_workspace(int B, int C, int R) {
     if (B <= 0 || C <= 0 || R <= 0 || C > DIC_MAX_CHANNELS || R > DIC_MAX_REFPOINTS) return 0;
     int E, nblk; size_t lds;
     bwd_geometry(B, C, R, &E, &nblk, &lds);
-    return (size_t)nblk * (C + C * C) * sizeof(float);
+    return (size_t)max(nblk, max(bwd_lane_blocks(B), min((B + 7) / 8, 8 * kNumCU))) * (C + C * C) * sizeof(float);
 }
 
 static int sci_cci_bwd_launch(const float* grad_out, const void* grad_packed, int xw, const float* saved, const float* sci_kernel,
@@ -817,11 +959,25 @@ static int sci_cci_bwd_launch(const float* grad_out, const void* grad_packed, in
     DIC_REQUIRE(!grad_packed || xw >= 3 * C, DIC_ERR_INVALID_ARG, "sci_cci_bwd: packed row width %d < 3C = %d", xw, 3 * C);
     DIC_REQUIRE(!cci_kernel || grad_cci_kernel, DIC_ERR_INVALID_ARG, "sci_cci_bwd: grad_cci_kernel is NULL");
     int E, nblk; size_t lds;
+    hipStream_t st = (hipStream_t)stream;
+    if (bwd_lane_ok(C, R, cci_kernel != nullptr, grad_packed != nullptr, xw)) {
+        nblk = bwd_lane_blocks(B, grad_packed != nullptr);
+        DIC_REQUIRE(workspace_bytes >= (size_t)nblk * (C + C * C) * sizeof(float), DIC_ERR_WORKSPACE, "sci_cci_bwd: workspace %zu B too small", workspace_bytes);
+        if (grad_packed)
+            hipLaunchKernelGGL((sci_cci_bwd_lane_kernel<6, true>), dim3(nblk), dim3(kBlock), 0, st, grad_out, (const __bf16*)grad_packed, xw, saved, cci_kernel,
+                               B, R, nblk, (float*)workspace);
+        else
+            hipLaunchKernelGGL((sci_cci_bwd_lane_kernel<6, false>), dim3(nblk), dim3(kBlock), 0, st, grad_out, (const __bf16*)grad_packed, xw, saved, cci_kernel,
+                               B, R, nblk, (float*)workspace);
+        const int n = C + C * C;
+        hipLaunchKernelGGL(interp_bwd_finalize, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)workspace, nblk, C, sci_kernel, grad_sci_kernel,
+                           grad_cci_kernel);
+        return check_launch("sci_cci_bwd");
+    }
     bwd_geometry(B, C, R, &E, &nblk, &lds);
     DIC_REQUIRE(lds <= 64 * 1024, DIC_ERR_UNSUPPORTED, "sci_cci_bwd: LDS %zu B", lds);
     DIC_REQUIRE(workspace_bytes >= (size_t)nblk * (C + C * C) * sizeof(float), DIC_ERR_WORKSPACE,
                 "sci_cci_bwd: workspace %zu B too small", workspace_bytes);
-    hipStream_t st = (hipStream_t)stream;
     if (C == 6 && R == 24)
         hipLaunchKernelGGL((sci_cci_bwd_kernel<6, 24>), dim3(nblk), dim3(kBlock), lds, st, grad_out, (const __bf16*)grad_packed, xw, saved, cci_kernel,
                            B, C, R, E, nblk, (float*)workspace);

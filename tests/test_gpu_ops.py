@@ -166,6 +166,41 @@ def test_sci_cci_forward_reference_shape_corner_cases(ops, B, T, lam, packed):
     np.testing.assert_allclose(kc.grad.cpu().numpy(), k2.grad.numpy(), rtol=2e-4, atol=2e-4 * float(k2.grad.abs().max()))
 
 
+@pytest.mark.parametrize('B,R,packed', [(1, 24, False), (2, 24, True), (37, 24, True), (1027, 24, False), (1027, 24, True), (130, 6, False), (9, 11, True),
+                                        (64, 32, True)])
+def test_sci_cci_backward_lane_kernel_equals_tile_kernel(B, R, packed, monkeypatch):
+    """sci_cci_bwd_lane_kernel (C = 6: a grid point per lane, half a wave per encounter; round 4) against the tile kernel (DIC_K1_BWD_LANES=0) on the same
+    saved planes and incoming gradient -- odd batch (a half-empty last pair), R below / at the 32 lanes of a half, the f32 (B,R,3C) and the packed bf16
+    (R,B,32) gradient layouts: dL/dkernel of both layers to summation order."""
+    from deep_interpolation_clustering_amd import _native as N
+    L = N.lib()
+    C = 6
+    torch.manual_seed(B * 31 + R)
+    dev = 'cuda'
+    saved = torch.randn(B, 7, C, R, device=dev)
+    saved[:, 3:] = saved[:, 3:].abs()
+    sk, ck = torch.randn(C, device=dev) * 0.5, torch.randn(C, C, device=dev) * 0.4
+    g32 = torch.randn(B, R, 3 * C, device=dev)
+    gp = torch.zeros(R, B, 32, device=dev, dtype=torch.bfloat16)
+    gp[:, :, :3 * C] = g32.permute(1, 0, 2).to(torch.bfloat16)
+    if packed:
+        g32 = gp[:, :, :3 * C].float().permute(1, 0, 2).contiguous()          # (the same bf16-rounded values through the f32 entry point as reference)
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DIC_K1_BWD_LANES', mode)
+        ws = torch.empty(max(16, L.dic_sci_cci_bwd_workspace(B, C, R)), dtype=torch.uint8, device=dev)
+        gs, gc = torch.zeros(C, device=dev), torch.zeros(C, C, device=dev)
+        if packed:
+            N.check(L.dic_sci_cci_bwd_packed(N.ptr(gp), 32, N.ptr(saved), N.ptr(sk), N.ptr(ck), B, C, R, N.ptr(gs), N.ptr(gc), N.ptr(ws), ws.numel(),
+                                             N.stream_of(gp)), 'bwd_packed')
+        else:
+            N.check(L.dic_sci_cci_bwd(N.ptr(g32), N.ptr(saved), N.ptr(sk), N.ptr(ck), B, C, R, N.ptr(gs), N.ptr(gc), N.ptr(ws), ws.numel(), N.stream_of(g32)), 'bwd')
+        res[mode] = (gs.clone(), gc.clone())
+    for a, b in zip(res['1'], res['0']):
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()))
+
+
 # ------------------------------------------------------------------------------------ k2 golden
 @pytest.mark.parametrize('name', RBF)
 def test_rbf_golden(ops, name):
