@@ -850,9 +850,11 @@ def main():
         table = kernel_table(net, X[lo:lo + a.batch], OB[lo:lo + a.batch], LEN[lo:lo + a.batch], K, a.kernel_iters)
         log('kernel table done:', {k: v['ms'] for k, v in table.items()})
         # which kernel dominates the STEP: launches x duration from a trace of the timed step itself
-        trace_name = {'sci_cci_fwd': 'dic::sci_cci_fwd_kernel', 'sci_cci_bwd': 'dic::sci_cci_bwd_kernel', 'rbf_fwd': 'dic::rbf_fwd_kernel',
-                      'rbf_bwd': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'), 'masked_sse_fwd': 'dic::masked_sse_kernel', 'masked_sse_bwd': 'dic::masked_sse_bwd_kernel',
-                      'sci_cci_fwd_store': 'dic::sci_cci_fwd_kernel', 'rbf_fwd_store': 'dic::rbf_fwd_kernel', 'rbf_bwd_store': ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel'),
+        k2b = ('dic::rbf_bwd_kernel', 'dic::rbf_bwd_wave_kernel', 'dic::rbf_bwd_slot_kernel')
+        k2f = ('dic::rbf_fwd_kernel', 'dic::rbf_fwd_row_kernel')
+        trace_name = {'sci_cci_fwd': 'dic::sci_cci_fwd_kernel', 'sci_cci_bwd': ('dic::sci_cci_bwd_kernel', 'dic::sci_cci_bwd_lane_kernel'), 'rbf_fwd': k2f,
+                      'rbf_bwd': k2b, 'masked_sse_fwd': 'dic::masked_sse_kernel', 'masked_sse_bwd': 'dic::masked_sse_bwd_kernel',
+                      'sci_cci_fwd_store': 'dic::sci_cci_fwd_kernel', 'rbf_fwd_store': k2f, 'rbf_bwd_store': k2b,
                       'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': ('dic::lstm_fwd8_gxn_kernel', 'dic::lstm_fwd_kernel'),
                       'lstm_fwd_proj': ('dic::lstm_fwd8_proj_kernel', 'dic::lstm_fwd_kernel'), 'lstm_bwd': ('dic::lstm_bwd8_kernel', 'dic::lstm_bwd_kernel'), 'lstm_dw': 'dic::lstm_dw_kernel',
                       'row_proj': 'dic::row_proj_kernel', 'row_proj_stats': 'dic::row_proj_kernel', 'fc_bwd': 'dic::fc_bwd_kernel',
