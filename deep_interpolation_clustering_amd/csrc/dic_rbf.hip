@@ -140,12 +140,11 @@ __global__ __launch_bounds__(kBlock) void rbf_fwd_row_kernel(RbfArgs a) {
     __syncthreads();
     float sse = 0.f, nvalid = 0.f;
     const int nrows = B * C, nwaves = gridDim.x * NW;
-    const size_t vlane = (size_t)min(lane, R - 1) * B * C;      // time-major v: this lane's grid point, row 0
     for (int row = blockIdx.x * NW + wave; row < nrows; row += nwaves) {
         const int e = row / C, c = row - e * C;
         const int n = max(0, min(a.lengths[row], T));
         const float nb = nbeta[c];
-        if (lane < R) lv[lane] = a.v[a.v_rbc ? vlane + row : (size_t)row * R + lane];      // ((r B + e) C + c = r B C + row)
+        if (lane < R) lv[lane] = a.v[a.v_rbc ? ((size_t)lane * B + e) * C + c : (size_t)row * R + lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const float* tp;
@@ -648,18 +647,8 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_slot_kernel(RbfBwdArgs a) {
     __syncthreads();
     float ref[RQ];
     bool rok[RQ];
-    size_t voff[RQ];                   // v / grad_v element of this lane's grid point j in row 0: + row (time-major: (r B + e) C + c = r B C + row) or + row R
 #pragma unroll
-    for (int j = 0; j < RQ; ++j) {
-        const int r = min(RQ * q + j, R - 1);
-        rok[j] = RQ * q + j < R;
-        ref[j] = a.ref_grid[r];
-        voff[j] = a.v_rbc ? (size_t)r * B * C : (size_t)r;
-    }
-    const size_t vrow = a.v_rbc ? 1 : (size_t)R;
-    size_t ooff = 0;                   // ... and of grid point RQ q + s, the one this lane stores
-#pragma unroll
-    for (int j = 0; j < RQ; ++j) ooff = s == j ? voff[j] : ooff;
+    for (int j = 0; j < RQ; ++j) { rok[j] = RQ * q + j < R; ref[j] = a.ref_grid[min(RQ * q + j, R - 1)]; }
     const float gscale = a.ob ? 2.0f * a.grad_loss[0] / a.sse_count[1] : 0.f;
     const int nrows = B * C, nwaves = a.nblk * NW;
     for (int row = blockIdx.x * NW + wave; row < nrows; row += nwaves) {
@@ -682,7 +671,8 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_slot_kernel(RbfBwdArgs a) {
         float vr[RQ], gv[RQ], q1[RQ], q2[RQ];
 #pragma unroll
         for (int j = 0; j < RQ; ++j) {
-            vr[j] = a.v[voff[j] + (size_t)row * vrow];
+            const int r = min(RQ * q + j, R - 1);
+            vr[j] = a.v[a.v_rbc ? ((size_t)r * B + e) * C + c : (size_t)row * R + r];
             gv[j] = q1[j] = q2[j] = 0.f;
         }
         const int last = max(n - 1, 0), nchunks = (n + 15) >> 4;
@@ -730,7 +720,8 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_slot_kernel(RbfBwdArgs a) {
         gbt += __shfl_xor(gbt, 16);
         gbt += __shfl_xor(gbt, 32);
         if (lane == 0) gb[wave * C + c] += gbt;
-        if (s < RQ && RQ * q + s < R) a.grad_v[ooff + (size_t)row * vrow] = out;
+        const int r = RQ * q + s;
+        if (s < RQ && r < R) a.grad_v[a.v_rbc ? ((size_t)r * B + e) * C + c : (size_t)row * R + r] = out;
     }
     __syncthreads();
     if (tid < C) {
