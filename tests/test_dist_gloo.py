@@ -59,12 +59,16 @@ def _single():
     return flat, float(gn), float(loss.detach()), net[1].running_mean, net[1].running_var
 
 
-def test_sharded_step_equals_single_process(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = torch.load(tmp_path / 'r0.pt'), torch.load(tmp_path / 'r1.pt')
-    assert r0['bounds'] == (0, 32) and r1['bounds'] == (32, 64)
-    assert torch.equal(r0['flat'], r1['flat'])                        # replicas stay bit-identical
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_step_equals_single_process(tmp_path, world):
+    """Two ranks with equal shards, and three with shards of 21 / 21 / 22 rows (a global batch the world size does not divide)."""
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / f'r{k}.pt') for k in range(world)]
+    r0, r1 = ranks[0], ranks[1]
+    assert [r['bounds'] for r in ranks] == [((64 * k) // world, (64 * (k + 1)) // world) for k in range(world)]
+    for r in ranks[1:]:
+        assert torch.equal(r0['flat'], r['flat'])                     # replicas stay bit-identical
     flat, gn, loss, rm, rv = _single()
     live = np.ones(flat.numel(), bool)
     live[16 * 128:16 * 128 + 128] = False      # Linear bias feeding BatchNorm: true gradient 0, Adam amplifies rounding noise
