@@ -307,6 +307,208 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
     }
 }
 
+// ---- the decoder's forward with its input projection INSIDE (round 4, experiment behind DIC_FWD_XPROJ): gx = relu(x) W_ih^T + b -- 1.6 GB written by
+// dic_row_proj and read back by the 64-row recurrence kernel at B = 32 768 -- is never formed.  What makes W_ih (4H x 256 bf16 = 256 KB per direction) fit next
+// to W_hh is the register budget of ONE wave per SIMD: four waves per workgroup = 512 registers per lane (VGPR + AGPR; the f32 kernels above live there too).
+// Wave w owns hidden units [32 w, 32 w + 32) x 4 gates: 64 k-steps of W_ih fragments (256 registers) + 32 of W_hh (128).  A step: the 64 projection MFMAs
+// of the x tile (staged one step ahead through registers -- relu applied on the way -- into LDS), barrier, the 32 recurrent MFMAs, the gate arithmetic.
+// The saved state leaves in the lane-native order of BOTH kernel families (the formula of snative_off = dic_lstm.hip's native_off), cell states in the 64-row
+// kernels' convention (R slots, c0 handed to the backward separately): dic_lstm_bwd reads it.
+struct FwdXArgs {
+    const __bf16* x;       // (R,B,XI) raw input rows (the encoder's output: rectified on load when relu_x)
+    const __bf16* wih;     // (2,4H,XI)
+    const __bf16* whh;     // (2,4H,H)
+    const __bf16* bias;    // (2,4H)  b_ih + b_hh
+    const float* h0; const float* c0;
+    __bf16* out; float* hn; float* cn;
+    __bf16* gates; __bf16* cs;      // lane-native (R,Bp,2,4,H) / (R,Bp,2,H), Bp = B rounded up to 64; or NULL
+    int R, B, bm, boundary, relu_x;
+    __bf16* out_r;                  // optional (R,B,2H): relu(out), for a consumer that rectifies the output (as dic_lstm_fwd's out_r)
+};
+constexpr int XI = 256;                 // decoder input width (2H)
+constexpr int XIP = XI + 8;             // LDS row pitch of the x tile (528 B: conflict-free 16-B reads)
+constexpr int XRK = 176;                // input columns of W_ih held in registers (176 regs); the other XLK live in LDS (90 KB)
+constexpr int XLK = XI - XRK;
+constexpr int XLP = XLK + 8;            // their row pitch
+
+__global__ __launch_bounds__(256, 1) void lstm_fwdx_kernel(FwdXArgs a) {
+    typedef __bf16 T;
+    typedef sbf16x4 V4;
+    constexpr int HP = Rec<T>::PITCH(SH);
+    extern __shared__ __align__(16) unsigned char fsm32[];
+    T* hbuf0 = reinterpret_cast<T*>(fsm32);                 // [2][SROWS*HP]
+    T* xbuf = hbuf0 + 2 * SROWS * HP;                        // [2][SROWS*XIP]
+    float* bsm = reinterpret_cast<float*>(xbuf + 2 * SROWS * XIP);      // [4H] bias of this direction
+    T* wl = reinterpret_cast<T*>(bsm + S4);                              // [4H][XLP] the last XLK input columns of W_ih: the registers end at 3/4 of it
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
+    const int nbt = gridDim.x, bt = blockIdx.x;
+    const int b = b0 + r;
+    const bool ok = b < B;
+    const int bc = min(b, B - 1);
+
+    // A fragments: gate g, hidden unit 32 w + (lane & 31); k = 16 ks + 8 hh + j
+    sbf16x8 wh[4][SH / 16], wx[4][XRK / 16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const size_t row = (size_t)(dir * 4 + g) * SH + 32 * w + r;
+#pragma unroll
+        for (int ks = 0; ks < SH / 16; ++ks) wh[g][ks] = *reinterpret_cast<const sbf16x8*>(a.whh + row * SH + ks * 16 + 8 * hh);
+#pragma unroll
+        for (int ks = 0; ks < XRK / 16; ++ks) wx[g][ks] = *reinterpret_cast<const sbf16x8*>(a.wih + row * XI + ks * 16 + 8 * hh);
+    }
+    for (int i = tid; i < S4; i += 256) bsm[i] = (float)a.bias[(size_t)dir * S4 + i];
+    for (int i = tid; i < S4 * (XLK / 8); i += 256) {           // 16-B pieces of the LDS-resident columns
+        const int row = i / (XLK / 8), pc = i % (XLK / 8);
+        *reinterpret_cast<sbf16x8*>(wl + row * XLP + pc * 8) = *reinterpret_cast<const sbf16x8*>(a.wih + ((size_t)dir * S4 + row) * XI + XRK + pc * 8);
+    }
+
+    float c[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int u = 32 * w + 8 * q + 4 * hh;
+        sf32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            if (a.h0) hv = *reinterpret_cast<const sf32x4*>(a.h0 + sstate_off(a.bm, dir, b, B) + u);
+            if (a.c0) cv = *reinterpret_cast<const sf32x4*>(a.c0 + sstate_off(a.bm, dir, b, B) + u);
+        }
+        V4 hb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; c[4 * q + j] = cv[j]; }
+        *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
+        if (a.boundary && ok) {
+            T* slot = dir ? a.out + (size_t)R * B * 2 * SH : a.out - (size_t)B * 2 * SH;
+            *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
+        }
+    }
+    // x tile of a step: 32 rows x 32 pieces of 16 B, four per thread; rectified (sign bit -> zero) on the way into LDS
+    typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
+    const int xrow = tid >> 3, xpc = tid & 7;                // rows xrow; pieces xpc, xpc + 8, xpc + 16, xpc + 24
+    xu32x4 xn[4];
+    auto load_x = [&](int step) {
+        const int t = dir ? R - 1 - step : step;
+        const T* src = a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * XI;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xn[k] = *reinterpret_cast<const xu32x4*>(src + (xpc + 8 * k) * 8);
+    };
+    auto land_x = [&](int buf) {
+        T* dst = xbuf + buf * SROWS * XIP + xrow * XIP;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xu32x4 v = xn[k];
+            if (a.relu_x) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned neg = ((v[e] >> 15) & 0x00010001u) * 0xFFFFu;       // 0xFFFF in every half whose sign bit is set
+                    v[e] &= ~neg;
+                }
+            }
+            *reinterpret_cast<xu32x4*>(dst + (xpc + 8 * k) * 8) = v;
+        }
+    };
+    load_x(0);
+    land_x(0);
+    if (R > 1) load_x(1);
+    __syncthreads();
+
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? R - 1 - step : step;
+        const int cur = step & 1;
+        const T* hcur = hbuf0 + cur * SROWS * HP;
+        T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
+        const T* xcur = xbuf + cur * SROWS * XIP + r * XIP;
+        sf32x16 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const sf32x4 bv = *reinterpret_cast<const sf32x4*>(bsm + g * SH + 32 * w + 8 * q + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g][4 * q + j] = bv[j];
+            }
+        // input projection: 16 k-steps, B fragments four ahead
+        {
+            constexpr int NK = XI / 16, NKR = XRK / 16, DEPTH = 4;
+            sbf16x8 ring[DEPTH];
+            const T* wrow = wl + (32 * w + r) * XLP + 8 * hh;       // + g SH rows, + 16 (ks - NKR) columns
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(xcur + i * 16 + 8 * hh);
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                if (ks < NKR) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[g][ks], ring[ks % DEPTH], acc[g], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const sbf16x8 af = *reinterpret_cast<const sbf16x8*>(wrow + g * SH * XLP + (ks - NKR) * 16);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ring[ks % DEPTH], acc[g], 0, 0, 0);
+                    }
+                }
+                if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(xcur + (ks + DEPTH) * 16 + 8 * hh);
+            }
+        }
+        // recurrent part
+        {
+            constexpr int NK = SH / 16, DEPTH = 4;
+            sbf16x8 ring[DEPTH];
+            const T* hrow = hcur + r * HP;
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(hrow + i * 16 + 8 * hh);
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[g][ks], ring[ks % DEPTH], acc[g], 0, 0, 0);
+                if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(hrow + (ks + DEPTH) * 16 + 8 * hh);
+            }
+        }
+        // the x tile of the next step -> the other buffer (nobody reads it during this step), the one after that requested
+        if (step + 1 < R) land_x(cur ^ 1);
+        if (step + 2 < R) load_x(step + 2);
+        const bool last = step == R - 1;
+        const size_t row = (size_t)t * B + bc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = 32 * w + 8 * q + 4 * hh;
+            V4 hb, ib, fb, gb, ob, cb;
+            sf32x4 cv, hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * q + j;
+                const float ig = sigmoid_acc<T>(acc[0][k]), fg = sigmoid_acc<T>(acc[1][k]), gg = tanh_acc<T>(acc[2][k]), og = sigmoid_acc<T>(acc[3][k]);
+                const float cn = fmaf(fg, c[k], ig * gg);
+                const float hn = og * tanh_acc<T>(cn);
+                c[k] = cn;
+                cv[j] = cn; hv[j] = hn;
+                hb[j] = (T)hn; ib[j] = (T)ig; fb[j] = (T)fg; gb[j] = (T)gg; ob[j] = (T)og; cb[j] = (T)cn;
+            }
+            *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
+            if (a.gates) {
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 0, q, hh, r)) = ib;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 1, q, hh, r)) = fb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 2, q, hh, r)) = gb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 3, q, hh, r)) = ob;
+                *reinterpret_cast<V4*>(a.cs + snative_off(t, nbt, bt, dir, w, 1, 0, q, hh, r)) = cb;
+            }
+            if (ok) {
+                *reinterpret_cast<V4*>(a.out + row * 2 * SH + dir * SH + u) = hb;
+                if (a.out_r) {
+                    V4 hr;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hr[j] = (T)fmaxf(hv[j], 0.f);
+                    *reinterpret_cast<V4*>(a.out_r + row * 2 * SH + dir * SH + u) = hr;
+                }
+                if (last) {
+                    *reinterpret_cast<sf32x4*>(a.hn + sstate_off(a.bm, dir, b, B) + u) = hv;
+                    *reinterpret_cast<sf32x4*>(a.cn + sstate_off(a.bm, dir, b, B) + u) = cv;
+                }
+            }
+        }
+        lds_barrier();
+    }
+}
+
 template <typename T>
 struct RecBwdArgs {
     const T* whh;          // (2,4H,H) -- read transposed (strided) once at start-up;  or whh_t (2,H,4H) when `transposed`
@@ -1271,6 +1473,27 @@ int dic_lstm_rec_fwd_proj(const void* x, const void* wih, const void* whh, const
 }
 
 // (sized for the 16-row kernels' one partial per 16 rows where they may run)
+int dic_lstm_fwd_xproj(const void* x, const void* wih, const void* whh, const void* bias, const float* h0, const float* c0, int R, int B, int H, int I,
+                       void* out, void* out_r, float* hn, float* cn, void* gates, void* cs, int state_flags, int relu_x, dic_stream_t stream) {
+    DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_fwd_xproj: non-positive size");
+    DIC_REQUIRE(H == SH && I == XI, DIC_ERR_UNSUPPORTED, "lstm_fwd_xproj: hidden size %d / input width %d (compiled for %d / %d)", H, I, SH, XI);
+    DIC_REQUIRE(x && wih && whh && bias && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_fwd_xproj: NULL pointer");
+    DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_fwd_xproj: gates and cs go together");
+    typedef __bf16 T;
+    FwdXArgs a{(const T*)x, (const T*)wih, (const T*)whh, (const T*)bias, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B,
+               (state_flags & 1) != 0, (state_flags & 2) != 0, relu_x != 0, (T*)out_r};
+    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)2 * SROWS * XIP + (size_t)S4 * XLP) * sizeof(T) + (size_t)S4 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_fwdx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd_xproj: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    const dim3 grid(2 * ((B + 63) / 64), 2);       // 32-row tiles of a batch padded to 64 rows: the tile count dic_lstm_bwd indexes the saved state with
+    hipLaunchKernelGGL(lstm_fwdx_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    return check_launch("lstm_fwd_xproj");
+}
+
 size_t dic_lstm_rec_bwd_workspace(int B) {
     if (B <= 0) return 0;
     const int rows = B <= rec16_max_batch() ? TROWS : SROWS;

@@ -44,6 +44,7 @@ ROW_PROJ = os.environ.get('DIC_ROW_PROJ', '1') != '0'                  # (A/B sw
 RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B switch: 0 = rectify the encoder output with a torch pass)
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
 REC_PROJ = os.environ.get('DIC_REC_PROJ', '1') != '0'                  # (A/B switch: 0 = dic_gemm_nt + dic_lstm_rec_fwd for the encoder's small-batch forward)
+FWD_XPROJ = os.environ.get('DIC_FWD_XPROJ', '1') != '0'                # (A/B switch: 0 = dic_row_proj + dic_lstm_fwd for the decoder's large-batch forward: gx through HBM)
 SMALL_BATCH = 4096             # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
 
 
@@ -212,7 +213,13 @@ class _BiLstm(torch.autograd.Function):
                                             N.ptr(hn), N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), int(FWD_EIGHT_WAVES), st), 'dic_lstm_fwd_proj')
             else:
                 native = 0
-                if Ip == WIDE_INPUT and ROW_PROJ:
+                if Ip == WIDE_INPUT and ROW_PROJ and FWD_XPROJ:
+                    # decoder: the input projection INSIDE the recurrence kernel (csrc/dic_lstm32.hip, lstm_fwdx_kernel: W_ih in registers + LDS next to
+                    # W_hh at one wave per SIMD) -- the (R*B, 8H) gx tensor, its 1.6 GB write and read-back at B = 32 768, does not exist
+                    N.check(L.dic_lstm_fwd_xproj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(bias), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out), N.ptr(out_r), N.ptr(hn),
+                                                 N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm) | (2 if kernel_boundary else 0), int(relu_kernel), st), 'dic_lstm_fwd_xproj')
+                    gx = None
+                elif Ip == WIDE_INPUT and ROW_PROJ:
                     # decoder: the input projection with the weights resident in registers (csrc/dic_rowproj.hip); batches that tile by 64
                     # rows get gx in the order of the recurrence kernel's accumulators (no LDS staging of the gx tile over there)
                     native = B if (GX_LANE_NATIVE and B % 64 == 0) else 0
@@ -220,7 +227,8 @@ class _BiLstm(torch.autograd.Function):
                     N.check(L.dic_row_proj(N.ptr(xb), N.ptr(wih), N.ptr(bias), R * B, Ip, 8 * H, N.ptr(gx), native, int(relu_kernel), st), 'dic_row_proj')
                 else:
                     gx = _ops.gemm_nt(xb.view(R * B, Ip), wih, bias.float())
-                N.check(L.dic_lstm_fwd(N.ptr(gx), (2 if FWD_EIGHT_WAVES else 1) if native > 0 else 0, N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
+                if gx is not None:
+                    N.check(L.dic_lstm_fwd(N.ptr(gx), (2 if FWD_EIGHT_WAVES else 1) if native > 0 else 0, N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(out_r), N.ptr(hn),
                                        N.ptr(cn), N.ptr(gates), N.ptr(cs), int(bm), int(kernel_boundary), st), 'dic_lstm_fwd')
         ctx.dims = (R, B, I, Ip, narrow, small, bool(packed), bool(bm), bool(f32), bool(relu))
         ctx.x3 = x3

@@ -328,6 +328,14 @@ int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0
 int dic_lstm_rec_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H, int I, void* out,
                           float* hn, float* cn, void* gates, void* cs, int state_flags, dic_stream_t stream);
 
+/* dic_lstm_fwd_xproj (bf16, H = 128, I = 256: the decoder; clustering_interp.py:30-41): the forward recurrence with the input projection x W_ih^T + b inside
+ * the kernel -- gx (R,B,8H) is never formed.  x (R,B,256) bf16 raw rows (relu_x != 0: rectified on load, the F.relu between encoder and decoder), wih (2,4H,256),
+ * whh (2,4H,H), bias (2,4H) bf16 as dic_lstm_pack writes them.  gates (R,Bp,2,4,H) / cs (R,Bp,2,H), Bp = B rounded up to 64, leave in the lane-native order
+ * dic_lstm_bwd reads (c0 goes to the backward separately, as with dic_lstm_fwd).  out_r: optional (R,B,2H) relu(out), as dic_lstm_fwd's.  state_flags as
+ * dic_lstm_rec_fwd. */
+int dic_lstm_fwd_xproj(const void* x, const void* wih, const void* whh, const void* bias, const float* h0, const float* c0, int R, int B, int H, int I,
+                       void* out, void* out_r, float* hn, float* cn, void* gates, void* cs, int state_flags, int relu_x, dic_stream_t stream);
+
 size_t dic_lstm_rec_bwd_workspace(int B);
 int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const void* gates, const void* cs, const void* dout,
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
