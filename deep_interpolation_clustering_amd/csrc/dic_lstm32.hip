@@ -307,13 +307,14 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
     }
 }
 
-// ---- the decoder's forward with its input projection INSIDE (round 4, experiment behind DIC_FWD_XPROJ): gx = relu(x) W_ih^T + b -- 1.6 GB written by
-// dic_row_proj and read back by the 64-row recurrence kernel at B = 32 768 -- is never formed.  What makes W_ih (4H x 256 bf16 = 256 KB per direction) fit next
-// to W_hh is the register budget of ONE wave per SIMD: four waves per workgroup = 512 registers per lane (VGPR + AGPR; the f32 kernels above live there too).
-// Wave w owns hidden units [32 w, 32 w + 32) x 4 gates: 64 k-steps of W_ih fragments (256 registers) + 32 of W_hh (128).  A step: the 64 projection MFMAs
-// of the x tile (staged one step ahead through registers -- relu applied on the way -- into LDS), barrier, the 32 recurrent MFMAs, the gate arithmetic.
-// The saved state leaves in the lane-native order of BOTH kernel families (the formula of snative_off = dic_lstm.hip's native_off), cell states in the 64-row
-// kernels' convention (R slots, c0 handed to the backward separately): dic_lstm_bwd reads it.
+// ---- the decoder's forward with its input projection INSIDE (round 4; lstm.FWD_XPROJ): gx = relu(x) W_ih^T + b -- 1.6 GB written by dic_row_proj and read
+// back by the 64-row recurrence kernel at B = 32 768 -- is never formed.  W_ih (4H x 256 bf16 = 256 KB per direction) does not fit the registers next to W_hh;
+// what fits is 3/4 of it: eight waves per 32-row tile as in lstm_rec_fwd8_kernel, wave w8 owning 16 hidden units x 4 gates -- W_hh in 64 registers, the first
+// 192 input columns of W_ih in 96, the last 64 in LDS (72 KB, read as A fragments), 250 registers in all.  A step: bias -> accumulators, the 32 projection
+// MFMAs of the x tile (staged one step ahead through registers -- rectified on the way -- into LDS), the 16 recurrent MFMAs, the gate arithmetic, barrier.
+// (A four-wave form with all of W_ih in 512 registers per lane -- one wave per SIMD -- ran 10 % slower: 1.05 against 0.95 ms.)
+// The saved state leaves in the lane-native order of BOTH kernel families (snative_off = dic_lstm.hip's native_off), cell states in the 64-row kernels'
+// convention (R slots, c0 handed to the backward separately): dic_lstm_bwd reads it.
 struct FwdXArgs {
     const __bf16* x;       // (R,B,XI) raw input rows (the encoder's output: rectified on load when relu_x)
     const __bf16* wih;     // (2,4H,XI)
@@ -327,47 +328,49 @@ struct FwdXArgs {
 };
 constexpr int XI = 256;                 // decoder input width (2H)
 constexpr int XIP = XI + 8;             // LDS row pitch of the x tile (528 B: conflict-free 16-B reads)
-constexpr int XRK = 176;                // input columns of W_ih held in registers (176 regs); the other XLK live in LDS (90 KB)
-constexpr int XLK = XI - XRK;
-constexpr int XLP = XLK + 8;            // their row pitch
 
-__global__ __launch_bounds__(256, 1) void lstm_fwdx_kernel(FwdXArgs a) {
+constexpr int X8RK = 192;               // input columns of W_ih held in registers (96 registers); the other X8LK: 72 KB of LDS
+constexpr int X8LK = XI - X8RK;
+constexpr int X8LP = X8LK + 8;
+
+__global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
     typedef __bf16 T;
     typedef sbf16x4 V4;
     constexpr int HP = Rec<T>::PITCH(SH);
     extern __shared__ __align__(16) unsigned char fsm32[];
     T* hbuf0 = reinterpret_cast<T*>(fsm32);                 // [2][SROWS*HP]
     T* xbuf = hbuf0 + 2 * SROWS * HP;                        // [2][SROWS*XIP]
-    float* bsm = reinterpret_cast<float*>(xbuf + 2 * SROWS * XIP);      // [4H] bias of this direction
-    T* wl = reinterpret_cast<T*>(bsm + S4);                              // [4H][XLP] the last XLK input columns of W_ih: the registers end at 3/4 of it
+    float* bsm = reinterpret_cast<float*>(xbuf + 2 * SROWS * XIP);      // [4H]
+    T* wl = reinterpret_cast<T*>(bsm + S4);                              // [4H][X8LP]
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = w8 >> 1, qh = w8 & 1;
     const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
     const int nbt = gridDim.x, bt = blockIdx.x;
     const int b = b0 + r;
     const bool ok = b < B;
     const int bc = min(b, B - 1);
 
-    // A fragments: gate g, hidden unit 32 w + (lane & 31); k = 16 ks + 8 hh + j
-    sbf16x8 wh[4][SH / 16], wx[4][XRK / 16];
+    // A rows of block blk: m = lane & 31 -> gate 2 blk + (m >> 4), unit 16 w8 + (m & 15)
+    sbf16x8 wh[2][SH / 16], wx[2][X8RK / 16];
+    const int arow[2] = {(0 + (r >> 4)) * SH + 16 * w8 + (r & 15), (2 + (r >> 4)) * SH + 16 * w8 + (r & 15)};
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const size_t row = (size_t)(dir * 4 + g) * SH + 32 * w + r;
+    for (int blk = 0; blk < 2; ++blk) {
+        const size_t row = (size_t)dir * S4 + arow[blk];
 #pragma unroll
-        for (int ks = 0; ks < SH / 16; ++ks) wh[g][ks] = *reinterpret_cast<const sbf16x8*>(a.whh + row * SH + ks * 16 + 8 * hh);
+        for (int ks = 0; ks < SH / 16; ++ks) wh[blk][ks] = *reinterpret_cast<const sbf16x8*>(a.whh + row * SH + ks * 16 + 8 * hh);
 #pragma unroll
-        for (int ks = 0; ks < XRK / 16; ++ks) wx[g][ks] = *reinterpret_cast<const sbf16x8*>(a.wih + row * XI + ks * 16 + 8 * hh);
+        for (int ks = 0; ks < X8RK / 16; ++ks) wx[blk][ks] = *reinterpret_cast<const sbf16x8*>(a.wih + row * XI + ks * 16 + 8 * hh);
     }
-    for (int i = tid; i < S4; i += 256) bsm[i] = (float)a.bias[(size_t)dir * S4 + i];
-    for (int i = tid; i < S4 * (XLK / 8); i += 256) {           // 16-B pieces of the LDS-resident columns
-        const int row = i / (XLK / 8), pc = i % (XLK / 8);
-        *reinterpret_cast<sbf16x8*>(wl + row * XLP + pc * 8) = *reinterpret_cast<const sbf16x8*>(a.wih + ((size_t)dir * S4 + row) * XI + XRK + pc * 8);
+    for (int i = tid; i < S4; i += 512) bsm[i] = (float)a.bias[(size_t)dir * S4 + i];
+    for (int i = tid; i < S4 * (X8LK / 8); i += 512) {
+        const int row = i / (X8LK / 8), pc = i % (X8LK / 8);
+        *reinterpret_cast<sbf16x8*>(wl + row * X8LP + pc * 8) = *reinterpret_cast<const sbf16x8*>(a.wih + ((size_t)dir * S4 + row) * XI + X8RK + pc * 8);
     }
 
-    float c[16];
+    float c[8];                      // element e = 4 qq + j: unit 16 w8 + 8 qq + 4 hh + j
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int u = 32 * w + 8 * q + 4 * hh;
+    for (int qq = 0; qq < 2; ++qq) {
+        const int u = 16 * w8 + 8 * qq + 4 * hh;
         sf32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
         if (ok) {
             if (a.h0) hv = *reinterpret_cast<const sf32x4*>(a.h0 + sstate_off(a.bm, dir, b, B) + u);
@@ -375,108 +378,104 @@ __global__ __launch_bounds__(256, 1) void lstm_fwdx_kernel(FwdXArgs a) {
         }
         V4 hb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; c[4 * q + j] = cv[j]; }
+        for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; c[4 * qq + j] = cv[j]; }
         *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
         if (a.boundary && ok) {
             T* slot = dir ? a.out + (size_t)R * B * 2 * SH : a.out - (size_t)B * 2 * SH;
             *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
         }
     }
-    // x tile of a step: 32 rows x 32 pieces of 16 B, four per thread; rectified (sign bit -> zero) on the way into LDS
+    // x tile of a step: 32 rows x 32 pieces of 16 B, two per thread; rectified on the way into LDS
     typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
-    const int xrow = tid >> 3, xpc = tid & 7;                // rows xrow; pieces xpc, xpc + 8, xpc + 16, xpc + 24
-    xu32x4 xn[4];
+    const int xrow = tid >> 4, xpc = tid & 15;               // pieces xpc, xpc + 16
+    xu32x4 xn[2];
     auto load_x = [&](int step) {
         const int t = dir ? R - 1 - step : step;
         const T* src = a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * XI;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xn[k] = *reinterpret_cast<const xu32x4*>(src + (xpc + 8 * k) * 8);
+        for (int k = 0; k < 2; ++k) xn[k] = *reinterpret_cast<const xu32x4*>(src + (xpc + 16 * k) * 8);
     };
     auto land_x = [&](int buf) {
         T* dst = xbuf + buf * SROWS * XIP + xrow * XIP;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
             xu32x4 v = xn[k];
             if (a.relu_x) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const unsigned neg = ((v[e] >> 15) & 0x00010001u) * 0xFFFFu;       // 0xFFFF in every half whose sign bit is set
+                    const unsigned neg = ((v[e] >> 15) & 0x00010001u) * 0xFFFFu;
                     v[e] &= ~neg;
                 }
             }
-            *reinterpret_cast<xu32x4*>(dst + (xpc + 8 * k) * 8) = v;
+            *reinterpret_cast<xu32x4*>(dst + (xpc + 16 * k) * 8) = v;
         }
     };
     load_x(0);
     land_x(0);
     if (R > 1) load_x(1);
     __syncthreads();
-
+    // (Running the two waves of a SIMD half a step apart -- one wave's projection MFMAs under the other's gate arithmetic, x tiles staged two steps ahead --
+    //  was tried: no change, 0.76 ms without the saved-state stores either way.  A step costs the sum of its parts: 96 MFMAs and ~590 vector instructions per
+    //  SIMD, 160 of them quarter-rate exp / rcp: 3.9 us, against 3.0 us of HBM time for its 64 KB.)
     for (int step = 0; step < R; ++step) {
         const int t = dir ? R - 1 - step : step;
         const int cur = step & 1;
         const T* hcur = hbuf0 + cur * SROWS * HP;
         T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
         const T* xcur = xbuf + cur * SROWS * XIP + r * XIP;
-        sf32x16 acc[4];
+        sf32x16 acc[2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const sf32x4 bv = *reinterpret_cast<const sf32x4*>(bsm + g * SH + 32 * w + 8 * q + 4 * hh);
+            for (int gs = 0; gs < 2; ++gs)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][4 * q + j] = bv[j];
-            }
-        // input projection: 16 k-steps, B fragments four ahead
+                for (int qq = 0; qq < 2; ++qq) {
+                    const sf32x4 bv = *reinterpret_cast<const sf32x4*>(bsm + (2 * blk + gs) * SH + 16 * w8 + 8 * qq + 4 * hh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[blk][8 * gs + 4 * qq + j] = bv[j];
+                }
         {
-            constexpr int NK = XI / 16, NKR = XRK / 16, DEPTH = 4;
+            constexpr int NK = XI / 16, NKR = X8RK / 16, DEPTH = 4;
             sbf16x8 ring[DEPTH];
-            const T* wrow = wl + (32 * w + r) * XLP + 8 * hh;       // + g SH rows, + 16 (ks - NKR) columns
 #pragma unroll
             for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(xcur + i * 16 + 8 * hh);
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 if (ks < NKR) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[g][ks], ring[ks % DEPTH], acc[g], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[0][ks], ring[ks % DEPTH], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[1][ks], ring[ks % DEPTH], acc[1], 0, 0, 0);
                 } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const sbf16x8 af = *reinterpret_cast<const sbf16x8*>(wrow + g * SH * XLP + (ks - NKR) * 16);
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ring[ks % DEPTH], acc[g], 0, 0, 0);
-                    }
+                    const sbf16x8 a0 = *reinterpret_cast<const sbf16x8*>(wl + arow[0] * X8LP + (ks - NKR) * 16 + 8 * hh);
+                    const sbf16x8 a1 = *reinterpret_cast<const sbf16x8*>(wl + arow[1] * X8LP + (ks - NKR) * 16 + 8 * hh);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ring[ks % DEPTH], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ring[ks % DEPTH], acc[1], 0, 0, 0);
                 }
                 if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(xcur + (ks + DEPTH) * 16 + 8 * hh);
             }
         }
-        // recurrent part
         {
-            constexpr int NK = SH / 16, DEPTH = 4;
-            sbf16x8 ring[DEPTH];
-            const T* hrow = hcur + r * HP;
+            sbf16x8 hf[SH / 16];
 #pragma unroll
-            for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(hrow + i * 16 + 8 * hh);
+            for (int ks = 0; ks < SH / 16; ++ks) hf[ks] = *reinterpret_cast<const sbf16x8*>(hcur + r * HP + ks * 16 + 8 * hh);
 #pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[g][ks], ring[ks % DEPTH], acc[g], 0, 0, 0);
-                if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(hrow + (ks + DEPTH) * 16 + 8 * hh);
+            for (int ks = 0; ks < SH / 16; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][ks], hf[ks], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][ks], hf[ks], acc[1], 0, 0, 0);
             }
         }
-        // the x tile of the next step -> the other buffer (nobody reads it during this step), the one after that requested
-        if (step + 1 < R) land_x(cur ^ 1);
+        if (step + 1 < R) land_x(cur ^ 1);               // the x tile of the next step -> the other buffer (nobody reads it during this step)
         if (step + 2 < R) load_x(step + 2);
         const bool last = step == R - 1;
         const size_t row = (size_t)t * B + bc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int u = 32 * w + 8 * q + 4 * hh;
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
             V4 hb, ib, fb, gb, ob, cb;
             sf32x4 cv, hv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = 4 * q + j;
-                const float ig = sigmoid_acc<T>(acc[0][k]), fg = sigmoid_acc<T>(acc[1][k]), gg = tanh_acc<T>(acc[2][k]), og = sigmoid_acc<T>(acc[3][k]);
+                const int k = 4 * qq + j;
+                const float ig = sigmoid_acc<T>(acc[0][k]), fg = sigmoid_acc<T>(acc[0][8 + k]), gg = tanh_acc<T>(acc[1][k]), og = sigmoid_acc<T>(acc[1][8 + k]);
                 const float cn = fmaf(fg, c[k], ig * gg);
                 const float hn = og * tanh_acc<T>(cn);
                 c[k] = cn;
@@ -485,11 +484,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwdx_kernel(FwdXArgs a) {
             }
             *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
             if (a.gates) {
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 0, q, hh, r)) = ib;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 1, q, hh, r)) = fb;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 2, q, hh, r)) = gb;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 3, q, hh, r)) = ob;
-                *reinterpret_cast<V4*>(a.cs + snative_off(t, nbt, bt, dir, w, 1, 0, q, hh, r)) = cb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 0, q, hh, r)) = ib;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 1, q, hh, r)) = fb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 2, q, hh, r)) = gb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 3, q, hh, r)) = ob;
+                *reinterpret_cast<V4*>(a.cs + snative_off(t, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cb;
             }
             if (ok) {
                 *reinterpret_cast<V4*>(a.out + row * 2 * SH + dir * SH + u) = hb;
@@ -1482,15 +1481,15 @@ int dic_lstm_fwd_xproj(const void* x, const void* wih, const void* whh, const vo
     typedef __bf16 T;
     FwdXArgs a{(const T*)x, (const T*)wih, (const T*)whh, (const T*)bias, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B,
                (state_flags & 1) != 0, (state_flags & 2) != 0, relu_x != 0, (T*)out_r};
-    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)2 * SROWS * XIP + (size_t)S4 * XLP) * sizeof(T) + (size_t)S4 * sizeof(float);
+    const dim3 grid(2 * ((B + 63) / 64), 2);       // 32-row tiles of a batch padded to 64 rows: the tile count dic_lstm_bwd indexes the saved state with
+    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)2 * SROWS * XIP + (size_t)S4 * X8LP) * sizeof(T) + (size_t)S4 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_fwdx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_fwdx8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd_xproj: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
-    const dim3 grid(2 * ((B + 63) / 64), 2);       // 32-row tiles of a batch padded to 64 rows: the tile count dic_lstm_bwd indexes the saved state with
-    hipLaunchKernelGGL(lstm_fwdx_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(lstm_fwdx8_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
     return check_launch("lstm_fwd_xproj");
 }
 

@@ -49,3 +49,7 @@ for k in a:
     d = (a[k].float() - b[k].float()).abs()
     print('%-6s max|a-b| %.3e  mean %.3e  max|a| %.3e' % (k, float(d.max()), float(d.mean()), float(a[k].float().abs().max())))
 print('row_proj + lstm_fwd: %.1f us    lstm_fwd_xproj: %.1f us' % (bench.time_kernel(old, 10) * 1e3, bench.time_kernel(new, 10) * 1e3))
+if os.environ.get('FWDX_NOSAVE'):
+    def nosave():
+        N.check(L.dic_lstm_fwd_xproj(P(x), P(wih), P(whh), P(bias), P(h0), P(c0), R, B, H, I, P(b['out']), None, P(b['hn']), P(b['cn']), None, None, 0, 1, st), 'fwd_xproj')
+    print('lstm_fwd_xproj without the saved state: %.1f us' % (bench.time_kernel(nosave, 10) * 1e3))
