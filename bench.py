@@ -252,6 +252,10 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
         keep2 = (wdec, bdec, w1, b1, zfc, dzfc, sums, dxfc, dw1, ws9, ws10)
         calls['row_proj'] = (lambda: L.dic_row_proj(P(xdec), P(wdec), P(bdec), R * B, 256, 8 * Hh, P(ldgx), B if B % 64 == 0 else 0, 1, st) + 0 * len(keep2),
                              R * B * (256 * 2 + 8 * Hh * 2))                                   # x once; gx out
+        # the decoder's forward as the step runs it: the input projection inside the recurrence kernel (no gx): x read once per direction; h, gates, c out
+        calls['lstm_fwd_xproj'] = (lambda: L.dic_lstm_fwd_xproj(P(xdec), P(wdec), P(whh), P(bdec), None, None, R, B, Hh, 256, P(lout), None, P(lhn), P(lcn),
+                                                                P(lgates), P(lcs), 0, 1, st) + 0 * len(keep2),
+                                   2 * R * B * 256 * 2 + rows * (Hh * 2 + 4 * Hh * 2 + Hh * 2))
         calls['row_proj_stats'] = (lambda: L.dic_row_proj_stats(P(xdec), P(w1), P(b1), R * B, 256, 128, P(zfc), P(sums), P(ws9), ws9.numel(), st),
                                    R * B * (256 * 2 + 128 * 2))                                # x once; z out (+ the column sums)
         calls['fc_bwd'] = (lambda: L.dic_fc_bwd(P(dzfc), P(xdec), P(w1), R * B, 256, 128, P(dxfc), P(dw1), P(ws10), ws10.numel(), st),
@@ -858,7 +862,7 @@ def main():
                       'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': ('dic::lstm_fwd8_gxn_kernel', 'dic::lstm_fwd_kernel'),
                       'lstm_fwd_proj': ('dic::lstm_fwd8_proj_kernel', 'dic::lstm_fwd_kernel'), 'lstm_bwd': ('dic::lstm_bwd8_kernel', 'dic::lstm_bwd_kernel'), 'lstm_dw': 'dic::lstm_dw_kernel',
                       'row_proj': 'dic::row_proj_kernel', 'row_proj_stats': 'dic::row_proj_kernel', 'fc_bwd': 'dic::fc_bwd_kernel',
-                      'lstm_dw_wide': 'dic::lstm_dw_wide_kernel'}
+                      'lstm_dw_wide': 'dic::lstm_dw_wide_kernel', 'lstm_fwd_xproj': 'dic::lstm_fwdx8_kernel'}
         kernels = groups = None
         ran = [0]
 
