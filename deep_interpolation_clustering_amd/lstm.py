@@ -45,7 +45,7 @@ RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B sw
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
 REC_PROJ = os.environ.get('DIC_REC_PROJ', '1') != '0'                  # (A/B switch: 0 = dic_gemm_nt + dic_lstm_rec_fwd for the encoder's small-batch forward)
 FWD_XPROJ = os.environ.get('DIC_FWD_XPROJ', '1') != '0'                # (A/B switch: 0 = dic_row_proj + dic_lstm_fwd for the decoder's large-batch forward: gx through HBM)
-SMALL_BATCH = 4096             # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
+SMALL_BATCH = int(os.environ.get('DIC_SMALL_BATCH', 4096))      # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
 
 
 def _lstm_ok(lstm):
