@@ -672,6 +672,29 @@ def test_decoder_forward_with_the_projection_inside_tracks_the_gx_path(R, B, ini
         assert err < 3e-2, (k, err)
 
 
+def test_decoder_forward_with_the_projection_inside_without_saved_state(monkeypatch):
+    """The same kernel under no_grad (evaluation passes: no gates / cell states are written, no boundary rows) and with the rectified-output variant
+    (out_r): against the gx path, and relu(out) == out_r."""
+    from deep_interpolation_clustering_amd import lstm as L
+    monkeypatch.setattr(L, 'SMALL_BATCH', 0)
+    torch.manual_seed(11)
+    dev = torch.device('cuda')
+    R, B = 9, 157
+    net = torch.nn.LSTM(2 * H, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, 2 * H, device=dev) * 0.5
+    h0, c0 = torch.randn(B, 2, H, device=dev) * 0.3, torch.randn(B, 2, H, device=dev) * 0.3
+    res = {}
+    for inside in (False, True):
+        monkeypatch.setattr(L, 'FWD_XPROJ', inside)
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            out, (hn, cn) = L.bilstm(x, net, h0, c0, batch_major_state=True, input_rectify=True)
+            outr, _ = L.bilstm(x, net, h0, c0, batch_major_state=True, input_rectify=True, rectified_out=True)
+        assert torch.equal(outr, torch.relu(out))
+        res[inside] = (out.float(), hn, cn)
+    for a_, b_ in zip(res[True], res[False]):
+        torch.testing.assert_close(a_, b_, rtol=0, atol=2.0 ** -6)
+
+
 @pytest.mark.parametrize('mode', ['pipelined64', 'tile32', 'f32'])
 @pytest.mark.parametrize('I,B', [(18, 200), (256, 70)])
 def test_rectified_output_equals_relu_applied_outside(mode, I, B, monkeypatch):
