@@ -499,8 +499,11 @@ def record_loss_deviation(K, dev):
     return out
 
 
-def record_cfg4(dev, iters, batch=8192):
-    """BASELINE configs[3] (interp kernel stress): C=12 channels, ~200 observations per channel (T=288), R=24, K=16."""
+def record_cfg4(dev, iters, batch=8192, n_enc=300000, steps=100, warmup=20):
+    """BASELINE configs[3] (interp kernel stress): 300 000 encounters, C=12 channels, ~200 observations per channel (T=288), R=24, K=16.
+    The kernel table runs on one padded batch; the JOINT STEP runs on the configured cohort: a 300 000-encounter ragged store resident in
+    HBM (built on the device, ~6.5 GB; the padded planes would be 16.6 GB), batches of ``batch`` drawn through a per-run randperm over the
+    WHOLE cohort as the reference's shuffling loader does (p1_pretrain_main.py:122-131), ``warmup`` + ``steps`` steps."""
     from deep_interpolation_clustering_amd import synthetic
     from deep_interpolation_clustering_amd.clustering_interp import Net
     C4, T4, LAM4, K4 = 12, 288, 200.0, 16
@@ -511,52 +514,71 @@ def record_cfg4(dev, iters, batch=8192):
     a.num_variables, a.num_timestamps = C4, T4
     net = Net(a, dev).to(dev)
     table = kernel_table(net, x, ob, ln, K4, iters, with_lstm=False)
-    out = {'workload': f'C={C4}, T={T4}, ~{int(LAM4)} obs/channel, R={R}, K={K4}, batch {batch} (300k-encounter cohort streams through in batches)',
-           'kernels': table}
+    out = {'workload': f'{n_enc} encounters, C={C4}, T={T4}, ~{int(LAM4)} obs/channel, R={R}, K={K4}; batches of {batch}', 'kernels_one_padded_batch': table}
+    del x, ob, ln, net, x_np, ob_np, coh
     # the JOINT STEP at this shape (encoder input 3C = 36: 64-wide packed rows through k1 -> fused-projection recurrence -> one-pass dW), bf16 mode,
     # ragged store input; pinned against the reference by tests/test_gpu_traj.py::test_joint_step_wide_shape_K16 (f32) / ..._bf16_tracks_f32
     try:
-        from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore
+        from deep_interpolation_clustering_amd.ragged import RaggedBatch
         from deep_interpolation_clustering_amd.step import Stepper
         from deep_interpolation_clustering_amd.utils import pytorch_optimizer
-        store = RaggedStore(x_np, C4, dev)
-        del x, ob
-        torch.manual_seed(1234)
-        net = Net(a, dev).to(dev)
-        net.train()
-        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), a, autocast_dtype=torch.bfloat16)
-        perm = torch.randperm(batch, device=dev, generator=torch.Generator(device=dev).manual_seed(2)).to(torch.int32)
-        rb = RaggedBatch(store, perm)
-
-        def one(i):
-            return st.step(rb, None, None)
-        for i in range(4):
-            one(i)
-        torch.cuda.synchronize()
-        steps = 20
         t0 = time.perf_counter()
-        for i in range(steps):
-            one(i)
+        store, _ = synthetic.device_cohort_store(n_enc, C4, T4, H, LAM4, K4, 4, dev)
         torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / steps
-        rec = {'per_gpu_batch': batch, 'dtype': 'bf16', 'steps': steps, 'ms_per_step': round(ms, 3), 'encounters_per_s': round(batch / ms * 1e3, 1),
-               'input': 'ragged encounter store, shuffled index'}
-        kernels, groups = step_trace(one, 0, 2)
-        rec['step_trace'] = {'groups': groups, 'top_kernels': dict(list(kernels.items())[:16])}
-        rec['library_gemm_ms'] = groups.get('library_gemm', {}).get('ms_per_step', 0.0)
+        out['cohort'] = {'encounters': store.N, 'store_GB': round(store.nbytes() / 1e9, 2), 'padded_GB': round(store.N * 4 * C4 * T4 * 4 / 1e9, 1),
+                         'mean_obs_per_channel': round(float(store.lengths.float().mean()), 1), 'built_on_device_s': round(time.perf_counter() - t0, 1)}
+        perm = torch.randperm(store.N, device=dev, generator=torch.Generator(device=dev).manual_seed(2)).to(torch.int32)
+        lens = store.lengths.index_select(0, perm.to(torch.int64)).contiguous()
+        nb = store.N // batch
+
+        def run(dtype, precision, n_warm, n_steps):
+            torch.manual_seed(1234)
+            net = Net(a, dev).to(dev)
+            net.train()
+            st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), a, autocast_dtype=dtype, precision=precision)
+
+            def one(i):
+                lo = (i % nb) * batch
+                return st.step(RaggedBatch(store, perm[lo:lo + batch], lens[lo:lo + batch]), None, None)
+            for i in range(n_warm):
+                one(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n_steps):
+                one(n_warm + i)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t1) / n_steps
+            rec = {'per_gpu_batch': batch, 'dtype': 'bf16' if dtype is not None else 'f32' + (precision or ''), 'steps': n_steps, 'warmup': n_warm,
+                   'ms_per_step': round(ms, 3), 'encounters_per_s': round(batch / ms * 1e3, 1),
+                   'input': f'ragged store of {store.N} encounters, batches through a randperm of the whole cohort ({nb} batches per epoch)'}
+            kernels, groups = step_trace(one, n_warm + n_steps, 2)
+            rec['step_trace'] = {'groups': groups, 'top_kernels': dict(list(kernels.items())[:16])}
+            rec['library_gemm_ms'] = groups.get('library_gemm', {}).get('ms_per_step', 0.0)
+            return rec, kernels
+        rec, kernels = run(torch.bfloat16, None, warmup, steps)
         units = 2.0 * R * batch
         dom = max(((v['ms_per_step'], k, v) for k, v in kernels.items() if k.startswith('dic::')), default=None)
         if dom is not None:
             _, k, v = dom
             per_unit = {'dic::lstm_bwd8_kernel': 2560, 'dic::lstm_bwd_kernel': 2560, 'dic::lstm_fwd8_gxn_kernel': 2560, 'dic::lstm_fwd_kernel': 2560,
-                        'dic::lstm_fwd8_proj_kernel': 1536 + 64}.get(k.split('<')[0])
+                        'dic::lstm_fwd8_proj_kernel': 1536 + 128}.get(k.split('<')[0])
             rec['dominant_kernel'] = {'kernel': k, 'ms_per_launch': round(v['us_per_launch'] / 1e3, 4), 'launches_per_step': v['launches_per_step']}
             if per_unit:
                 nb_ = units * per_unit
                 rec['dominant_kernel'].update({'algorithmic_bytes_per_launch': int(nb_), 'frac_hbm_peak': round(nb_ / (v['us_per_launch'] / 1e3) / 1e6 / HBM_PEAK_GBS, 4)})
+        # k1 / k2 inside the step, on batches that do NOT sit in the Infinity Cache from the previous step (algorithmic bytes: SURVEY.md 8d, this batch's mean lengths)
+        nsum = float(lens[:batch].sum())
+        alg = {'dic::sci_cci_fwd_kernel': 8 * nsum + 4 * batch * C4 + 12 * batch * C4 * R, 'dic::rbf_fwd_row_kernel': 12 * nsum + 4 * batch * C4 * R,
+               'dic::rbf_bwd_slot_kernel': 8 * nsum + 8 * batch * C4 * R, 'dic::sci_cci_bwd_kernel': 8 * nsum + 24 * batch * C4 * R}
+        rec['interp_kernels_in_step'] = {k.split('dic::')[1]: {'ms': round(v['us_per_launch'] / 1e3, 4), 'algorithmic_bytes': int(alg[k.split('<')[0]]),
+                                                               'frac_hbm_peak': round(alg[k.split('<')[0]] / (v['us_per_launch'] / 1e3) / 1e6 / HBM_PEAK_GBS, 4)}
+                                         for k, v in kernels.items() if k.split('<')[0] in alg}
         out['step'] = rec
+        x3, _ = run(None, 'x3', 5, 20)
+        out['step']['f32x3'] = {k: x3[k] for k in ('ms_per_step', 'encounters_per_s', 'library_gemm_ms', 'steps', 'warmup')}
+        out['step_f32x3_trace'] = x3['step_trace']
     except Exception as e:
-        out['step'] = {'error': repr(e)[:300]}
+        out.setdefault('step', {})['error'] = repr(e)[:300]
     return out
 
 
@@ -647,8 +669,13 @@ def record_cfg5(dev, sweep=True):
                                                                 'padding_mask': np.ones((m, 1, 1), np.float32)})
             a = p2.get_arguments(['--k_max', '20', '--n_init', '10', '--gap_b', '10'])
             a.restore_metric = ['ae_mse']
+            import logging
+            logging.disable(logging.INFO)        # (the sweep logs a line per K: stderr stays short for the driver's tail)
             t0 = time.perf_counter()
-            res = p2.main(a)['ae_mse']
+            try:
+                res = p2.main(a)['ae_mse']
+            finally:
+                logging.disable(logging.NOTSET)
             out['p2_sweep'] = {'seconds': round(time.perf_counter() - t0, 2), 'k_range': '2..20', 'n_init': 10, 'gap_b': 10,
                                'k_by_gap': int(res['gap_sts']['k'][res['gap_sts']['gap'].idxmax()]),
                                'k_by_silhouette': int(res['gap_sts']['k'][res['gap_sts']['Sihouette'].idxmax()])}
@@ -737,6 +764,69 @@ def cpu_baseline(K, seconds, B=256, threads=None, max_steps=200, all_cores=False
                          'repeat / log / exp sequence): if anything FASTER than the reference\'s own modules on the same cores',
             'sample': f'{n} joint steps of B={B} (C={C}, T={T}, R={R}, K={K}, f32) on torch-CPU, {el:.1f} s',
             'ms_per_step': round(1e3 * el / n, 2)}
+
+
+CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+CONTRACT_MAX_CHARS = 4096
+SECONDARY_FILE = 'bench_secondary.json'
+
+
+def _finite(o):
+    """JSON has no NaN / Infinity: non-finite floats become None (json.dumps(..., allow_nan=False) then never raises)."""
+    if isinstance(o, float):
+        return o if o == o and abs(o) != float('inf') else None
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, (np.floating, np.integer)):
+        return _finite(o.item())
+    return o
+
+
+def contract_line(out):
+    """The ONE stdout line of the bench contract: exactly CONTRACT_KEYS, compact (< CONTRACT_MAX_CHARS: the driver keeps a bounded tail of
+    stdout and parses this line out of it -- round 4's 22 KB line was cut), strict JSON.  Everything else goes to SECONDARY_FILE / stderr."""
+    line = json.dumps(_finite({k: out.get(k) for k in CONTRACT_KEYS}), allow_nan=False, separators=(', ', ': '))
+    if len(line) >= CONTRACT_MAX_CHARS:        # never lose the line to a verbose sub-record: drop the optional detail, keep the contract fields
+        slim = {k: out.get(k) for k in CONTRACT_KEYS}
+        slim['roofline'] = {k: v for k, v in (out.get('roofline') or {}).items() if k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
+        slim['cpu_baseline'] = {k: v for k, v in (out.get('cpu_baseline') or {}).items() if k in ('value', 'unit', 'cores', 'kind', 'sample')}
+        slim['config'] = {k: (v[:200] if isinstance(v, str) else v) for k, v in (out.get('config') or {}).items()}
+        line = json.dumps(_finite(slim), allow_nan=False, separators=(', ', ': '))
+    assert len(line) < CONTRACT_MAX_CHARS and '\n' not in line, len(line)
+    json.loads(line)
+    return line
+
+
+class Secondary:
+    """The records beside the contract line (kernel table, step trace, batch sweep, f32 / f32x3 steps, configs[3] / [4] ...): kept in one JSON file
+    (rewritten after every record, so a later failure cannot cost the earlier ones) under the repo root and, when there is one, gpurun_out/;
+    each record also goes to stderr as one line, cut to a bounded length."""
+
+    def __init__(self, headline):
+        self.doc = {'headline': _finite(headline)}
+        self.paths = [os.path.join(ROOT, SECONDARY_FILE)]
+        if os.path.isdir(os.path.join(ROOT, 'gpurun_out')):
+            self.paths.append(os.path.join(ROOT, 'gpurun_out', SECONDARY_FILE))
+        self.flush()
+
+    def add(self, key, rec, echo=True):
+        self.doc[key] = _finite(rec)
+        self.flush()
+        if echo:
+            txt = json.dumps({key: self.doc[key]}, allow_nan=False)
+            log(txt if len(txt) <= 1500 else txt[:1500] + f' ... ({len(txt)} chars: see {SECONDARY_FILE})')
+
+    def flush(self):
+        for p in self.paths:
+            try:
+                with open(p + '.tmp', 'w') as f:
+                    json.dump(self.doc, f, allow_nan=False)
+                os.replace(p + '.tmp', p)
+            except OSError as e:
+                log('cannot write', p, repr(e))
 
 
 def log(*msg):
@@ -926,64 +1016,72 @@ def main():
                                'note': 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of a separate run, scaled by batch; not measured in this run'}
         custom_ms = sum(per_step.values())
         gflop = FLOP_PER_ENCOUNTER * a.batch / 1e9
-        out = {
-            'metric': 'encounters/sec per joint interp+DEC step', 'value': round(value, 1), 'unit': 'encounters/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
-            'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
-            'dtype': a.dtype, 'dtype_note': {'bf16': 'HIP kernels compute in f32; bf16 = torch.autocast for the bi-LSTMs / FC heads only '
-                                                     '(outside the 1e-5 parity configuration: see loss_rel_dev_vs_oracle; the f32 / f32x3 records carry the parity-grade rates)',
-                                             'f32': 'every tensor and product f32: exact-f32 MFMA recurrence, f32 library GEMMs (the 1e-5 parity configuration of the tests)',
-                                             'f32x3': 'every tensor f32; every dense product a three-term bf16 split (hi.hi + lo.hi + hi.lo) on the bf16 matrix cores '
-                                                      'with f32 accumulation: no library GEMM; losses within 1e-5 of the reference (loss_rel_dev_vs_oracle)'}[a.dtype],
-            'data': 'synthetic',
-            'config': {'workload': (f'{n_enc} of ONE {max(a.encounters, a.batch * world)}-encounter synthetic cohort per GPU' if strong else f'{n_enc} synthetic encounters/GPU') +
-                                   ', 6 vitals, ~50 irregular samples per channel per 24h '
-                                   f'(T={T}), R={R}, K={K}, loss ' + ('ae_mse+fake_detect+10*kl' if a.fake_detection else 'ae_mse+10*kl'), 'per_gpu_batch': a.batch,
-                       'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single',
-                       'tuned_gemm_table': bool(gemm_table),
-                       'index_order': 'shuffled (a per-run randperm of the cohort, as the trainers\' DeviceLoader draws batches)' if shuffled else 'file order (contiguous rows)',
-                       'input': 'padded (B,4C,T) batches' if store is None else
-                                f'ragged encounter store read in place ({store.nbytes() / 1e6:.0f} MB resident; the padded array would be {n_enc * 4 * C * T * 4 / 1e6:.0f} MB)'},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': round(dom_gbps, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(dom_gbps / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-                         'ms_per_launch': round(dom_ms, 5), 'ms_per_step': round(per_step[dom], 4),
-                         'algorithmic_bytes_per_launch': table[dom]['algorithmic_bytes'],
-                         'duration_source': 'in-step: per-dispatch durations of this kernel in a trace of the timed step' if dom in in_step_ms
-                                            else 'stand-alone HIP events (no step trace available)',
-                         'frac_standalone': table[dom]['frac_hbm_peak'], 'ms_per_launch_standalone': table[dom]['ms'],
-                         'chosen_by': 'launches per step x in-step duration (trace of the timed step)',
-                         'note': 'frac = algorithmic bytes per launch / the duration this kernel has INSIDE the timed step (per-dispatch GPU timestamps); '
-                                 'frac_standalone = HIP events around back-to-back launches on an otherwise idle chip.  With DIC_DW_SIDE_STREAM=1 '
-                                 '(round 2 default, now off: measured slower) the encoder-side launch shares the chip with lstm_dw_wide and the in-step figure drops'},
-            'kernels': table,
-            'whole_step': {'gflop_per_step_dense(lstm+fc, fwd+bwd)': round(gflop, 1), 'tflops': round(gflop / ms, 1),
-                           'frac_bf16_mfma_peak(2500 TF)': round(gflop / ms / 2500.0, 4),
-                           'hip_kernels_ms(table x launches)': round(custom_ms, 3)},
-            'final_loss': final_loss,
-        }
+        workload = ((f'{n_enc} of ONE {max(a.encounters, a.batch * world)}-encounter synthetic cohort per GPU' if strong else f'{n_enc} synthetic encounters/GPU') +
+                    f', 6 vitals, ~50 irregular samples per channel per 24h (T={T}), R={R}, K={K}, loss ' +
+                    ('ae_mse+fake_detect+10*kl' if a.fake_detection else 'ae_mse+10*kl') + ' [BASELINE.json configs[' + ('2' if K == 8 else '1') + ']]')
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(dom_gbps, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(dom_gbps / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'ms_per_launch': round(dom_ms, 5), 'launches_per_step': round(per_step[dom] / dom_ms, 2) if dom_ms else None,
+                    'algorithmic_bytes_per_launch': table[dom]['algorithmic_bytes'],
+                    'duration_source': 'in-step per-dispatch GPU timestamps (trace of the timed step)' if dom in in_step_ms else 'stand-alone HIP events',
+                    'traffic_source': (f"{traffic_src['from_profile']} (rocprofv3 --pmc, round {traffic_src['profile_round']}, scaled by batch)" if traffic_src else None)}
+        roofline_detail = {'frac_standalone': table[dom]['frac_hbm_peak'], 'ms_per_launch_standalone': table[dom]['ms'], 'ms_per_step': round(per_step[dom], 4),
+                           'chosen_by': 'launches per step x in-step duration (trace of the timed step)', 'traffic_source': traffic_src,
+                           'note': 'frac = algorithmic bytes per launch / the duration this kernel has INSIDE the timed step (per-dispatch GPU timestamps); '
+                                   'frac_standalone = HIP events around back-to-back launches on an otherwise idle chip'}
         if a.dtype != 'bf16' and kernels is not None:       # the f32 modes run the 32-row recurrence kernels: their own roofline
             rl = f32_roofline(kernels, a.batch, 'x3' if a.dtype == 'f32x3' else 'exact')
             if rl:
-                out['roofline'] = rl
+                roofline_detail = {'full': rl}
+                roofline = {k: rl[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'ms_per_launch', 'launches_per_step',
+                                               'algorithmic_bytes_per_launch', 'frac_hbm', 'frac_mfma')}
+        out = {
+            'metric': 'encounters/sec per joint interp+DEC step', 'value': round(value, 1), 'unit': 'encounters/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': workload, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'index_order': 'shuffled' if shuffled else 'file order',
+                       'input': 'padded (B,4C,T) batches' if store is None else f'ragged encounter store read in place ({store.nbytes() / 1e6:.0f} MB resident)'},
+            'roofline': roofline,
+            'cpu_baseline': None,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(K, a.cpu_seconds)
+        # ---- the contract line: the ONLY thing this program writes to stdout, written before any secondary record runs
+        print(contract_line(out), flush=True)
+
+        sec = Secondary(out)
+        sec.add('dtype_note', {'bf16': 'HIP kernels compute in f32; bf16 = torch.autocast for the bi-LSTMs / FC heads only '
+                                       '(outside the 1e-5 parity configuration: see loss_rel_dev_vs_oracle; the f32 / f32x3 records carry the parity-grade rates)',
+                               'f32': 'every tensor and product f32: exact-f32 MFMA recurrence, f32 library GEMMs',
+                               'f32x3': 'every tensor f32; every dense product a three-term bf16 split (hi.hi + lo.hi + hi.lo) on the bf16 matrix cores '
+                                        'with f32 accumulation: no library GEMM; losses within 1e-5 of the reference (loss_rel_dev_vs_oracle)'}[a.dtype], echo=False)
+        sec.add('config_detail', {'tuned_gemm_table': bool(gemm_table), 'padded_array_MB': round(n_enc * 4 * C * T * 4 / 1e6),
+                                  'index_order': 'shuffled (a per-run randperm of the cohort, as the trainers\' DeviceLoader draws batches)' if shuffled
+                                                 else 'file order (contiguous rows)'}, echo=False)
+        sec.add('roofline_detail', roofline_detail, echo=False)
+        sec.add('kernels', table, echo=False)
+        whole = {'gflop_per_step_dense(lstm+fc, fwd+bwd)': round(gflop, 1), 'tflops': round(gflop / ms, 1),
+                 'frac_bf16_mfma_peak(2500 TF)': round(gflop / ms / 2500.0, 4), 'hip_kernels_ms(table x launches)': round(custom_ms, 3), 'final_loss': final_loss}
         if groups is not None:
-            out['step_trace'] = {'groups': groups, 'top_kernels': dict(list(kernels.items())[:24]),
-                                 'kernel_ms_per_step': round(sum(g['ms_per_step'] for g in groups.values()), 3),
-                                 'launches_per_step': round(sum(g['launches_per_step'] for g in groups.values()), 1)}
+            sec.add('step_trace', {'groups': groups, 'top_kernels': dict(list(kernels.items())[:24]),
+                                   'kernel_ms_per_step': round(sum(g['ms_per_step'] for g in groups.values()), 3),
+                                   'launches_per_step': round(sum(g['launches_per_step'] for g in groups.values()), 1)}, echo=False)
             gg = groups.get('library_gemm')
             if gg:
-                out['whole_step']['library_gemm_ms'] = gg['ms_per_step']
+                whole['library_gemm_ms'] = gg['ms_per_step']
         st_file = os.path.join(ROOT, 'profiles', 'step_traffic.json')
         if os.path.exists(st_file):
             sj = json.load(open(st_file))
             if 'total_bytes' in sj:
                 gb = sj['total_bytes'] * a.batch / sj.get('_batch', 32768) / 1e9
-                out['whole_step']['hbm_traffic'] = {'GB_per_step': round(gb, 2), 'TBps_over_step': round(gb / ms, 3), 'from_profile': 'profiles/step_traffic.json',
-                                                    'profile_round': sj.get('_round')}
-        if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(K, a.cpu_seconds)
-            if not a.no_secondary:        # the other two points of SURVEY.md 8d's CPU comparison, a few seconds each
-                out['cpu_baseline_more'] = [guarded(cpu_baseline, K, 6.0, 256, 8, 60), guarded(cpu_baseline, K, 8.0, 2048, None, 12),
-                                            guarded(cpu_baseline, K, 8.0, 2048, None, 6, True)]      # every core the process may use (count stated; capped by the cgroup quota and at 64)
+                whole['hbm_traffic'] = {'GB_per_step': round(gb, 2), 'TBps_over_step': round(gb / ms, 3), 'from_profile': 'profiles/step_traffic.json',
+                                        'profile_round': sj.get('_round')}
+        sec.add('whole_step', whole)
+        if world == 1 and not a.no_cpu_baseline and not a.no_secondary:
+            # the other points of SURVEY.md 8d's CPU comparison, a few seconds each (the last: every core the process may use, capped by the cgroup quota and at 64)
+            sec.add('cpu_baseline_more', [guarded(cpu_baseline, K, 6.0, 256, 8, 60), guarded(cpu_baseline, K, 8.0, 2048, None, 12),
+                                          guarded(cpu_baseline, K, 8.0, 2048, None, 6, True)])
         if world == 1 and not a.no_secondary:
             del stepper
             torch.cuda.empty_cache()
@@ -994,12 +1092,10 @@ def main():
                 n2 = Net(args, dev).to(dev)
                 n2.train()
                 return Stepper(n2, opt_f, args, autocast_dtype=dtype, use_graphs=graphs, precision=precision)
-            out['batch256'] = guarded(record_small_batch, lambda g: fresh(torch.bfloat16, g), X, OB, LEN)
-            log('batch256 done', out['batch256'])
+            sec.add('batch256', guarded(record_small_batch, lambda g: fresh(torch.bfloat16, g), X, OB, LEN))
             # SURVEY.md 8d's throughput sweep (B = 256, 2 048, 16 384 per GPU; 256 is the record above, the headline is 32 768)
-            out['batch_sweep'] = {str(bs): guarded(record_small_batch, lambda g: fresh(torch.bfloat16, g), X, OB, LEN, bs, st_)
-                                  for bs, st_ in ((2048, 60), (4096, 40), (16384, 20))}
-            log('batch sweep done', out['batch_sweep'])
+            sec.add('batch_sweep', {str(bs): guarded(record_small_batch, lambda g: fresh(torch.bfloat16, g), X, OB, LEN, bs, st_)
+                                    for bs, st_ in ((2048, 60), (4096, 40), (16384, 20))})
             # the f32 step at the headline batch on the headline's input path: the reference's own arithmetic ('exact') and the same tensors with
             # every dense product as a three-term bf16 split on the matrix cores ('x3': the parity-grade throughput record)
             if store is not None:
@@ -1011,18 +1107,20 @@ def main():
                     lo_ = i * a.batch
                     return X[lo_:lo_ + a.batch], OB[lo_:lo_ + a.batch], None, LEN[lo_:lo_ + a.batch]
             for key, products in (('f32x3', 'x3'), ('f32', 'exact')):
-                out[key] = guarded(record_f32, lambda pr: fresh(None, False, pr), f32_batch, nb, a.batch, products)
+                rec = guarded(record_f32, lambda pr: fresh(None, False, pr), f32_batch, nb, a.batch, products)
                 torch.cuda.empty_cache()
-                log(key, 'done', {k: v for k, v in out[key].items() if k in ('ms_per_step', 'encounters_per_s', 'library_gemm_ms', 'roofline', 'error')})
-            out['fake_detection_objective'] = guarded(record_fake_detection, K, dev, X, OB, LEN, a.batch)
-            log('fake-detection objective done', out['fake_detection_objective'])
-            out['loss_rel_dev_vs_oracle'] = guarded(record_loss_deviation, K, dev)
-            log('loss deviation done', out['loss_rel_dev_vs_oracle'])
-            out['cfg4'] = guarded(record_cfg4, dev, a.kernel_iters)
-            log('cfg4 done')
-            out['cfg5'] = guarded(record_cfg5, dev, not a.no_sweep)
-            log('cfg5 done')
-        print(json.dumps(out))
+                sec.add(key, rec, echo=False)
+                log(key, 'done', json.dumps(_finite({k: v for k, v in rec.items() if k in ('ms_per_step', 'encounters_per_s', 'library_gemm_ms', 'error')})))
+            sec.add('fake_detection_objective', guarded(record_fake_detection, K, dev, X, OB, LEN, a.batch))
+            sec.add('loss_rel_dev_vs_oracle', guarded(record_loss_deviation, K, dev))
+            del X, OB
+            torch.cuda.empty_cache()
+            rec = guarded(record_cfg4, dev, a.kernel_iters)
+            sec.add('cfg4', rec, echo=False)
+            log('cfg4 done', json.dumps(_finite({k: v for k, v in rec.get('step', rec).items() if k in ('cohort', 'per_gpu_batch', 'ms_per_step', 'encounters_per_s',
+                                                                                                          'library_gemm_ms', 'dominant_kernel', 'f32x3', 'error')})))
+            sec.add('cfg5', guarded(record_cfg5, dev, not a.no_sweep))
+        log('secondary records:', ', '.join(sec.paths))
     elif world > 1:
         # rank 0 traces TRACE_STEPS more optimisation steps for the roofline record: a sharded step is full of collectives (loss
         # sums, BatchNorm moments, the gradient bucket), so every rank has to run them with it or rank 0 waits forever

@@ -152,6 +152,17 @@ class DataSet(Dataset):
         return fake
 
 
+def _same_device(a, b):
+    """'cuda' and 'cuda:0' name the same card when 0 is the current device: compare with the index filled in."""
+    a, b = torch.device(a), torch.device(b)
+    if a.type != b.type:
+        return False
+    if a.type != 'cuda':
+        return True
+    cur = torch.cuda.current_device() if (a.index is None or b.index is None) else 0
+    return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
+
+
 class DeviceLoader:
     """Iterates a ``DataSet`` held in HBM; yields ``(batch_sample, fake_batch_sample)`` dicts of device tensors.
 
@@ -171,7 +182,7 @@ class DeviceLoader:
         self.ds, self.batch_size, self.shuffle, self.device, self.drop_last = ds, int(batch_size), shuffle, device, drop_last
         self.C = ds.num_features
         if store is not None:
-            if store.N != len(ds) or store.C != self.C or torch.device(store.device) != torch.device(device):
+            if store.N != len(ds) or store.C != self.C or not _same_device(store.t_pk.device, device):
                 raise ValueError('DeviceLoader(store=...): the store does not belong to this dataset / device')
             use_store = True
         else:

@@ -153,6 +153,42 @@ def init_from_env(backend=None):
     return rk, ws, lr
 
 
+def launch_ranks(n_ranks, module, argv):
+    """Start ``n_ranks`` ranks of ``python -m <module> <argv>`` through ``torch.distributed.run`` (one process per GPU, 127.0.0.1 rendezvous on a
+    free port) as CHILD processes and return their exit code.  The caller must not have touched the GPU: it only waits (replacing a process
+    that has initialised HIP takes the machine down on this pool, and a parent holding the card would be one process too many on it)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={int(n_ranks)}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), '-m', module] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def ranks_for_num_gpus(num_gpus, module, argv):
+    """The reference's multi-GPU entry is ``python p1_pretrain_main.py --num_gpus N`` -> ``DataParallel(device_ids=range(N))`` in ONE process
+    (p1_pretrain_main.py:27,118; pretrain_trainer.py:21; clustering_trainer.py:25).  Here N GPUs are N processes, so a driver started that way
+    starts its own ranks: returns the children's exit code when this process was the launcher (the caller exits with it), None when this
+    process is a rank (or a single-GPU / CPU run) and should go on.  A launcher's WORLD_SIZE that contradicts an explicit ``--num_gpus N``
+    (N > 1) is an error; under a launcher with the default ``--num_gpus 1`` the world size is the launcher's."""
+    import sys
+    ws = os.environ.get('WORLD_SIZE')
+    if ws is None:
+        if num_gpus > 1:
+            print(f'[dist] --num_gpus {num_gpus}: starting {num_gpus} ranks of {module} through torch.distributed.run', file=sys.stderr, flush=True)
+            return launch_ranks(num_gpus, module, sys.argv[1:] if argv is None else argv)
+        return None
+    if num_gpus > 1 and int(ws) != num_gpus:
+        raise SystemExit(f'--num_gpus {num_gpus} but WORLD_SIZE={ws}: start {module} either plainly with --num_gpus N (it launches its own ranks) '
+                         f'or under torch.distributed.run with --nproc-per-node equal to --num_gpus')
+    return None
+
+
 def shard_bounds(n, rk=None, ws=None):
     """Contiguous shard [lo, hi) of n items for this rank (rank r gets rows [r*n/P, (r+1)*n/P))."""
     rk = rank() if rk is None else rk

@@ -3,7 +3,8 @@
     cd <run dir>;  python -m deep_interpolation_clustering_amd.p1_pretrain_main --mode train [...]
 
 Reads ../Data/model_data/split_processed/<cohort>.pickle, writes Results/Pretrain/{weight,summary,out_feat}.
-With several GPUs launch it under torchrun: one process per GPU, encounters sharded per batch.
+Several GPUs: ``--num_gpus N`` as upstream (p1_pretrain_main.py:27,118) -- the driver then starts its own N ranks, one process per GPU, encounters
+sharded per batch -- or under ``python -m torch.distributed.run --nproc-per-node N -m ...``.
 """
 import os
 import random
@@ -46,7 +47,10 @@ def main(args):
     exp_path = os.path.join(os.getcwd(), 'Results', 'Pretrain')
     os.makedirs(exp_path, exist_ok=True)
     logger.info('Root directory for saving and loading experiments: {}'.format(exp_path))
-    device = torch.device('cuda', local) if args.num_gpus > 0 else torch.device('cpu')
+    # (LOCAL_RANK modulo the visible cards: under DIC_DIST_BACKEND=gloo several ranks may share one GPU -- the rehearsal of the N > 1 path on a 1-GPU box)
+    device = torch.device('cuda', local % max(1, torch.cuda.device_count())) if args.num_gpus > 0 else torch.device('cpu')
+    if world > 1:
+        logger.info('rank {} of {} on {} ({}): encounters of every batch are sharded over the ranks'.format(rank, world, device, dist.td.get_backend()))
     model = Net(args, device=device)
     dl_dict, n_train = build_loaders(args, device)
     n_param = count_parameters(model)
@@ -61,5 +65,15 @@ def main(args):
             trainer.eval(cohort, generate_feat=True, viz_feat=True, denoise=False)
 
 
+def cli(argv=None):
+    """``python -m ...p1_pretrain_main --num_gpus N``: N > 1 without a launcher around it starts the N ranks itself (before anything here touches
+    the GPU) and relays their exit code; a rank -- or a single-GPU run -- goes straight to ``main``."""
+    args = get_arguments(argv)
+    code = dist.ranks_for_num_gpus(args.num_gpus, __spec__.name if __spec__ else 'deep_interpolation_clustering_amd.p1_pretrain_main', argv)
+    if code is not None:
+        raise SystemExit(code)
+    main(args)
+
+
 if __name__ == '__main__':
-    main(get_arguments())
+    cli()

@@ -89,3 +89,32 @@ def latent_blobs(seed, N, D, K, centers_seed=None, spread=0.35, noise=0.25):
     comp = rng.integers(0, K, N)
     X = (cent[comp] + rng.normal(0, noise, (N, D))).astype(np.float32)
     return X, comp
+
+
+def device_cohort_store(n_enc, C, T, H, lam, G, seed, device, chunk=16384, scale=5.0):
+    """A whole synthetic cohort as a ``RaggedStore`` resident on ``device`` WITHOUT ever holding its padded planes on the host: the same
+    generative rule as ``make_cohort`` / ``stacked_batch`` (Poisson lengths, sorted U(0,H) times in a prefix, phenotype mean + diurnal sine +
+    noise clipped to [0,1] and rescaled to +-scale/2, 20 % hold-out flags), drawn chunk by chunk from a torch generator on the device
+    (other draws than ``make_cohort``'s NumPy stream, same distribution).  BASELINE configs[3] -- 300 000 encounters x 12 channels x ~200
+    observations -- is 16.6 GB padded and 6.5 GB as a store.  Returns (store, phenotype (N,) int64 on the device)."""
+    import torch
+
+    from .ragged import RaggedStore
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    mu = torch.as_tensor(np.random.default_rng(SEED).uniform(0.2, 0.8, (G, C)), dtype=torch.float32, device=device)
+    stores, pheno = [], []
+    for lo in range(0, n_enc, chunk):
+        b = min(chunk, n_enc - lo)
+        n = torch.poisson(torch.full((b, C), float(lam), device=device), generator=g).clamp_(1, T)
+        mask = torch.arange(T, device=device)[None, None, :] < n[..., None]
+        t = torch.rand((b, C, T), device=device, generator=g) * H
+        t = torch.where(mask, t, torch.full_like(t, 2 * H)).sort(dim=-1).values * mask
+        ph = torch.randint(0, G, (b,), device=device, generator=g)
+        phi = torch.rand((b, 1, 1), device=device, generator=g) * (2 * np.pi)
+        val = mu[ph][:, :, None] + 0.10 * torch.sin(2 * np.pi * t / 24.0 + phi) + 0.05 * torch.randn((b, C, T), device=device, generator=g)
+        val = (scale * val.clamp_(0.0, 1.0) - scale / 2) * mask
+        hold = ((torch.rand((b, C, T), device=device, generator=g) >= 0.2) & mask).float()
+        stores.append(RaggedStore.from_device(torch.cat([val, mask.float(), t, hold], dim=1), C))
+        pheno.append(ph)
+        del val, mask, t, hold
+    return (stores[0] if len(stores) == 1 else RaggedStore.concat(stores)), torch.cat(pheno)

@@ -476,6 +476,43 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert bad.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in bad.stderr
 
 
+def test_driver_with_num_gpus_starts_its_own_ranks(tmp_path):
+    """``python -m ...p1_pretrain_main --num_gpus 2`` with NO launcher around it -- upstream's multi-GPU entry (p1_pretrain_main.py:27,118 ->
+    DataParallel over N devices, pretrain_trainer.py:21).  Here N GPUs are N processes: the driver starts its own two ranks (over gloo they
+    share the test GPU), both log their shard, rank 0 writes ONE complete feature dump; p3 the same way from that checkpoint; a launcher
+    environment that contradicts --num_gpus is an error."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    from deep_interpolation_clustering_amd import synthetic
+    base = str(tmp_path)
+    synthetic.write_split(base, 300, C=6, T=96, H=24.0, lam=50.0, G=4)
+    run = os.path.join(base, 'run')
+    os.makedirs(run)
+    env = dict(os.environ, DIC_DIST_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    common = [a for a in COMMON if a not in ('WARNING',)]
+    common[common.index('--log-level') + 1:common.index('--log-level') + 1] = ['INFO']
+    cmd = [sys.executable, '-m', 'deep_interpolation_clustering_amd.p1_pretrain_main', '--num_gpus', '2'] + common + \
+          ['--mode', 'train', '--max_epochs', '2', '--loss', 'ae_mse']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=run)
+    assert res.returncode == 0, res.stderr[-3000:]
+    log = res.stdout + res.stderr
+    assert 'starting 2 ranks' in log and 'rank 0 of 2' in log and 'rank 1 of 2' in log, log[-3000:]
+    for cohort, n in (('training', 240), ('validation', 30), ('testing', 30)):
+        d = np.load(os.path.join(run, f'Results/Pretrain/out_feat/ae_mse/{cohort}.npy'), allow_pickle=True).item()
+        assert d['hidden'].shape == (n, 256) and len(set(d['encounter_id'].tolist())) == n and np.isfinite(d['hidden']).all()
+    cmd3 = [sys.executable, '-m', 'deep_interpolation_clustering_amd.p3_clustering_main', '--num_gpus', '2'] + common + \
+           ['--mode', 'train', '--max_epochs', '2', '--loss', 'ae_mse_kl', '--cluster_number', '4']
+    res = subprocess.run(cmd3, env=env, capture_output=True, text=True, timeout=280, cwd=run)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert 'rank 1 of 2' in res.stdout + res.stderr
+    d = np.load(os.path.join(run, 'Results/Clustering/out_feat/ae_mse/training.npy'), allow_pickle=True).item()
+    assert d['hidden'].shape == (240, 256) and d['cluster_pred'].shape == (240, 4)
+    bad = subprocess.run(cmd, env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=120, cwd=run)
+    assert bad.returncode != 0 and '--num_gpus 2 but WORLD_SIZE=1' in bad.stderr
+
+
 def test_sharded_paths_on_rccl_with_one_rank(tmp_path):
     """The box has one GPU, and RCCL wants one GPU per rank: so ONE rank joins a `nccl` process group (dist.init_from_env as on a real
     node: device_id, current device) with DIC_DIST_SINGLE_RANK=1, which makes that world count as sharded.  Every collective of the

@@ -43,3 +43,111 @@ def test_gap_stream_walker_deals_problems_and_replicates_the_stream():
         assert rank == j % 2
         assert (u is None and buf is None) or np.array_equal(u, buf)
         assert np.array_equal(first, f)
+
+
+def test_bench_contract_line_is_compact_strict_json():
+    """bench.py's ONE stdout line: exactly the contract keys, < 4 KB, strict JSON (no NaN / Infinity) whatever the sub-records hold -- round 4's
+    22 KB line was cut by the driver's bounded stdout tail and never parsed."""
+    import json
+
+    import bench
+    roof = {'bound': 'hbm', 'kernel': 'lstm_bwd', 'achieved': 5378.1, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 0.6723, 'traffic': 4098000000,
+            'ms_per_launch': 0.74885, 'launches_per_step': 2.0, 'algorithmic_bytes_per_launch': 4026531840,
+            'duration_source': 'in-step per-dispatch GPU timestamps (trace of the timed step)', 'traffic_source': 'profiles/traffic.json (...)'}
+    cpu = {'value': 2011.3, 'unit': 'encounters/s', 'cores': 16, 'kind': 'port', 'cpu_model': 'AMD EPYC 9575F 64-Core Processor', 'cores_available': 256,
+           'cpu_quota_cores': 16, 'port_note': 'x' * 300, 'sample': '118 joint steps of B=256 (C=6, T=96, R=24, K=4, f32) on torch-CPU, 15.0 s', 'ms_per_step': 127.3}
+    out = {'metric': 'encounters/sec per joint interp+DEC step', 'value': 5710000.0, 'unit': 'encounters/s', 'n_gpus': 1, 'steps': 100, 'warmup': 20,
+           'ms_per_step': 5.742, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+           'config': {'workload': '75000 synthetic encounters/GPU, 6 vitals, ...', 'per_gpu_batch': 32768, 'global_batch': 32768, 'parallelism': 'single',
+                      'index_order': 'shuffled', 'input': 'ragged encounter store read in place (208 MB resident)'},
+           'roofline': roof, 'cpu_baseline': cpu, 'kernels': {'k%d' % i: {'ms': 0.1} for i in range(400)}, 'final_loss': float('nan')}
+    line = bench.contract_line(out)
+    assert len(line) < 4096 and '\n' not in line
+    d = json.loads(line)
+    assert tuple(d) == bench.CONTRACT_KEYS
+    assert d['roofline']['frac'] == 0.6723 and d['cpu_baseline']['cores'] == 16 and d['config']['per_gpu_batch'] == 32768
+    # non-finite numbers never reach the line; an over-long sub-record is cut down to the contract fields instead of costing the line
+    out['roofline'] = dict(roof, frac=float('inf'), note='y' * 5000)
+    out['ms_per_step'] = float('nan')
+    line = bench.contract_line(out)
+    d = json.loads(line)
+    assert len(line) < 4096 and d['roofline']['frac'] is None and d['ms_per_step'] is None and 'note' not in d['roofline']
+    assert set(d['roofline']) == {'bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+
+
+def test_bench_secondary_records_go_to_a_side_file(tmp_path, monkeypatch, capsys):
+    import json
+
+    import bench
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    sec = bench.Secondary({'value': 1.0})
+    sec.add('cfg4', {'ms': float('nan'), 'big': list(range(2000))})
+    doc = json.load(open(tmp_path / bench.SECONDARY_FILE))
+    assert doc['headline'] == {'value': 1.0} and doc['cfg4']['ms'] is None and len(doc['cfg4']['big']) == 2000
+    cap = capsys.readouterr()
+    assert cap.out == ''                                     # stdout belongs to the contract line alone
+    assert all(len(ln) < 1700 for ln in cap.err.splitlines())
+
+
+def test_ragged_store_built_on_the_device_and_joined_equals_the_host_built_store():
+    """RaggedStore.from_device / concat (cohorts too large to pad on the host) against the constructor on the same planes."""
+    import torch
+
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.ragged import RaggedStore
+    C = 3
+    coh = synthetic.make_cohort(37, C=C, T=20, H=24.0, lam=7.0, G=2, seed=5)
+    x_np, _, _ = synthetic.stacked_batch(coh)
+    ref = RaggedStore(x_np, C, 'cpu')
+    x = torch.tensor(x_np)
+    whole = RaggedStore.from_device(x, C)
+    joined = RaggedStore.concat([RaggedStore.from_device(x[:10].contiguous(), C), RaggedStore.from_device(x[10:11].contiguous(), C),
+                                 RaggedStore.from_device(x[11:].contiguous(), C)])
+    for s in (whole, joined):
+        assert (s.N, s.C, s.T, s.times_sorted) == (ref.N, ref.C, ref.T, ref.times_sorted)
+        for name in ('t_pk', 'v_pk', 'hold_pk', 'row_off', 'lengths', 'pad_value'):
+            a, b = getattr(s, name), getattr(ref, name)
+            assert a.dtype == b.dtype and torch.equal(a, b), name
+        idx = torch.tensor([36, 0, 10, 11, 5])
+        assert torch.equal(s.dense_rows(idx), ref.dense_rows(idx))
+    st, ph = synthetic.device_cohort_store(50, C, 20, 24.0, 7.0, 2, 3, 'cpu', chunk=16)
+    assert st.N == 50 and ph.shape == (50,) and st.times_sorted and int(st.lengths.min()) >= 1
+    assert float(st.v_pk.abs().max()) <= 2.5 and int(st.row_off[-1]) == int(st.lengths.sum())
+
+
+def test_num_gpus_decides_between_launching_ranks_and_being_one(monkeypatch):
+    """dist.ranks_for_num_gpus: upstream's ``--num_gpus N`` (p1_pretrain_main.py:27,118) means N processes here -- a plain start launches them (children
+    through torch.distributed.run; the parent relays the exit code), a rank goes on, a contradicting launcher environment is an error."""
+    import pytest
+
+    from deep_interpolation_clustering_amd import dist
+    calls = []
+    monkeypatch.setattr(dist, 'launch_ranks', lambda n, module, argv: calls.append((n, module, list(argv))) or 7)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    assert dist.ranks_for_num_gpus(1, 'pkg.p1', ['--mode', 'train']) is None and dist.ranks_for_num_gpus(0, 'pkg.p1', []) is None and not calls
+    assert dist.ranks_for_num_gpus(4, 'pkg.p1', ['--num_gpus', '4', '--mode', 'train']) == 7
+    assert calls == [(4, 'pkg.p1', ['--num_gpus', '4', '--mode', 'train'])]
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    assert dist.ranks_for_num_gpus(4, 'pkg.p1', []) is None                     # a rank of the launched job
+    assert dist.ranks_for_num_gpus(1, 'pkg.p1', []) is None                     # under a launcher with the default --num_gpus: the launcher's world
+    with pytest.raises(SystemExit, match='--num_gpus 2 but WORLD_SIZE=4'):
+        dist.ranks_for_num_gpus(2, 'pkg.p1', [])
+    assert len(calls) == 1
+
+
+def test_launch_ranks_command_line(monkeypatch):
+    import subprocess
+    import sys
+
+    from deep_interpolation_clustering_amd import dist
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return subprocess.CompletedProcess(cmd, 3)
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    assert dist.launch_ranks(2, 'pkg.p3', ['--num_gpus', '2']) == 3
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nproc-per-node=2' in cmd and cmd[-4:] == ['-m', 'pkg.p3', '--num_gpus', '2']
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
