@@ -101,4 +101,6 @@ def finalize(args):
         args.fake_detection = False
     if not hasattr(args, 'cluster_number'):
         args.cluster_number = 0
+    if getattr(args, 'amp_bf16', False) and getattr(args, 'f32_products', None) is not None:
+        raise SystemExit('--f32_products selects how the f32 step forms its dense products; it does not combine with --amp_bf16')
     return args

@@ -14,6 +14,9 @@ import threading
 
 import torch
 
+from . import switches
+
+switches.validate()          # unknown DIC_* names / values outside the table raise here, once (switches.py)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DIC_LIB_PATH') or os.path.join(_HERE, 'libdic_hip.so')      # (DIC_LIB_PATH: another build of the library, for A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dic_hip.h')

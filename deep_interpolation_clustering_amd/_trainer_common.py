@@ -34,6 +34,8 @@ class TrainerBase(object):
         self.args, self.device = args, device
         self.model = model.to(device)
         autocast = torch.bfloat16 if (getattr(args, 'amp_bf16', False) and device.type == 'cuda') else None
+        if autocast is not None and getattr(args, 'f32_products', None) is not None:
+            raise ValueError('f32_products selects how the f32 step forms its dense products; it does not combine with amp_bf16')
         if autocast is not None:
             from . import tuned
             tuned.enable()                       # pre-tuned library GEMM picks for the step's shapes (read-only; tuned.py)

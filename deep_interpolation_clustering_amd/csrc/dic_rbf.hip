@@ -678,7 +678,9 @@ __global__ __launch_bounds__(kBlock) void rbf_bwd_slot_kernel(RbfBwdArgs a) {
         const int last = max(n - 1, 0), nchunks = (n + 15) >> 4;
         // exp(-beta u) = exp2(-(sc d)^2), sc = sqrt(beta log2 e): the bandwidth rides on the time stamps (one multiplication per slot and RQ per row
         // instead of one per (slot, grid point)); the two u-weighted sums come out scaled by sc^2 and are scaled back once per row
-        const float sc = __builtin_sqrtf(-nb), unscale = __builtin_amdgcn_rcpf(-nb);
+        // (a bandwidth whose softplus underflows to 0 -- raw parameter below about -100 -- gives sc = 0 and all-zero scaled sums: no rescale then,
+        //  0 * inf would put a NaN into dL/dbeta, whose factor sigmoid(raw) is 0 there anyway)
+        const float sc = __builtin_sqrtf(-nb), unscale = nb < 0.f ? __builtin_amdgcn_rcpf(-nb) : 0.f;
         float refs[RQ];
 #pragma unroll
         for (int j = 0; j < RQ; ++j) refs[j] = sc * ref[j];

@@ -50,39 +50,60 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
         return t
     riders = []
     if _RIDERS and t.numel() <= RIDER_MAX_CARRIER and t.is_contiguous():
-        for r in list(_RIDERS):
+        for entry in list(_RIDERS):
+            r = entry[0]
             if r.device == t.device and (r.dtype == t.dtype or (t.dtype == torch.float64 and r.dtype == torch.float32)):
-                riders.append(r)
-                _RIDERS.remove(r)
+                riders.append(entry)
+                _RIDERS.remove(entry)
     if not riders:
         td.all_reduce(t, op=td.ReduceOp.SUM)
         return t
-    buf = torch.cat([t.reshape(-1)] + [r.reshape(-1).to(t.dtype) for r in riders])
+    buf = torch.cat([t.reshape(-1)] + [r.reshape(-1).to(t.dtype) for r, _ in riders])
     td.all_reduce(buf, op=td.ReduceOp.SUM)
     o = t.numel()
     t.copy_(buf[:o].view_as(t))
-    for r in riders:
+    for r, then in riders:
         r.copy_(buf[o:o + r.numel()].view_as(r))          # (f32 riders on an f64 carrier: summed in f64, rounded once)
         o += r.numel()
+        if then is not None:
+            then()
     return t
 
 
-def deferred_sum_(t: torch.Tensor) -> torch.Tensor:
-    """Queue ``t`` for an in-place sum all-reduce that rides on the next small ``all_reduce_sum_``; ``resolve_sum_(t)`` before reading it."""
-    if is_sharded() and not any(r is t for r in _RIDERS):
-        _RIDERS.append(t)
+def deferred_sum_(t: torch.Tensor, then=None) -> torch.Tensor:
+    """Queue ``t`` for an in-place sum all-reduce that rides on the next small ``all_reduce_sum_``; ``resolve_sum_(t)`` (or ``resolve_all_()``)
+    before reading it.  ``then``: called right after ``t`` holds its global sum (whatever carried it) -- for values derived from it."""
+    if is_sharded() and not any(r is t for r, _ in _RIDERS):
+        _RIDERS.append((t, then))
+    elif not is_sharded() and then is not None:
+        then()
     return t
 
 
 def resolve_sum_(t: torch.Tensor) -> torch.Tensor:
     """``t`` holds its global sum after this call: a rider that found no carrier gets a collective of its own."""
-    for i, r in enumerate(_RIDERS):
+    for i, (r, then) in enumerate(_RIDERS):
         if r is t:
             del _RIDERS[i]
             if is_sharded():
                 td.all_reduce(t, op=td.ReduceOp.SUM)
+            if then is not None:
+                then()
             break
     return t
+
+
+def resolve_all_():
+    """Every pending rider holds its global sum after this call: the ones still waiting travel together in ONE collective per dtype."""
+    while _RIDERS:
+        first = _RIDERS[0][0]
+        if sum(1 for r, _ in _RIDERS if r.dtype == first.dtype and r.device == first.device) > 1 and first.numel() <= RIDER_MAX_CARRIER:
+            r, then = _RIDERS.pop(0)
+            all_reduce_sum_(r)                  # carries the others of its dtype
+            if then is not None:
+                then()
+        else:
+            resolve_sum_(first)
 
 
 def drop_riders():

@@ -361,18 +361,28 @@ class _RbfRecLoss(torch.autograd.Function):
         else:
             N.check(L.dic_rbf_fwd_loss(N.ptr(x), N.ptr(lengths), B, C, T, R, N.ptr(grid), N.ptr(rk), N.ptr(vb), int(tm), N.ptr(obc), N.ptr(y),
                                        N.ptr(norm), 1, N.ptr(out2), N.ptr(ws), ws.numel(), N.stream_of(x)), 'dic_rbf_fwd_loss')
-        dist.all_reduce_sum_(out2)          # global SSE and global #valid slots
+        # global SSE and global #valid slots.  Sharded: the pair does not pay a latency-bound exchange of its own -- it rides on the next small
+        # all-reduce of the step (the KL sum + row count, or the first global-mean loss term: dist.deferred_sum_) and the mean is formed when
+        # it lands; step.compute_losses resolves whatever is still pending before it hands the losses out (one packed buffer)
+        mse = torch.empty((), device=x.device, dtype=torch.float32)
+        if dist.is_sharded():
+            mse_out = mse.detach()
+            dist.deferred_sum_(out2, then=lambda: torch.div(out2[0], out2[1], out=mse_out))
+        else:
+            torch.div(out2[0], out2[1], out=mse)
         ctx.dims = (B, C, T, R, bool(tm))
         ctx.sink_params = (rbf_kernel,)
         ctx.rb = x if store else None
-        ctx.save_for_backward(None if store else x, lengths, grid, rk, vb, y, norm, obc, out2)
+        ctx.out2 = out2                     # (not through save_for_backward: the deferred reduction writes it in place after this forward returns)
+        ctx.save_for_backward(None if store else x, lengths, grid, rk, vb, y, norm, obc)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(y)
-        return y, out2[0] / out2[1]
+        return y, mse
 
     @staticmethod
     def backward(ctx, grad_y, grad_mse):
-        x, lengths, grid, rk, vb, y, norm, obc, out2 = ctx.saved_tensors
+        x, lengths, grid, rk, vb, y, norm, obc = ctx.saved_tensors
+        out2 = ctx.out2
         B, C, T, R, tm = ctx.dims
         if grad_mse is None:
             return None, None, None, None, None, None

@@ -20,7 +20,15 @@ LOSS_NAMES = ('ae_mse', 'ae_mse_sup', 'ae_mse_fake_detect', 'ae_mse_fake_detect_
 
 def compute_losses(model, args, hidden, rec_ob, aux_pred, ob, padding_mask, lengths=None, aux_label_dict=None,
                    future_vital_mask=None, fake_det_label=None):
-    """The loss switch of the trainers (pretrain_trainer.py:196-221, clustering_trainer.py:227-272)."""
+    """The loss switch of the trainers (pretrain_trainer.py:196-221, clustering_trainer.py:227-272).  Sharded: batch statistics queued to ride
+    on a later exchange (the fused reconstruction SSE + count: ops.rbf_rec_loss) have landed when this returns."""
+    try:
+        return _loss_switch(model, args, hidden, rec_ob, aux_pred, ob, padding_mask, lengths, aux_label_dict, future_vital_mask, fake_det_label)
+    finally:
+        dist.resolve_all_()
+
+
+def _loss_switch(model, args, hidden, rec_ob, aux_pred, ob, padding_mask, lengths, aux_label_dict, future_vital_mask, fake_det_label):
     rec = model.rec_loss(ob, rec_ob, padding_mask, lengths)
     name = args.loss
     if name not in LOSS_NAMES:
@@ -69,22 +77,30 @@ class Stepper:
         # hipGraph capture of the whole step (single-GPU): at the reference's batch size (256) the ~250 launches of a
         # step are launch-bound (2.5 ms); one graph replay runs them back to back.
         # 'auto': graphs for batches up to AUTO_GRAPH_BATCH encounters (0.89 against 1.5 ms per step at the reference's B = 256)
-        # Sharded (one process per GPU): RCCL collectives are stream operations and capture with the kernels around them, so an EXPLICIT
-        # use_graphs=True (or DIC_SHARDED_GRAPHS=1 for 'auto') captures the sharded step too -- what a strong-scaled batch of a few
-        # thousand encounters per rank needs, where the step is launch-bound; rehearsed on RCCL with one rank (tests/test_gpu_dist.py),
-        # off by default until it has run on a multi-GPU node.  gloo (CPU-side collectives) cannot be captured.
+        # Sharded (one process per GPU): RCCL collectives are stream operations and capture with the kernels around them, so on the `nccl`
+        # backend 'auto' captures the sharded step too for per-rank batches up to AUTO_GRAPH_BATCH -- what a strong-scaled batch of a few
+        # thousand encounters per rank needs, where the step is launch-bound (4 096 rows: 1.53 ms eager for 1.10 ms of kernels); rehearsed
+        # on RCCL with one rank (tests/test_gpu_dist.py).  DIC_SHARDED_GRAPHS=0 opts out.  gloo (CPU-side collectives) cannot be captured.
         self.auto_graphs = use_graphs == 'auto'
         want = self.auto_graphs or bool(use_graphs)
         if dist.is_sharded():
-            explicit = (use_graphs is True) or (self.auto_graphs and os.environ.get('DIC_SHARDED_GRAPHS') == '1')
-            want = want and explicit and dist.graph_capturable()
+            allowed = (use_graphs is True) or (self.auto_graphs and os.environ.get('DIC_SHARDED_GRAPHS', '1') != '0')
+            want = want and allowed and dist.graph_capturable()
         self.use_graphs = want
         self._graphs = {}
 
     def _ctx(self):
+        """Around the model's forward: autocast (bf16 step) or the f32 step's products mode."""
         if self.autocast_dtype is None:
-            return contextlib.nullcontext() if self.precision is None else ops.f32_products_mode(self.precision)
+            return self._mode()
         return torch.autocast('cuda', dtype=self.autocast_dtype)
+
+    def _mode(self):
+        """The f32 step's products mode ('exact' / 'x3'): entered around the WHOLE step -- forward, the loss operators and the backward --
+        so that an operator consulting ops.f32_products() anywhere on that path sees this Stepper's mode, not the process default."""
+        if self.autocast_dtype is None and self.precision is not None:
+            return ops.f32_products_mode(self.precision)
+        return contextlib.nullcontext()
 
     def forward_loss(self, x, ob, padding_mask, lengths=None, fake_x=None, fake_perm_idx=None, positive_x=None,
                      aux_label_dict=None, future_vital_mask=None, fake_det_label=None):
@@ -189,10 +205,11 @@ class Stepper:
         # ... and with prefix lengths its loss comes out of the de-interpolation kernels themselves (ops.rbf_rec_loss)
         self.model.rec_target = ob if (padding_mask is None and lengths is not None and ob.is_cuda) else None
         try:
-            losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
-            # the small parameter gradients: one add launch for all of them at the end; the decoder's weight-gradient kernel on a side stream
-            with ops.grad_sink_session(), fused_lstm.side_stream_session():
-                losses['loss'].backward()
+            with self._mode():
+                losses, hidden, _, _ = self.forward_loss(x, ob, padding_mask, lengths, **kw)
+                # the small parameter gradients: one add launch for all of them at the end; the decoder's weight-gradient kernel on a side stream
+                with ops.grad_sink_session(), fused_lstm.side_stream_session():
+                    losses['loss'].backward()
         finally:
             dist.drop_riders()
             self.model.internal_step = False

@@ -151,7 +151,7 @@ def _run(rank, world, port, out, rccl=False):
         res.append([float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(losses['kl'].detach()), float(gnorm)])
     td.all_reduce = inner
     torch.save({'traj': np.array(res), 'flat': st.flat.flat.detach().cpu(), 'bn_mean': net.rbf.compress_fc.module.model[1].running_mean.cpu(),
-                'collectives': per_step},
+                'collectives': per_step, 'bucket': [int(st.flat._split or 0), int(st.flat.grad.numel())]},
                os.path.join(out, f'w{world}{"x" if rccl else ""}_r{rank}.pt'))
     _leave()
 
@@ -174,14 +174,18 @@ def test_two_rank_step_equals_single_device(tmp_path):
     assert float(d.max()) < 2e-2 and float((d > 1e-4).float().mean()) < 0.01        # Adam amplifies noise only where grad ~ 0
     # the exchanges of a sharded joint step, bounded by what the data dependencies force (at 4 096 rows per GPU every extra
     # latency-bound exchange is 1-2 % of the step): forward -- BatchNorm moments of CompressFC carrying the DEC column sums f_j (they are
-    # known earlier and needed later: dist.deferred_sum_), the reconstruction SSE + mask count (needs the BatchNorm output), the KL sum +
-    # batch rows (needs f_j); backward -- BatchNorm's two column sums, the gradient bucket in two pieces (the decoder-side piece overlaps
-    # the encoder backward)
+    # known earlier and needed later: dist.deferred_sum_), ONE buffer with the reconstruction SSE + mask count (needs the BatchNorm output)
+    # and the KL sum + batch rows (needs f_j) -- the former waits for the latter; backward -- BatchNorm's two column sums, the gradient
+    # bucket in two pieces (the decoder-side piece overlaps the encoder backward): five
     assert one['collectives'] == [[], [], []]
+    split, total = r0['bucket']
+    assert 0 < split < total
     for step in r0['collectives']:
-        assert len(step) <= 6, step
-        assert sorted(step)[-2:] == sorted(step)[-2:] and sum(1 for n in step if n > 10000) == 2      # two big pieces, the rest small statistics
+        assert len(step) <= 5, step
+        assert sorted(step)[-2:] == sorted([split, total - split]), (step, split, total)                # the gradient bucket in its two pieces; the rest small statistics
+        assert sum(1 for n in step if n > 10000) == 2
         assert any(n == 2 * 128 + 1 + 4 for n in step), step                                            # f_j (K = 4) rode with the 257 BatchNorm sums
+        assert any(n == 2 + 2 for n in step), step                                                      # reconstruction SSE + count rode with the KL sum + row count
 
 
 def _run_cfg3(rank, world, port, out):
@@ -602,4 +606,7 @@ def test_bench_runs_on_rccl_with_one_rank():
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, res.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec['n_gpus'] == 1 and rec['value'] > 0 and np.isfinite(rec['final_loss'])
+    assert rec['n_gpus'] == 1 and rec['value'] > 0 and set(rec) == {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                                                     'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'}
+    side = json.load(open(os.path.join(ROOT, 'bench_secondary.json')))          # everything else goes to the side file
+    assert side['headline']['value'] == rec['value'] and np.isfinite(side['whole_step']['final_loss']) and 'kernels' in side

@@ -734,3 +734,37 @@ def test_interp_full_size_properties(ops, B, C, T, R, H, lam):
         np.testing.assert_allclose(yp[:16].cpu().numpy(), ref.numpy(), rtol=RT, atol=3e-6)
         y2 = ops.rbf_deinterp(v * -3.0, x, kr, grid, lengths=n)
         assert float((y2 + 3.0 * y).abs().max()) <= 2e-6 * float(y.abs().max()) * 3.0
+
+
+@pytest.mark.parametrize('shape', [(64, 6, 96, 24, 24, 50), (9, 12, 288, 24, 24, 200)])
+def test_rbf_backward_with_an_underflowing_bandwidth(ops, shape):
+    """a raw bandwidth parameter so negative that softplus underflows to 0 (beta = 0: every basis function is 1).  The slots-on-lanes
+    backward folds sqrt(beta) into the time stamps and scales its u-weighted sums back by 1 / beta: that must not put 0 * inf = NaN into
+    dL/dbeta (sigmoid(raw) = 0 there, so the parameter gradient is exactly 0), on any backward kernel; the other channels are unaffected."""
+    B, C, T, R, H, lam = shape
+    x, n = vitals_stack(5 + B, B, C, T, H, lam)
+    rng = np.random.default_rng(B)
+    v_np = rng.normal(0, 1, (B, C, R)).astype(np.float32)
+    k_np = rng.uniform(-0.5, 1.5, C).astype(np.float32)
+    k_np[1] = -200.0
+    cot = rng.normal(0, 1, (B, C, T)).astype(np.float32)
+    grid = ops.ref_grid(H, R, 'cuda')
+    res = {}
+    for mode in ('0', '2'):
+        os.environ['DIC_RBF_BWD_SLOT'] = mode
+        try:
+            v, k = G(v_np, True), G(k_np, True)
+            y = ops.rbf_deinterp(v, G(x), k, grid, lengths=G(n, dtype=torch.int32))
+            (y * G(cot)).sum().backward()
+        finally:
+            os.environ.pop('DIC_RBF_BWD_SLOT', None)
+        assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(v.grad).all()) and bool(torch.isfinite(k.grad).all()), mode
+        assert float(k.grad[1]) == 0.0
+        res[mode] = (v.grad.cpu().numpy(), k.grad.cpu().numpy())
+    v64 = torch.tensor(v_np, dtype=torch.float64, requires_grad=True)
+    k64 = torch.tensor(k_np, dtype=torch.float64, requires_grad=True)
+    ref = O.rbf_deinterp(v64, torch.tensor(x, dtype=torch.float64), k64, R, H)
+    (ref * torch.tensor(cot, dtype=torch.float64)).sum().backward()
+    for mode in res:
+        np.testing.assert_allclose(res[mode][0], v64.grad.numpy(), rtol=2e-4, atol=2e-5 * float(v64.grad.abs().max()))
+        np.testing.assert_allclose(res[mode][1], k64.grad.numpy(), rtol=3e-4, atol=3e-5 * float(k64.grad.abs().max()))

@@ -202,3 +202,56 @@ def test_device_loader_on_the_store_yields_what_the_padded_loader_yields(tmp_pat
         assert f is s and set(s) == {'encounter_id', 'lengths', 'ragged'} and s['ragged'].shape == (64, 24, 96)
     finally:
         dataloader.BASE_PATH = old
+
+
+@pytest.mark.parametrize('C,T,R,lam', [(6, 96, 24, 50.0), (12, 288, 24, 200.0)])
+def test_unsorted_and_duplicate_time_stamps_through_the_store(C, T, R, lam):
+    """k1 takes each grid point's nearest sample by BISECTION when the store certifies sorted time stamps (RaggedStore.times_sorted) and by a
+    pass over the row otherwise.  (a) a cohort whose rows are shuffled in time: the store must say so and the store path must
+    equal the dense path bit for bit; (b) a sorted cohort with ties -- duplicated stamps, some of them exactly on a grid point: the
+    bisection and the full pass (flag forced to 0) must agree bit for bit, both with the dense path."""
+    from deep_interpolation_clustering_amd import ops
+    from deep_interpolation_clustering_amd.ragged import RaggedBatch
+    dev = torch.device('cuda')
+    x_np, _, n_np = cohort(53, C, T, lam, seed=8)
+    rng = np.random.default_rng(5)
+    grid = ops.ref_grid(24.0, R, dev)
+    sk = torch.rand(C, device=dev)
+    ck = torch.eye(C, device=dev) + 0.1 * torch.randn(C, C, device=dev)
+    idx = torch.randperm(53, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def both_paths(x, expect_sorted):
+        store = make_store(x, C, dev)
+        assert store.times_sorted is expect_sorted
+        rb = RaggedBatch(store, idx)
+        X = torch.tensor(x, device=dev).index_select(0, idx)
+        LEN = torch.tensor(n_np, device=dev).index_select(0, idx)
+        dense = ops.sci_cci(X, sk, ck, grid, LEN)
+        got = ops.sci_cci(rb, sk, ck, grid)
+        assert torch.equal(dense, got)
+        if ops.packed_width(3 * C):
+            assert torch.equal(ops.sci_cci_packed(X, sk, ck, grid, LEN), ops.sci_cci_packed(rb, sk, ck, grid))
+        return store, rb, got
+    # (a) every row's observed prefix permuted in time (values and hold-out flags travel with their stamps)
+    xs = x_np.copy()
+    for b in range(xs.shape[0]):
+        for c in range(C):
+            n = int(n_np[b, c])
+            p = rng.permutation(n)
+            for plane in (0, 2, 3):
+                xs[b, plane * C + c, :n] = xs[b, plane * C + c, :n][p]
+    both_paths(xs, False)
+    # (b) sorted with ties: every third stamp repeats its predecessor, a few sit exactly on grid points
+    xt = x_np.copy()
+    gridv = np.linspace(0, 24.0, R).astype(np.float32)
+    for b in range(xt.shape[0]):
+        for c in range(C):
+            n = int(n_np[b, c])
+            t = xt[b, 2 * C + c, :n].copy()
+            t[2::3] = t[1:-1:3][:len(t[2::3])]
+            if n > 4:
+                t[n // 2] = gridv[np.abs(gridv - t[n // 2]).argmin()]
+            xt[b, 2 * C + c, :n] = np.sort(t)
+    store, rb, with_bisection = both_paths(xt, True)
+    store.times_sorted = False                                        # the same rows through the full pass
+    assert torch.equal(ops.sci_cci(rb, sk, ck, grid), with_bisection)

@@ -151,3 +151,35 @@ def test_launch_ranks_command_line(monkeypatch):
     cmd = seen['cmd']
     assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nproc-per-node=2' in cmd and cmd[-4:] == ['-m', 'pkg.p3', '--num_gpus', '2']
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_environment_switch_table():
+    """switches.py: the ONE table of DIC_* variables.  Unknown names and values outside the allowed sets raise (a typo used to mean the default
+    silently); every variable the sources read is in the table; INTEGRATION.md section 4 is the generated table."""
+    import glob
+    import re
+
+    import pytest
+
+    from deep_interpolation_clustering_amd import switches
+    switches.validate({'PATH': '/bin', 'DIC_ROW_PROJ': '0', 'DIC_SMALL_BATCH': '2048', 'DIC_RBF_BWD_SLOT': '2', 'DIC_LIB_PATH': '/tmp/x.so'})
+    with pytest.raises(RuntimeError, match='DIC_ROW_PROJS: unknown switch .did you mean DIC_ROW_PROJ'):
+        switches.validate({'DIC_ROW_PROJS': '0'})
+    with pytest.raises(RuntimeError, match="DIC_ROW_PROJ='off': allowed values are 0, 1"):
+        switches.validate({'DIC_ROW_PROJ': 'off'})
+    with pytest.raises(RuntimeError, match='DIC_SMALL_BATCH=.4k.: an integer'):
+        switches.validate({'DIC_SMALL_BATCH': '4k'})
+    with pytest.raises(RuntimeError, match='DIC_F32_PRODUCTS'):
+        switches.validate({'DIC_F32_PRODUCTS': 'x6'})
+    assert switches.get('DIC_RBF_BWD_SLOT', {}) == '1' and switches.get('DIC_RBF_BWD_SLOT', {'DIC_RBF_BWD_SLOT': '0'}) == '0'
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, 'deep_interpolation_clustering_amd')
+    read = set()
+    for f in glob.glob(os.path.join(pkg, '*.py')) + glob.glob(os.path.join(pkg, 'csrc', '*.h*')) + [os.path.join(root, 'bench.py')]:
+        for ln in open(f):
+            if 'getenv' in ln or 'os.environ' in ln:
+                read.update(re.findall(r'DIC_[A-Z0-9_]+', ln))
+    assert read and read <= set(switches.SWITCHES), sorted(read - set(switches.SWITCHES))
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    block = doc[doc.index(switches.BEGIN) + len(switches.BEGIN):doc.index(switches.END)].strip()
+    assert block == switches.markdown_table(), 'INTEGRATION.md section 4 is stale: python -m deep_interpolation_clustering_amd.switches --write'
