@@ -147,6 +147,157 @@ __global__ __launch_bounds__(XW * 64, 1) void dx_proj_kernel(DxProjArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the OTHER design -- 256 x 256 macro-tiles, nothing resident.  dX (N, 256) = dG (N, 1024) . W_ih (1024, 256) as an "NT" product of two
+// row-major operands with k contiguous: dG rows and the rows of W_ih^T (256, 1024).  One persistent workgroup of 8 waves per CU walks its
+// 256-row tiles; a tile's k range streams through LDS in 64-deep slabs (128 B = one cache line per row): dG slabs (32 KB, from HBM) through a
+// 3-slot ring, W^T slabs (32 KB, L2-resident: the whole matrix is 512 KB) through a 2-slot ring -- all 160 KB of the CU's LDS, filled by LDS-DMA
+// only (asm: the compiler does not count it), one raw barrier and one counted vmcnt wait per slab, the ring running on ACROSS tile boundaries.
+// Every CU takes in its row share of dG ONCE (6.3 MB at B = 32 768) plus 6.3 MB of W^T from L2; round 3's resident-weight kernel above took in
+// dG twice (12.5 MB per CU) and lost to the library on exactly that.
+// Wave (wm, wn) = (w & 3, w >> 2) owns 64 rows x 128 columns: the product is issued transposed, D^T = W^T . dG^T (A fragment = 32 rows of W^T,
+// B fragment = 32 rows of dG), so lane (m = lane & 31, hh) ends up with output row m and FOUR consecutive columns per accumulator quad; one
+// v_permlane32_swap per quad pair makes that eight -- 16-B stores straight from the registers, no staging tile (there is no LDS left for one).
+// LDS image: rows of 128 B back to back, the eight 16-B pieces of row r stored at position p ^ ((r >> 1) & 7) -- the permutation is applied
+// through the DMA's per-lane SOURCE address (a DMA instruction fills 1 KiB = 8 rows in lane order), and it makes every 16-lane group of a
+// ds_read_b128 fragment read (16 rows, same logical piece) cover all 64 banks once.
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int T_ROWB = TK * 2;                        // bytes of a row inside a slab
+constexpr int T_ASLOT = TM * T_ROWB;                  // 32 KB: a slab of dG rows
+constexpr int T_BSLOT = TN * T_ROWB;                  // 32 KB: a slab of W^T rows
+constexpr int T_NA = 3, T_NB = 2;
+constexpr int T_LDS = T_NA * T_ASLOT + T_NB * T_BSLOT;   // 163 840 B
+constexpr int T_SLABS = XK / TK;                      // 16 slabs per tile
+static_assert(TN == XN && T_LDS <= 160 * 1024, "dx_tile: tile / LDS budget");
+
+struct DxTileArgs {
+    const __bf16* dg;      // (N, 1024)
+    const __bf16* wt;      // (256, 1024) = W_ih^T
+    __bf16* dx;            // (N, 256)
+    long N;
+};
+
+__global__ __launch_bounds__(512, 1) void dx_tile_kernel(DxTileArgs a) {
+    extern __shared__ __align__(16) unsigned char tsm[];
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, l31 = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w & 3, wn = w >> 2;
+    const long N = a.N;
+    const int ntiles = (int)((N + TM - 1) / TM), nch = gridDim.x;
+    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / nch + 1 : 0;
+    const int S = my_tiles * T_SLABS;
+    if (S == 0) return;
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)tsm);
+    const unsigned ldsA = lds0, ldsB = lds0 + T_NA * T_ASLOT;
+    // DMA: wave w fills the 1-KiB pieces c = w, w + 8, w + 16, w + 24 of a slab (rows 8c .. 8c + 7); lane L -> row 8c + (L >> 3), physical piece L & 7,
+    // i.e. logical piece (L & 7) ^ ((row >> 1) & 7) with (row >> 1) & 7 = (4 (w & 1) + (L >> 4)) & 7 for every piece of this wave (c = w mod 8)
+    const unsigned v_dma = (unsigned)(lane >> 3) * (XK * 2) + (unsigned)(((lane & 7) ^ ((4 * (w & 1) + (lane >> 4)) & 7)) * 16);
+    auto tile_row0 = [&](int i) { return min((long)((int)blockIdx.x + i * nch) * TM, N - TM); };
+    auto issue_a = [&](int s) {
+        const int i = s / T_SLABS, ks = s % T_SLABS;
+        const __bf16* src = a.dg + (size_t)tile_row0(i) * XK + ks * TK;
+        const unsigned dst = ldsA + (s % T_NA) * T_ASLOT;
+#pragma unroll
+        for (int j = 0; j < TM / 64; ++j) {
+            const int c = w + 8 * j;
+            xdma16(src + (size_t)(8 * c) * XK, v_dma, dst + c * 1024);
+        }
+    };
+    auto issue_b = [&](int s) {
+        const int ks = s % T_SLABS;
+        const __bf16* src = a.wt + ks * TK;
+        const unsigned dst = ldsB + (s % T_NB) * T_BSLOT;
+#pragma unroll
+        for (int j = 0; j < TN / 64; ++j) {
+            const int c = w + 8 * j;
+            xdma16(src + (size_t)(8 * c) * XK, v_dma, dst + c * 1024);
+        }
+    };
+    // fragment reads: row (32 block + l31), logical piece 2 kk + hh -> physical piece ^ sw
+    const int sw = (l31 >> 1) & 7;
+    int poff[TK / 16];
+#pragma unroll
+    for (int kk = 0; kk < TK / 16; ++kk) poff[kk] = ((2 * kk + hh) ^ sw) * 16;
+    const int a_row = (128 * wn + l31) * T_ROWB;          // W^T rows of this wave's 4 column blocks (+ 32 nb rows)
+    const int b_row = (64 * wm + l31) * T_ROWB;           // dG rows of this wave's 2 row blocks (+ 32 mb rows)
+
+    issue_a(0);
+    issue_b(0);
+    if (S > 1) issue_a(1);
+    xf32x16 acc[4][2];
+    for (int s = 0; s < S; ++s) {
+        const int ks = s % T_SLABS;
+        if (ks == 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[nb][mb][k] = 0.f;
+        }
+        // this wave's pieces of slab s (dG: issued two iterations ago, W^T: one) have landed once only what was issued AFTER them is still in
+        // flight: the 4 dG pieces of slab s + 1 -- and, on the first slab of a later tile, the previous tile's 16 output stores behind them
+        if (s + 1 < S) {
+            if (ks == 0 && s > 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everybody's pieces of slab s are in; everybody is done reading slab s - 1 (its two slots are free)
+        if (s + 1 < S) issue_b(s + 1);
+        if (s + 2 < S) issue_a(s + 2);
+        const unsigned char* A = tsm + T_NA * T_ASLOT + (s % T_NB) * T_BSLOT + a_row;
+        const unsigned char* Bm = tsm + (s % T_NA) * T_ASLOT + b_row;
+#pragma unroll
+        for (int kk = 0; kk < TK / 16; ++kk) {
+            xbf16x8 af[4], bf[2];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) af[nb] = *reinterpret_cast<const xbf16x8*>(A + nb * 32 * T_ROWB + poff[kk]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) bf[mb] = *reinterpret_cast<const xbf16x8*>(Bm + mb * 32 * T_ROWB + poff[kk]);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bf[mb], acc[nb][mb], 0, 0, 0);
+        }
+        if (ks == T_SLABS - 1) {
+            // D^T layout: lane (m = l31, hh), register k -> column 32 nb + (k & 3) + 8 (k >> 2) + 4 hh.  Quads g = k >> 2: (0, 1) and (2, 3) are traded
+            // between the lane halves so that each lane holds eight consecutive columns: [g even own | partner's] for hh = 0, [partner's | g odd own] for hh = 1
+            const long r0 = tile_row0(s / T_SLABS);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                __bf16* orow = a.dx + (size_t)(r0 + 64 * wm + 32 * mb + l31) * XN + 128 * wn + 8 * hh;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        typedef __bf16 obf16x2 __attribute__((ext_vector_type(2)));
+                        unsigned q[2][2];
+#pragma unroll
+                        for (int g = 0; g < 2; ++g)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const float v0 = acc[nb][mb][4 * (2 * gp + g) + 2 * h2], v1 = acc[nb][mb][4 * (2 * gp + g) + 2 * h2 + 1];
+                                obf16x2 pr = {(__bf16)v0, (__bf16)v1};
+                                q[g][h2] = __builtin_bit_cast(unsigned, pr);
+                            }
+                        // permlane32_swap(x, y): x of lanes 32..63 <-> y of lanes 0..31
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(q[0][0], q[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(q[0][1], q[1][1], false, false);
+                        uint4 v;
+                        v.x = s0[0]; v.y = s1[0]; v.z = s0[1]; v.w = s1[1];
+                        *reinterpret_cast<uint4*>(orow + 32 * nb + 16 * gp) = v;
+                    }
+            }
+        }
+    }
+}
+
+static int dx_tile_chunks(long N) {
+    const int ntiles = (int)((N + TM - 1) / TM);
+    return max(1, min(ntiles, kNumCU));
+}
+
 static int dx_proj_chunks(long N) {
     const int ntiles = (int)((N + XT - 1) / XT);
     int nch = max(1, min(ntiles, kNumCU / 2));
@@ -173,6 +324,22 @@ int dic_lstm_dx_wide(const void* dg, const void* w_ih, int64_t N, int gate_colum
     DxProjArgs a{(const __bf16*)dg, (const __bf16*)w_ih, (__bf16*)dx, (long)N};
     hipLaunchKernelGGL(dx_proj_kernel, dim3(dx_proj_chunks(N), XN / (32 * XW)), dim3(XW * 64), X_LDS, (hipStream_t)stream, a);
     return check_launch("lstm_dx_wide");
+}
+
+int dic_lstm_dx_tile(const void* dg, const void* w_ih_t, int64_t N, int gate_columns, int in_features, void* dx, dic_stream_t stream) {
+    DIC_REQUIRE(N >= TM, DIC_ERR_INVALID_ARG, "lstm_dx_tile: %lld rows (needs at least %d)", (long long)N, TM);
+    DIC_REQUIRE(gate_columns == XK && in_features == XN, DIC_ERR_UNSUPPORTED, "lstm_dx_tile: (%d gate columns -> %d inputs) (compiled for 1024 -> 256)",
+                gate_columns, in_features);
+    DIC_REQUIRE(dg && w_ih_t && dx, DIC_ERR_INVALID_ARG, "lstm_dx_tile: NULL pointer");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)dx_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_dx_tile: cannot reserve %d B of LDS: %s", T_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    DxTileArgs a{(const __bf16*)dg, (const __bf16*)w_ih_t, (__bf16*)dx, (long)N};
+    hipLaunchKernelGGL(dx_tile_kernel, dim3(dx_tile_chunks(N)), dim3(512), T_LDS, (hipStream_t)stream, a);
+    return check_launch("lstm_dx_tile");
 }
 
 }  // extern "C"

@@ -333,6 +333,17 @@ constexpr int X8RK = 192;               // input columns of W_ih held in registe
 constexpr int X8LK = XI - X8RK;
 constexpr int X8LP = X8LK + 8;
 
+// Timing-only experiment switches (wrong results by design, like the other DIC_*_EXP_* builds; scripts/fwdx_experiments.sh): which part of a step is on
+// the chain?  -DDIC_FWDX_EXP_NOTRANS: the ten quarter-rate exp / rcp per element become full-rate multiply-adds; -DDIC_FWDX_EXP_NOPROJ: no projection
+// MFMAs (32 of a wave's 48 per step); -DDIC_FWDX_EXP_NOGATE: no gate arithmetic at all; -DDIC_FWDX_EXP_NOXLOAD: the x tile is never loaded / staged.
+#if defined(DIC_FWDX_EXP_NOTRANS) || defined(DIC_FWDX_EXP_NOGATE)
+__device__ __forceinline__ float fx_sigmoid(float x) { return fmaf(x, 0.25f, 0.5f); }
+__device__ __forceinline__ float fx_tanh(float x) { return x * 0.5f; }
+#else
+__device__ __forceinline__ float fx_sigmoid(float x) { return sigmoid_acc<__bf16>(x); }
+__device__ __forceinline__ float fx_tanh(float x) { return tanh_acc<__bf16>(x); }
+#endif
+
 __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
     typedef __bf16 T;
     typedef sbf16x4 V4;
@@ -440,7 +451,11 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
 #pragma unroll
             for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(xcur + i * 16 + 8 * hh);
 #pragma unroll
+#ifdef DIC_FWDX_EXP_NOPROJ
+            for (int ks = 0; ks < 1; ++ks) {
+#else
             for (int ks = 0; ks < NK; ++ks) {
+#endif
                 if (ks < NKR) {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[0][ks], ring[ks % DEPTH], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[1][ks], ring[ks % DEPTH], acc[1], 0, 0, 0);
@@ -463,8 +478,10 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][ks], hf[ks], acc[1], 0, 0, 0);
             }
         }
+#ifndef DIC_FWDX_EXP_NOXLOAD
         if (step + 1 < R) land_x(cur ^ 1);               // the x tile of the next step -> the other buffer (nobody reads it during this step)
         if (step + 2 < R) load_x(step + 2);
+#endif
         const bool last = step == R - 1;
         const size_t row = (size_t)t * B + bc;
 #pragma unroll
@@ -475,9 +492,14 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * qq + j;
-                const float ig = sigmoid_acc<T>(acc[0][k]), fg = sigmoid_acc<T>(acc[0][8 + k]), gg = tanh_acc<T>(acc[1][k]), og = sigmoid_acc<T>(acc[1][8 + k]);
+#ifdef DIC_FWDX_EXP_NOGATE
+                const float ig = acc[0][k], fg = acc[0][8 + k], gg = acc[1][k], og = acc[1][8 + k];
+                const float cn = c[k] + ig, hn = og;
+#else
+                const float ig = fx_sigmoid(acc[0][k]), fg = fx_sigmoid(acc[0][8 + k]), gg = fx_tanh(acc[1][k]), og = fx_sigmoid(acc[1][8 + k]);
                 const float cn = fmaf(fg, c[k], ig * gg);
-                const float hn = og * tanh_acc<T>(cn);
+                const float hn = og * fx_tanh(cn);
+#endif
                 c[k] = cn;
                 cv[j] = cn; hv[j] = hn;
                 hb[j] = (T)hn; ib[j] = (T)ig; fb[j] = (T)fg; gb[j] = (T)gg; ob[j] = (T)og; cb[j] = (T)cn;

@@ -69,9 +69,11 @@ def f32_available(x, lstm):
 # 6.46 ms); round 3's same-box A/B (3 x 60 steps each) has it LOSING by 0.03-0.07 ms (6.505 vs 6.44-6.48 ms): both kernels are bound by the
 # same HBM, the encoder's lstm_bwd stretches from 0.85 to 1.77 ms while they share the chip, and nothing is hidden.  Off by default.
 DW_SIDE_STREAM = os.environ.get('DIC_DW_SIDE_STREAM', '0') == '1'
-# the decoder's input gradient dX = dG.W_ih on the hand-written resident-weight kernel (csrc/dic_dxproj.hip) instead of the library GEMM:
-# OFF by default -- measured 571 us against the library's 447 us at B = 32 768 (per-CU ingest bound, see the kernel's header)
-DX_KERNEL = os.environ.get('DIC_DX_KERNEL', '0') == '1'
+# the decoder's large-batch input gradient dX = dG.W_ih (csrc/dic_dxproj.hip): 2 = dic_lstm_dx_tile (round 5: 256 x 256 macro-tiles, both operands
+# streamed through LDS-DMA rings, every CU takes in its share of dG once), 1 = dic_lstm_dx_wide (round 3: W_ih resident in registers -- measured
+# 571 us against the library's 447 us at B = 32 768, per-CU ingest bound), 0 = library GEMM
+DX_KERNEL = int(os.environ.get('DIC_DX_KERNEL', '2'))
+DX_TILE_MIN_ROWS = 256
 _SIDE = {'on': False, 'streams': {}, 'pending': [], 'keep': []}
 RECORD_STREAM = os.environ.get('DIC_SIDE_RECORD_STREAM', '0') == '1'      # (experiment switch: the allocator-side alternative)
 
@@ -278,14 +280,19 @@ class _BiLstm(torch.autograd.Function):
         dxp = torch.empty((2, R * B, Ip), device=dev, dtype=T) if (fuse_dx and ctx.needs_input_grad[0]) else None
         dx = None
         if ctx.needs_input_grad[0] and dxp is None:
-            if DX_KERNEL and (not f32) and I == WIDE_INPUT and Ip == I and R * B >= 32:
-                # decoder: dX = dG . W_ih with the weights resident in registers (csrc/dic_dxproj.hip; round 2: a library GEMM)
+            if DX_KERNEL == 2 and (not f32) and I == WIDE_INPUT and Ip == I and not small and R * B >= DX_TILE_MIN_ROWS:
+                # decoder: dX = dG . W_ih on 256 x 256 macro-tiles, dG and W_ih^T streamed through LDS (csrc/dic_dxproj.hip; until round 4: a library GEMM)
+                dx = torch.empty((R * B, Ip), device=dev, dtype=T)
+                wih_t = wih.t().contiguous()                         # (256, 1024): k contiguous like the rows of dG (512 KB)
+                N.check(Lb.dic_lstm_dx_tile(N.ptr(dg2), N.ptr(wih_t), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_tile')
+            elif DX_KERNEL == 1 and (not f32) and I == WIDE_INPUT and Ip == I and R * B >= 32:
+                # decoder: dX = dG . W_ih with the weights resident in registers (round 3; measured slower than the library GEMM)
                 dx = torch.empty((R * B, Ip), device=dev, dtype=T)
                 N.check(Lb.dic_lstm_dx_wide(N.ptr(dg2), N.ptr(wih), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_wide')
             elif f32 and not x3:
                 dx = dg2 @ wih                                       # (R*B, Ip): the exact-f32 parity mode
             elif (not f32) and I == WIDE_INPUT and not small:
-                dx = dg2 @ wih                                       # the decoder's large-batch dX: the one library GEMM left (see DX_KERNEL)
+                dx = dg2 @ wih                                       # DIC_DX_KERNEL=0: the decoder's large-batch dX as a library GEMM (A/B)
             else:
                 dx = _ops.gemm_nt(dg2, wih.t().contiguous())         # dX = dG . W_ih on dic_gemm_nt (W_ih^T: a (Ip, 8H) copy of the packed weights)
             if packed:

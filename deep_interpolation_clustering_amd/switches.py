@@ -29,7 +29,8 @@ SWITCHES = {
                            'it 0.03-0.07 ms slower per step: both are bound by the same HBM)'),
     'DIC_SIDE_RECORD_STREAM': (ON_OFF, '0', 'lstm.py', '1: side-stream tensors kept alive through `record_stream` (the allocator-side alternative; experiment)'),
     'DIC_KMEANS_SMALLK_MFMA': (ON_OFF, '1', 'csrc/dic_kmeans_mfma.hip', '0: Lloyd iterations with K <= 8 always on the wave-per-row kernel (round 2), also when several restarts could share X tiles'),
-    'DIC_DX_KERNEL': (ON_OFF, '0', 'lstm.py', '1: the decoder\'s input gradient on `dic_lstm_dx_wide` instead of the library GEMM (measured slower)'),
+    'DIC_DX_KERNEL': (('0', '1', '2'), '2', 'lstm.py', 'the decoder\'s large-batch input gradient dX = dG W_ih: 2 = `dic_lstm_dx_tile` (256 x 256 macro-tiles, both operands through '
+                      'LDS-DMA rings; round 5), 1 = `dic_lstm_dx_wide` (weights resident in registers; round 3: measured slower), 0 = library GEMM'),
     'DIC_SHARDED_GRAPHS': (ON_OFF, '1', 'step.py', '0: `Stepper(use_graphs=\'auto\')` never captures a SHARDED step (default: on the `nccl` backend the sharded step of a per-rank batch '
                            '<= 8192 is replayed from a hipGraph -- RCCL collectives are stream operations; see DESIGN section 6)'),
     'DIC_DIST_BACKEND': (('nccl', 'gloo'), 'nccl on GPUs', 'dist.py', '`gloo`: several ranks may share one GPU (rehearsal of the N > 1 path)'),

@@ -1065,6 +1065,34 @@ def test_eight_wave_decoder_recurrence_equals_the_four_wave_kernel(R, B, init):
     assert torch.isfinite(res[0][0].float()).all() and float(res[0][0].float().abs().mean()) > 0.01
 
 
+@pytest.mark.parametrize('rows', [256, 257, 1000, 24 * 4160, 70000])
+def test_decoder_input_gradient_tile_kernel_equals_matmul(rows):
+    """dic_lstm_dx_tile (csrc/dic_dxproj.hip, round 5: dX = dG . W_ih on 256 x 256 macro-tiles, dG and W_ih^T through LDS-DMA rings)
+    against the f64 product and torch's bf16 matmul: one tile, ragged row counts (the shifted last tile), more tiles than workgroups (the ring runs on
+    across tile boundaries), every output element checked."""
+    from deep_interpolation_clustering_amd import _native as N
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(rows)
+    dg = (torch.randn(rows, 1024, device=dev, generator=g) * 0.3).to(torch.bfloat16)
+    w = (torch.randn(1024, 256, device=dev, generator=g) * 0.06).to(torch.bfloat16)
+    wt = w.t().contiguous()
+    dx = torch.full((rows, 256), float('nan'), device=dev, dtype=torch.bfloat16)
+    N.check(N.lib().dic_lstm_dx_tile(N.ptr(dg), N.ptr(wt), rows, 1024, 256, N.ptr(dx), N.stream_of(dg)), 'dic_lstm_dx_tile')
+    ref64 = dg.double() @ w.double()
+    assert torch.isfinite(dx.float()).all()
+    err = (dx.double() - ref64).abs()
+    assert float(err.max()) <= 2.0 ** -8 * float(ref64.abs().max()) + 1e-6              # one bf16 rounding of an f32-accumulated sum
+    lib = (dg @ w).double()
+    assert float((dx.double() - lib).abs().max()) <= 2.0 ** -7 * float(ref64.abs().max())
+    # a structured operand catches a permuted fragment or a misplaced output column that random data could hide behind the tolerance
+    dg2 = torch.zeros(rows, 1024, device=dev, dtype=torch.bfloat16)
+    dg2[torch.arange(rows, device=dev), torch.arange(rows, device=dev) % 1024] = 1.0      # dX row i = row (i mod 1024) of W
+    dx2 = torch.empty((rows, 256), device=dev, dtype=torch.bfloat16)
+    N.check(N.lib().dic_lstm_dx_tile(N.ptr(dg2), N.ptr(wt), rows, 1024, 256, N.ptr(dx2), N.stream_of(dg)), 'dic_lstm_dx_tile')
+    assert torch.equal(dx2, w[torch.arange(rows, device=dev) % 1024])
+    assert N.lib().dic_lstm_dx_tile(N.ptr(dg), N.ptr(wt), 255, 1024, 256, N.ptr(dx), N.stream_of(dg)) == -1      # fewer rows than a tile: rejected
+
+
 @pytest.mark.parametrize('rows', [32, 33, 1000, 24 * 4096 + 7])
 def test_decoder_input_gradient_kernel_equals_matmul(rows):
     """dic_lstm_dx_wide (csrc/dic_dxproj.hip: dX = dG . W_ih, weights resident in registers) against torch's bf16 matmul
