@@ -73,7 +73,7 @@ SIGNATURES = {
     'dic_lstm_fwd_proj': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'dic_lstm_bwd_workspace': (_sz, [_i]),
     'dic_lstm_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _i, _i, _p]),
-    'dic_lstm_pack': (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'dic_lstm_pack': (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     'dic_lstm_rec_fwd': (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     'dic_lstm_rec_fwd_proj': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     'dic_lstm_fwd_xproj': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p]),

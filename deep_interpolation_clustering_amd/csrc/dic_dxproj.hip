@@ -165,10 +165,14 @@ constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int T_ROWB = TK * 2;                        // bytes of a row inside a slab
 constexpr int T_ASLOT = TM * T_ROWB;                  // 32 KB: a slab of dG rows
 constexpr int T_BSLOT = TN * T_ROWB;                  // 32 KB: a slab of W^T rows
-constexpr int T_NA = 3, T_NB = 2;
+#ifndef DIC_DXT_NA
+#define DIC_DXT_NA 3
+#define DIC_DXT_NB 2
+#endif
+constexpr int T_NA = DIC_DXT_NA, T_NB = DIC_DXT_NB;       // (ring depths: -D overrides for A/B builds, scripts/dx_experiments.sh)
 constexpr int T_LDS = T_NA * T_ASLOT + T_NB * T_BSLOT;   // 163 840 B
 constexpr int T_SLABS = XK / TK;                      // 16 slabs per tile
-static_assert(TN == XN && T_LDS <= 160 * 1024, "dx_tile: tile / LDS budget");
+static_assert(TN == XN && T_LDS <= 160 * 1024 && T_NB >= 2 && T_NB <= T_NA, "dx_tile: tile / LDS budget / ring depths");
 
 struct DxTileArgs {
     const __bf16* dg;      // (N, 1024)
@@ -220,50 +224,19 @@ __global__ __launch_bounds__(512, 1) void dx_tile_kernel(DxTileArgs a) {
     const int a_row = (128 * wn + l31) * T_ROWB;          // W^T rows of this wave's 4 column blocks (+ 32 nb rows)
     const int b_row = (64 * wm + l31) * T_ROWB;           // dG rows of this wave's 2 row blocks (+ 32 mb rows)
 
-    issue_a(0);
-    issue_b(0);
-    if (S > 1) issue_a(1);
+    // prologue = what iterations -(T_NA - 1) .. -1 of the steady state would have issued, in its order (W^T slab first, then the dG slab)
+#pragma unroll
+    for (int it = 1 - T_NA; it < 0; ++it) {
+        if (it + T_NB - 1 >= 0 && it + T_NB - 1 < S) issue_b(it + T_NB - 1);
+        if (it + T_NA - 1 < S) issue_a(it + T_NA - 1);
+    }
     xf32x16 acc[4][2];
-    for (int s = 0; s < S; ++s) {
-        const int ks = s % T_SLABS;
-        if (ks == 0) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) acc[nb][mb][k] = 0.f;
-        }
-        // this wave's pieces of slab s (dG: issued two iterations ago, W^T: one) have landed once only what was issued AFTER them is still in
-        // flight: the 4 dG pieces of slab s + 1 -- and, on the first slab of a later tile, the previous tile's 16 output stores behind them
-        if (s + 1 < S) {
-            if (ks == 0 && s > 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // everybody's pieces of slab s are in; everybody is done reading slab s - 1 (its two slots are free)
-        if (s + 1 < S) issue_b(s + 1);
-        if (s + 2 < S) issue_a(s + 2);
-        const unsigned char* A = tsm + T_NA * T_ASLOT + (s % T_NB) * T_BSLOT + a_row;
-        const unsigned char* Bm = tsm + (s % T_NA) * T_ASLOT + b_row;
-#pragma unroll
-        for (int kk = 0; kk < TK / 16; ++kk) {
-            xbf16x8 af[4], bf[2];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) af[nb] = *reinterpret_cast<const xbf16x8*>(A + nb * 32 * T_ROWB + poff[kk]);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) bf[mb] = *reinterpret_cast<const xbf16x8*>(Bm + mb * 32 * T_ROWB + poff[kk]);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bf[mb], acc[nb][mb], 0, 0, 0);
-        }
-        if (ks == T_SLABS - 1) {
+    // a finished tile's accumulators -> bf16 -> global: called one iteration LATE (behind the next tile's first barrier and DMA issue), so that the 16
+    // stores are the youngest entries of the in-order memory queue and nothing waits for them for the next two slabs
+    auto store_tile = [&](int tile_i) {
             // D^T layout: lane (m = l31, hh), register k -> column 32 nb + (k & 3) + 8 (k >> 2) + 4 hh.  Quads g = k >> 2: (0, 1) and (2, 3) are traded
             // between the lane halves so that each lane holds eight consecutive columns: [g even own | partner's] for hh = 0, [partner's | g odd own] for hh = 1
-            const long r0 = tile_row0(s / T_SLABS);
+            const long r0 = tile_row0(tile_i);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 __bf16* orow = a.dx + (size_t)(r0 + 64 * wm + 32 * mb + l31) * XN + 128 * wn + 8 * hh;
@@ -289,8 +262,82 @@ __global__ __launch_bounds__(512, 1) void dx_tile_kernel(DxTileArgs a) {
                         *reinterpret_cast<uint4*>(orow + 32 * nb + 16 * gp) = v;
                     }
             }
+    };
+    for (int s = 0; s < S; ++s) {
+        const int ks = s % T_SLABS;
+        // this wave's pieces of slab s (dG: issued two iterations ago, W^T: one) have landed once only what was issued AFTER them is still in
+        // flight: the 4 dG pieces of slab s + 1 -- and, on the first slab of a later tile, the previous tile's 16 output stores behind them
+        // Counted wait.  An iteration issues 4 DMA instructions for W^T slab j + NB - 1, then 4 for dG slab j + NA - 1.  W^T slab s went out first thing in
+        // iteration s - NB + 1; behind it came that iteration's dG slab and the whole iterations s - NB + 2 .. s - 1: 4 + 8 (NB - 2) instructions may
+        // still be in flight when it has landed (dG slab s is older when NA > NB; with NA == NB it is that iteration's own dG slab and only the
+        // 8 (NB - 2) count).  A tile's 16 output stores are issued in the FIRST iteration of the next tile, behind that iteration's DMA instructions: they
+        // sit behind the slabs waited for in the NB - 1 iterations after it.  Towards the end of the stream fewer instructions were issued than the count
+        // assumes: drain.
+        {
+            constexpr int inflight = (T_NA > T_NB ? 4 : 0) + 8 * (T_NB - 2);
+            const int tail = S - 1 - s;
+            if (tail >= T_NA - 1) {
+                if (ks >= 1 && ks <= T_NB - 1 && s >= T_SLABS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(inflight + 16) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(inflight) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everybody's pieces of slab s are in; everybody is done reading slab s - 1 (its two slots are free)
+        const unsigned char* A = tsm + T_NA * T_ASLOT + (s % T_NB) * T_BSLOT + a_row;
+        const unsigned char* Bm = tsm + (s % T_NA) * T_ASLOT + b_row;
+        // fragments of k-step kk + 1 are requested before the MFMAs of k-step kk are issued (two register sets): a ds_read_b128 takes ~100+ cycles to
+        // come back, and both waves of a SIMD leave the barrier together -- with one register set every group of MFMAs waited for the reads just issued
+        xbf16x8 af[2][4], bf[2][2];
+        auto load_frags = [&](int kk, int set) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) bf[set][mb] = *reinterpret_cast<const xbf16x8*>(Bm + mb * 32 * T_ROWB + poff[kk]);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) af[set][nb] = *reinterpret_cast<const xbf16x8*>(A + nb * 32 * T_ROWB + poff[kk]);
+        };
+        load_frags(0, 0);
+        __builtin_amdgcn_sched_barrier(0);          // (the first fragment reads go out BEFORE the DMA instructions: their latency hides behind the DMA issue)
+#ifndef DIC_DXT_EXP_NOB
+        if (s + T_NB - 1 < S) issue_b(s + T_NB - 1);
+#endif
+#ifndef DIC_DXT_EXP_NOA
+        if (s + T_NA - 1 < S) issue_a(s + T_NA - 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) {
+#ifndef DIC_DXT_EXP_NOSTORE
+            if (s > 0) store_tile(s / T_SLABS - 1);
+#endif
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[nb][mb][k] = 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < TK / 16; ++kk) {
+            if (kk + 1 < TK / 16) load_frags(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);          // (left alone the scheduler folds the two register sets back into one and re-serialises reads and MFMAs)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+#ifdef DIC_DXT_EXP_NOMMA
+                    if (nb + mb == 0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][nb], bf[kk & 1][mb], acc[0][0], 0, 0, 0);
+#else
+                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][nb], bf[kk & 1][mb], acc[nb][mb], 0, 0, 0);
+#endif
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#ifndef DIC_DXT_EXP_NOSTORE
+    store_tile(my_tiles - 1);
+#else
+    if (a.N < 0) store_tile(my_tiles - 1);
+#endif
 }
 
 static int dx_tile_chunks(long N) {

@@ -58,11 +58,21 @@ struct LstmGrads {
 // wih (2*4H, Ip) bf16: columns [0,I) = W_ih, column I = b_ih + b_hh when `bias_col` (narrow inputs: the projection runs inside
 // the recurrence kernel with a constant-one input column), other padding 0;  whh (2,4H,H) bf16;  whh_t (2,H,4H) bf16;
 // bias (2*4H) bf16 = b_ih + b_hh (the addmm operand of the library projection).
+// wih_t (Ip, 2*4H) bf16 (optional) = wih transposed: the k-contiguous operand of dic_lstm_dx_tile (decoder: Ip = I = 256).
 template <typename T>
-__global__ __launch_bounds__(256) void lstm_pack_kernel(LstmParams p, int I, int Ip, int bias_col, T* wih, T* whh, T* whh_t, T* bias) {
+__global__ __launch_bounds__(256) void lstm_pack_kernel(LstmParams p, int I, int Ip, int bias_col, T* wih, T* whh, T* whh_t, T* bias, T* wih_t) {
     const int n_ih = 2 * G4 * Ip, n_hh = 2 * G4 * GH;
-    const int total = n_ih + 2 * n_hh + 2 * G4;
+    const int total = n_ih + 2 * n_hh + 2 * G4 + (wih_t ? n_ih : 0);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        if (i >= n_ih + 2 * n_hh + 2 * G4) {
+            // wih_t[c][row] = wih[row][c]: consecutive threads walk the gate rows (coalesced writes; the f32 source rows stay in L2)
+            const int j = i - (n_ih + 2 * n_hh + 2 * G4), c = j / (2 * G4), row = j - c * (2 * G4), d = row / G4, g = row - d * G4;
+            float v = 0.f;
+            if (c < I) v = p.w_ih[d][(size_t)g * I + c];
+            else if (c == I && bias_col) v = p.b_ih[d][g] + p.b_hh[d][g];
+            wih_t[j] = (T)v;
+            continue;
+        }
         if (i < n_ih) {
             const int row = i / Ip, c = i - row * Ip, d = row / G4, g = row - d * G4;
             float v = 0.f;
@@ -541,7 +551,7 @@ using namespace dic;
 extern "C" {
 
 int dic_lstm_pack(int dtype, const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
-                  dic_stream_t stream) {
+                  void* wih_t, dic_stream_t stream) {
     DIC_REQUIRE(dtype == DIC_DTYPE_F32 || dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "lstm_pack: dtype %d", dtype);
     DIC_REQUIRE(H == GH, DIC_ERR_UNSUPPORTED, "lstm_pack: hidden size %d (compiled for %d)", H, GH);
     DIC_REQUIRE(params && wih && whh, DIC_ERR_INVALID_ARG, "lstm_pack: NULL pointer");
@@ -551,14 +561,14 @@ int dic_lstm_pack(int dtype, const float* const* params, int H, int I, int Ip, i
         p.w_ih[d] = params[4 * d + 0]; p.w_hh[d] = params[4 * d + 1]; p.b_ih[d] = params[4 * d + 2]; p.b_hh[d] = params[4 * d + 3];
         DIC_REQUIRE(p.w_ih[d] && p.w_hh[d] && p.b_ih[d] && p.b_hh[d], DIC_ERR_INVALID_ARG, "lstm_pack: NULL parameter (direction %d)", d);
     }
-    const int total = 2 * G4 * Ip + 4 * G4 * GH + 2 * G4;
+    const int total = 2 * G4 * Ip + 4 * G4 * GH + 2 * G4 + (wih_t ? 2 * G4 * Ip : 0);
     const dim3 grid(min((total + 255) / 256, 2 * kNumCU));
     if (dtype == DIC_DTYPE_BF16)
         hipLaunchKernelGGL(lstm_pack_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, p, I, Ip, bias_col, (__bf16*)wih, (__bf16*)whh,
-                           (__bf16*)whh_t, (__bf16*)bias);
+                           (__bf16*)whh_t, (__bf16*)bias, (__bf16*)wih_t);
     else
         hipLaunchKernelGGL(lstm_pack_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p, I, Ip, bias_col, (float*)wih, (float*)whh,
-                           (float*)whh_t, (float*)bias);
+                           (float*)whh_t, (float*)bias, (float*)wih_t);
     return check_launch("lstm_pack");
 }
 

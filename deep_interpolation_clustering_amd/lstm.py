@@ -150,7 +150,11 @@ class _BiLstm(torch.autograd.Function):
         whh_t = torch.empty((2, H, 4 * H), device=dev, dtype=T) if (need and not f32) else None
         bias = None if narrow else torch.empty(8 * H, device=dev, dtype=T)
         L, st = N.lib(), N.stream_of(x)
-        N.check(L.dic_lstm_pack(code, N.ptr_array(pf), H, I, Ip, int(narrow), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), st), 'dic_lstm_pack')
+        # (the decoder's large-batch input gradient runs on dic_lstm_dx_tile, whose weight operand is W_ih^T: packed in the same launch)
+        dx_tile = need and ctx.needs_input_grad[0] and DX_KERNEL == 2 and (not f32) and I == WIDE_INPUT and Ip == I and not small and R * B >= DX_TILE_MIN_ROWS
+        wih_t = torch.empty((Ip, 8 * H), device=dev, dtype=T) if dx_tile else None
+        N.check(L.dic_lstm_pack(code, N.ptr_array(pf), H, I, Ip, int(narrow), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), N.ptr(wih_t), st), 'dic_lstm_pack')
+        ctx.wih_t = wih_t
         if packed:                                                 # (R,B,32) bf16 rows [features | 1 | 0...] from ops.sci_cci_packed
             if not narrow or I_in != Ip or x.dtype != T:
                 raise ValueError(f'packed input must be (R,B,{Ip}) bf16 for an LSTM of input size {I}')
@@ -280,11 +284,11 @@ class _BiLstm(torch.autograd.Function):
         dxp = torch.empty((2, R * B, Ip), device=dev, dtype=T) if (fuse_dx and ctx.needs_input_grad[0]) else None
         dx = None
         if ctx.needs_input_grad[0] and dxp is None:
-            if DX_KERNEL == 2 and (not f32) and I == WIDE_INPUT and Ip == I and not small and R * B >= DX_TILE_MIN_ROWS:
-                # decoder: dX = dG . W_ih on 256 x 256 macro-tiles, dG and W_ih^T streamed through LDS (csrc/dic_dxproj.hip; until round 4: a library GEMM)
+            if ctx.wih_t is not None:
+                # decoder: dX = dG . W_ih on 256 x 256 macro-tiles, dG and W_ih^T (256, 1024: k contiguous like the rows of dG; written by the forward's
+                # dic_lstm_pack) streamed through LDS (csrc/dic_dxproj.hip; until round 4: a library GEMM)
                 dx = torch.empty((R * B, Ip), device=dev, dtype=T)
-                wih_t = wih.t().contiguous()                         # (256, 1024): k contiguous like the rows of dG (512 KB)
-                N.check(Lb.dic_lstm_dx_tile(N.ptr(dg2), N.ptr(wih_t), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_tile')
+                N.check(Lb.dic_lstm_dx_tile(N.ptr(dg2), N.ptr(ctx.wih_t), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_tile')
             elif DX_KERNEL == 1 and (not f32) and I == WIDE_INPUT and Ip == I and R * B >= 32:
                 # decoder: dX = dG . W_ih with the weights resident in registers (round 3; measured slower than the library GEMM)
                 dx = torch.empty((R * B, Ip), device=dev, dtype=T)

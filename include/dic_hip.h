@@ -358,7 +358,7 @@ int dic_lstm_dx_tile(const void* dg, const void* w_ih_t, int64_t N, int gate_col
  * that order.
  *   dic_lstm_pack: (dtype = DIC_DTYPE_BF16 or DIC_DTYPE_F32 selects the OUTPUT element type) -> wih (2*4H, Ip) bf16 [columns [0,I) = W_ih; column I = b_ih + b_hh when bias_col (dic_lstm_fwd_proj's
  *     constant-one input column); rest 0], whh (2,4H,H) bf16, whh_t (2,H,4H) bf16 or NULL, bias (2*4H) bf16 = b_ih + b_hh
- *     or NULL.  One launch replaces the stack / add / cast / pad / transpose sequence of torch ops.
+ *     or NULL, wih_t (Ip, 2*4H) = wih transposed (dic_lstm_dx_tile's operand) or NULL.  One launch replaces the stack / add / cast / pad / transpose sequence of torch ops.
  *   dic_lstm_dw (encoder, packed input width Ip == 32): weight gradients from ONE pass over the gate gradients,
  *     dW_hh[d] = sum_t dG_t[d]^T h_prev_t[d] (h_{t-1} for d = 0, h_{t+1} for d = 1) and dW_ih[d] = sum_t dG_t[d]^T x_t[:, :I]
  *     (x (R,B,Ip) bf16).  out_ext (R+2,B,2H) bf16 = the layer's own output in time slots 1..R (pass &out_ext[1] to
@@ -375,7 +375,7 @@ int dic_lstm_dx_tile(const void* dg, const void* w_ih_t, int64_t N, int gate_col
  *   dic_lstm_unpack_grads: staging tensors dw_ih (2*4H, ldw) / dw_hh (2,4H,H) / dbias (2*4H) f32 (each may be NULL) ->
  *     the parameter gradients (dbias goes to bias_ih AND bias_hh). */
 int dic_lstm_pack(int dtype, const float* const* params, int H, int I, int Ip, int bias_col, void* wih, void* whh, void* whh_t, void* bias,
-                  dic_stream_t stream);
+                  void* wih_t, dic_stream_t stream);
 size_t dic_lstm_dw_workspace(int R, int B);
 int dic_lstm_dw(const void* dgx, const void* out_ext, const void* x, const void* wih, void* dx_parts, int R, int B, int H, int I, int Ip,
                 float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);

@@ -380,8 +380,9 @@ def test_lstm_pack_matches_torch(I):
     whh, whh_t = torch.empty((2, 4 * H, H), device=dev, dtype=bf), torch.empty((2, H, 4 * H), device=dev, dtype=bf)
     bias = torch.empty(8 * H, device=dev, dtype=bf)
     ps = [p.detach() for p in _lstm_params(net)]
-    N.check(N.lib().dic_lstm_pack(N.DTYPE_BF16, N.ptr_array(ps), H, I, Ip, int(proj), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), N.stream_of(wih)),
-            'dic_lstm_pack')
+    wih_t = torch.full((Ip, 8 * H), 7.0, device=dev, dtype=bf)
+    N.check(N.lib().dic_lstm_pack(N.DTYPE_BF16, N.ptr_array(ps), H, I, Ip, int(proj), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), N.ptr(wih_t),
+                                  N.stream_of(wih)), 'dic_lstm_pack')
     w_ih = torch.stack([net.weight_ih_l0, net.weight_ih_l0_reverse]).detach()
     w_hh = torch.stack([net.weight_hh_l0, net.weight_hh_l0_reverse]).detach()
     b = torch.stack([net.bias_ih_l0 + net.bias_hh_l0, net.bias_ih_l0_reverse + net.bias_hh_l0_reverse]).detach()
@@ -389,13 +390,13 @@ def test_lstm_pack_matches_torch(I):
     want[:, :I] = w_ih.reshape(8 * H, I)
     if proj:
         want[:, I] = b.reshape(8 * H)
-    assert torch.equal(wih, want.to(bf))
+    assert torch.equal(wih, want.to(bf)) and torch.equal(wih_t, want.to(bf).t().contiguous())
     assert torch.equal(whh, w_hh.to(bf))
     assert torch.equal(whh_t, w_hh.transpose(1, 2).contiguous().to(bf))
     assert torch.equal(bias, b.reshape(8 * H).to(bf))
     # f32 outputs: the parameters themselves, re-arranged
     wih32, whh32, bias32 = torch.empty((8 * H, I), device=dev), torch.empty((2, 4 * H, H), device=dev), torch.empty(8 * H, device=dev)
-    N.check(N.lib().dic_lstm_pack(N.DTYPE_F32, N.ptr_array(ps), H, I, I, 0, N.ptr(wih32), N.ptr(whh32), None, N.ptr(bias32), N.stream_of(wih)),
+    N.check(N.lib().dic_lstm_pack(N.DTYPE_F32, N.ptr_array(ps), H, I, I, 0, N.ptr(wih32), N.ptr(whh32), None, N.ptr(bias32), None, N.stream_of(wih)),
             'dic_lstm_pack')
     assert torch.equal(wih32, w_ih.reshape(8 * H, I)) and torch.equal(whh32, w_hh) and torch.equal(bias32, b.reshape(8 * H))
 
