@@ -258,6 +258,12 @@ def _lstm_calls(calls, L, P, st, B, R, dev):
                                    2 * R * B * 256 * 2 + rows * (Hh * 2 + 4 * Hh * 2 + Hh * 2))
         calls['row_proj_stats'] = (lambda: L.dic_row_proj_stats(P(xdec), P(w1), P(b1), R * B, 256, 128, P(zfc), P(sums), P(ws9), ws9.numel(), st),
                                    R * B * (256 * 2 + 128 * 2))                                # x once; z out (+ the column sums)
+        # the decoder's input gradient dX = dG . W_ih (round 5: 256 x 256 macro-tiles, csrc/dic_dxproj.hip; a library GEMM until round 4): dG once, dX out
+        wih_t = (torch.randn((256, 8 * Hh), **f32) * 0.06).to(bf)
+        dxd = torch.empty((R * B, 256), device=dev, dtype=bf)
+        if R * B >= 256:
+            calls['lstm_dx_tile'] = (lambda: L.dic_lstm_dx_tile(P(ldgx), P(wih_t), R * B, 8 * Hh, 256, P(dxd), st) + 0 * len(keep2),
+                                     R * B * (8 * Hh * 2 + 256 * 2))
         calls['fc_bwd'] = (lambda: L.dic_fc_bwd(P(dzfc), P(xdec), P(w1), R * B, 256, 128, P(dxfc), P(dw1), P(ws10), ws10.numel(), st),
                            R * B * (128 * 2 + 256 * 2 + 256 * 2))                               # dz, x in; dx out
 
@@ -952,7 +958,7 @@ def main():
                       'dec_fwd': 'dic::dec_fwd_kernel', 'dec_bwd': 'dic::dec_bwd_kernel', 'lstm_fwd': ('dic::lstm_fwd8_gxn_kernel', 'dic::lstm_fwd_kernel'),
                       'lstm_fwd_proj': ('dic::lstm_fwd8_proj_kernel', 'dic::lstm_fwd_kernel'), 'lstm_bwd': ('dic::lstm_bwd8_kernel', 'dic::lstm_bwd_kernel'), 'lstm_dw': 'dic::lstm_dw_kernel',
                       'row_proj': 'dic::row_proj_kernel', 'row_proj_stats': 'dic::row_proj_kernel', 'fc_bwd': 'dic::fc_bwd_kernel',
-                      'lstm_dw_wide': 'dic::lstm_dw_wide_kernel', 'lstm_fwd_xproj': 'dic::lstm_fwdx8_kernel'}
+                      'lstm_dw_wide': 'dic::lstm_dw_wide_kernel', 'lstm_fwd_xproj': 'dic::lstm_fwdx8_kernel', 'lstm_dx_tile': 'dic::dx_tile_kernel'}
         kernels = groups = None
         ran = [0]
 

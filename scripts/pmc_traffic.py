@@ -10,7 +10,7 @@ KEYS = {'sci_cci_fwd_kernel': 'sci_cci_fwd', 'sci_cci_bwd_kernel': 'sci_cci_bwd'
         'masked_sse_kernel': 'masked_sse_fwd', 'masked_sse_bwd_kernel': 'masked_sse_bwd', 'dec_fwd_kernel': 'dec_fwd',
         'dec_bwd_kernel': 'dec_bwd', 'lstm_fwd_kernel<0>': 'lstm_fwd', 'lstm_fwd_kernel<2>': 'lstm_fwd', 'lstm_fwd8_gxn_kernel': 'lstm_fwd', 'lstm_fwd_kernel<1>': 'lstm_fwd_proj', 'lstm_fwd8_proj_kernel': 'lstm_fwd_proj', 'lstm_fwdx8_kernel': 'lstm_fwd_xproj',
         'lstm_bwd_kernel': 'lstm_bwd', 'lstm_bwd8_kernel': 'lstm_bwd', 'rbf_bwd_wave_kernel': 'rbf_bwd', 'lstm_dw_kernel': 'lstm_dw', 'lstm_dw_wide_kernel': 'lstm_dw_wide',
-        'row_proj_kernel<8': 'row_proj', 'row_proj_kernel<4': 'row_proj_stats', 'fc_bwd_kernel': 'fc_bwd'}
+        'row_proj_kernel<8': 'row_proj', 'row_proj_kernel<4': 'row_proj_stats', 'fc_bwd_kernel': 'fc_bwd', 'dx_tile_kernel': 'lstm_dx_tile'}
 
 
 def match(kernel_name, pat):
