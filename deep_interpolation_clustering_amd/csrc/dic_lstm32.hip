@@ -530,228 +530,6 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
     }
 }
 
-// ---- the same kernel with the step SOFTWARE-PIPELINED inside each wave (round 5; DIC_FWDX_PIPE=0 keeps the one above).  Timing-only builds of the kernel above
-// (scripts/fwdx_experiments.sh) show a step to be the SUM of its parts: the 32 projection MFMAs per wave cost their full serial time (230 of 932 us), the gate
-// arithmetic its own (44-107 us), the x staging 118 us -- the two waves of a SIMD run the same phase at the same time, so the matrix pipe idles through the
-// vector phase and the vector pipe through the matrix phase.  Here the wave's two MFMA row blocks are re-cut so that each is SELF-CONTAINED -- block b = all four
-// gates of units 16 w8 + 8 b + {0..7} (A row m -> gate m >> 3, unit m & 7) instead of a gate pair of 16 units; a lane owns the same eight units as before, so the
-// saved-state layout and every store address are unchanged -- and the instruction stream of a step interleaves one block's MFMAs with the other block's gate
-// arithmetic:     R0 | R1 + V0 | P0' + V1 | P1' + x staging | barrier        (R = recurrent MFMAs, V = gate arithmetic, P' = NEXT step's projection MFMAs)
-// The next step's projection reads the x tile staged during the previous step (still two x buffers: a step's tile is dead once the step before it has projected it).  Same arithmetic per element in the
-// same order: outputs bit-identical to lstm_fwdx8_kernel.
-constexpr int XPB = 2;                  // x tile buffers: the tile of step t is dead once step t - 1 has projected it
-constexpr int XPRK = 160;               // input columns of W_ih in registers (80); the other XPLK = 96: 104 KB of LDS
-constexpr int XPLK = XI - XPRK;
-constexpr int XPLP = XPLK + 8;
-__global__ __launch_bounds__(512, 1) void lstm_fwdx8p_kernel(FwdXArgs a) {
-    typedef __bf16 T;
-    typedef sbf16x4 V4;
-    constexpr int HP = Rec<T>::PITCH(SH);
-    extern __shared__ __align__(16) unsigned char fsm32[];
-    T* hbuf0 = reinterpret_cast<T*>(fsm32);                 // [2][SROWS*HP]
-    T* xbuf = hbuf0 + 2 * SROWS * HP;                        // [XPB][SROWS*XIP]
-    float* bsm = reinterpret_cast<float*>(xbuf + XPB * SROWS * XIP);    // [4H]
-    T* wl = reinterpret_cast<T*>(bsm + S4);                              // [4H][XPLP]
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = w8 >> 1, qh = w8 & 1;
-    const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
-    const int nbt = gridDim.x, bt = blockIdx.x;
-    const int b = b0 + r;
-    const bool ok = b < B;
-    const int bc = min(b, B - 1);
-
-    // A rows of block blk: m = lane & 31 -> gate m >> 3, unit 16 w8 + 8 blk + (m & 7)
-    sbf16x8 wh[2][SH / 16], wx[2][XPRK / 16];
-    const int arow[2] = {(r >> 3) * SH + 16 * w8 + (r & 7), (r >> 3) * SH + 16 * w8 + 8 + (r & 7)};
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const size_t row = (size_t)dir * S4 + arow[blk];
-#pragma unroll
-        for (int ks = 0; ks < SH / 16; ++ks) wh[blk][ks] = *reinterpret_cast<const sbf16x8*>(a.whh + row * SH + ks * 16 + 8 * hh);
-#pragma unroll
-        for (int ks = 0; ks < XPRK / 16; ++ks) wx[blk][ks] = *reinterpret_cast<const sbf16x8*>(a.wih + row * XI + ks * 16 + 8 * hh);
-    }
-    for (int i = tid; i < S4; i += 512) bsm[i] = (float)a.bias[(size_t)dir * S4 + i];
-    for (int i = tid; i < S4 * (XPLK / 8); i += 512) {
-        const int row = i / (XPLK / 8), pc = i % (XPLK / 8);
-        *reinterpret_cast<sbf16x8*>(wl + row * XPLP + pc * 8) = *reinterpret_cast<const sbf16x8*>(a.wih + ((size_t)dir * S4 + row) * XI + XPRK + pc * 8);
-    }
-
-    float c[8];                      // element e = 4 qq + j: unit 16 w8 + 8 qq + 4 hh + j  (block qq, accumulator register 4 gate + j)
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-        const int u = 16 * w8 + 8 * qq + 4 * hh;
-        sf32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-            if (a.h0) hv = *reinterpret_cast<const sf32x4*>(a.h0 + sstate_off(a.bm, dir, b, B) + u);
-            if (a.c0) cv = *reinterpret_cast<const sf32x4*>(a.c0 + sstate_off(a.bm, dir, b, B) + u);
-        }
-        V4 hb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; c[4 * qq + j] = cv[j]; }
-        *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
-        if (a.boundary && ok) {
-            T* slot = dir ? a.out + (size_t)R * B * 2 * SH : a.out - (size_t)B * 2 * SH;
-            *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
-        }
-    }
-    typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
-    const int xrow = tid >> 4, xpc = tid & 15;               // pieces xpc, xpc + 16 of row xrow
-    xu32x4 xn[2];
-    auto load_x = [&](int step) {
-        const int t = dir ? R - 1 - step : step;
-        const T* src = a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * XI;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) xn[k] = *reinterpret_cast<const xu32x4*>(src + (xpc + 16 * k) * 8);
-    };
-    auto land_x = [&](int buf) {
-        T* dst = xbuf + buf * SROWS * XIP + xrow * XIP;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            xu32x4 v = xn[k];
-            if (a.relu_x) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned neg = ((v[e] >> 15) & 0x00010001u) * 0xFFFFu;
-                    v[e] &= ~neg;
-                }
-            }
-            *reinterpret_cast<xu32x4*>(dst + (xpc + 16 * k) * 8) = v;
-        }
-    };
-    sf32x16 acc[2];
-    // bias -> accumulators of block blk: register 4 gate + j <- bias[gate][16 w8 + 8 blk + 4 hh + j]
-    auto bias_in = [&](int blk) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const sf32x4 bv = *reinterpret_cast<const sf32x4*>(bsm + g * SH + 16 * w8 + 8 * blk + 4 * hh);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[blk][4 * g + j] = bv[j];
-        }
-    };
-    // the 16 projection MFMAs of block blk on the x tile in buffer xb (B fragments through a four-deep register ring)
-    auto proj = [&](int blk, int xb) {
-        const T* xcur = xbuf + xb * SROWS * XIP + r * XIP;
-        constexpr int NK = XI / 16, NKR = XPRK / 16, DEPTH = 4;
-        sbf16x8 ring[DEPTH];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(xcur + i * 16 + 8 * hh);
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            if (ks < NKR) {
-                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wx[blk][ks], ring[ks % DEPTH], acc[blk], 0, 0, 0);
-            } else {
-                const sbf16x8 a0 = *reinterpret_cast<const sbf16x8*>(wl + arow[blk] * XPLP + (ks - NKR) * 16 + 8 * hh);
-                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ring[ks % DEPTH], acc[blk], 0, 0, 0);
-            }
-            if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(xcur + (ks + DEPTH) * 16 + 8 * hh);
-        }
-    };
-
-    // prologue: x tiles of steps 0 and 1 staged, step 2's in flight; both blocks' projections of step 0
-    load_x(0);
-    land_x(0);
-    if (R > 1) { load_x(1); land_x(1); }
-    if (R > 2) load_x(2);
-    __syncthreads();
-    bias_in(0); proj(0, 0);
-    bias_in(1); proj(1, 0);
-
-    for (int step = 0; step < R; ++step) {
-        const int t = dir ? R - 1 - step : step;
-        const int cur = step & 1;
-        const T* hcur = hbuf0 + cur * SROWS * HP;
-        T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
-        const bool last = step == R - 1;
-        const size_t row = (size_t)t * B + bc;
-        const int xnb = (step + 1) % XPB;                     // buffer of the NEXT step's x tile (staged during the previous step)
-        // gate arithmetic + stores of block qq (accumulator registers 4 gate + j; elements c[4 qq + j])
-        auto gate = [&](int qq) {
-            const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
-            V4 hb, ib, fb, gb, ob, cb;
-            sf32x4 cv, hv;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 4 * qq + j;
-                const float ig = sigmoid_acc<T>(acc[qq][j]), fg = sigmoid_acc<T>(acc[qq][4 + j]), gg = tanh_acc<T>(acc[qq][8 + j]), og = sigmoid_acc<T>(acc[qq][12 + j]);
-                const float cn = fmaf(fg, c[k], ig * gg);
-                const float hn = og * tanh_acc<T>(cn);
-                c[k] = cn;
-                cv[j] = cn; hv[j] = hn;
-                hb[j] = (T)hn; ib[j] = (T)ig; fb[j] = (T)fg; gb[j] = (T)gg; ob[j] = (T)og; cb[j] = (T)cn;
-            }
-            *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
-            if (a.gates) {
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 0, q, hh, r)) = ib;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 1, q, hh, r)) = fb;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 2, q, hh, r)) = gb;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 3, q, hh, r)) = ob;
-                *reinterpret_cast<V4*>(a.cs + snative_off(t, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cb;
-            }
-            if (ok) {
-                *reinterpret_cast<V4*>(a.out + row * 2 * SH + dir * SH + u) = hb;
-                if (a.out_r) {
-                    V4 hr;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) hr[j] = (T)fmaxf(hv[j], 0.f);
-                    *reinterpret_cast<V4*>(a.out_r + row * 2 * SH + dir * SH + u) = hr;
-                }
-                if (last) {
-                    *reinterpret_cast<sf32x4*>(a.hn + sstate_off(a.bm, dir, b, B) + u) = hv;
-                    *reinterpret_cast<sf32x4*>(a.cn + sstate_off(a.bm, dir, b, B) + u) = cv;
-                }
-            }
-        };
-        // the eight recurrent MFMAs of block blk (h fragments through a four-deep register ring: each block reads them itself -- keeping all eight
-        // alive across block 0's gate arithmetic spills)
-        auto rec = [&](int blk) {
-            constexpr int NK = SH / 16, DEPTH = 4;
-            sbf16x8 ring[DEPTH];
-#pragma unroll
-            for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(hcur + r * HP + i * 16 + 8 * hh);
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[blk][ks], ring[ks % DEPTH], acc[blk], 0, 0, 0);
-                if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(hcur + r * HP + (ks + DEPTH) * 16 + 8 * hh);
-            }
-        };
-        // ---- R0: the recurrent MFMAs of block 0
-        rec(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- R1 + V0: block 1's recurrent MFMAs go out between the vector instructions of block 0's gate arithmetic
-        rec(1);
-        gate(0);
-#pragma unroll
-        for (int i = 0; i < SH / 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);     // a dozen vector instructions
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- P0' + V1: the NEXT step's projection of block 0 between block 1's gate arithmetic
-        if (!last) {
-            bias_in(0);
-            proj(0, xnb);
-        }
-        gate(1);
-        if (!last) {
-#pragma unroll
-            for (int i = 0; i < XI / 16; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- P1' + the x tile of step + 2 -> LDS, the loads of step + 3
-        if (!last) {
-            bias_in(1);
-            proj(1, xnb);
-        }
-        if (step + 2 < R) land_x((step + 2) % XPB);             // (its buffer held the tile of THIS step, which the previous step projected: nobody reads it any more)
-        if (step + 3 < R) load_x(step + 3);
-        lds_barrier();
-    }
-}
-
 template <typename T>
 struct RecBwdArgs {
     const T* whh;          // (2,4H,H) -- read transposed (strided) once at start-up;  or whh_t (2,H,4H) when `transposed`
@@ -1726,18 +1504,14 @@ int dic_lstm_fwd_xproj(const void* x, const void* wih, const void* whh, const vo
     FwdXArgs a{(const T*)x, (const T*)wih, (const T*)whh, (const T*)bias, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B,
                (state_flags & 1) != 0, (state_flags & 2) != 0, relu_x != 0, (T*)out_r};
     const dim3 grid(2 * ((B + 63) / 64), 2);       // 32-row tiles of a batch padded to 64 rows: the tile count dic_lstm_bwd indexes the saved state with
-    // DIC_FWDX_PIPE=0: the kernel without the in-wave software pipeline (A/B switch, read per call; outputs are bit-identical)
-    const char* pe = getenv("DIC_FWDX_PIPE");
-    const bool pipe = pe && pe[0] == '1';          // (work in progress: off by default)
-    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)2 * SROWS * XIP + (size_t)S4 * (pipe ? XPLP : X8LP)) * sizeof(T) + (size_t)S4 * sizeof(float);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[pipe]) {
-        hipError_t e = hipFuncSetAttribute(pipe ? (const void*)lstm_fwdx8p_kernel : (const void*)lstm_fwdx8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)2 * SROWS * XIP + (size_t)S4 * X8LP) * sizeof(T) + (size_t)S4 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_fwdx8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_fwd_xproj: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-        attr_set[pipe] = true;
+        attr_set = true;
     }
-    if (pipe) hipLaunchKernelGGL(lstm_fwdx8p_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(lstm_fwdx8_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(lstm_fwdx8_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
     return check_launch("lstm_fwd_xproj");
 }
 
