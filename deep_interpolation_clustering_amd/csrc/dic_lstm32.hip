@@ -329,7 +329,7 @@ struct FwdXArgs {
 constexpr int XI = 256;                 // decoder input width (2H)
 constexpr int XIP = XI + 8;             // LDS row pitch of the x tile (528 B: conflict-free 16-B reads)
 
-constexpr int X8RK = 192;               // input columns of W_ih held in registers (96 registers); the other X8LK: 72 KB of LDS
+constexpr int X8RK = 176;               // input columns of W_ih held in registers (88 registers; 192 until the x tile took a second register set); the other X8LK: 90 KB of LDS
 constexpr int X8LK = XI - X8RK;
 constexpr int X8LP = X8LK + 8;
 
@@ -342,6 +342,17 @@ __device__ __forceinline__ float fx_tanh(float x) { return x * 0.5f; }
 #else
 __device__ __forceinline__ float fx_sigmoid(float x) { return sigmoid_acc<__bf16>(x); }
 __device__ __forceinline__ float fx_tanh(float x) { return tanh_acc<__bf16>(x); }
+#endif
+
+#ifdef DIC_FWDX_EXP_TIMING      // experiment: per-phase cycle stamps of lane 0 of every wave of workgroup (7, 0) (scripts/fwdx_timing.py)
+__device__ unsigned long long dic_fwdx_stamps[8][32][8];
+#define FX_STAMP(step, slot)                                                                                          \
+    do {                                                                                                              \
+        if (blockIdx.x == 7 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (step) < 32)                              \
+            dic_fwdx_stamps[threadIdx.x >> 6][step][slot] = __builtin_readcyclecounter();                              \
+    } while (0)
+#else
+#define FX_STAMP(step, slot) do {} while (0)
 #endif
 
 __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
@@ -399,18 +410,21 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
     // x tile of a step: 32 rows x 32 pieces of 16 B, two per thread; rectified on the way into LDS
     typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
     const int xrow = tid >> 4, xpc = tid & 15;               // pieces xpc, xpc + 16
-    xu32x4 xn[2];
+    // The x tile of a step is requested TWO steps ahead (two register sets, chosen by the step's parity -- the loop is unrolled by two): cycle stamps of
+    // the kernel with one step of distance (scripts/fwdx_timing.py, round 5) show the wave that lands the tile waiting 950-2150 of a step's 8 540 cycles
+    // for loads issued a whole step (4.85 us) earlier -- behind ~190 stores per workgroup and step a load takes ~6 us to come back.
+    xu32x4 xn[2][2];
     auto load_x = [&](int step) {
         const int t = dir ? R - 1 - step : step;
         const T* src = a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * XI;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) xn[k] = *reinterpret_cast<const xu32x4*>(src + (xpc + 16 * k) * 8);
+        for (int k = 0; k < 2; ++k) xn[step & 1][k] = *reinterpret_cast<const xu32x4*>(src + (xpc + 16 * k) * 8);
     };
-    auto land_x = [&](int buf) {
-        T* dst = xbuf + buf * SROWS * XIP + xrow * XIP;
+    auto land_x = [&](int step) {
+        T* dst = xbuf + (step & 1) * SROWS * XIP + xrow * XIP;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            xu32x4 v = xn[k];
+            xu32x4 v = xn[step & 1][k];
             if (a.relu_x) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -424,6 +438,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
     load_x(0);
     land_x(0);
     if (R > 1) load_x(1);
+    if (R > 2) load_x(2);
     __syncthreads();
     // (Running the two waves of a SIMD half a step apart -- one wave's projection MFMAs under the other's gate arithmetic, x tiles staged two steps ahead --
     //  was tried: no change, 0.76 ms without the saved-state stores either way.  A step costs the sum of its parts: 96 MFMAs and ~590 vector instructions per
@@ -434,6 +449,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
         const T* hcur = hbuf0 + cur * SROWS * HP;
         T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
         const T* xcur = xbuf + cur * SROWS * XIP + r * XIP;
+        FX_STAMP(step, 0);
         sf32x16 acc[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -468,6 +484,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
                 if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(xcur + (ks + DEPTH) * 16 + 8 * hh);
             }
         }
+        FX_STAMP(step, 1);
         {
             sbf16x8 hf[SH / 16];
 #pragma unroll
@@ -478,12 +495,14 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][ks], hf[ks], acc[1], 0, 0, 0);
             }
         }
+        FX_STAMP(step, 2);
 #ifndef DIC_FWDX_EXP_NOXLOAD
-        if (step + 1 < R) land_x(cur ^ 1);               // the x tile of the next step -> the other buffer (nobody reads it during this step)
-        if (step + 2 < R) load_x(step + 2);
+        if (step + 1 < R) land_x(step + 1);              // the x tile of the next step -> the other buffer (nobody reads it during this step)
+        if (step + 3 < R) load_x(step + 3);              // ... into the register set that just emptied
 #endif
         const bool last = step == R - 1;
         const size_t row = (size_t)t * B + bc;
+        FX_STAMP(step, 3);
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
             const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
@@ -526,7 +545,9 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
                 }
             }
         }
+        FX_STAMP(step, 4);
         lds_barrier();
+        FX_STAMP(step, 5);
     }
 }
 
@@ -1514,6 +1535,12 @@ int dic_lstm_fwd_xproj(const void* x, const void* wih, const void* whh, const vo
     hipLaunchKernelGGL(lstm_fwdx8_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
     return check_launch("lstm_fwd_xproj");
 }
+
+#ifdef DIC_FWDX_EXP_TIMING
+int dic_fwdx_debug_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dic_fwdx_stamps), sizeof(unsigned long long) * 8 * 32 * 8);
+}
+#endif
 
 size_t dic_lstm_rec_bwd_workspace(int B) {
     if (B <= 0) return 0;

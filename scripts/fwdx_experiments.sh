@@ -7,6 +7,10 @@ build() {
   rm -f deep_interpolation_clustering_amd/csrc/dic_lstm32.o
   make -s -C deep_interpolation_clustering_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$PWD/include -Wall -Wno-unused-function $1" > /dev/null 2>&1
 }
+if [ "$1" == "timing" ]; then
+  build "-DDIC_FWDX_EXP_TIMING"; python3 scripts/fwdx_timing.py 2>/dev/null; python3 scripts/fwdx_timing.py nosave 2>/dev/null
+  build ""; exit 0
+fi
 if [ $# -eq 0 ]; then set -- "" "-DDIC_FWDX_EXP_NOTRANS" "-DDIC_FWDX_EXP_NOGATE" "-DDIC_FWDX_EXP_NOPROJ" "-DDIC_FWDX_EXP_NOXLOAD" "-DDIC_FWDX_EXP_NOPROJ -DDIC_FWDX_EXP_NOGATE" "-fno-slp-vectorize" ""; fi
 for flags in "$@"; do
   build "$flags"; echo "== flags: [$flags]"
