@@ -327,9 +327,9 @@ struct FwdXArgs {
     __bf16* out_r;                  // optional (R,B,2H): relu(out), for a consumer that rectifies the output (as dic_lstm_fwd's out_r)
 };
 constexpr int XI = 256;                 // decoder input width (2H)
-constexpr int XIP = XI + 8;             // LDS row pitch of the x tile (528 B: conflict-free 16-B reads)
 
-constexpr int X8RK = 176;               // input columns of W_ih held in registers (88 registers; 192 until the x tile took a second register set); the other X8LK: 90 KB of LDS
+constexpr int X8RK = 192;               // input columns of W_ih held in registers (96 registers); the other X8LK: 72 KB of LDS
+constexpr int XNB = 3;                  // x tile buffers: one being read, one landed and rectified, one in flight
 constexpr int X8LK = XI - X8RK;
 constexpr int X8LP = X8LK + 8;
 
@@ -361,8 +361,8 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
     constexpr int HP = Rec<T>::PITCH(SH);
     extern __shared__ __align__(16) unsigned char fsm32[];
     T* hbuf0 = reinterpret_cast<T*>(fsm32);                 // [2][SROWS*HP]
-    T* xbuf = hbuf0 + 2 * SROWS * HP;                        // [2][SROWS*XIP]
-    float* bsm = reinterpret_cast<float*>(xbuf + 2 * SROWS * XIP);      // [4H]
+    T* xbuf = hbuf0 + 2 * SROWS * HP;                        // [XNB][SROWS][XI], 16-B piece p of row r at p ^ (r & 15)
+    float* bsm = reinterpret_cast<float*>(xbuf + XNB * SROWS * XI);     // [4H]
     T* wl = reinterpret_cast<T*>(bsm + S4);                              // [4H][X8LP]
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = w8 >> 1, qh = w8 & 1;
@@ -407,39 +407,69 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
             *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
         }
     }
-    // x tile of a step: 32 rows x 32 pieces of 16 B, two per thread; rectified on the way into LDS
+    // x tile of a step: 32 rows x 512 B.  Round 5: by LDS-DMA (asm: the compiler does not count it) straight into one of THREE tile buffers, one step ahead,
+    // behind a COUNTED vmcnt wait -- cycle stamps of the register-staged form (scripts/fwdx_timing.py) showed 950-2150 of a step's 8 540 cycles in
+    // `s_waitcnt vmcnt(0)`: with loads and stores both pending the compiler's wait for a load drains the queue, i.e. every step waited for the previous
+    // step's ~24 saved-state stores per wave to be acknowledged.  A DMA instruction fills 1 KiB = two rows in lane order, so the rows lie unpadded and the
+    // bank spread of the fragment reads comes from a permutation applied through the per-lane SOURCE address: piece p of row r sits at p ^ (r & 15) (the 16
+    // rows of a ds_read_b128 lane group then cover all 64 banks).  Each thread rectifies the two pieces its own DMA lanes landed, in place, one step before
+    // the tile is read (sign bit -> zero).
     typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
-    const int xrow = tid >> 4, xpc = tid & 15;               // pieces xpc, xpc + 16
-    // The x tile of a step is requested TWO steps ahead (two register sets, chosen by the step's parity -- the loop is unrolled by two): cycle stamps of
-    // the kernel with one step of distance (scripts/fwdx_timing.py, round 5) show the wave that lands the tile waiting 950-2150 of a step's 8 540 cycles
-    // for loads issued a whole step (4.85 us) earlier -- behind ~190 stores per workgroup and step a load takes ~6 us to come back.
-    xu32x4 xn[2][2];
-    auto load_x = [&](int step) {
+    const unsigned xlds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)xbuf);
+    unsigned xv[2];                                          // per-lane source byte offsets of this wave's two DMA pieces (rows 2 c, 2 c + 1; c = w8 + 8 j)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 2 * (w8 + 8 * j) + (lane >> 5), p = (lane & 31) ^ (row & 15);
+        xv[j] = (unsigned)min(b0 + row, B - 1) * (unsigned)(XI * sizeof(T)) + (unsigned)p * 16u;
+    }
+    auto dma_x = [&](int step) {
         const int t = dir ? R - 1 - step : step;
-        const T* src = a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * XI;
+        const T* src = a.x + (size_t)t * B * XI;
+        const unsigned dst = xlds0 + (step % XNB) * (SROWS * XI * (int)sizeof(T));
 #pragma unroll
-        for (int k = 0; k < 2; ++k) xn[step & 1][k] = *reinterpret_cast<const xu32x4*>(src + (xpc + 16 * k) * 8);
-    };
-    auto land_x = [&](int step) {
-        T* dst = xbuf + (step & 1) * SROWS * XIP + xrow * XIP;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            xu32x4 v = xn[step & 1][k];
-            if (a.relu_x) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned neg = ((v[e] >> 15) & 0x00010001u) * 0xFFFFu;
-                    v[e] &= ~neg;
-                }
-            }
-            *reinterpret_cast<xu32x4*>(dst + (xpc + 16 * k) * 8) = v;
+        for (int j = 0; j < 2; ++j) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(xv[j]), "s"(src), "s"(dst + (w8 + 8 * j) * 1024) : "memory");
         }
     };
-    load_x(0);
-    land_x(0);
-    if (R > 1) load_x(1);
-    if (R > 2) load_x(2);
+    auto rectify_x = [&](int step) {                          // this thread's own two landed pieces of the tile of `step`
+        if (!a.relu_x) return;
+        unsigned char* base = reinterpret_cast<unsigned char*>(xbuf) + (step % XNB) * (SROWS * XI * (int)sizeof(T)) + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            xu32x4* pp = reinterpret_cast<xu32x4*>(base + (w8 + 8 * j) * 1024);
+            xu32x4 v = *pp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned neg = ((v[e] >> 15) & 0x00010001u) * 0xFFFFu;
+                v[e] &= ~neg;
+            }
+            *pp = v;
+        }
+    };
+    // fragment reads: row r, logical piece 2 ks + hh -> byte offset ((32 ks) ^ khi) + klo inside the row
+    const int xkey = (r & 15) * 16, xklo = (hh * 16) ^ (xkey & 16), xkhi = xkey & 0xE0;
+    dma_x(0);
+    if (R > 1) dma_x(1);
+    if (R > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // tile 0 has landed (tile 1's two pieces may still be in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    rectify_x(0);
     __syncthreads();
+    // pieces A and B (`delta` elements apart) of the lane-native saved state, one 16-B store per lane (see the store comment in the step loop)
+    const bool odd = lane & 1;
+    const int pslot = (hh * 32 + (r & ~1)) * 4;                 // the even lane's slot of the pair, in elements
+    auto pair_store = [&](T* piece_a, V4 va, V4 vb, int delta) {
+        typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
+        const su32x2 ua = __builtin_bit_cast(su32x2, va), ub = __builtin_bit_cast(su32x2, vb);
+        const unsigned s0 = odd ? ua[0] : ub[0], s1 = odd ? ua[1] : ub[1];                       // what the neighbour stores: the odd lane's A, the even lane's B
+        const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]: lanes 2 i <-> 2 i + 1
+        const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+        uint4 v;
+        v.x = odd ? r0 : ua[0]; v.y = odd ? r1 : ua[1];
+        v.z = odd ? ub[0] : r0; v.w = odd ? ub[1] : r1;
+        *reinterpret_cast<uint4*>(piece_a + pslot + (odd ? delta : 0)) = v;
+    };
     // (Running the two waves of a SIMD half a step apart -- one wave's projection MFMAs under the other's gate arithmetic, x tiles staged two steps ahead --
     //  was tried: no change, 0.76 ms without the saved-state stores either way.  A step costs the sum of its parts: 96 MFMAs and ~590 vector instructions per
     //  SIMD, 160 of them quarter-rate exp / rcp: 3.9 us, against 3.0 us of HBM time for its 64 KB.)
@@ -448,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
         const int cur = step & 1;
         const T* hcur = hbuf0 + cur * SROWS * HP;
         T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
-        const T* xcur = xbuf + cur * SROWS * XIP + r * XIP;
+        const unsigned char* xcur = reinterpret_cast<const unsigned char*>(xbuf) + (step % XNB) * (SROWS * XI * (int)sizeof(T)) + r * (XI * (int)sizeof(T)) + xklo;
         FX_STAMP(step, 0);
         sf32x16 acc[2];
 #pragma unroll
@@ -465,7 +495,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
             constexpr int NK = XI / 16, NKR = X8RK / 16, DEPTH = 4;
             sbf16x8 ring[DEPTH];
 #pragma unroll
-            for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(xcur + i * 16 + 8 * hh);
+            for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(xcur + ((32 * i) ^ xkhi));
 #pragma unroll
 #ifdef DIC_FWDX_EXP_NOPROJ
             for (int ks = 0; ks < 1; ++ks) {
@@ -481,7 +511,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ring[ks % DEPTH], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ring[ks % DEPTH], acc[1], 0, 0, 0);
                 }
-                if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(xcur + (ks + DEPTH) * 16 + 8 * hh);
+                if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(xcur + ((32 * (ks + DEPTH)) ^ xkhi));
             }
         }
         FX_STAMP(step, 1);
@@ -497,12 +527,20 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
         }
         FX_STAMP(step, 2);
 #ifndef DIC_FWDX_EXP_NOXLOAD
-        if (step + 1 < R) land_x(step + 1);              // the x tile of the next step -> the other buffer (nobody reads it during this step)
-        if (step + 3 < R) load_x(step + 3);              // ... into the register set that just emptied
+        // the tile of step + 1 (requested during step - 1) has landed once only what this wave issued AFTER its two DMA instructions is still in flight:
+        // the saved-state stores of step - 1 (5 per wave: 16 B per lane; the `out` store may have been branched over) -- a counted wait, never a drain
+        if (step + 1 < R) {
+            if (a.gates) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rectify_x(step + 1);
+        }
+        if (step + 2 < R) dma_x(step + 2);                   // (its buffer held the tile of step - 1: every wave is past the barrier that closed that step)
 #endif
         const bool last = step == R - 1;
         const size_t row = (size_t)t * B + bc;
         FX_STAMP(step, 3);
+        V4 cb0 = {}, hb0 = {};
+        sf32x4 hv0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
             const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
@@ -524,25 +562,43 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
                 hb[j] = (T)hn; ib[j] = (T)ig; fb[j] = (T)fg; gb[j] = (T)gg; ob[j] = (T)og; cb[j] = (T)cn;
             }
             *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
+            // ---- stores, 16 B per lane (round 5).  Eight-byte stores cap a CU at ~7 B per cycle (store issue, MI355X_MICROARCH.md: the epilogue store
+            // tail) and this kernel writes 5.9: cycle stamps show the second wave of every SIMD stuck in its store phase.  The lane-native layout keeps a
+            // lane's four elements of a (gate, block) piece at slot (hh, r) of a 512-B piece, so NEIGHBOURING lanes hold neighbouring 8-B slots: lanes
+            // 2 i and 2 i + 1 trade (one quad-permute per dword) so that the even lane holds both lanes' values of piece A (16 B at its own slot) and the odd
+            // lane both lanes' values of piece B (16 B at the even lane's slot of B): one 16-B store per lane covers two whole pieces.  Same bytes, same
+            // addresses as the two 8-B stores it replaces.
             if (a.gates) {
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 0, q, hh, r)) = ib;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 1, q, hh, r)) = fb;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 2, q, hh, r)) = gb;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 3, q, hh, r)) = ob;
-                *reinterpret_cast<V4*>(a.cs + snative_off(t, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cb;
+                const size_t g0 = snative_off(t, nbt, bt, dir, w4, 4, 0, q, 0, 0), c0o = snative_off(t, nbt, bt, dir, w4, 1, 0, 2 * qh, 0, 0);
+                pair_store(a.gates + g0, ib, fb, 1024);                    // gates i | f: pieces 1024 elements apart
+                pair_store(a.gates + g0 + 2 * 1024, gb, ob, 1024);         // gates g | o
+                if (qq == 0) cb0 = cb;
+                else pair_store(a.cs + c0o, cb0, cb, 256);                 // cell state of blocks 0 | 1: pieces 256 elements apart
             }
-            if (ok) {
-                *reinterpret_cast<V4*>(a.out + row * 2 * SH + dir * SH + u) = hb;
+            if (qq == 0) { hb0 = hb; hv0 = hv; }
+            else if (ok) {
+                // output rows: the halves of a wave hold units +0..3 / +4..7 (block 0) and +8..11 / +12..15 (block 1) of the same row: one
+                // v_permlane32_swap per dword makes that +0..7 in the lower half and +8..15 in the upper one
+                auto out16 = [&](T* base, V4 lo, V4 hi) {
+                    typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
+                    const su32x2 x = __builtin_bit_cast(su32x2, lo), y = __builtin_bit_cast(su32x2, hi);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(x[0], y[0], false, false);      // x of lanes 32..63 <-> y of lanes 0..31
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(x[1], y[1], false, false);
+                    uint4 v;
+                    v.x = s0[0]; v.y = s1[0]; v.z = s0[1]; v.w = s1[1];
+                    *reinterpret_cast<uint4*>(base + row * 2 * SH + dir * SH + 16 * w8 + 8 * hh) = v;
+                };
+                out16(a.out, hb0, hb);
                 if (a.out_r) {
-                    V4 hr;
+                    V4 hr0, hr1;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) hr[j] = (T)fmaxf(hv[j], 0.f);
-                    *reinterpret_cast<V4*>(a.out_r + row * 2 * SH + dir * SH + u) = hr;
+                    for (int j = 0; j < 4; ++j) { hr0[j] = (T)fmaxf(hv0[j], 0.f); hr1[j] = (T)fmaxf(hv[j], 0.f); }
+                    out16(a.out_r, hr0, hr1);
                 }
-                if (last) {
-                    *reinterpret_cast<sf32x4*>(a.hn + sstate_off(a.bm, dir, b, B) + u) = hv;
-                    *reinterpret_cast<sf32x4*>(a.cn + sstate_off(a.bm, dir, b, B) + u) = cv;
-                }
+            }
+            if (ok && last) {
+                *reinterpret_cast<sf32x4*>(a.hn + sstate_off(a.bm, dir, b, B) + u) = hv;
+                *reinterpret_cast<sf32x4*>(a.cn + sstate_off(a.bm, dir, b, B) + u) = cv;
             }
         }
         FX_STAMP(step, 4);
@@ -1525,7 +1581,7 @@ int dic_lstm_fwd_xproj(const void* x, const void* wih, const void* whh, const vo
     FwdXArgs a{(const T*)x, (const T*)wih, (const T*)whh, (const T*)bias, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B,
                (state_flags & 1) != 0, (state_flags & 2) != 0, relu_x != 0, (T*)out_r};
     const dim3 grid(2 * ((B + 63) / 64), 2);       // 32-row tiles of a batch padded to 64 rows: the tile count dic_lstm_bwd indexes the saved state with
-    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)2 * SROWS * XIP + (size_t)S4 * X8LP) * sizeof(T) + (size_t)S4 * sizeof(float);
+    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)XNB * SROWS * XI + (size_t)S4 * X8LP) * sizeof(T) + (size_t)S4 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)lstm_fwdx8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
