@@ -327,9 +327,9 @@ struct FwdXArgs {
     __bf16* out_r;                  // optional (R,B,2H): relu(out), for a consumer that rectifies the output (as dic_lstm_fwd's out_r)
 };
 constexpr int XI = 256;                 // decoder input width (2H)
+constexpr int XIP = XI + 8;             // LDS row pitch of the x tile (528 B: conflict-free 16-B reads)
 
 constexpr int X8RK = 192;               // input columns of W_ih held in registers (96 registers); the other X8LK: 72 KB of LDS
-constexpr int XNB = 3;                  // x tile buffers: one being read, one landed and rectified, one in flight
 constexpr int X8LK = XI - X8RK;
 constexpr int X8LP = X8LK + 8;
 
@@ -361,8 +361,8 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
     constexpr int HP = Rec<T>::PITCH(SH);
     extern __shared__ __align__(16) unsigned char fsm32[];
     T* hbuf0 = reinterpret_cast<T*>(fsm32);                 // [2][SROWS*HP]
-    T* xbuf = hbuf0 + 2 * SROWS * HP;                        // [XNB][SROWS][XI], 16-B piece p of row r at p ^ (r & 15)
-    float* bsm = reinterpret_cast<float*>(xbuf + XNB * SROWS * XI);     // [4H]
+    T* xbuf = hbuf0 + 2 * SROWS * HP;                        // [2][SROWS*XIP]
+    float* bsm = reinterpret_cast<float*>(xbuf + 2 * SROWS * XIP);      // [4H]
     T* wl = reinterpret_cast<T*>(bsm + S4);                              // [4H][X8LP]
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = w8 >> 1, qh = w8 & 1;
@@ -407,54 +407,37 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
             *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
         }
     }
-    // x tile of a step: 32 rows x 512 B.  Round 5: by LDS-DMA (asm: the compiler does not count it) straight into one of THREE tile buffers, one step ahead,
-    // behind a COUNTED vmcnt wait -- cycle stamps of the register-staged form (scripts/fwdx_timing.py) showed 950-2150 of a step's 8 540 cycles in
-    // `s_waitcnt vmcnt(0)`: with loads and stores both pending the compiler's wait for a load drains the queue, i.e. every step waited for the previous
-    // step's ~24 saved-state stores per wave to be acknowledged.  A DMA instruction fills 1 KiB = two rows in lane order, so the rows lie unpadded and the
-    // bank spread of the fragment reads comes from a permutation applied through the per-lane SOURCE address: piece p of row r sits at p ^ (r & 15) (the 16
-    // rows of a ds_read_b128 lane group then cover all 64 banks).  Each thread rectifies the two pieces its own DMA lanes landed, in place, one step before
-    // the tile is read (sign bit -> zero).
+    // x tile of a step: 32 rows x 32 pieces of 16 B, two per thread; rectified on the way into LDS.  (Round 5 tried the tile by LDS-DMA into three swizzled
+    // buffers behind a counted vmcnt wait -- the compiler's wait for these register loads is `vmcnt(0)`, a drain of the step's stores -- and two steps of
+    // distance through two register sets: interleaved two-library A/Bs, scripts/two_lib_ab.py: DMA 951-969 us against 936-941 with 8-B stores, ~900 against
+    // ~878 with the paired 16-B stores below; two register sets 1 089 us.  With five 16-B stores per wave and step the drain is short; the register form stays.)
     typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
-    const unsigned xlds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)xbuf);
-    unsigned xv[2];                                          // per-lane source byte offsets of this wave's two DMA pieces (rows 2 c, 2 c + 1; c = w8 + 8 j)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 2 * (w8 + 8 * j) + (lane >> 5), p = (lane & 31) ^ (row & 15);
-        xv[j] = (unsigned)min(b0 + row, B - 1) * (unsigned)(XI * sizeof(T)) + (unsigned)p * 16u;
-    }
-    auto dma_x = [&](int step) {
+    const int xrow = tid >> 4, xpc = tid & 15;               // pieces xpc, xpc + 16
+    xu32x4 xn[2];
+    auto load_x = [&](int step) {
         const int t = dir ? R - 1 - step : step;
-        const T* src = a.x + (size_t)t * B * XI;
-        const unsigned dst = xlds0 + (step % XNB) * (SROWS * XI * (int)sizeof(T));
+        const T* src = a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * XI;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(xv[j]), "s"(src), "s"(dst + (w8 + 8 * j) * 1024) : "memory");
-        }
+        for (int k = 0; k < 2; ++k) xn[k] = *reinterpret_cast<const xu32x4*>(src + (xpc + 16 * k) * 8);
     };
-    auto rectify_x = [&](int step) {                          // this thread's own two landed pieces of the tile of `step`
-        if (!a.relu_x) return;
-        unsigned char* base = reinterpret_cast<unsigned char*>(xbuf) + (step % XNB) * (SROWS * XI * (int)sizeof(T)) + lane * 16;
+    auto land_x = [&](int buf) {
+        T* dst = xbuf + buf * SROWS * XIP + xrow * XIP;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            xu32x4* pp = reinterpret_cast<xu32x4*>(base + (w8 + 8 * j) * 1024);
-            xu32x4 v = *pp;
+        for (int k = 0; k < 2; ++k) {
+            xu32x4 v = xn[k];
+            if (a.relu_x) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned neg = ((v[e] >> 15) & 0x00010001u) * 0xFFFFu;
-                v[e] &= ~neg;
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned neg = ((v[e] >> 15) & 0x00010001u) * 0xFFFFu;
+                    v[e] &= ~neg;
+                }
             }
-            *pp = v;
+            *reinterpret_cast<xu32x4*>(dst + (xpc + 16 * k) * 8) = v;
         }
     };
-    // fragment reads: row r, logical piece 2 ks + hh -> byte offset ((32 ks) ^ khi) + klo inside the row
-    const int xkey = (r & 15) * 16, xklo = (hh * 16) ^ (xkey & 16), xkhi = xkey & 0xE0;
-    dma_x(0);
-    if (R > 1) dma_x(1);
-    if (R > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // tile 0 has landed (tile 1's two pieces may still be in flight)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    rectify_x(0);
+    load_x(0);
+    land_x(0);
+    if (R > 1) load_x(1);
     __syncthreads();
     // pieces A and B (`delta` elements apart) of the lane-native saved state, one 16-B store per lane (see the store comment in the step loop)
     const bool odd = lane & 1;
@@ -478,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
         const int cur = step & 1;
         const T* hcur = hbuf0 + cur * SROWS * HP;
         T* hnxt = hbuf0 + (cur ^ 1) * SROWS * HP;
-        const unsigned char* xcur = reinterpret_cast<const unsigned char*>(xbuf) + (step % XNB) * (SROWS * XI * (int)sizeof(T)) + r * (XI * (int)sizeof(T)) + xklo;
+        const T* xcur = xbuf + cur * SROWS * XIP + r * XIP;
         FX_STAMP(step, 0);
         sf32x16 acc[2];
 #pragma unroll
@@ -495,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
             constexpr int NK = XI / 16, NKR = X8RK / 16, DEPTH = 4;
             sbf16x8 ring[DEPTH];
 #pragma unroll
-            for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(xcur + ((32 * i) ^ xkhi));
+            for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const sbf16x8*>(xcur + i * 16 + 8 * hh);
 #pragma unroll
 #ifdef DIC_FWDX_EXP_NOPROJ
             for (int ks = 0; ks < 1; ++ks) {
@@ -511,7 +494,7 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ring[ks % DEPTH], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ring[ks % DEPTH], acc[1], 0, 0, 0);
                 }
-                if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(xcur + ((32 * (ks + DEPTH)) ^ xkhi));
+                if (ks + DEPTH < NK) ring[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(xcur + (ks + DEPTH) * 16 + 8 * hh);
             }
         }
         FX_STAMP(step, 1);
@@ -527,14 +510,8 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
         }
         FX_STAMP(step, 2);
 #ifndef DIC_FWDX_EXP_NOXLOAD
-        // the tile of step + 1 (requested during step - 1) has landed once only what this wave issued AFTER its two DMA instructions is still in flight:
-        // the saved-state stores of step - 1 (5 per wave: 16 B per lane; the `out` store may have been branched over) -- a counted wait, never a drain
-        if (step + 1 < R) {
-            if (a.gates) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            rectify_x(step + 1);
-        }
-        if (step + 2 < R) dma_x(step + 2);                   // (its buffer held the tile of step - 1: every wave is past the barrier that closed that step)
+        if (step + 1 < R) land_x(cur ^ 1);               // the x tile of the next step -> the other buffer (nobody reads it during this step)
+        if (step + 2 < R) load_x(step + 2);
 #endif
         const bool last = step == R - 1;
         const size_t row = (size_t)t * B + bc;
@@ -568,15 +545,33 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
             // 2 i and 2 i + 1 trade (one quad-permute per dword) so that the even lane holds both lanes' values of piece A (16 B at its own slot) and the odd
             // lane both lanes' values of piece B (16 B at the even lane's slot of B): one 16-B store per lane covers two whole pieces.  Same bytes, same
             // addresses as the two 8-B stores it replaces.
+#ifdef DIC_FWDX_EXP_NOPAIR       // (A/B: round 4's 8-B stores)
             if (a.gates) {
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 0, q, hh, r)) = ib;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 1, q, hh, r)) = fb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 2, q, hh, r)) = gb;
+                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 3, q, hh, r)) = ob;
+                *reinterpret_cast<V4*>(a.cs + snative_off(t, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cb;
+                (void)cb0; (void)pair_store;
+            }
+            if (ok) *reinterpret_cast<V4*>(a.out + row * 2 * SH + dir * SH + u) = hb;
+            (void)hb0; (void)hv0;
+            if (false) {
+#else
+            if (a.gates) {
+#endif
                 const size_t g0 = snative_off(t, nbt, bt, dir, w4, 4, 0, q, 0, 0), c0o = snative_off(t, nbt, bt, dir, w4, 1, 0, 2 * qh, 0, 0);
                 pair_store(a.gates + g0, ib, fb, 1024);                    // gates i | f: pieces 1024 elements apart
                 pair_store(a.gates + g0 + 2 * 1024, gb, ob, 1024);         // gates g | o
                 if (qq == 0) cb0 = cb;
                 else pair_store(a.cs + c0o, cb0, cb, 256);                 // cell state of blocks 0 | 1: pieces 256 elements apart
             }
+#ifdef DIC_FWDX_EXP_NOPAIR
+            if (false) {
+#else
             if (qq == 0) { hb0 = hb; hv0 = hv; }
             else if (ok) {
+#endif
                 // output rows: the halves of a wave hold units +0..3 / +4..7 (block 0) and +8..11 / +12..15 (block 1) of the same row: one
                 // v_permlane32_swap per dword makes that +0..7 in the lower half and +8..15 in the upper one
                 auto out16 = [&](T* base, V4 lo, V4 hi) {
@@ -1581,7 +1576,7 @@ int dic_lstm_fwd_xproj(const void* x, const void* wih, const void* whh, const vo
     FwdXArgs a{(const T*)x, (const T*)wih, (const T*)whh, (const T*)bias, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B,
                (state_flags & 1) != 0, (state_flags & 2) != 0, relu_x != 0, (T*)out_r};
     const dim3 grid(2 * ((B + 63) / 64), 2);       // 32-row tiles of a batch padded to 64 rows: the tile count dic_lstm_bwd indexes the saved state with
-    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)XNB * SROWS * XI + (size_t)S4 * X8LP) * sizeof(T) + (size_t)S4 * sizeof(float);
+    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)2 * SROWS * XIP + (size_t)S4 * X8LP) * sizeof(T) + (size_t)S4 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)lstm_fwdx8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
