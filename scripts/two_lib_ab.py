@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of one entry point between TWO builds of libdic_hip.so in one process (boxes drift by several per cent within a run, so builds are
-timed alternately, several rounds): DIC_AB_LIB=<second .so> python3 scripts/two_lib_ab.py {fwd_proj|fwd_xproj} [B] [rounds]"""
+timed alternately, several rounds): DIC_AB_LIB=<second .so> python3 scripts/two_lib_ab.py {fwd_proj|fwd_xproj|bwd} [B] [rounds]"""
 import ctypes as C
 import os
 import sys
@@ -29,7 +29,7 @@ hn, cn = torch.empty(2, B, H, device=dev), torch.empty(2, B, H, device=dev)
 gates, cs = torch.empty(R, Bp, 2, 4, H, device=dev, dtype=bf), torch.empty(R + 1, Bp, 2, H, device=dev, dtype=bf)
 whh = (torch.randn(2, 4 * H, H, device=dev) * 0.08).to(bf)
 st = N.stream_of(out)
-if what == 'fwd_proj':
+if what == 'fwd_proj' or what == 'bwd':
     x = torch.randn(R, B, 32, device=dev).to(bf)
     wih = (torch.randn(2, 4 * H, 32, device=dev) * 0.1).to(bf)
 
@@ -42,9 +42,25 @@ else:
 
     def call(L):
         return lambda: N.check(L.dic_lstm_fwd_xproj(P(x), P(wih), P(whh), P(bias), None, None, R, B, H, 256, P(out[1]), None, P(hn), P(cn), P(gates), P(cs), 0, 1, st), what)
+if what == 'bwd':
+    # the 64-row backward on the state a forward saved: lstm_bwd8 (dic_lstm_bwd)
+    x = torch.randn(R, B, 32, device=dev).to(bf)
+    wih = (torch.randn(2, 4 * H, 32, device=dev) * 0.1).to(bf)
+    N.check(LA.dic_lstm_fwd_proj(P(x), P(wih), P(whh), None, None, R, B, H, 32, P(out[1]), None, P(hn), P(cn), P(gates), P(cs), 0, 0, 1, st), 'fwd')
+    whh_t = whh.transpose(1, 2).contiguous()
+    dout = (torch.randn(R, B, 2 * H, device=dev) * 0.1).to(bf)
+    dgx = torch.empty(R, B, 2, 4, H, device=dev, dtype=bf)
+    dh0, dc0, db = torch.empty(2, B, H, device=dev), torch.empty(2, B, H, device=dev), torch.empty(2, 4 * H, device=dev)
+    ws = torch.empty(max(16, LA.dic_lstm_bwd_workspace(B)), dtype=torch.uint8, device=dev)
+
+    def call(L):
+        return lambda: N.check(L.dic_lstm_bwd(P(whh_t), P(gates), P(cs), None, P(dout), None, None, R, B, H, P(dgx), P(dh0), P(dc0), P(db), P(ws), ws.numel(), 0, 0, st), what)
+    chk = lambda: (dgx.float().abs().sum().item(), dh0.abs().sum().item(), dc0.abs().sum().item())
+else:
+    chk = lambda: (out[1:R + 1].float().abs().sum().item(), gates.float().abs().sum().item(), cs[:R].float().abs().sum().item())
 a, b = call(LA), call(LB)
-a(); sa = (out.float().abs().sum().item(), gates.float().abs().sum().item(), cs[:R].float().abs().sum().item())
-b(); sb = (out.float().abs().sum().item(), gates.float().abs().sum().item(), cs[:R].float().abs().sum().item())
+a(); sa = chk()
+b(); sb = chk()
 print('checksums A', sa, 'B', sb)
 ta, tb = [], []
 for _ in range(rounds):
