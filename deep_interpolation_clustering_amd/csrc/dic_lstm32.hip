@@ -453,6 +453,10 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
         v.z = odd ? ub[0] : r0; v.w = odd ? ub[1] : r1;
         *reinterpret_cast<uint4*>(piece_a + pslot + (odd ? delta : 0)) = v;
     };
+    // (Round 5 also tried the overlap INSIDE a wave, twice: the row blocks re-cut so that each holds all four gates of eight units (same lane <-> unit map, so
+    //  bit-identical outputs), then (a) the next step's projection MFMAs between this step's gate arithmetic (three x tiles; 23 registers over budget: 933-961 us
+    //  against 942-945) and (b) block 1's 24 MFMAs between block 0's gate arithmetic, no extra state (252 registers: 933 against 868 us, interleaved A/B).  The
+    //  two waves of a SIMD already fill each other's gaps; interleaving within one only adds fragment re-reads and pipe switches.)
     // (Running the two waves of a SIMD half a step apart -- one wave's projection MFMAs under the other's gate arithmetic, x tiles staged two steps ahead --
     //  was tried: no change, 0.76 ms without the saved-state stores either way.  A step costs the sum of its parts: 96 MFMAs and ~590 vector instructions per
     //  SIMD, 160 of them quarter-rate exp / rcp: 3.9 us, against 3.0 us of HBM time for its 64 KB.)
@@ -545,33 +549,15 @@ __global__ __launch_bounds__(512, 1) void lstm_fwdx8_kernel(FwdXArgs a) {
             // 2 i and 2 i + 1 trade (one quad-permute per dword) so that the even lane holds both lanes' values of piece A (16 B at its own slot) and the odd
             // lane both lanes' values of piece B (16 B at the even lane's slot of B): one 16-B store per lane covers two whole pieces.  Same bytes, same
             // addresses as the two 8-B stores it replaces.
-#ifdef DIC_FWDX_EXP_NOPAIR       // (A/B: round 4's 8-B stores)
             if (a.gates) {
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 0, q, hh, r)) = ib;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 1, q, hh, r)) = fb;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 2, q, hh, r)) = gb;
-                *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 3, q, hh, r)) = ob;
-                *reinterpret_cast<V4*>(a.cs + snative_off(t, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cb;
-                (void)cb0; (void)pair_store;
-            }
-            if (ok) *reinterpret_cast<V4*>(a.out + row * 2 * SH + dir * SH + u) = hb;
-            (void)hb0; (void)hv0;
-            if (false) {
-#else
-            if (a.gates) {
-#endif
                 const size_t g0 = snative_off(t, nbt, bt, dir, w4, 4, 0, q, 0, 0), c0o = snative_off(t, nbt, bt, dir, w4, 1, 0, 2 * qh, 0, 0);
                 pair_store(a.gates + g0, ib, fb, 1024);                    // gates i | f: pieces 1024 elements apart
                 pair_store(a.gates + g0 + 2 * 1024, gb, ob, 1024);         // gates g | o
                 if (qq == 0) cb0 = cb;
                 else pair_store(a.cs + c0o, cb0, cb, 256);                 // cell state of blocks 0 | 1: pieces 256 elements apart
             }
-#ifdef DIC_FWDX_EXP_NOPAIR
-            if (false) {
-#else
             if (qq == 0) { hb0 = hb; hv0 = hv; }
             else if (ok) {
-#endif
                 // output rows: the halves of a wave hold units +0..3 / +4..7 (block 0) and +8..11 / +12..15 (block 1) of the same row: one
                 // v_permlane32_swap per dword makes that +0..7 in the lower half and +8..15 in the upper one
                 auto out16 = [&](T* base, V4 lo, V4 hi) {
