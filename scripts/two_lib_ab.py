@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of one entry point between TWO builds of libdic_hip.so in one process (boxes drift by several per cent within a run, so builds are
-timed alternately, several rounds): DIC_AB_LIB=<second .so> python3 scripts/two_lib_ab.py {fwd_proj|fwd_xproj|bwd} [B] [rounds]"""
+timed alternately, several rounds): DIC_AB_LIB=<second .so> python3 scripts/two_lib_ab.py {fwd_proj|fwd_xproj|bwd|dx} [B] [rounds]"""
 import ctypes as C
 import os
 import sys
@@ -42,7 +42,16 @@ else:
 
     def call(L):
         return lambda: N.check(L.dic_lstm_fwd_xproj(P(x), P(wih), P(whh), P(bias), None, None, R, B, H, 256, P(out[1]), None, P(hn), P(cn), P(gates), P(cs), 0, 1, st), what)
-if what == 'bwd':
+if what == 'dx':
+    rows = R * B
+    dg = (torch.randn(rows, 1024, device=dev) * 0.3).to(bf)
+    wt = (torch.randn(256, 1024, device=dev) * 0.06).to(bf)
+    dxo = torch.empty(rows, 256, device=dev, dtype=bf)
+
+    def call(L):
+        return lambda: N.check(L.dic_lstm_dx_tile(P(dg), P(wt), rows, 1024, 256, P(dxo), st), what)
+    chk = lambda: (dxo.float().abs().sum().item(),)
+elif what == 'bwd':
     # the 64-row backward on the state a forward saved: lstm_bwd8 (dic_lstm_bwd)
     x = torch.randn(R, B, 32, device=dev).to(bf)
     wih = (torch.randn(2, 4 * H, 32, device=dev) * 0.1).to(bf)
@@ -56,7 +65,7 @@ if what == 'bwd':
     def call(L):
         return lambda: N.check(L.dic_lstm_bwd(P(whh_t), P(gates), P(cs), None, P(dout), None, None, R, B, H, P(dgx), P(dh0), P(dc0), P(db), P(ws), ws.numel(), 0, 0, st), what)
     chk = lambda: (dgx.float().abs().sum().item(), dh0.abs().sum().item(), dc0.abs().sum().item())
-else:
+elif True:
     chk = lambda: (out[1:R + 1].float().abs().sum().item(), gates.float().abs().sum().item(), cs[:R].float().abs().sum().item())
 a, b = call(LA), call(LB)
 a(); sa = chk()
