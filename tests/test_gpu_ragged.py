@@ -255,3 +255,43 @@ def test_unsorted_and_duplicate_time_stamps_through_the_store(C, T, R, lam):
     store, rb, with_bisection = both_paths(xt, True)
     store.times_sorted = False                                        # the same rows through the full pass
     assert torch.equal(ops.sci_cci(rb, sk, ck, grid), with_bisection)
+
+
+def test_device_built_cohort_store_equals_the_host_built_one_and_steps():
+    """bench.py times BASELINE configs[3] on a cohort built ON the device (synthetic.device_cohort_store -> RaggedStore.from_device / concat: the padded planes of
+    300 000 x 12 x 288 would be 16.6 GB).  The device-built store must equal the host constructor on the same planes field for field, and a joint step on a
+    shuffled batch of it must equal the step on the padded batch bit for bit (same kernels, same samples)."""
+    from types import SimpleNamespace
+
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    dev = torch.device('cuda')
+    C, T, K = 12, 288, 16
+    store, pheno = synthetic.device_cohort_store(300, C, T, 24.0, 200.0, K, 4, dev, chunk=128)      # three chunks, joined
+    assert store.N == 300 and store.times_sorted and pheno.shape == (300,) and int(pheno.max()) < K
+    x = store.dense_rows(torch.arange(300, device=dev), masked_values=True)                          # (300, 4C, T) planes rebuilt from the packed rows
+    host = RaggedStore(x.cpu().numpy(), C, dev)
+    for name in ('t_pk', 'v_pk', 'hold_pk', 'row_off', 'lengths', 'pad_value'):
+        assert torch.equal(getattr(store, name), getattr(host, name)), name
+    whole = RaggedStore.from_device(x, C)
+    assert torch.equal(whole.t_pk, store.t_pk) and torch.equal(whole.row_off, store.row_off)
+    args = SimpleNamespace(num_variables=C, num_timestamps=T, ref_points=24, hours_from_admission=24.0, dropout=0.0, aux_tasks={}, fake_detection=False,
+                           triple_margin=0.0, cluster_number=K, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.}, aux_pos_weights={})
+    idx = torch.randperm(300, device=dev, generator=torch.Generator(device=dev).manual_seed(2))[:192].to(torch.int32)
+    res = []
+    for ragged in (True, False):
+        torch.manual_seed(3)
+        net = Net(args, dev).to(dev)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=torch.bfloat16)
+        if ragged:
+            losses, gnorm, _ = st.step(RaggedBatch(store, idx), None, None)
+        else:
+            xb = x.index_select(0, idx.to(torch.int64))
+            losses, gnorm, _ = st.step(xb, xb[:, :C].contiguous(), None, store.lengths.index_select(0, idx.to(torch.int64)))
+        res.append((float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(losses['kl'].detach()), float(gnorm)))
+    assert res[0] == res[1] and all(np.isfinite(res[0])), res
