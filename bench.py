@@ -49,7 +49,6 @@ def parse():
                    help="upstream's default unsupervised loss ae_mse_fake_detect_kl (p3:78 minus the private supervised labels): "
                         "sci/cci/encoder run a second time on corrupted samples; NOT the headline configuration")
     p.add_argument('--dropout', type=float, default=0.0, help='CompressFC / head dropout (upstream default 0.2; the headline uses 0)')
-    p.add_argument('--no-tuned-gemm', action='store_true', help='library GEMMs with the default heuristics instead of the shipped table')
     p.add_argument('--cpu-seconds', type=float, default=15.0)
     p.add_argument('--no-secondary', action='store_true', help='skip the secondary records (cfg4, cfg5, batch256, f32, loss deviation)')
     p.add_argument('--no-sweep', action='store_true', help='skip the p2 K=2..20 sweep inside the cfg5 record')
@@ -862,8 +861,6 @@ def main():
     torch.cuda.set_device(dev)
     K = a.clusters or (8 if world == 8 else 4)
     args = make_args(K, a.fake_detection, a.dropout)
-    from deep_interpolation_clustering_amd import tuned
-    gemm_table = (not a.no_tuned_gemm) and a.dtype == 'bf16' and tuned.enable()      # read-only: pre-tuned hipBLASLt / rocBLAS picks
 
     # ---- cohort shard, resident in HBM before anything is timed
     strong = a.scaling == 'strong'
@@ -1062,7 +1059,7 @@ def main():
                                'f32': 'every tensor and product f32: exact-f32 MFMA recurrence, f32 library GEMMs',
                                'f32x3': 'every tensor f32; every dense product a three-term bf16 split (hi.hi + lo.hi + hi.lo) on the bf16 matrix cores '
                                         'with f32 accumulation: no library GEMM; losses within 1e-5 of the reference (loss_rel_dev_vs_oracle)'}[a.dtype], echo=False)
-        sec.add('config_detail', {'tuned_gemm_table': bool(gemm_table), 'padded_array_MB': round(n_enc * 4 * C * T * 4 / 1e6),
+        sec.add('config_detail', {'padded_array_MB': round(n_enc * 4 * C * T * 4 / 1e6),
                                   'index_order': 'shuffled (a per-run randperm of the cohort, as the trainers\' DeviceLoader draws batches)' if shuffled
                                                  else 'file order (contiguous rows)'}, echo=False)
         sec.add('roofline_detail', roofline_detail, echo=False)

@@ -83,7 +83,6 @@ SIGNATURES = {
     'dic_lstm_dw': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
     'dic_lstm_dw_wide_workspace': (_sz, [_i, _i]),
     'dic_lstm_dw_wide': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
-    'dic_lstm_dx_wide': (_i, [_p, _p, C.c_int64, _i, _i, _p, _p]),
     'dic_lstm_dx_tile': (_i, [_p, _p, C.c_int64, _i, _i, _p, _p]),
     'dic_lstm_unpack_grads': (_i, [_p, _i, _p, _p, _i, _i, _p, _i, _p]),
     'dic_row_proj': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _i, _i, _p]),

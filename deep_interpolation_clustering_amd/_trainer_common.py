@@ -36,9 +36,6 @@ class TrainerBase(object):
         autocast = torch.bfloat16 if (getattr(args, 'amp_bf16', False) and device.type == 'cuda') else None
         if autocast is not None and getattr(args, 'f32_products', None) is not None:
             raise ValueError('f32_products selects how the f32 step forms its dense products; it does not combine with amp_bf16')
-        if autocast is not None:
-            from . import tuned
-            tuned.enable()                       # pre-tuned library GEMM picks for the step's shapes (read-only; tuned.py)
         self.stepper = Stepper(self.model, lambda m: pytorch_optimizer(m, args.optimizer, args.init_lr, args.weight_decay_rate),
                                args, autocast_dtype=autocast, precision=(getattr(args, 'f32_products', None) if autocast is None else None),
                                use_graphs=False if getattr(args, 'no_hip_graph', False) else (True if getattr(args, 'hip_graph', None) else 'auto'))
@@ -193,7 +190,8 @@ class TrainerBase(object):
         total = len(dl)
         for i_batch, (batch_sample, fake_batch_sample) in enumerate(dl, start=1):
             b = self._prepare(batch_sample, fake_batch_sample, denoise, train=True)
-            losses, _, _ = self.stepper.step(b['x'], b['ob'], b['padding_mask'], b['lengths'], **self._model_kwargs(b))
+            losses, _, _ = self.stepper.step(b['x'], b['ob'], b['padding_mask'], b['lengths'], global_rows=b['sample'].get('global_rows'),
+                                              **self._model_kwargs(b))
             for k, v in losses.items():
                 sums[k] = sums[k] + v.detach()
             n_batches += 1
@@ -220,7 +218,7 @@ class TrainerBase(object):
                 for k, v in losses.items():
                     sums[k] = sums[k] + v
                 n_batches += 1
-                rec = {k: v for k, v in b['sample'].items() if k not in ('lengths', 'ragged')}      # inputs + labels, as upstream dumps them
+                rec = {k: v for k, v in b['sample'].items() if k not in ('lengths', 'ragged', 'global_rows')}      # inputs + labels, as upstream dumps them
                 if getattr(self.args, 'cpu_padded_ob', False) and torch.is_tensor(rec.get('ob')) and torch.is_tensor(rec.get('padding_mask')):
                     # upstream masks the observations IN PLACE before the forward (`ob *= padding_mask`, clustering_trainer.py:299-303): on a CPU run
                     # `.to(device)` is the identity, so the loader's tensor -- the one the dump keeps -- is the masked one (padded slots 0 ->

@@ -937,7 +937,7 @@ static bool bwd_lane_ok(int C, int R, bool with_cci, bool packed, int xw) {
 static int bwd_lane_blocks(int B, bool packed = true) {
     const int per_block = 2 * (kBlock / kWave);          // encounters per workgroup and trip
     const char* e = getenv("DIC_K1_BWD_LANE_WGS");          // workgroups per CU (tuning knob; default: 3 = one round at 123-131 registers)
-    const int per_cu = e ? max(1, atoi(e)) : 3;
+    const int per_cu = (e && e[0]) ? max(1, atoi(e)) : 3;
     (void)packed;
     return max(1, min((B + per_block - 1) / per_block, per_cu * kNumCU));
 }

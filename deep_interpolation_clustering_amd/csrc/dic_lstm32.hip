@@ -1432,7 +1432,7 @@ static bool rec_eight_waves() {
 // flip it -- forward and backward of one LSTM call must see the same value, the saved-state layouts differ)
 static int rec16_max_batch() {
     const char* e = getenv("DIC_REC16_MAX");
-    return e ? atoi(e) : REC16_MAX_BATCH;
+    return (e && e[0]) ? atoi(e) : REC16_MAX_BATCH;          // (an empty value is the switch unset)
 }
 static bool rec_sixteen(int B) {
     const char* e = getenv("DIC_REC_SIXTEEN");

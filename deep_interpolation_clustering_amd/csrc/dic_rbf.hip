@@ -937,7 +937,7 @@ static bool rbf_bwd_wave_geometry(int B, int C, int T, int R, int* nblk, size_t*
 // wave-per-encounter kernel where both apply (A/B)
 static int rbf_bwd_slot_mode() {
     const char* e = getenv("DIC_RBF_BWD_SLOT");
-    return e ? atoi(e) : 1;
+    return (e && e[0]) ? atoi(e) : 1;
 }
 static bool rbf_bwd_slot_geometry(int B, int C, int R, int* nblk) {
     if (R > 24 || rbf_bwd_slot_mode() == 0) return false;

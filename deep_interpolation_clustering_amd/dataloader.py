@@ -264,7 +264,7 @@ class DeviceLoader:
         order = order_h.to(self.device)
         C = self.C
         for b in range(len(self)):
-            _, _, lo, hi = self._bounds(b)
+            glo, ghi, lo, hi = self._bounds(b)
             idx, idx_h = order[lo:hi], order_h[lo:hi].numpy()
             lengths = None if self.lengths is None else self.lengths.index_select(0, idx)
             aug = self.ds.transform.aug
@@ -274,7 +274,7 @@ class DeviceLoader:
                 rb = RaggedBatch(self.store, idx, lengths)
                 dense = self.dense_samples if self.dense_samples is not None else (not self.shuffle or self.ds.fake_detection or aug)
                 if not dense:          # the training pass of the plain objectives: nothing reads the padded tensors
-                    sample = {'encounter_id': self.ids[idx_h], 'lengths': lengths, 'ragged': rb}
+                    sample = {'encounter_id': self.ids[idx_h], 'lengths': lengths, 'ragged': rb, 'global_rows': ghi - glo}
                     for k, v in self.aux.items():
                         sample[k] = v.index_select(0, idx)
                     yield sample, sample
@@ -290,7 +290,7 @@ class DeviceLoader:
                 ob = self._noise(ob, mask, self.ds.aug_std)
                 ts = self._noise(ts, mask, 0.01)
             sample = {'encounter_id': self.ids[idx_h], 'ob': ob, 'padding_mask': mask, 'timestamp': ts,
-                      'ae_mask': ae, 'lengths': lengths}
+                      'ae_mask': ae, 'lengths': lengths, 'global_rows': ghi - glo}     # (global_rows: rows of the GLOBAL batch -- step.Stepper's rank-invariant graph key)
             for k, v in self.aux.items():
                 sample[k] = v.index_select(0, idx)
             if rb is not None and not aug:

@@ -149,6 +149,17 @@ def global_mean(local_sum: torch.Tensor, local_count) -> torch.Tensor:
     return _GlobalMean.apply(local_sum, local_count)
 
 
+def all_agree(ok: bool, device=None) -> bool:
+    """True on every rank iff ``ok`` was true on every rank (one MIN all-reduce of one int; not sharded: ``ok``).  A host sync -- for decisions
+    taken once (step.Stepper: did the capture of the sharded step succeed everywhere?), not per step."""
+    if not is_sharded():
+        return bool(ok)
+    on_dev = td.get_backend() == 'nccl'
+    flag = torch.full((1,), 1 if ok else 0, dtype=torch.int32, device=(device if on_dev and device is not None else 'cpu'))
+    td.all_reduce(flag, op=td.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
 def barrier():
     """Rank barrier (no-op when not sharded): rank 0 writes checkpoints / feature files that the other ranks read."""
     if is_sharded():

@@ -45,7 +45,7 @@ RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B sw
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
 REC_PROJ = os.environ.get('DIC_REC_PROJ', '1') != '0'                  # (A/B switch: 0 = dic_gemm_nt + dic_lstm_rec_fwd for the encoder's small-batch forward)
 FWD_XPROJ = os.environ.get('DIC_FWD_XPROJ', '1') != '0'                # (A/B switch: 0 = dic_row_proj + dic_lstm_fwd for the decoder's large-batch forward: gx through HBM)
-SMALL_BATCH = int(os.environ.get('DIC_SMALL_BATCH', 4096))      # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
+SMALL_BATCH = int(os.environ.get('DIC_SMALL_BATCH') or 4096)      # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
 
 
 def _lstm_ok(lstm):
@@ -69,10 +69,7 @@ def f32_available(x, lstm):
 # 6.46 ms); round 3's same-box A/B (3 x 60 steps each) has it LOSING by 0.03-0.07 ms (6.505 vs 6.44-6.48 ms): both kernels are bound by the
 # same HBM, the encoder's lstm_bwd stretches from 0.85 to 1.77 ms while they share the chip, and nothing is hidden.  Off by default.
 DW_SIDE_STREAM = os.environ.get('DIC_DW_SIDE_STREAM', '0') == '1'
-# the decoder's large-batch input gradient dX = dG.W_ih (csrc/dic_dxproj.hip): 2 = dic_lstm_dx_tile (round 5: 256 x 256 macro-tiles, both operands
-# streamed through LDS-DMA rings, every CU takes in its share of dG once), 1 = dic_lstm_dx_wide (round 3: W_ih resident in registers -- measured
-# 571 us against the library's 447 us at B = 32 768, per-CU ingest bound), 0 = library GEMM
-DX_KERNEL = int(os.environ.get('DIC_DX_KERNEL', '2'))
+# the decoder's large-batch input gradient dX = dG.W_ih: dic_lstm_dx_tile (csrc/dic_dxproj.hip; 256 x 256 macro-tiles, both operands through LDS-DMA rings)
 DX_TILE_MIN_ROWS = 256
 _SIDE = {'on': False, 'streams': {}, 'pending': [], 'keep': []}
 RECORD_STREAM = os.environ.get('DIC_SIDE_RECORD_STREAM', '0') == '1'      # (experiment switch: the allocator-side alternative)
@@ -151,7 +148,7 @@ class _BiLstm(torch.autograd.Function):
         bias = None if narrow else torch.empty(8 * H, device=dev, dtype=T)
         L, st = N.lib(), N.stream_of(x)
         # (the decoder's large-batch input gradient runs on dic_lstm_dx_tile, whose weight operand is W_ih^T: packed in the same launch)
-        dx_tile = need and ctx.needs_input_grad[0] and DX_KERNEL == 2 and (not f32) and I == WIDE_INPUT and Ip == I and not small and R * B >= DX_TILE_MIN_ROWS
+        dx_tile = need and ctx.needs_input_grad[0] and (not f32) and I == WIDE_INPUT and Ip == I and not small and R * B >= DX_TILE_MIN_ROWS
         wih_t = torch.empty((Ip, 8 * H), device=dev, dtype=T) if dx_tile else None
         N.check(L.dic_lstm_pack(code, N.ptr_array(pf), H, I, Ip, int(narrow), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), N.ptr(wih_t), st), 'dic_lstm_pack')
         ctx.wih_t = wih_t
@@ -289,14 +286,8 @@ class _BiLstm(torch.autograd.Function):
                 # dic_lstm_pack) streamed through LDS (csrc/dic_dxproj.hip; until round 4: a library GEMM)
                 dx = torch.empty((R * B, Ip), device=dev, dtype=T)
                 N.check(Lb.dic_lstm_dx_tile(N.ptr(dg2), N.ptr(ctx.wih_t), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_tile')
-            elif DX_KERNEL == 1 and (not f32) and I == WIDE_INPUT and Ip == I and R * B >= 32:
-                # decoder: dX = dG . W_ih with the weights resident in registers (round 3; measured slower than the library GEMM)
-                dx = torch.empty((R * B, Ip), device=dev, dtype=T)
-                N.check(Lb.dic_lstm_dx_wide(N.ptr(dg2), N.ptr(wih), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_wide')
             elif f32 and not x3:
                 dx = dg2 @ wih                                       # (R*B, Ip): the exact-f32 parity mode
-            elif (not f32) and I == WIDE_INPUT and not small:
-                dx = dg2 @ wih                                       # DIC_DX_KERNEL=0: the decoder's large-batch dX as a library GEMM (A/B)
             else:
                 dx = _ops.gemm_nt(dg2, wih.t().contiguous())         # dX = dG . W_ih on dic_gemm_nt (W_ih^T: a (Ip, 8H) copy of the packed weights)
             if packed:

@@ -364,11 +364,12 @@ class _RbfRecLoss(torch.autograd.Function):
         # global SSE and global #valid slots.  Sharded: the pair does not pay a latency-bound exchange of its own -- it rides on the next small
         # all-reduce of the step (the KL sum + row count, or the first global-mean loss term: dist.deferred_sum_) and the mean is formed when
         # it lands; step.compute_losses resolves whatever is still pending before it hands the losses out (one packed buffer)
-        mse = torch.empty((), device=x.device, dtype=torch.float32)
         if dist.is_sharded():
+            mse = torch.full((), float('nan'), device=x.device, dtype=torch.float32)      # (NaN until the pair has landed: an early read shows)
             mse_out = mse.detach()
             dist.deferred_sum_(out2, then=lambda: torch.div(out2[0], out2[1], out=mse_out))
         else:
+            mse = torch.empty((), device=x.device, dtype=torch.float32)
             torch.div(out2[0], out2[1], out=mse)
         ctx.dims = (B, C, T, R, bool(tm))
         ctx.sink_params = (rbf_kernel,)
@@ -726,7 +727,7 @@ def splitk_tn(a, b, chunks=(8192, 4096, 2048)):
 #   'x3'     operands split on the fly into bf16 hi + lo pieces, products as hi.hi + lo.hi + hi.lo on the bf16 matrix cores with f32
 #            accumulation (dic_gemm_nt / dic_gemm_tn, the split recurrence kernels): every tensor stays f32, no library GEMM, the step's losses
 #            within ~1e-6 of the reference (tests/test_gpu_traj.py) at several times the exact mode's throughput.
-_F32_PRODUCTS = [os.environ.get('DIC_F32_PRODUCTS', 'exact')]
+_F32_PRODUCTS = [os.environ.get('DIC_F32_PRODUCTS') or 'exact']
 
 
 def f32_products():
@@ -856,7 +857,7 @@ def mfma_linear(x, weight, bias, bias_grad_is_zero=False):
 
 
 FC_BWD_SHAPE = (128, 256)      # dic_fc_bwd's compiled Linear(256, 128)
-FC_BWD_MIN_ROWS = int(os.environ.get('DIC_FC_BWD_MIN_ROWS', 1024))          # (8192 until round 3: the one-node path also wins where the step is launch-bound --
+FC_BWD_MIN_ROWS = int(os.environ.get('DIC_FC_BWD_MIN_ROWS') or 1024)          # (8192 until round 3: the one-node path also wins where the step is launch-bound --
                                                                             # B = 256, 6144 rows: 73 -> 63 launches, 0.708 -> 0.677 ms from the hipGraph; 0.66 -> 0.63 at B = 64)
 
 

@@ -48,6 +48,7 @@ class RaggedStore:
         # channel): kept so that dense_rows() reproduces feed_data bit for bit
         pad = ~mask
         self.pad_value = torch.as_tensor(np.array([fd[:, c][pad[:, c]][0] if pad[:, c].any() else 0.0 for c in range(C)], np.float32), device=device)
+        self.has_pad = torch.as_tensor(np.array([bool(pad[:, c].any()) for c in range(C)]), device=device)      # (a channel with no padded slot SAYS nothing about the constant: concat)
         self.device = device
 
     @classmethod
@@ -62,6 +63,9 @@ class RaggedStore:
         dev = x.device
         mask = x[:, C:2 * C] != 0
         lengths = mask.sum(-1).to(torch.int32)
+        # the host path's preconditions (fits()), checked here too: a mask that is not a prefix would be packed silently and wrongly
+        if not bool((mask == (torch.arange(T, device=dev)[None, None] < lengths[..., None])).all()):
+            raise ValueError('RaggedStore.from_device: the masks are not prefix masks')
         row_off = torch.zeros(N * C + 1, dtype=torch.int64, device=dev)
         torch.cumsum(lengths.reshape(-1), 0, out=row_off[1:])
         total = int(row_off[-1])
@@ -79,10 +83,14 @@ class RaggedStore:
         self.row_off, self.lengths = row_off, lengths
         pad = ~mask
         pv = torch.zeros(C, dtype=torch.float32, device=dev)
+        has = torch.zeros(C, dtype=torch.bool, device=dev)
         for c in range(C):
             if bool(pad[:, c].any()):
-                pv[c] = x[:, c][pad[:, c]][0]
-        self.pad_value = pv
+                vals = x[:, c][pad[:, c]]
+                if not bool((vals == vals[0]).all()):
+                    raise ValueError(f'RaggedStore.from_device: the padding of channel {c} is not one constant')
+                pv[c], has[c] = vals[0], True
+        self.pad_value, self.has_pad = pv, has
         self.device = dev
         return self
 
@@ -92,8 +100,16 @@ class RaggedStore:
         s0 = stores[0]
         if any(s.C != s0.C or s.T != s0.T or torch.device(s.device) != torch.device(s0.device) for s in stores):
             raise ValueError('RaggedStore.concat: the stores differ in C, T or device')
-        if any(not torch.equal(s.pad_value, s0.pad_value) for s in stores):
-            raise ValueError('RaggedStore.concat: the stores differ in their padding constants')
+        # the padding constant of a channel is whatever the stores that HAVE padded slots in it agree on (a chunk whose rows are all full-length
+        # in some channel knows nothing about it and must not veto the others)
+        pad_value, has_pad = s0.pad_value.clone(), s0.has_pad.clone()
+        for s in stores[1:]:
+            both = has_pad & s.has_pad
+            if bool((pad_value[both] != s.pad_value[both]).any()):
+                raise ValueError('RaggedStore.concat: the stores differ in their padding constants')
+            new = s.has_pad & ~has_pad
+            pad_value[new] = s.pad_value[new]
+            has_pad |= s.has_pad
         self = object.__new__(cls)
         self.N, self.C, self.T, self.device = sum(s.N for s in stores), s0.C, s0.T, s0.device
         self.times_sorted = all(s.times_sorted for s in stores)
@@ -109,7 +125,7 @@ class RaggedStore:
             base += int(s.row_off[-1])
         self.row_off = torch.cat(offs + [torch.tensor([base], dtype=torch.int64, device=s0.row_off.device)])
         self.lengths = torch.cat([s.lengths for s in stores])
-        self.pad_value = s0.pad_value
+        self.pad_value, self.has_pad = pad_value, has_pad
         return self
 
     @staticmethod

@@ -1,7 +1,8 @@
 """The ``DIC_*`` environment switches: ONE table (name -> allowed values -> default -> effect), validated once when the native binding is
 imported (``_native.py``).  None is needed in production -- every fast path is on by default and falls back by itself when its shape
-conditions do not hold; the switches exist for A/B measurements and for the tests.  An unknown ``DIC_*`` name or a value outside the allowed
-set raises at import (a typo used to be silently the default); ``INTEGRATION.md`` section 4 is generated from this table
+conditions do not hold; the switches exist for A/B measurements and for the tests.  A value outside the allowed set, or an unknown ``DIC_*`` name
+that is a near miss of a known one, raises at import (a typo used to be silently the default); any other unknown ``DIC_*`` name -- a site's own
+variable, an exported build-macro name -- only warns, and an empty value counts as unset; ``INTEGRATION.md`` section 4 is generated from this table
 (``python -m deep_interpolation_clustering_amd.switches --write``).
 """
 import os
@@ -29,10 +30,9 @@ SWITCHES = {
                            'it 0.03-0.07 ms slower per step: both are bound by the same HBM)'),
     'DIC_SIDE_RECORD_STREAM': (ON_OFF, '0', 'lstm.py', '1: side-stream tensors kept alive through `record_stream` (the allocator-side alternative; experiment)'),
     'DIC_KMEANS_SMALLK_MFMA': (ON_OFF, '1', 'csrc/dic_kmeans_mfma.hip', '0: Lloyd iterations with K <= 8 always on the wave-per-row kernel (round 2), also when several restarts could share X tiles'),
-    'DIC_DX_KERNEL': (('0', '1', '2'), '2', 'lstm.py', 'the decoder\'s large-batch input gradient dX = dG W_ih: 2 = `dic_lstm_dx_tile` (256 x 256 macro-tiles, both operands through '
-                      'LDS-DMA rings; round 5), 1 = `dic_lstm_dx_wide` (weights resident in registers; round 3: measured slower), 0 = library GEMM'),
     'DIC_SHARDED_GRAPHS': (ON_OFF, '1', 'step.py', '0: `Stepper(use_graphs=\'auto\')` never captures a SHARDED step (default: on the `nccl` backend the sharded step of a per-rank batch '
-                           '<= 8192 is replayed from a hipGraph -- RCCL collectives are stream operations; see DESIGN section 6)'),
+                           '<= 8192 is replayed from a hipGraph -- RCCL collectives are stream operations; replay-or-capture is keyed on the GLOBAL batch and a capture counts only '
+                           'when every rank succeeded, else all ranks run eagerly; see DESIGN section 6)'),
     'DIC_DIST_BACKEND': (('nccl', 'gloo'), 'nccl on GPUs', 'dist.py', '`gloo`: several ranks may share one GPU (rehearsal of the N > 1 path)'),
     'DIC_DIST_SINGLE_RANK': (ON_OFF, '0', 'dist.py', '1: a process group of ONE rank counts as sharded (every collective runs on the real backend; tests)'),
     'DIC_GEMM_NT8': (ON_OFF, '1', 'csrc/dic_gemm.hip', '0: four waves per 128 x 128 tile in `dic_gemm_nt` (eight: half the work per wave, twice the waves per CU)'),
@@ -54,21 +54,28 @@ SWITCHES = {
     'DIC_CPU_THREADS_MAX': (INT, '64', 'bench.py', 'cap of the all-usable-cores CPU baseline point'),
     'DIC_AB_LIB': (PATH, '-', 'scripts/', 'A/B scripts: path of the second library build'),
     'DIC_FWD8': (ON_OFF, '1', 'scripts/lstm_ab.py', 'A/B scripts: eight-wave forward variant'),
+    'DIC_REFERENCE': (PATH, '/root/reference', 'oracle/make_golden*.py', 'fixture generation only: where the upstream repository lies'),
 }
 
 
 def validate(environ=None):
-    """Raise ``RuntimeError`` for a ``DIC_*`` variable this build does not know or a value outside its allowed set."""
+    """Raise ``RuntimeError`` for a value outside a switch's allowed set and for an unknown ``DIC_*`` name that is a near miss of a known switch
+    (a typo); warn about any other unknown ``DIC_*`` name (not ours to forbid); an empty value is the switch unset."""
     environ = os.environ if environ is None else environ
-    bad = []
+    bad, foreign = [], []
     for name, value in environ.items():
         if not name.startswith('DIC_'):
             continue
         spec = SWITCHES.get(name)
         if spec is None:
             import difflib
-            near = difflib.get_close_matches(name, SWITCHES, n=1)
-            bad.append(f'{name}: unknown switch' + (f' (did you mean {near[0]}?)' if near else ''))
+            near = difflib.get_close_matches(name, SWITCHES, n=1, cutoff=0.85)
+            if near:
+                bad.append(f'{name}: unknown switch (did you mean {near[0]}?)')
+            else:
+                foreign.append(name)
+            continue
+        if value == '':
             continue
         allowed = spec[0]
         if allowed == INT:
@@ -76,11 +83,11 @@ def validate(environ=None):
                 int(value)
             except ValueError:
                 bad.append(f'{name}={value!r}: an integer is expected')
-        elif allowed == PATH:
-            if not value:
-                bad.append(f'{name}: empty path')
-        elif value not in allowed:
+        elif allowed != PATH and value not in allowed:
             bad.append(f'{name}={value!r}: allowed values are {", ".join(allowed)}')
+    if foreign:
+        import warnings
+        warnings.warn('deep_interpolation_clustering_amd: environment variables ' + ', '.join(sorted(foreign)) + ' are not switches of this build (ignored)')
     if bad:
         raise RuntimeError('environment switches of deep_interpolation_clustering_amd: ' + '; '.join(bad) + ' (table: deep_interpolation_clustering_amd/switches.py)')
 
@@ -91,7 +98,7 @@ def get(name, environ=None):
     if name not in SWITCHES:
         raise KeyError(name)
     validate({name: environ[name]} if name in environ else {})
-    return environ.get(name, SWITCHES[name][1])
+    return environ.get(name) or SWITCHES[name][1]
 
 
 BEGIN, END = '<!-- switches:begin (generated from switches.py) -->', '<!-- switches:end -->'

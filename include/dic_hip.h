@@ -341,12 +341,8 @@ int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const vo
                      const float* dhn, const float* dcn, int R, int B, int H, void* dgx, float* dh0, float* dc0, float* dbias,
                      void* workspace, size_t workspace_bytes, int state_batch_major, int dout_of_relu, dic_stream_t stream);
 
-/* The decoder LSTM's input gradient dX = dG . W_ih (the backward of nn.LSTM's input projection, clustering_interp.py:29-41) with the
- * weights resident in registers: dg (N, gate_columns = 1024) bf16 gate gradients of both directions as dic_lstm_bwd writes them,
- * w_ih (1024, in_features = 256) bf16 (dic_lstm_pack's wih), dx (N, 256) bf16 OVERWRITTEN = the gradient w.r.t. the LSTM's input rows
- * (with input_rectify upstream of a ReLU: w.r.t. relu(x); the mask is the producer's).  N >= 32.  Replaces round 2's library GEMM. */
-int dic_lstm_dx_wide(const void* dg, const void* w_ih, int64_t N, int gate_columns, int in_features, void* dx, dic_stream_t stream);
-/* dic_lstm_dx_tile (round 5): the same product on 256 x 256 macro-tiles with nothing resident -- one persistent 8-wave workgroup per CU, dG slabs
+/* dic_lstm_dx_tile: the decoder LSTM's input gradient dX = dG . W_ih (the backward of nn.LSTM's input projection, clustering_interp.py:29-41; dg (N, 1024)
+ * bf16 gate gradients of both directions as dic_lstm_bwd writes them) on 256 x 256 macro-tiles with nothing resident -- one persistent 8-wave workgroup per CU, dG slabs
  * (HBM) through a 3-slot and W_ih^T slabs (L2) through a 2-slot all-LDS-DMA ring, 16-B stores straight from the accumulators: every CU takes in its
  * row share of dG once.  w_ih_t (in_features = 256, gate_columns = 1024) bf16 = W_ih TRANSPOSED (k contiguous, like the rows of dg); dx (N, 256)
  * bf16 OVERWRITTEN.  N >= 256.  Replaces the last library GEMM of the bf16 step (nn.LSTM's backward: clustering_interp.py:29-41). */

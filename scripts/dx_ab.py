@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The decoder's input gradient dX = dG . W_ih three ways on the same operands (N = 24 x B rows, K = 1024, 256 columns, bf16): the library GEMM,
-dic_lstm_dx_wide (round 3: weights resident) and dic_lstm_dx_tile (round 5: 256 x 256 macro-tiles).  usage: python3 scripts/dx_ab.py [B]"""
+"""The decoder's input gradient dX = dG . W_ih on the same operands (N = 24 x B rows, K = 1024, 256 columns, bf16): dic_lstm_dx_tile (256 x 256
+macro-tiles; the product's only form in the library from round 6 on) beside torch's library GEMM as a yardstick.  usage: python3 scripts/dx_ab.py [B]"""
 import os
 import sys
 
@@ -26,10 +26,6 @@ def lib():
     return dg @ w
 
 
-def wide():
-    N.check(L.dic_lstm_dx_wide(P(dg), P(w), rows, 1024, 256, P(dx), st), 'dx_wide')
-
-
 def tile():
     N.check(L.dic_lstm_dx_tile(P(dg), P(wt), rows, 1024, 256, P(dx), st), 'dx_tile')
 
@@ -44,6 +40,6 @@ tile()
 torch.cuda.synchronize()
 print('max |tile - lib| = %.3e (max |lib| %.3e)' % (float((dx.float() - ref.float()).abs().max()), float(ref.float().abs().max())))
 gb = (rows * 1024 * 2 + rows * 256 * 2) / 1e9
-for name, fn in (('library GEMM', lib), ('dx_wide', wide), ('dx_tile', tile), ('dx_tile + W^T copy', tile_with_transpose), ('library GEMM', lib), ('dx_tile', tile)):
+for name, fn in (('library GEMM', lib), ('dx_tile', tile), ('dx_tile + W^T copy', tile_with_transpose), ('library GEMM', lib), ('dx_tile', tile)):
     ms = bench.time_kernel(fn, 20)
     print('%-20s %8.1f us   %.2f TB/s algorithmic   %.0f TFLOP/s' % (name, ms * 1e3, gb / ms, 2.0 * rows * 1024 * 256 / ms / 1e9))

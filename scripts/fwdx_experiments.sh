@@ -5,8 +5,10 @@ set -e
 cd "$(dirname "$0")/.."
 build() {
   rm -f deep_interpolation_clustering_amd/csrc/dic_lstm32.o
-  make -s -C deep_interpolation_clustering_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$PWD/include -Wall -Wno-unused-function $1" > /dev/null 2>&1
+  make -s -C deep_interpolation_clustering_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$PWD/include -Wall -Wno-unused-function $1" > /dev/null
 }
+# whatever happens below (a failed compile, an interrupted run), the DEFAULT library is rebuilt on the way out: a timing-only variant is wrong by design
+trap 'build ""' EXIT
 if [ "$1" == "timing" ]; then
   build "-DDIC_FWDX_EXP_TIMING"; python3 scripts/fwdx_timing.py 2>/dev/null; python3 scripts/fwdx_timing.py nosave 2>/dev/null
   build ""; exit 0

@@ -3,8 +3,6 @@ Times torch.addmm with the output (and the input) placed at different offsets in
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
-from deep_interpolation_clustering_amd import tuned
-tuned.enable()
 dev, bf = torch.device('cuda'), torch.bfloat16
 M, K, N = 786432, 256, 1024
 arena = torch.empty(6 * 1024 ** 3, dtype=torch.uint8, device=dev)

@@ -3,11 +3,10 @@ sys.path.insert(0, '/root/repo')
 import torch
 from torch.profiler import profile, ProfilerActivity
 import bench
-from deep_interpolation_clustering_amd import synthetic, tuned
+from deep_interpolation_clustering_amd import synthetic
 from deep_interpolation_clustering_amd.clustering_interp import Net
 from deep_interpolation_clustering_amd.step import Stepper
 from deep_interpolation_clustering_amd.utils import pytorch_optimizer
-tuned.enable()
 B = 32768
 dev = torch.device('cuda')
 coh = synthetic.make_cohort(B, seed=3)

@@ -10,7 +10,7 @@ from torch.autograd import DeviceType  # noqa: E402
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 import bench  # noqa: E402
-from deep_interpolation_clustering_amd import synthetic, tuned  # noqa: E402
+from deep_interpolation_clustering_amd import synthetic  # noqa: E402
 from deep_interpolation_clustering_amd.clustering_interp import Net  # noqa: E402
 from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore  # noqa: E402
 from deep_interpolation_clustering_amd.step import Stepper  # noqa: E402
@@ -18,7 +18,6 @@ from deep_interpolation_clustering_amd.utils import pytorch_optimizer  # noqa: E
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = torch.device('cuda', 0)
-tuned.enable()
 args = bench.make_args(4)
 coh = synthetic.make_cohort(4 * B, C=bench.C, T=bench.T, H=bench.H, lam=bench.LAM, G=4, seed=synthetic.SEED)
 x_np, ob_np, len_np = synthetic.stacked_batch(coh)

@@ -187,3 +187,195 @@ def test_deferred_sums_ride_on_the_next_small_all_reduce(tmp_path):
         assert r['calls_a'][0] == 1 and r['calls_a'][1] == 1 and r['calls_a'][2] == [261]          # 257 + 4 in ONE collective, none at resolve
         assert float(r['lone']) == 1.0 and r['calls_b'] == 2
         assert r['still_pending'] in (1.5, 3.0) and r['r64'] == 4.5 and r['calls_c'] == [10000, 4, 1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# step.Stepper's sharded hipGraph path: replay-or-capture must fall the same way on every rank, and a capture counts only when it
+# succeeded everywhere.  gloo cannot be captured, so the CUDA-specific pieces (_warm_up, _capture) are replaced by host stand-ins that keep
+# their CONTRACT -- warm-up = two eager steps that leave no trace, capture = records without executing (no collective), replay = one step --
+# and the agreement logic around them is the product's own.
+class _TinyNet(torch.nn.Module):
+    """The Net surface Stepper drives (forward -> (hidden, rec_ob, aux_pred), rec_loss), with a global-batch BatchNorm (two exchanges per
+    step) and a reconstruction loss normalised over the global batch (a third)."""
+
+    def __init__(self):
+        super().__init__()
+        self.body = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 8))
+
+    def forward(self, x, fake_x=None, fake_perm_idx=None, positive_x=None, lengths=None):
+        return x, self.body(x), {}
+
+    def rec_loss(self, ob, rec_ob, padding_mask, lengths=None):
+        from deep_interpolation_clustering_amd import dist
+        mse = dist.global_mean(((rec_ob - ob) ** 2).sum(), ob.numel())
+        return {'loss': mse, 'ae_mse': mse}
+
+
+class _FakeGraph:
+    def __init__(self, run, out):
+        self.run, self.out, self.was_reset = run, out, False
+
+    def replay(self):
+        self.out['last'] = self.run()
+
+    def reset(self):
+        self.was_reset = True
+
+
+def _capture_worker(rank, world, port, out, scenario):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import types
+    import torch.distributed as td
+    from deep_interpolation_clustering_amd import dist
+    from deep_interpolation_clustering_amd.step import Stepper
+    dist.init_from_env('gloo')
+    try:
+        log = {'captures': 0, 'replays_or_eager': 0, 'collectives': []}
+
+        class HostStepper(Stepper):
+            def _graphable(self, x):
+                return True
+
+            def _warm_up(self, run, device):
+                snap = self._snapshot(device)
+                for _ in range(2):
+                    run()
+                self._restore(snap, device)
+
+            def _capture(self, run):
+                log['captures'] += 1
+                if scenario == 'capture_raises_on_rank_1' and rank == 1:
+                    raise RuntimeError('injected: capture failed on this rank')
+                return _FakeGraph(run, {}), {}
+
+        inner = td.all_reduce
+
+        def counting(t, *a, **k):
+            log['collectives'].append(int(t.numel()))
+            return inner(t, *a, **k)
+        td.all_reduce = counting
+        dist.graph_capturable = lambda: True              # (what RCCL answers)
+
+        def make(use_graphs):
+            torch.manual_seed(0)
+            net = dist.convert_batchnorm_(_TinyNet())
+            args = types.SimpleNamespace(loss='ae_mse', grad_clip=15.0, aux_tasks={}, unsup_aux_tasks={})
+            return Stepper.__new__(HostStepper if use_graphs else Stepper), net, args
+
+        def run_steps(use_graphs):
+            obj, net, args = make(use_graphs)
+            obj.__init__(net, lambda m: torch.optim.Adam(m.parameters(), lr=3e-3, weight_decay=4e-4, amsgrad=True), args, use_graphs=use_graphs)
+            g = torch.Generator().manual_seed(11)
+            X = torch.randn(300, 8, generator=g)
+            # global batches of 100, 99 (a tail the world does not divide: rank 0 gets 49 rows -- a NEW local shape --, rank 1 gets 50 -- the
+            # shape it already holds a graph for), 100 again
+            per_step = []
+            for lo, m in ((0, 100), (100, 99), (200, 100)):
+                a, b = dist.shard_bounds(m)
+                x = X[lo + a:lo + b]
+                n0 = len(log['collectives'])
+                obj.step(x, x.clone(), None, None, global_rows=m)
+                per_step.append(len(log['collectives']) - n0)
+            return obj, per_step
+
+        eager, _ = run_steps(False)
+        n_eager_caps = log['captures']
+        st, per_step = run_steps(True)
+        td.all_reduce = inner
+        torch.save({'eager': eager.flat.flat.clone(), 'graphed': st.flat.flat.clone(), 'captures': log['captures'] - n_eager_caps,
+                    'per_step': per_step, 'off': st._sharded_capture_off, 'cached': len(st._graphs), 'use_graphs': st.use_graphs},
+                   os.path.join(out, f'cap{rank}.pt'))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize('scenario', ['uneven_tail', 'capture_raises_on_rank_1'])
+def test_sharded_capture_is_agreed_between_ranks(tmp_path, scenario):
+    """(ADVICE r5 / VERDICT r5 #3.)  Three sharded steps through Stepper's graph path on two ranks -- global batches of 100, 99, 100 rows.
+    'uneven_tail': the 99-row batch gives rank 0 a new shard shape and rank 1 a cached one; keyed on the GLOBAL batch both ranks warm up and
+    capture together (same number of collectives per step on both ranks), and the trajectory is the eager one.  'capture_raises_on_rank_1':
+    the capture raises on one rank only; both ranks agree (one MIN all-reduce), drop to the eager step together, finish the same three
+    steps with identical parameters."""
+    port = 30100 + (os.getpid() % 1000) + (0 if scenario == 'uneven_tail' else 7)
+    mp.spawn(_capture_worker, args=(2, port, str(tmp_path), scenario), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'cap{r}.pt', weights_only=False) for r in (0, 1))
+    assert r0['use_graphs'] and r1['use_graphs']
+    assert r0['per_step'] == r1['per_step']                               # the ranks issued the same collectives on every step
+    assert torch.equal(r0['graphed'], r1['graphed'])                      # replicas stay bit-identical
+    assert torch.equal(r0['graphed'], r0['eager'])                        # and on the eager trajectory (the stand-in replay IS an eager step)
+    if scenario == 'uneven_tail':
+        assert r0['captures'] == r1['captures'] == 2 and r0['cached'] == r1['cached'] == 2 and not r0['off'] and not r1['off']
+        # a new key = 2 warm-up steps + the flag + 1 replay, a cached key = 1 replay
+        assert r0['per_step'][0] == r0['per_step'][1] == 3 * r0['per_step'][2] + 1
+    else:
+        assert r0['captures'] == r1['captures'] == 1 and r0['off'] and r1['off'] and r0['cached'] == r1['cached'] == 0
+        assert r0['per_step'][1] == r0['per_step'][2]                     # eager from the second step on, on both ranks
+
+
+def _resolve_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import types
+    import torch.distributed as td
+    from deep_interpolation_clustering_amd import dist, step
+    dist.init_from_env('gloo')
+    try:
+        calls, inner = [], td.all_reduce
+
+        def counting(t, *a, **k):
+            calls.append(int(t.numel()))
+            return inner(t, *a, **k)
+        td.all_reduce = counting
+        res = {}
+        # resolve_all_: the riders still waiting travel together, one collective per dtype, each `then` runs once its rider has landed
+        a, b, c = torch.tensor([1.0 + rank, 2.0]), torch.tensor([10.0 * (rank + 1)]), torch.tensor([0.5], dtype=torch.float64)
+        derived = {}
+        dist.deferred_sum_(a, then=lambda: derived.__setitem__('mean', float(a[0] / a[1])))
+        dist.deferred_sum_(b, then=lambda: derived.__setitem__('b', float(b)))
+        dist.deferred_sum_(c)
+        dist.resolve_all_()
+        res['a'], res['b'], res['c'], res['derived'], res['calls'] = a.clone(), float(b), float(c), dict(derived), calls[:]
+        dist.resolve_all_()                                               # nothing pending: no collective
+        res['calls_after'] = len(calls)
+
+        # a loss configuration in which NO term carries the queued reconstruction pair (plain 'ae_mse'): compute_losses resolves it before
+        # the value is handed out; the value is NaN until then (what ops._RbfRecLoss does)
+        class Net:
+            def rec_loss(self, ob, rec_ob, padding_mask, lengths=None):
+                pair = torch.tensor([4.0 * (rank + 1), 2.0])              # (SSE, count) of this rank
+                mse = torch.full((), float('nan'))
+                dist.deferred_sum_(pair, then=lambda: torch.div(pair[0], pair[1], out=mse))
+                res['before'] = float(mse)
+                return {'loss': mse, 'ae_mse': mse}
+        n0 = len(calls)
+        losses = step.compute_losses(Net(), types.SimpleNamespace(loss='ae_mse'), None, None, {}, None, None)
+        res['mse'], res['n_resolve'] = float(losses['loss']), len(calls) - n0
+
+        # a loss switch that raises issues no collective on its way out (the other rank would not be there to meet it)
+        class Bad(Net):
+            pass
+        n0 = len(calls)
+        try:
+            step.compute_losses(Bad(), types.SimpleNamespace(loss='no_such_loss'), None, None, {}, None, None)
+        except NotImplementedError:
+            res['raised'] = True
+        res['n_on_error'] = len(calls) - n0
+        dist.drop_riders()
+        td.all_reduce = inner
+        torch.save(res, os.path.join(out, f'res{rank}.pt'))
+    finally:
+        td.destroy_process_group()
+
+
+def test_resolve_all_and_completion_callbacks(tmp_path):
+    """  dist.resolve_all_ / deferred_sum_(then=...) directly, a loss configuration with no carrier, and no collective while an
+    exception unwinds."""
+    port = 30500 + (os.getpid() % 1000)
+    mp.spawn(_resolve_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in (torch.load(tmp_path / f'res{k}.pt', weights_only=False) for k in (0, 1)):
+        assert torch.equal(r['a'], torch.tensor([3.0, 4.0])) and r['b'] == 30.0 and r['c'] == 1.0
+        assert r['derived'] == {'mean': 0.75, 'b': 30.0}
+        assert r['calls'] == [3, 1] and r['calls_after'] == 2            # the two f32 riders in ONE collective, the f64 one alone
+        assert np.isnan(r['before']) and r['mse'] == 3.0 and r['n_resolve'] == 1
+        assert r['raised'] and r['n_on_error'] == 0

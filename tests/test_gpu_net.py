@@ -470,3 +470,43 @@ def test_joint_step_K8_large_batch_bf16_tracks_f32():
     assert traj['f32'][0, 2] > 0.01
     np.testing.assert_allclose(traj['bf16'], traj['f32'], rtol=2e-2)
     assert traj['f32'][2, 1] < traj['f32'][0, 1]
+
+
+@pytest.mark.parametrize('shape', ['cfg2-256', 'cfg2-4096', 'cfg2-32768', 'cfg4-8192', 'x3-4096'])
+def test_bf16_step_launches_no_library_gemm(shape):
+    """(one way to form each product.)  Every dense product of the bf16 step -- and of the f32 step on split products -- runs
+    on a kernel of this library at every batch size: one traced step (the ROCm tracer behind torch.profiler) at the reference's batch of
+    256, at 4 096 (the 32-row recurrence path), at the headline's 32 768 and at configs[3]'s shape must show no hipBLASLt / rocBLAS / Tensile
+    kernel.  (The exact-f32 parity mode keeps its f32 library GEMMs: not traced here.)"""
+    from torch.autograd import DeviceType
+    from torch.profiler import ProfilerActivity, profile
+    from deep_interpolation_clustering_amd import synthetic
+    from deep_interpolation_clustering_amd.clustering_interp import Net
+    from deep_interpolation_clustering_amd.step import Stepper
+    from deep_interpolation_clustering_amd.utils import pytorch_optimizer
+    cfg, B = shape.split('-')
+    B = int(B)
+    C, T, lam, K = (12, 288, 200.0, 16) if cfg == 'cfg4' else (6, 96, 50.0, 4)
+    args = SimpleNamespace(num_variables=C, num_timestamps=T, ref_points=24, hours_from_admission=24, dropout=0.0, aux_tasks={},
+                           fake_detection=False, triple_margin=0.0, cluster_number=K, loss='ae_mse_kl', grad_clip=15.0,
+                           unsup_aux_tasks={'fake_detection': 1., 'triplet': 1., 'kl': 10.})
+    dev = torch.device('cuda')
+    coh = synthetic.make_cohort(B, C=C, T=T, lam=lam, G=K, seed=77)
+    x_np, ob_np, n = synthetic.stacked_batch(coh)
+    X, OB, LEN = torch.tensor(x_np, device=dev), torch.tensor(ob_np, device=dev), torch.tensor(n, device=dev)
+    del x_np, ob_np
+    torch.manual_seed(4)
+    net = Net(args, dev).to(dev)
+    net.train()
+    st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, autocast_dtype=None if cfg == 'x3' else torch.bfloat16,
+                 precision='x3' if cfg == 'x3' else None, use_graphs=False)
+    st.step(X, OB, None, LEN)                                # (lazy initialisation outside the trace)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        losses, _, _ = st.step(X, OB, None, LEN)
+        torch.cuda.synchronize()
+    names = {ev.name for ev in prof.events() if ev.device_type == DeviceType.CUDA}
+    assert any('dic' in n_ for n_ in names), sorted(names)[:5]                 # the trace saw this library's kernels
+    library = sorted(n_ for n_ in names if 'Cijk' in n_ or 'rocblas' in n_.lower() or 'hipblas' in n_.lower() or 'tensile' in n_.lower())
+    assert not library, library
+    assert np.isfinite(float(losses['loss']))

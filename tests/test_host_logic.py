@@ -110,6 +110,25 @@ def test_ragged_store_built_on_the_device_and_joined_equals_the_host_built_store
             assert a.dtype == b.dtype and torch.equal(a, b), name
         idx = torch.tensor([36, 0, 10, 11, 5])
         assert torch.equal(s.dense_rows(idx), ref.dense_rows(idx))
+    #  a chunk whose rows are all full-length in a channel has no padded slot there: it says nothing about that channel's constant
+    # and must not veto the join; a mask that is not a prefix is refused instead of being packed wrongly
+    xf = x.clone()
+    xf[:, C:2 * C, :] = 0
+    xf[:, C:2 * C, :5] = 1                        # five observed slots everywhere ...
+    xf[:4, C, :] = 1                              # ... except that channel 0 of the first four rows is full-length
+    pad_const = torch.tensor([-2.5, -2.0, -1.5])
+    xf[:, 0:C] = torch.where(xf[:, C:2 * C] != 0, xf[:, 0:C], pad_const[None, :, None].expand(-1, -1, xf.shape[-1]))
+    xf[:, 2 * C:3 * C] = xf[:, 2 * C:3 * C] * xf[:, C:2 * C]
+    xf[:, 3 * C:4 * C] = xf[:, 3 * C:4 * C] * xf[:, C:2 * C]
+    head, rest = RaggedStore.from_device(xf[:4].contiguous(), C), RaggedStore.from_device(xf[4:].contiguous(), C)
+    assert not bool(head.has_pad[0]) and bool(rest.has_pad.all())
+    both = RaggedStore.concat([head, rest])
+    assert torch.equal(both.pad_value, pad_const) and torch.equal(both.dense_rows(torch.arange(37)), RaggedStore(xf.numpy(), C, 'cpu').dense_rows(torch.arange(37)))
+    import pytest
+    bad = xf.clone()
+    bad[0, C + 1, 2] = 0                          # a hole inside the prefix
+    with pytest.raises(ValueError, match='not prefix masks'):
+        RaggedStore.from_device(bad, C)
     st, ph = synthetic.device_cohort_store(50, C, 20, 24.0, 7.0, 2, 3, 'cpu', chunk=16)
     assert st.N == 50 and ph.shape == (50,) and st.times_sorted and int(st.lengths.min()) >= 1
     assert float(st.v_pk.abs().max()) <= 2.5 and int(st.row_off[-1]) == int(st.lengths.sum())
@@ -172,11 +191,18 @@ def test_environment_switch_table():
     with pytest.raises(RuntimeError, match='DIC_F32_PRODUCTS'):
         switches.validate({'DIC_F32_PRODUCTS': 'x6'})
     assert switches.get('DIC_RBF_BWD_SLOT', {}) == '1' and switches.get('DIC_RBF_BWD_SLOT', {'DIC_RBF_BWD_SLOT': '0'}) == '0'
+    #  an empty value is the switch unset; a DIC_* name that is nobody's typo -- a build-macro name someone exported, a site's own -- warns
+    switches.validate({'DIC_LIB_PATH': '', 'DIC_SMALL_BATCH': '', 'DIC_ROW_PROJ': '', 'DIC_REFERENCE': '/somewhere'})
+    assert switches.get('DIC_SMALL_BATCH', {'DIC_SMALL_BATCH': ''}) == '4096'
+    with pytest.warns(UserWarning, match='DIC_NO_NT, DIC_SITE_QUEUE are not switches'):
+        switches.validate({'DIC_NO_NT': '1', 'DIC_SITE_QUEUE': 'a'})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(root, 'deep_interpolation_clustering_amd')
     read = set()
-    for f in glob.glob(os.path.join(pkg, '*.py')) + glob.glob(os.path.join(pkg, 'csrc', '*.h*')) + [os.path.join(root, 'bench.py')]:
-        for ln in open(f):
+    files = (glob.glob(os.path.join(pkg, '*.py')) + glob.glob(os.path.join(pkg, 'csrc', '*.h*')) + [os.path.join(root, 'bench.py')]
+             + glob.glob(os.path.join(root, 'scripts', '*')) + glob.glob(os.path.join(root, 'oracle', '*.py')))
+    for f in files:
+        for ln in open(f, errors='replace'):
             if 'getenv' in ln or 'os.environ' in ln:
                 read.update(re.findall(r'DIC_[A-Z0-9_]+', ln))
     assert read and read <= set(switches.SWITCHES), sorted(read - set(switches.SWITCHES))
