@@ -838,6 +838,20 @@ def log(*msg):
     print('[bench]', *msg, file=sys.stderr, flush=True)
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources, in name order: profiles/traffic.json / step_traffic.json record the value they were
+    measured on (scripts/pmc_traffic.py, step_traffic.py), and a line printed from OTHER sources says traffic: null instead of repeating a
+    number that no longer describes the kernels (VERDICT r5 #5)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'deep_interpolation_clustering_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(d, '*.hip')) + glob.glob(os.path.join(d, '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -882,15 +896,34 @@ def main():
     # the cohort as the trainers' DeviceLoader keeps it: a ragged store (observed samples only, packed); a batch = an index range into it
     from deep_interpolation_clustering_amd.ragged import RaggedBatch, RaggedStore
     store = None if a.dense_input else RaggedStore(x_np, C, dev)
-    # batches are drawn from a shuffled index, as the trainers' DeviceLoader does (a contiguous slab of the packed store would be the most
-    # favourable access pattern for the in-place reads: ~1 KB row groups behind an index -> row_off -> samples chain are what a real epoch sees)
-    PERM = torch.randperm(n_enc, device=dev, generator=torch.Generator(device=dev).manual_seed(7529 + rank))
+    # An EPOCH is the whole cohort (VERDICT r5: the bench walked 65 536 of its 75 000 resident encounters): ceil(n / batch) batches INCLUDING the
+    # short last one -- upstream's DataLoader has no drop_last (p1_pretrain_main.py:122-131) -- behind a fresh permutation per epoch, as the
+    # trainers' DeviceLoader draws them (a contiguous slab of the packed store would be the most favourable access pattern for the in-place
+    # reads: ~1 KB row groups behind an index -> row_off -> samples chain are what a real epoch sees).  `value` counts the encounters stepped.
+    if strong:
+        n_enc = n_total // world            # (every rank walks the same number of rows: identical batch sizes, identical collectives)
+        X, OB, LEN = X[:n_enc], OB[:n_enc], LEN[:n_enc]
     shuffled = store is not None and not a.fake_detection       # (--fake-detection keeps file order: its corrupted copies XF are a padded tensor in that order)
-    IDX = PERM.to(torch.int32) if shuffled else torch.arange(n_enc, device=dev, dtype=torch.int32)
-    LEN_B = LEN.index_select(0, PERM).contiguous() if shuffled else LEN      # lengths in batch order
+    perm_gen = torch.Generator(device=dev).manual_seed(7529 + rank)
+    nb = (n_enc + a.batch - 1) // a.batch
+    nb_full = max(1, n_enc // a.batch)
+
+    def rows_of(i):
+        """[lo, hi) of step i's batch inside its epoch's order."""
+        lo = (i % nb) * a.batch
+        return lo, min(lo + a.batch, n_enc)
+    order = {'epoch': -1, 'IDX': torch.arange(n_enc, device=dev, dtype=torch.int32), 'LEN_B': LEN}
+
+    def epoch_order(i):
+        e = i // nb
+        if shuffled and e != order['epoch']:
+            perm = torch.randperm(n_enc, device=dev, generator=perm_gen)
+            order['IDX'], order['LEN_B'], order['epoch'] = perm.to(torch.int32), LEN.index_select(0, perm).contiguous(), e      # lengths in batch order
+        return order['IDX'], order['LEN_B']
+    epoch_order(0)
     del coh, x_np, ob_np
-    nb = max(1, n_enc // a.batch)
-    log(f'rank {rank}: {n_enc} encounters resident after {time.perf_counter() - t_start:.1f}s ({a.scaling} scaling, {a.batch} per step and rank)')
+    log(f'rank {rank}: {n_enc} encounters resident after {time.perf_counter() - t_start:.1f}s ({a.scaling} scaling, {a.batch} per step and rank, '
+        f'{nb} batches per epoch, the last of {n_enc - (nb - 1) * a.batch})')
 
     torch.manual_seed(1234)
     net = Net(args, dev).to(dev)
@@ -906,31 +939,43 @@ def main():
         m = X[:, C:2 * C] > 0
         hit = m & (torch.rand(m.shape, device=dev, generator=g) < 0.5)
         XF[:, :C] = torch.where(hit, torch.rand(m.shape, device=dev, generator=g) * 5.0 - 2.5, X[:, :C])
-        label2 = torch.cat([torch.ones(a.batch, device=dev), torch.zeros(a.batch, device=dev)])
+        label2 = {}
 
     def one_step(i):
-        lo = (i % nb) * a.batch
+        lo, hi = rows_of(i)
+        IDX, LEN_B = epoch_order(i)
         if store is not None:
-            xb, obb = RaggedBatch(store, IDX[lo:lo + a.batch], LEN_B[lo:lo + a.batch]), None
+            xb, obb = RaggedBatch(store, IDX[lo:hi], LEN_B[lo:hi]), None
         else:
-            xb, obb = X[lo:lo + a.batch], OB[lo:lo + a.batch]
+            xb, obb = X[lo:hi], OB[lo:hi]
+        g_rows = (hi - lo) * world           # rows of the GLOBAL batch: what a sharded Stepper keys its captured steps on
         if XF is None:
-            return stepper.step(xb, obb, None, LEN_B[lo:lo + a.batch])
-        perm = torch.randperm(2 * a.batch, device=dev)                       # as the trainers draw it (pretrain_trainer.py:156-160)
-        return stepper.step(xb, obb, None, LEN_B[lo:lo + a.batch], fake_x=XF[lo:lo + a.batch],
-                            fake_perm_idx=perm, fake_det_label=label2[perm].to(torch.int64))
+            return stepper.step(xb, obb, None, LEN_B[lo:hi], global_rows=g_rows)
+        m = hi - lo
+        if m not in label2:
+            label2[m] = torch.cat([torch.ones(m, device=dev), torch.zeros(m, device=dev)])
+        perm = torch.randperm(2 * m, device=dev)                             # as the trainers draw it (pretrain_trainer.py:156-160)
+        return stepper.step(xb, obb, None, LEN_B[lo:hi], fake_x=XF[lo:hi], fake_perm_idx=perm, fake_det_label=label2[m][perm].to(torch.int64),
+                            global_rows=g_rows)
 
     def barrier():
         if sharded:
             td.barrier()
         torch.cuda.synchronize()
 
+    # the steps traced after the timed region (kernel durations INSIDE the step, for the roofline record): one whole epoch from an epoch
+    # boundary when an epoch is a handful of batches, else TRACE_STEPS batches
+    n_trace = nb if nb <= 8 else TRACE_STEPS
+    first_trace = ((a.warmup + a.steps + nb - 1) // nb) * nb
+    trace_rows = sum(rows_of(first_trace + i)[1] - rows_of(first_trace + i)[0] for i in range(n_trace))
     for i in range(a.warmup):
         one_step(i)
     barrier()
     t0 = time.perf_counter()
+    rows_stepped = 0
     for i in range(a.steps):
         losses, gnorm, _ = one_step(a.warmup + i)
+        rows_stepped += rows_of(a.warmup + i)[1] - rows_of(a.warmup + i)[0]
     barrier()
     el = time.perf_counter() - t0
     if sharded:
@@ -938,11 +983,11 @@ def main():
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         el = float(tt)
     final_loss = float(losses['loss'].detach())
-    log(f'{a.steps} steps in {el:.3f}s ({1e3 * el / a.steps:.2f} ms/step), loss {final_loss:.5f}')
+    log(f'{a.steps} steps = {rows_stepped} encounters per rank in {el:.3f}s ({1e3 * el / a.steps:.2f} ms/step), loss {final_loss:.5f}')
 
     if rank == 0:
         ms = 1e3 * el / a.steps
-        value = world * a.batch * a.steps / el
+        value = world * rows_stepped / el          # encounters actually stepped (every rank walks the same batch sizes)
         lo = 0
         table = kernel_table(net, X[lo:lo + a.batch], OB[lo:lo + a.batch], LEN[lo:lo + a.batch], K, a.kernel_iters)
         log('kernel table done:', {k: v['ms'] for k, v in table.items()})
@@ -963,11 +1008,14 @@ def main():
             ran[0] += 1
             return one_step(i)
         try:
-            kernels, groups = step_trace(counted_step, a.warmup + a.steps, TRACE_STEPS)    # (sharded: the other ranks run these steps with it, below)
+            kernels, groups = step_trace(counted_step, first_trace, n_trace)    # (sharded: the other ranks run these steps with it, below)
         except Exception as e:
             log('step trace unavailable:', repr(e))
-        for i in range(ran[0], TRACE_STEPS if sharded else 0):                              # stay in lockstep with the other ranks whatever the tracer did
-            one_step(a.warmup + a.steps + i)
+        for i in range(ran[0], n_trace if sharded else 0):                              # stay in lockstep with the other ranks whatever the tracer did
+            one_step(first_trace + i)
+        # the traced steps are one whole epoch (full batches + the short last one): a kernel's average launch moves trace_rows / n_trace
+        # encounters, and its algorithmic bytes per launch are the table's (stated for a full batch; every figure is per encounter) scaled to that
+        row_scale = trace_rows / n_trace / a.batch
         per_step = {}
         # k1 / k2 appear twice in the table (padded input, ragged store): the step runs ONE of the two
         twin = {'sci_cci_fwd': 'sci_cci_fwd_store', 'rbf_fwd': 'rbf_fwd_store', 'rbf_bwd': 'rbf_bwd_store'}
@@ -1005,28 +1053,33 @@ def main():
                 in_step_ms[name] = sum(v['ms_per_step'] for v in hits) / n_l
                 per_step[name] = n_l * in_step_ms[name]
                 table[name]['ms_in_step'] = round(in_step_ms[name], 5)
-                table[name]['frac_hbm_peak_in_step'] = round(table[name]['algorithmic_bytes'] / in_step_ms[name] / 1e6 / HBM_PEAK_GBS, 4)
+                table[name]['frac_hbm_peak_in_step'] = round(table[name]['algorithmic_bytes'] * row_scale / in_step_ms[name] / 1e6 / HBM_PEAK_GBS, 4)
         dom = max(per_step, key=per_step.get)
         dom_ms = in_step_ms.get(dom, table[dom]['ms'])
-        dom_gbps = table[dom]['algorithmic_bytes'] / dom_ms / 1e6
+        dom_bytes = table[dom]['algorithmic_bytes'] * (row_scale if dom in in_step_ms else 1.0)      # per AVERAGE launch of the traced epoch
+        dom_gbps = dom_bytes / dom_ms / 1e6
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')      # PMC-derived HBM bytes per launch (see its _note)
         if os.path.exists(tf):
             tj = json.load(open(tf))
-            if dom in tj:
-                traffic = int(tj[dom]['hbm_bytes'] * a.batch / tj.get('_batch', a.batch))
+            if dom in tj and tj.get('_csrc_sha16') == csrc_sha16():
+                traffic = int(tj[dom]['hbm_bytes'] * (row_scale if dom in in_step_ms else 1.0) * a.batch / tj.get('_batch', a.batch))
                 traffic_src = {'from_profile': 'profiles/traffic.json', 'profile_batch': tj.get('_batch'), 'profile_round': tj.get('_round'),
-                               'note': 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of a separate run, scaled by batch; not measured in this run'}
+                               'note': 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of a separate run ON THESE kernel sources (sha recorded in the file), scaled to the encounters of an average launch; not measured in this run'}
+            elif dom in tj:
+                log(f"roofline.traffic: null -- profiles/traffic.json was measured on other kernel sources ({tj.get('_csrc_sha16')} != {csrc_sha16()}): re-run scripts/profile_round.sh")
         custom_ms = sum(per_step.values())
-        gflop = FLOP_PER_ENCOUNTER * a.batch / 1e9
+        gflop = FLOP_PER_ENCOUNTER * (rows_stepped / a.steps) / 1e9          # (of an average step of the timed loop)
         workload = ((f'{n_enc} of ONE {max(a.encounters, a.batch * world)}-encounter synthetic cohort per GPU' if strong else f'{n_enc} synthetic encounters/GPU') +
                     f', 6 vitals, ~50 irregular samples per channel per 24h (T={T}), R={R}, K={K}, loss ' +
-                    ('ae_mse+fake_detect+10*kl' if a.fake_detection else 'ae_mse+10*kl') + ' [BASELINE.json configs[' + ('2' if K == 8 else '1') + ']]')
+                    ('ae_mse+fake_detect+10*kl' if a.fake_detection else 'ae_mse+10*kl') + ' [BASELINE.json configs[' + ('2' if K == 8 else '1') + ']]' +
+                    f'; every epoch walks the WHOLE cohort behind a fresh permutation: {nb} batches of {a.batch} incl. the last of {n_enc - (nb - 1) * a.batch} '
+                    f'(no drop_last, as upstream); value = encounters stepped / s; ms_per_step = mean over those steps')
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(dom_gbps, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(dom_gbps / HBM_PEAK_GBS, 4), 'traffic': traffic,
                     'ms_per_launch': round(dom_ms, 5), 'launches_per_step': round(per_step[dom] / dom_ms, 2) if dom_ms else None,
-                    'algorithmic_bytes_per_launch': table[dom]['algorithmic_bytes'],
-                    'duration_source': 'in-step per-dispatch GPU timestamps (trace of the timed step)' if dom in in_step_ms else 'stand-alone HIP events',
+                    'algorithmic_bytes_per_launch': int(dom_bytes), 'encounters_per_launch': round(row_scale * a.batch, 1) if dom in in_step_ms else a.batch,
+                    'duration_source': f'in-step per-dispatch GPU timestamps (trace of one epoch = {n_trace} steps of the timed loop)' if dom in in_step_ms else 'stand-alone HIP events',
                     'traffic_source': (f"{traffic_src['from_profile']} (rocprofv3 --pmc, round {traffic_src['profile_round']}, scaled by batch)" if traffic_src else None)}
         roofline_detail = {'frac_standalone': table[dom]['frac_hbm_peak'], 'ms_per_launch_standalone': table[dom]['ms'], 'ms_per_step': round(per_step[dom], 4),
                            'chosen_by': 'launches per step x in-step duration (trace of the timed step)', 'traffic_source': traffic_src,
@@ -1042,7 +1095,8 @@ def main():
             'metric': 'encounters/sec per joint interp+DEC step', 'value': round(value, 1), 'unit': 'encounters/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': workload, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'parallelism': f'dp{world}' if world > 1 else 'single',
+            'config': {'workload': workload, 'per_gpu_batch': a.batch, 'global_batch': a.batch * world, 'batches_per_epoch': nb,
+                       'encounters_stepped': world * rows_stepped, 'parallelism': f'dp{world}' if world > 1 else 'single',
                        'index_order': 'shuffled' if shuffled else 'file order',
                        'input': 'padded (B,4C,T) batches' if store is None else f'ragged encounter store read in place ({store.nbytes() / 1e6:.0f} MB resident)'},
             'roofline': roofline,
@@ -1076,8 +1130,8 @@ def main():
         st_file = os.path.join(ROOT, 'profiles', 'step_traffic.json')
         if os.path.exists(st_file):
             sj = json.load(open(st_file))
-            if 'total_bytes' in sj:
-                gb = sj['total_bytes'] * a.batch / sj.get('_batch', 32768) / 1e9
+            if 'total_bytes' in sj and sj.get('_csrc_sha16') == csrc_sha16():
+                gb = sj['total_bytes'] * (rows_stepped / a.steps) / sj.get('_batch', 32768) / 1e9
                 whole['hbm_traffic'] = {'GB_per_step': round(gb, 2), 'TBps_over_step': round(gb / ms, 3), 'from_profile': 'profiles/step_traffic.json',
                                         'profile_round': sj.get('_round')}
         sec.add('whole_step', whole)
@@ -1104,13 +1158,13 @@ def main():
             if store is not None:
                 def f32_batch(i):
                     lo_ = i * a.batch
-                    return RaggedBatch(store, IDX[lo_:lo_ + a.batch], LEN_B[lo_:lo_ + a.batch]), None, None
+                    return RaggedBatch(store, order['IDX'][lo_:lo_ + a.batch], order['LEN_B'][lo_:lo_ + a.batch]), None, None
             else:
                 def f32_batch(i):
                     lo_ = i * a.batch
                     return X[lo_:lo_ + a.batch], OB[lo_:lo_ + a.batch], None, LEN[lo_:lo_ + a.batch]
             for key, products in (('f32x3', 'x3'), ('f32', 'exact')):
-                rec = guarded(record_f32, lambda pr: fresh(None, False, pr), f32_batch, nb, a.batch, products)
+                rec = guarded(record_f32, lambda pr: fresh(None, False, pr), f32_batch, nb_full, a.batch, products)          # (full batches: the x3 / f32 records keep round 5's definition)
                 torch.cuda.empty_cache()
                 sec.add(key, rec, echo=False)
                 log(key, 'done', json.dumps(_finite({k: v for k, v in rec.items() if k in ('ms_per_step', 'encounters_per_s', 'library_gemm_ms', 'error')})))
@@ -1125,10 +1179,10 @@ def main():
             sec.add('cfg5', guarded(record_cfg5, dev, not a.no_sweep))
         log('secondary records:', ', '.join(sec.paths))
     elif world > 1:
-        # rank 0 traces TRACE_STEPS more optimisation steps for the roofline record: a sharded step is full of collectives (loss
+        # rank 0 traces n_trace more optimisation steps for the roofline record: a sharded step is full of collectives (loss
         # sums, BatchNorm moments, the gradient bucket), so every rank has to run them with it or rank 0 waits forever
-        for i in range(TRACE_STEPS):
-            one_step(a.warmup + a.steps + i)
+        for i in range(n_trace):
+            one_step(first_trace + i)
         torch.cuda.synchronize()
     if sharded:
         td.barrier()

@@ -5,6 +5,8 @@
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and on gfx950 FETCH_SIZE reports half of
 a wide coalesced read stream (MI355X_MICROARCH.md, HBM section)."""
 import csv, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from bench import csrc_sha16          # noqa: E402  (the kernel sources these counters were taken on: bench.py prints traffic only for the same sources)
 KEYS = {'sci_cci_fwd_kernel': 'sci_cci_fwd', 'sci_cci_bwd_kernel': 'sci_cci_bwd', 'sci_cci_bwd_lane_kernel': 'sci_cci_bwd', 'rbf_fwd_kernel': 'rbf_fwd', 'rbf_fwd_row_kernel': 'rbf_fwd',
         'rbf_bwd_kernel': 'rbf_bwd', 'rbf_bwd_slot_kernel': 'rbf_bwd',
         'masked_sse_kernel': 'masked_sse_fwd', 'masked_sse_bwd_kernel': 'masked_sse_bwd', 'dec_fwd_kernel': 'dec_fwd',
@@ -36,7 +38,7 @@ fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'W
 out = {'_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/kbench.py %s 3; see '
                 'scripts/pmc_traffic.py): bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; the factor 2 is the gfx950 correction of '
                 'MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced read stream). bench.py scales it linearly with the batch.' % sys.argv[3],
-       '_batch': int(sys.argv[3]), '_round': int(sys.argv[4]) if len(sys.argv) > 4 else 2}
+       '_batch': int(sys.argv[3]), '_round': int(sys.argv[4]) if len(sys.argv) > 4 else 2, '_csrc_sha16': csrc_sha16()}
 for k in dict.fromkeys(KEYS.values()):
     if k in fetch and k in write:
         out[k] = {'fetch_size_kb': round(fetch[k], 1), 'write_size_kb': round(write[k], 1), 'hbm_bytes': int((2 * fetch[k] + write[k]) * 1024)}

@@ -3,7 +3,7 @@
 #   bash scripts/profile_round.sh 2
 # Counters are collected in passes of their own (--pmc with --kernel-trace only), as gpurun requires.
 set -e
-R=${1:-4}
+R=${1:-6}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_r$R
 mkdir -p $OUT
@@ -23,8 +23,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/d_write -o
 python3 $ROOT/scripts/pmc_generic.py /tmp/d_fetch/p_counter_collection.csv /tmp/d_write/p_counter_collection.csv 'sci_cci|rbf_' > $OUT/k1k2_padded_input_pmc_traffic.json
 echo "[profile] kernel traffic done"
 # 3. HBM traffic of the whole step
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/s_fetch -o p -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline --steps 6 --warmup 2 --kernel-iters 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/s_write -o p -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline --steps 6 --warmup 2 --kernel-iters 1 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/s_fetch -o p -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline --steps 6 --warmup 3 --kernel-iters 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/s_write -o p -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline --steps 6 --warmup 3 --kernel-iters 1 > /dev/null 2>&1
 python3 $ROOT/scripts/step_traffic.py /tmp/s_fetch/p_counter_collection.csv /tmp/s_write/p_counter_collection.csv $R > $OUT/step_traffic.txt
 cp $ROOT/profiles/step_traffic.json $OUT/step_traffic.json
 echo "[profile] step traffic done"

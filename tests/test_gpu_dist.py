@@ -452,6 +452,16 @@ def test_bench_runs_sharded_on_two_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['scaling'] == 'weak' and rec['config']['global_batch'] == 1024
     assert abs(rec['value'] - 2 * 512 * 3 / (rec['ms_per_step'] * 3e-3)) <= 0.01 * rec['value']      # whole-job rate over all ranks
+    # the bench walks its cohort: 1 200 encounters per rank in batches of 512 = 512 + 512 + 176 per epoch, no drop_last; three
+    # warm-up + three timed steps = exactly one timed epoch on each rank; `value` counts the encounters stepped, not steps x batch
+    cmd2 = [c for c in cmd]
+    cmd2[cmd2.index('--encounters') + 1], cmd2[cmd2.index('--warmup') + 1] = '1200', '3'
+    res = subprocess.run(cmd2, env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][0])
+    assert rec['config']['batches_per_epoch'] == 3 and rec['config']['encounters_stepped'] == 2 * 1200
+    assert 'incl. the last of 176' in rec['config']['workload']
+    assert abs(rec['value'] - 2 * 1200 / (rec['ms_per_step'] * 3e-3)) <= 0.01 * rec['value']
     # strong scaling (BASELINE configs[2]'s shape of run): ONE cohort sharded over the ranks, the GLOBAL batch fixed
     res = subprocess.run(cmd + ['--scaling', 'strong'], env=env, capture_output=True, text=True, timeout=280, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
