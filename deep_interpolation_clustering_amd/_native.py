@@ -76,6 +76,7 @@ SIGNATURES = {
     'dic_lstm_pack': (_i, [_i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     'dic_lstm_rec_fwd': (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     'dic_lstm_rec_fwd_proj': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
+    'dic_lstm_rec_fwd_proj_x3': (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     'dic_lstm_fwd_xproj': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     'dic_lstm_rec_bwd_workspace': (_sz, [_i]),
     'dic_lstm_rec_bwd': (_i, [_i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _i, _i, _p]),
@@ -112,6 +113,8 @@ SIGNATURES = {
     'dic_grad_norm_clip': (_i, [_p, C.c_int64, _f, _p, _p, _sz, _p]),
     'dic_accumulate_many': (_i, [_p, _p, _p, _i, _p]),
     'dic_gemm_nt': (_i, [_i, _i, _p, C.c_int64, _p, C.c_int64, _p, C.c_int64, _i, _i, _p, C.c_int64, _i, _p]),
+    'dic_gemm_nt_planes': (_i, [_p, C.c_int64, C.c_int64, _p, C.c_int64, _p, C.c_int64, _i, _i, _p, C.c_int64, _p]),
+    'dic_gemm_tn_planes': (_i, [_p, C.c_int64, C.c_int64, _p, C.c_int64, C.c_int64, _i, _i, _p, C.c_int64, _i, _p, C.c_int64, _i, _p, C.c_int64, _i, _i, _p, _sz, _p]),
     'dic_x3_row_proj': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _i, _p]),
     'dic_gemm_tn_workspace': (_sz, [C.c_int64, _i, _i, _i]),
     'dic_gemm_tn': (_i, [_i, _p, C.c_int64, _p, C.c_int64, C.c_int64, _i, _i, _p, C.c_int64, _i, _p, C.c_int64, _i, _p, C.c_int64, _i, _i, _p, _sz, _p]),

@@ -124,10 +124,14 @@ struct GemmNtArgs {
     long M; int N, K;
     int relu_a;                    // the product runs on max(A, 0)
     int tiles_n;
+    long a_plane = 0;              // AP kernels: A is a pair of bf16 planes -- hi at A, lo a_plane elements behind it (lda in bf16 elements): x = hi + lo
 };
 
-template <typename TIN, typename TOUT, int BN>
+// AP ("A in split planes", round 6): the A operand arrives as two bf16 planes hi / lo with A = hi + lo (what the x3 recurrence kernels write: the gate
+// gradients) -- its pieces go to the two LDS images as they are, no conversion in the loop; W (small, L2-resident) is still split on the way in.
+template <typename TIN, typename TOUT, int BN, bool AP = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs a) {
+    static_assert(!AP || sizeof(TIN) == 4, "split planes stand for an f32 operand");
     constexpr bool SPLIT = sizeof(TIN) == 4;
     constexpr int NB = BN / 64;                              // 32-column blocks per wave
     constexpr int IMG = SPLIT ? 2 : 1;
@@ -142,6 +146,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs a) {
     const TIN* W = reinterpret_cast<const TIN*>(a.W);
     const int lrow = tid >> 1, lk = 16 * (tid & 1);         // this thread's tile row / first reduction element of its 16
     const TIN* arow = A + (size_t)min(m0 + lrow, a.M - 1) * a.lda;
+    const __bf16* aph = reinterpret_cast<const __bf16*>(a.A) + (size_t)min(m0 + lrow, a.M - 1) * a.lda;      // (AP)
+    const __bf16* apl = aph + a.a_plane;
     const bool wload = lrow < BN;
     const bool wvalid = wload && n0 + lrow < a.N;
     const TIN* wrow = W + (size_t)min(n0 + lrow, a.N - 1) * a.ldw;
@@ -155,15 +161,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs a) {
             for (int k = 0; k < 16; ++k) acc[mb][nb][k] = 0.f;
 
     Chunk16<TIN> ca, cw;
+    Chunk16<__bf16> cah, cal;
     const int nkt = (a.K + GBK - 1) / GBK;
-    chunk_load(ca, arow, lk, a.K);
+    if constexpr (AP) { chunk_load(cah, aph, lk, a.K); chunk_load(cal, apl, lk, a.K); }
+    else chunk_load(ca, arow, lk, a.K);
     if (wvalid) chunk_load(cw, wrow, lk, a.K); else chunk_zero(cw);
     for (int kt = 0; kt < nkt; ++kt) {
-        chunk_store(ca, &sa[0][lrow * GP + lk], &sa[IMG - 1][lrow * GP + lk], a.relu_a != 0);
+        if constexpr (AP) {
+            chunk_store(cah, &sa[0][lrow * GP + lk], nullptr, false);
+            chunk_store(cal, &sa[1][lrow * GP + lk], nullptr, false);
+        } else {
+            chunk_store(ca, &sa[0][lrow * GP + lk], &sa[IMG - 1][lrow * GP + lk], a.relu_a != 0);
+        }
         if (wload) chunk_store(cw, &sw[0][lrow * GP + lk], &sw[IMG - 1][lrow * GP + lk], false);
         __syncthreads();
         if (kt + 1 < nkt) {                                  // in flight while the matrix cores work on this tile
-            chunk_load(ca, arow, (kt + 1) * GBK + lk, a.K);
+            if constexpr (AP) { chunk_load(cah, aph, (kt + 1) * GBK + lk, a.K); chunk_load(cal, apl, (kt + 1) * GBK + lk, a.K); }
+            else chunk_load(ca, arow, (kt + 1) * GBK + lk, a.K);
             if (wvalid) chunk_load(cw, wrow, (kt + 1) * GBK + lk, a.K);
         }
 #pragma unroll
@@ -247,8 +261,9 @@ __device__ __forceinline__ void chunk8_store(const Chunk8<__bf16>& c, __bf16* hi
     *reinterpret_cast<gbf16x8*>(hi) = v;
 }
 
-template <typename TIN, typename TOUT>
+template <typename TIN, typename TOUT, bool AP = false>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
+    static_assert(!AP || sizeof(TIN) == 4, "split planes stand for an f32 operand");
     constexpr bool SPLIT = sizeof(TIN) == 4;
     constexpr int IMG = SPLIT ? 2 : 1, BN = 128;
     __shared__ __align__(16) __bf16 sa[IMG][GBM * GP];
@@ -262,6 +277,8 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
     const TIN* W = reinterpret_cast<const TIN*>(a.W);
     const int lrow = tid >> 2, lk = 8 * (tid & 3);
     const TIN* arow = A + (size_t)min(m0 + lrow, a.M - 1) * a.lda;
+    const __bf16* aph = reinterpret_cast<const __bf16*>(a.A) + (size_t)min(m0 + lrow, a.M - 1) * a.lda;      // (AP)
+    const __bf16* apl = aph + a.a_plane;
     const bool wvalid = n0 + lrow < a.N;
     const TIN* wrow = W + (size_t)min(n0 + lrow, a.N - 1) * a.ldw;
 
@@ -271,15 +288,23 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[mb][k] = 0.f;
     Chunk8<TIN> ca, cw;
+    Chunk8<__bf16> cah, cal;
     const int nkt = (a.K + GBK - 1) / GBK;
-    chunk8_load(ca, arow, lk, a.K, true);
+    if constexpr (AP) { chunk8_load(cah, aph, lk, a.K, true); chunk8_load(cal, apl, lk, a.K, true); }
+    else chunk8_load(ca, arow, lk, a.K, true);
     chunk8_load(cw, wrow, lk, a.K, wvalid);
     for (int kt = 0; kt < nkt; ++kt) {
-        chunk8_store(ca, &sa[0][lrow * GP + lk], &sa[IMG - 1][lrow * GP + lk], a.relu_a != 0);
+        if constexpr (AP) {
+            chunk8_store(cah, &sa[0][lrow * GP + lk], nullptr, false);
+            chunk8_store(cal, &sa[1][lrow * GP + lk], nullptr, false);
+        } else {
+            chunk8_store(ca, &sa[0][lrow * GP + lk], &sa[IMG - 1][lrow * GP + lk], a.relu_a != 0);
+        }
         chunk8_store(cw, &sw[0][lrow * GP + lk], &sw[IMG - 1][lrow * GP + lk], false);
         __syncthreads();
         if (kt + 1 < nkt) {
-            chunk8_load(ca, arow, (kt + 1) * GBK + lk, a.K, true);
+            if constexpr (AP) { chunk8_load(cah, aph, (kt + 1) * GBK + lk, a.K, true); chunk8_load(cal, apl, (kt + 1) * GBK + lk, a.K, true); }
+            else chunk8_load(ca, arow, (kt + 1) * GBK + lk, a.K, true);
             chunk8_load(cw, wrow, (kt + 1) * GBK + lk, a.K, wvalid);
         }
 #pragma unroll
@@ -330,14 +355,16 @@ struct GemmTnArgs {
     long rows_per_chunk;           // multiple of TROWS
     int tiles_n, tiles_k, tiles_k1;      // tiles_k = tiles_k1 (of X) + those of X2
     int relu_x;                          // the product runs on max(X, 0) (X only, not X2): the decoder LSTM's input is relu(encoder output), rectified on load
+    long a_plane = 0;                    // AP kernels: A is a pair of bf16 planes (hi at A, lo a_plane elements behind it; lda in bf16 elements)
 };
 
 __device__ __forceinline__ gs16x4 glds_tr16(const __bf16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs16x4*)(p));
 }
 
-template <typename TIN, int BKO>
+template <typename TIN, int BKO, bool AP = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
+    static_assert(!AP || sizeof(TIN) == 4, "split planes stand for an f32 operand");
     constexpr bool SPLIT = sizeof(TIN) == 4;
     constexpr int IMG = SPLIT ? 2 : 1;
     constexpr int PA = 128 + 32, PX = BKO + 32;              // row pitches in bf16 elements (320 B / 320 or 192 B)
@@ -371,14 +398,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
             for (int k = 0; k < 16; ++k) acc[nb][kb][k] = 0.f;
 
     Chunk16<TIN> ca, cx;
+    Chunk16<__bf16> cah, cal;
+    const __bf16* APH = reinterpret_cast<const __bf16*>(a.A);
     auto load = [&](long m) {
         const long row = m + lrow;
         if (row < mend) {
-            chunk_load(ca, A + (size_t)row * a.lda + n0, 16 * seg, nvalid_a);
+            if constexpr (AP) {
+                chunk_load(cah, APH + (size_t)row * a.lda + n0, 16 * seg, nvalid_a);
+                chunk_load(cal, APH + a.a_plane + (size_t)row * a.lda + n0, 16 * seg, nvalid_a);
+            } else {
+                chunk_load(ca, A + (size_t)row * a.lda + n0, 16 * seg, nvalid_a);
+            }
             if (XC == 16) chunk_load(cx, X + (size_t)row * ldx + k0, 16 * seg, kvalid);
             else chunk_load(cx, X + (size_t)row * ldx + k0, 8 * seg, min(kvalid, 8 * seg + 8));      // 8 columns: the second half stays zero
         } else {
-            chunk_zero(ca);
+            if constexpr (AP) { chunk_zero(cah); chunk_zero(cal); }
+            else chunk_zero(ca);
             chunk_zero(cx);
         }
     };
@@ -396,7 +431,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     };
     if (mbeg < mend) load(mbeg);
     for (long m = mbeg; m < mend; m += TROWS) {
-        chunk_store(ca, &sa[0][lrow * PA + 16 * seg], &sa[IMG - 1][lrow * PA + 16 * seg], false);
+        if constexpr (AP) {
+            chunk_store(cah, &sa[0][lrow * PA + 16 * seg], nullptr, false);
+            chunk_store(cal, &sa[1][lrow * PA + 16 * seg], nullptr, false);
+        } else {
+            chunk_store(ca, &sa[0][lrow * PA + 16 * seg], &sa[IMG - 1][lrow * PA + 16 * seg], false);
+        }
         const bool rx = a.relu_x != 0 && !second;
         if (XC == 16) {
             chunk_store(cx, &sx[0][lrow * PX + 16 * seg], &sx[IMG - 1][lrow * PX + 16 * seg], rx);
@@ -595,9 +635,12 @@ using namespace dic;
 
 extern "C" {
 
-int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void* W, long ldw, const float* bias, long M, int N, int K,
-                void* Y, long ldy, int relu_a, dic_stream_t stream) {
+static int gemm_nt_impl(int in_dtype, int out_dtype, const void* A, long a_plane, long lda, const void* W, long ldw, const float* bias, long M, int N, int K,
+                        void* Y, long ldy, int relu_a, dic_stream_t stream) {
     DIC_REQUIRE(in_dtype == DIC_DTYPE_F32 || in_dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "gemm_nt: input dtype %d", in_dtype);
+    const bool ap = a_plane != 0;
+    DIC_REQUIRE(!ap || (in_dtype == DIC_DTYPE_F32 && out_dtype == DIC_DTYPE_F32 && !relu_a && K % 8 == 0 && lda % 8 == 0), DIC_ERR_UNSUPPORTED,
+                "gemm_nt: a split-plane A operand goes with f32 W / Y, no rectification, K and lda multiples of 8 (K=%d lda=%ld)", K, lda);
     DIC_REQUIRE(out_dtype == DIC_DTYPE_F32 || out_dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "gemm_nt: output dtype %d", out_dtype);
     DIC_REQUIRE(A && W && Y, DIC_ERR_INVALID_ARG, "gemm_nt: NULL pointer");
     DIC_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, DIC_ERR_INVALID_ARG, "gemm_nt: M=%ld N=%d K=%d lda=%ld ldw=%ld ldy=%ld", M, N, K, lda, ldw, ldy);
@@ -606,6 +649,7 @@ int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void
                 "gemm_nt: K, lda, ldw must be multiples of %d elements and the operands 16-B aligned (K=%d lda=%ld ldw=%ld): pad the rows", vec, K, lda, ldw);
     const int bn = N > 64 ? 128 : 64;
     GemmNtArgs a{A, lda, W, ldw, bias, Y, ldy, M, N, K, relu_a, (N + bn - 1) / bn};
+    a.a_plane = a_plane;
     const long tiles = ((M + GBM - 1) / GBM) * a.tiles_n;
     DIC_REQUIRE(tiles < (1L << 31), DIC_ERR_UNSUPPORTED, "gemm_nt: %ld tiles", tiles);
     const dim3 grid((unsigned)tiles), blk(256);
@@ -613,7 +657,10 @@ int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void
     const bool f32in = in_dtype == DIC_DTYPE_F32, f32out = out_dtype == DIC_DTYPE_F32;
 #define DIC_NT(TI, TO, BN) hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, BN>), grid, blk, 0, st, a)
     static const bool eight = [] { const char* e = getenv("DIC_GEMM_NT8"); return !(e && e[0] == '0'); }();      // (A/B switch: 0 = four waves per 128 x 128 tile)
-    if (bn == 128 && eight) {
+    if (ap) {
+        if (bn == 128) hipLaunchKernelGGL((gemm_nt8_kernel<float, float, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, float, 64, true>), grid, blk, 0, st, a);
+    } else if (bn == 128 && eight) {
 #define DIC_NT8(TI, TO) hipLaunchKernelGGL((gemm_nt8_kernel<TI, TO>), grid, dim3(512), 0, st, a)
         if (f32in) { if (f32out) DIC_NT8(float, float); else DIC_NT8(float, __bf16); }
         else { if (f32out) DIC_NT8(__bf16, float); else DIC_NT8(__bf16, __bf16); }
@@ -629,6 +676,17 @@ int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void
     return check_launch("gemm_nt");
 }
 
+int dic_gemm_nt(int in_dtype, int out_dtype, const void* A, long lda, const void* W, long ldw, const float* bias, long M, int N, int K,
+                void* Y, long ldy, int relu_a, dic_stream_t stream) {
+    return gemm_nt_impl(in_dtype, out_dtype, A, 0, lda, W, ldw, bias, M, N, K, Y, ldy, relu_a, stream);
+}
+
+int dic_gemm_nt_planes(const void* A_hi, long a_plane, long lda, const float* W, long ldw, const float* bias, long M, int N, int K, float* Y, long ldy,
+                       dic_stream_t stream) {
+    DIC_REQUIRE(a_plane > 0, DIC_ERR_INVALID_ARG, "gemm_nt_planes: plane stride %ld", a_plane);
+    return gemm_nt_impl(DIC_DTYPE_F32, DIC_DTYPE_F32, A_hi, a_plane, lda, W, ldw, bias, M, N, K, Y, ldy, 0, stream);
+}
+
 size_t dic_gemm_tn_workspace(long M, int N, int K, int K2) {
     if (M <= 0 || N <= 0 || K <= 0 || K2 < 0) return 0;
     long rpc; int bko;
@@ -636,9 +694,12 @@ size_t dic_gemm_tn_workspace(long M, int N, int K, int K2) {
     return (size_t)S * N * (K + K2) * sizeof(float);
 }
 
-int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
-                const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, int relu_x, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+static int gemm_tn_impl(int in_dtype, const void* A, long a_plane, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
+                        const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, int relu_x, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(in_dtype == DIC_DTYPE_F32 || in_dtype == DIC_DTYPE_BF16, DIC_ERR_INVALID_ARG, "gemm_tn: input dtype %d", in_dtype);
+    const bool ap = a_plane != 0;
+    DIC_REQUIRE(!ap || (in_dtype == DIC_DTYPE_F32 && N % 8 == 0 && lda % 8 == 0), DIC_ERR_UNSUPPORTED,
+                "gemm_tn: a split-plane A operand goes with f32 X, N and lda multiples of 8 (N=%d lda=%ld)", N, lda);
     DIC_REQUIRE(A && X && D && workspace, DIC_ERR_INVALID_ARG, "gemm_tn: NULL pointer");
     DIC_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= N && ldx >= K && kcols > 0 && kcols <= K && ldd >= kcols, DIC_ERR_INVALID_ARG,
                 "gemm_tn: M=%ld N=%d K=%d lda=%ld ldx=%ld ldd=%ld kcols=%d", M, N, K, lda, ldx, ldd, kcols);
@@ -656,9 +717,13 @@ int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, 
                 (size_t)S * N * KT * sizeof(float));
     const int tk1 = (K + bko - 1) / bko, tk2 = (K2 + bko - 1) / bko;
     GemmTnArgs a{A, lda, X, ldx, X2, ldx2, K2, (float*)workspace, M, N, K, rpc, (N + 127) / 128, tk1 + tk2, tk1, relu_x};
+    a.a_plane = a_plane;
     const dim3 grid((unsigned)(S * a.tiles_n * a.tiles_k)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    if (in_dtype == DIC_DTYPE_F32) {
+    if (ap) {
+        if (bko == 128) hipLaunchKernelGGL((gemm_tn_kernel<float, 128, true>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((gemm_tn_kernel<float, 64, true>), grid, blk, 0, st, a);
+    } else if (in_dtype == DIC_DTYPE_F32) {
         if (bko == 128) hipLaunchKernelGGL((gemm_tn_kernel<float, 128>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((gemm_tn_kernel<float, 64>), grid, blk, 0, st, a);
     } else {
@@ -668,6 +733,17 @@ int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, 
     hipLaunchKernelGGL(gemm_tn_finalize, dim3((N * KT + 255) / 256), dim3(256), 0, st, (const float*)workspace, S, N, KT, K, D, ldd, kcols, D2, ldd2,
                        accumulate ? 1.0f : 0.0f);
     return check_launch("gemm_tn");
+}
+
+int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
+                const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, int relu_x, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    return gemm_tn_impl(in_dtype, A, 0, lda, X, ldx, M, N, K, D, ldd, kcols, X2, ldx2, K2, D2, ldd2, accumulate, relu_x, workspace, workspace_bytes, stream);
+}
+
+int dic_gemm_tn_planes(const void* A_hi, long a_plane, long lda, const float* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
+                       const float* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, int relu_x, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(a_plane > 0, DIC_ERR_INVALID_ARG, "gemm_tn_planes: plane stride %ld", a_plane);
+    return gemm_tn_impl(DIC_DTYPE_F32, A_hi, a_plane, lda, X, ldx, M, N, K, D, ldd, kcols, X2, ldx2, K2, D2, ldd2, accumulate, relu_x, workspace, workspace_bytes, stream);
 }
 
 int dic_x3_row_proj(const float* x, const float* w, const float* bias, int64_t N, int in_features, int out_features, float* out, int relu_input,

@@ -182,6 +182,7 @@ struct RecFwdArgs {
     int boundary;          // out is time slots 1..R of an (R+2,B,2H) buffer: also write h0 (zeros without one) into slot 0 [:, :H] / slot R+1 [:, H:]
     const T* x = nullptr;  // lstm_rec_fwd8_kernel<XK>: (R,B,XK) packed inputs [features | 1 | 0...] and wih (2*4H, XK): the input projection runs in-kernel
     const T* wih = nullptr;
+    int ldx = 0;           // lstm_rec_fwd8x3_kernel<XK>: row length of x and wih in elements (a multiple of 4, <= XK)
 };
 
 template <typename T, bool X3 = false>
@@ -1114,6 +1115,408 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_bwd8_kernel(RecBwdArgs<__bf16
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The x3 f32 recurrence on EIGHT waves per 32-row tile (round 6; VERDICT r5 #1b).  The four-wave x3 kernels above hold a wave's W_hh slice as
+// hi / lo fragments in 256 registers -- one wave per SIMD, nothing to overlap with: their step was a serial chain of 96 MFMAs, 80 libm
+// transcendentals per lane (expf / tanhf: ~40 % of the step) and, in the backward, four exposed global-load round trips (no registers left to
+// prefetch into): 9.8-10.2 us per 32-row step against 6.5 us of HBM time for its 160 KB.  Here a wave owns 16 hidden units (W_hh hi / lo: 128
+// registers), two waves share a SIMD, the next step's saved state is requested a step ahead, and the gate non-linearities run on the
+// transcendental unit with a few ulp of error (sigmoid_x3 / tanh_x3 below: ~3e-7 relative, against the 2^-17 ~ 8e-6 the split products
+// carry).  Same saved-state layout (snative_off, f32 elements) and the same tensors as the four-wave kernels.
+//   XK = 32: the narrow encoder input is projected IN the kernel (rows [features | 1 | 0...] f32, W_ih rows [W | b_ih + b_hh | 0...] f32, both
+//   split into hi / lo on their way into registers / LDS): the 3.2 GB f32 gx tensor of the encoder -- written by dic_gemm_nt, read back here --
+//   does not exist.  The bias rides on the constant-one column (hi + lo of the bias: good to 2^-17 like every other term).
+__device__ __forceinline__ float sigmoid_x3(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp2(-kLog2e * x)); }
+__device__ __forceinline__ float tanh_x3(float x) {
+    // |x| < 0.3: the odd Taylor polynomial through x^9 (truncation 6e-8 relative at 0.3); else 1 - 2 / (1 + e^2|x|), whose absolute error of ~1e-7 is
+    // then at most 3.5e-7 relative.  Both branches are a handful of full-rate operations + one v_exp_f32 + one v_rcp_f32.
+    const float ax = fabsf(x), x2 = x * x;
+    const float p = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f), -1.0f / 3.0f), 1.0f);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp2(2.0f * kLog2e * ax));
+    return ax < 0.3f ? p : copysignf(t, x);
+}
+__device__ __forceinline__ void split8(const float* v, sbf16x8& hi, sbf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { __bf16 h, l; RecX3::split(v[j], h, l); hi[j] = h; lo[j] = l; }
+}
+
+template <int XK>
+__global__ __launch_bounds__(512, 1) void lstm_rec_fwd8x3_kernel(RecFwdArgs<float> a) {
+    constexpr bool PROJ = XK > 0;
+    constexpr int HP = RecX3::PITCH(SH);                   // 136 bf16 per row of an h image
+    constexpr int HIMG = SROWS * HP;
+    constexpr int GXP = S4 + 4;                            // f32 elements per staged gx row
+    constexpr int XS = XK + 8;                             // bf16 elements per row of an x image
+    constexpr int XIMG = SROWS * XS;
+    extern __shared__ __align__(16) unsigned char fsm32[];
+    __bf16* himg = reinterpret_cast<__bf16*>(fsm32);      // [2 buffers][hi | lo][HIMG]
+    float* gst = reinterpret_cast<float*>(himg + 4 * HIMG);            // !PROJ: [SROWS][GXP]
+    __bf16* ximg = himg + 4 * HIMG;                        // PROJ: [2 buffers][hi | lo][XIMG]
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = w8 >> 1, qh = w8 & 1;
+    const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
+    const int nbt = gridDim.x, bt = blockIdx.x;
+    const int b = b0 + r;
+    const bool ok = b < B;
+    const int bc = min(b, B - 1);
+
+    // A rows of block blk: m = lane & 31 -> gate 2 blk + (m >> 4), unit 16 w8 + (m & 15); hi / lo of the f32 weights, split once
+    sbf16x8 wfh[2][SH / 16], wfl[2][SH / 16];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < SH / 16; ++ks) {
+            const float* src = a.whh + ((size_t)(dir * 4 + 2 * blk + (r >> 4)) * SH + 16 * w8 + (r & 15)) * SH + ks * 16 + 8 * hh;
+            float v[8];
+            *reinterpret_cast<sf32x4*>(v) = *reinterpret_cast<const sf32x4*>(src);
+            *reinterpret_cast<sf32x4*>(v + 4) = *reinterpret_cast<const sf32x4*>(src + 4);
+            split8(v, wfh[blk][ks], wfl[blk][ks]);
+        }
+    sbf16x8 wxh[2][PROJ ? XK / 16 : 1], wxl[2][PROJ ? XK / 16 : 1];
+    if constexpr (PROJ) {
+        const int ldx = a.ldx;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int ks = 0; ks < XK / 16; ++ks) {
+                const float* src = a.wih + ((size_t)(dir * 4 + 2 * blk + (r >> 4)) * SH + 16 * w8 + (r & 15)) * ldx;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int k = ks * 16 + 8 * hh + j; v[j] = k < ldx ? src[k] : 0.f; }
+                split8(v, wxh[blk][ks], wxl[blk][ks]);
+            }
+    }
+
+    float c[8];                      // element e = 4 qq + j: unit 16 w8 + 8 qq + 4 hh + j
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
+        sf32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            if (a.h0) hv = *reinterpret_cast<const sf32x4*>(a.h0 + sstate_off(a.bm, dir, b, B) + u);
+            if (a.c0) cv = *reinterpret_cast<const sf32x4*>(a.c0 + sstate_off(a.bm, dir, b, B) + u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[4 * qq + j] = cv[j];
+        RecX3::store4(himg + r * HP + u, himg + HIMG + r * HP + u, hv);
+        if (a.boundary && ok) {
+            float* slot = dir ? a.out + (size_t)R * B * 2 * SH : a.out - (size_t)B * 2 * SH;
+            *reinterpret_cast<sf32x4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hv;
+        }
+        if (a.cs) *reinterpret_cast<sf32x4*>(a.cs + snative_off(R, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cv;
+    }
+    auto request_gx = [&](int step) {                      // 32 rows x two 1-KiB pieces by LDS-DMA, eight per wave
+        const int t = dir ? R - 1 - step : step;
+#pragma unroll
+        for (int k = 0; k < SROWS * 2 / 8; ++k) {
+            const int piece = k * 8 + w8, rowl = piece >> 1, part = piece & 1;
+            const int bb = min(b0 + rowl, B - 1);
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(a.gx + (((size_t)t * B + bb) * 2 + dir) * S4) + part * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(gst + rowl * GXP) + part * 1024), 16, 0, 0);
+        }
+    };
+    // PROJ: a step's x tile = 32 rows x ldx / 4 pieces of four f32 (ldx <= XK, a multiple of 4); columns [ldx, XK) of both images stay zero
+    const int xpc_n = PROJ ? a.ldx >> 2 : 1;
+    const bool xloader = PROJ && tid < SROWS * xpc_n;
+    const int xrow = tid / xpc_n, xpc = tid - xrow * xpc_n;
+    auto load_x = [&](int step) {
+        const int t = dir ? R - 1 - step : step;
+        return *reinterpret_cast<const sf32x4*>(a.x + ((size_t)t * B + min(b0 + xrow, B - 1)) * a.ldx + xpc * 4);
+    };
+    sf32x4 xnext = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (PROJ) {
+        for (int i = tid; i < 4 * XIMG / 8; i += 512) reinterpret_cast<uint4*>(ximg)[i] = uint4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        if (xloader) RecX3::store4(ximg + xrow * XS + xpc * 4, ximg + XIMG + xrow * XS + xpc * 4, load_x(0));
+    } else {
+        request_gx(0);
+    }
+    __syncthreads();
+
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? R - 1 - step : step;
+        const int cur = step & 1;
+        const __bf16* hcur = himg + cur * 2 * HIMG;
+        __bf16* hnxt = himg + (cur ^ 1) * 2 * HIMG;
+        sf32x16 acc[2];
+        if constexpr (PROJ) {
+            if (xloader && step + 1 < R) xnext = load_x(step + 1);       // in flight across the MFMA and gate-math phases
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[blk][k] = 0.f;
+            const __bf16* xc = ximg + cur * 2 * XIMG;
+#pragma unroll
+            for (int ks = 0; ks < XK / 16; ++ks) {          // G = W_ih . x_t^T (bias: the constant-one column)
+                const sbf16x8 xh = *reinterpret_cast<const sbf16x8*>(xc + r * XS + ks * 16 + 8 * hh);
+                const sbf16x8 xl = *reinterpret_cast<const sbf16x8*>(xc + XIMG + r * XS + ks * 16 + 8 * hh);
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wxh[blk][ks], xh, acc[blk], 0, 0, 0);
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wxl[blk][ks], xh, acc[blk], 0, 0, 0);
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wxh[blk][ks], xl, acc[blk], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const sf32x4 gv = *reinterpret_cast<const sf32x4*>(gst + r * GXP + g * SH + 16 * w8 + 8 * qq + 4 * hh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[g >> 1][8 * (g & 1) + 4 * qq + j] = gv[j];
+                }
+            lds_barrier();                                 // every wave has read its part of the staged tile
+            if (step + 1 < R) request_gx(step + 1);        // lands during the MFMAs / gate math (the closing wait counts the stores behind it)
+        }
+        {   // the recurrent product: B fragments (hi and lo image) requested DEPTH k-steps ahead
+            constexpr int NK = SH / 16, DEPTH = 4;
+            sbf16x8 rh[DEPTH], rl[DEPTH];
+            const __bf16* bh = hcur + r * HP + 8 * hh;
+            const __bf16* bl = bh + HIMG;
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) {
+                rh[i] = *reinterpret_cast<const sbf16x8*>(bh + i * 16);
+                rl[i] = *reinterpret_cast<const sbf16x8*>(bl + i * 16);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfh[blk][ks], rh[ks % DEPTH], acc[blk], 0, 0, 0);
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfl[blk][ks], rh[ks % DEPTH], acc[blk], 0, 0, 0);
+                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfh[blk][ks], rl[ks % DEPTH], acc[blk], 0, 0, 0);
+                }
+                if (ks + DEPTH < NK) {
+                    rh[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(bh + (ks + DEPTH) * 16);
+                    rl[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(bl + (ks + DEPTH) * 16);
+                }
+            }
+        }
+        const bool last = step == R - 1;
+        const size_t row = (size_t)t * B + bc;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
+            sf32x4 iv, fv, gv, ov, cv, hv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * qq + j;
+                const float ig = sigmoid_x3(acc[0][k]), fg = sigmoid_x3(acc[0][8 + k]), gg = tanh_x3(acc[1][k]), og = sigmoid_x3(acc[1][8 + k]);
+                const float cn = fmaf(fg, c[k], ig * gg);
+                const float hn = og * tanh_x3(cn);
+                c[k] = cn;
+                cv[j] = cn; hv[j] = hn; iv[j] = ig; fv[j] = fg; gv[j] = gg; ov[j] = og;
+            }
+            RecX3::store4(hnxt + r * HP + u, hnxt + HIMG + r * HP + u, hv);
+            if (a.gates) {
+                *reinterpret_cast<sf32x4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 0, q, hh, r)) = iv;
+                *reinterpret_cast<sf32x4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 1, q, hh, r)) = fv;
+                *reinterpret_cast<sf32x4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 2, q, hh, r)) = gv;
+                *reinterpret_cast<sf32x4*>(a.gates + snative_off(t, nbt, bt, dir, w4, 4, 3, q, hh, r)) = ov;
+                *reinterpret_cast<sf32x4*>(a.cs + snative_off(t, nbt, bt, dir, w4, 1, 0, q, hh, r)) = cv;
+            }
+            if (ok) {
+                *reinterpret_cast<sf32x4*>(a.out + row * 2 * SH + dir * SH + u) = hv;
+                if (last) {
+                    *reinterpret_cast<sf32x4*>(a.hn + sstate_off(a.bm, dir, b, B) + u) = hv;
+                    *reinterpret_cast<sf32x4*>(a.cn + sstate_off(a.bm, dir, b, B) + u) = cv;
+                }
+            }
+        }
+        if constexpr (PROJ) {
+            if (xloader && step + 1 < R) {
+                __bf16* xn = ximg + (cur ^ 1) * 2 * XIMG + xrow * XS + xpc * 4;
+                RecX3::store4(xn, xn + XIMG, xnext);
+            }
+        } else {
+            // (as in the bf16 kernel: the DMA of the next tile has landed once only the stores issued after it are in flight -- 10 saved-state
+            // stores per wave; the 2 `out` stores may have been branched over)
+            if (a.gates) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        lds_barrier();
+    }
+}
+
+// The backward of the same: dh[unit][batch] on v_mfma_f32_16x16x32_bf16 as in lstm_rec_bwd8_kernel, three MFMAs per (k-step, batch block) -- W_hh^T hi / lo
+// (split once at start-up) against the hi / lo images of the dG tile.  The gate gradients LEAVE AS THOSE TWO IMAGES: dgx is a pair of bf16 planes
+// [hi | lo][R*B][2*4H] ("split planes": dG = hi + lo to 2^-17, the same bytes as f32) -- what the weight-gradient and input-gradient products downstream
+// multiply anyway (dic_gemm_tn / dic_gemm_nt take the planes as they lie: no conversion in their loops), and the f32 copy of the tile (66 KB of LDS, a third
+// store per element) is gone.  Half of W_hh^T's lo fragments live in the LDS that frees (the register file is full at two waves per SIMD: 128 registers of
+// weights + 48 of prefetched state).  The next step's saved gates / cell states / dL/dout are requested BEFORE the product of the current one (the four-wave
+// kernel had no registers for that: four exposed round trips per step).
+constexpr int BX_LDSK = 8;                       // k-steps (of 16) whose lo fragments of W_hh^T are read from LDS instead of held in registers
+__global__ __launch_bounds__(512, 1) void lstm_rec_bwd8x3_kernel(RecBwdArgs<float> a) {
+    constexpr int GPB = RecX3::PITCH(S4);                 // 520 bf16 per row of an image
+    constexpr int NKS = S4 / 32, NREG = NKS - BX_LDSK;
+    extern __shared__ __align__(16) unsigned char rsm[];
+    __bf16* dgh = reinterpret_cast<__bf16*>(rsm);         // [32][GPB] hi image, then the lo image: the MFMA operands AND what leaves for global memory
+    __bf16* dgl = dgh + SROWS * GPB;
+    sbf16x8* wlds = reinterpret_cast<sbf16x8*>(rsm + (size_t)2 * SROWS * GPB * sizeof(__bf16));      // [8 waves][BX_LDSK][64 lanes] lo fragments
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5, n16 = lane & 15, g4 = lane >> 4;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6), w4 = w8 >> 1, qh = w8 & 1;
+    const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
+    const int b = b0 + r;
+    const bool ok = b < B;
+    const int bc = min(b, B - 1);
+
+    // A operand (as lstm_rec_bwd8_kernel): lane (m = lane & 15, kg = lane >> 4) holds W_hh^T[unit s(m)][32 ks + 8 kg .. + 7], s(m) = 8 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3)
+    sbf16x8 wth[NKS], wtl[NREG];
+    sbf16x8* wl_mine = wlds + (size_t)w8 * BX_LDSK * 64 + lane;
+    {
+        const int m = n16, unit = 16 * w8 + 8 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            float v[8];
+            if (a.transposed) {
+                const float* src = a.whh + ((size_t)dir * SH + unit) * S4 + ks * 32 + 8 * g4;
+                *reinterpret_cast<sf32x4*>(v) = *reinterpret_cast<const sf32x4*>(src);
+                *reinterpret_cast<sf32x4*>(v + 4) = *reinterpret_cast<const sf32x4*>(src + 4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = a.whh[((size_t)dir * S4 + ks * 32 + 8 * g4 + j) * SH + unit];
+            }
+            sbf16x8 lo;
+            split8(v, wth[ks], lo);
+            if (ks < NREG) wtl[ks] = lo;
+            else wl_mine[(ks - NREG) * 64] = lo;           // (read back by this lane only: no barrier needed)
+        }
+    }
+    float dh[8], dc[8], ccar[8];     // element e = 4 qq + j: unit 16 w8 + 8 qq + 4 hh + j of batch row r
+    float bsum[8];                   // bias gradient: this wave copies out the pieces of ONE image (hi for even waves, lo for odd) -> columns 8 lane .. + 7 of it
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    const int nbt = gridDim.x, bt = blockIdx.x;
+    {
+        const int t0 = dir ? 0 : R - 1;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh, q = 2 * qh + qq;
+            sf32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                if (a.dhn) hv = *reinterpret_cast<const sf32x4*>(a.dhn + sstate_off(a.bm, dir, b, B) + u);
+                if (a.dcn) cv = *reinterpret_cast<const sf32x4*>(a.dcn + sstate_off(a.bm, dir, b, B) + u);
+            }
+            const sf32x4 ct = *reinterpret_cast<const sf32x4*>(a.cs + snative_off(t0, nbt, bt, dir, w4, 1, 0, q, hh, r));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dh[4 * qq + j] = hv[j]; dc[4 * qq + j] = cv[j]; ccar[4 * qq + j] = ct[j]; }
+        }
+    }
+    // Addresses: snative_off(t, nbt, bt, dir, w4, G, g, q, hh, r) = (((t nbt + bt) 2 + dir) 4 + w4) G 1024 + g 1024 + q 256 + 4 lane elements -- a wave-uniform
+    // base (scalar registers) + ONE per-lane 32-bit offset, instead of a 64-bit per-lane address per load
+    struct StepQ { sf32x4 ib, fb, gb, ob, cp, go; };
+    const unsigned lane4 = 4u * (unsigned)lane;
+    const unsigned go_lane = (unsigned)bc * (2 * SH) + 4u * (unsigned)hh;
+    auto load_q = [&](int step, int qq, StepQ& d) {
+        const int t = dir ? step : R - 1 - step;
+        const int tp = step == R - 1 ? R : (dir ? t + 1 : t - 1);
+        const float* gb_ = a.gates + ((((size_t)t * nbt + bt) * 2 + dir) * 4 + w4) * 4096 + (2 * qh + qq) * 256;
+        const float* cb_ = a.cs + ((((size_t)tp * nbt + bt) * 2 + dir) * 4 + w4) * 1024 + (2 * qh + qq) * 256;
+        d.ib = *reinterpret_cast<const sf32x4*>(gb_ + lane4);
+        d.fb = *reinterpret_cast<const sf32x4*>(gb_ + 1024 + lane4);
+        d.gb = *reinterpret_cast<const sf32x4*>(gb_ + 2048 + lane4);
+        d.ob = *reinterpret_cast<const sf32x4*>(gb_ + 3072 + lane4);
+        d.cp = *reinterpret_cast<const sf32x4*>(cb_ + lane4);
+        if (a.dout) d.go = *reinterpret_cast<const sf32x4*>(a.dout + (size_t)t * B * 2 * SH + dir * SH + 16 * w8 + 8 * qq + go_lane);
+    };
+    __bf16* plane = reinterpret_cast<__bf16*>(a.dgx) + (size_t)qh * R * B * 2 * S4;       // this wave's output plane (hi: even waves, lo: odd)
+    const __bf16* img = qh ? dgl : dgh;
+    StepQ in0, in1, nx0, nx1;
+    load_q(0, 0, in0); load_q(0, 1, in1);
+    for (int step = 0; step < R; ++step) {
+        const int t = dir ? step : R - 1 - step;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh;
+            const StepQ cur = qq == 0 ? in0 : in1;
+            sf32x4 di, df, dg, dO;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * qq + j;
+                const float ig = cur.ib[j], fg = cur.fb[j], gg = cur.gb[j], og = cur.ob[j], cp = cur.cp[j];
+                const float go = a.dout ? cur.go[j] : 0.f;
+                const float tc = tanh_x3(ccar[k]);
+                const float dht = dh[k] + ((a.relu && !(tc > 0.f)) ? 0.f : go);
+                const float dct = fmaf(dht * og, 1.0f - tc * tc, dc[k]);
+                const float vi = dct * gg * ig * (1.0f - ig), vf = dct * cp * fg * (1.0f - fg);
+                const float vg = dct * ig * (1.0f - gg * gg), vo = dht * tc * og * (1.0f - og);
+                di[j] = ok ? vi : 0.f; df[j] = ok ? vf : 0.f; dg[j] = ok ? vg : 0.f; dO[j] = ok ? vo : 0.f;
+                dc[k] = dct * fg;
+                ccar[k] = cp;
+            }
+            const int o = r * GPB + u;
+            RecX3::store4(dgh + o, dgl + o, di);
+            RecX3::store4(dgh + o + SH, dgl + o + SH, df);
+            RecX3::store4(dgh + o + 2 * SH, dgl + o + 2 * SH, dg);
+            RecX3::store4(dgh + o + 3 * SH, dgl + o + 3 * SH, dO);
+        }
+        if (step + 1 < R) { load_q(step + 1, 0, nx0); load_q(step + 1, 1, nx1); }
+        lds_barrier();                                     // the dG tile of this step is complete
+        // dh_prev[unit][batch] = sum_n W_hh[n][unit] dG[batch][n]: two batch blocks (rows n16, 16 + n16) x 16 k-steps of 32 gate columns x (hi.hi + lo.hi + hi.lo)
+        sf32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const __bf16* b0h = dgh + n16 * GPB + 8 * g4;
+        const __bf16* b1h = dgh + (16 + n16) * GPB + 8 * g4;
+        const __bf16* b0l = b0h + SROWS * GPB;
+        const __bf16* b1l = b1h + SROWS * GPB;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const sbf16x8 f0h = *reinterpret_cast<const sbf16x8*>(b0h + ks * 32), f1h = *reinterpret_cast<const sbf16x8*>(b1h + ks * 32);
+            const sbf16x8 f0l = *reinterpret_cast<const sbf16x8*>(b0l + ks * 32), f1l = *reinterpret_cast<const sbf16x8*>(b1l + ks * 32);
+            const sbf16x8 wl = ks < NREG ? wtl[ks < NREG ? ks : 0] : wl_mine[(ks - NREG) * 64];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wth[ks], f0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wth[ks], f1h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, f0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, f1h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wth[ks], f0l, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wth[ks], f1l, acc1, 0, 0, 0);
+            if (ks & 1) {                                  // one of this wave's eight 1-KiB rows of its image: LDS -> its plane in global memory + bias column sums
+                const int rowl = (ks >> 1) * 4 + w4;
+                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(img + rowl * GPB) + lane * 16);
+                if (b0 + rowl < B)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(plane + (((size_t)t * B + b0 + rowl) * 2 + dir) * S4) + lane * 16) = v;
+                const sbf16x8 x = __builtin_bit_cast(sbf16x8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[e] += (float)x[e];
+            }
+        }
+        // (lane (n, g) -> math lane n + 16 g: see lstm_rec_bwd8_kernel)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, (float)acc0[e]), __builtin_bit_cast(unsigned, (float)acc1[e]), false, false);
+            dh[e] = __builtin_bit_cast(float, (unsigned)s[0]);
+            dh[4 + e] = __builtin_bit_cast(float, (unsigned)s[1]);
+        }
+        lds_barrier();                                     // every wave is done reading the tile
+        in0 = nx0; in1 = nx1;
+    }
+    if (a.dbias_part) {      // column sums of hi (even waves) and lo (odd waves) over disjoint rows: add the eight through LDS (the images are free now), one partial per workgroup
+        float* red = reinterpret_cast<float*>(rsm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w8 * S4 + lane * 8 + e] = bsum[e];
+        __syncthreads();
+        float* o = a.dbias_part + ((size_t)blockIdx.x * 2 + dir) * S4;
+        for (int i = tid; i < S4; i += 512) {
+            float sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) sum += red[ww * S4 + i];
+            o[i] = sum;
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh;
+            sf32x4 hv, cv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hv[j] = dh[4 * qq + j]; cv[j] = dc[4 * qq + j]; }
+            *reinterpret_cast<sf32x4*>(a.dh0 + sstate_off(a.bm, dir, b, B) + u) = hv;
+            *reinterpret_cast<sf32x4*>(a.dc0 + sstate_off(a.bm, dir, b, B) + u) = cv;
+        }
+    }
+}
+
 // ---- 16-row tiles (round 4): batches up to REC16_MAX_BATCH.  At the reference's own B = 256 the 32-row kernels above put 16 workgroups on 256 CUs and
 // every recurrence step costs 2.4 (forward) / 3.2 us (backward) of serial MFMA + gate math per workgroup; half the rows per workgroup is half of both on
 // twice the CUs.  The product runs on v_mfma_f32_16x16x32_bf16 in the same transposed form (A = weights, B = h^T / dG^T of the 16 batch rows): lane
@@ -1474,6 +1877,24 @@ static int rec_fwd(const void* gx, const void* whh, const float* h0, const float
     return check_launch("lstm_rec_fwd");
 }
 
+// the x3 recurrence forward on eight waves (XK = 0: gx from the projection kernel; XK = 32: the narrow input projected in the kernel)
+template <int XK>
+static int rec_fwd8x3(const float* gx, const float* x, const float* wih, int ldx, const float* whh, const float* h0, const float* c0, int R, int B, float* out,
+                      float* hn, float* cn, float* gates, float* cs, int bm, hipStream_t st) {
+    RecFwdArgs<float> a{gx, whh, h0, c0, out, hn, cn, gates, cs, R, B, (bm & 1) != 0, (bm & 2) != 0};
+    a.x = x; a.wih = wih; a.ldx = ldx;
+    const size_t himg = (size_t)4 * SROWS * RecX3::PITCH(SH) * sizeof(__bf16);
+    const size_t lds = himg + (XK ? (size_t)4 * SROWS * (XK + 8) * sizeof(__bf16) : (size_t)SROWS * (S4 + 4) * sizeof(float));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd8x3_kernel<XK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_fwd8x3: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lstm_rec_fwd8x3_kernel<XK>, dim3((B + SROWS - 1) / SROWS, 2), dim3(512), lds, st, a);
+    return check_launch("lstm_rec_fwd8x3");
+}
+
 template <typename T, bool X3 = false>
 static int rec_bwd(const void* whh, int transposed, const void* gates, const void* cs, const void* dout, const float* dhn,
                    const float* dcn, int R, int B, void* dgx, float* dh0, float* dc0, float* dbias, void* workspace, int bm, int relu, hipStream_t st) {
@@ -1504,6 +1925,17 @@ static int rec_bwd(const void* whh, int transposed, const void* gates, const voi
             eight = true;
         }
     }
+    if constexpr (X3) {
+        const size_t lds = (size_t)2 * SROWS * RecX3::PITCH(S4) * sizeof(__bf16) + (size_t)8 * BX_LDSK * 64 * 16;      // the two images + the W_hh^T lo fragments kept in LDS
+        static bool attrx_set = false;
+        if (!attrx_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_bwd8x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_bwd8x3: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            attrx_set = true;
+        }
+        hipLaunchKernelGGL(lstm_rec_bwd8x3_kernel, dim3(nwg, 2), dim3(512), lds, st, a);
+        eight = true;
+    }
     if (!eight) hipLaunchKernelGGL((lstm_rec_bwd_kernel<T, X3>), dim3(nwg, 2), dim3(256), lds, st, a);
     if (dbias) hipLaunchKernelGGL(lstm_rec_dbias_finalize, dim3(2 * S4 / 32), dim3(256), 0, st, (const float*)workspace, nwg, dbias);
     return check_launch("lstm_rec_bwd");
@@ -1523,7 +1955,9 @@ int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0
     DIC_REQUIRE(dtype == DIC_DTYPE_F32 || dtype == DIC_DTYPE_BF16 || dtype == DIC_DTYPE_F32X3, DIC_ERR_INVALID_ARG, "lstm_rec_fwd: dtype %d", dtype);
     DIC_REQUIRE(gx && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_rec_fwd: NULL pointer");
     DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_rec_fwd: gates and cs go together");
-    if (dtype == DIC_DTYPE_F32X3) return rec_fwd<float, true>(gx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_batch_major, (hipStream_t)stream);
+    if (dtype == DIC_DTYPE_F32X3)
+        return rec_fwd8x3<0>((const float*)gx, nullptr, nullptr, 0, (const float*)whh, h0, c0, R, B, (float*)out, hn, cn, (float*)gates, (float*)cs, state_batch_major,
+                             (hipStream_t)stream);
     if (dtype == DIC_DTYPE_F32) return rec_fwd<float>(gx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_batch_major, (hipStream_t)stream);
     return rec_fwd<__bf16>(gx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_batch_major, (hipStream_t)stream);
 }
@@ -1549,6 +1983,16 @@ int dic_lstm_rec_fwd_proj(const void* x, const void* wih, const void* whh, const
     if (I == 32) hipLaunchKernelGGL(lstm_rec_fwd8_kernel<32>, grid, dim3(512), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(lstm_rec_fwd8_kernel<64>, grid, dim3(512), lds, (hipStream_t)stream, a);
     return check_launch("lstm_rec_fwd_proj");
+}
+
+int dic_lstm_rec_fwd_proj_x3(const float* x, const float* wih, int ldx, const float* whh, const float* h0, const float* c0, int R, int B, int H, float* out,
+                             float* hn, float* cn, float* gates, float* cs, int state_flags, dic_stream_t stream) {
+    DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_rec_fwd_proj_x3: non-positive size");
+    DIC_REQUIRE(H == SH, DIC_ERR_UNSUPPORTED, "lstm_rec_fwd_proj_x3: hidden size %d (compiled for %d)", H, SH);
+    DIC_REQUIRE(ldx >= 4 && ldx <= 32 && ldx % 4 == 0, DIC_ERR_UNSUPPORTED, "lstm_rec_fwd_proj_x3: row length %d (a multiple of 4 up to 32)", ldx);
+    DIC_REQUIRE(x && wih && whh && out && hn && cn, DIC_ERR_INVALID_ARG, "lstm_rec_fwd_proj_x3: NULL pointer");
+    DIC_REQUIRE((gates == nullptr) == (cs == nullptr), DIC_ERR_INVALID_ARG, "lstm_rec_fwd_proj_x3: gates and cs go together");
+    return rec_fwd8x3<32>(nullptr, x, wih, ldx, whh, h0, c0, R, B, out, hn, cn, gates, cs, state_flags, (hipStream_t)stream);
 }
 
 // (sized for the 16-row kernels' one partial per 16 rows where they may run)

@@ -43,6 +43,7 @@ GX_LANE_NATIVE = os.environ.get('DIC_GX_LANE_NATIVE', '1') != '0'     # (A/B swi
 ROW_PROJ = os.environ.get('DIC_ROW_PROJ', '1') != '0'                  # (A/B switch: 0 = library GEMM for the decoder's input projection)
 RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B switch: 0 = rectify the encoder output with a torch pass)
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
+X3_REC_PROJ = os.environ.get('DIC_X3_REC_PROJ', '1') != '0'            # (A/B switch: 0 = dic_gemm_nt + gx for the encoder's forward in the x3 step)
 REC_PROJ = os.environ.get('DIC_REC_PROJ', '1') != '0'                  # (A/B switch: 0 = dic_gemm_nt + dic_lstm_rec_fwd for the encoder's small-batch forward)
 FWD_XPROJ = os.environ.get('DIC_FWD_XPROJ', '1') != '0'                # (A/B switch: 0 = dic_row_proj + dic_lstm_fwd for the decoder's large-batch forward: gx through HBM)
 SMALL_BATCH = int(os.environ.get('DIC_SMALL_BATCH') or 4096)      # up to here the one-tile-per-workgroup kernels of csrc/dic_lstm32.hip beat the 64-row pipelined ones
@@ -138,19 +139,21 @@ class _BiLstm(torch.autograd.Function):
         x3 = f32 and _ops.f32_products() == 'x3'                  # f32 tensors, products as three bf16 MFMAs (csrc/dic_gemm.hip)
         narrow = (not f32) and packed_width(I) > 0                 # bf16, narrow input (encoder): rows packed to 32 / 64 with the bias as a constant-one column
         proj = narrow and not small                                # ... and projected inside the 64-row recurrence kernel
-        # K of the projection (bf16: padded to the MFMA step; f32 'x3': to the 16-B vector loads of dic_gemm_nt)
-        Ip = ((I + 3) // 4 * 4 if x3 else I) if f32 else (packed_width(I) if narrow else (I + 15) // 16 * 16)
+        # x3, narrow input (encoder): projected INSIDE the eight-wave x3 recurrence kernel from f32 rows [features | 1 | 0...] (round 6: no gx tensor)
+        x3proj = x3 and I + 1 <= 32 and X3_REC_PROJ
+        # K of the projection (bf16: padded to the MFMA step; f32 'x3': to the 16-B vector loads of dic_gemm_nt / the in-kernel projection)
+        Ip = (((I + 1 if x3proj else I) + 3) // 4 * 4 if x3 else I) if f32 else (packed_width(I) if narrow else (I + 15) // 16 * 16)
         need = any(ctx.needs_input_grad)
         pf = [N.f32c(p.detach()) for p in params]
         wih = torch.empty((8 * H, Ip), device=dev, dtype=T)
         whh = torch.empty((2, 4 * H, H), device=dev, dtype=T)
-        whh_t = torch.empty((2, H, 4 * H), device=dev, dtype=T) if (need and not f32) else None
-        bias = None if narrow else torch.empty(8 * H, device=dev, dtype=T)
+        whh_t = torch.empty((2, H, 4 * H), device=dev, dtype=T) if (need and (x3 or not f32)) else None
+        bias = None if (narrow or x3proj) else torch.empty(8 * H, device=dev, dtype=T)
         L, st = N.lib(), N.stream_of(x)
         # (the decoder's large-batch input gradient runs on dic_lstm_dx_tile, whose weight operand is W_ih^T: packed in the same launch)
         dx_tile = need and ctx.needs_input_grad[0] and (not f32) and I == WIDE_INPUT and Ip == I and not small and R * B >= DX_TILE_MIN_ROWS
         wih_t = torch.empty((Ip, 8 * H), device=dev, dtype=T) if dx_tile else None
-        N.check(L.dic_lstm_pack(code, N.ptr_array(pf), H, I, Ip, int(narrow), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), N.ptr(wih_t), st), 'dic_lstm_pack')
+        N.check(L.dic_lstm_pack(code, N.ptr_array(pf), H, I, Ip, int(narrow or x3proj), N.ptr(wih), N.ptr(whh), N.ptr(whh_t), N.ptr(bias), N.ptr(wih_t), st), 'dic_lstm_pack')
         ctx.wih_t = wih_t
         if packed:                                                 # (R,B,32) bf16 rows [features | 1 | 0...] from ops.sci_cci_packed
             if not narrow or I_in != Ip or x.dtype != T:
@@ -163,7 +166,7 @@ class _BiLstm(torch.autograd.Function):
             if Ip != I:
                 xb = torch.nn.functional.pad(xb, (0, Ip - I))
             xb = xb.contiguous()
-            if narrow:
+            if narrow or x3proj:
                 xb[..., I].fill_(1.0)                              # the bias rides along as a constant-one input column
         # input_rectify: relu(x) is applied by the projection / weight-gradient kernels on the raw x (large decoder path), else here
         relu_kernel = bool(relu_in) and (((not small) and (not proj) and Ip == WIDE_INPUT and ROW_PROJ)
@@ -187,7 +190,7 @@ class _BiLstm(torch.autograd.Function):
                 cs = torch.empty((R + 1, Bp, 2, H), device=dev, dtype=T)     # (time slot R: c0, written by the forward)
             # input projection gx (R*B, 2*4*H) of all steps: hand-written MFMA kernels (no library GEMM) except in the exact-f32 parity mode
             gx = None
-            if narrow and REC_PROJ:
+            if (narrow and REC_PROJ) or x3proj:
                 pass                                                             # (projected inside the recurrence kernel below: no gx)
             elif narrow:
                 gx = _ops.gemm_nt(xb.view(R * B, Ip), wih)                       # (the bias rides in the constant-one column)
@@ -200,7 +203,10 @@ class _BiLstm(torch.autograd.Function):
                 gx = _ops.gemm_nt(xb.view(R * B, Ip), wih, bias.float(), relu_a=relu_kernel)
             else:
                 gx = torch.addmm(bias, xb.view(R * B, Ip), wih.t())
-            if gx is None:
+            if gx is None and x3proj:
+                N.check(L.dic_lstm_rec_fwd_proj_x3(N.ptr(xb), N.ptr(wih), Ip, N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, N.ptr(out), N.ptr(hn), N.ptr(cn),
+                                                   N.ptr(gates), N.ptr(cs), int(bm) | (2 if kernel_boundary else 0), st), 'dic_lstm_rec_fwd_proj_x3')
+            elif gx is None:
                 N.check(L.dic_lstm_rec_fwd_proj(N.ptr(xb), N.ptr(wih), N.ptr(whh), N.ptr(h0c), N.ptr(c0c), R, B, H, Ip, N.ptr(out), N.ptr(hn), N.ptr(cn),
                                                 N.ptr(gates), N.ptr(cs), int(bm) | (2 if kernel_boundary else 0), st), 'dic_lstm_rec_fwd_proj')
             else:
@@ -239,7 +245,7 @@ class _BiLstm(torch.autograd.Function):
         ctx.x_dtype = x.dtype
         ctx.has_init = h0 is not None
         ctx.params = params
-        ctx.save_for_backward(xb, wih, whh if f32 else whh_t, gates, cs, out_ext, h0c, c0c)
+        ctx.save_for_backward(xb, wih, whh if (f32 and not x3) else whh_t, gates, cs, out_ext, h0c, c0c)
         ctx.set_materialize_grads(False)       # an output nobody differentiates (c_n, often h_n or out) arrives as None, not as a zero tensor
         # relu: the caller consumes relu(out) only (the decoder's input, clustering_interp.py:38-41).  The raw rows stay in out_ext for the
         # weight-gradient products (the 64-row kernels write the rectified copy next to them); the backward kernel applies the ReLU
@@ -258,7 +264,9 @@ class _BiLstm(torch.autograd.Function):
         T = torch.float32 if f32 else torch.bfloat16
         code = N.DTYPE_F32 if f32 else N.DTYPE_BF16
         dev = out_ext.device
-        dgx = torch.empty((R, B, 2, 4, H), device=dev, dtype=T)
+        # x3: the gate gradients leave the recurrence kernel as SPLIT PLANES (2, R*B, 8H) bf16 -- hi / lo with dG = hi + lo, the same bytes as f32 -- which the
+        # products below multiply as they lie (csrc/dic_lstm32.hip lstm_rec_bwd8x3_kernel; dic_gemm_tn_planes / dic_gemm_nt_planes)
+        dgx = torch.empty((2, R * B, 8 * H), device=dev, dtype=torch.bfloat16) if ctx.x3 else torch.empty((R, B, 2, 4, H), device=dev, dtype=T)
         dh0 = torch.empty((B, 2, H) if bm else (2, B, H), device=dev, dtype=torch.float32)
         dc0 = torch.empty_like(dh0)
         doutb = None if dout is None else (dout if dout.dtype == T else dout.to(T)).contiguous()
@@ -268,13 +276,13 @@ class _BiLstm(torch.autograd.Function):
         dbias = torch.empty((2, 4 * H), device=dev, dtype=torch.float32)         # summed inside the kernel, f32
         if small:
             ws = torch.empty(max(16, Lb.dic_lstm_rec_bwd_workspace(B)), device=dev, dtype=torch.uint8)
-            N.check(Lb.dic_lstm_rec_bwd(N.DTYPE_F32X3 if ctx.x3 else code, N.ptr(whh_b), int(not f32), N.ptr(gates), N.ptr(cs), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
+            N.check(Lb.dic_lstm_rec_bwd(N.DTYPE_F32X3 if ctx.x3 else code, N.ptr(whh_b), int(ctx.x3 or not f32), N.ptr(gates), N.ptr(cs), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
                                         R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), int(relu), st), 'dic_lstm_rec_bwd')
         else:
             ws = torch.empty(max(16, Lb.dic_lstm_bwd_workspace(B)), device=dev, dtype=torch.uint8)
             N.check(Lb.dic_lstm_bwd(N.ptr(whh_b), N.ptr(gates), N.ptr(cs), N.ptr(c0c), N.ptr(doutb), N.ptr(dhnc), N.ptr(dcnc),
                                     R, B, H, N.ptr(dgx), N.ptr(dh0), N.ptr(dc0), N.ptr(dbias), N.ptr(ws), ws.numel(), int(bm), int(relu), st), 'dic_lstm_bwd')
-        dg2 = dgx.view(R * B, 8 * H)
+        dg2 = dgx if ctx.x3 else dgx.view(R * B, 8 * H)
         use_dw = narrow and R * B >= 32                              # one-pass weight-gradient kernel (csrc/dic_lstmgrad.hip; it tiles the R*B rows by 32)
         fuse_dx = use_dw and Ip == 32 and I <= 19 and any(ctx.needs_input_grad[8:])       # ... which then also forms dX = dG.W_ih per direction (32-wide rows)
         x3 = ctx.x3
@@ -288,6 +296,8 @@ class _BiLstm(torch.autograd.Function):
                 N.check(Lb.dic_lstm_dx_tile(N.ptr(dg2), N.ptr(ctx.wih_t), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_tile')
             elif f32 and not x3:
                 dx = dg2 @ wih                                       # (R*B, Ip): the exact-f32 parity mode
+            elif x3:
+                dx = _ops.gemm_nt_planes(dg2, wih.t().contiguous())  # dX = dG . W_ih from the split planes of dG (W_ih^T: a (Ip, 8H) copy of the packed weights)
             else:
                 dx = _ops.gemm_nt(dg2, wih.t().contiguous())         # dX = dG . W_ih on dic_gemm_nt (W_ih^T: a (Ip, 8H) copy of the packed weights)
             if packed:
@@ -337,7 +347,7 @@ class _BiLstm(torch.autograd.Function):
                 xv = xb.view(R * B, Ip)
                 for d in range(2):              # (both products of a direction from ONE pass over its gate gradients)
                     hp = oe[:R * B, :H] if d == 0 else oe[2 * B:, H:]
-                    _ops.gemm_tn_into(dg2[:, 4 * H * d:4 * H * (d + 1)], xv, sinks[4 * d], kcols=I, accumulate=accumulate, x2=hp, dst2=sinks[4 * d + 1],
+                    _ops.gemm_tn_into(dg2[..., 4 * H * d:4 * H * (d + 1)], xv, sinks[4 * d], kcols=I, accumulate=accumulate, x2=hp, dst2=sinks[4 * d + 1],
                                       relu_x=ctx.x_relu_in_kernel)
                 N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             else:

@@ -782,6 +782,34 @@ def gemm_nt(a, w, bias=None, out_dtype=None, relu_a=False, out=None):
     return y
 
 
+def _planes(a):
+    """A "split-plane" f32 operand: (2, M, K) bf16, plane 0 = hi = bf16(x), plane 1 = lo = bf16(x - hi), x = hi + lo to 2^-17 -- what the x3 recurrence
+    kernels write (same bytes as f32; the products multiply the planes as they lie).  Rows contiguous, both planes with the same row stride."""
+    if a.dim() != 3 or a.shape[0] != 2 or a.dtype != torch.bfloat16 or a.stride(2) != 1:
+        raise ValueError(f'split planes: need a (2, M, K) bf16 tensor with contiguous rows, got {tuple(a.shape)} {a.dtype} strides {a.stride()}')
+    return a
+
+
+def planes_to_f32(a):
+    """The f32 tensor a split-plane operand stands for (tests, odd consumers)."""
+    return a[0].float() + a[1].float()
+
+
+def gemm_nt_planes(a, w, bias=None):
+    """y (M,N) f32 = a . w (N,K)^T (+ bias) with ``a`` a split-plane operand (2, M, K) and w f32: the three-term product without converting a."""
+    N.require_gpu(a, w)
+    a, w = _planes(a), _rows(w)
+    _, M, K = a.shape
+    if w.dtype != torch.float32 or w.shape[1] != K:
+        raise ValueError(f'gemm_nt_planes: a {tuple(a.shape)} vs w {tuple(w.shape)} {w.dtype}')
+    n = w.shape[0]
+    y = torch.empty((M, n), device=a.device, dtype=torch.float32)
+    b = None if bias is None else N.f32c(bias)
+    N.check(N.lib().dic_gemm_nt_planes(N.ptr(a), a.stride(0), a.stride(1), N.ptr(w), w.stride(0), N.ptr(b), M, n, K, N.ptr(y), y.stride(0), N.stream_of(a)),
+            'dic_gemm_nt_planes')
+    return y
+
+
 X3_ROW_PROJ = os.environ.get('DIC_X3_ROW_PROJ', '1') != '0'      # (A/B switch: 0 = dic_gemm_nt for the 256-input projections of the x3 step too)
 
 
@@ -806,10 +834,12 @@ def gemm_tn_into(a, x, dst, kcols=None, accumulate=False, x2=None, dst2=None, re
     product a^T . x2 from the same pass over ``a`` (dW_ih and dW_hh of one LSTM direction read the gate gradients once).  ``relu_x``: the first product
     runs on relu(x)."""
     N.require_gpu(a, x, dst)
-    a, x, dst = _rows(a), _rows(x), _rows(dst)
-    if a.dtype != x.dtype or a.shape[0] != x.shape[0] or dst.dtype != torch.float32:
+    planes = a.dim() == 3                            # a split-plane operand (2, M, N) bf16 standing for f32 gate gradients: x / x2 are f32
+    a, x, dst = (_planes(a) if planes else _rows(a)), _rows(x), _rows(dst)
+    a_dtype = torch.float32 if planes else a.dtype
+    if a_dtype != x.dtype or a.shape[-2] != x.shape[0] or dst.dtype != torch.float32:
         raise ValueError(f'gemm_tn: a {tuple(a.shape)} {a.dtype}, x {tuple(x.shape)} {x.dtype}, dst {dst.dtype}')
-    M, n = a.shape
+    M, n = a.shape[-2:]
     K = x.shape[1]
     kcols = K if kcols is None else int(kcols)
     if tuple(dst.shape) != (n, kcols):
@@ -818,10 +848,15 @@ def gemm_tn_into(a, x, dst, kcols=None, accumulate=False, x2=None, dst2=None, re
     if x2 is not None:
         x2, dst2 = _rows(x2), _rows(dst2)
         K2 = x2.shape[1]
-        if x2.dtype != a.dtype or x2.shape[0] != M or tuple(dst2.shape) != (n, K2) or dst2.dtype != torch.float32:
+        if x2.dtype != a_dtype or x2.shape[0] != M or tuple(dst2.shape) != (n, K2) or dst2.dtype != torch.float32:
             raise ValueError(f'gemm_tn: x2 {tuple(x2.shape)} {x2.dtype}, dst2 {tuple(dst2.shape)} {dst2.dtype}')
     L = N.lib()
     ws = _ws(L.dic_gemm_tn_workspace(M, n, K, K2), a.device)
+    if planes:
+        N.check(L.dic_gemm_tn_planes(N.ptr(a), a.stride(0), a.stride(1), N.ptr(x), x.stride(0), M, n, K, N.ptr(dst), dst.stride(0), kcols,
+                                     N.ptr(x2), x2.stride(0) if x2 is not None else 0, K2, N.ptr(dst2), dst2.stride(0) if dst2 is not None else 0,
+                                     int(bool(accumulate)), int(bool(relu_x)), N.ptr(ws), ws.numel(), N.stream_of(a)), 'dic_gemm_tn_planes')
+        return dst
     N.check(L.dic_gemm_tn(_dt(a), N.ptr(a), a.stride(0), N.ptr(x), x.stride(0), M, n, K, N.ptr(dst), dst.stride(0), kcols,
                           N.ptr(x2), x2.stride(0) if x2 is not None else 0, K2, N.ptr(dst2), dst2.stride(0) if dst2 is not None else 0,
                           int(bool(accumulate)), int(bool(relu_x)), N.ptr(ws), ws.numel(), N.stream_of(a)), 'dic_gemm_tn')

@@ -309,7 +309,9 @@ int dic_lstm_bwd(const void* whh_t, const void* gates, const void* cs, const flo
  * DIC_DTYPE_F32 -- every tensor f32, the recurrent product on v_mfma_f32_32x32x2_f32 (exact f32: the configuration of the 1e-5
  * parity tests, which round 1 left on MIOpen's nn.LSTM) -- and dtype = DIC_DTYPE_BF16 for small batches (the reference's own
  * B = 256: one 32-row tile per workgroup instead of two; round 4: one 16-row tile up to 2048 rows, v_mfma_f32_16x16x32_bf16, same results bit
- * for bit).  Element type T of gx, whh, out, gates, cs, dout, dgx follows dtype;
+ * for bit).  Element type T of gx, whh, out, gates, cs, dout, dgx follows dtype -- except that with DIC_DTYPE_F32X3 (round 6: eight waves per 32-row tile,
+ * any batch size; gate non-linearities on the transcendental unit, ~3e-7 relative) dgx leaves as SPLIT PLANES: (2, R*B, 2*4H) bf16, plane 0 = bf16(dG),
+ * plane 1 = bf16(dG - plane 0) -- the f32 tensor's bytes in the form dic_gemm_tn_planes / dic_gemm_nt_planes multiply without converting;
  * gates (R,Bp,2,4,H) and cs (R+1,Bp,2,H), Bp = B rounded up to 32, are an opaque lane-native layout exchanged between the two
  * calls of one (dtype, B) -- the 16- and 32-row kernels order it differently, and which pair runs is a function of B and the process environment
  * (DIC_REC_SIXTEEN, DIC_REC16_MAX) alone -- (time slot R of cs carries c0, so the backward takes no c0).  whh (2,4H,H); the backward takes either that (read transposed
@@ -327,6 +329,14 @@ int dic_lstm_rec_fwd(int dtype, const void* gx, const void* whh, const float* h0
  * the (R,B,8H) gx tensor and the projection launch of nn.LSTM (clustering_interp.py:22) do not exist.  Other arguments as dic_lstm_rec_fwd. */
 int dic_lstm_rec_fwd_proj(const void* x, const void* wih, const void* whh, const float* h0, const float* c0, int R, int B, int H, int I, void* out,
                           float* hn, float* cn, void* gates, void* cs, int state_flags, dic_stream_t stream);
+
+/* dic_lstm_rec_fwd_proj_x3 (round 6): the x3 (DIC_DTYPE_F32X3) forward recurrence -- eight waves per 32-row tile, any batch size -- with the NARROW input
+ * projection inside the kernel: x (R,B,ldx) f32 rows [features | 1 | 0...], wih (2*4H, ldx) f32 rows [W_ih | b_ih + b_hh | 0...] (dic_lstm_pack(DIC_DTYPE_F32,
+ * bias_col = 1)), ldx a multiple of 4 up to 32; both are split into bf16 hi + lo on their way into LDS / registers and the product is hi.hi + lo.hi + hi.lo
+ * like the recurrent one.  The f32 gx tensor of nn.LSTM's input projection (clustering_interp.py:22; 3.2 GB at 32 768 encounters) does not exist.  Other
+ * arguments as dic_lstm_rec_fwd with f32 tensors. */
+int dic_lstm_rec_fwd_proj_x3(const float* x, const float* wih, int ldx, const float* whh, const float* h0, const float* c0, int R, int B, int H, float* out,
+                             float* hn, float* cn, float* gates, float* cs, int state_flags, dic_stream_t stream);
 
 /* dic_lstm_fwd_xproj (bf16, H = 128, I = 256: the decoder; clustering_interp.py:30-41): the forward recurrence with the input projection x W_ih^T + b inside
  * the kernel -- gx (R,B,8H) is never formed.  x (R,B,256) bf16 raw rows (relu_x != 0: rectified on load, the F.relu between encoder and decoder), wih (2,4H,256),
@@ -528,6 +538,14 @@ size_t dic_gemm_tn_workspace(long M, int N, int K, int K2);
  * -- dW_ih = dG^T.x and dW_hh = dG^T.h_prev read the gate gradients once.  relu_x != 0: the first product runs on max(X, 0). */
 int dic_gemm_tn(int in_dtype, const void* A, long lda, const void* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
                 const void* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, int relu_x, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* Split-plane A operands (round 6).  The x3 recurrence backward (dic_lstm_rec_bwd, DIC_DTYPE_F32X3) writes the gate gradients -- f32 in nn.LSTM's backward,
+ * clustering_interp.py:14-41 -- as TWO bf16 planes, hi = bf16(x) at A_hi and lo = bf16(x - hi) a_plane elements behind it (x = hi + lo to 2^-17, the same
+ * bytes as f32); these take them as they lie -- no conversion of A in the loop -- against f32 W / X (split on the way in) and produce what dic_gemm_nt /
+ * dic_gemm_tn produce for the f32 tensor hi + lo.  lda in bf16 elements; K (nt) / N (tn) and lda multiples of 8. */
+int dic_gemm_nt_planes(const void* A_hi, long a_plane, long lda, const float* W, long ldw, const float* bias, long M, int N, int K, float* Y, long ldy,
+                       dic_stream_t stream);
+int dic_gemm_tn_planes(const void* A_hi, long a_plane, long lda, const float* X, long ldx, long M, int N, int K, float* D, long ldd, int kcols,
+                       const float* X2, long ldx2, int K2, float* D2, long ldd2, int accumulate, int relu_x, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -575,19 +575,28 @@ def _run_graphed(rank, world, port, out):
     x_np, ob_np, n = synthetic.stacked_batch(coh)
     X, OB, LEN = (torch.tensor(a, device=dev) for a in (x_np, ob_np, n))
     res = {}
-    for graphs in (False, True):
+    for graphs in (False, True, 'capture_fails', 'no_global_rows'):
         torch.manual_seed(5)
         net = _pretrained(Net(_args(), dev).to(dev))
         net.train()
-        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), _args(), autocast_dtype=torch.bfloat16, use_graphs=graphs)
-        assert st.use_graphs == graphs
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), _args(), autocast_dtype=torch.bfloat16, use_graphs=bool(graphs))
+        assert st.use_graphs == bool(graphs)
+        if graphs == 'capture_fails':           # (round 6: a capture that fails is agreed on -- dist.all_agree on RCCL -- and every rank steps eagerly from there)
+            def failing(run):
+                raise RuntimeError('injected: capture failed')
+            st._capture = failing
         traj = []
         for i in range(6):
             lo = (i % 2) * 256
-            losses, gnorm, _ = st.step(X[lo:lo + 256], OB[lo:lo + 256], None, LEN[lo:lo + 256])
+            # the replay-or-capture decision of a SHARDED step is keyed on the global batch's row count (the loaders' samples carry it)
+            losses, gnorm, _ = st.step(X[lo:lo + 256], OB[lo:lo + 256], None, LEN[lo:lo + 256], global_rows=None if graphs == 'no_global_rows' else 256 * world)
             traj.append([float(losses['loss'].detach()), float(losses['ae_mse'].detach()), float(losses['kl'].detach()), float(gnorm)])
-        if graphs:
-            assert len(st._graphs) == 1
+        if graphs is True:
+            assert len(st._graphs) == 1 and not st._sharded_capture_off
+        elif graphs == 'capture_fails':
+            assert len(st._graphs) == 0 and st._sharded_capture_off
+        elif graphs == 'no_global_rows':
+            assert len(st._graphs) == 0 and not st._sharded_capture_off       # nothing rank-invariant to key on: eager
         res[graphs] = np.array(traj)
     torch.save(res, os.path.join(out, 'graphed.pt'))
     _leave()
@@ -601,6 +610,10 @@ def test_sharded_step_is_hip_graph_capturable_on_rccl(tmp_path):
     res = torch.load(tmp_path / 'graphed.pt', weights_only=False)
     np.testing.assert_allclose(res[True], res[False], rtol=2e-3)
     assert np.isfinite(res[True]).all() and not np.allclose(res[True][0], res[True][-1])        # the replays do advance the parameters
+    # a capture that failed (agreed through dist.all_agree on RCCL) and a step without a rank-invariant key both ARE the eager trajectory: the two
+    # warm-up steps before the failed capture left no trace
+    np.testing.assert_array_equal(res['capture_fails'], res[False])
+    np.testing.assert_array_equal(res['no_global_rows'], res[False])
 
 
 def test_bench_runs_on_rccl_with_one_rank():

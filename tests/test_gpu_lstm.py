@@ -635,6 +635,86 @@ def test_f32_recurrence_matches_nn_lstm(R, B, I, init, bm):
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=tol * max(1.0, float(np.abs(b).max())), err_msg=k)
 
 
+@pytest.mark.parametrize('R,B,I,init,bm,proj', [(24, 200, 18, False, False, True), (24, 200, 18, True, True, False), (24, 96, 256, True, True, True),
+                                                  (5, 1, 256, True, False, True), (3, 130, 28, True, True, True), (2, 33, 1, False, False, True),
+                                                  (1, 4099, 18, True, True, True), (6, 65, 36, False, True, True)])
+def test_x3_recurrence_matches_nn_lstm(R, B, I, init, bm, proj, monkeypatch):
+    """The x3 recurrence kernels of round 6 (csrc/dic_lstm32.hip: lstm_rec_fwd8x3 / lstm_rec_bwd8x3 -- eight waves per 32-row tile, every product hi.hi + lo.hi
+    + hi.lo on the bf16 matrix cores, gate non-linearities on the transcendental unit, the narrow encoder input projected INSIDE the kernel, gate gradients
+    leaving as split planes for dic_gemm_tn_planes / dic_gemm_nt_planes) against torch.nn.LSTM in f32: outputs, final states and every gradient to the
+    2^-17-per-product accuracy of the split -- ragged last tiles, R = 1, one row, with / without initial states, the in-kernel projection on and off (I = 36
+    does not fit its 32 columns: the gx path), the wide decoder input."""
+    from deep_interpolation_clustering_amd import lstm as L, ops
+    monkeypatch.setattr(L, 'X3_REC_PROJ', proj)
+    torch.manual_seed(R * 100 + B)
+    dev = torch.device('cuda')
+    net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
+    x = torch.randn(R, B, I, device=dev) * (1.0 if I < 100 else 0.5)
+    h0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    c0 = torch.randn(2, B, H, device=dev) * 0.5 if init else None
+    go, gh, gc = torch.randn(R, B, 2 * H, device=dev), torch.randn(2, B, H, device=dev), torch.randn(2, B, H, device=dev)
+    res = {}
+    for mode in ('x3', 'torch'):
+        net.zero_grad()
+        xi = x.clone().requires_grad_()
+        hi = None if not init else h0.clone().requires_grad_()
+        ci = None if not init else c0.clone().requires_grad_()
+        if mode == 'x3':
+            hin = hi.transpose(0, 1).contiguous() if (init and bm) else hi
+            cin = ci.transpose(0, 1).contiguous() if (init and bm) else ci
+            with ops.f32_products_mode('x3'):
+                out, (hn, cn) = L.bilstm(xi, net, hin, cin, batch_major_state=bm)
+                assert out.dtype == torch.float32
+                if bm:
+                    hn, cn = hn.transpose(0, 1), cn.transpose(0, 1)
+                ((out * go).sum() + (hn * gh).sum() + (cn * gc).sum()).backward()
+        else:
+            out, (hn, cn) = net(xi) if not init else net(xi, (hi, ci))
+            ((out * go).sum() + (hn * gh).sum() + (cn * gc).sum()).backward()
+        res[mode] = dict(out=out.detach(), hn=hn.detach(), cn=cn.detach(), dx=xi.grad, **{k: p.grad.clone() for k, p in net.named_parameters()})
+        if init:
+            res[mode].update(dh0=hi.grad, dc0=ci.grad)
+    for k, ref in res['torch'].items():
+        a, b = res['x3'][k].double().cpu().numpy(), ref.double().cpu().numpy()
+        assert np.isfinite(a).all(), k
+        # 2^-17 ~ 8e-6 per product term; sums over up to R * B rows average it down, recurrences compound it
+        tol = 2e-5 if k in ('out', 'hn', 'cn') else 5e-5
+        assert float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max())), (k, float(np.abs(a - b).max()), float(np.abs(b).max()))
+
+
+def test_split_plane_products_equal_the_f32_operand_products():
+    """dic_gemm_nt_planes / dic_gemm_tn_planes (A = two bf16 planes hi + lo, as the x3 backward writes the gate gradients) against dic_gemm_nt / dic_gemm_tn
+    on the f32 tensor the planes stand for: the same three-term products, so equal to f32 summation-order noise -- and against the f64 product."""
+    from deep_interpolation_clustering_amd import ops
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(3)
+    M, Ncol, K = 4099, 1024, 20
+    a = torch.randn(M, Ncol, device=dev, generator=g)
+    hi = a.to(torch.bfloat16)
+    lo = (a - hi.float()).to(torch.bfloat16)
+    planes = torch.stack([hi, lo])                          # (2, M, 1024)
+    a2 = ops.planes_to_f32(planes)                          # what the planes stand for (a to 2^-17)
+    assert float((a2 - a).abs().max()) <= 2.0 ** -16 * float(a.abs().max())
+    w = torch.randn(K, Ncol, device=dev, generator=g) * 0.1  # dX = dG . W_ih: (M, 1024) x (20, 1024)^T
+    y = ops.gemm_nt_planes(planes, w)
+    ref = (a2.double() @ w.double().t())
+    assert float((y.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+    assert float((y - ops.gemm_nt(a2, w)).abs().max()) <= 2e-5 * float(ref.abs().max())
+    w2 = torch.randn(256, Ncol, device=dev, generator=g) * 0.1      # the 128-column-tile kernel
+    y2, ref2 = ops.gemm_nt_planes(planes, w2), a2.double() @ w2.double().t()
+    assert float((y2.double() - ref2).abs().max()) <= 3e-5 * float(ref2.abs().max())
+    x = torch.randn(M, 20, device=dev, generator=g)
+    h = torch.randn(M, 128, device=dev, generator=g)
+    for d in range(2):                                      # dW_ih / dW_hh of one direction from its half of the planes (strided column views)
+        ad = planes[..., 512 * d:512 * (d + 1)]
+        dst, dst2 = torch.zeros(512, 18, device=dev), torch.full((512, 128), 0.5, device=dev)
+        ops.gemm_tn_into(ad, x, dst, kcols=18, x2=h, dst2=dst2, accumulate=True)
+        r1 = a2[:, 512 * d:512 * (d + 1)].double().t() @ x[:, :18].double()
+        r2 = a2[:, 512 * d:512 * (d + 1)].double().t() @ h.double() + 0.5
+        assert float((dst.double() - r1).abs().max()) <= 3e-5 * float(r1.abs().max())
+        assert float((dst2.double() - r2).abs().max()) <= 3e-5 * float(r2.abs().max())
+
+
 @pytest.mark.parametrize('R,B,init,relu_in', [(24, 200, True, True), (7, 70, False, False), (1, 64, True, True), (5, 333, True, False), (3, 1, False, True)])
 def test_decoder_forward_with_the_projection_inside_tracks_the_gx_path(R, B, init, relu_in, monkeypatch):
     """dic_lstm_fwd_xproj (the decoder's input projection inside the recurrence kernel: no gx tensor; round 4) against dic_row_proj + dic_lstm_fwd on the same
