@@ -426,14 +426,14 @@ def f32_roofline(kernels, batch, products):
     f_hbm, f_mfma = gbps / HBM_PEAK_GBS, tf / peak_tf
     bound = 'hbm' if f_hbm >= f_mfma else 'mfma'
     traffic = traffic_src = None
-    tf_file = os.path.join(ROOT, 'profiles', 'r4_step_f32x3_pmc_traffic.json')      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `--dtype f32x3` at B = 32768
+    tf_file = os.path.join(ROOT, 'profiles', 'x3_traffic.json')      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `--dtype f32x3` (scripts/profile_round.sh, step 8)
     if products == 'x3' and os.path.exists(tf_file):
         tj = json.load(open(tf_file))
-        key = name.split('dic::')[-1].split('<')[0]
-        if key in tj:
-            traffic = int(tj[key]['hbm_bytes'] * batch / 32768)
-            traffic_src = {'from_profile': 'profiles/r4_step_f32x3_pmc_traffic.json', 'profile_batch': 32768,
-                           'note': 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of a separate run, scaled by batch; not measured in this run'}
+        key = name.split('dic::')[-1].split('<')[0].split('(')[0]
+        if key in tj and tj.get('_csrc_sha16') == csrc_sha16():      # (only a profile taken on THESE kernel sources)
+            traffic = int(tj[key]['hbm_bytes'] * batch / tj.get('_batch', 32768))
+            traffic_src = {'from_profile': 'profiles/x3_traffic.json', 'profile_batch': tj.get('_batch', 32768),
+                           'note': 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of a separate run on these kernel sources, scaled by batch; not measured in this run'}
     return {'kernel': name, 'bound': bound, 'achieved': round(gbps if bound == 'hbm' else tf, 1), 'peak': HBM_PEAK_GBS if bound == 'hbm' else peak_tf,
             'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s', 'frac': round(max(f_hbm, f_mfma), 4), 'frac_hbm': round(f_hbm, 4), 'frac_mfma': round(f_mfma, 4),
             'ms_per_launch': round(ms, 4), 'launches_per_step': v['launches_per_step'], 'algorithmic_bytes_per_launch': int(nbytes),
@@ -1086,7 +1086,7 @@ def main():
                            'note': 'frac = algorithmic bytes per launch / the duration this kernel has INSIDE the timed step (per-dispatch GPU timestamps); '
                                    'frac_standalone = HIP events around back-to-back launches on an otherwise idle chip'}
         if a.dtype != 'bf16' and kernels is not None:       # the f32 modes run the 32-row recurrence kernels: their own roofline
-            rl = f32_roofline(kernels, a.batch, 'x3' if a.dtype == 'f32x3' else 'exact')
+            rl = f32_roofline(kernels, row_scale * a.batch, 'x3' if a.dtype == 'f32x3' else 'exact')      # (encounters of an average launch of the traced epoch)
             if rl:
                 roofline_detail = {'full': rl}
                 roofline = {k: rl[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'ms_per_launch', 'launches_per_step',

@@ -539,9 +539,234 @@ __global__ __launch_bounds__(256) void lstm_unpack_grads_kernel(const float* dw_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ x3: weight gradients from split planes (round 6)
+// The f32 step on split products (DIC_DTYPE_F32X3): dW[gate row][h_prev | x] = sum over the (t, b) rows of dG^T [h_prev | x] with every product hi.hi + lo.hi +
+// hi.lo.  Until round 5 this was dic_gemm_tn on f32 operands: 128 x 128 output tiles, both operands through registers, converted in the loop -- five launches,
+// 4.9 ms of a 19 ms step at B = 32 768, each CU taking in its operands three to four times over (per-CU ingest bound).  Here, in the form of lstm_dw_kernel /
+// lstm_dw_wide_kernel above:
+//   * dG arrives as the two bf16 PLANES the x3 recurrence backward writes (hi | lo, dG = hi + lo) and goes from HBM into LDS by LDS-DMA, untouched, through a
+//     3-slot ring of 16-row tiles (one MFMA k-step); every CU takes in its rows of dG ONCE;
+//   * h_prev and x are f32 (the layer's outputs / inputs as every other consumer reads them): 1 + 1 (encoder) or 1 + 2 (decoder) 16-B loads per thread and
+//     tile, hand-issued (asm: counted in the same vmcnt queue as the DMAs by THIS code, not drained by the compiler's), split into hi / lo on their way into a
+//     2-slot pair of LDS images one tile ahead; the decoder's x is rectified there when the LSTM ran on relu(x);
+//   * one raw barrier and one counted wait per tile; 30 (encoder: wave = 64 gate rows x 5 column blocks) or 36 (decoder: 64 x 6) MFMAs per wave and tile.
+// Same partial-sum layouts as the bf16 kernels: their finalize kernels (fixed-order f64) write the parameter gradients.
+constexpr int TX = 16;                                   // rows per tile
+template <int XWT, int DMH> struct DwX3 {
+    static constexpr int NG = G4 / DMH;                  // column groups of waves: 1 (a workgroup owns all 512 gate rows of a direction) or 2 (half of them)
+    static constexpr int MW = DMH / 64;                  // waves along the gate rows
+    static constexpr int NBN = (4 + XWT / 32) / NG;      // 32-column blocks of [h_prev (4) | x] per wave: 5 or 6
+    static constexpr int NWT = GH + XWT;
+    static constexpr int DGP = DMH == G4 ? 2 * DMH + 64 : 2 * DMH;        // dG image row pitch in bytes: 1088, or 512 with XOR-swizzled 16-B pieces
+    static constexpr int L_PL = TX * DGP, L_DG = 2 * L_PL;                 // one plane / both planes of a tile
+    static constexpr int HP = 2 * GH + 64;               // 320 B: pitch = 64 B mod 256 B -> the 4 rows of a transposed read fall on disjoint bank groups
+    static constexpr int XP = XWT == 32 ? 64 : 2 * XWT + 64;               // 64-B rows are conflict-free as they lie; 576 B
+    static constexpr int L_H = TX * HP, L_X = TX * XP;   // one image
+    static constexpr int L_HX = 2 * L_H + 2 * L_X;       // hi + lo of both
+    static constexpr int LDS = 3 * L_DG + 2 * L_HX;
+    static constexpr int NXL = XWT == 32 ? 1 : 2;        // 16-B loads of x per thread and tile
+    static constexpr int NDMA = DMH == G4 ? 4 : 2;       // LDS-DMA instructions per wave and tile
+};
+
+struct DwX3Args {
+    const __bf16* dg;      // planes: (2, R*B, 2*4H) -- hi at dg, lo dg_plane elements behind it
+    long dg_plane;
+    const float* hext;     // ((R+2)*B, 2H) f32: see DwArgs
+    const float* x;        // (R*B, ldx) f32
+    int ldx;               // row length of x in elements (a multiple of 4; <= XWT)
+    float* partials;
+    int R, B, x_relu;
+};
+
+__device__ __forceinline__ f32x4_t gload16(const void* sbase, unsigned voff) {      // 16 B per lane, hand-issued: see the waits in the kernel
+    f32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(sbase) : "memory");
+    return v;
+}
+__device__ __forceinline__ void split4_store(unsigned char* hi, unsigned char* lo, f32x4_t v, bool relu, bool zero) {
+    bf16x8 dummy; (void)dummy;
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    b4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x = zero ? 0.f : v[j];
+        if (relu) x = fmaxf(x, 0.f);
+        const __bf16 xh = (__bf16)x;
+        h[j] = xh;
+        l[j] = (__bf16)(x - (float)xh);
+    }
+    *reinterpret_cast<b4*>(hi) = h;
+    *reinterpret_cast<b4*>(lo) = l;
+}
+
+template <int XWT, int DMH>
+__global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
+    typedef DwX3<XWT, DMH> C;
+    extern __shared__ __align__(16) unsigned char dwsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y / C::NG, mh = blockIdx.y % C::NG;
+    const int mg = w % C::MW, ng = w / C::MW;
+    const long nrows = (long)a.R * a.B;
+    const int ntiles = (int)((nrows + TX - 1) / TX), nch = gridDim.x;
+    const int mine = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / nch + 1 : 0;
+    if (mine == 0) return;                                               // (uniform: the whole workgroup)
+    const float* hsrc = a.hext + (dir ? (size_t)2 * a.B * 2 * GH + GH : 0);                  // row i of this view = h_prev of row i
+    const __bf16* gsrc = a.dg + (size_t)dir * G4 + mh * DMH;                                   // row i: + i * 2 * G4 (either plane)
+
+    f32x16 acc[2][C::NBN];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < C::NBN; ++nb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[mb][nb][k] = 0.f;
+
+    unsigned char* const hx0 = dwsm + 3 * C::L_DG;                                            // the two image slots behind the three dG slots
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)dwsm);
+    // tile j of this workgroup (clamped: requests past the end re-read the last tile into a slot nobody computes on -- every wave issues the same number
+    // of memory instructions per iteration, which is what the counted waits count)
+    auto tile_r0 = [&](int j) { return min((long)((int)blockIdx.x + min(j, mine - 1) * nch) * TX, nrows - TX); };
+    // ---- dG planes by LDS-DMA.  1-KiB rows (DMH = 512): one row per instruction, rows w and w + 8 of either plane.  512-B rows: two per instruction (row
+    // pair w), 16-B pieces XOR-swizzled by (row & 3) << 2 through the source address (as lstm_dw_wide_kernel)
+    const int r2 = lane >> 5, sw2 = ((2 * (w & 1) + r2) & 3) << 2;
+    const unsigned v_dg = DMH == G4 ? (unsigned)lane * 16 : (unsigned)(r2 * (2 * G4 * 2) + (((lane & 31) ^ sw2) * 16));
+    auto request_dg = [&](int j) {
+        const long r0 = tile_r0(j);
+        const unsigned base = lds0 + (j % 3) * C::L_DG;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const __bf16* src = gsrc + (size_t)p * a.dg_plane;
+            if constexpr (DMH == G4) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) dma16(src + (size_t)(r0 + w + 8 * k) * 2 * G4, v_dg, base + p * C::L_PL + (w + 8 * k) * C::DGP);
+            } else {
+                dma16(src + (size_t)(r0 + 2 * w) * 2 * G4, v_dg, base + p * C::L_PL + 2 * w * C::DGP);
+            }
+        }
+    };
+    // ---- h_prev / x through registers: thread -> (row, 16-B piece)
+    const int hrow = tid >> 5, hc4 = tid & 31;
+    const unsigned v_h = (unsigned)(hrow * (2 * GH * 4) + hc4 * 16);
+    const int xpc = a.ldx >> 2;                                          // 16-B pieces per x row
+    int xrow[C::NXL], xc4[C::NXL];
+    unsigned v_x[C::NXL];
+    bool xon[C::NXL];
+#pragma unroll
+    for (int i = 0; i < C::NXL; ++i) {
+        const int p = tid + 512 * i;
+        xon[i] = p < TX * xpc;
+        const int pc = xon[i] ? p : 0;
+        xrow[i] = pc / xpc; xc4[i] = pc - xrow[i] * xpc;
+        v_x[i] = (unsigned)((xrow[i] * a.ldx + 4 * xc4[i]) * 4);
+    }
+    f32x4_t hreg, xreg[C::NXL];
+    auto request_hx = [&](int j) {
+        const long r0 = tile_r0(j);
+        hreg = gload16(hsrc + (size_t)r0 * 2 * GH, v_h);
+#pragma unroll
+        for (int i = 0; i < C::NXL; ++i) xreg[i] = gload16(a.x + (size_t)r0 * a.ldx, v_x[i]);
+    };
+    auto store_hx = [&](int j) {                                         // split -> the images of slot j & 1; rows the shifted last tile shares with its predecessor: zeros
+        const long t0 = (long)((int)blockIdx.x + min(j, mine - 1) * nch) * TX;
+        const int dup = (int)max(0L, t0 + TX - nrows);
+        unsigned char* base = hx0 + (j & 1) * C::L_HX;
+        split4_store(base + hrow * C::HP + hc4 * 8, base + C::L_H + hrow * C::HP + hc4 * 8, hreg, false, hrow < dup);
+#pragma unroll
+        for (int i = 0; i < C::NXL; ++i)
+            if (xon[i]) split4_store(base + 2 * C::L_H + xrow[i] * C::XP + xc4[i] * 8, base + 2 * C::L_H + C::L_X + xrow[i] * C::XP + xc4[i] * 8, xreg[i],
+                                     a.x_relu != 0, xrow[i] < dup);
+    };
+
+    // ---- transposed-read addressing (ds_read_b64_tr_b16; see lstm_dw_kernel)
+    const int kq = (lane & 15) >> 2, kp = lane & 3, cb = (lane >> 4) & 1, hh = lane >> 5;
+    const int rowoff = 8 * hh + kq;
+    auto piece = [&](int j) { return (((4 * j + 2 * cb + (kp >> 1)) ^ (kq << 2)) * 16) + (kp & 1) * 8; };
+    int pa_off[2], pb_off[C::NBN], pb_pitch[C::NBN], pb_lo[C::NBN];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+        pa_off[mb] = DMH == G4 ? rowoff * C::DGP + (64 * mg + 32 * mb + 16 * cb + 4 * kp) * 2 : rowoff * C::DGP + piece(2 * mg + mb);
+#pragma unroll
+    for (int i = 0; i < C::NBN; ++i) {
+        const int jn = C::NBN * ng + i;                                  // column block of [h (4 blocks) | x]
+        pb_pitch[i] = jn < 4 ? C::HP : C::XP;
+        pb_lo[i] = jn < 4 ? C::L_H : C::L_X;
+        pb_off[i] = jn < 4 ? rowoff * C::HP + (32 * jn + 16 * cb + 4 * kp) * 2 : 2 * C::L_H + rowoff * C::XP + (32 * (jn - 4) + 16 * cb + 4 * kp) * 2;
+    }
+    auto frag = [&](const unsigned char* p, int pitch) {
+        const s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 4 * pitch);
+        s16x8 f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+        return __builtin_bit_cast(bf16x8, f);
+    };
+
+    // ---- prologue: the x images' padding columns are zero for good; tile 0 in, tile 1 requested
+    if constexpr (XWT == 32) {
+        for (int i = tid; i < 2 * C::L_HX / 16; i += 512) reinterpret_cast<uint4*>(hx0)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+    }
+    request_hx(0);
+    request_dg(0);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(C::NDMA) : "memory");     // h / x of tile 0 have landed (its DMAs may still fly)
+    asm volatile("" : "+v"(hreg));
+#pragma unroll
+    for (int i = 0; i < C::NXL; ++i) asm volatile("" : "+v"(xreg[i]));
+    store_hx(0);
+    request_hx(1);
+    request_dg(1);
+    for (int j = 0; j < mine; ++j) {
+        // queue, oldest first: [DMA(j)] h / x (j + 1), DMA(j + 1): everything up to the h / x loads has landed once only the last tile's DMAs are outstanding
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(C::NDMA) : "memory");
+        asm volatile("" : "+v"(hreg));
+#pragma unroll
+        for (int i = 0; i < C::NXL; ++i) asm volatile("" : "+v"(xreg[i]));
+        __builtin_amdgcn_s_barrier();              // every wave's DMA of tile j has landed and its image writes are visible; all are done with tile j - 1
+        store_hx(j + 1);                           // -> the image slot tile j - 1 was read from
+        request_hx(j + 2);
+        request_dg(j + 2);                         // -> the dG slot tile j - 1 was read from
+        const unsigned char* dgb = dwsm + (j % 3) * C::L_DG;
+        const unsigned char* hxb = hx0 + (j & 1) * C::L_HX;
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            ah[mb] = frag(dgb + pa_off[mb], C::DGP);
+            al[mb] = frag(dgb + C::L_PL + pa_off[mb], C::DGP);
+        }
+#pragma unroll
+        for (int i = 0; i < C::NBN; ++i) {
+            const bf16x8 bh = frag(hxb + pb_off[i], pb_pitch[i]);
+            const bf16x8 bl = frag(hxb + pb_off[i] + pb_lo[i], pb_pitch[i]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb][i], 0, 0, 0);
+                acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh, acc[mb][i], 0, 0, 0);
+                acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb][i], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the clamped requests past the end)
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float* o = a.partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * DMH * C::NWT;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < C::NBN; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int m = 64 * mg + 32 * mb + (k & 3) + 8 * (k >> 2) + 4 * hh;
+                o[(size_t)m * C::NWT + 32 * (C::NBN * ng + i) + (lane & 31)] = acc[mb][i][k];
+            }
+}
+
 static int dw_chunks(int R, int B) {
     const int ntiles = (int)(((long)R * B + TR - 1) / TR);
     return max(1, min(ntiles, kNumCU / 2));        // x 2 directions = one workgroup per CU
+}
+static int dwx3_chunks(int R, int B, bool wide) {
+    const int ntiles = (int)(((long)R * B + TX - 1) / TX);
+    const int n = max(1, min(ntiles, wide ? kNumCU / 4 : kNumCU / 2));
+    return (wide && n >= 8) ? n / 8 * 8 : n;           // (decoder: the four workgroups of a chunk on one XCD, as dw_wide_chunks)
 }
 
 }  // namespace dic
@@ -648,6 +873,50 @@ int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int x_
     hipLaunchKernelGGL(lstm_dw_wide_kernel, dim3(nch, 4), dim3(512), WD_LDS, st, a);
     hipLaunchKernelGGL(lstm_dw_wide_finalize, dim3((WD_OUT / 4 + 255) / 256), dim3(256), 0, st, (const float*)workspace, nch, g, accumulate ? 1.0f : 0.0f);
     return check_launch("lstm_dw_wide");
+}
+
+size_t dic_lstm_dw_x3_workspace(int R, int B, int I) {
+    if (R <= 0 || B <= 0 || I <= 0) return 0;
+    const bool wide = I == DXW;
+    return (size_t)dwx3_chunks(R, B, wide) * (wide ? (size_t)WD_OUT : (size_t)2 * G4 * (GH + XW)) * sizeof(float);
+}
+
+int dic_lstm_dw_x3(const void* dg_hi, long dg_plane, const float* out_ext, const float* x, int ldx, int x_relu, int R, int B, int H, int I,
+                   float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_dw_x3: non-positive size");
+    DIC_REQUIRE(H == GH, DIC_ERR_UNSUPPORTED, "lstm_dw_x3: hidden size %d (compiled for %d)", H, GH);
+    const bool wide = I == DXW;
+    DIC_REQUIRE(wide ? ldx == DXW : (I > 0 && I <= ldx && ldx <= XW && ldx % 4 == 0), DIC_ERR_UNSUPPORTED,
+                "lstm_dw_x3: input width %d in rows of %d (compiled for %d, or up to %d in rows that are a multiple of 4)", I, ldx, DXW, XW);
+    DIC_REQUIRE(dg_hi && dg_plane > 0 && out_ext && x && workspace, DIC_ERR_INVALID_ARG, "lstm_dw_x3: NULL pointer / plane stride");
+    DIC_REQUIRE(((uintptr_t)dg_hi & 15) == 0 && dg_plane % 8 == 0 && ((uintptr_t)out_ext & 15) == 0 && ((uintptr_t)x & 15) == 0, DIC_ERR_UNSUPPORTED,
+                "lstm_dw_x3: operands must be 16-B aligned");
+    DIC_REQUIRE((long)R * B >= TX, DIC_ERR_UNSUPPORTED, "lstm_dw_x3: R*B = %ld rows < one %d-row tile (use the GEMM path)", (long)R * B, TX);
+    LstmGrads g;
+    int rc = grads_from(grads, &g, true, false, "lstm_dw_x3");
+    if (rc) return rc;
+    const int nch = dwx3_chunks(R, B, wide);
+    DIC_REQUIRE(workspace_bytes >= dic_lstm_dw_x3_workspace(R, B, I), DIC_ERR_WORKSPACE, "lstm_dw_x3: workspace %zu < %zu", workspace_bytes,
+                dic_lstm_dw_x3_workspace(R, B, I));
+    hipStream_t st = (hipStream_t)stream;
+    DwX3Args a{(const __bf16*)dg_hi, dg_plane, out_ext, x, ldx, (float*)workspace, R, B, x_relu != 0};
+    static bool attr_set[2] = {false, false};
+    const int lds = wide ? DwX3<DXW, G4 / 2>::LDS : DwX3<XW, G4>::LDS;
+    if (!attr_set[wide]) {
+        hipError_t e = hipFuncSetAttribute(wide ? (const void*)lstm_dwx3_kernel<DXW, G4 / 2> : (const void*)lstm_dwx3_kernel<XW, G4>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_dw_x3: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+        attr_set[wide] = true;
+    }
+    if (wide) {
+        hipLaunchKernelGGL((lstm_dwx3_kernel<DXW, G4 / 2>), dim3(nch, 4), dim3(512), lds, st, a);
+        hipLaunchKernelGGL(lstm_dw_wide_finalize, dim3((WD_OUT / 4 + 255) / 256), dim3(256), 0, st, (const float*)workspace, nch, g, accumulate ? 1.0f : 0.0f);
+    } else {
+        const int nw = GH + XW, n_out = 2 * G4 * nw;
+        hipLaunchKernelGGL((lstm_dwx3_kernel<XW, G4>), dim3(nch, 2), dim3(512), lds, st, a);
+        hipLaunchKernelGGL(lstm_dw_finalize, dim3((n_out + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, I, nw, g, accumulate ? 1.0f : 0.0f);
+    }
+    return check_launch("lstm_dw_x3");
 }
 
 int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,

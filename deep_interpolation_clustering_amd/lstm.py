@@ -43,6 +43,7 @@ GX_LANE_NATIVE = os.environ.get('DIC_GX_LANE_NATIVE', '1') != '0'     # (A/B swi
 ROW_PROJ = os.environ.get('DIC_ROW_PROJ', '1') != '0'                  # (A/B switch: 0 = library GEMM for the decoder's input projection)
 RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B switch: 0 = rectify the encoder output with a torch pass)
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
+X3_DW = os.environ.get('DIC_X3_DW', '1') != '0'                        # (A/B switch: 0 = dic_gemm_tn_planes for the x3 step's LSTM weight gradients)
 X3_REC_PROJ = os.environ.get('DIC_X3_REC_PROJ', '1') != '0'            # (A/B switch: 0 = dic_gemm_nt + gx for the encoder's forward in the x3 step)
 REC_PROJ = os.environ.get('DIC_REC_PROJ', '1') != '0'                  # (A/B switch: 0 = dic_gemm_nt + dic_lstm_rec_fwd for the encoder's small-batch forward)
 FWD_XPROJ = os.environ.get('DIC_FWD_XPROJ', '1') != '0'                # (A/B switch: 0 = dic_row_proj + dic_lstm_fwd for the decoder's large-batch forward: gx through HBM)
@@ -340,6 +341,13 @@ class _BiLstm(torch.autograd.Function):
                     _SIDE['keep'].append((dgx, out_ext, xb, dbias, wih, sinks))
                 else:
                     weight_grads(st)
+            elif x3 and X3_DW and R * B >= 16 and (I == WIDE_INPUT or Ip <= 32):
+                # x3: dW_ih and dW_hh of both directions from ONE pass over the split planes of dG (csrc/dic_lstmgrad.hip, lstm_dwx3_kernel: the planes by
+                # LDS-DMA as they lie, h_prev / x f32 through registers; round 6 -- until then five dic_gemm_tn launches on f32 operands)
+                ws2 = torch.empty(max(16, Lb.dic_lstm_dw_x3_workspace(R, B, I)), device=dev, dtype=torch.uint8)
+                N.check(Lb.dic_lstm_dw_x3(N.ptr(dgx), dgx.stride(0), N.ptr(out_ext), N.ptr(xb), Ip, int(ctx.x_relu_in_kernel), R, B, H, I, gp, int(accumulate),
+                                          N.ptr(ws2), ws2.numel(), st), 'dic_lstm_dw_x3')
+                N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             elif x3 or not f32:
                 # dic_gemm_tn: dW_ih[d] = dG[d]^T . x and dW_hh[d] = dG[d]^T . h_prev[d] straight into the parameter gradients; h_prev = row-shifted
                 # views of the extended output buffer (see below)

@@ -52,11 +52,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c4s_stats -o k -- p
 cp /tmp/c4s_stats/k_kernel_stats.csv $OUT/cfg4_step_kernel_stats.csv
 echo "[profile] cfg4 step done"
 # 8. the f32 step with every dense product as a three-term bf16 split (--dtype f32x3) at the headline batch: kernel statistics + HBM traffic of its
-#    recurrence / product kernels
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/x3_stats -o k -- python3 $ROOT/bench.py --dtype f32x3 --no-secondary --no-cpu-baseline --steps 10 --warmup 3 --kernel-iters 1 > $OUT/bench_f32x3_under_rocprof.json 2> /dev/null
+#    recurrence / product kernels (65 536 encounters = two FULL batches per epoch: every launch of the profiled run moves 32 768 encounters)
+X3="--dtype f32x3 --encounters 65536 --no-secondary --no-cpu-baseline --kernel-iters 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/x3_stats -o k -- python3 $ROOT/bench.py $X3 --steps 10 --warmup 4 > $OUT/bench_f32x3_under_rocprof.json 2> /dev/null
 cp /tmp/x3_stats/k_kernel_stats.csv $OUT/step_f32x3_B32768_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/x3_fetch -o p -- python3 $ROOT/bench.py --dtype f32x3 --no-secondary --no-cpu-baseline --steps 4 --warmup 2 --kernel-iters 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/x3_write -o p -- python3 $ROOT/bench.py --dtype f32x3 --no-secondary --no-cpu-baseline --steps 4 --warmup 2 --kernel-iters 1 > /dev/null 2>&1
-python3 $ROOT/scripts/pmc_generic.py /tmp/x3_fetch/p_counter_collection.csv /tmp/x3_write/p_counter_collection.csv 'lstm_rec_|gemm_|bnhead|bn_colstats' > $OUT/step_f32x3_pmc_traffic.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/x3_fetch -o p -- python3 $ROOT/bench.py $X3 --steps 4 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/x3_write -o p -- python3 $ROOT/bench.py $X3 --steps 4 --warmup 2 > /dev/null 2>&1
+python3 $ROOT/scripts/pmc_generic.py /tmp/x3_fetch/p_counter_collection.csv /tmp/x3_write/p_counter_collection.csv 'lstm_rec_|lstm_dwx3|gemm_|x3_row_proj|bnhead|bn_colstats' 32768 > $OUT/step_f32x3_pmc_traffic.json
+cp $OUT/step_f32x3_pmc_traffic.json $ROOT/profiles/x3_traffic.json
 echo "[profile] f32x3 done"
 ls -la $OUT
