@@ -1423,14 +1423,14 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_bwd8x3_kernel(RecBwdArgs<floa
     };
     __bf16* plane = reinterpret_cast<__bf16*>(a.dgx) + (size_t)qh * R * B * 2 * S4;       // this wave's output plane (hi: even waves, lo: odd)
     const __bf16* img = qh ? dgl : dgh;
-    StepQ in0, in1, nx0, nx1;
+    StepQ in0, in1;
     load_q(0, 0, in0); load_q(0, 1, in1);
     for (int step = 0; step < R; ++step) {
         const int t = dir ? step : R - 1 - step;
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
             const int u = 16 * w8 + 8 * qq + 4 * hh;
-            const StepQ cur = qq == 0 ? in0 : in1;
+            const StepQ cur = qq == 0 ? in0 : in1;          // (a copy: the registers are refilled below)
             sf32x4 di, df, dg, dO;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1451,8 +1451,9 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_bwd8x3_kernel(RecBwdArgs<floa
             RecX3::store4(dgh + o + SH, dgl + o + SH, df);
             RecX3::store4(dgh + o + 2 * SH, dgl + o + 2 * SH, dg);
             RecX3::store4(dgh + o + 3 * SH, dgl + o + 3 * SH, dO);
+            // this group's inputs of the NEXT step, into the registers just consumed: in flight across the rest of the gate arithmetic, the barrier and the product
+            if (step + 1 < R) load_q(step + 1, qq, qq == 0 ? in0 : in1);
         }
-        if (step + 1 < R) { load_q(step + 1, 0, nx0); load_q(step + 1, 1, nx1); }
         lds_barrier();                                     // the dG tile of this step is complete
         // dh_prev[unit][batch] = sum_n W_hh[n][unit] dG[batch][n]: two batch blocks (rows n16, 16 + n16) x 16 k-steps of 32 gate columns x (hi.hi + lo.hi + hi.lo)
         sf32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1489,7 +1490,6 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_bwd8x3_kernel(RecBwdArgs<floa
             dh[4 + e] = __builtin_bit_cast(float, (unsigned)s[1]);
         }
         lds_barrier();                                     // every wave is done reading the tile
-        in0 = nx0; in1 = nx1;
     }
     if (a.dbias_part) {      // column sums of hi (even waves) and lo (odd waves) over disjoint rows: add the eight through LDS (the images are free now), one partial per workgroup
         float* red = reinterpret_cast<float*>(rsm);

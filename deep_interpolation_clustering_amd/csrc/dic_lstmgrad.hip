@@ -555,7 +555,8 @@ constexpr int TX = 16;                                   // rows per tile
 template <int XWT, int DMH> struct DwX3 {
     static constexpr int NG = G4 / DMH;                  // column groups of waves: 1 (a workgroup owns all 512 gate rows of a direction) or 2 (half of them)
     static constexpr int MW = DMH / 64;                  // waves along the gate rows
-    static constexpr int NBN = (4 + XWT / 32) / NG;      // 32-column blocks of [h_prev (4) | x] per wave: 5 or 6
+    static constexpr int NBT = 4 + XWT / 32;             // 32-column blocks of [h_prev (4) | x]: 5 (encoder) or 12 (decoder)
+    static constexpr int NBN = (NBT + NG - 1) / NG;      // ... per wave: 3 (the second column group of the encoder has two: its third is idle) or 6
     static constexpr int NWT = GH + XWT;
     static constexpr int DGP = DMH == G4 ? 2 * DMH + 64 : 2 * DMH;        // dG image row pitch in bytes: 1088, or 512 with XOR-swizzled 16-B pieces
     static constexpr int L_PL = TX * DGP, L_DG = 2 * L_PL;                 // one plane / both planes of a tile
@@ -563,7 +564,8 @@ template <int XWT, int DMH> struct DwX3 {
     static constexpr int XP = XWT == 32 ? 64 : 2 * XWT + 64;               // 64-B rows are conflict-free as they lie; 576 B
     static constexpr int L_H = TX * HP, L_X = TX * XP;   // one image
     static constexpr int L_HX = 2 * L_H + 2 * L_X;       // hi + lo of both
-    static constexpr int LDS = 3 * L_DG + 2 * L_HX;
+    static constexpr int L_RED = XWT == 32 ? 2 * 8 * 1024 : 0;             // encoder: two parities x eight waves x one 16 x 16 f32 partial tile of the fused dX
+    static constexpr int LDS = 3 * L_DG + 2 * L_HX + L_RED;
     static constexpr int NXL = XWT == 32 ? 1 : 2;        // 16-B loads of x per thread and tile
     static constexpr int NDMA = DMH == G4 ? 4 : 2;       // LDS-DMA instructions per wave and tile
 };
@@ -576,6 +578,8 @@ struct DwX3Args {
     int ldx;               // row length of x in elements (a multiple of 4; <= XWT)
     float* partials;
     int R, B, x_relu;
+    const float* wih;      // encoder only, or NULL: (2*4H, ldx) f32 packed input weights -> the input gradient rides along:
+    float* dxp;            //   (4, R*B, ldx) f32 partial input gradients, one per (direction, half of its gate rows): their sum is dX = dG . W_ih
 };
 
 __device__ __forceinline__ f32x4_t gload16(const void* sbase, unsigned voff) {      // 16 B per lane, hand-issued: see the waits in the kernel
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
         pa_off[mb] = DMH == G4 ? rowoff * C::DGP + (64 * mg + 32 * mb + 16 * cb + 4 * kp) * 2 : rowoff * C::DGP + piece(2 * mg + mb);
 #pragma unroll
     for (int i = 0; i < C::NBN; ++i) {
-        const int jn = C::NBN * ng + i;                                  // column block of [h (4 blocks) | x]
+        const int jn = min(C::NBN * ng + i, C::NBT - 1);                 // column block of [h (4 blocks) | x] (an idle slot repeats the last one: never stored)
         pb_pitch[i] = jn < 4 ? C::HP : C::XP;
         pb_lo[i] = jn < 4 ? C::L_H : C::L_X;
         pb_off[i] = jn < 4 ? rowoff * C::HP + (32 * jn + 16 * cb + 4 * kp) * 2 : 2 * C::L_H + rowoff * C::XP + (32 * (jn - 4) + 16 * cb + 4 * kp) * 2;
@@ -699,6 +703,41 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
         return __builtin_bit_cast(bf16x8, f);
+    };
+
+    // ---- encoder: the input gradient dX[row][input column] = sum over the gate columns of dG[row][k] W_ih[k][column] from the SAME dG tiles (the separate
+    // product re-read all of dG: 0.78 ms at B = 32 768).  16x16x32 MFMAs: wave (mg, ng) multiplies the tile's 16 rows by gate columns [64 mg, 64 mg + 64) of this
+    // workgroup's half direction for the 16 input columns of block ng -- W_ih^T hi / lo for those, split once at start-up: 16 registers -- and parks its 16 x 16
+    // partial tile in LDS; one barrier later (the next tile's) thread (row, column) adds the four partials of its column block in a fixed order and stores the
+    // f32 result into THIS workgroup's slice of dx_parts (direction x half: four partial tensors, summed by the caller).
+    constexpr bool DXOK = XWT == 32 && C::NG == 2;
+    const bool want_dx = DXOK && a.wih != nullptr;
+    float* red = reinterpret_cast<float*>(dwsm + 3 * C::L_DG + 2 * C::L_HX);
+    bf16x8 wdh[2], wdl[2];                                               // [k-step]
+    const int li = lane & 15, kg4 = lane >> 4;
+    if (want_dx) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int col = 16 * ng + li, k = mh * DMH + 64 * mg + 32 * ks + 8 * kg4 + jj;
+                const float v = col < a.ldx ? a.wih[((size_t)dir * G4 + k) * a.ldx + col] : 0.f;
+                const __bf16 vh = (__bf16)v;
+                wdh[ks][jj] = vh;
+                wdl[ks][jj] = (__bf16)(v - (float)vh);
+            }
+    }
+    // A fragment: row li of the tile, gate columns 64 mg + 32 ks + 8 kg4 .. + 7 of the (swizzled) half-direction image: 16-B piece 8 mg + 4 ks + kg4, stored at
+    // piece ^ ((row & 3) << 2)
+    int dxa_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) dxa_off[ks] = li * C::DGP + (((8 * mg + 4 * ks + kg4) ^ ((li & 3) << 2)) * 16);
+    auto finish_dx = [&](int jprev) {                                    // thread (row = tid >> 5, column = tid & 31) of tile jprev: its partials were parked before the barrier
+        if (!want_dx || jprev < 0) return;
+        const int row = tid >> 5, col = tid & 31;
+        const float* src = red + (jprev & 1) * (8 * 256) + (col >> 4) * (4 * 256) + ((col & 15) + 16 * (row >> 2)) * 4 + (row & 3);
+        const float sum = (src[0] + src[256]) + (src[512] + src[768]);   // the four gate-column slices (mg) of column group col >> 4
+        if (col < a.ldx) a.dxp[((size_t)blockIdx.y * nrows + tile_r0(jprev) + row) * a.ldx + col] = sum;
     };
 
     // ---- prologue: the x images' padding columns are zero for good; tile 0 in, tile 1 requested
@@ -722,6 +761,7 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
 #pragma unroll
         for (int i = 0; i < C::NXL; ++i) asm volatile("" : "+v"(xreg[i]));
         __builtin_amdgcn_s_barrier();              // every wave's DMA of tile j has landed and its image writes are visible; all are done with tile j - 1
+        if constexpr (DXOK) finish_dx(j - 1);
         store_hx(j + 1);                           // -> the image slot tile j - 1 was read from
         request_hx(j + 2);
         request_dg(j + 2);                         // -> the dG slot tile j - 1 was read from
@@ -744,19 +784,42 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
                 acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb][i], 0, 0, 0);
             }
         }
+        if constexpr (DXOK) {
+            if (want_dx) {
+                f32x4_t d0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 avh = *reinterpret_cast<const bf16x8*>(dgb + dxa_off[ks]);
+                    const bf16x8 avl = *reinterpret_cast<const bf16x8*>(dgb + C::L_PL + dxa_off[ks]);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avh, wdh[ks], d0, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avl, wdh[ks], d0, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avh, wdl[ks], d0, 0, 0, 0);
+                }
+                *reinterpret_cast<f32x4_t*>(red + (j & 1) * (8 * 256) + (ng * 4 + mg) * 256 + lane * 4) = d0;
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the clamped requests past the end)
+    if constexpr (DXOK) {
+        if (want_dx) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            finish_dx(mine - 1);
+        }
+    }
     // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     float* o = a.partials + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * DMH * C::NWT;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int i = 0; i < C::NBN; ++i)
+        for (int i = 0; i < C::NBN; ++i) {
+            if (C::NBN * ng + i >= C::NBT) continue;                      // (the encoder's idle slot)
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int m = 64 * mg + 32 * mb + (k & 3) + 8 * (k >> 2) + 4 * hh;
                 o[(size_t)m * C::NWT + 32 * (C::NBN * ng + i) + (lane & 31)] = acc[mb][i][k];
             }
+        }
 }
 
 static int dw_chunks(int R, int B) {
@@ -765,8 +828,9 @@ static int dw_chunks(int R, int B) {
 }
 static int dwx3_chunks(int R, int B, bool wide) {
     const int ntiles = (int)(((long)R * B + TX - 1) / TX);
-    const int n = max(1, min(ntiles, wide ? kNumCU / 4 : kNumCU / 2));
-    return (wide && n >= 8) ? n / 8 * 8 : n;           // (decoder: the four workgroups of a chunk on one XCD, as dw_wide_chunks)
+    (void)wide;
+    const int n = max(1, min(ntiles, kNumCU / 4));      // x 4 (direction, half) = one workgroup per CU
+    return n >= 8 ? n / 8 * 8 : n;                      // a multiple of 8: the four workgroups of a chunk land on one XCD (they share the h / x rows through its L2)
 }
 
 }  // namespace dic
@@ -881,8 +945,8 @@ size_t dic_lstm_dw_x3_workspace(int R, int B, int I) {
     return (size_t)dwx3_chunks(R, B, wide) * (wide ? (size_t)WD_OUT : (size_t)2 * G4 * (GH + XW)) * sizeof(float);
 }
 
-int dic_lstm_dw_x3(const void* dg_hi, long dg_plane, const float* out_ext, const float* x, int ldx, int x_relu, int R, int B, int H, int I,
-                   float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+int dic_lstm_dw_x3(const void* dg_hi, long dg_plane, const float* out_ext, const float* x, int ldx, int x_relu, const float* wih, float* dx_parts, int R, int B, int H,
+                   int I, float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
     DIC_REQUIRE(R > 0 && B > 0, DIC_ERR_INVALID_ARG, "lstm_dw_x3: non-positive size");
     DIC_REQUIRE(H == GH, DIC_ERR_UNSUPPORTED, "lstm_dw_x3: hidden size %d (compiled for %d)", H, GH);
     const bool wide = I == DXW;
@@ -892,6 +956,7 @@ int dic_lstm_dw_x3(const void* dg_hi, long dg_plane, const float* out_ext, const
     DIC_REQUIRE(((uintptr_t)dg_hi & 15) == 0 && dg_plane % 8 == 0 && ((uintptr_t)out_ext & 15) == 0 && ((uintptr_t)x & 15) == 0, DIC_ERR_UNSUPPORTED,
                 "lstm_dw_x3: operands must be 16-B aligned");
     DIC_REQUIRE((long)R * B >= TX, DIC_ERR_UNSUPPORTED, "lstm_dw_x3: R*B = %ld rows < one %d-row tile (use the GEMM path)", (long)R * B, TX);
+    DIC_REQUIRE((wih == nullptr) == (dx_parts == nullptr) && (!wih || !wide), DIC_ERR_INVALID_ARG, "lstm_dw_x3: wih and dx_parts go together (narrow input only)");
     LstmGrads g;
     int rc = grads_from(grads, &g, true, false, "lstm_dw_x3");
     if (rc) return rc;
@@ -899,11 +964,11 @@ int dic_lstm_dw_x3(const void* dg_hi, long dg_plane, const float* out_ext, const
     DIC_REQUIRE(workspace_bytes >= dic_lstm_dw_x3_workspace(R, B, I), DIC_ERR_WORKSPACE, "lstm_dw_x3: workspace %zu < %zu", workspace_bytes,
                 dic_lstm_dw_x3_workspace(R, B, I));
     hipStream_t st = (hipStream_t)stream;
-    DwX3Args a{(const __bf16*)dg_hi, dg_plane, out_ext, x, ldx, (float*)workspace, R, B, x_relu != 0};
+    DwX3Args a{(const __bf16*)dg_hi, dg_plane, out_ext, x, ldx, (float*)workspace, R, B, x_relu != 0, wih, dx_parts};
     static bool attr_set[2] = {false, false};
-    const int lds = wide ? DwX3<DXW, G4 / 2>::LDS : DwX3<XW, G4>::LDS;
+    const int lds = wide ? DwX3<DXW, G4 / 2>::LDS : DwX3<XW, G4 / 2>::LDS;
     if (!attr_set[wide]) {
-        hipError_t e = hipFuncSetAttribute(wide ? (const void*)lstm_dwx3_kernel<DXW, G4 / 2> : (const void*)lstm_dwx3_kernel<XW, G4>,
+        hipError_t e = hipFuncSetAttribute(wide ? (const void*)lstm_dwx3_kernel<DXW, G4 / 2> : (const void*)lstm_dwx3_kernel<XW, G4 / 2>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_dw_x3: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
         attr_set[wide] = true;
@@ -913,7 +978,7 @@ int dic_lstm_dw_x3(const void* dg_hi, long dg_plane, const float* out_ext, const
         hipLaunchKernelGGL(lstm_dw_wide_finalize, dim3((WD_OUT / 4 + 255) / 256), dim3(256), 0, st, (const float*)workspace, nch, g, accumulate ? 1.0f : 0.0f);
     } else {
         const int nw = GH + XW, n_out = 2 * G4 * nw;
-        hipLaunchKernelGGL((lstm_dwx3_kernel<XW, G4>), dim3(nch, 2), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((lstm_dwx3_kernel<XW, G4 / 2>), dim3(nch, 4), dim3(512), lds, st, a);
         hipLaunchKernelGGL(lstm_dw_finalize, dim3((n_out + 31) / 32), dim3(256), 0, st, (const float*)workspace, nch, I, nw, g, accumulate ? 1.0f : 0.0f);
     }
     return check_launch("lstm_dw_x3");

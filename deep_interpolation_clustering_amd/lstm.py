@@ -289,7 +289,10 @@ class _BiLstm(torch.autograd.Function):
         x3 = ctx.x3
         dxp = torch.empty((2, R * B, Ip), device=dev, dtype=T) if (fuse_dx and ctx.needs_input_grad[0]) else None
         dx = None
-        if ctx.needs_input_grad[0] and dxp is None:
+        # x3, narrow input: dX rides along with the weight gradients (four partial tensors, one per direction and half of its gate rows: dic_lstm_dw_x3)
+        x3_dw = x3 and X3_DW and R * B >= 16 and (I == WIDE_INPUT or Ip <= 32) and any(ctx.needs_input_grad[8:])
+        dxp4 = torch.empty((4, R * B, Ip), device=dev, dtype=torch.float32) if (x3_dw and I != WIDE_INPUT and ctx.needs_input_grad[0]) else None
+        if ctx.needs_input_grad[0] and dxp is None and dxp4 is None:
             if ctx.wih_t is not None:
                 # decoder: dX = dG . W_ih on 256 x 256 macro-tiles, dG and W_ih^T (256, 1024: k contiguous like the rows of dG; written by the forward's
                 # dic_lstm_pack) streamed through LDS (csrc/dic_dxproj.hip; until round 4: a library GEMM)
@@ -341,12 +344,15 @@ class _BiLstm(torch.autograd.Function):
                     _SIDE['keep'].append((dgx, out_ext, xb, dbias, wih, sinks))
                 else:
                     weight_grads(st)
-            elif x3 and X3_DW and R * B >= 16 and (I == WIDE_INPUT or Ip <= 32):
-                # x3: dW_ih and dW_hh of both directions from ONE pass over the split planes of dG (csrc/dic_lstmgrad.hip, lstm_dwx3_kernel: the planes by
-                # LDS-DMA as they lie, h_prev / x f32 through registers; round 6 -- until then five dic_gemm_tn launches on f32 operands)
+            elif x3_dw:
+                # x3: dW_ih and dW_hh of both directions (and the narrow input's dX) from ONE pass over the split planes of dG (csrc/dic_lstmgrad.hip,
+                # lstm_dwx3_kernel: the planes by LDS-DMA as they lie, h_prev / x f32 through registers; round 6 -- until then five dic_gemm_tn launches and a
+                # dic_gemm_nt on f32 operands)
                 ws2 = torch.empty(max(16, Lb.dic_lstm_dw_x3_workspace(R, B, I)), device=dev, dtype=torch.uint8)
-                N.check(Lb.dic_lstm_dw_x3(N.ptr(dgx), dgx.stride(0), N.ptr(out_ext), N.ptr(xb), Ip, int(ctx.x_relu_in_kernel), R, B, H, I, gp, int(accumulate),
-                                          N.ptr(ws2), ws2.numel(), st), 'dic_lstm_dw_x3')
+                N.check(Lb.dic_lstm_dw_x3(N.ptr(dgx), dgx.stride(0), N.ptr(out_ext), N.ptr(xb), Ip, int(ctx.x_relu_in_kernel), N.ptr(wih) if dxp4 is not None else None,
+                                          N.ptr(dxp4), R, B, H, I, gp, int(accumulate), N.ptr(ws2), ws2.numel(), st), 'dic_lstm_dw_x3')
+                if dxp4 is not None:
+                    dx = dxp4.sum(0)[:, :I].reshape(R, B, I).to(ctx.x_dtype)
                 N.check(Lb.dic_lstm_unpack_grads(None, 0, None, N.ptr(dbias), H, I, gp, int(accumulate), st), 'dic_lstm_unpack_grads')
             elif x3 or not f32:
                 # dic_gemm_tn: dW_ih[d] = dG[d]^T . x and dW_hh[d] = dG[d]^T . h_prev[d] straight into the parameter gradients; h_prev = row-shifted

@@ -392,10 +392,12 @@ int dic_lstm_dw_wide(const void* dgx, const void* out_ext, const void* x, int x_
  * every product hi.hi + lo.hi + hi.lo -- from ONE pass over the gate gradients in the form dic_lstm_rec_bwd(DIC_DTYPE_F32X3) writes them: two bf16 planes, hi at
  * dg_hi and lo dg_plane elements behind it, (R*B, 2*4H) each, streamed by LDS-DMA as they lie.  out_ext ((R+2)*B, 2H) f32 and x (R*B, ldx) f32 as the other f32
  * kernels take them (x_relu != 0: the LSTM ran on relu(x)).  I = 256 (the decoder; ldx = 256) or I <= ldx <= 32 with ldx a multiple of 4 (the encoder's rows
- * [features | 1 | 0...]; only columns [0, I) reach weight_ih).  R*B >= 16.  Replaces dic_gemm_tn on the f32 tensors (nn.LSTM's backward, clustering_interp.py:14-41). */
+ * [features | 1 | 0...]; only columns [0, I) reach weight_ih).  R*B >= 16.  Narrow input, wih (2*4H, ldx) f32 (dic_lstm_pack) and dx_parts (4, R*B, ldx) f32 given:
+ * four partial input gradients -- one per (direction, half of its gate rows) -- come out of the same pass (their sum is dX = dG . W_ih).  Replaces dic_gemm_tn / dic_gemm_nt on the f32 tensors (nn.LSTM's
+ * backward, clustering_interp.py:14-41). */
 size_t dic_lstm_dw_x3_workspace(int R, int B, int I);
-int dic_lstm_dw_x3(const void* dg_hi, long dg_plane, const float* out_ext, const float* x, int ldx, int x_relu, int R, int B, int H, int I,
-                   float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
+int dic_lstm_dw_x3(const void* dg_hi, long dg_plane, const float* out_ext, const float* x, int ldx, int x_relu, const float* wih, float* dx_parts, int R, int B, int H,
+                   int I, float* const* grads, int accumulate, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const float* dbias, int H, int I, float* const* grads,
                           int accumulate, dic_stream_t stream);
 
