@@ -116,45 +116,14 @@ template <> struct Rec<__bf16> {
     }
 };
 
-// ---- f32 tensors, products as THREE bf16 MFMAs ("x3": DIC_DTYPE_F32X3): every operand x is split into hi = bf16(x) and lo = bf16(x - hi) --
-// the weights once at start-up (the same 256 registers the f32 fragments take), h / dG on their way into LDS (two bf16 images instead of
-// one f32 image) -- and W.x ~ hi.hi + lo.hi + hi.lo accumulates in f32: 96 v_mfma_f32_32x32x16_bf16 per step and wave instead of 256
-// v_mfma_f32_32x32x2_f32 at twice the cycles each (5.3x less matrix-core time); products good to ~2^-17, the joint step's losses within ~1e-6
-// of the exact-f32 kernels (tests/test_gpu_gemm.py).  Everything else -- gx, saved gates / cell states, dG, the gate math -- is the f32 path.
+// ---- f32 tensors, products as THREE bf16 MFMAs ("x3": DIC_DTYPE_F32X3): every operand x is split into hi = bf16(x) and lo = bf16(x - hi) -- the weights
+// once at start-up, h / dG on their way into LDS (two bf16 images instead of one f32 image) -- and W.x ~ hi.hi + lo.hi + hi.lo accumulates in f32 on
+// v_mfma_f32_32x32x16_bf16 / 16x16x32 (5.3x less matrix-core time than v_mfma_f32_32x32x2_f32); products good to ~2^-17, the joint step's losses within ~1e-6
+// of the exact-f32 kernels (tests/test_gpu_gemm.py).  The kernels are lstm_rec_fwd8x3_kernel / lstm_rec_bwd8x3_kernel below (round 6: eight waves per tile;
+// rounds 4-5 ran the four-wave f32 kernels with this product policy: one wave per SIMD, 487-502 registers); these are the pieces they share.
 struct RecX3 {
     static constexpr int PITCH(int K) { return K + 8; }       // bf16 images: 272-B / 1040-B rows
-    template <int K> struct Frag { sbf16x8 hi[K / 16], lo[K / 16]; };
     __device__ static void split(float x, __bf16& hi, __bf16& lo) { hi = (__bf16)x; lo = (__bf16)(x - (float)hi); }
-    template <int K> __device__ static void load_a(Frag<K>& f, const float* row, int hh, int stride) {
-#pragma unroll
-        for (int ks = 0; ks < K / 16; ++ks)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                __bf16 h, l;
-                split(row[(size_t)(ks * 16 + 8 * hh + j) * stride], h, l);
-                f.hi[ks][j] = h; f.lo[ks][j] = l;
-            }
-    }
-    template <int K> __device__ static sf32x16 mma(const Frag<K>& a, const __bf16* bhi, const __bf16* blo, int hh, sf32x16 acc) {
-        constexpr int NK = K / 16, DEPTH = NK < 4 ? NK : 4;
-        sbf16x8 rh[DEPTH], rl[DEPTH];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i) {
-            rh[i] = *reinterpret_cast<const sbf16x8*>(bhi + i * 16 + 8 * hh);
-            rl[i] = *reinterpret_cast<const sbf16x8*>(blo + i * 16 + 8 * hh);
-        }
-#pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi[ks], rh[ks % DEPTH], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo[ks], rh[ks % DEPTH], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi[ks], rl[ks % DEPTH], acc, 0, 0, 0);
-            if (ks + DEPTH < NK) {
-                rh[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(bhi + (ks + DEPTH) * 16 + 8 * hh);
-                rl[ks % DEPTH] = *reinterpret_cast<const sbf16x8*>(blo + (ks + DEPTH) * 16 + 8 * hh);
-            }
-        }
-        return acc;
-    }
     // four f32 values -> the two images of an LDS tile
     __device__ static void store4(__bf16* hi, __bf16* lo, sf32x4 v) {
         sbf16x4 h, l;
@@ -185,14 +154,13 @@ struct RecFwdArgs {
     int ldx = 0;           // lstm_rec_fwd8x3_kernel<XK>: row length of x and wih in elements (a multiple of 4, <= XK)
 };
 
-template <typename T, bool X3 = false>
+template <typename T>
 __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
-    static_assert(!X3 || sizeof(T) == 4, "the split products run on f32 tensors");
     typedef typename Vec4<T>::type V4;
-    typedef typename std::conditional<X3, __bf16, T>::type HT;      // element type of the h tile images
-    typedef typename std::conditional<X3, RecX3, Rec<T>>::type P;   // product policy
+    typedef T HT;                                           // element type of the h tile image
+    typedef Rec<T> P;                                       // product policy
     constexpr int HP = P::PITCH(SH);
-    constexpr int HBUF = (X3 ? 2 : 1) * SROWS * HP;        // elements per h buffer (x3: hi image, then lo image)
+    constexpr int HBUF = SROWS * HP;                        // elements per h buffer
     constexpr int GXP = S4 + 16 / sizeof(T);               // staged gx row pitch (elements): whole rows + 16 B
     extern __shared__ __align__(16) unsigned char fsm32[];
     HT* hbuf0 = reinterpret_cast<HT*>(fsm32);             // [2][HBUF]
@@ -221,8 +189,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
         V4 hb, cb;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { hb[j] = (T)hv[j]; cb[j] = (T)cv[j]; c[4 * q + j] = cv[j]; }
-        if constexpr (X3) RecX3::store4(hbuf0 + r * HP + u, hbuf0 + SROWS * HP + r * HP + u, hv);
-        else *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
+        *reinterpret_cast<V4*>(hbuf0 + r * HP + u) = hb;
         if (a.boundary && ok) {
             T* slot = dir ? a.out + (size_t)R * B * 2 * SH : a.out - (size_t)B * 2 * SH;
             *reinterpret_cast<V4*>(slot + (size_t)b * 2 * SH + dir * SH + u) = hb;
@@ -263,8 +230,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
         if (step + 1 < R) request_gx(step + 1);            // lands during the MFMAs / gate math (the closing barrier waits for it)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if constexpr (X3) acc[g] = RecX3::template mma<SH>(wf[g], hcur + r * HP, hcur + SROWS * HP + r * HP, hh, acc[g]);
-            else acc[g] = P::template mma<SH>(wf[g], hcur + r * HP, hh, acc[g]);
+            acc[g] = P::template mma<SH>(wf[g], hcur + r * HP, hh, acc[g]);
         }
         const bool last = step == R - 1;
         const size_t row = (size_t)t * B + bc;
@@ -283,8 +249,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_fwd_kernel(RecFwdArgs<T> a) {
                 cv[j] = cn; hv[j] = hn;
                 hb[j] = (T)hn; ib[j] = (T)ig; fb[j] = (T)fg; gb[j] = (T)gg; ob[j] = (T)og; cb[j] = (T)cn;
             }
-            if constexpr (X3) RecX3::store4(hnxt + r * HP + u, hnxt + SROWS * HP + r * HP + u, hv);
-            else *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
+            *reinterpret_cast<V4*>(hnxt + r * HP + u) = hb;
             if (a.gates) {
                 *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 0, q, hh, r)) = ib;
                 *reinterpret_cast<V4*>(a.gates + snative_off(t, nbt, bt, dir, w, 4, 1, q, hh, r)) = fb;
@@ -603,17 +568,13 @@ struct RecBwdArgs {
     int relu;              // dout is the gradient of relu(out): it passes where h_t > 0, i.e. where tanh(c_t) > 0
 };
 
-template <typename T, bool X3 = false>
+template <typename T>
 __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
-    static_assert(!X3 || sizeof(T) == 4, "the split products run on f32 tensors");
     typedef typename Vec4<T>::type V4;
-    typedef typename std::conditional<X3, RecX3, Rec<T>>::type P;
+    typedef Rec<T> P;
     constexpr int GP = Rec<T>::PITCH(S4);
-    constexpr int GPB = RecX3::PITCH(S4);               // x3: row pitch of the two bf16 images behind the f32 tile
     extern __shared__ __align__(16) unsigned char rsm[];
     T* dgt = reinterpret_cast<T*>(rsm);                 // [32][GP] gate gradients of the current step (the rows that leave for global memory)
-    __bf16* dgh = reinterpret_cast<__bf16*>(rsm + (size_t)SROWS * GP * sizeof(T));      // x3: [32][GPB] hi image, [32][GPB] lo image: the MFMA operands
-    __bf16* dgl = dgh + SROWS * GPB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int dir = blockIdx.y, b0 = blockIdx.x * SROWS, B = a.B, R = a.R;
     const int b = b0 + r;
@@ -699,13 +660,6 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
             *reinterpret_cast<V4*>(lp + SH) = df;
             *reinterpret_cast<V4*>(lp + 2 * SH) = dg;
             *reinterpret_cast<V4*>(lp + 3 * SH) = dO;
-            if constexpr (X3) {
-                const int o = r * GPB + u;
-                RecX3::store4(dgh + o, dgl + o, di);
-                RecX3::store4(dgh + o + SH, dgl + o + SH, df);
-                RecX3::store4(dgh + o + 2 * SH, dgl + o + 2 * SH, dg);
-                RecX3::store4(dgh + o + 3 * SH, dgl + o + 3 * SH, dO);
-            }
         }
         if (PREFETCH && step + 1 < R) { load_q(step + 1, 0, nx0); load_q(step + 1, 1, nx1); load_q(step + 1, 2, nx2); load_q(step + 1, 3, nx3); }
         lds_barrier();                                     // the dG tile of this step is complete
@@ -743,8 +697,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_bwd_kernel(RecBwdArgs<T> a) {
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) dh[k] = 0.f;
-        if constexpr (X3) dh = RecX3::template mma<S4>(wt, dgh + r * GPB, dgl + r * GPB, hh, dh);
-        else dh = P::template mma<S4>(wt, dgt + r * GP, hh, dh);          // dh_{prev}[u][b] = sum_n W_hh[n][u] dG[b][n]
+        dh = P::template mma<S4>(wt, dgt + r * GP, hh, dh);               // dh_{prev}[u][b] = sum_n W_hh[n][u] dG[b][n]
         lds_barrier();                                     // every wave is done reading the tile
         if (PREFETCH) { in0 = nx0; in1 = nx1; in2 = nx2; in3 = nx3; }
     }
@@ -1845,15 +1798,14 @@ static size_t rec16_fwd_lds(int xk) {
     return ((size_t)2 * TROWS * Rec<__bf16>::PITCH(SH) + (xk ? (size_t)2 * TROWS * (xk + 8) : (size_t)TROWS * (S4 + 8))) * sizeof(__bf16);
 }
 
-template <typename T, bool X3 = false>
+template <typename T>
 static int rec_fwd(const void* gx, const void* whh, const float* h0, const float* c0, int R, int B, void* out, float* hn, float* cn,
                    void* gates, void* cs, int bm, hipStream_t st) {
     RecFwdArgs<T> a{(const T*)gx, (const T*)whh, h0, c0, (T*)out, hn, cn, (T*)gates, (T*)cs, R, B, (bm & 1) != 0, (bm & 2) != 0};
-    const size_t lds = X3 ? (size_t)2 * 2 * SROWS * RecX3::PITCH(SH) * sizeof(__bf16) + (size_t)SROWS * (S4 + 16 / sizeof(T)) * sizeof(T)
-                          : ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)SROWS * (S4 + 16 / sizeof(T))) * sizeof(T);
+    const size_t lds = ((size_t)2 * SROWS * Rec<T>::PITCH(SH) + (size_t)SROWS * (S4 + 16 / sizeof(T))) * sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd_kernel<T, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_fwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
@@ -1873,7 +1825,7 @@ static int rec_fwd(const void* gx, const void* whh, const float* h0, const float
             return check_launch("lstm_rec_fwd8");
         }
     }
-    hipLaunchKernelGGL((lstm_rec_fwd_kernel<T, X3>), dim3((B + SROWS - 1) / SROWS, 2), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((lstm_rec_fwd_kernel<T>), dim3((B + SROWS - 1) / SROWS, 2), dim3(256), lds, st, a);
     return check_launch("lstm_rec_fwd");
 }
 
@@ -1895,13 +1847,13 @@ static int rec_fwd8x3(const float* gx, const float* x, const float* wih, int ldx
     return check_launch("lstm_rec_fwd8x3");
 }
 
-template <typename T, bool X3 = false>
+template <typename T, bool X3 = false>      // X3: f32 tensors on the eight-wave split-product kernel; dgx leaves as split planes
 static int rec_bwd(const void* whh, int transposed, const void* gates, const void* cs, const void* dout, const float* dhn,
                    const float* dcn, int R, int B, void* dgx, float* dh0, float* dc0, float* dbias, void* workspace, int bm, int relu, hipStream_t st) {
-    const size_t lds = (size_t)SROWS * Rec<T>::PITCH(S4) * sizeof(T) + (X3 ? (size_t)2 * SROWS * RecX3::PITCH(S4) * sizeof(__bf16) : 0);
+    const size_t lds = (size_t)SROWS * Rec<T>::PITCH(S4) * sizeof(T);
     static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_bwd_kernel<T, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!X3 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_rec_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
@@ -1936,7 +1888,7 @@ static int rec_bwd(const void* whh, int transposed, const void* gates, const voi
         hipLaunchKernelGGL(lstm_rec_bwd8x3_kernel, dim3(nwg, 2), dim3(512), lds, st, a);
         eight = true;
     }
-    if (!eight) hipLaunchKernelGGL((lstm_rec_bwd_kernel<T, X3>), dim3(nwg, 2), dim3(256), lds, st, a);
+    if (!eight) hipLaunchKernelGGL((lstm_rec_bwd_kernel<T>), dim3(nwg, 2), dim3(256), lds, st, a);
     if (dbias) hipLaunchKernelGGL(lstm_rec_dbias_finalize, dim3(2 * S4 / 32), dim3(256), 0, st, (const float*)workspace, nwg, dbias);
     return check_launch("lstm_rec_bwd");
 }
