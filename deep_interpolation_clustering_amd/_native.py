@@ -80,6 +80,7 @@ SIGNATURES = {
     'dic_lstm_fwd_xproj': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     'dic_lstm_rec_bwd_workspace': (_sz, [_i]),
     'dic_lstm_rec_bwd': (_i, [_i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _i, _i, _p]),
+    'dic_lstm_dx_tile_x3': (_i, [_p, C.c_int64, _p, C.c_int64, C.c_int64, _i, _i, _p, _p]),
     'dic_lstm_dw_x3_workspace': (_sz, [_i, _i, _i]),
     'dic_lstm_dw_x3': (_i, [_p, C.c_int64, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
     'dic_lstm_dw_workspace': (_sz, [_i, _i]),

@@ -213,6 +213,167 @@ __global__ __launch_bounds__(512, 1) void dx_tile_kernel(DxTileArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// The same product for the f32 step on split products (DIC_DTYPE_F32X3; round 6): dX (N, 256) f32 = dG . W_ih with dG and W_ih^T as PAIRS OF bf16 PLANES
+// (x = hi + lo; the recurrence backward writes dG that way, W_ih^T is split by the caller) and every product hi.hi + lo.hi + hi.lo.  Same machine as
+// dx_tile_kernel -- one persistent 8-wave workgroup per CU, 256 x 256 macro-tiles, all-LDS-DMA rings with one raw barrier and one counted wait per slab,
+// the transposed product, stores straight from the accumulators -- with a slab = BOTH planes of a 32-deep k range (2 x 16 KB: the same 32 KB per slab and
+// ring slot, the same four DMA instructions per wave, operand and slab), 48 MFMAs per wave and slab instead of 32 (three terms x two k-steps x eight blocks),
+// and f32 output (a lane's accumulator quad is four consecutive columns: one 16-B store).  Until then: dic_gemm_nt on the f32 operand (128 x 128 tiles, W
+// converted in the loop, two barriers per 32-deep tile): 1.62 ms at B = 32 768, matrix cores 41 % busy.
+// LDS image of a plane: 64-B rows back to back, 16-B piece p of row r at p ^ ((r >> 2) & 3) (through the DMA's source address): the 16 rows of every
+// ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: MI355X_MICROARCH.md) then cover all 64 banks once.
+constexpr int PK = 32;                                // k per slab
+constexpr int P_ROWB = PK * 2;                        // 64 B
+constexpr int P_PLANE = TM * P_ROWB;                  // 16 KB: one plane of a slab (dG rows or W^T rows: TM == TN)
+constexpr int P_SLOT = 2 * P_PLANE;                   // 32 KB: hi | lo
+constexpr int P_SLABS = XK / PK;                      // 32 slabs per tile
+constexpr int P_LDS = (T_NA + T_NB) * P_SLOT;         // 163 840 B
+static_assert(P_LDS <= 160 * 1024 && TM == TN, "dx_tile_x3: LDS budget");
+
+struct DxTileX3Args {
+    const __bf16* dg; long dg_plane;      // (N, 1024) hi plane; lo plane dg_plane elements behind it
+    const __bf16* wt; long wt_plane;      // (256, 1024) = W_ih^T hi plane; lo plane wt_plane elements behind it
+    float* dx;                            // (N, 256)
+    long N;
+};
+
+__global__ __launch_bounds__(512, 1) void dx_tile_x3_kernel(DxTileX3Args a) {
+    extern __shared__ __align__(16) unsigned char tsm[];
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, l31 = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w & 3, wn = w >> 2;
+    const long N = a.N;
+    const int ntiles = (int)((N + TM - 1) / TM), nch = gridDim.x;
+    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / nch + 1 : 0;
+    const int S = my_tiles * P_SLABS;
+    if (S == 0) return;
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)tsm);
+    const unsigned ldsA = lds0, ldsB = lds0 + T_NA * P_SLOT;
+    // DMA: a plane of a slab = 16 instructions of 16 rows; wave w issues c = w, w + 8, w + 16, w + 24 of the 32 (plane c >> 4, row group c & 15); lane L -> row
+    // 16 rg + (L >> 2), physical piece L & 3 = logical piece (L & 3) ^ ((row >> 2) & 3), and (row >> 2) & 3 = (L >> 4) & 3 for every row group
+    const unsigned v_dma = (unsigned)(lane >> 2) * (XK * 2) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+    auto tile_row0 = [&](int i) { return min((long)((int)blockIdx.x + i * nch) * TM, N - TM); };
+    auto issue_a = [&](int s) {
+        const int i = s / P_SLABS, ks = s % P_SLABS;
+        const __bf16* src = a.dg + (size_t)tile_row0(i) * XK + ks * PK;
+        const unsigned dst = ldsA + (s % T_NA) * P_SLOT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = w + 8 * j, pl = c >> 4, rg = c & 15;
+            xdma16(src + (size_t)pl * a.dg_plane + (size_t)(16 * rg) * XK, v_dma, dst + pl * P_PLANE + rg * 1024);
+        }
+    };
+    auto issue_b = [&](int s) {
+        const int ks = s % P_SLABS;
+        const __bf16* src = a.wt + ks * PK;
+        const unsigned dst = ldsB + (s % T_NB) * P_SLOT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = w + 8 * j, pl = c >> 4, rg = c & 15;
+            xdma16(src + (size_t)pl * a.wt_plane + (size_t)(16 * rg) * XK, v_dma, dst + pl * P_PLANE + rg * 1024);
+        }
+    };
+    // fragment reads: row (32 block + l31), logical piece 2 kk + hh -> physical piece ^ ((l31 >> 2) & 3)
+    const int sw = (l31 >> 2) & 3;
+    int poff[PK / 16];
+#pragma unroll
+    for (int kk = 0; kk < PK / 16; ++kk) poff[kk] = ((2 * kk + hh) ^ sw) * 16;
+    const int a_row = (128 * wn + l31) * P_ROWB;          // W^T rows of this wave's 4 column blocks (+ 32 nb rows)
+    const int b_row = (64 * wm + l31) * P_ROWB;           // dG rows of this wave's 2 row blocks (+ 32 mb rows)
+
+#pragma unroll
+    for (int it = 1 - T_NA; it < 0; ++it) {
+        if (it + T_NB - 1 >= 0 && it + T_NB - 1 < S) issue_b(it + T_NB - 1);
+        if (it + T_NA - 1 < S) issue_a(it + T_NA - 1);
+    }
+    xf32x16 acc[4][2];
+    // a finished tile's accumulators -> global, one iteration LATE (see dx_tile_kernel): D^T layout, lane (m = l31, hh), register k -> column
+    // 32 nb + (k & 3) + 8 (k >> 2) + 4 hh: quad g = k >> 2 is four consecutive f32 columns
+    auto store_tile = [&](int tile_i) {
+        const long r0 = tile_row0(tile_i);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            float* orow = a.dx + (size_t)(r0 + 64 * wm + 32 * mb + l31) * XN + 128 * wn + 4 * hh;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typedef float of32x4 __attribute__((ext_vector_type(4)));
+                    const of32x4 v = {acc[nb][mb][4 * g], acc[nb][mb][4 * g + 1], acc[nb][mb][4 * g + 2], acc[nb][mb][4 * g + 3]};
+                    *reinterpret_cast<of32x4*>(orow + 32 * nb + 8 * g) = v;
+                }
+        }
+    };
+    for (int s = 0; s < S; ++s) {
+        const int ks = s % P_SLABS;
+        // counted wait: as dx_tile_kernel (4 + 4 DMA instructions per wave and iteration), with 32 output stores per wave behind the first DMAs of a later tile
+        {
+            constexpr int inflight = (T_NA > T_NB ? 4 : 0) + 8 * (T_NB - 2);
+            const int tail = S - 1 - s;
+            if (tail >= T_NA - 1) {
+                if (ks >= 1 && ks <= T_NB - 1 && s >= P_SLABS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(inflight + 32) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(inflight) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everybody's pieces of slab s are in; everybody is done reading slab s - 1 (its two slots are free)
+        const unsigned char* A = tsm + T_NA * P_SLOT + (s % T_NB) * P_SLOT + a_row;
+        const unsigned char* Bm = tsm + (s % T_NA) * P_SLOT + b_row;
+        // registers: the hi fragments of a k-step in two sets (the next k-step's are requested under the current one's second term), the lo fragments in one
+        // (requested under the first term, which does not use them)
+        xbf16x8 ah[2][4], bh[2][2], al[4], bl[2];
+        auto load_hi = [&](int kk, int set) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) bh[set][mb] = *reinterpret_cast<const xbf16x8*>(Bm + mb * 32 * P_ROWB + poff[kk]);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) ah[set][nb] = *reinterpret_cast<const xbf16x8*>(A + nb * 32 * P_ROWB + poff[kk]);
+        };
+        auto load_lo = [&](int kk) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) bl[mb] = *reinterpret_cast<const xbf16x8*>(Bm + P_PLANE + mb * 32 * P_ROWB + poff[kk]);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) al[nb] = *reinterpret_cast<const xbf16x8*>(A + P_PLANE + nb * 32 * P_ROWB + poff[kk]);
+        };
+        load_hi(0, 0);
+        __builtin_amdgcn_sched_barrier(0);          // (the first fragment reads go out BEFORE the DMA instructions)
+        if (s + T_NB - 1 < S) issue_b(s + T_NB - 1);
+        if (s + T_NA - 1 < S) issue_a(s + T_NA - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) {
+            if (s > 0) store_tile(s / P_SLABS - 1);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[nb][mb][k] = 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < PK / 16; ++kk) {
+            load_lo(kk);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk & 1][nb], bh[kk & 1][mb], acc[nb][mb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < PK / 16) load_hi(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[nb], bh[kk & 1][mb], acc[nb][mb], 0, 0, 0);
+                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk & 1][nb], bl[mb], acc[nb][mb], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    store_tile(my_tiles - 1);
+}
+
 static int dx_tile_chunks(long N) {
     const int ntiles = (int)((N + TM - 1) / TM);
     return max(1, min(ntiles, kNumCU));
@@ -238,6 +399,25 @@ int dic_lstm_dx_tile(const void* dg, const void* w_ih_t, int64_t N, int gate_col
     DxTileArgs a{(const __bf16*)dg, (const __bf16*)w_ih_t, (__bf16*)dx, (long)N};
     hipLaunchKernelGGL(dx_tile_kernel, dim3(dx_tile_chunks(N)), dim3(512), T_LDS, (hipStream_t)stream, a);
     return check_launch("lstm_dx_tile");
+}
+
+int dic_lstm_dx_tile_x3(const void* dg_hi, long dg_plane, const void* w_ih_t_hi, long wt_plane, int64_t N, int gate_columns, int in_features, float* dx,
+                        dic_stream_t stream) {
+    DIC_REQUIRE(N >= TM, DIC_ERR_INVALID_ARG, "lstm_dx_tile_x3: %lld rows (needs at least %d)", (long long)N, TM);
+    DIC_REQUIRE(gate_columns == XK && in_features == XN, DIC_ERR_UNSUPPORTED, "lstm_dx_tile_x3: (%d gate columns -> %d inputs) (compiled for 1024 -> 256)",
+                gate_columns, in_features);
+    DIC_REQUIRE(dg_hi && w_ih_t_hi && dx && dg_plane > 0 && wt_plane > 0, DIC_ERR_INVALID_ARG, "lstm_dx_tile_x3: NULL pointer / plane stride");
+    DIC_REQUIRE(((uintptr_t)dg_hi & 15) == 0 && ((uintptr_t)w_ih_t_hi & 15) == 0 && ((uintptr_t)dx & 15) == 0 && dg_plane % 8 == 0 && wt_plane % 8 == 0,
+                DIC_ERR_UNSUPPORTED, "lstm_dx_tile_x3: operands must be 16-B aligned");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)dx_tile_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "lstm_dx_tile_x3: cannot reserve %d B of LDS: %s", P_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    DxTileX3Args a{(const __bf16*)dg_hi, dg_plane, (const __bf16*)w_ih_t_hi, wt_plane, dx, (long)N};
+    hipLaunchKernelGGL(dx_tile_x3_kernel, dim3(dx_tile_chunks(N)), dim3(512), P_LDS, (hipStream_t)stream, a);
+    return check_launch("lstm_dx_tile_x3");
 }
 
 }  // extern "C"

@@ -43,6 +43,7 @@ GX_LANE_NATIVE = os.environ.get('DIC_GX_LANE_NATIVE', '1') != '0'     # (A/B swi
 ROW_PROJ = os.environ.get('DIC_ROW_PROJ', '1') != '0'                  # (A/B switch: 0 = library GEMM for the decoder's input projection)
 RELU_IN_KERNEL = os.environ.get('DIC_RELU_IN_KERNEL', '1') != '0'      # (A/B switch: 0 = rectify the encoder output with a torch pass)
 WIDE_INPUT = 256               # dic_lstm_dw_wide's compiled input width (the decoder: 2H rectified encoder outputs)
+X3_DX_TILE = os.environ.get('DIC_X3_DX_TILE', '1') != '0'              # (A/B switch: 0 = dic_gemm_nt_planes for the decoder's dX in the x3 step)
 X3_DW = os.environ.get('DIC_X3_DW', '1') != '0'                        # (A/B switch: 0 = dic_gemm_tn_planes for the x3 step's LSTM weight gradients)
 X3_REC_PROJ = os.environ.get('DIC_X3_REC_PROJ', '1') != '0'            # (A/B switch: 0 = dic_gemm_nt + gx for the encoder's forward in the x3 step)
 REC_PROJ = os.environ.get('DIC_REC_PROJ', '1') != '0'                  # (A/B switch: 0 = dic_gemm_nt + dic_lstm_rec_fwd for the encoder's small-batch forward)
@@ -300,6 +301,12 @@ class _BiLstm(torch.autograd.Function):
                 N.check(Lb.dic_lstm_dx_tile(N.ptr(dg2), N.ptr(ctx.wih_t), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_tile')
             elif f32 and not x3:
                 dx = dg2 @ wih                                       # (R*B, Ip): the exact-f32 parity mode
+            elif x3 and X3_DX_TILE and I == WIDE_INPUT and Ip == I and R * B >= DX_TILE_MIN_ROWS:
+                # decoder, x3: dX = dG . W_ih on 256 x 256 macro-tiles from the split planes of dG and of W_ih^T, both streamed through LDS by DMA
+                # (csrc/dic_dxproj.hip dx_tile_x3_kernel; round 6 -- until then dic_gemm_nt on the f32 operand)
+                wt_pl = _ops.split_planes(wih.t())                   # (2, 256, 1024) bf16: a few launches on 1 MB
+                dx = torch.empty((R * B, Ip), device=dev, dtype=torch.float32)
+                N.check(Lb.dic_lstm_dx_tile_x3(N.ptr(dg2), dg2.stride(0), N.ptr(wt_pl), wt_pl.stride(0), R * B, 8 * H, Ip, N.ptr(dx), st), 'dic_lstm_dx_tile_x3')
             elif x3:
                 dx = _ops.gemm_nt_planes(dg2, wih.t().contiguous())  # dX = dG . W_ih from the split planes of dG (W_ih^T: a (Ip, 8H) copy of the packed weights)
             else:

@@ -790,6 +790,13 @@ def _planes(a):
     return a
 
 
+def split_planes(x):
+    """(2, *x.shape) bf16: hi = bf16(x), lo = bf16(x - hi) of an f32 tensor (contiguous planes)."""
+    xc = x.contiguous()
+    hi = xc.to(torch.bfloat16)
+    return torch.stack([hi, (xc - hi.float()).to(torch.bfloat16)])
+
+
 def planes_to_f32(a):
     """The f32 tensor a split-plane operand stands for (tests, odd consumers)."""
     return a[0].float() + a[1].float()

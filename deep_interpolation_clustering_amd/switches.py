@@ -44,6 +44,7 @@ SWITCHES = {
     'DIC_SMALL_BATCH': (INT, '4096', 'lstm.py', 'largest batch served by the one-tile-per-workgroup recurrence kernels (`dic_lstm_rec_*`); above it the 64-row kernels and `dic_lstm_fwd_xproj`'),
     'DIC_FWD_XPROJ': (ON_OFF, '1', 'lstm.py', '0: the decoder\'s large-batch forward as `dic_row_proj` + `dic_lstm_fwd` (gx through HBM) instead of `dic_lstm_fwd_xproj`'),
     'DIC_REC_PROJ': (ON_OFF, '1', 'lstm.py', '0: `dic_gemm_nt` + `dic_lstm_rec_fwd` for the encoder\'s forward at batches up to 4096 (gx materialised)'),
+    'DIC_X3_DX_TILE': (ON_OFF, '1', 'lstm.py', '0: `dic_gemm_nt_planes` for the decoder\'s input gradient in the x3 step instead of `dic_lstm_dx_tile_x3`'),
     'DIC_X3_DW': (ON_OFF, '1', 'lstm.py', '0: `dic_gemm_tn_planes` (two launches per LSTM) for the x3 step\'s LSTM weight gradients instead of `dic_lstm_dw_x3`'),
     'DIC_X3_REC_PROJ': (ON_OFF, '1', 'lstm.py', '0: `dic_gemm_nt` + a gx tensor for the encoder\'s forward in the x3 step instead of the projection inside `dic_lstm_rec_fwd_proj_x3`'),
     'DIC_X3_ROW_PROJ': (ON_OFF, '1', 'ops.py', '0: `dic_gemm_nt` for the 256-input projections of the x3 step too'),

@@ -357,6 +357,12 @@ int dic_lstm_rec_bwd(int dtype, const void* whh, int whh_is_transposed, const vo
  * row share of dG once.  w_ih_t (in_features = 256, gate_columns = 1024) bf16 = W_ih TRANSPOSED (k contiguous, like the rows of dg); dx (N, 256)
  * bf16 OVERWRITTEN.  N >= 256.  Replaces the last library GEMM of the bf16 step (nn.LSTM's backward: clustering_interp.py:29-41). */
 int dic_lstm_dx_tile(const void* dg, const void* w_ih_t, int64_t N, int gate_columns, int in_features, void* dx, dic_stream_t stream);
+/* dic_lstm_dx_tile_x3 (round 6): the same product for the f32 step on split products -- dX (N, 256) F32 = dG . W_ih with dG as the two bf16 planes
+ * dic_lstm_rec_bwd(DIC_DTYPE_F32X3) writes (hi at dg_hi, lo dg_plane elements behind it, (N, 1024) each) and W_ih^T (256, 1024) split the same way by the
+ * caller (hi at w_ih_t_hi, lo wt_plane elements behind it); every product hi.hi + lo.hi + hi.lo.  Same macro-tiles and LDS-DMA rings, a slab = both planes of
+ * a 32-deep k range.  N >= 256.  Replaces dic_gemm_nt on the f32 operand (nn.LSTM's backward, clustering_interp.py:29-41). */
+int dic_lstm_dx_tile_x3(const void* dg_hi, long dg_plane, const void* w_ih_t_hi, long wt_plane, int64_t N, int gate_columns, int in_features, float* dx,
+                        dic_stream_t stream);
 
 /* ------------------------------------------------------------------ bi-LSTM parameters --------
  * The eight f32 parameters of one bidirectional nn.LSTM layer (clustering_interp.py:22,35: weight_ih_l0, weight_hh_l0,

@@ -1174,6 +1174,33 @@ def test_decoder_input_gradient_tile_kernel_equals_matmul(rows):
     assert N.lib().dic_lstm_dx_tile(N.ptr(dg), N.ptr(wt), 255, 1024, 256, N.ptr(dx), N.stream_of(dg)) == -1      # fewer rows than a tile: rejected
 
 
+@pytest.mark.parametrize('rows', [256, 257, 1000, 24 * 1030 + 7])
+def test_decoder_input_gradient_tile_kernel_on_split_planes(rows):
+    """dic_lstm_dx_tile_x3 (csrc/dic_dxproj.hip: dX = dG . W_ih on 256 x 256 macro-tiles, dG and W_ih^T as hi / lo bf16 planes, three MFMAs per product,
+    f32 output) against the f64 product of the f32 tensors the planes stand for and against dic_gemm_nt_planes: one tile, ragged row counts (the shifted last
+    tile), more tiles than workgroups; and a structured operand that would expose a permuted fragment, plane or column."""
+    from deep_interpolation_clustering_amd import _native as N, ops
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(rows)
+    dg = torch.randn(rows, 1024, device=dev, generator=g) * 0.3
+    w = torch.randn(1024, 256, device=dev, generator=g) * 0.06
+    dgp, wtp = ops.split_planes(dg), ops.split_planes(w.t())
+    dx = torch.full((rows, 256), float('nan'), device=dev)
+    N.check(N.lib().dic_lstm_dx_tile_x3(N.ptr(dgp), dgp.stride(0), N.ptr(wtp), wtp.stride(0), rows, 1024, 256, N.ptr(dx), N.stream_of(dg)), 'dic_lstm_dx_tile_x3')
+    ref = ops.planes_to_f32(dgp).double() @ ops.planes_to_f32(wtp).double().t()
+    assert torch.isfinite(dx).all()
+    scale = float(ref.abs().max())
+    assert float((dx.double() - ref).abs().max()) <= 3e-5 * scale                       # the dropped lo.lo term and f32 accumulation
+    assert float((dx - ops.gemm_nt_planes(dgp, w.t().contiguous())).abs().max()) <= 2e-5 * scale
+    # row i of dG = e_(i mod 1024) (exactly representable: lo plane zero): dX row i = row (i mod 1024) of W to the split's accuracy
+    dg2 = torch.zeros(rows, 1024, device=dev)
+    dg2[torch.arange(rows, device=dev), torch.arange(rows, device=dev) % 1024] = 1.0
+    dgp2 = ops.split_planes(dg2)
+    N.check(N.lib().dic_lstm_dx_tile_x3(N.ptr(dgp2), dgp2.stride(0), N.ptr(wtp), wtp.stride(0), rows, 1024, 256, N.ptr(dx), N.stream_of(dg)), 'dic_lstm_dx_tile_x3')
+    assert torch.equal(dx, ops.planes_to_f32(wtp).t()[torch.arange(rows, device=dev) % 1024])
+    assert N.lib().dic_lstm_dx_tile_x3(N.ptr(dgp), dgp.stride(0), N.ptr(wtp), wtp.stride(0), 255, 1024, 256, N.ptr(dx), N.stream_of(dg)) == -1
+
+
 def test_eight_wave_small_batch_recurrence_equals_four_wave(tmp_path):
     """The eight-waves-per-tile bf16 recurrence kernels of csrc/dic_lstm32.hip (a wave owns 16 hidden units; the backward's dh on
     16x16x32 MFMAs with a permlane16 swap between the two batch blocks) against the four-wave kernels on the same inputs, batch sizes
