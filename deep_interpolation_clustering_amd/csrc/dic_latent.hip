@@ -608,6 +608,36 @@ static int latent_check(const char* who, int rows, int D, int K) {
         default: { constexpr int KP = 32; __VA_ARGS__; } break; \
     }
 
+// (dic_cumsum_f64)
+__global__ __launch_bounds__(1024) void cumsum_f64_kernel(const float* x, int n, double* out) {
+    __shared__ double wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* xr = x + (size_t)blockIdx.x * n;
+    double* orow = out + (size_t)blockIdx.x * n;
+    const int chunk = ((n + 15) / 16 + 63) / 64 * 64;
+    const int lo = min(n, w * chunk), hi = min(n, lo + chunk);
+    double s = 0.0;
+    for (int i = lo + lane; i < hi; i += 64) s += (double)xr[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) wsum[w] = s;
+    __syncthreads();
+    double carry = 0.0;
+    for (int j = 0; j < w; ++j) carry += wsum[j];
+    for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        double v = i < hi ? (double)xr[i] : 0.0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double t = __shfl_up(v, d);
+            if (lane >= d) v += t;
+        }
+        v += carry;
+        if (i < hi) orow[i] = v;
+        carry = __shfl(v, 63);
+    }
+}
+
 }  // namespace dic
 
 using namespace dic;
@@ -824,6 +854,17 @@ int dic_kmeans_pp_candidates_rows(const float* X, int N, int D, int row_lo, int 
                                   const float* closest, float* dist_out, double* pot_out, void* workspace,
                                   size_t workspace_bytes, dic_stream_t stream) {
     return pp_candidates(X, N, D, row_lo, row_hi, cand, L, group, closest, dist_out, pot_out, workspace, workspace_bytes, stream);
+}
+
+// f64 inclusive running sums along the rows of an f32 matrix: k-means++ draws its next centre where stable_cumsum(closest_dist_sq) crosses the sampled
+// thresholds (sklearn/cluster/_kmeans.py:218-243; the reference's call sites: clustering_trainer.py:75-82, p2_clustering_optK.py:260-389).  One workgroup of
+// 16 waves per row: every wave sums its contiguous chunk, the chunk totals are prefixed in a fixed order, then the chunk is scanned 64 elements at a time
+// with the carry running along -- coalesced reads and writes, a deterministic summation order.
+int dic_cumsum_f64(const float* x, int n_rows, int n, double* out, dic_stream_t stream) {
+    DIC_REQUIRE(x && out, DIC_ERR_INVALID_ARG, "cumsum_f64: NULL pointer");
+    DIC_REQUIRE(n_rows > 0 && n_rows <= 65535 && n > 0, DIC_ERR_INVALID_ARG, "cumsum_f64: %d rows of %d", n_rows, n);
+    hipLaunchKernelGGL(cumsum_f64_kernel, dim3(n_rows), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+    return check_launch("cumsum_f64");
 }
 
 }  // extern "C"

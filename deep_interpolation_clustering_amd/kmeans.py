@@ -136,6 +136,15 @@ def lloyd_sharded(X, xnorm, centers, tol, max_iter):
     return labels, inertia, status
 
 
+def _cumsum_f64(x):
+    """(n_rows, n) f64 inclusive running sums along the rows of an f32 matrix (dic_cumsum_f64: one workgroup per row, fixed summation order --
+    torch.cumsum's innermost-dimension scan took 175 us per call on the 10 x 75 000 potentials of p2's sweep, 2 090 calls)."""
+    out = torch.empty(x.shape, dtype=torch.float64, device=x.device)
+    xc = x.contiguous()
+    N.check(N.lib().dic_cumsum_f64(N.ptr(xc), xc.shape[0], xc.shape[1], N.ptr(out), N.stream_of(xc)), 'dic_cumsum_f64')
+    return out
+
+
 def seed_draw_count(K, n_init):
     """Doubles a k-means++ fit takes from its random stream (``_pp_init``: per restart one ``choice`` = one double, then K-1 times
     ``uniform(size=trials)``) -- independent of the data, so a caller can advance a stream past a fit it does not run (p2's sharded sweep)."""
@@ -186,7 +195,7 @@ def _pp_init(X, K, n_runs, rs, shard=False):
     ar = torch.arange(n_runs, device=dev)
     for c in range(1, K):
         cur = pot.float().double()                                   # current_pot is an f32 scalar upstream
-        cum = torch.cumsum(closest, dim=1, dtype=torch.float64)      # stable_cumsum(sample_weight * closest)
+        cum = _cumsum_f64(closest)                                   # stable_cumsum(sample_weight * closest): f64 running sums of the f32 distances
         cand = torch.searchsorted(cum, u[:, c - 1] * cur[:, None]).clamp_(max=Nn - 1)      # (n_runs, trials)
         candidates(cand.contiguous(), n_runs * trials, trials, closest, dist_c, pot_c)
         best = torch.argmin(pot_c.view(n_runs, trials), dim=1)
@@ -302,6 +311,22 @@ class KMeans:
         N.check(N.lib().dic_kmeans_predict(N.ptr(Xd), Nn, D, c.shape[1], 1, N.ptr(c), N.ptr(labels), None, None, None, 0,
                                            N.stream_of(Xd)), 'dic_kmeans_predict')
         return labels[0].cpu().numpy()
+
+    def nearest_distance(self, X):
+        """(N,) f32 on the device: Euclidean distance of every row of X to its nearest centre -- what p2's elbow curve averages
+        (``cdist(X, centers).min(1)``, p2_clustering_optK.py:253-270) -- from the E-step kernel's exact ||x - c_label||^2 instead of an N x K
+        distance matrix out of a library GEMM."""
+        dev = _device()
+        Xd = _pad_features(_as_device_matrix(X, dev))
+        c = _pad_features(_as_device_matrix(self.cluster_centers_, dev))[None].contiguous()
+        Nn, D = Xd.shape
+        labels = torch.empty((1, Nn), dtype=torch.int32, device=dev)
+        mind = torch.empty((1, Nn), dtype=torch.float32, device=dev)
+        L = N.lib()
+        ws = _ws(L.dic_kmeans_workspace(Nn, D, c.shape[1], 1), dev)
+        N.check(L.dic_kmeans_predict(N.ptr(Xd), Nn, D, c.shape[1], 1, N.ptr(c), N.ptr(labels), N.ptr(mind), None, N.ptr(ws), ws.numel(),
+                                     N.stream_of(Xd)), 'dic_kmeans_predict')
+        return mind[0].clamp_min_(0).sqrt_()
 
     def transform(self, X):
         raise NotImplementedError('transform is not on the reference path')

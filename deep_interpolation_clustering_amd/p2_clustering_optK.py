@@ -160,9 +160,8 @@ class KM(object):
         for k in range(2, self.k_max + 1):
             logger.info('Running K: {}'.format(k))
             km = KMeans(n_clusters=k, init='k-means++').fit(tr)                  # n_init='auto' -> 1, as sklearn >= 1.4
-            c = torch.as_tensor(km.cluster_centers_, device=dev)
-            rows.append(dict(k=k, train=float(torch.cdist(tr, c).min(1).values.mean()),
-                             valid=float(torch.cdist(va, c).min(1).values.mean())))
+            # mean distance to the nearest centre (p2:253-270's cdist(...).min(1).mean()) from the E-step kernel: no N x K matrix, no library GEMM
+            rows.append(dict(k=k, train=float(km.nearest_distance(tr).mean()), valid=float(km.nearest_distance(va).mean())))
         df = pd.DataFrame(rows)
         if dist.rank() == 0:
             df.to_csv(osp.join(self.out_path, 'elbow.csv'), index=False)

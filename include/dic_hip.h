@@ -261,6 +261,9 @@ int dic_kmeans_pp_candidates(const float* X, int N, int D, const int64_t* cand, 
 int dic_kmeans_pp_candidates_rows(const float* X, int N, int D, int row_lo, int row_hi, const int64_t* cand, int L, int group,
                                   const float* closest, float* dist_out, double* pot_out,
                                   void* workspace, size_t workspace_bytes, dic_stream_t stream);
+/* out (n_rows, n) f64 = inclusive running sums along the rows of x (n_rows, n) f32, in f64: the stable_cumsum of scikit-learn's k-means++ sampling
+ * (sklearn/cluster/_kmeans.py:218-243, as called from clustering_trainer.py:75-82 and p2_clustering_optK.py:260-389); deterministic summation order. */
+int dic_cumsum_f64(const float* x, int n_rows, int n, double* out, dic_stream_t stream);
 
 /* ------------------------------------------------------------------ bi-LSTM recurrence -----
  * Sequential half of one bidirectional torch.nn.LSTM layer with hidden size H = 128 (EncoderRNN /

@@ -768,3 +768,31 @@ def test_rbf_backward_with_an_underflowing_bandwidth(ops, shape):
     for mode in res:
         np.testing.assert_allclose(res[mode][0], v64.grad.numpy(), rtol=2e-4, atol=2e-5 * float(v64.grad.abs().max()))
         np.testing.assert_allclose(res[mode][1], k64.grad.numpy(), rtol=3e-4, atol=3e-5 * float(k64.grad.abs().max()))
+
+
+@pytest.mark.parametrize('rows,n', [(1, 1), (3, 63), (10, 75000), (2, 4737), (20, 1000)])
+def test_cumsum_f64_matches_numpy(rows, n):
+    """dic_cumsum_f64 (the stable_cumsum of k-means++ sampling: sklearn/cluster/_kmeans.py:218-243) against NumPy's sequential f64 running sums: equal to
+    f64 summation-order noise -- and the draw it feeds (searchsorted against thresholds away from that noise) identical."""
+    from deep_interpolation_clustering_amd import kmeans
+    rng = np.random.default_rng(n)
+    x = (rng.random((rows, n)) ** 2).astype(np.float32)
+    got = kmeans._cumsum_f64(torch.tensor(x, device='cuda')).cpu().numpy()
+    ref = np.cumsum(x.astype(np.float64), axis=1)
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-13, atol=0)
+    assert (np.diff(got, axis=1) >= 0).all()
+    thr = rng.random((rows, 5)) * ref[:, -1:]
+    for r in range(rows):
+        assert np.array_equal(np.searchsorted(got[r], thr[r]), np.searchsorted(ref[r], thr[r]))
+
+
+def test_nearest_distance_equals_cdist_min():
+    """KMeans.nearest_distance (p2's elbow curve: cdist(X, centers).min(1), p2_clustering_optK.py:253-270) from the E-step kernel against the distance matrix."""
+    from deep_interpolation_clustering_amd.kmeans import KMeans
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(3001, 256)).astype(np.float32)
+    km = KMeans(n_clusters=7, n_init=1, random_state=0).fit(X)
+    got = km.nearest_distance(X[:1999]).cpu().numpy()
+    ref = np.sqrt(((X[:1999, None, :].astype(np.float64) - km.cluster_centers_[None].astype(np.float64)) ** 2).sum(-1)).min(1)
+    np.testing.assert_allclose(got, ref, rtol=2e-5)

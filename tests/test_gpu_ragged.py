@@ -199,7 +199,8 @@ def test_device_loader_on_the_store_yields_what_the_padded_loader_yields(tmp_pat
         assert torch.equal(dl_r.store.dense_rows(torch.arange(len(ds), device=dev)), full)     # the padded array, bit for bit
         train = DeviceLoader(ds, 64, True, dev, seed=1, shard=False)
         s, f = next(iter(train))
-        assert f is s and set(s) == {'encounter_id', 'lengths', 'ragged'} and s['ragged'].shape == (64, 24, 96)
+        assert f is s and set(s) == {'encounter_id', 'lengths', 'ragged', 'global_rows'} and s['ragged'].shape == (64, 24, 96)
+        assert s['global_rows'] == 64          # rows of the GLOBAL batch (round 6: what a sharded Stepper keys its captured steps on)
     finally:
         dataloader.BASE_PATH = old
 
