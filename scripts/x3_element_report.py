@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""What the x3 mode (f32 tensors, every dense product hi.hi + lo.hi + hi.lo on the bf16 matrix cores) misses the reference's own joint step by, quantity
+by quantity, beside the exact-f32 mode -- on the fixtures the 1e-5 tests use (tests/golden/netstep_cfg_K4 / K8: the reference's clustering_interp.Net at the
+configured shape, from its pretrained state with scikit-learn centroids).  VERDICT r5 #1: the numbers behind the decision whether `--f32_products x3` could
+be the default.  usage (GPU box): python3 scripts/x3_element_report.py > gpurun_out/x3_element_report.json"""
+import json
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import test_gpu_traj as T  # noqa: E402  (fixture loaders: load, p1_state, trainer_args)
+from deep_interpolation_clustering_amd.clustering_interp import Net  # noqa: E402
+from deep_interpolation_clustering_amd.step import Stepper  # noqa: E402
+from deep_interpolation_clustering_amd.utils import pytorch_optimizer  # noqa: E402
+
+dev = torch.device('cuda')
+out = {'_note': 'max |got - reference| (and relative to the largest |reference| of the tensor) after ONE joint step from the fixture state; tolerance = what '
+                'tests/test_gpu_traj.py::test_joint_step_cfg_shape_kmeans_centroids holds the exact mode to'}
+for K in (4, 8):
+    g = T.load(f'netstep_cfg_K{K}.npz')
+    for mode in ('exact', 'x3'):
+        _, sd = T.p1_state()
+        sd['cluster_assignment.cluster_centers'] = torch.tensor(g['centers'])
+        args = T.trainer_args(loss='ae_mse_kl', cluster_number=K)
+        net = Net(args, dev).to(dev)
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        st = Stepper(net, lambda m: pytorch_optimizer(m, 'Adam', 3e-3, 4e-4), args, precision=mode)
+        x, ob = torch.tensor(g['x'], device=dev), torch.tensor(g['ob'], device=dev)
+        mask = x[:, 6:12].contiguous()
+        losses, gnorm, z = st.step(x, ob, mask, mask.sum(-1).to(torch.int32))
+        rec = {}
+        for k in ('loss', 'ae_mse', 'kl'):
+            rec['loss_rel/' + k] = abs(float(losses[k]) - float(g['loss_' + k])) / abs(float(g['loss_' + k]))
+        rec['gnorm_rel'] = abs(float(gnorm) - float(g['gnorm'])) / float(g['gnorm'])
+        zz = z.detach().cpu().numpy()
+        rec['latent_abs'] = float(np.abs(zz - g['z']).max())
+        rec['latent_rel_to_max'] = rec['latent_abs'] / float(np.abs(g['z']).max())
+        q = net.cluster_assignment(z.detach()).cpu().numpy()
+        rec['q_abs'] = float(np.abs(q - g['q']).max())
+        rec['argmax_q_equal'] = bool((q.argmax(1) == g['q'].argmax(1)).all())
+        worst, worst_k = 0.0, None
+        for k, v in net.state_dict().items():
+            if 'sd1/' + k not in g:
+                continue
+            got, ref = v.detach().cpu().numpy(), g['sd1/' + k]
+            if 'g/' + k in g:
+                live = np.abs(g['g/' + k]) >= 1e-4 * float(g['gnorm'])
+                got, ref = got[live], ref[live]
+            if got.size:
+                d = float(np.abs(got - ref).max())
+                if d > worst:
+                    worst, worst_k = d, k
+        rec['updated_param_abs(worst tensor)'] = worst
+        rec['updated_param_worst_tensor'] = worst_k
+        out[f'K{K}/{mode}'] = rec
+out['_tolerances_of_the_exact_mode_tests'] = {'loss_rel': 1e-5, 'gnorm_rel': 1e-4, 'latent': 'rtol 1e-4 + atol 2e-6', 'updated_param': 'rtol 1e-4 + atol 2e-5'}
+print(json.dumps(out, indent=1))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """The x3 f32 recurrence kernels alone at the headline shape (R = 24, H = 128; B rows): forward with gx from HBM (decoder), forward with the narrow
-input projected in the kernel (encoder), backward.  usage: python3 scripts/x3_rec_bench.py [B]"""
+input projected in the kernel (encoder), backward.  usage: python3 scripts/x3_rec_bench.py [B]
+With DIC_AB_LIB=<second libdic_hip.so> (scripts/two_lib_build.sh) both builds are timed alternately in this one process (boxes drift by several per cent)."""
+import ctypes as C
 import os
 import sys
 
@@ -11,6 +13,14 @@ import bench  # noqa: E402
 from deep_interpolation_clustering_amd import _native as N  # noqa: E402
 
 L, P = N.lib(), N.ptr
+LIBS = [('this build', L)]
+if os.environ.get('DIC_AB_LIB'):
+    LB = C.CDLL(os.path.abspath(os.environ['DIC_AB_LIB']))
+    for name, (res, args) in N.SIGNATURES.items():
+        if hasattr(LB, name):
+            fn = getattr(LB, name)
+            fn.restype, fn.argtypes = res, args
+    LIBS.append(('DIC_AB_LIB', LB))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 R, H = 24, 128
 dev = 'cuda'
@@ -35,22 +45,26 @@ ws = torch.empty(max(16, L.dic_lstm_rec_bwd_workspace(B)), device=dev, dtype=tor
 st = N.stream_of(gx)
 
 
-def fwd():
+def fwd(L=L):
     N.check(L.dic_lstm_rec_fwd(N.DTYPE_F32X3, P(gx), P(whh), None, None, R, B, H, P(out), P(hn), P(cn), P(gates), P(cs), 3, st), 'fwd')
 
 
-def fwd_proj():
+def fwd_proj(L=L):
     N.check(L.dic_lstm_rec_fwd_proj_x3(P(x), P(wih), 20, P(whh), None, None, R, B, H, P(out), P(hn), P(cn), P(gates), P(cs), 3, st), 'fwd_proj')
 
 
-def bwd():
+def bwd(L=L):
     N.check(L.dic_lstm_rec_bwd(N.DTYPE_F32X3, P(whh_t), 1, P(gates), P(cs), P(dout), None, None, R, B, H, P(dgx), P(dh0), P(dc0), P(dbias), P(ws), ws.numel(), 1, 1, st), 'bwd')
 
 
 rows = R * B * 2
 for name, fn, nbytes in (('rec_fwd8x3 (gx in)', fwd, rows * (2048 + 2048 + 512 + 512)), ('rec_fwd8x3 (proj)', fwd_proj, rows * (2048 + 512 + 512) + R * B * 80),
                          ('rec_bwd8x3', bwd, rows * (2048 + 512 + 512 + 2048))):
-    fn()
-    torch.cuda.synchronize()
-    ms = bench.time_kernel(fn, 10)
-    print('%-22s %8.1f us   %.2f TB/s algorithmic (%.2f GB)   %.3f of the 8 TB/s peak' % (name, ms * 1e3, nbytes / ms / 1e9, nbytes / 1e9, nbytes / ms / 1e9 / 8.0), flush=True)
+    for rnd in range(3 if len(LIBS) > 1 else 1):
+        for tag, lib in LIBS:
+            f = (lambda lib=lib: fn(lib))
+            f()
+            torch.cuda.synchronize()
+            ms = bench.time_kernel(f, 10)
+            print('%-22s %-12s %8.1f us   %.2f TB/s algorithmic (%.2f GB)   %.3f of the 8 TB/s peak' % (name, tag, ms * 1e3, nbytes / ms / 1e9, nbytes / 1e9, nbytes / ms / 1e9 / 8.0),
+                  flush=True)
