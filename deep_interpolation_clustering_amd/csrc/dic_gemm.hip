@@ -553,15 +553,24 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
 
     // x pieces: piece p = tid + NT j of a tile: row p / 32, floats 8 (p % 32) .. + 7
     gf32x4 px[PPT][2];
+    // hand-issued loads (asm: the compiler neither counts nor waits for them): the wait in front of `land` is OURS and counted -- the tile's output stores
+    // issued behind these loads stay in flight across it (the compiler's own wait for a plain load cannot know how many of the predicated stores went out and
+    // drains the queue: every tile then waits for the acknowledgement of the previous tile's stores)
     auto request = [&](int tile) {
         const long r0 = (long)tile * XT;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const int p = tid + NT * j;
             const float* src = a.x + (size_t)min(r0 + (p >> 5), N - 1) * XK + (p & 31) * 8;
-            px[j][0] = *reinterpret_cast<const gf32x4*>(src);
-            px[j][1] = *reinterpret_cast<const gf32x4*>(src + 4);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(px[j][0]) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(px[j][1]) : "v"(src) : "memory");
         }
+    };
+    auto arrived = [&](bool counted) {      // the 2 PPT loads of the last `request` have landed; `counted`: exactly 16 stores were issued behind them
+        if (counted) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) { asm volatile("" : "+v"(px[j][0])); asm volatile("" : "+v"(px[j][1])); }
     };
     auto land = [&](int slot) {
         unsigned char* base = xsm + slot * 2 * XIMG;
@@ -585,10 +594,11 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
     const int a_off = (lane & 31) * XPITCH + hh * 16;          // A operand: row (lane & 31), 16-B piece 2 ks + hh
 
     int tile = blockIdx.x;
-    if (tile < ntiles) { request(tile); land(0); }
+    if (tile < ntiles) { request(tile); arrived(false); land(0); }
     if (tile + nch < ntiles) request(tile + nch);
     __syncthreads();
     int slot = 0;
+    bool stored16 = false;                  // the previous iteration issued all of its 16 stores (a full tile, all columns inside) behind the loads in flight
     for (; tile < ntiles; tile += nch) {
         const unsigned char* base = xsm + slot * 2 * XIMG;
         gf32x16 acc;
@@ -602,18 +612,32 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, whi[ks], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wlo[ks], acc, 0, 0, 0);
         }
-        if (tile + nch < ntiles) land(slot ^ 1);               // (the other slot was read in the previous iteration: everybody is past its barrier)
+        if (tile + nch < ntiles) { arrived(stored16); land(slot ^ 1); }      // (the other slot was read in the previous iteration: everybody is past its barrier)
         if (tile + 2 * nch < ntiles) request(tile + 2 * nch);
         // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         const long r0 = (long)tile * XT;
-        if (ncol < a.Nout) {
+        const bool full = r0 + XT <= N && n0 + NCOLS <= a.Nout;          // (workgroup-uniform)
+        if (full) {                                                       // 16 unconditional stores: what the counted wait of the next iteration counts
+            float* o = a.out + (size_t)(r0 + 4 * hh) * a.Nout + ncol;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float* dst = o + (size_t)((k & 3) + 8 * (k >> 2)) * a.Nout;
+                asm volatile("global_store_dword %0, %1, off" :: "v"(dst), "v"(acc[k]) : "memory");
+            }
+        } else if (ncol < a.Nout) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const long m = r0 + (k & 3) + 8 * (k >> 2) + 4 * hh;
                 if (m < N) a.out[(size_t)m * a.Nout + ncol] = acc[k];
             }
         }
-        __syncthreads();
+        stored16 = full;
+        // LDS-only barrier (round 6): __syncthreads() carries s_waitcnt vmcnt(0), i.e. every tile waited for the acknowledgement of its own 16 output stores
+        // per wave (and for the next tile's loads) before the next tile's MFMAs could start -- SQ_WAIT_INST_ANY 0.50, matrix cores 41 % busy.  What the
+        // barrier orders is the LDS slot hand-over only; the loads are waited for where `land` consumes them (a counted wait: the stores behind them fly on)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         slot ^= 1;
     }
 }
