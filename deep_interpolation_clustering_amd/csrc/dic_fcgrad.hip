@@ -252,7 +252,11 @@ __global__ __launch_bounds__(512) void fc_bwd_kernel(FcBwdArgs a) {
                 *reinterpret_cast<unsigned*>(sdst + m * FS_PITCH) = pk;
             }
         }
-        __syncthreads();
+        // LDS-only barrier (round 6): __syncthreads() carries s_waitcnt vmcnt(0) -- every 32-row tile then waited out the full latency of the loads `request`
+        // had just issued (they are consumed a whole tile later, in `land`, where the compiler's own wait stands) and of the previous tile's row stores
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         store_rows(slot, (long)tile * FT);
         slot ^= 1;
     }

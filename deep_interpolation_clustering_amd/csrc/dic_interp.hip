@@ -23,7 +23,7 @@
 namespace dic {
 
 struct InterpLayout {   // LDS carve-up, identical on host and device
-    int cnt, order, rank, roff, alpha, refg, kmat, res, mean, lse, amat, obs;   // offsets in 4-byte words
+    int cnt, order, roff, alpha, refg, kmat, res, mean, lse, amat, obs;   // offsets in 4-byte words
     int stride;                                              // float2 elements per staged row
     int total_words;
 };
@@ -32,10 +32,11 @@ constexpr int kMaxSplit = 16;
 
 // Row stride of the staged (t,v) rows: room for the tail padding of the unrolled loops, and ODD so that
 // the 2-4 rows one wave touches per ds_read_b64 fall on different LDS banks (768-B rows all hit bank 0).
-// (Round 6: that holds for rows at NEIGHBOURING positions only -- two rows 32 positions apart share their banks again (2 dwords x odd stride x 32 = 0 mod 64
-// banks) -- and since round 4 a wave visits rows in LENGTH order, i.e. rows from anywhere in the tile: one ds_read_b64 in eight was served in two passes
-// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.125).  The rows are therefore staged at their position in the length order: the rows of a
-// wave are 2-4 consecutive positions again.)
+// (Round 6, VERDICT r5 #6: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.125 here has ONE source -- since round 4 a wave visits rows in LENGTH order, i.e.
+// rows from anywhere in the tile, and two rows 32 positions apart share their banks again (2 dwords x odd stride x 32 = 0 mod 64 banks).  Staging the rows
+// AT their position in the length order (a rank array + one more barrier) makes a wave's rows neighbours again; same-box A/B, both libraries alternately:
+// 192-193 -> 196-199 us at configs[1], 292 -> 302 us at configs[3] -- slower, not kept: the kernel is bound by vector issue, the doubled LDS passes were
+// not on its chain.)
 __host__ __device__ inline int interp_row_stride(int Tcap) { return (Tcap + kMaxSplit) | 1; }
 
 __host__ __device__ inline InterpLayout interp_layout(int E, int C, int R, int Tcap) {
@@ -43,7 +44,6 @@ __host__ __device__ inline InterpLayout interp_layout(int E, int C, int R, int T
     int o = 0;
     L.cnt = o;   o += E * C + 1;   // +1: tile maximum
     L.order = o; o += E * C;       // the tile's rows sorted by length (k1 forward: a wave's items then span rows of nearly equal length)
-    L.rank = o;  o += E * C;       // ... and each row's position in that order: rows are STAGED in length order (sci_cci_fwd_kernel, phase 2)
     o = (o + 1) & ~1;
     L.roff = o;  o += 2 * E * C;   // int64 offset of each row in the packed arrays of a ragged store
     L.alpha = o; o += C;
@@ -148,7 +148,6 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
     const int stride = L.stride;
     int* cnt = reinterpret_cast<int*>(smem + L.cnt);
     int* order = reinterpret_cast<int*>(smem + L.order);
-    int* rank_of = reinterpret_cast<int*>(smem + L.rank);
     int64_t* roff = reinterpret_cast<int64_t*>(smem + L.roff);
     float* alpha = smem + L.alpha;
     float* refg = smem + L.refg;
@@ -195,9 +194,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
             rank += (cj < ci || (cj == ci && j < i)) ? 1 : 0;
         }
         order[rank] = i;
-        rank_of[i] = rank;                       // row i is staged at position `rank` (phase 2), where the item loop looks for it (phase 3)
     }
-    __syncthreads();
 
     K1_STAMP(1);
     // ---- 2. stage (time,value) rows into LDS: one wave per 64-slot chunk of a row, 4 chunks in flight per
@@ -226,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
                     tt[k] = a.t_pk[off];
                     vv[k] = a.v_pk[off];
                     if (a.hold_pk) vv[k] *= (float)a.hold_pk[off];          // denoising step: held-out samples enter as 0 (pretrain_trainer.py:139-141)
-                    dst[k] = (u0 + k < units && i < npad) ? rank_of[row] * stride + i : -1;
+                    dst[k] = (u0 + k < units && i < npad) ? row * stride + i : -1;
                     valid[k] = i < n;
                 }
 #pragma unroll
@@ -250,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
                     const int ic = min(i, a.T - 1);
                     tt[k] = base[(size_t)(2 * C + c) * a.T + ic];
                     vv[k] = base[(size_t)c * a.T + ic];
-                    dst[k] = (u0 + k < units && i < npad) ? rank_of[row] * stride + i : -1;
+                    dst[k] = (u0 + k < units && i < npad) ? row * stride + i : -1;
                     valid[k] = i < cnt[row];
                 }
 #pragma unroll
@@ -270,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
                     const int row = u / nchunk;
                     const int i = (u - row * nchunk) * kWave + lane;
                     if (i < npad) {
-                        dst[k] = rank_of[row] * stride + i;
+                        dst[k] = row * stride + i;
                         if (i < cnt[row]) {
                             {
                                 const int e = row / C, c = row - e * C;
@@ -303,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
         const int pos = q / R, r = q - pos * R;
         const int row = order[pos];                              // (rows are visited in length order)
         const int e = row / C, c = row - e * C;
-        const float2* p = obs + pos * stride + s;                 // (staged at its position in the length order)
+        const float2* p = obs + row * stride + s;
         const float ref = refg[r];
         const float al = alpha[c];
         // wave-uniform trip count: the longest row any lane of this wave works on.  The wave's 64 items are consecutive, i.e. a
@@ -327,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void sci_cci_fwd_kernel(InterpArgs a) {
         if (a.sorted_t) {
             // sorted time stamps (the ragged store certifies them): the nearest sample is a neighbour of the insertion point of the grid point --
             // ~log2 n LDS reads instead of a pass over the row (|t - ref| falls, then rises: the exact same minimum, rounding included)
-            const float2* prow = obs + pos * stride;
+            const float2* prow = obs + row * stride;
             const int n = cnt[row];
             int lo = 0, hi = n;
             while (lo < hi) {

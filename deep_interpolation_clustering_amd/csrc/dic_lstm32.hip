@@ -1300,12 +1300,13 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_fwd8x3_kernel(RecFwdArgs<floa
 // store per element) is gone.  Half of W_hh^T's lo fragments live in the LDS that frees (the register file is full at two waves per SIMD: 128 registers of
 // weights + 48 of prefetched state).  The next step's saved gates / cell states / dL/dout are requested BEFORE the product of the current one (the four-wave
 // kernel had no registers for that: four exposed round trips per step).
-constexpr int BX_LDSK = 12;                      // k-steps (of 16) whose lo fragments of W_hh^T are read from LDS instead of held in registers
+// (Round 6 A/B, not kept: the images at a 1 024-B pitch with lstm_bwd8_kernel's XOR swizzle -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE is 0.45 at this padded
+// pitch: row 12 of one k-group meets row 11 of the next in every 16-lane group of a fragment read, rows r and r + 16 share banks in every 8-B store -- needs
+// four more per-lane offsets, i.e. 12 instead of 8 lo fragments in LDS to stay spill-free, and runs 1 636-1 649 us against 1 614-1 625 us for this form, both
+// builds timed alternately on one box: as in lstm_bwd8_kernel, the conflict cycles are not on the chain.)
+constexpr int BX_LDSK = 8;                       // k-steps (of 16) whose lo fragments of W_hh^T are read from LDS instead of held in registers
 __global__ __launch_bounds__(512, 1) void lstm_rec_bwd8x3_kernel(RecBwdArgs<float> a) {
-    // Image rows at a 1 024-B pitch, XOR-swizzled (as lstm_bwd8_kernel's dG tile, dic_lstm.hip): the 16-B piece q of row n sits at q ^ (n & 15) and rows 16-31
-    // keep the two 8-B halves of every piece swapped.  At the padded 1 040-B pitch of the four-wave kernels row 12 of one k-group met row 11 of the next in every
-    // 16-lane group of a fragment read, and rows r, r + 16 shared their banks in every 8-B store: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.45 (round 6).
-    constexpr int GPB = S4;                               // 512 bf16 per row of an image
+    constexpr int GPB = RecX3::PITCH(S4);                 // 520 bf16 per row of an image
     constexpr int NKS = S4 / 32, NREG = NKS - BX_LDSK;
     extern __shared__ __align__(16) unsigned char rsm[];
     __bf16* dgh = reinterpret_cast<__bf16*>(rsm);         // [32][GPB] hi image, then the lo image: the MFMA operands AND what leaves for global memory
@@ -1385,6 +1386,7 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_bwd8x3_kernel(RecBwdArgs<floa
         const int t = dir ? step : R - 1 - step;
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
+            const int u = 16 * w8 + 8 * qq + 4 * hh;
             const StepQ cur = qq == 0 ? in0 : in1;          // (a copy: the registers are refilled below)
             sf32x4 di, df, dg, dO;
 #pragma unroll
@@ -1401,31 +1403,25 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_bwd8x3_kernel(RecBwdArgs<floa
                 dc[k] = dct * fg;
                 ccar[k] = cp;
             }
-            // element u of gate g: piece (u >> 3) + 16 g, half hh -> piece ^ (r & 15), half ^ (r >> 4)
-            const int pc = 2 * w8 + qq, hf = (hh ^ (r >> 4)) * 4, rx = r & 15;
-            // (pc < 16 and r & 15 < 16: the XOR touches the low four bits only, the gate's 16 pieces are an immediate offset)
-            const int o0 = r * GPB + ((pc ^ rx) * 8) + hf, o1 = o0 + SH, o2 = o0 + 2 * SH, o3 = o0 + 3 * SH;
-            RecX3::store4(dgh + o0, dgl + o0, di);
-            RecX3::store4(dgh + o1, dgl + o1, df);
-            RecX3::store4(dgh + o2, dgl + o2, dg);
-            RecX3::store4(dgh + o3, dgl + o3, dO);
+            const int o = r * GPB + u;
+            RecX3::store4(dgh + o, dgl + o, di);
+            RecX3::store4(dgh + o + SH, dgl + o + SH, df);
+            RecX3::store4(dgh + o + 2 * SH, dgl + o + 2 * SH, dg);
+            RecX3::store4(dgh + o + 3 * SH, dgl + o + 3 * SH, dO);
             // this group's inputs of the NEXT step, into the registers just consumed: in flight across the rest of the gate arithmetic, the barrier and the product
             if (step + 1 < R) load_q(step + 1, qq, qq == 0 ? in0 : in1);
         }
         lds_barrier();                                     // the dG tile of this step is complete
         // dh_prev[unit][batch] = sum_n W_hh[n][unit] dG[batch][n]: two batch blocks (rows n16, 16 + n16) x 16 k-steps of 32 gate columns x (hi.hi + lo.hi + hi.lo)
         sf32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        // logical piece 4 ks + g4 of rows n16 / 16 + n16 sits at ((4 ks + g4) ^ n16) = 4 ((ks >> 2) << 2 | ((ks & 3) ^ (n16 >> 2))) + (g4 ^ (n16 & 3)): FOUR per-lane
-        // offsets (one per ks & 3); k-group, batch block and image are immediate offsets of the read
-        auto swap_halves = [](sbf16x8 f) { return __builtin_shufflevector(f, f, 4, 5, 6, 7, 0, 1, 2, 3); };      // (rows 16-31: a register renaming)
-        const __bf16* bq[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bq[j] = dgh + n16 * GPB + (((j ^ (n16 >> 2)) * 4 + (g4 ^ (n16 & 3))) * 8);
+        const __bf16* b0h = dgh + n16 * GPB + 8 * g4;
+        const __bf16* b1h = dgh + (16 + n16) * GPB + 8 * g4;
+        const __bf16* b0l = b0h + SROWS * GPB;
+        const __bf16* b1l = b1h + SROWS * GPB;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            const __bf16* bp = bq[ks & 3] + (ks >> 2) * 128;
-            const sbf16x8 f0h = *reinterpret_cast<const sbf16x8*>(bp), f1h = swap_halves(*reinterpret_cast<const sbf16x8*>(bp + 16 * GPB));
-            const sbf16x8 f0l = *reinterpret_cast<const sbf16x8*>(bp + SROWS * GPB), f1l = swap_halves(*reinterpret_cast<const sbf16x8*>(bp + (SROWS + 16) * GPB));
+            const sbf16x8 f0h = *reinterpret_cast<const sbf16x8*>(b0h + ks * 32), f1h = *reinterpret_cast<const sbf16x8*>(b1h + ks * 32);
+            const sbf16x8 f0l = *reinterpret_cast<const sbf16x8*>(b0l + ks * 32), f1l = *reinterpret_cast<const sbf16x8*>(b1l + ks * 32);
             const sbf16x8 wl = ks < NREG ? wtl[ks < NREG ? ks : 0] : wl_mine[(ks - NREG) * 64];
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wth[ks], f0h, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wth[ks], f1h, acc1, 0, 0, 0);
@@ -1435,8 +1431,7 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_bwd8x3_kernel(RecBwdArgs<floa
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wth[ks], f1l, acc1, 0, 0, 0);
             if (ks & 1) {                                  // one of this wave's eight 1-KiB rows of its image: LDS -> its plane in global memory + bias column sums
                 const int rowl = (ks >> 1) * 4 + w4;
-                uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(img + rowl * GPB) + ((lane ^ (rowl & 15)) * 16));      // logical piece `lane`
-                if (rowl >= 16) v = make_uint4(v.z, v.w, v.x, v.y);
+                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(img + rowl * GPB) + lane * 16);
                 if (b0 + rowl < B)
                     *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(plane + (((size_t)t * B + b0 + rowl) * 2 + dir) * S4) + lane * 16) = v;
                 const sbf16x8 x = __builtin_bit_cast(sbf16x8, v);
@@ -1887,7 +1882,7 @@ static int rec_bwd(const void* whh, int transposed, const void* gates, const voi
         }
     }
     if constexpr (X3) {
-        const size_t lds = (size_t)2 * SROWS * S4 * sizeof(__bf16) + (size_t)8 * BX_LDSK * 64 * 16;      // the two images (1 024-B rows) + the W_hh^T lo fragments kept in LDS
+        const size_t lds = (size_t)2 * SROWS * RecX3::PITCH(S4) * sizeof(__bf16) + (size_t)8 * BX_LDSK * 64 * 16;      // the two images + the W_hh^T lo fragments kept in LDS
         static bool attrx_set = false;
         if (!attrx_set) {
             hipError_t e = hipFuncSetAttribute((const void*)lstm_rec_bwd8x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

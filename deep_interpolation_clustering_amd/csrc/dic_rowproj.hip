@@ -137,7 +137,9 @@ __global__ __launch_bounds__(NW * 64, 2) void row_proj_kernel(RowProjArgs a) {
             *reinterpret_cast<pbf16x8*>(a.out + o * 8) = lo;
             *reinterpret_cast<pbf16x8*>(a.out + (o + 2 * 32) * 8) = hi;
 #endif
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // (LDS-only, round 6: __syncthreads() also drains the vector-memory queue -- the loads just requested, the stores just issued)
+            asm volatile("" ::: "memory");
             slot ^= 1;
             continue;
         }
@@ -157,7 +159,9 @@ __global__ __launch_bounds__(NW * 64, 2) void row_proj_kernel(RowProjArgs a) {
             }
         }
         if (STATS) { s1 += (double)t1; s2 += (double)t2; }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // (LDS-only, round 6: see above)
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int k = 0; k < PT * (NCOLS / 8) / NT; ++k) {
             const int p = tid + NT * k, row = p / (NCOLS / 8), pc = p % (NCOLS / 8);

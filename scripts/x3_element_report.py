@@ -36,12 +36,12 @@ for K in (4, 8):
         losses, gnorm, z = st.step(x, ob, mask, mask.sum(-1).to(torch.int32))
         rec = {}
         for k in ('loss', 'ae_mse', 'kl'):
-            rec['loss_rel/' + k] = abs(float(losses[k]) - float(g['loss_' + k])) / abs(float(g['loss_' + k]))
+            rec['loss_rel/' + k] = abs(float(losses[k].detach()) - float(g['loss_' + k])) / abs(float(g['loss_' + k]))
         rec['gnorm_rel'] = abs(float(gnorm) - float(g['gnorm'])) / float(g['gnorm'])
         zz = z.detach().cpu().numpy()
         rec['latent_abs'] = float(np.abs(zz - g['z']).max())
         rec['latent_rel_to_max'] = rec['latent_abs'] / float(np.abs(g['z']).max())
-        q = net.cluster_assignment(z.detach()).cpu().numpy()
+        q = net.cluster_assignment(z.detach()).detach().cpu().numpy()
         rec['q_abs'] = float(np.abs(q - g['q']).max())
         rec['argmax_q_equal'] = bool((q.argmax(1) == g['q'].argmax(1)).all())
         worst, worst_k = 0.0, None
