@@ -637,7 +637,8 @@ def test_f32_recurrence_matches_nn_lstm(R, B, I, init, bm):
 
 @pytest.mark.parametrize('R,B,I,init,bm,proj', [(24, 200, 18, False, False, True), (24, 200, 18, True, True, False), (24, 96, 256, True, True, True),
                                                   (5, 1, 256, True, False, True), (3, 130, 28, True, True, True), (2, 33, 1, False, False, True),
-                                                  (1, 4099, 18, True, True, True), (6, 65, 36, False, True, True)])
+                                                  (1, 4099, 18, True, True, True), (6, 65, 36, False, True, True),
+                                                  (24, 200, 18, True, True, 'generic'), (24, 96, 256, True, False, 'generic')])
 def test_x3_recurrence_matches_nn_lstm(R, B, I, init, bm, proj, monkeypatch):
     """The x3 recurrence kernels of round 6 (csrc/dic_lstm32.hip: lstm_rec_fwd8x3 / lstm_rec_bwd8x3 -- eight waves per 32-row tile, every product hi.hi + lo.hi
     + hi.lo on the bf16 matrix cores, gate non-linearities on the transcendental unit, the narrow encoder input projected INSIDE the kernel, gate gradients
@@ -645,7 +646,10 @@ def test_x3_recurrence_matches_nn_lstm(R, B, I, init, bm, proj, monkeypatch):
     2^-17-per-product accuracy of the split -- ragged last tiles, R = 1, one row, with / without initial states, the in-kernel projection on and off (I = 36
     does not fit its 32 columns: the gx path), the wide decoder input."""
     from deep_interpolation_clustering_amd import lstm as L, ops
-    monkeypatch.setattr(L, 'X3_REC_PROJ', proj)
+    monkeypatch.setattr(L, 'X3_REC_PROJ', bool(proj))
+    if proj == 'generic':          # the fallbacks behind DIC_X3_DW=0 / DIC_X3_DX_TILE=0: dic_gemm_tn_planes / dic_gemm_nt_planes on the split planes of dG
+        monkeypatch.setattr(L, 'X3_DW', False)
+        monkeypatch.setattr(L, 'X3_DX_TILE', False)
     torch.manual_seed(R * 100 + B)
     dev = torch.device('cuda')
     net = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True).to(dev)
