@@ -121,6 +121,8 @@ SIGNATURES = {
     'dic_x3_row_proj': (_i, [_p, _p, _p, C.c_int64, _i, _i, _p, _i, _p]),
     'dic_gemm_tn_workspace': (_sz, [C.c_int64, _i, _i, _i]),
     'dic_gemm_tn': (_i, [_i, _p, C.c_int64, _p, C.c_int64, C.c_int64, _i, _i, _p, C.c_int64, _i, _p, C.c_int64, _i, _p, C.c_int64, _i, _i, _p, _sz, _p]),
+    'dic_segment_sum_workspace': (_sz, [_i, _i]),
+    'dic_segment_sum_f64': (_i, [_p, C.c_int64, _p, _i, _i, _i, _p, _p, _sz, _p]),
     'dic_cumsum_f64': (_i, [_p, _i, _i, _p, _p]),
     'dic_kmeans_pp_workspace': (_sz, [_i, _i]),
     'dic_kmeans_pp_candidates': (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _sz, _p]),

@@ -36,11 +36,18 @@ def _encode(labels, device):
 
 
 def _segment_sum(values, lab, K):
-    """(K, ...) f64 sums of ``values`` rows per label: a one-hot f64 GEMM (rocBLAS dgemm on the matrix cores) -- index_add_ on
-    f64 is an atomic scatter that took 65 ms per call on 75 000 x 256 (4 s of the K sweep)."""
-    oh = torch.nn.functional.one_hot(lab, K).to(torch.float64).t()              # (K, N)
+    """(K, ...) f64 sums of ``values`` rows per label (``dic_segment_sum_f64``: private f64 sums per thread and cluster in LDS, fixed order -- until round 6 a
+    one-hot f64 GEMM through rocBLAS; index_add_ on f64 is an atomic scatter that took 65 ms per call on 75 000 x 256)."""
     v = values.double()
-    return oh @ v if v.dim() == 2 else (oh @ v[:, None])[:, 0]
+    one_d = v.dim() == 1
+    v2 = (v[:, None] if one_d else v).contiguous()
+    n, d = v2.shape
+    out = torch.empty((K, d), dtype=torch.float64, device=v2.device)
+    L = N.lib()
+    ws = torch.empty(max(16, L.dic_segment_sum_workspace(d, K)), dtype=torch.uint8, device=v2.device)
+    labc = lab.to(torch.int64).contiguous()
+    N.check(L.dic_segment_sum_f64(N.ptr(v2), v2.stride(0), N.ptr(labc), n, d, K, N.ptr(out), N.ptr(ws), ws.numel(), N.stream_of(v2)), 'dic_segment_sum_f64')
+    return out[:, 0] if one_d else out
 
 
 class PairStats:

@@ -156,6 +156,40 @@ __global__ __launch_bounds__(256) void pairdist_kernel(const float* __restrict__
     }
 }
 
+// Per-cluster f64 sums of the rows of an f64 matrix: out[k][c] = sum over rows i with lab[i] == k of v[i][c] -- the centroids of the Calinski-Harabasz / Davies-
+// Bouldin scores and the per-cluster distance sums of the gap statistic (internal_eval.py:112-147, p2_clustering_optK.py:334-351).  Until round 6 a one-hot f64
+// GEMM through rocBLAS (the last library GEMM of the K sweep).  grid (row chunks, 64-column blocks): thread (row phase rq, column c) owns private f64 sums for every
+// cluster in LDS ([4][K][64]: no atomics, fixed order), the four phases are added, one partial row block per workgroup; a second kernel adds the chunks in order.
+constexpr int SEG_CHUNKS = 64;
+__global__ __launch_bounds__(256) void segment_sum_kernel(const double* v, long ldv, const long long* lab, int N, int D, int K, double* part) {
+    extern __shared__ double seg_acc[];                       // [4][K][64]
+    const int tid = threadIdx.x, c = tid & 63, rq = tid >> 6;
+    const int col = blockIdx.y * 64 + c;
+    for (int i = tid; i < 4 * K * 64; i += 256) seg_acc[i] = 0.0;
+    __syncthreads();
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * per, r1 = min(N, r0 + per);
+    double* mine = seg_acc + (size_t)rq * K * 64 + c;
+    if (col < D)
+        for (int r = r0 + rq; r < r1; r += 4) {
+            const int k = (int)lab[r];
+            if (k >= 0 && k < K) mine[k * 64] += v[(size_t)r * ldv + col];
+        }
+    __syncthreads();
+    for (int i = tid; i < K * 64; i += 256) {
+        const int k = i >> 6, cc = i & 63;
+        if (blockIdx.y * 64 + cc < D)
+            part[((size_t)blockIdx.x * K + k) * D + blockIdx.y * 64 + cc] = (seg_acc[i] + seg_acc[K * 64 + i]) + (seg_acc[2 * K * 64 + i] + seg_acc[3 * K * 64 + i]);
+    }
+}
+__global__ __launch_bounds__(256) void segment_sum_finalize(const double* part, int nch, int n, double* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int ch = 0; ch < nch; ++ch) s += part[(size_t)ch * n + i];
+    out[i] = s;
+}
+
 }  // namespace dic
 
 using namespace dic;
@@ -181,6 +215,28 @@ int dic_cluster_intra_sums(const float* X, const int32_t* seg, int N, int D, int
     const int grid = (N + PT - 1) / PT;
     hipLaunchKernelGGL(pairdist_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, seg, N, D, K, S_own, (float*)nullptr, (float*)nullptr);
     return check_launch("cluster_intra_sums");
+}
+
+size_t dic_segment_sum_workspace(int D, int K) { return (D > 0 && K > 0) ? (size_t)SEG_CHUNKS * K * D * sizeof(double) : 0; }
+
+int dic_segment_sum_f64(const double* values, long ldv, const int64_t* labels, int N, int D, int K, double* out, void* workspace, size_t workspace_bytes,
+                        dic_stream_t stream) {
+    DIC_REQUIRE(N > 0 && D > 0 && K > 0 && ldv >= D, DIC_ERR_INVALID_ARG, "segment_sum_f64: N=%d D=%d K=%d ldv=%ld", N, D, K, ldv);
+    DIC_REQUIRE(K <= 64, DIC_ERR_UNSUPPORTED, "segment_sum_f64: K=%d > 64", K);
+    DIC_REQUIRE(values && labels && out && workspace, DIC_ERR_INVALID_ARG, "segment_sum_f64: NULL pointer");
+    DIC_REQUIRE(workspace_bytes >= dic_segment_sum_workspace(D, K), DIC_ERR_WORKSPACE, "segment_sum_f64: workspace %zu < %zu", workspace_bytes,
+                dic_segment_sum_workspace(D, K));
+    const size_t lds = (size_t)4 * K * 64 * sizeof(double);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)segment_sum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "segment_sum_f64: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+        lds_set = lds;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(SEG_CHUNKS, (D + 63) / 64), dim3(256), lds, st, values, ldv, (const long long*)labels, N, D, K, (double*)workspace);
+    hipLaunchKernelGGL(segment_sum_finalize, dim3((K * D + 255) / 256), dim3(256), 0, st, (const double*)workspace, SEG_CHUNKS, K * D, out);
+    return check_launch("segment_sum_f64");
 }
 
 }  // extern "C"

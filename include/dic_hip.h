@@ -514,6 +514,12 @@ int dic_cluster_pairdist(const float* X, const int32_t* seg, int N, int D, int K
  * 334-351: np.mean / np.sum of pairwise_distances(X[a == c]) per cluster): sum_c n_c^2 pairs instead of N^2.
  *   S_own (N) OVERWRITTEN: S_own[i] = sum over the points j of i's own cluster of ||x_i - x_j||  (rows sorted by cluster, as above). */
 int dic_cluster_intra_sums(const float* X, const int32_t* seg, int N, int D, int K, float* S_own, dic_stream_t stream);
+/* out (K, D) f64 = per-cluster sums of the rows of values (N, D) f64 at row stride ldv, labels (N) int64 in [0, K) (others are skipped): the centroids of
+ * scikit-learn's calinski_harabasz_score / davies_bouldin_score and the per-cluster distance sums of p2's gap statistic (internal_eval.py:112-147,
+ * p2_clustering_optK.py:334-351).  Deterministic (no atomics, fixed order).  workspace: dic_segment_sum_workspace(D, K) bytes.  K <= 64. */
+size_t dic_segment_sum_workspace(int D, int K);
+int dic_segment_sum_f64(const double* values, long ldv, const int64_t* labels, int N, int D, int K, double* out, void* workspace, size_t workspace_bytes,
+                        dic_stream_t stream);
 
 /* ------------------------------------------------------------- optimisation step tail ---------
  * clip_grad_norm_ scaling + torch.optim.Adam(amsgrad=True, L2 weight decay) (pretrain_trainer.py:228-229, utils.py:83)

@@ -128,3 +128,23 @@ def test_gap_table_equals_reference(tmp_path):
     assert pos == float(g['stream_pos']), 'the global stream was consumed differently'
     for j, c in enumerate(cols):
         np.testing.assert_allclose(df[c].to_numpy(), ref[:, j], rtol=1e-5, atol=1e-5 if c == 'gap' else 0, err_msg=c)   # gap = ref - act
+
+
+def test_segment_sum_matches_numpy():
+    """dic_segment_sum_f64 (the per-cluster f64 sums behind the centroid scores and the gap statistic's distance sums; round 6: no one-hot dgemm) against
+    NumPy: matrices and vectors, K up to 20, labels in file order, an empty cluster; deterministic run to run."""
+    from deep_interpolation_clustering_amd import cluster_stats
+    rng = np.random.default_rng(3)
+    for n, d, K in ((75000, 256, 20), (1001, 7, 3), (64, 1, 2), (5000, 256, 1)):
+        lab = rng.integers(0, K, n)
+        if K > 2:
+            lab[lab == 1] = 0                                   # cluster 1 stays empty
+        v = rng.normal(size=(n, d))
+        ref = np.zeros((K, d))
+        np.add.at(ref, lab, v)
+        vt, lt = torch.tensor(v, device='cuda'), torch.tensor(lab, device='cuda')
+        got = cluster_stats._segment_sum(vt, lt, K)
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-12, atol=1e-10)
+        assert torch.equal(got, cluster_stats._segment_sum(vt, lt, K))
+        g1 = cluster_stats._segment_sum(vt[:, 0], lt, K)
+        np.testing.assert_allclose(g1.cpu().numpy(), ref[:, 0], rtol=1e-12, atol=1e-10)
