@@ -54,19 +54,66 @@ class PairStats:
     """Result of one pair pass: ``labels`` (N) encoded 0..K-1, ``counts`` (K), ``S`` / ``Dmin`` (N,K) f32 and ``own_max`` (N),
     all in the caller's row order."""
 
-    def __init__(self, labels, counts, S, Dmin, own_max, S_own=None):
-        self.labels, self.counts, self.S, self.Dmin, self.own_max, self.S_own = labels, counts, S, Dmin, own_max, S_own
+    def __init__(self, labels, counts, S, Dmin, own_max, S_own=None, totals=None):
+        self.labels, self.counts, self.S, self.Dmin, self.own_max, self.S_own, self.totals = labels, counts, S, Dmin, own_max, S_own, totals
         self.K = int(counts.numel())
 
     def intra_sums(self):
         """(K,) f64: sum over ordered pairs (i, j) of one cluster of ||x_i - x_j||  (= np.sum(pairwise_distances(X_c)))."""
+        if self.totals is not None:
+            return self.totals
         own = (self.S_own if self.S is None else self.S.gather(1, self.labels[:, None])[:, 0]).double()
         return _segment_sum(own, self.labels, self.K)
 
 
+TOTALS_MAX_D = 256          # dic_cluster_intra_totals: augmented rows of 256 coordinates
+
+
+def _tile_list(counts_host):
+    """(ntiles, 4) int32 for ``dic_cluster_intra_totals``: every pair of 256-row blocks I <= J of one cluster, sorted by cluster."""
+    out, start = [], 0
+    for c, n_c in enumerate(int(v) for v in counts_host):
+        nb = -(-n_c // 256)
+        if nb:
+            bi, bj = np.triu_indices(nb)
+            t = np.empty((bi.size, 4), np.int32)
+            t[:, 0], t[:, 1], t[:, 2], t[:, 3] = start + 256 * bi, start + 256 * bj, start + n_c, c
+            out.append(t)
+        start += n_c
+    return np.concatenate(out) if out else np.zeros((0, 4), np.int32)
+
+
+def intra_totals(x, labels):
+    """PairStats with only ``totals`` (K,) f64 = np.sum(pairwise_distances(X[a == c])) per cluster (``dic_cluster_intra_totals``: the distances of a cluster's block
+    pairs I <= J on the matrix cores) -- all the two inertia definitions of the gap statistic need (p2_clustering_optK.py:334-351)."""
+    x = _device_points(x)
+    n, d = x.shape
+    lab, K = _encode(labels, x.device)
+    if lab.numel() != n:
+        raise ValueError('labels: %d entries for %d points' % (lab.numel(), n))
+    if d > TOTALS_MAX_D:
+        return pair_stats(x, lab, intra_only=True)
+    if d % 4:
+        x = torch.nn.functional.pad(x, (0, 4 - d % 4))
+        d = x.shape[1]
+    order = torch.argsort(lab, stable=True)
+    xs = x[order].contiguous()
+    counts = torch.bincount(lab, minlength=K)
+    seg = torch.zeros(K + 1, dtype=torch.int32, device=x.device)
+    seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    centres = (_segment_sum(xs, lab[order], K) / counts.double().clamp(min=1)[:, None]).float().contiguous()
+    tiles = torch.from_numpy(_tile_list(counts.cpu().numpy())).to(x.device)
+    L = N.lib()
+    ws = torch.empty(L.dic_cluster_intra_totals_workspace(n, K), dtype=torch.uint8, device=x.device)
+    totals = torch.empty(K, dtype=torch.float64, device=x.device)
+    N.check(L.dic_cluster_intra_totals(N.ptr(xs), xs.stride(0), N.ptr(seg), N.ptr(centres), n, d, K, N.ptr(tiles) if tiles.numel() else None, tiles.shape[0],
+                                       N.ptr(totals), N.ptr(ws), ws.numel(), N.stream_of(xs)), 'dic_cluster_intra_totals')
+    return PairStats(lab, counts, None, None, None, None, totals)
+
+
 def pair_stats(x, labels, need_min=True, need_max=True, intra_only=False):
-    """``intra_only``: only the pairs inside a cluster (``dic_cluster_intra_sums``: sum_c n_c^2 of the N^2 pairs) -- what the two inertia
-    definitions of the gap statistic need; ``S`` / ``Dmin`` / ``own_max`` are then None and ``S_own`` (N) holds each point's own-cluster sum."""
+    """``intra_only``: only the pairs inside a cluster (``dic_cluster_intra_sums``: sum_c n_c^2 of the N^2 pairs); ``S`` / ``Dmin`` / ``own_max`` are then None and
+    ``S_own`` (N) holds each point's own-cluster sum.  (The gap statistic's inertias need only the per-cluster totals: ``intra_totals``.)"""
     x = _device_points(x)
     n, d = x.shape
     lab, K = _encode(labels, x.device)
@@ -104,14 +151,14 @@ def pair_stats(x, labels, need_min=True, need_max=True, intra_only=False):
 # ---------------------------------------------------------------------------- gap-statistic inertia (p2:334-351)
 def inertia_v1(x, labels, stats=None):
     """np.mean([np.mean(pairwise_distances(X[a == c])) for c in unique(a)])  (p2:334-342)."""
-    st = stats or pair_stats(x, labels, intra_only=True)
+    st = stats or intra_totals(x, labels)
     n = st.counts.double()
     return float((st.intra_sums() / (n * n)).mean())
 
 
 def inertia_v2(x, labels, stats=None):
     """sum_c sum(pairwise_distances(X[a == c])) / (2 n_c)  (p2:344-351)."""
-    st = stats or pair_stats(x, labels, intra_only=True)
+    st = stats or intra_totals(x, labels)
     return float((st.intra_sums() / (2.0 * st.counts.double())).sum())
 
 

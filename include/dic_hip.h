@@ -514,6 +514,16 @@ int dic_cluster_pairdist(const float* X, const int32_t* seg, int N, int D, int K
  * 334-351: np.mean / np.sum of pairwise_distances(X[a == c]) per cluster): sum_c n_c^2 pairs instead of N^2.
  *   S_own (N) OVERWRITTEN: S_own[i] = sum over the points j of i's own cluster of ||x_i - x_j||  (rows sorted by cluster, as above). */
 int dic_cluster_intra_sums(const float* X, const int32_t* seg, int N, int D, int K, float* S_own, dic_stream_t stream);
+/* The per-cluster TOTALS of that pass on the matrix cores (round 6):  totals[c] (K) f64 OVERWRITTEN = sum over the ordered pairs (i, j) of cluster c of
+ * ||x_i - x_j|| = np.sum(pairwise_distances(X[a == c])) (p2_clustering_optK.py:334-351) -- all the inertia of a gap-statistic reference set needs.  d^2 =
+ * ||x_i||^2 + ||x_j||^2 - 2 x_i . x_j with x taken relative to centres[c] (K, D) f32 (any point near the cluster: its centroid) as ONE bf16 MFMA inner product of
+ * augmented rows, every coordinate as hi + lo bf16 with the three leading partial products (the norms enter exactly): within 2e-7 of the f64 sum on the golden
+ * clusterings.  X (N, D) f32 at row stride ldx, rows sorted by cluster as above, D <= 256, D % 4 == 0.  tiles (ntiles, 4) int32 on the device, sorted by
+ * cluster: (first row of I, first row of J, end row of the cluster, cluster) for every pair of 256-row blocks I <= J of one cluster (block b of cluster c starts
+ * at seg[c] + 256 b).  Only these pairs are visited (sum_c n_c^2 / 2 of the N^2).  Deterministic.  workspace: dic_cluster_intra_totals_workspace(N, K) bytes. */
+size_t dic_cluster_intra_totals_workspace(int64_t N, int K);
+int dic_cluster_intra_totals(const float* X, long ldx, const int32_t* seg, const float* centres, int64_t N, int D, int K, const int32_t* tiles, int ntiles,
+                             double* totals, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 /* out (K, D) f64 = per-cluster sums of the rows of values (N, D) f64 at row stride ldv, labels (N) int64 in [0, K) (others are skipped): the centroids of
  * scikit-learn's calinski_harabasz_score / davies_bouldin_score and the per-cluster distance sums of p2's gap statistic (internal_eval.py:112-147,
  * p2_clustering_optK.py:334-351).  Deterministic (no atomics, fixed order).  workspace: dic_segment_sum_workspace(D, K) bytes.  K <= 64. */

@@ -109,6 +109,37 @@ def test_intra_only_pass_equals_own_column_of_the_full_pass(cs, n, d, k):
     assert intra.S is None and torch.equal(intra.intra_sums(), full.intra_sums())
 
 
+@pytest.mark.parametrize('n,d,k,spread', [(63, 4, 2, 1.0), (700, 36, 3, 1.0), (3000, 256, 7, 1.0), (1537, 20, 64, 1.0), (5000, 256, 1, 1.0), (2600, 256, 2, 30.0),
+                                          (20000, 256, 4, 1.0), (513, 255, 2, 1.0)])
+def test_intra_totals_on_the_matrix_cores_match_f64(cs, n, d, k, spread):
+    """dic_cluster_intra_totals (centred hi / lo bf16 planes, norms folded into the MFMA inner product, block pairs I <= J only): every cluster's sum of pairwise
+    distances against the f64 sum of the same pairs, for clusters smaller than a block, cluster ends inside a block, a singleton cluster, a width that needs
+    zero-padding, and clusters far from the origin (``spread``: the norm form's cancellation is what the centring removes).  Measured <= 2e-7; the reference sums
+    f32 distances (tests of the golden tables: rtol 1e-5).  Same result on a second call (no atomics)."""
+    rng = np.random.default_rng(n + d + k)
+    lab = rng.integers(0, k, n)
+    lab[:k] = np.arange(k)
+    if k > 3:
+        lab[lab == k - 1] = 0
+        lab[k - 1] = k - 1                       # a singleton cluster
+    x = (rng.normal(0, 1, (n, d)) + spread * rng.normal(0, 1, (k, d))[lab]).astype(np.float32)
+    st = cs.intra_totals(x, lab)
+    assert st.S is None and st.S_own is None
+    got = st.intra_sums().cpu().numpy()
+    xd = torch.as_tensor(x, device='cuda', dtype=torch.float64)
+    want = np.zeros(k)
+    for c in range(k):
+        xc = xd[torch.as_tensor(lab == c, device='cuda')]
+        for lo in range(0, xc.shape[0], 128):          # (torch.cdist returned a third of this sum for 4096 x 5000 f64 rows on this image)
+            want[c] += float((xc[lo:lo + 128, None, :] - xc[None, :, :]).square_().sum(-1).sqrt_().sum())
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
+    assert np.array_equal(cs.intra_totals(x, lab).intra_sums().cpu().numpy(), got)
+    # and the two inertia definitions built on it agree with the per-point pass (dic_cluster_intra_sums)
+    per_point = cs.pair_stats(x, lab, intra_only=True)
+    np.testing.assert_allclose(cs.inertia_v1(x, lab), cs.inertia_v1(x, lab, per_point), rtol=2e-6)
+    np.testing.assert_allclose(cs.inertia_v2(x, lab), cs.inertia_v2(x, lab, per_point), rtol=2e-6)
+
+
 def test_gap_table_equals_reference(tmp_path):
     """KM.compute_gap_internal_metric against the table the REFERENCE's own method produced (oracle/make_golden_gap.py; p2:353-410):
     every column at rtol 1e-5 AND the position of NumPy's global stream afterwards -- i.e. the draw order reference set -> that fit's
