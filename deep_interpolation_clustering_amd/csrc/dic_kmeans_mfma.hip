@@ -251,6 +251,11 @@ __global__ __launch_bounds__(256, NMB == 1 ? 2 : 1) void kmeans_assign_mfma_kern
 // One MFMA row block (32 centroid columns) per workgroup: 32 / KP restarts share its X tiles.  (Two row blocks = 64 columns per
 // workgroup was the first layout: it needs all 512 registers -- one workgroup per CU, spilling -- and pads 10 restarts of K = 16 to
 // 192 columns where 32-column groups need 160; with half the accumulators two workgroups fit a CU: 284 -> 254 us per iteration.)
+// A/B, round 6 (scripts/kmeans_bench.py with DIC_AB_LIB): placing the restart groups of one row block on ONE XCD (workgroup id -> (row block, group) such that
+// ids b and b + 8 walk the same X tiles; 8 x floor(64 / groups) row blocks so that no XCD gets a 65th workgroup) leaves the iteration where it was -- K = 16 x 10
+// restarts 160.9 against 158.6 us, K = 8 109.3 / 109.7, K = 20 265.6 / 266.1: the kernel does not wait for X out of the Infinity Cache (4.8 TB/s over all CUs);
+// its time is the two f32 MFMA chains (2 x 128 v_mfma_f32_32x32x2 per 32-row tile and wave, two waves per SIMD: ~95 us of matrix-core time at K = 16 at the
+// clock the part sustains under MFMA load) plus the argmin / label phase between them.  Not kept.
 static int kmeans_mfma_groups(int K, int n_runs) {
     const int G = 32 / (K <= 8 ? 8 : K <= 16 ? 16 : 32);
     return (n_runs + G - 1) / G;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """k-means (row a10 / BASELINE config 5) timing on the MI355X next to scikit-learn on the host cores.
-Usage: python3 scripts/kmeans_bench.py [N] [--sklearn]"""
+Usage: python3 scripts/kmeans_bench.py [N] [--sklearn]      (DIC_AB_LIB=<second libdic_hip.so>: the Lloyd iteration of both builds, timed alternately)"""
+import ctypes as C
 import os
 import sys
 import time
@@ -34,8 +35,15 @@ for K, n_init in ((4, 20), (8, 20), (16, 10)):
     dt, km = timed(lambda: KMeans(n_clusters=K, n_init=n_init).fit(Xd))
     print(f'HIP  KMeans(K={K}, n_init={n_init}).fit: {dt * 1e3:8.1f} ms  inertia {km.inertia_:.1f}  n_iter {km.n_iter_}')
 # one Lloyd iteration, all restarts in one launch: algorithmic bytes = n_runs * N * (4D + 4)
-L = N.lib()
-for K, runs in ((4, 1), (4, 20), (16, 10), (16, 20), (20, 10)):
+LIBS = [('this build', N.lib())]
+if os.environ.get('DIC_AB_LIB'):
+    LB = C.CDLL(os.path.abspath(os.environ['DIC_AB_LIB']))
+    for name, (res, args) in N.SIGNATURES.items():
+        if hasattr(LB, name):
+            fn = getattr(LB, name)
+            fn.restype, fn.argtypes = res, args
+    LIBS.append(('DIC_AB_LIB', LB))
+for (lib_name, L), (K, runs) in [(lb, kr) for kr in ((4, 1), (4, 10), (4, 20), (8, 10), (16, 10), (16, 20), (20, 10)) for lb in LIBS * (2 if len(LIBS) > 1 else 1)]:
     Xc = Xd - Xd.mean(0)
     xn = (Xc * Xc).sum(1)
     cent = Xc[torch.randint(0, n, (runs, K), device='cuda')].contiguous()
@@ -56,7 +64,7 @@ for K, runs in ((4, 1), (4, 20), (16, 10), (16, 20), (20, 10)):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     gb = runs * n * (4 * 256 + 4) / 1e9
-    print(f'lloyd_iter K={K} restarts={runs}: {ms * 1e3:8.1f} us  {gb / ms * 1e3:8.1f} GB/s algorithmic (data cache-resident: {n * 1024 / 1e6:.0f} MB)')
+    print(f'[{lib_name}] lloyd_iter K={K} restarts={runs}: {ms * 1e3:8.1f} us  {gb / ms * 1e3:8.1f} GB/s algorithmic (data cache-resident: {n * 1024 / 1e6:.0f} MB)')
 if '--sklearn' in sys.argv:
     from sklearn.cluster import KMeans as SK
     from threadpoolctl import threadpool_limits
