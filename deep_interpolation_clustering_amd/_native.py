@@ -112,6 +112,8 @@ SIGNATURES = {
     'dic_cluster_pairdist': (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p]),
     'dic_cluster_intra_sums': (_i, [_p, _p, _i, _i, _i, _p, _p]),
     'dic_cluster_intra_totals_workspace': (_sz, [C.c_int64, _i]),
+    'dic_cluster_pair_rowsums_workspace': (_sz, [C.c_int64, _i]),
+    'dic_cluster_pair_rowsums': (_i, [_p, C.c_long, _p, C.c_int64, _i, _i, _p, _i, _p, _i, _p, _p, _sz, _p]),
     'dic_cluster_intra_totals': (_i, [_p, C.c_long, _p, _p, C.c_int64, _i, _i, _p, _i, _p, _p, _sz, _p]),
     'dic_adam_amsgrad_step': (_i, [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     'dic_grad_norm_workspace': (_sz, [C.c_int64]),

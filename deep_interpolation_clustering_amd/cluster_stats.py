@@ -83,6 +83,43 @@ def _tile_list(counts_host):
     return np.concatenate(out) if out else np.zeros((0, 4), np.int32)
 
 
+# The sums-only all-pairs pass goes to the matrix cores from this many points on.  Its distances come from the norm form on split bf16 planes: a pair's d^2 is off
+# by ~2^-17 |x - mean| |y - mean| (random sign), which the sums over thousands of pairs average away (tests: <= 2e-6 of a row's largest sum at 70 001 x 256) but
+# which shows on a handful of close points in few dimensions (4e-6 at 63 x 4) -- and below this size the difference-form kernel takes well under a millisecond.
+ROWSUM_MIN_POINTS = 8192
+ROWSUM_WORKGROUPS = 256     # dic_cluster_pair_rowsums: one persistent workgroup per CU, each a contiguous range of the tile list
+
+
+def _row_tile_list(counts_host, n):
+    """Tile list of ``dic_cluster_pair_rowsums``: every 256-row block I of the (cluster-sorted) points against every 256-row block J of every cluster, sorted by
+    (I, cluster, J); (tiles (ntiles, 4) int32 = (I0, J0, end of J's cluster, slot), group_start (blocks x K + 1) int32, n_slots).  A slot = a maximal run of one
+    (I, cluster) inside one workgroup's contiguous range of the list."""
+    K = len(counts_host)
+    j0, jend, jc, start = [], [], [], 0
+    for c, n_c in enumerate(int(v) for v in counts_host):
+        nb = -(-n_c // 256)
+        j0.append(start + 256 * np.arange(nb))
+        jend.append(np.full(nb, start + n_c))
+        jc.append(np.full(nb, c))
+        start += n_c
+    j0, jend, jc = (np.concatenate(a).astype(np.int64) for a in (j0, jend, jc))
+    n_i, n_j = -(-n // 256), j0.size
+    ntiles = n_i * n_j
+    tiles = np.empty((ntiles, 4), np.int32)
+    tiles[:, 0] = np.repeat(256 * np.arange(n_i), n_j)
+    tiles[:, 1], tiles[:, 2] = np.tile(j0, n_i), np.tile(jend, n_i)
+    group = np.repeat(np.arange(n_i) * K, n_j) + np.tile(jc, n_i)              # (I, cluster), ascending along the list
+    nwg = min(ntiles, ROWSUM_WORKGROUPS)
+    per = -(-ntiles // nwg)
+    wg = np.arange(ntiles) // per
+    new_slot = np.ones(ntiles, bool)
+    new_slot[1:] = (group[1:] != group[:-1]) | (wg[1:] != wg[:-1])
+    slot = np.cumsum(new_slot) - 1
+    tiles[:, 3] = slot
+    group_start = np.searchsorted(group[new_slot], np.arange(n_i * K + 1)).astype(np.int32)
+    return tiles, group_start, int(slot[-1]) + 1
+
+
 def intra_totals(x, labels):
     """PairStats with only ``totals`` (K,) f64 = np.sum(pairwise_distances(X[a == c])) per cluster (``dic_cluster_intra_totals``: the distances of a cluster's block
     pairs I <= J on the matrix cores) -- all the two inertia definitions of the gap statistic need (p2_clustering_optK.py:334-351)."""
@@ -134,6 +171,18 @@ def pair_stats(x, labels, need_min=True, need_max=True, intra_only=False):
         out[order] = S_own
         return PairStats(lab, counts, None, None, None, out)
     S = torch.empty((n, K), device=x.device, dtype=torch.float32)
+    if not need_min and not need_max and d <= TOTALS_MAX_D and n >= ROWSUM_MIN_POINTS:
+        # only the sums (the silhouette): the all-pairs pass on the matrix cores (dic_cluster_pair_rowsums), points relative to their mean
+        tiles, group_start, n_slots = _row_tile_list(counts.cpu().numpy(), n)
+        tiles, group_start = torch.from_numpy(tiles).to(x.device), torch.from_numpy(group_start).to(x.device)
+        centre = xs.mean(0, keepdim=True, dtype=torch.float64).float().contiguous()
+        L = N.lib()
+        ws = torch.empty(L.dic_cluster_pair_rowsums_workspace(n, n_slots), dtype=torch.uint8, device=x.device)
+        N.check(L.dic_cluster_pair_rowsums(N.ptr(xs), xs.stride(0), N.ptr(centre), n, d, K, N.ptr(tiles), tiles.shape[0], N.ptr(group_start), n_slots, N.ptr(S),
+                                           N.ptr(ws), ws.numel(), N.stream_of(xs)), 'dic_cluster_pair_rowsums')
+        out = torch.empty_like(S)
+        out[order] = S
+        return PairStats(lab, counts, out, None, None)
     Dmin = torch.empty_like(S) if need_min else None
     omax = torch.empty(n, device=x.device, dtype=torch.float32) if need_max else None
     N.check(N.lib().dic_cluster_pairdist(N.ptr(xs), N.ptr(seg), n, d, K, N.ptr(S), N.ptr(Dmin), N.ptr(omax), N.stream_of(xs)),

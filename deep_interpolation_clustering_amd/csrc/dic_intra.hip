@@ -120,16 +120,25 @@ __device__ __forceinline__ qi32x4 sload_tile(const int4* p) {
 // ------------------------------------------------------------------------------------------------------------------------------------------
 struct IntraX3Args {
     const __bf16* pa; const __bf16* pb; long plane;
-    const int4* tiles; int ntiles;      // (first row of I, first row of J, end row of the cluster, cluster), sorted by cluster
-    double* partial; int K;             // (workgroups x 8 waves, K), zeroed by the caller
+    const int4* tiles; int ntiles;      // totals: (first row of I, first row of J, end row of the cluster, cluster), sorted by cluster
+    double* partial; int K;             //         (workgroups x 8 waves, K), zeroed by the caller
+    float* rows_out; int n_rows;        // row sums (ROWS): tiles = (first row of I, first row of J, end row of J's cluster, output slot), rows_out (slots, 2, 256)
 };
 
+// ROWS = false: the per-cluster totals (above).  ROWS = true: the ROW SUMS of the same distance tiles over ALL point pairs, S[i][c] = sum_{j in c} ||x_i - x_j||
+// (the silhouette's mean distances, internal_eval.py:112-123): a tile is 256 rows of ANY cluster against 256 rows of one cluster c; a workgroup walks a CONTIGUOUS
+// range of the tile list (sorted by row block, then cluster), and every maximal run of one (row block, cluster) inside a range is an output "slot": the lane's two
+// row sums (its two 32-row blocks, 64 columns each per tile: a tile's 64 terms first, then the running sum -- f32 throughout) are written once per slot, the two
+// column halves (wn) side by side; rows_reduce_kernel adds a (row block, cluster)'s slots in order.  No atomics, no weights, i == j masked wherever the ranges meet.
+template <bool ROWS>
 __global__ __launch_bounds__(512, 1) void intra_x3_kernel(IntraX3Args a) {
     extern __shared__ __align__(16) unsigned char qsm[];
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, l31 = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w & 3, wn = w >> 2;
     const int nch = gridDim.x;
-    const int my_tiles = (int)blockIdx.x < a.ntiles ? (a.ntiles - 1 - (int)blockIdx.x) / nch + 1 : 0;
+    const int per = (a.ntiles + nch - 1) / nch;          // (ROWS: contiguous ranges)
+    const int my_tiles = ROWS ? max(0, min(per, a.ntiles - (int)blockIdx.x * per))
+                              : ((int)blockIdx.x < a.ntiles ? (a.ntiles - 1 - (int)blockIdx.x) / nch + 1 : 0);
     const int S = my_tiles * Q_SLABS;
     if (S == 0) return;
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)qsm);
@@ -138,7 +147,10 @@ __global__ __launch_bounds__(512, 1) void intra_x3_kernel(IntraX3Args a) {
     // 16 rg + (L >> 2), physical 16-B piece L & 3 = logical piece (L & 3) ^ ((row >> 2) & 3), and (row >> 2) & 3 = (L >> 4) & 3 for every row group
     const unsigned v_dma = (unsigned)(lane >> 2) * (QLD * 2) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
     // the entries of the tile being multiplied and of the next one (whose first slabs are requested two iterations ahead) live in scalar registers
-    auto tile = [&](int i) { return sload_tile(a.tiles + ((int)blockIdx.x + min(i, my_tiles - 1) * nch)); };
+    auto tile = [&](int i) {
+        const int t = min(i, my_tiles - 1);
+        return sload_tile(a.tiles + __builtin_amdgcn_readfirstlane(ROWS ? (int)blockIdx.x * per + t : (int)blockIdx.x + t * nch));
+    };
     qi32x4 e_cur = tile(0), e_nxt = tile(1), e_prev = e_cur;
     int cur_tile = 0;
     auto issue = [&](const __bf16* mat, int row0, int ks, unsigned dst) {
@@ -176,7 +188,54 @@ __global__ __launch_bounds__(512, 1) void intra_x3_kernel(IntraX3Args a) {
         dsum = 0.0;
     };
     // a finished tile: D^T layout, lane (i = 64 wm + 32 mb + l31, hh), register k of block nb -> j = 128 wn + 32 nb + (k & 3) + 8 (k >> 2) + 4 hh
-    auto finish_tile = [&](qi32x4 e) {
+    float rs[2] = {0.f, 0.f};
+    auto flush_rows = [&]() {
+        if (cur_c < 0) return;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const float v = rs[mb] + __shfl_xor(rs[mb], 32);
+            if (hh == 0) a.rows_out[((size_t)cur_c * 2 + wn) * QT + 64 * wm + 32 * mb + l31] = v;
+            rs[mb] = 0.f;
+        }
+    };
+    auto finish_rows = [&](qi32x4 e) {
+        const int I0 = e[0], J0 = e[1], end = e[2];
+        if (e[3] != cur_c) {
+            flush_rows();
+            cur_c = e[3];
+        }
+        const bool apart = I0 + QT <= J0 || J0 + QT <= I0;
+        if (apart && I0 + QT <= a.n_rows && J0 + QT <= end) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                float t = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) t += __builtin_amdgcn_sqrtf(fmaxf(acc[nb][mb][k], 0.f));
+                rs[mb] += t;
+            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int gi = I0 + 64 * wm + 32 * mb + l31;
+                const bool iv = gi < a.n_rows;
+                float t = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const int jb = J0 + 128 * wn + 32 * nb + 4 * hh;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int gj = jb + (k & 3) + 8 * (k >> 2);
+                        const bool ok = iv && gj < end && gi != gj;
+                        t += ok ? __builtin_amdgcn_sqrtf(fmaxf(acc[nb][mb][k], 0.f)) : 0.f;
+                    }
+                }
+                rs[mb] += t;
+            }
+        }
+    };
+    auto finish_totals = [&](qi32x4 e) {
         const int I0 = e[0], J0 = e[1], end = e[2];
         if (e[3] != cur_c) {
             flush();
@@ -244,7 +303,10 @@ __global__ __launch_bounds__(512, 1) void intra_x3_kernel(IntraX3Args a) {
         if (s + Q_NI - 1 < S) issue_i(s + Q_NI - 1);
         __builtin_amdgcn_sched_barrier(0);
         if (ks == 0) {
-            if (s > 0) finish_tile(e_prev);
+            if (s > 0) {
+                if constexpr (ROWS) finish_rows(e_prev);
+                else finish_totals(e_prev);
+            }
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -276,8 +338,23 @@ __global__ __launch_bounds__(512, 1) void intra_x3_kernel(IntraX3Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    finish_tile(e_cur);
-    flush();
+    if constexpr (ROWS) {
+        finish_rows(e_cur);
+        flush_rows();
+    } else {
+        finish_totals(e_cur);
+        flush();
+    }
+}
+
+// S[i][c] = the sum of the slots of (row block of i, c), both column halves, in slot order.  grid (row blocks, K).
+__global__ __launch_bounds__(QT) void rows_reduce_kernel(const float* rows_out, const int* group_start, int n_rows, int K, float* S) {
+    const int g = blockIdx.x * K + blockIdx.y, i = blockIdx.x * QT + threadIdx.x;
+    if (i >= n_rows) return;
+    float s = 0.f;
+    for (int slot = group_start[g]; slot < group_start[g + 1]; ++slot)
+        s += rows_out[((size_t)slot * 2) * QT + threadIdx.x] + rows_out[((size_t)slot * 2 + 1) * QT + threadIdx.x];
+    S[(size_t)i * K + blockIdx.y] = s;
 }
 
 __global__ __launch_bounds__(64) void intra_finalize_kernel(const double* partial, int rows, int K, double* out) {
@@ -298,6 +375,66 @@ using namespace dic;
 
 extern "C" {
 
+size_t dic_cluster_pair_rowsums_workspace(int64_t N, int n_slots) {
+    if (N <= 0 || n_slots < 0) return 0;
+    return 4 * intra_plane_elems(N) * sizeof(__bf16) + (size_t)max(1, n_slots) * 2 * QT * sizeof(float);
+}
+
+static int intra_reserve_lds(const char* who) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)intra_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)intra_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "%s: cannot reserve %d B of LDS: %s", who, Q_LDS, hipGetErrorString(e));
+        attr_set = true;
+    }
+    return DIC_OK;
+}
+
+// planes of the augmented rows (+ zeroed padding rows) at the head of the workspace; returns the first byte behind them
+static int intra_planes(const char* who, const float* X, long ldx, const int32_t* seg, const float* centres, int64_t N, int D, int K, void* workspace, hipStream_t st,
+                        __bf16** pa_out, __bf16** pb_out) {
+    const size_t plane = intra_plane_elems(N);
+    __bf16* pa = (__bf16*)workspace;
+    __bf16* pb = pa + 2 * plane;
+    // the padding rows behind the last point are read by the last tiles (and masked): zero, not stale, so that no NaN pattern ever enters an accumulator
+    hipError_t e = hipMemsetAsync(pa + (size_t)N * QLD, 0, (size_t)QT * QLD * sizeof(__bf16), st);
+    if (e == hipSuccess) e = hipMemsetAsync(pa + plane + (size_t)N * QLD, 0, (size_t)QT * QLD * sizeof(__bf16), st);
+    if (e == hipSuccess) e = hipMemsetAsync(pb + (size_t)N * QLD, 0, (size_t)QT * QLD * sizeof(__bf16), st);
+    if (e == hipSuccess) e = hipMemsetAsync(pb + plane + (size_t)N * QLD, 0, (size_t)QT * QLD * sizeof(__bf16), st);
+    DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
+    IntraPrepArgs p{X, (int)ldx, seg, centres, pa, pb, (long)plane, (int)N, D, K};
+    hipLaunchKernelGGL(intra_prep_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p);
+    *pa_out = pa;
+    *pb_out = pb;
+    return DIC_OK;
+}
+
+int dic_cluster_pair_rowsums(const float* X, long ldx, const float* centre, int64_t N, int D, int K, const int32_t* tiles, int ntiles, const int32_t* group_start,
+                             int n_slots, float* S, void* workspace, size_t workspace_bytes, dic_stream_t stream) {
+    DIC_REQUIRE(N > 0 && D > 0 && K > 0 && ldx >= D, DIC_ERR_INVALID_ARG, "cluster_pair_rowsums: N=%lld D=%d K=%d ldx=%ld", (long long)N, D, K, ldx);
+    DIC_REQUIRE(D <= QD && D % 4 == 0 && ldx % 4 == 0, DIC_ERR_UNSUPPORTED, "cluster_pair_rowsums: D=%d (row stride %ld): at most %d, multiples of 4", D, ldx, QD);
+    DIC_REQUIRE(N < (1 << 30) && K <= 65535, DIC_ERR_UNSUPPORTED, "cluster_pair_rowsums: N=%lld K=%d", (long long)N, K);
+    DIC_REQUIRE(X && centre && tiles && group_start && S && workspace && ntiles > 0 && n_slots > 0, DIC_ERR_INVALID_ARG, "cluster_pair_rowsums: NULL pointer / empty list");
+    DIC_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)centre & 15) == 0 && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)tiles & 15) == 0, DIC_ERR_UNSUPPORTED,
+                "cluster_pair_rowsums: operands must be 16-B aligned");
+    DIC_REQUIRE(workspace_bytes >= dic_cluster_pair_rowsums_workspace(N, n_slots), DIC_ERR_WORKSPACE, "cluster_pair_rowsums: workspace %zu < %zu", workspace_bytes,
+                dic_cluster_pair_rowsums_workspace(N, n_slots));
+    int rc = intra_reserve_lds("cluster_pair_rowsums");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    __bf16 *pa, *pb;
+    // ONE centre for every point (pairs cross clusters): "cluster" 0 = all rows; the prep kernel only needs seg[0] = 0 <= row, which K = 1 never reads
+    rc = intra_planes("cluster_pair_rowsums", X, ldx, (const int32_t*)nullptr, centre, N, D, 1, workspace, st, &pa, &pb);
+    if (rc) return rc;
+    const size_t plane = intra_plane_elems(N);
+    float* rows_out = (float*)(pb + 2 * plane);
+    IntraX3Args a{pa, pb, (long)plane, (const int4*)tiles, ntiles, nullptr, K, rows_out, (int)N};
+    hipLaunchKernelGGL(intra_x3_kernel<true>, dim3(intra_chunks(ntiles)), dim3(512), Q_LDS, st, a);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)((N + QT - 1) / QT), K), dim3(QT), 0, st, (const float*)rows_out, group_start, (int)N, K, S);
+    return check_launch("cluster_pair_rowsums");
+}
+
 size_t dic_cluster_intra_totals_workspace(int64_t N, int K) {
     if (N <= 0 || K <= 0) return 0;
     return 4 * intra_plane_elems(N) * sizeof(__bf16) + intra_partial_bytes(K);
@@ -313,29 +450,19 @@ int dic_cluster_intra_totals(const float* X, long ldx, const int32_t* seg, const
                 "cluster_intra_totals: operands must be 16-B aligned");
     DIC_REQUIRE(workspace_bytes >= dic_cluster_intra_totals_workspace(N, K), DIC_ERR_WORKSPACE, "cluster_intra_totals: workspace %zu < %zu", workspace_bytes,
                 dic_cluster_intra_totals_workspace(N, K));
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)intra_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
-        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "cluster_intra_totals: cannot reserve %d B of LDS: %s", Q_LDS, hipGetErrorString(e));
-        attr_set = true;
-    }
+    int rc = intra_reserve_lds("cluster_intra_totals");
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    __bf16 *pa, *pb;
+    rc = intra_planes("cluster_intra_totals", X, ldx, seg, centres, N, D, K, workspace, st, &pa, &pb);
+    if (rc) return rc;
     const size_t plane = intra_plane_elems(N);
-    __bf16* pa = (__bf16*)workspace;
-    __bf16* pb = pa + 2 * plane;
     double* partial = (double*)(pb + 2 * plane);
-    // the padding rows behind the last point are read by the last tiles (and masked): zero, not stale, so that no NaN pattern ever enters an accumulator
-    hipError_t e = hipMemsetAsync(pa + (size_t)N * QLD, 0, (size_t)QT * QLD * sizeof(__bf16), st);
-    if (e == hipSuccess) e = hipMemsetAsync(pa + plane + (size_t)N * QLD, 0, (size_t)QT * QLD * sizeof(__bf16), st);
-    if (e == hipSuccess) e = hipMemsetAsync(pb + (size_t)N * QLD, 0, (size_t)QT * QLD * sizeof(__bf16), st);
-    if (e == hipSuccess) e = hipMemsetAsync(pb + plane + (size_t)N * QLD, 0, (size_t)QT * QLD * sizeof(__bf16), st);
-    if (e == hipSuccess) e = hipMemsetAsync(partial, 0, intra_partial_bytes(K), st);
+    hipError_t e = hipMemsetAsync(partial, 0, intra_partial_bytes(K), st);
     DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "cluster_intra_totals: memset: %s", hipGetErrorString(e));
-    IntraPrepArgs p{X, (int)ldx, seg, centres, pa, pb, (long)plane, (int)N, D, K};
-    hipLaunchKernelGGL(intra_prep_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, p);
     if (ntiles > 0) {
-        IntraX3Args a{pa, pb, (long)plane, (const int4*)tiles, ntiles, partial, K};
-        hipLaunchKernelGGL(intra_x3_kernel, dim3(intra_chunks(ntiles)), dim3(512), Q_LDS, st, a);
+        IntraX3Args a{pa, pb, (long)plane, (const int4*)tiles, ntiles, partial, K, nullptr, (int)N};
+        hipLaunchKernelGGL(intra_x3_kernel<false>, dim3(intra_chunks(ntiles)), dim3(512), Q_LDS, st, a);
     }
     hipLaunchKernelGGL(intra_finalize_kernel, dim3((K + 63) / 64), dim3(64), 0, st, partial, kNumCU * Q_WAVES, K, totals);
     return check_launch("cluster_intra_totals");

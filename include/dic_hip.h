@@ -521,6 +521,15 @@ int dic_cluster_intra_sums(const float* X, const int32_t* seg, int N, int D, int
  * clusterings.  X (N, D) f32 at row stride ldx, rows sorted by cluster as above, D <= 256, D % 4 == 0.  tiles (ntiles, 4) int32 on the device, sorted by
  * cluster: (first row of I, first row of J, end row of the cluster, cluster) for every pair of 256-row blocks I <= J of one cluster (block b of cluster c starts
  * at seg[c] + 256 b).  Only these pairs are visited (sum_c n_c^2 / 2 of the N^2).  Deterministic.  workspace: dic_cluster_intra_totals_workspace(N, K) bytes. */
+/* The ROW SUMS of the all-pairs pass on the same machine (round 6):  S (N, K) f32 OVERWRITTEN, S[i][c] = sum over the points j of cluster c of ||x_i - x_j||
+ * -- dic_cluster_pairdist's S without Dmin / own_max: what silhouette_score needs (internal_eval.py:112-123), 12 instead of 67 ms on 75 000 x 256.  Points
+ * relative to ONE centre (1, D) f32 (their mean).  tiles (ntiles, 4) int32 on the device: (first row of a 256-row block I, first row of a 256-row block J of
+ * cluster c, end row of c, output slot), sorted by (I, c, J); workgroup b of min(ntiles, 256) takes tiles [b per, (b + 1) per), per = ceil(ntiles / workgroups),
+ * and a slot is a maximal run of one (I, c) inside one such range (slots numbered in list order).  group_start (blocks of I x K + 1) int32: the first slot of
+ * every (I, c), in that order.  Deterministic.  workspace: dic_cluster_pair_rowsums_workspace(N, n_slots) bytes.  (Host side: cluster_stats._row_tile_list.) */
+size_t dic_cluster_pair_rowsums_workspace(int64_t N, int n_slots);
+int dic_cluster_pair_rowsums(const float* X, long ldx, const float* centre, int64_t N, int D, int K, const int32_t* tiles, int ntiles, const int32_t* group_start,
+                             int n_slots, float* S, void* workspace, size_t workspace_bytes, dic_stream_t stream);
 size_t dic_cluster_intra_totals_workspace(int64_t N, int K);
 int dic_cluster_intra_totals(const float* X, long ldx, const int32_t* seg, const float* centres, int64_t N, int D, int K, const int32_t* tiles, int ntiles,
                              double* totals, void* workspace, size_t workspace_bytes, dic_stream_t stream);

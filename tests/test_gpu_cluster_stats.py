@@ -33,6 +33,10 @@ def test_scores_match_reference(cs, name):
     np.testing.assert_allclose(cs.inertia_v2(x, lab), g['inertia_v2'], rtol=1e-5)
     np.testing.assert_allclose(cs.dunn_index(x, lab, st), g['dunn'], rtol=1e-5)
     np.testing.assert_allclose(cs.silhouette_score(x, lab, st), g['silhouette'], rtol=1e-5, atol=1e-6)
+    # ... and from the sums-only pass on the matrix cores (dic_cluster_pair_rowsums: what p2's sweep runs when no Dunn index is asked for)
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setattr(cs, 'ROWSUM_MIN_POINTS', 0)
+        np.testing.assert_allclose(cs.silhouette_score(x, lab, cs.pair_stats(x, lab, need_min=False, need_max=False)), g['silhouette'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(cs.calinski_harabasz_score(x, lab), g['calinski_harabasz'], rtol=1e-5)
     np.testing.assert_allclose(cs.davies_bouldin_score(x, lab), g['davies_bouldin'], rtol=1e-5)
 
@@ -102,7 +106,7 @@ def test_intra_only_pass_equals_own_column_of_the_full_pass(cs, n, d, k):
     if k > 3:
         lab[lab == k - 1] = 0
         lab[k - 1] = k - 1                       # a singleton cluster
-    full = cs.pair_stats(x, lab, need_min=False, need_max=False)
+    full = cs.pair_stats(x, lab, need_min=True, need_max=False)          # (with Dmin: the difference-form kernel; sums only would take the matrix-core pass)
     intra = cs.pair_stats(x, lab, intra_only=True)
     own = full.S.gather(1, full.labels[:, None])[:, 0]
     assert torch.equal(intra.S_own, own)
@@ -138,6 +142,33 @@ def test_intra_totals_on_the_matrix_cores_match_f64(cs, n, d, k, spread):
     per_point = cs.pair_stats(x, lab, intra_only=True)
     np.testing.assert_allclose(cs.inertia_v1(x, lab), cs.inertia_v1(x, lab, per_point), rtol=2e-6)
     np.testing.assert_allclose(cs.inertia_v2(x, lab), cs.inertia_v2(x, lab, per_point), rtol=2e-6)
+
+
+@pytest.mark.parametrize('n,d,k,spread', [(1, 4, 1, 1.0), (63, 4, 2, 1.0), (700, 36, 3, 1.0), (3000, 256, 7, 1.0), (1537, 20, 64, 1.0), (2600, 256, 2, 10.0),
+                                          (70001, 256, 3, 1.0), (513, 255, 2, 1.0)])
+def test_row_sums_on_the_matrix_cores_match_the_difference_form(cs, n, d, k, spread, monkeypatch):
+    """dic_cluster_pair_rowsums (need_min = need_max = False: split bf16 planes relative to the mean, norms folded into the inner product, contiguous tile ranges per
+    workgroup, slots added in order) against the direct-difference f32 pass (dic_cluster_pairdist): every S[i][c], with empty label values, a singleton cluster,
+    clusters smaller than a block, more tiles than workgroups (70 001 points: slots that split a (row block, cluster) run between two workgroups).  Measured:
+    1.1e-6 of the row's largest sum at 70 001 x 256 (the size the pass is used from: cluster_stats.ROWSUM_MIN_POINTS), up to 4.4e-6 on the tiny shapes forced
+    through it here (63 points in 4 dimensions: few pairs, nothing averages).  The same result on a second call."""
+    monkeypatch.setattr(cs, 'ROWSUM_MIN_POINTS', 0)
+    rng = np.random.default_rng(n + d + k)
+    lab = rng.integers(0, k, n)
+    lab[:min(k, n)] = np.arange(min(k, n))
+    if k > 3:
+        lab[lab == k - 1] = 0
+        lab[k - 1] = k - 1                       # a singleton cluster
+    x = (rng.normal(0, 1, (n, d)) + spread * rng.normal(0, 1, (k, d))[lab]).astype(np.float32)
+    want = cs.pair_stats(x, lab, need_min=True, need_max=False)
+    got = cs.pair_stats(x, lab, need_min=False, need_max=False)
+    assert got.Dmin is None and got.own_max is None and torch.equal(got.labels, want.labels)
+    w, g_ = want.S.double(), got.S.double()
+    scale = w.max(1, keepdim=True).values.clamp(min=1e-3)
+    assert float(((g_ - w).abs() / scale).max()) <= (3e-6 if n >= 8192 else 1.5e-5)
+    assert torch.equal(cs.pair_stats(x, lab, need_min=False, need_max=False).S, got.S)
+    if n > k:
+        np.testing.assert_allclose(cs.silhouette_score(x, lab, got), cs.silhouette_score(x, lab, want), rtol=1e-5, atol=2e-6 if n >= 8192 else 2e-5)
 
 
 def test_gap_table_equals_reference(tmp_path):
