@@ -357,12 +357,14 @@ __global__ __launch_bounds__(QT) void rows_reduce_kernel(const float* rows_out, 
     S[(size_t)i * K + blockIdx.y] = s;
 }
 
+// one wave per cluster: lane l adds rows l, l + 64, ... in order, then the 64 lane sums are added by a fixed butterfly
 __global__ __launch_bounds__(64) void intra_finalize_kernel(const double* partial, int rows, int K, double* out) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= K) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += partial[(size_t)r * K + c];
-    out[c] = s;
+    for (int r = lane; r < rows; r += 64) s += partial[(size_t)r * K + c];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[c] = s;
 }
 
 static int intra_chunks(int ntiles) { return max(1, min(ntiles, kNumCU)); }
@@ -464,7 +466,7 @@ int dic_cluster_intra_totals(const float* X, long ldx, const int32_t* seg, const
         IntraX3Args a{pa, pb, (long)plane, (const int4*)tiles, ntiles, partial, K, nullptr, (int)N};
         hipLaunchKernelGGL(intra_x3_kernel<false>, dim3(intra_chunks(ntiles)), dim3(512), Q_LDS, st, a);
     }
-    hipLaunchKernelGGL(intra_finalize_kernel, dim3((K + 63) / 64), dim3(64), 0, st, partial, kNumCU * Q_WAVES, K, totals);
+    hipLaunchKernelGGL(intra_finalize_kernel, dim3(K), dim3(64), 0, st, partial, kNumCU * Q_WAVES, K, totals);
     return check_launch("cluster_intra_totals");
 }
 

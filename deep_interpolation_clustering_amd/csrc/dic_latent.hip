@@ -559,27 +559,74 @@ __global__ __launch_bounds__(256) void inertia_kernel(const float* mind_all, int
     if (threadIdx.x == 0) inertia[run] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
-// k-means++ inner step: exact (f64) squared distances to L candidate rows, min with `closest`, potential.
-__global__ __launch_bounds__(kLatBlock) void kmeans_pp_kernel(const float* X, int N, int D, int row_lo, int row_hi, const int64_t* cand, int L,
-                                                             int group, const float* closest_all, float* dist_out,
-                                                             double* ppart) {
-    __shared__ double red[kLatWaves];
-    const int l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* closest = closest_all + (size_t)(l / group) * N;
-    const float4 c = load_row4(X, cand[l], D, lane);
+// k-means++ inner step (sklearn/cluster/_kmeans.py:218-243): exact (f64) squared distances of every row to L candidate rows, min with the restart's running
+// `closest`, the candidates' potentials.  Round 6: ONE pass over the rows for up to LC = 64 candidates (grid.y = further groups of LC).  The candidate rows sit in
+// LDS; a wave takes a row (lane = 4 features), forms its per-lane partial of all LC distances in f64 and folds the LC partials across the 64 lanes with the
+// halving exchange of `fold` (63 exchanges for 64 sums instead of 6 each: lane l ends up with the distance to candidate l), so each lane then finishes ONE
+// (row, candidate): min with closest, store, potential.  Until then one workgroup COLUMN per candidate re-read X and paid a six-step f64 butterfly per (row,
+// candidate): 357 us per launch for 40 candidates on 75 000 x 256 (0.9 s of p2's sweep).
+template <int N_, int MASK>
+__device__ __forceinline__ void fold_f64(double* v, int lane) {
+    if constexpr (N_ > 1) {
+        constexpr int H = N_ / 2;
+        const bool hi = (lane & MASK) != 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const double send = hi ? v[i] : v[i + H];
+            const double keep = hi ? v[i + H] : v[i];
+            v[i] = keep + __shfl_xor(send, MASK);
+        }
+        fold_f64<H, MASK / 2>(v, lane);
+    } else {
+#pragma unroll
+        for (int m = MASK; m >= 1; m >>= 1) v[0] += __shfl_xor(v[0], m);
+    }
+}
+
+template <int LC>
+__global__ __launch_bounds__(kLatBlock) void kmeans_pp_kernel(const float* X, int N, int D, int row_lo, int row_hi, const int64_t* cand, int L, int group,
+                                                             const float* closest_all, float* dist_out, double* ppart) {
+    extern __shared__ __align__(16) float pp_cl[];                  // [LC][256] candidate rows, zero beyond D / L
+    __shared__ double red[kLatWaves][LC];
+    constexpr int LG = LC == 64 ? 6 : LC == 32 ? 5 : 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l0 = blockIdx.y * LC;
+    for (int i = threadIdx.x; i < LC * 64; i += kLatBlock) {
+        const int l = i >> 6, q = i & 63;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l0 + l < L) v = load_row4(X, cand[l0 + l], D, q);
+        *reinterpret_cast<float4*>(pp_cl + l * 256 + 4 * q) = v;
+    }
+    __syncthreads();
+    const int lidx = lane >> (6 - LG), my_l = l0 + lidx;          // the candidate this lane finishes (fold: index = the lane's top LG bits)
+    const bool writer = (lane & ((64 >> LG) - 1)) == 0 && my_l < L;
+    const float* closest = closest_all + (size_t)(writer ? my_l / group : 0) * N;
     double pot = 0.0;
     const long nw = (long)gridDim.x * kLatWaves;
+    const int n_here = min(LC, L - l0);
     for (long row = (long)row_lo + (long)blockIdx.x * kLatWaves + wave; row < row_hi; row += nw) {      // this rank's rows of the (.,N) arrays
         const float4 x = load_row4(X, row, D, lane);
-        const double d0 = (double)x.x - c.x, d1 = (double)x.y - c.y, d2 = (double)x.z - c.z, d3 = (double)x.w - c.w;
-        const double dist = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-        const float m = fminf(closest[row], (float)dist);
-        if (lane == 0) dist_out[(size_t)l * N + row] = m;
-        pot += (double)m;
+        asm volatile("" ::: "memory");          // (the candidate rows are re-read from LDS for every row: hoisted out of this loop as doubles they need 512 registers)
+        double p[LC];
+#pragma unroll
+        for (int l = 0; l < LC; ++l) {
+            p[l] = 0.0;
+            if (l < n_here) {                                      // (uniform: the slots behind the last candidate cost nothing)
+                const float4 c = *reinterpret_cast<const float4*>(pp_cl + l * 256 + 4 * lane);
+                const double d0 = (double)x.x - c.x, d1 = (double)x.y - c.y, d2 = (double)x.z - c.z, d3 = (double)x.w - c.w;
+                p[l] = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+        }
+        fold_f64<LC, 32>(p, lane);
+        if (writer) {
+            const float m = fminf(closest[row], (float)p[0]);
+            dist_out[(size_t)my_l * N + row] = m;
+            pot += (double)m;
+        }
     }
-    if (lane == 0) red[wave] = pot;
+    if ((lane & ((64 >> LG) - 1)) == 0) red[wave][lidx] = pot;
     __syncthreads();
-    if (threadIdx.x == 0) ppart[(size_t)blockIdx.x * L + l] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x < LC && l0 + threadIdx.x < L)
+        ppart[(size_t)blockIdx.x * L + l0 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void kmeans_pp_finalize(const double* ppart, int nblk, int L, double* pot) {
     __shared__ double red[256];
@@ -838,8 +885,22 @@ static int pp_candidates(const float* X, int N, int D, int row_lo, int row_hi, c
     const int nblk = km_blocks(row_hi - row_lo);
     DIC_REQUIRE(workspace_bytes >= (size_t)L * nblk * sizeof(double), DIC_ERR_WORKSPACE, "kmeans_pp_candidates: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(kmeans_pp_kernel, dim3(nblk, L), dim3(kLatBlock), 0, st, X, N, D, row_lo, row_hi, cand, L, group, closest, dist_out,
-                       (double*)workspace);
+    // candidates per pass over the rows: 16 / 32 / 64 (the LDS image of 64 candidate rows is 64 KB)
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kmeans_pp_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        DIC_REQUIRE(e == hipSuccess, DIC_ERR_LAUNCH, "kmeans_pp_candidates: cannot reserve 64 KB of LDS: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    if (L <= 16)
+        hipLaunchKernelGGL(kmeans_pp_kernel<16>, dim3(nblk, 1), dim3(kLatBlock), 16 * 1024, st, X, N, D, row_lo, row_hi, cand, L, group, closest, dist_out,
+                           (double*)workspace);
+    else if (L <= 32)
+        hipLaunchKernelGGL(kmeans_pp_kernel<32>, dim3(nblk, 1), dim3(kLatBlock), 32 * 1024, st, X, N, D, row_lo, row_hi, cand, L, group, closest, dist_out,
+                           (double*)workspace);
+    else
+        hipLaunchKernelGGL(kmeans_pp_kernel<64>, dim3(nblk, (L + 63) / 64), dim3(kLatBlock), 64 * 1024, st, X, N, D, row_lo, row_hi, cand, L, group, closest,
+                           dist_out, (double*)workspace);
     hipLaunchKernelGGL(kmeans_pp_finalize, dim3((L + 31) / 32), dim3(256), 0, st, (const double*)workspace, nblk, L, pot_out);
     return check_launch("kmeans_pp_candidates");
 }
