@@ -23,3 +23,4 @@ cpif $S/step_f32x3_B32768_kernel_stats.csv profiles/r${R}_step_f32x3_B32768_kern
 cpif $S/step_f32x3_pmc_traffic.json profiles/r${R}_step_f32x3_pmc_traffic.json
 cpif $S/step_f32x3_pmc_traffic.json profiles/x3_traffic.json
 cpif $S/bench_f32x3_under_rocprof.json profiles/r${R}_bench_f32x3_under_rocprof_B32768.json
+cpif $S/p2_sweep_kernel_stats.csv profiles/r${R}_p2_sweep_final_kernel_stats.csv

@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_r$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-STEPS=${2:-"1 2 3 4 5 6 7 8"}
+STEPS=${2:-"1 2 3 4 5 6 7 8 9"}
 step1() {
   # 1. kernel statistics of the bench command itself
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- python3 $ROOT/bench.py --no-secondary --no-cpu-baseline --steps 30 --warmup 9 --kernel-iters 1 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
@@ -74,9 +74,15 @@ step8() {
   cp /tmp/x3_stats/k_kernel_stats.csv $OUT/step_f32x3_B32768_kernel_stats.csv
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/x3_fetch -o p -- python3 $ROOT/bench.py $X3 --steps 4 --warmup 2 > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/x3_write -o p -- python3 $ROOT/bench.py $X3 --steps 4 --warmup 2 > /dev/null 2>&1
-  python3 $ROOT/scripts/pmc_generic.py /tmp/x3_fetch/p_counter_collection.csv /tmp/x3_write/p_counter_collection.csv 'lstm_rec_|lstm_dwx3|gemm_|x3_row_proj|bnhead|bn_colstats' 32768 > $OUT/step_f32x3_pmc_traffic.json
+  python3 $ROOT/scripts/pmc_generic.py /tmp/x3_fetch/p_counter_collection.csv /tmp/x3_write/p_counter_collection.csv 'lstm_rec_|lstm_dwx3|dx_tile_x3|gemm_|x3_row_proj|bnhead|bn_colstats' 32768 > $OUT/step_f32x3_pmc_traffic.json
   cp $OUT/step_f32x3_pmc_traffic.json $ROOT/profiles/x3_traffic.json
   echo "[profile] f32x3 done"
+}
+step9() {
+  # 9. configs[4]: p2's K sweep (K = 2..20, 10 reference sets, three indices per K) on 75 000 x 256 latents: kernel statistics
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2_stats -o p2 -- python3 $ROOT/scripts/p2_sweep_75k.py > $OUT/p2_sweep.txt 2>&1
+  cp /tmp/p2_stats/p2_kernel_stats.csv $OUT/p2_sweep_kernel_stats.csv
+  echo "[profile] p2 sweep done"
 }
 for s in $STEPS; do step$s; done
 ls -la $OUT
