@@ -209,3 +209,42 @@ def test_environment_switch_table():
     doc = open(os.path.join(root, 'INTEGRATION.md')).read()
     block = doc[doc.index(switches.BEGIN) + len(switches.BEGIN):doc.index(switches.END)].strip()
     assert block == switches.markdown_table(), 'INTEGRATION.md section 4 is stale: python -m deep_interpolation_clustering_amd.switches --write'
+
+
+def test_distance_pass_tile_lists_cover_every_block_pair_once():
+    """The host side of dic_cluster_intra_totals / dic_cluster_pair_rowsums (cluster_stats._tile_list / _row_tile_list): the totals list holds every pair of
+    256-row blocks I <= J of one cluster exactly once, sorted by cluster; the row-sum list every (row block, cluster block) pair, sorted by (row block, cluster,
+    block), its slots are the maximal runs of one (row block, cluster) inside a workgroup's contiguous range and group_start indexes them per (row block, cluster)
+    -- with an empty cluster, a cluster smaller than a block and more tiles than workgroups."""
+    from deep_interpolation_clustering_amd import cluster_stats as cs
+    counts = np.array([700, 0, 5, 1300, 256])
+    n, K = int(counts.sum()), len(counts)
+    seg = np.concatenate([[0], np.cumsum(counts)])
+    t = cs._tile_list(counts)
+    want = [(seg[c] + 256 * i, seg[c] + 256 * j, seg[c + 1], c) for c in range(K) for i in range(-(-counts[c] // 256)) for j in range(i, -(-counts[c] // 256))]
+    assert sorted(map(tuple, t.tolist())) == sorted(want) and (np.diff(t[:, 3]) >= 0).all() and t.dtype == np.int32
+    assert cs._tile_list(np.array([0, 0])).shape == (0, 4)
+
+    for workgroups in (256, 7):                       # 9 x 10 = 90 tiles: fewer / more tiles than workgroups
+        cs_wg, cs.ROWSUM_WORKGROUPS = cs.ROWSUM_WORKGROUPS, workgroups
+        try:
+            tiles, group_start, n_slots = cs._row_tile_list(counts, n)
+        finally:
+            cs.ROWSUM_WORKGROUPS = cs_wg
+        n_i = -(-n // 256)
+        jb = [(seg[c] + 256 * j, seg[c + 1], c) for c in range(K) for j in range(-(-counts[c] // 256))]
+        assert [tuple(r[:3]) for r in tiles.tolist()] == [(256 * i, j0, je) for i in range(n_i) for j0, je, _ in jb]
+        group = np.repeat(np.arange(n_i) * K, len(jb)) + np.tile([c for _, _, c in jb], n_i)
+        slot = tiles[:, 3]
+        assert slot[0] == 0 and set(np.diff(slot)) <= {0, 1} and n_slots == slot[-1] + 1
+        nwg = min(len(tiles), workgroups)
+        per = -(-len(tiles) // nwg)
+        wg = np.arange(len(tiles)) // per
+        for s_ in range(n_slots):                     # one (row block, cluster) and one workgroup per slot; neighbours differ in one of the two
+            m = slot == s_
+            assert len(set(group[m])) == 1 and len(set(wg[m])) == 1
+        same = (group[1:] == group[:-1]) & (wg[1:] == wg[:-1])
+        assert ((np.diff(slot) == 0) == same).all()
+        assert group_start.shape == (n_i * K + 1,) and group_start[0] == 0 and group_start[-1] == n_slots
+        for g in range(n_i * K):
+            assert sorted(set(slot[group == g])) == list(range(group_start[g], group_start[g + 1]))
