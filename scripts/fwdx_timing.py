@@ -5,7 +5,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 from deep_interpolation_clustering_amd import _native as N
-if os.environ.get('DIC_AB_LIB'):          # the stamped build as a second library (scripts/two_lib_build.sh dic_lstm32.hip - "-DDIC_FWDX_EXP_TIMING" <out.so>): the tree stays as it is
+# the stamped build may be a second library (scripts/two_lib_build.sh dic_lstm32.hip - "-DDIC_FWDX_EXP_TIMING" <out.so>): the tree stays as it is
+if os.environ.get('DIC_AB_LIB'):
     N.LIB_PATH = os.path.abspath(os.environ['DIC_AB_LIB'])
 L, P = N.lib(), N.ptr
 nosave = len(sys.argv) > 1 and sys.argv[1] == 'nosave'
