@@ -603,6 +603,17 @@ __device__ __forceinline__ void split4_store(unsigned char* hi, unsigned char* l
     *reinterpret_cast<b4*>(lo) = l;
 }
 
+#ifdef DIC_DWX3_EXP_TIMING      // experiment: per-phase cycle stamps of lane 0 of every wave of workgroup (5, 0), tiles 8..39 (scripts/dwx3_timing.py)
+__device__ unsigned long long dic_dwx3_stamps[8][32][8];
+#define DWX_STAMP(tile, slot)                                                                                         \
+    do {                                                                                                              \
+        if (blockIdx.x == 5 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (tile) >= 8 && (tile) < 40)               \
+            dic_dwx3_stamps[threadIdx.x >> 6][(tile) - 8][slot] = __builtin_readcyclecounter();                        \
+    } while (0)
+#else
+#define DWX_STAMP(tile, slot) do {} while (0)
+#endif
+
 template <int XWT, int DMH>
 __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
     typedef DwX3<XWT, DMH> C;
@@ -664,6 +675,11 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
         xrow[i] = pc / xpc; xc4[i] = pc - xrow[i] * xpc;
         v_x[i] = (unsigned)((xrow[i] * a.ldx + 4 * xc4[i]) * 4);
     }
+    // (the LDS positions of a thread's pieces: row * pitch + 8 piece, and row < dup <=> position < dup * pitch -- the rows and pieces themselves need not stay)
+    const int h_pos = hrow * C::HP + hc4 * 8;
+    int x_pos[C::NXL];
+#pragma unroll
+    for (int i = 0; i < C::NXL; ++i) x_pos[i] = xrow[i] * C::XP + xc4[i] * 8;
     f32x4_t hreg, xreg[C::NXL];
     auto request_hx = [&](int j) {
         const long r0 = tile_r0(j);
@@ -671,22 +687,36 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
 #pragma unroll
         for (int i = 0; i < C::NXL; ++i) xreg[i] = gload16(a.x + (size_t)r0 * a.ldx, v_x[i]);
     };
-    auto store_hx = [&](int j) {                                         // split -> the images of slot j & 1; rows the shifted last tile shares with its predecessor: zeros
+    // split -> the images of slot j & 1, in 1 + NXL pieces (h, then the x registers) so that the main loop can put one piece behind each of its first MFMA groups;
+    // rows the shifted last tile shares with its predecessor: zeros
+    constexpr int NPIECE = 1 + C::NXL;
+    static_assert(NPIECE <= C::NBN, "dwx3: one MFMA group per piece");
+    auto store_piece = [&](int j, int pc) {
         const long t0 = (long)((int)blockIdx.x + min(j, mine - 1) * nch) * TX;
         const int dup = (int)max(0L, t0 + TX - nrows);
         unsigned char* base = hx0 + (j & 1) * C::L_HX;
-        split4_store(base + hrow * C::HP + hc4 * 8, base + C::L_H + hrow * C::HP + hc4 * 8, hreg, false, hrow < dup);
+        if (dup == 0) {                          // (uniform; every tile but a shifted last one: no zero selects)
+            if (pc == 0) split4_store(base + h_pos, base + C::L_H + h_pos, hreg, false, false);
+            else if (xon[pc - 1]) split4_store(base + 2 * C::L_H + x_pos[pc - 1], base + 2 * C::L_H + C::L_X + x_pos[pc - 1], xreg[pc - 1], a.x_relu != 0, false);
+        } else if (pc == 0) {
+            split4_store(base + h_pos, base + C::L_H + h_pos, hreg, false, h_pos < dup * C::HP);
+        } else {
+            const int i = pc - 1;
+            if (xon[i]) split4_store(base + 2 * C::L_H + x_pos[i], base + 2 * C::L_H + C::L_X + x_pos[i], xreg[i], a.x_relu != 0, x_pos[i] < dup * C::XP);
+        }
+    };
+    auto store_hx = [&](int j) {
 #pragma unroll
-        for (int i = 0; i < C::NXL; ++i)
-            if (xon[i]) split4_store(base + 2 * C::L_H + xrow[i] * C::XP + xc4[i] * 8, base + 2 * C::L_H + C::L_X + xrow[i] * C::XP + xc4[i] * 8, xreg[i],
-                                     a.x_relu != 0, xrow[i] < dup);
+        for (int pc = 0; pc < NPIECE; ++pc) store_piece(j, pc);
     };
 
     // ---- transposed-read addressing (ds_read_b64_tr_b16; see lstm_dw_kernel)
     const int kq = (lane & 15) >> 2, kp = lane & 3, cb = (lane >> 4) & 1, hh = lane >> 5;
     const int rowoff = 8 * hh + kq;
     auto piece = [&](int j) { return (((4 * j + 2 * cb + (kp >> 1)) ^ (kq << 2)) * 16) + (kp & 1) * 8; };
-    int pa_off[2], pb_off[C::NBN], pb_pitch[C::NBN], pb_lo[C::NBN];
+    int pa_off[2], pb_pitch[C::NBN], pb_lo[C::NBN];
+    int pb_sel[C::NBN], pb_soff[C::NBN];                                 // (scalar) column block i of this wave: in the h image or the x image, and its byte offset there
+    const int pb_h = rowoff * C::HP + (16 * cb + 4 * kp) * 2, pb_x = 2 * C::L_H + rowoff * C::XP + (16 * cb + 4 * kp) * 2;      // (per lane: two registers, not one per block)
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
         pa_off[mb] = DMH == G4 ? rowoff * C::DGP + (64 * mg + 32 * mb + 16 * cb + 4 * kp) * 2 : rowoff * C::DGP + piece(2 * mg + mb);
@@ -695,8 +725,10 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
         const int jn = min(C::NBN * ng + i, C::NBT - 1);                 // column block of [h (4 blocks) | x] (an idle slot repeats the last one: never stored)
         pb_pitch[i] = jn < 4 ? C::HP : C::XP;
         pb_lo[i] = jn < 4 ? C::L_H : C::L_X;
-        pb_off[i] = jn < 4 ? rowoff * C::HP + (32 * jn + 16 * cb + 4 * kp) * 2 : 2 * C::L_H + rowoff * C::XP + (32 * (jn - 4) + 16 * cb + 4 * kp) * 2;
+        pb_sel[i] = jn < 4;
+        pb_soff[i] = 64 * (jn < 4 ? jn : jn - 4);
     }
+    auto pb_off = [&](int i) { return (pb_sel[i] ? pb_h : pb_x) + pb_soff[i]; };
     auto frag = [&](const unsigned char* p, int pitch) {
         const s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 4 * pitch);
         s16x8 f;
@@ -755,16 +787,18 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
     request_hx(1);
     request_dg(1);
     for (int j = 0; j < mine; ++j) {
+        DWX_STAMP(j, 0);
         // queue, oldest first: [DMA(j)] h / x (j + 1), DMA(j + 1): everything up to the h / x loads has landed once only the last tile's DMAs are outstanding
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(C::NDMA) : "memory");
+        DWX_STAMP(j, 1);
         asm volatile("" : "+v"(hreg));
 #pragma unroll
         for (int i = 0; i < C::NXL; ++i) asm volatile("" : "+v"(xreg[i]));
         __builtin_amdgcn_s_barrier();              // every wave's DMA of tile j has landed and its image writes are visible; all are done with tile j - 1
+        DWX_STAMP(j, 2);
         if constexpr (DXOK) finish_dx(j - 1);
-        store_hx(j + 1);                           // -> the image slot tile j - 1 was read from
-        request_hx(j + 2);
-        request_dg(j + 2);                         // -> the dG slot tile j - 1 was read from
+        DWX_STAMP(j, 3);
+        DWX_STAMP(j, 4);
         const unsigned char* dgb = dwsm + (j % 3) * C::L_DG;
         const unsigned char* hxb = hx0 + (j & 1) * C::L_HX;
         bf16x8 ah[2], al[2];
@@ -773,17 +807,39 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
             ah[mb] = frag(dgb + pa_off[mb], C::DGP);
             al[mb] = frag(dgb + C::L_PL + pa_off[mb], C::DGP);
         }
+        // the [h | x] fragments of column block i + 1 are requested UNDER the MFMAs of block i, into the registers those MFMAs have just read (there is no room
+        // for a second set at 255 registers): hi (i + 1) behind the four products on hi (i), lo (i + 1) behind the two on lo (i).  As first written -- both
+        // fragments read, waited for, then six MFMAs -- every block exposed an LDS round trip: the matrix cores were 52-56 % busy (rocprofv3).
+        bf16x8 bh = frag(hxb + pb_off(0), pb_pitch[0]);
+        bf16x8 bl = frag(hxb + pb_off(0) + pb_lo[0], pb_pitch[0]);
 #pragma unroll
         for (int i = 0; i < C::NBN; ++i) {
-            const bf16x8 bh = frag(hxb + pb_off[i], pb_pitch[i]);
-            const bf16x8 bl = frag(hxb + pb_off[i] + pb_lo[i], pb_pitch[i]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb][i], 0, 0, 0);
-                acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh, acc[mb][i], 0, 0, 0);
-                acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb][i], 0, 0, 0);
+            for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb][i], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh, acc[mb][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < C::NBN) bh = frag(hxb + pb_off(i + 1), pb_pitch[i + 1]);
+            // the NEXT tile's h / x registers -> split -> the other image slot (the one tile j - 1 was read from), one piece per MFMA group: vector and LDS-write
+            // work in the shadow of the four MFMAs just issued (cycle stamps, scripts/dwx3_timing.py: done in one go behind the barrier it cost the wave that
+            // issues second 1 170 of its 4 430 cycles per tile; this way the launch takes 2 053 instead of 2 209 us on the same box -- the two waves of a SIMD still
+            // convert at the same time, so most of that vector work stays exposed); the requests for tile j + 2 reuse those registers and follow the last piece
+            // (Measured and not kept: the two waves of a SIMD converting at OPPOSITE ends of the loop, so that one's vector work meets the other's MFMAs -- the
+            // late wave then requests tile j + 2 five MFMA groups later and waits 700 cycles for it at the top of the next tile: 2 297 against 2 053 us.)
+            if (i < NPIECE) store_piece(j + 1, i);
+            if (i == NPIECE - 1) {
+                request_hx(j + 2);
+                request_dg(j + 2);                 // -> the dG slot tile j - 1 was read from
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < C::NBN) bl = frag(hxb + pb_off(i + 1) + pb_lo[i + 1], pb_pitch[i + 1]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        DWX_STAMP(j, 5);
         if constexpr (DXOK) {
             if (want_dx) {
                 f32x4_t d0 = {0.f, 0.f, 0.f, 0.f};
@@ -997,5 +1053,11 @@ int dic_lstm_unpack_grads(const float* dw_ih, int ldw, const float* dw_hh, const
                        dw_hh, dbias, I, g, accumulate ? 1.0f : 0.0f);
     return check_launch("lstm_unpack_grads");
 }
+
+#ifdef DIC_DWX3_EXP_TIMING
+int dic_dwx3_debug_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dic_dwx3_stamps), sizeof(unsigned long long) * 8 * 32 * 8);
+}
+#endif
 
 }  // extern "C"
