@@ -516,6 +516,11 @@ __global__ __launch_bounds__(256) void gemm_tn_finalize(const float* part, int S
 // two bf16 images in LDS, 560-B pitch: conflict-free straight 16-B reads), 48 MFMAs per tile and wave (hi.hi + lo.hi + hi.lo), f32 outputs straight from
 // the accumulators as 128-B row segments.  Against gemm_nt on the same shapes: no weight traffic and no weight conversion inside the loop, a tile's x
 // split once per 256 output columns instead of once per 128, one barrier per tile.  grid (row chunks, Nout / (32 NW)): the stripes of a chunk share an XCD.
+// (Round 6, measured and not kept: the product issued TRANSPOSED -- A = the resident W fragments, B = the x rows -- so that a lane holds four consecutive columns
+// of its row and a tile leaves as four 16-B stores per wave instead of sixteen 4-B ones: 1 592-1 628 against 1 281 us for the decoder's 1024 columns (a store
+// instruction then writes 32-B pieces of 32 different rows -- four partial writes per 128-B line -- where the straight product writes whole 128-B row segments),
+// 252 against 296 us for CompressFC's 128.  An asm 16-B store also needs wait states before the next tile's accumulator initialisation: the hardware reads a wide
+// store's data registers late, and only for its own stores does the compiler keep writes off them -- without them columns 0, 1 of rows 12-15 / 28-31 came out stale.)
 constexpr int XK = 256, XT = 32;
 constexpr int XPITCH = XK * 2 + 48;                  // bytes per LDS row of a bf16 image
 constexpr int XIMG = XT * XPITCH;                    // 17 920 B
