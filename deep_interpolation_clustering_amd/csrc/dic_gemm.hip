@@ -577,10 +577,9 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) { asm volatile("" : "+v"(px[j][0])); asm volatile("" : "+v"(px[j][1])); }
     };
-    auto land = [&](int slot) {
+    auto land_piece = [&](int slot, int j) {
         unsigned char* base = xsm + slot * 2 * XIMG;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
+        {
             const int p = tid + NT * j;
             gbf16x8 vh, vl;
 #pragma unroll
@@ -596,6 +595,10 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
             *reinterpret_cast<gbf16x8*>(dst + XIMG) = vl;
         }
     };
+    auto land = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) land_piece(slot, j);
+    };
     const int a_off = (lane & 31) * XPITCH + hh * 16;          // A operand: row (lane & 31), 16-B piece 2 ks + hh
 
     int tile = blockIdx.x;
@@ -609,15 +612,25 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
         gf32x16 acc;
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = bn;
+        // the next tile's x (requested one tile ago) is waited for half way through the MFMAs and split into the other slot (read in the previous iteration:
+        // everybody is past its barrier) piece by piece behind the k-steps that follow: vector work in the shadow of the matrix pipe instead of a phase of its own
+        const bool more = tile + nch < ntiles;
+        constexpr int KS = XK / 16, L0 = KS / 2;
+        static_assert(L0 + PPT <= KS, "x3_row_proj: one k-step per piece");
 #pragma unroll
-        for (int ks = 0; ks < XK / 16; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const gbf16x8 ah = *reinterpret_cast<const gbf16x8*>(base + a_off + ks * 32);
             const gbf16x8 al = *reinterpret_cast<const gbf16x8*>(base + XIMG + a_off + ks * 32);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, whi[ks], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, whi[ks], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wlo[ks], acc, 0, 0, 0);
+            if (ks == L0 - 1 && more) arrived(stored16);
+            if (ks >= L0 && ks < L0 + PPT && more) {
+                __builtin_amdgcn_sched_barrier(0);
+                land_piece(slot ^ 1, ks - L0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (tile + nch < ntiles) { arrived(stored16); land(slot ^ 1); }      // (the other slot was read in the previous iteration: everybody is past its barrier)
         if (tile + 2 * nch < ntiles) request(tile + 2 * nch);
         // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         const long r0 = (long)tile * XT;
