@@ -521,6 +521,9 @@ __global__ __launch_bounds__(256) void gemm_tn_finalize(const float* part, int S
 // instruction then writes 32-B pieces of 32 different rows -- four partial writes per 128-B line -- where the straight product writes whole 128-B row segments),
 // 252 against 296 us for CompressFC's 128.  An asm 16-B store also needs wait states before the next tile's accumulator initialisation: the hardware reads a wide
 // store's data registers late, and only for its own stores does the compiler keep writes off them -- without them columns 0, 1 of rows 12-15 / 28-31 came out stale.)
+// (Also measured, same round: a full tile's outputs through an LDS staging tile, leaving one iteration later as whole 1-KiB rows of 16-B stores -- 1 282 against
+// 1 291 us; the next tile's x split piece by piece behind the second half of the MFMA k-steps instead of in a phase of its own -- 1 276 against 1 285 us.  Neither the
+// store form nor the conversion phase is what the 3.3 us per tile wait for.)
 constexpr int XK = 256, XT = 32;
 constexpr int XPITCH = XK * 2 + 48;                  // bytes per LDS row of a bf16 image
 constexpr int XIMG = XT * XPITCH;                    // 17 920 B
@@ -577,9 +580,10 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) { asm volatile("" : "+v"(px[j][0])); asm volatile("" : "+v"(px[j][1])); }
     };
-    auto land_piece = [&](int slot, int j) {
+    auto land = [&](int slot) {
         unsigned char* base = xsm + slot * 2 * XIMG;
-        {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
             const int p = tid + NT * j;
             gbf16x8 vh, vl;
 #pragma unroll
@@ -595,10 +599,6 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
             *reinterpret_cast<gbf16x8*>(dst + XIMG) = vl;
         }
     };
-    auto land = [&](int slot) {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) land_piece(slot, j);
-    };
     const int a_off = (lane & 31) * XPITCH + hh * 16;          // A operand: row (lane & 31), 16-B piece 2 ks + hh
 
     int tile = blockIdx.x;
@@ -612,25 +612,15 @@ __global__ __launch_bounds__(NW * 64, 1) void x3_row_proj_kernel(X3ProjArgs a) {
         gf32x16 acc;
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = bn;
-        // the next tile's x (requested one tile ago) is waited for half way through the MFMAs and split into the other slot (read in the previous iteration:
-        // everybody is past its barrier) piece by piece behind the k-steps that follow: vector work in the shadow of the matrix pipe instead of a phase of its own
-        const bool more = tile + nch < ntiles;
-        constexpr int KS = XK / 16, L0 = KS / 2;
-        static_assert(L0 + PPT <= KS, "x3_row_proj: one k-step per piece");
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < XK / 16; ++ks) {
             const gbf16x8 ah = *reinterpret_cast<const gbf16x8*>(base + a_off + ks * 32);
             const gbf16x8 al = *reinterpret_cast<const gbf16x8*>(base + XIMG + a_off + ks * 32);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, whi[ks], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, whi[ks], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wlo[ks], acc, 0, 0, 0);
-            if (ks == L0 - 1 && more) arrived(stored16);
-            if (ks >= L0 && ks < L0 + PPT && more) {
-                __builtin_amdgcn_sched_barrier(0);
-                land_piece(slot ^ 1, ks - L0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
+        if (tile + nch < ntiles) { arrived(stored16); land(slot ^ 1); }      // (the other slot was read in the previous iteration: everybody is past its barrier)
         if (tile + 2 * nch < ntiles) request(tile + 2 * nch);
         // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         const long r0 = (long)tile * XT;
