@@ -695,7 +695,7 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
         const long t0 = (long)((int)blockIdx.x + min(j, mine - 1) * nch) * TX;
         const int dup = (int)max(0L, t0 + TX - nrows);
         unsigned char* base = hx0 + (j & 1) * C::L_HX;
-        if (dup == 0) {                          // (uniform; every tile but a shifted last one: no zero selects)
+        if (C::NBN >= 6 && dup == 0) {           // (uniform; every tile but a shifted last one: no zero selects -- the wide form only: the branch cost the narrow one 4 %)
             if (pc == 0) split4_store(base + h_pos, base + C::L_H + h_pos, hreg, false, false);
             else if (xon[pc - 1]) split4_store(base + 2 * C::L_H + x_pos[pc - 1], base + 2 * C::L_H + C::L_X + x_pos[pc - 1], xreg[pc - 1], a.x_relu != 0, false);
         } else if (pc == 0) {
@@ -797,6 +797,14 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
         __builtin_amdgcn_s_barrier();              // every wave's DMA of tile j has landed and its image writes are visible; all are done with tile j - 1
         DWX_STAMP(j, 2);
         if constexpr (DXOK) finish_dx(j - 1);
+        // the narrow form (three MFMA groups per tile and wave, the partial dX product behind them) splits and requests up front: spreading its two pieces over
+        // the groups delayed its requests by most of the tile's matrix work -- 1 361 against 1 292 us
+        constexpr bool SPREAD = C::NBN >= 6;
+        if constexpr (!SPREAD) {
+            store_hx(j + 1);                       // -> the image slot tile j - 1 was read from
+            request_hx(j + 2);
+            request_dg(j + 2);                     // -> the dG slot tile j - 1 was read from
+        }
         DWX_STAMP(j, 3);
         DWX_STAMP(j, 4);
         const unsigned char* dgb = dwsm + (j % 3) * C::L_DG;
@@ -807,38 +815,55 @@ __global__ __launch_bounds__(512) void lstm_dwx3_kernel(DwX3Args a) {
             ah[mb] = frag(dgb + pa_off[mb], C::DGP);
             al[mb] = frag(dgb + C::L_PL + pa_off[mb], C::DGP);
         }
-        // the [h | x] fragments of column block i + 1 are requested UNDER the MFMAs of block i, into the registers those MFMAs have just read (there is no room
-        // for a second set at 255 registers): hi (i + 1) behind the four products on hi (i), lo (i + 1) behind the two on lo (i).  As first written -- both
-        // fragments read, waited for, then six MFMAs -- every block exposed an LDS round trip: the matrix cores were 52-56 % busy (rocprofv3).
-        bf16x8 bh = frag(hxb + pb_off(0), pb_pitch[0]);
-        bf16x8 bl = frag(hxb + pb_off(0) + pb_lo[0], pb_pitch[0]);
+        if constexpr (!SPREAD) {
+            // (the narrow form keeps the plain loop: three column blocks do not repay the ordering fences of the pipelined one below -- 1 305 against 1 270 us)
 #pragma unroll
-        for (int i = 0; i < C::NBN; ++i) {
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < C::NBN; ++i) {
+                const bf16x8 bh = frag(hxb + pb_off(i), pb_pitch[i]);
+                const bf16x8 bl = frag(hxb + pb_off(i) + pb_lo[i], pb_pitch[i]);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb][i], 0, 0, 0);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh, acc[mb][i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 1 < C::NBN) bh = frag(hxb + pb_off(i + 1), pb_pitch[i + 1]);
-            // the NEXT tile's h / x registers -> split -> the other image slot (the one tile j - 1 was read from), one piece per MFMA group: vector and LDS-write
-            // work in the shadow of the four MFMAs just issued (cycle stamps, scripts/dwx3_timing.py: done in one go behind the barrier it cost the wave that
-            // issues second 1 170 of its 4 430 cycles per tile; this way the launch takes 2 053 instead of 2 209 us on the same box -- the two waves of a SIMD still
-            // convert at the same time, so most of that vector work stays exposed); the requests for tile j + 2 reuse those registers and follow the last piece
-            // (Measured and not kept: the two waves of a SIMD converting at OPPOSITE ends of the loop, so that one's vector work meets the other's MFMAs -- the
-            // late wave then requests tile j + 2 five MFMA groups later and waits 700 cycles for it at the top of the next tile: 2 297 against 2 053 us.)
-            if (i < NPIECE) store_piece(j + 1, i);
-            if (i == NPIECE - 1) {
-                request_hx(j + 2);
-                request_dg(j + 2);                 // -> the dG slot tile j - 1 was read from
+                for (int mb = 0; mb < 2; ++mb) {
+                    acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb][i], 0, 0, 0);
+                    acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh, acc[mb][i], 0, 0, 0);
+                    acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb][i], 0, 0, 0);
+                }
+            }
+        } else {
+            // the [h | x] fragments of column block i + 1 are requested UNDER the MFMAs of block i, into the registers those MFMAs have just read (there is no room
+            // for a second set at 255 registers): hi (i + 1) behind the four products on hi (i), lo (i + 1) behind the two on lo (i).  As first written -- both
+            // fragments read, waited for, then six MFMAs -- every block exposed an LDS round trip: the matrix cores were 52-56 % busy (rocprofv3).
+            bf16x8 bh = frag(hxb + pb_off(0), pb_pitch[0]);
+            bf16x8 bl = frag(hxb + pb_off(0) + pb_lo[0], pb_pitch[0]);
+    #pragma unroll
+            for (int i = 0; i < C::NBN; ++i) {
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb][i], 0, 0, 0);
+    #pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh, acc[mb][i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < C::NBN) bh = frag(hxb + pb_off(i + 1), pb_pitch[i + 1]);
+                // the NEXT tile's h / x registers -> split -> the other image slot (the one tile j - 1 was read from), one piece per MFMA group: vector and LDS-write
+                // work in the shadow of the four MFMAs just issued (cycle stamps, scripts/dwx3_timing.py: done in one go behind the barrier it cost the wave that
+                // issues second 1 170 of its 4 430 cycles per tile; this way the launch takes 2 053 instead of 2 209 us on the same box -- the two waves of a SIMD still
+                // convert at the same time, so most of that vector work stays exposed); the requests for tile j + 2 reuse those registers and follow the last piece
+                // (Measured and not kept: the two waves of a SIMD converting at OPPOSITE ends of the loop, so that one's vector work meets the other's MFMAs -- the
+                // late wave then requests tile j + 2 five MFMA groups later and waits 700 cycles for it at the top of the next tile: 2 297 against 2 053 us.)
+                if constexpr (SPREAD) {
+                    if (i < NPIECE) store_piece(j + 1, i);
+                    if (i == NPIECE - 1) {
+                        request_hx(j + 2);
+                        request_dg(j + 2);             // -> the dG slot tile j - 1 was read from
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb][i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < C::NBN) bl = frag(hxb + pb_off(i + 1) + pb_lo[i + 1], pb_pitch[i + 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb][i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 1 < C::NBN) bl = frag(hxb + pb_off(i + 1) + pb_lo[i + 1], pb_pitch[i + 1]);
         }
-        __builtin_amdgcn_sched_barrier(0);
         DWX_STAMP(j, 5);
         if constexpr (DXOK) {
             if (want_dx) {
